@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py — headline measurement of the hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+one 5x5 box_nbh2d launch over a 3840x2160 vuchar3 frame (BASELINE.json configs[1]), rotating over
+enough distinct frame buffers (> 256 MiB) that the Infinity Cache cannot serve the stream.
+value = Gpixels/s over all ranks (box / add / FAST "shard" as independent replicas: "replicas only").
+Extra objects on the same JSON line: roofline (dominant kernel vs HBM), cpu_baseline (the oracle timed on the host
+cores, bounded sample), add4k (4K int32 pixel_wise add) and — when built — pyrlk (tracks/s, keypoint-sharded + all-gather).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--workload", default="box5x5", choices=["box5x5"])
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from util import P, rand_image, DeviceImage
+    from vpp_amd import capi, image as vi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    multi = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if multi:
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    lib = capi.lib()
+    capi.check(lib.vpp_init(local_rank))
+    st = capi.stream_ptr()
+
+    def barrier():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    launch_mode = {"mode": "hipGraph"}
+
+    def timed(launch, steps, warmup):
+        """EXACTLY `steps` launches between barrier+sync pairs; also HIP-event time on the launch stream.
+        The K launches are captured once into a hipGraph (kernels of 8-18 us would otherwise be host-launch bound
+        from Python); the timed region is the replay of that graph.  Falls back to eager launches if capture fails."""
+        for i in range(warmup):
+            launch(i, st)
+        torch.cuda.synchronize()
+        g = None
+        if os.environ.get("VPP_BENCH_EAGER", "0") != "1":
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    cs = capi.stream_ptr()  # the capture stream
+                    for i in range(steps):
+                        launch(i, cs)
+                g.replay()  # one untimed replay (graph upload)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write(f"[bench] hipGraph capture failed ({e}); timing eager launches\n")
+                g = None
+        if g is None:
+            launch_mode["mode"] = "eager"
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        if g is not None:
+            g.replay()
+        else:
+            for i in range(steps):
+                launch(i, st)
+        e1.record()
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        wall = t1 - t0
+        if multi:
+            t = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, e0.elapsed_time(e1) * 1e-3
+
+    # ---------------- box5x5 on 4K vuchar3 (headline) ----------------
+    NR, NC = 2160, 3840
+    npx = NR * NC
+    src_h = rand_image(NR, NC, vi.U8, 3, border=2, seed=3, align=16)
+    nsets = 8  # 8 x (25.0 + 24.9 MB) = 399 MB > 256 MiB Infinity Cache
+    srcs = [DeviceImage.from_host(src_h, dev) for _ in range(nsets)]
+    dsts = [DeviceImage(NR, NC, vi.U8, 3, 0, 16, dev) for _ in range(nsets)]
+    for s in srcs:
+        capi.check(lib.vpp_fill_border(P(s.desc), 0, None, st))
+    sdesc = [s.desc for s in srcs]
+    ddesc = [d.desc for d in dsts]
+    box = lib.vpp_box_filter
+
+    def launch_box(i, stream):
+        k = i % nsets
+        box(P(ddesc[k]), P(sdesc[k]), 5, 5, stream)
+
+    wall, ev = timed(launch_box, args.steps, args.warmup)
+    ms_per_step = wall / args.steps * 1e3
+    value = npx * world / (wall / args.steps) / 1e9
+    box_kernel_s = ev / args.steps
+    roof = {"bound": "hbm", "kernel": "box5x5_u8_kernel<3>", "achieved": 6.0 * npx / box_kernel_s / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": 6 * npx, "avg_launch_us": box_kernel_s * 1e6}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+
+    # ---------------- 4K int32 pixel_wise add ----------------
+    nadd = 4  # 4 x 99.5 MB
+    A = [DeviceImage(NR, NC, vi.I32, 1, 0, 32, dev) for _ in range(nadd)]
+    b_h = rand_image(NR, NC, vi.I32, seed=2, lo=0, hi=2**30 - 1)
+    B = [DeviceImage.from_host(b_h, dev) for _ in range(nadd)]
+    C = [DeviceImage.from_host(b_h, dev) for _ in range(nadd)]
+    ad, bd, cd = [x.desc for x in A], [x.desc for x in B], [x.desc for x in C]
+    add = lib.vpp_pixelwise_binary
+
+    def launch_add(i, stream):
+        k = i % nadd
+        add(0, P(ad[k]), P(bd[k]), P(cd[k]), stream)
+
+    awall, aev = timed(launch_add, args.steps, args.warmup)
+    add_s = aev / args.steps
+    add4k = {"gpixels_per_s": npx * world / (awall / args.steps) / 1e9, "avg_launch_us": add_s * 1e6,
+             "roofline": {"bound": "hbm", "kernel": "binary_flat_kernel<add,int>", "achieved": 12.0 * npx / add_s / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 12.0 * npx / add_s / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+
+    extras = {}
+    try:
+        import bench_pyrlk
+        extras["pyrlk"] = bench_pyrlk.run(lib, dev, rank, world, timed, barrier)
+    except ImportError:
+        pass
+
+    # ---------------- CPU baseline: the oracle restatement on the host cores (rank 0, N=1 only) ----------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import binding
+        orc = binding.load(omp=True)
+        dst_h = src_h.like(border=0)
+        orc.orc_fill_border(P(src_h.desc), 0, None)
+        orc.orc_box_filter(P(dst_h.desc), P(src_h.desc), 5, 5)  # warm-up (benchmarks/box_5x5_filter.cc:193-203 protocol)
+        iters = 5
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            orc.orc_box_filter(P(dst_h.desc), P(src_h.desc), 5, 5)
+        dt = (time.perf_counter() - t0) / iters
+        cpu = {"value": npx / dt / 1e9, "unit": "Gpixels/s", "cores": int(orc.orc_num_threads()), "kind": "port",
+               "sample": f"{iters} passes of the same 3840x2160 vuchar3 box5x5 after 1 warm-up, oracle/liboracle_omp.so (-O3 -fopenmp)"}
+
+    if rank == 0:
+        out = {"metric": "Gpixels/s (4K box5x5 vuchar3)", "value": value, "unit": "Gpixels/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "box_nbh2d 5x5 mean on 3840x2160 vuchar3 (BASELINE configs[1]), border 2 mirror-filled, "
+                                      f"{nsets} rotating frame sets (>256 MiB)", "parallelism": f"replicas x{world}", "launch": launch_mode["mode"]},
+               "roofline": roof, "cpu_baseline": cpu, "add4k": add4k}
+        out.update(extras)
+        print(json.dumps(out))
+    if multi:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+/* vpp_amd.h — C ABI of the MI355X (gfx950) evaluation engine behind the Video++ (matt-42/vpp) API.
+ *
+ * The reference is a header-only C++14 template library with NO plugin/FFI layer.
+ * The drop-in boundary is therefore the set of C++ entry points listed next to each function below
+ * (paths relative to the reference tree); the vpp-shaped C++ headers in vpp_amd/include/vpp/ call these
+ * functions from exactly those entry points.  Signatures use plain pointers and sizes only.
+ *
+ * Conventions
+ *  - coordinates are (row, col); boxes inclusive (vpp/core/boxNd.hh:58-62)
+ *  - every image argument is a BORROWED descriptor of DEVICE memory laid out as imageNd::allocate does
+ *    (vpp/core/imageNd.hpp:151-196): `first_pixel` is the address of pixel (0,0); `border` pixels of valid,
+ *    addressable memory surround the domain on every side; rows are `pitch` bytes apart.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls enqueue work and return;
+ *    functions that hand results back to HOST memory synchronise the stream themselves (documented per call).
+ *  - every function returns a vpp_status; nothing throws across this boundary.  vpp_last_error() returns
+ *    a thread-local description of the last non-OK status.
+ */
+#ifndef VPP_AMD_H_
+#define VPP_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vpp_status {
+  VPP_OK = 0,
+  VPP_ERR_INVALID_ARG = 1,
+  VPP_ERR_BORDER_TOO_SMALL = 2, /* e.g. fast9 needs border >= 3 (vpp/algorithms/fast_detector/fast.hpp:937-938) */
+  VPP_ERR_HIP = 3,
+  VPP_ERR_UNSUPPORTED = 4,
+  VPP_ERR_CAPACITY = 5          /* caller-provided output buffer too small; required size reported */
+} vpp_status;
+
+typedef enum vpp_dtype { VPP_U8 = 0, VPP_I8 = 1, VPP_U16 = 2, VPP_I16 = 3, VPP_I32 = 4, VPP_U32 = 5, VPP_F32 = 6 } vpp_dtype;
+
+/* image2d<V> as seen by the device (vpp/core/imageNd.hh:17-40).  V = vector<dtype, channels>. */
+typedef struct vpp_image_desc {
+  void*   first_pixel; /* imageNd_data::begin_ */
+  int32_t nrows;       /* domain().nrows() */
+  int32_t ncols;       /* domain().ncols() */
+  int32_t pitch;       /* bytes between rows, imageNd_data::pitch_ */
+  int32_t border;      /* pixels, imageNd_data::border_ */
+  int32_t dtype;       /* vpp_dtype of one component */
+  int32_t channels;    /* 1 for scalars, N for vector<T,N> */
+} vpp_image_desc;
+
+/* ---- runtime (no reference counterpart: device residency is new; host code keeps vpp's shared_ptr ownership,
+ *      vpp/core/imageNd.hpp:177-180, and hangs the device mirror's deleter beside it) ---- */
+int vpp_init(int device);                       /* hipSetDevice + warm the context */
+int vpp_device_count(int* n);
+int vpp_malloc(size_t bytes, void** dptr);
+int vpp_free(void* dptr);
+int vpp_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int vpp_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int vpp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int vpp_memset(void* dst, int byte, size_t bytes, void* stream);
+int vpp_sync(void* stream);
+const char* vpp_last_error(void);
+const char* vpp_version(void);
+/* runtime tuning knob (launch geometry variants; used by bench/tuning scripts, never changes results) */
+int vpp_set_tuning(const char* name, int value);
+
+/* imageNd::allocate arithmetic (vpp/core/imageNd.hpp:151-196), host-only helper: pitch, allocation size
+ * (excluding the `align` slack) and byte offset of pixel (0,0) from the aligned buffer start. */
+int vpp_image_layout(int nrows, int ncols, int elem_bytes, int border, int align,
+                     int32_t* pitch, size_t* alloc_bytes, size_t* first_pixel_offset);
+
+/* ---- pixel_wise (vpp/core/pixel_wise.hpp:68-105,146-165 with an arithmetic kernel lambda, e.g.
+ *      benchmarks/image_add.cc:53-56 `a = b + c`) ---- */
+typedef enum vpp_binary_op { VPP_OP_ADD = 0, VPP_OP_SUB = 1, VPP_OP_MUL = 2, VPP_OP_MIN = 3, VPP_OP_MAX = 4, VPP_OP_ABSDIFF = 5 } vpp_binary_op;
+/* dst(p) = V(a(p) op b(p)) over dst's domain; arithmetic in the C++ promoted type of V's component then
+ * converted back (so u8 wraps modulo 256 and i32 wraps modulo 2^32, as the compiled reference does). */
+int vpp_pixelwise_binary(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, void* stream);
+/* copy(src,dst) (vpp/core/copy.hh:10-20); with_border=1 is copy_with_border (copy.hh:22-27): copies src's border too. */
+int vpp_copy(const vpp_image_desc* dst, const vpp_image_desc* src, int with_border, void* stream);
+/* fill (vpp/core/fill.hh:12-16) / fill_with_border (fill.hh:24-29): `value` points to one pixel (host memory). */
+int vpp_fill(const vpp_image_desc* img, const void* value, int with_border, void* stream);
+
+/* ---- neighbourhood access: box_nbh2d<V,R,C> / relative_access (vpp/core/pixel_wise.hpp:14-25,57-63;
+ *      vpp/core/relative_accessor.hh:26-33) with the R x C mean kernel of benchmarks/box_5x5_filter2.cc:73-80
+ *      and examples/box_filter.cc:23-32: per component, sum over the window in the promoted type (taps in
+ *      row-major order), C++ `/ (R*C)`, cast back.  Reads src's border (needs border >= max(R,C)/2). ---- */
+int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream);
+
+/* ---- borders (vpp/core/fill.hh:31-122) ---- */
+typedef enum vpp_border_mode { VPP_BORDER_MIRROR = 0, VPP_BORDER_CLOSEST = 1, VPP_BORDER_VALUE = 2 } vpp_border_mode;
+int vpp_fill_border(const vpp_image_desc* img, int mode, const void* value /* VALUE mode: one pixel, host */, void* stream);
+
+/* ---- pyramid (vpp/core/pyramid.hh:12-81,169-192): one level step of propagate_level0 for factor 2:
+ *      next = subsample2(antialiasing_lowpass_filter(prev)); fill_border_mirror(next).
+ *      prev must have border >= 2 already filled.  next dims must be (1+nr/2, 1+nc/2).
+ *      The reference's temporaries are uninitialised heap; the canonical value is 0. ---- */
+int vpp_pyr_down(const vpp_image_desc* next, const vpp_image_desc* prev, void* stream);
+/* antialiasing_lowpass_filter alone (pyramid.hh:12-59); out may have any border (left untouched). */
+int vpp_lowpass5(const vpp_image_desc* out, const vpp_image_desc* in, void* stream);
+
+/* ---- scharr(in, out) (vpp/algorithms/filters/scharr.hh:46-87): in u8 x1 (border>=1), out 2 channels f32 or i32 ---- */
+int vpp_scharr(const vpp_image_desc* out, const vpp_image_desc* in, void* stream);
+
+/* ---- FAST-9 (vpp/algorithms/fast_detector/fast.hpp:254-508 detector, :38-77 score, :676-707 maxima,
+ *      :745-799 blockwise, :889-928 local maxima, :931-955 front end `fast9`) ---- */
+typedef enum vpp_fast9_mode { VPP_FAST9_RAW = 0, VPP_FAST9_LOCAL_MAXIMA = 1, VPP_FAST9_BLOCKWISE = 2 } vpp_fast9_mode;
+typedef enum vpp_fast9_compat {
+  VPP_FAST9_REFERENCE = 0, /* ring samples 4 and 12 taken from row r-3 as fast.hpp:367-368 does */
+  VPP_FAST9_CORRECTED = 1  /* true Bresenham ring, = is_fast9_keypoint (fast.hpp:80-112) */
+} vpp_fast9_compat;
+/* Detect on `src` (u8 x1, border >= 3 else VPP_ERR_BORDER_TOO_SMALL).  `mask` may be NULL (fast.hpp:317) else u8 x1
+ * same domain, AND-ed bitwise with the plane byte (0x10 brighter | 0x01 darker; fast.hpp:120-126,312,333).
+ * Writes up to `capacity` keypoints as (row,col) int32 pairs in ROW-MAJOR order into device buffer out_rc and
+ * (if non-NULL) scores into device buffer out_scores: RAW -> full fast9_score; maxima modes -> score/16 as
+ * stored in the uchar score image (fast.hpp:693,698-704).  *count (HOST int) receives the number found;
+ * synchronises the stream.  count > capacity => VPP_ERR_CAPACITY (first `capacity` entries valid). */
+int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* mask, int mode, int block_size,
+                     int compat, int32_t* out_rc, int32_t* out_scores, int capacity, int* count, void* stream);
+/* fast9_scores (fast.hpp:643-652): n (row,col) pairs in device memory -> n int32 full scores. */
+int vpp_fast9_scores(const vpp_image_desc* src, int th, const int32_t* rc, int n, int32_t* out_scores, void* stream);
+
+/* ---- pyramidal Lucas-Kanade ----
+ * vpp_pyrlk_match = pyrlk_match (vpp/algorithms/pyrlk/pyrlk_match.hh:15-55) with matcher
+ *   lk_match_point_square_win<winsize> (vpp/algorithms/pyrlk/lk.hh:43-175).
+ * prev/next: nlevels u8x1 images; grad: nlevels f32x2 images (scharr of level 0 propagated, as
+ *   benchmarks/pyrlk_opencv_comparison.cc:56-60 builds them).  All levels need border >= 1 + (their reads).
+ * kps: device array of n records {pos_r,pos_c,vel_r,vel_c (f32), age (i32)} = keypoint<float>
+ *   (vpp/core/keypoint_container.hh:13-25); updated IN PLACE exactly as keypoints.move / remove do
+ *   (keypoint_container.hpp:136-167): moved => velocity=new-old, position=new, age++ ; removed => age=0.
+ *   Records with age<=0 are skipped (kp.alive()).  out_dist (optional, device, n floats) = last level error. */
+typedef struct vpp_keypoint_f32 { float pos_r, pos_c, vel_r, vel_c; int32_t age; } vpp_keypoint_f32;
+int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, const vpp_image_desc* next, int nlevels,
+                    vpp_keypoint_f32* kps, int n, int winsize, float min_ev, float max_err, int max_iterations,
+                    float convergence_delta, int min_scale, float* out_dist, void* stream);
+/* vpp_lucas_kanade = the per-keypoint loop of lucas_kanade (vpp/algorithms/lucas_kanade/lucas_kanade.hpp:159-183)
+ * over pyramids the caller built (u8x1 images, i32x2 gradients; :150-157).  min_ev/delta are the already-truncated
+ * ints of :143-144.  pts: n (row,col) f32 pairs; prediction: n (row,col) f32 pairs or NULL (= 0);
+ * out_flow: n f32 pairs; out_dist: n f32. */
+int vpp_lucas_kanade(const vpp_image_desc* prev, const vpp_image_desc* grad, const vpp_image_desc* next, int nlevels,
+                     const float* pts, const float* prediction, int n, int winsize, int min_ev, int niterations,
+                     int delta, float* out_flow, float* out_dist, void* stream);
+
+/* ---- semi-dense optical flow (vpp/algorithms/optical_flow/semi_dense_optical_flow.hpp:48-214 with
+ *      gradient_descent_match, gradient_descent.hh:10-89; epipolar options unsupported) ----
+ * i1/i2: u8x1 frames (any border; pyramids with border 2*winsize are built internally, :70-73).
+ * kps: n (row,col) int32 pairs (device).  Outputs (device): out_pos n int32 pairs, out_dist n int32, out_valid n
+ * u8 (1 where match_callback would have fired, :205-212).  Serial-order semantics. */
+int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n,
+                                int winsize, int nscales, int min_scale, int propagation, int patchsize,
+                                int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

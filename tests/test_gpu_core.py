@@ -1,0 +1,166 @@
+"""GPU parity tests (through the C ABI) for pixel_wise add, box_nbh2d mean, borders, copy/fill.
+Bit-exact against the CPU oracle on the same seeded inputs; full-size cases use the benchmarks' inline checkers
+(benchmarks/image_add.cc:21-28, box_5x5_filter2.cc:26-41) restated in numpy on a sampled subset."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from util import P, rand_image, HostImage, DeviceImage
+from vpp_amd import image as vi
+from vpp_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _sync(lib):
+    capi.check(lib.vpp_sync(capi.stream_ptr()))
+
+
+@pytest.mark.parametrize("op", range(6))
+@pytest.mark.parametrize("dtype,ch,shape,border,align", [
+    (vi.I32, 1, (1080, 1920), 0, 32),     # BASELINE config 1 shape (flat path)
+    (vi.I32, 1, (61, 77), 0, 32),         # pitched rows, ragged
+    (vi.U8, 3, (64, 100), 2, 16),         # pitched rows with border
+    (vi.F32, 2, (33, 47), 1, 32),
+    (vi.I16, 1, (17, 19), 0, 2),          # unaligned -> scalar kernel
+    (vi.U8, 1, (5, 7), 0, 1),
+])
+def test_pixelwise_binary_matches_oracle(lib, orc, op, dtype, ch, shape, border, align):
+    lo, hi = (0, 2**30 - 1) if dtype == vi.I32 and op != 2 else (None, None)
+    b = rand_image(*shape, dtype, ch, border=border, seed=1, lo=lo, hi=hi, align=align)
+    c = rand_image(*shape, dtype, ch, border=border, seed=2, lo=lo, hi=hi, align=align)
+    want = b.like()
+    assert orc.orc_pixelwise_binary(op, P(want.desc), P(b.desc), P(c.desc)) == 0
+    db, dc, da = DeviceImage.from_host(b), DeviceImage.from_host(c), DeviceImage.from_host(b.like())
+    capi.check(lib.vpp_pixelwise_binary(op, P(da.desc), P(db.desc), P(dc.desc), capi.stream_ptr()))
+    _sync(lib)
+    got = da.download()
+    np.testing.assert_array_equal(got.raw, want.raw)  # bit-exact, and nothing outside the domain was touched
+
+
+def test_add_4k_checker(lib):
+    """BASELINE config 1': 4K int32, inline checker A == B + C everywhere (image_add.cc:21-28)."""
+    shape = (2160, 3840)
+    b = rand_image(*shape, vi.I32, seed=2, lo=0, hi=2**30 - 1)
+    c = rand_image(*shape, vi.I32, seed=3, lo=0, hi=2**30 - 1)
+    db, dc = DeviceImage.from_host(b), DeviceImage.from_host(c)
+    da = DeviceImage(*shape, vi.I32)
+    for unroll in (1, 2, 4, 8):
+        for nt in (0, 1):
+            lib.vpp_set_tuning(b"add.unroll", unroll); lib.vpp_set_tuning(b"add.nt", nt)
+            da.store.zero_()
+            capi.check(lib.vpp_pixelwise_binary(0, P(da.desc), P(db.desc), P(dc.desc), capi.stream_ptr()))
+            _sync(lib)
+            np.testing.assert_array_equal(da.download().view(), b.view() + c.view())
+    lib.vpp_set_tuning(b"add.unroll", 4); lib.vpp_set_tuning(b"add.nt", 0)
+
+
+@pytest.mark.parametrize("dtype,ch,R,C,shape,border,align", [
+    (vi.U8, 3, 5, 5, (67, 131), 2, 16),     # fast path, ragged row end, border exactly 2
+    (vi.U8, 3, 5, 5, (64, 1024), 2, 32),
+    (vi.U8, 3, 5, 5, (40, 5000), 3, 32),    # > one block wide
+    (vi.U8, 1, 5, 5, (50, 300), 2, 32),
+    (vi.U8, 2, 5, 5, (50, 300), 2, 32),
+    (vi.U8, 4, 5, 5, (50, 300), 5, 32),
+    (vi.U8, 3, 3, 3, (31, 45), 1, 32),      # generic kernel
+    (vi.I32, 1, 5, 5, (100, 200), 2, 32),   # the reference benchmark's own element type
+    (vi.F32, 1, 5, 5, (64, 64), 2, 32),
+    (vi.U8, 3, 7, 5, (30, 40), 3, 32),
+    (vi.I16, 2, 3, 5, (30, 40), 2, 32),
+])
+def test_box_filter_matches_oracle(lib, orc, dtype, ch, R, C, shape, border, align):
+    lo, hi = (0, 999) if dtype == vi.I32 else (None, None)
+    src = rand_image(*shape, dtype, ch, border=border, seed=3, lo=lo, hi=hi, align=align, fill_border=True)
+    want = src.like(border=0)
+    assert orc.orc_box_filter(P(want.desc), P(src.desc), R, C) == 0
+    dsrc = DeviceImage.from_host(src)
+    for rows in ((4, 8, 16, 32) if (dtype == vi.U8 and R == 5 and C == 5) else (8,)):
+        lib.vpp_set_tuning(b"box.rows", rows)
+        ddst = DeviceImage.from_host(src.like(border=0))
+        capi.check(lib.vpp_box_filter(P(ddst.desc), P(dsrc.desc), R, C, capi.stream_ptr()))
+        _sync(lib)
+        got = ddst.download()
+        if dtype == vi.F32:
+            np.testing.assert_array_equal(got.view().view(np.uint32), want.view().view(np.uint32))
+        else:
+            np.testing.assert_array_equal(got.view(), want.view())
+    lib.vpp_set_tuning(b"box.rows", 8)
+
+
+def test_box_fast_equals_generic_on_device(lib):
+    src = rand_image(200, 777, vi.U8, 3, border=2, seed=11, fill_border=True)
+    dsrc = DeviceImage.from_host(src)
+    outs = []
+    for g in (0, 1):
+        lib.vpp_set_tuning(b"box.force_generic", g)
+        d = DeviceImage.from_host(src.like(border=0))
+        capi.check(lib.vpp_box_filter(P(d.desc), P(dsrc.desc), 5, 5, capi.stream_ptr()))
+        _sync(lib)
+        outs.append(d.download().view().copy())
+    lib.vpp_set_tuning(b"box.force_generic", 0)
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_box_4k_vuchar3_checker(lib, orc):
+    """BASELINE config 2 at full size: interior checker of box_5x5_filter2.cc:26-41 on sampled pixels + oracle on a band."""
+    nr, nc = 2160, 3840
+    src = rand_image(nr, nc, vi.U8, 3, border=2, seed=3, align=16)
+    orc.orc_fill_border(P(src.desc), 0, None)
+    dsrc = DeviceImage.from_host(src)
+    ddst = DeviceImage(nr, nc, vi.U8, 3, 0, 16)
+    capi.check(lib.vpp_box_filter(P(ddst.desc), P(dsrc.desc), 5, 5, capi.stream_ptr()))
+    _sync(lib)
+    got = ddst.download().view()
+    full = src.view(with_border=True).astype(np.int64)
+    rng = np.random.default_rng(0)
+    rs = np.concatenate([rng.integers(0, nr, 4000), [0, 0, nr - 1, nr - 1]])
+    cs = np.concatenate([rng.integers(0, nc, 4000), [0, nc - 1, 0, nc - 1]])
+    for r, c in zip(rs, cs):
+        want = full[r:r + 5, c:c + 5].sum(axis=(0, 1)) // 25
+        assert (got[r, c] == want).all(), (r, c)
+    # whole-image check against the oracle
+    want = src.like(border=0)
+    orc.orc_box_filter(P(want.desc), P(src.desc), 5, 5)
+    np.testing.assert_array_equal(got, want.view())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("dtype,ch,shape,border", [(vi.U8, 1, (9, 13), 3), (vi.U8, 3, (40, 50), 2), (vi.F32, 2, (30, 20), 5), (vi.I32, 1, (7, 5), 10)])
+def test_fill_border_matches_oracle(lib, orc, mode, dtype, ch, shape, border):
+    im = rand_image(*shape, dtype, ch, border=border, seed=5)
+    val = (ctypes.c_uint8 * 16)(*range(1, 17))
+    dim = DeviceImage.from_host(im)
+    assert orc.orc_fill_border(P(im.desc), mode, val) == 0
+    capi.check(lib.vpp_fill_border(P(dim.desc), mode, val, capi.stream_ptr()))
+    _sync(lib)
+    np.testing.assert_array_equal(dim.download().raw, im.raw)
+
+
+def test_copy_and_fill(lib, orc):
+    src = rand_image(33, 21, vi.U8, 3, border=2, seed=6, fill_border=True)
+    for wb in (0, 1):
+        dst = src.like(border=4)
+        want = src.like(border=4)
+        orc.orc_copy(P(want.desc), P(src.desc), wb)
+        ds, dd = DeviceImage.from_host(src), DeviceImage.from_host(dst)
+        capi.check(lib.vpp_copy(P(dd.desc), P(ds.desc), wb, capi.stream_ptr()))
+        _sync(lib)
+        np.testing.assert_array_equal(dd.download().raw, want.raw)
+    val = (ctypes.c_uint8 * 3)(9, 8, 7)
+    for wb in (0, 1):
+        want = src.like()
+        orc.orc_fill(P(want.desc), val, wb)
+        dd = DeviceImage.from_host(src.like())
+        capi.check(lib.vpp_fill(P(dd.desc), val, wb, capi.stream_ptr()))
+        _sync(lib)
+        np.testing.assert_array_equal(dd.download().raw, want.raw)
+
+
+def test_error_statuses(lib):
+    a = DeviceImage(8, 8, vi.U8, 3, border=1)
+    b = DeviceImage(8, 8, vi.U8, 3, border=0)
+    assert lib.vpp_box_filter(P(b.desc), P(a.desc), 5, 5, None) == capi.ERR_BORDER_TOO_SMALL
+    assert b"border" in lib.vpp_last_error()
+    c = DeviceImage(8, 9, vi.U8, 3)
+    assert lib.vpp_pixelwise_binary(0, P(b.desc), P(b.desc), P(c.desc), None) == capi.ERR_INVALID_ARG

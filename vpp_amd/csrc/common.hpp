@@ -1,0 +1,66 @@
+// common.hpp — shared host-side plumbing of the gfx950 engine (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/vpp_amd.h"
+
+namespace vpp_amd {
+
+void set_error(const char* fmt, ...);
+int tuning(const char* name, int dflt);  // runtime tuning knobs (vpp_set_tuning)
+
+#define VPP_HIP_TRY(expr)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      ::vpp_amd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return VPP_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+#define VPP_REQUIRE(cond, status, ...)        \
+  do {                                        \
+    if (!(cond)) {                            \
+      ::vpp_amd::set_error(__VA_ARGS__);      \
+      return (status);                        \
+    }                                         \
+  } while (0)
+
+#define VPP_LAUNCH_CHECK() VPP_HIP_TRY(hipGetLastError())
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+__host__ __device__ inline int dtype_size(int dt) {
+  switch (dt) { case VPP_U8: case VPP_I8: return 1; case VPP_U16: case VPP_I16: return 2; default: return 4; }
+}
+
+// Device-side image handle, passed to kernels by value.
+struct DImg {
+  uint8_t* p0; int nr, nc, pitch, border, dtype, ch;
+  template <class T> __device__ __forceinline__ T* row(int r) const { return (T*)(p0 + (ptrdiff_t)r * pitch); }
+  __device__ __forceinline__ bool has(int r, int c) const { return r >= 0 && c >= 0 && r < nr && c < nc; }
+};
+inline DImg dimg(const vpp_image_desc* d) {
+  return DImg{(uint8_t*)d->first_pixel, d->nrows, d->ncols, d->pitch, d->border, d->dtype, d->channels};
+}
+inline bool valid_desc(const vpp_image_desc* d) {
+  return d && d->first_pixel && d->nrows > 0 && d->ncols > 0 && d->pitch > 0 && d->border >= 0 && d->channels > 0 &&
+         d->dtype >= VPP_U8 && d->dtype <= VPP_F32;
+}
+inline int elem_bytes(const vpp_image_desc* d) { return dtype_size(d->dtype) * d->channels; }
+inline bool same_domain(const vpp_image_desc* a, const vpp_image_desc* b) { return a->nrows == b->nrows && a->ncols == b->ncols; }
+inline bool same_type(const vpp_image_desc* a, const vpp_image_desc* b) { return a->dtype == b->dtype && a->channels == b->channels; }
+inline bool aligned16(const vpp_image_desc* d) { return ((uintptr_t)d->first_pixel % 16) == 0 && (d->pitch % 16) == 0; }
+
+// blockIdx remap so that consecutive logical blocks share an XCD (hardware places block b on XCD b % 8;
+// MI355X_MICROARCH.md "Workgroup dispatch").  Speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblocks) {
+  const unsigned per = nblocks >> 3;            // blocks per XCD (floor)
+  const unsigned main = per << 3;
+  if (b >= main) return b;                      // ragged tail keeps its index
+  return (b & 7u) * per + (b >> 3);
+}
+
+}  // namespace vpp_amd

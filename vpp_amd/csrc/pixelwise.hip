@@ -1,0 +1,247 @@
+// pixelwise.hip — K1: pixel_wise maps (reference: vpp/core/pixel_wise.hpp:68-105,146-165) for arithmetic kernels,
+// plus copy / fill (vpp/core/copy.hh:10-27, vpp/core/fill.hh:12-29).
+//
+// HBM-bound streaming: one lane moves 16 B per access (64 lanes = 1 KiB per wave instruction), UNROLL independent
+// accesses in flight per lane.  Row-pitch aware: images whose rows are contiguous are walked as one flat byte range,
+// otherwise one grid row per image row.  Algorithmic bytes: (2 reads + 1 write) * sizeof(V) per pixel (12 B/px for int).
+#include "common.hpp"
+#include <cstring>
+#include <type_traits>
+using namespace vpp_amd;
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int OP, class T> __device__ __forceinline__ T op_scalar(T a, T b) {
+  if constexpr (sizeof(T) == 4 && !__is_floating_point(T)) {
+    typedef uint32_t U;  // wrap-around in unsigned arithmetic
+    if constexpr (OP == VPP_OP_ADD) return (T)((U)a + (U)b);
+    if constexpr (OP == VPP_OP_SUB) return (T)((U)a - (U)b);
+    if constexpr (OP == VPP_OP_MUL) return (T)((U)a * (U)b);
+    if constexpr (OP == VPP_OP_MIN) return a < b ? a : b;
+    if constexpr (OP == VPP_OP_MAX) return a > b ? a : b;
+    return a > b ? (T)((U)a - (U)b) : (T)((U)b - (U)a);
+  } else if constexpr (__is_floating_point(T)) {
+    if constexpr (OP == VPP_OP_ADD) return a + b;
+    if constexpr (OP == VPP_OP_SUB) return a - b;
+    if constexpr (OP == VPP_OP_MUL) return a * b;
+    if constexpr (OP == VPP_OP_MIN) return a < b ? a : b;
+    if constexpr (OP == VPP_OP_MAX) return a > b ? a : b;
+    return a > b ? a - b : b - a;
+  } else {
+    int x = a, y = b;  // integer promotion, then conversion back to T (modulo 2^bits)
+    if constexpr (OP == VPP_OP_ADD) return (T)(x + y);
+    if constexpr (OP == VPP_OP_SUB) return (T)(x - y);
+    if constexpr (OP == VPP_OP_MUL) return (T)(x * y);
+    if constexpr (OP == VPP_OP_MIN) return a < b ? a : b;
+    if constexpr (OP == VPP_OP_MAX) return a > b ? a : b;
+    return (T)(a > b ? x - y : y - x);
+  }
+}
+
+template <int OP, class T> __device__ __forceinline__ u32x4 op_vec(u32x4 a, u32x4 b) {
+  constexpr int N = 16 / sizeof(T);
+  union { u32x4 v; T e[N]; } ua, ub, ur;
+  ua.v = a; ub.v = b;
+#pragma unroll
+  for (int i = 0; i < N; i++) ur.e[i] = op_scalar<OP, T>(ua.e[i], ub.e[i]);
+  return ur.v;
+}
+
+// Flat range of nvec 16-byte vectors (+ tail bytes handled by the scalar kernel).
+template <int OP, class T, int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void binary_flat_kernel(u32x4* __restrict__ d, const u32x4* __restrict__ a,
+                                                          const u32x4* __restrict__ b, size_t nvec) {
+  const size_t base = (size_t)blockIdx.x * (256 * UNROLL) + threadIdx.x;
+  u32x4 va[UNROLL], vb[UNROLL];
+#pragma unroll
+  for (int u = 0; u < UNROLL; u++) {
+    size_t i = base + (size_t)u * 256;
+    if (i < nvec) {
+      va[u] = NT ? __builtin_nontemporal_load(a + i) : a[i];
+      vb[u] = NT ? __builtin_nontemporal_load(b + i) : b[i];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UNROLL; u++) {
+    size_t i = base + (size_t)u * 256;
+    if (i < nvec) {
+      u32x4 r = op_vec<OP, T>(va[u], vb[u]);
+      if (NT) __builtin_nontemporal_store(r, d + i); else d[i] = r;
+    }
+  }
+}
+
+// Pitched rows: blockIdx.y = row, x covers the row's 16-byte vectors; row tail (< 16 B) done scalar by one lane.
+template <int OP, class T>
+__global__ __launch_bounds__(256) void binary_rows_kernel(DImg d, DImg a, DImg b, int row_bytes) {
+  const int r = blockIdx.y;
+  const int nvec = row_bytes >> 4;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  uint8_t* dr = d.p0 + (ptrdiff_t)r * d.pitch;
+  const uint8_t* ar = a.p0 + (ptrdiff_t)r * a.pitch;
+  const uint8_t* br = b.p0 + (ptrdiff_t)r * b.pitch;
+  if (i < nvec) ((u32x4*)dr)[i] = op_vec<OP, T>(((const u32x4*)ar)[i], ((const u32x4*)br)[i]);
+  if (i == nvec) {
+    const int n0 = (nvec << 4) / (int)sizeof(T), n1 = row_bytes / (int)sizeof(T);
+    for (int k = n0; k < n1; k++) ((T*)dr)[k] = op_scalar<OP, T>(((const T*)ar)[k], ((const T*)br)[k]);
+  }
+}
+
+// Fully general fallback (unaligned pointers / pitches): one component per lane.
+template <int OP, class T>
+__global__ __launch_bounds__(256) void binary_scalar_kernel(DImg d, DImg a, DImg b, int ncomp) {
+  const int r = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < ncomp) d.row<T>(r)[c] = op_scalar<OP, T>(a.row<T>(r)[c], b.row<T>(r)[c]);
+}
+
+template <int OP, class T>
+int launch_binary(const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, hipStream_t st) {
+  const int row_bytes = dst->ncols * elem_bytes(dst);
+  const bool al = aligned16(dst) && aligned16(a) && aligned16(b);
+  const bool flat = al && dst->pitch == row_bytes && a->pitch == row_bytes && b->pitch == row_bytes;
+  if (flat) {
+    const size_t total = (size_t)row_bytes * dst->nrows;
+    const size_t nvec = total >> 4;
+    const int unroll = tuning("add.unroll", 4);
+    const int nt = tuning("add.nt", 0);
+    auto go = [&](auto U, auto NTc) {
+      constexpr int UN = decltype(U)::value; constexpr bool N = decltype(NTc)::value;
+      const size_t per_block = 256 * UN;
+      const unsigned blocks = (unsigned)((nvec + per_block - 1) / per_block);
+      if (blocks) binary_flat_kernel<OP, T, UN, N><<<blocks, 256, 0, st>>>((u32x4*)dst->first_pixel, (const u32x4*)a->first_pixel, (const u32x4*)b->first_pixel, nvec);
+    };
+    auto pick = [&](auto NTc) {
+      switch (unroll) {
+        case 1: go(std::integral_constant<int, 1>(), NTc); break;
+        case 2: go(std::integral_constant<int, 2>(), NTc); break;
+        case 8: go(std::integral_constant<int, 8>(), NTc); break;
+        default: go(std::integral_constant<int, 4>(), NTc); break;
+      }
+    };
+    if (nt) pick(std::true_type()); else pick(std::false_type());
+    const size_t tail = total - (nvec << 4);
+    if (tail) {  // < 16 bytes: reuse the scalar kernel on a 1-row view
+      DImg dd{(uint8_t*)dst->first_pixel + (nvec << 4), 1, 0, 0, 0, dst->dtype, 1}, aa = dd, bb = dd;
+      aa.p0 = (uint8_t*)a->first_pixel + (nvec << 4); bb.p0 = (uint8_t*)b->first_pixel + (nvec << 4);
+      binary_scalar_kernel<OP, T><<<dim3(1, 1), 256, 0, st>>>(dd, aa, bb, (int)(tail / sizeof(T)));
+    }
+  } else if (al) {
+    const int nvec = row_bytes >> 4;
+    dim3 grid((nvec + 1 + 255) / 256, dst->nrows);
+    binary_rows_kernel<OP, T><<<grid, 256, 0, st>>>(dimg(dst), dimg(a), dimg(b), row_bytes);
+  } else {
+    const int ncomp = dst->ncols * dst->channels;
+    dim3 grid((ncomp + 255) / 256, dst->nrows);
+    binary_scalar_kernel<OP, T><<<grid, 256, 0, st>>>(dimg(dst), dimg(a), dimg(b), ncomp);
+  }
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+template <class T> int dispatch_op(int op, const vpp_image_desc* d, const vpp_image_desc* a, const vpp_image_desc* b, hipStream_t st) {
+  switch (op) {
+    case VPP_OP_ADD: return launch_binary<VPP_OP_ADD, T>(d, a, b, st);
+    case VPP_OP_SUB: return launch_binary<VPP_OP_SUB, T>(d, a, b, st);
+    case VPP_OP_MUL: return launch_binary<VPP_OP_MUL, T>(d, a, b, st);
+    case VPP_OP_MIN: return launch_binary<VPP_OP_MIN, T>(d, a, b, st);
+    case VPP_OP_MAX: return launch_binary<VPP_OP_MAX, T>(d, a, b, st);
+    case VPP_OP_ABSDIFF: return launch_binary<VPP_OP_ABSDIFF, T>(d, a, b, st);
+  }
+  set_error("vpp_pixelwise_binary: unknown op %d", op);
+  return VPP_ERR_INVALID_ARG;
+}
+
+// copy rows [r0, r1) x byte range [b0, b1) relative to first_pixel; 1 lane = 1..16 bytes.
+__global__ __launch_bounds__(256) void copy_rows_kernel(DImg d, DImg s, int r0, int byte0, int nbytes, int vec_ok) {
+  const int r = r0 + blockIdx.y;
+  uint8_t* dr = d.p0 + (ptrdiff_t)r * d.pitch + byte0;
+  const uint8_t* sr = s.p0 + (ptrdiff_t)r * s.pitch + byte0;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (vec_ok) {
+    const int nvec = nbytes >> 4;
+    if (i < nvec) ((u32x4*)dr)[i] = ((const u32x4*)sr)[i];
+    else if (i == nvec) for (int k = nvec << 4; k < nbytes; k++) dr[k] = sr[k];
+  } else {
+    for (int k = i * 16; k < min(nbytes, i * 16 + 16); k++) dr[k] = sr[k];
+  }
+}
+
+template <int ES>
+__global__ __launch_bounds__(256) void fill_kernel(DImg d, int r0, int c0, int ncols, const uint8_t* __restrict__ val) {
+  const int r = r0 + blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols) return;
+  uint8_t* p = d.p0 + (ptrdiff_t)r * d.pitch + (ptrdiff_t)(c0 + c) * ES;
+#pragma unroll
+  for (int k = 0; k < ES; k++) p[k] = val[k];
+}
+struct FillVal { uint8_t b[16]; };
+template <int ES>
+__global__ __launch_bounds__(256) void fill_kernel_v(DImg d, int r0, int c0, int ncols, FillVal v) {
+  const int r = r0 + blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols) return;
+  uint8_t* p = d.p0 + (ptrdiff_t)r * d.pitch + (ptrdiff_t)(c0 + c) * ES;
+#pragma unroll
+  for (int k = 0; k < ES; k++) p[k] = v.b[k];
+}
+
+}  // namespace
+
+extern "C" {
+
+int vpp_pixelwise_binary(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, void* stream) {
+  VPP_REQUIRE(valid_desc(dst) && valid_desc(a) && valid_desc(b), VPP_ERR_INVALID_ARG, "vpp_pixelwise_binary: invalid descriptor");
+  VPP_REQUIRE(same_domain(dst, a) && same_domain(dst, b), VPP_ERR_INVALID_ARG, "vpp_pixelwise_binary: domains differ");
+  VPP_REQUIRE(same_type(dst, a) && same_type(dst, b), VPP_ERR_UNSUPPORTED, "vpp_pixelwise_binary: mixed element types");
+  hipStream_t st = as_stream(stream);
+  switch (dst->dtype) {
+    case VPP_U8: return dispatch_op<uint8_t>(op, dst, a, b, st);
+    case VPP_I8: return dispatch_op<int8_t>(op, dst, a, b, st);
+    case VPP_U16: return dispatch_op<uint16_t>(op, dst, a, b, st);
+    case VPP_I16: return dispatch_op<int16_t>(op, dst, a, b, st);
+    case VPP_I32: return dispatch_op<int32_t>(op, dst, a, b, st);
+    case VPP_U32: return dispatch_op<uint32_t>(op, dst, a, b, st);
+    case VPP_F32: return dispatch_op<float>(op, dst, a, b, st);
+  }
+  return VPP_ERR_UNSUPPORTED;
+}
+
+int vpp_copy(const vpp_image_desc* dst, const vpp_image_desc* src, int with_border, void* stream) {
+  VPP_REQUIRE(valid_desc(dst) && valid_desc(src), VPP_ERR_INVALID_ARG, "vpp_copy: invalid descriptor");
+  VPP_REQUIRE(same_domain(dst, src) && same_type(dst, src), VPP_ERR_INVALID_ARG, "vpp_copy: domain/type mismatch");
+  const int b = with_border ? src->border : 0;
+  VPP_REQUIRE(dst->border >= b, VPP_ERR_BORDER_TOO_SMALL, "vpp_copy: dst border %d < src border %d (copy.hh:25)", dst->border, b);
+  const int es = elem_bytes(dst);
+  const int byte0 = -b * es, nbytes = (dst->ncols + 2 * b) * es;
+  const bool vec_ok = ((uintptr_t)((uint8_t*)dst->first_pixel + byte0) % 16 == 0) && ((uintptr_t)((uint8_t*)src->first_pixel + byte0) % 16 == 0) &&
+                      dst->pitch % 16 == 0 && src->pitch % 16 == 0;
+  dim3 grid(((nbytes + 15) / 16 + 1 + 255) / 256, dst->nrows + 2 * b);
+  copy_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(dimg(dst), dimg(src), -b, byte0, nbytes, vec_ok ? 1 : 0);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+int vpp_fill(const vpp_image_desc* img, const void* value, int with_border, void* stream) {
+  VPP_REQUIRE(valid_desc(img) && value, VPP_ERR_INVALID_ARG, "vpp_fill: invalid argument");
+  const int es = elem_bytes(img);
+  VPP_REQUIRE(es <= 16, VPP_ERR_UNSUPPORTED, "vpp_fill: element of %d bytes", es);
+  const int b = with_border ? img->border : 0;
+  FillVal v; memcpy(v.b, value, es);
+  dim3 grid((img->ncols + 2 * b + 255) / 256, img->nrows + 2 * b);
+  hipStream_t st = as_stream(stream);
+  DImg d = dimg(img);
+#define VPP_FILL_CASE(ES) case ES: fill_kernel_v<ES><<<grid, 256, 0, st>>>(d, -b, -b, img->ncols + 2 * b, v); break;
+  switch (es) {
+    VPP_FILL_CASE(1) VPP_FILL_CASE(2) VPP_FILL_CASE(3) VPP_FILL_CASE(4) VPP_FILL_CASE(6) VPP_FILL_CASE(8) VPP_FILL_CASE(12) VPP_FILL_CASE(16)
+    default: set_error("vpp_fill: unsupported element size %d", es); return VPP_ERR_UNSUPPORTED;
+  }
+#undef VPP_FILL_CASE
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+}  // extern "C"
