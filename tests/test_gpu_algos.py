@@ -1,0 +1,219 @@
+"""GPU parity tests (through the C ABI) for pyramid, Scharr, FAST-9 and Lucas-Kanade against the CPU oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import pyr
+from test_oracle_algos import run_detect, pyrlk_cc_fixture, lk_scene
+from util import P, rand_image, HostImage, DeviceImage, rects_image, u8_image, texture, translate
+from vpp_amd import image as vi
+from vpp_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _sync(lib):
+    capi.check(lib.vpp_sync(capi.stream_ptr()))
+
+
+@pytest.mark.parametrize("shape", [(40, 56), (41, 57), (271, 481), (1080, 1920)])
+@pytest.mark.parametrize("dtype,ch,border", [(vi.U8, 1, 3), (vi.I32, 2, 2), (vi.F32, 2, 3), (vi.U8, 1, 14)])
+def test_pyr_down_matches_oracle(lib, orc, shape, dtype, ch, border):
+    if shape == (1080, 1920) and dtype == vi.I32:
+        pytest.skip("covered by the smaller shapes")
+    lo, hi = (-500, 500) if dtype == vi.I32 else (None, None)
+    prev = rand_image(*shape, dtype, ch, border=border, seed=7, lo=lo, hi=hi)
+    orc.orc_fill_border(P(prev.desc), 0, None)
+    want = HostImage(1 + shape[0] // 2, 1 + shape[1] // 2, dtype, ch, border)
+    assert orc.orc_pyr_down(P(want.desc), P(prev.desc)) == 0
+    dprev, dnext = DeviceImage.from_host(prev), DeviceImage.from_host(want.like())
+    capi.check(lib.vpp_pyr_down(P(dnext.desc), P(dprev.desc), capi.stream_ptr()))
+    _sync(lib)
+    got = dnext.download()
+    np.testing.assert_array_equal(got.view(with_border=True).view(np.uint8), want.view(with_border=True).view(np.uint8))
+
+
+def test_lowpass5_matches_oracle(lib, orc):
+    for dtype, ch in [(vi.U8, 3), (vi.F32, 1)]:
+        src = rand_image(50, 70, dtype, ch, border=2, seed=8)
+        orc.orc_fill_border(P(src.desc), 0, None)
+        want = src.like(border=0)
+        assert orc.orc_lowpass5(P(want.desc), P(src.desc)) == 0
+        d, o = DeviceImage.from_host(src), DeviceImage.from_host(want.like())
+        capi.check(lib.vpp_lowpass5(P(o.desc), P(d.desc), capi.stream_ptr()))
+        _sync(lib)
+        np.testing.assert_array_equal(o.download().raw, want.raw)
+
+
+@pytest.mark.parametrize("odt", [vi.F32, vi.I32])
+@pytest.mark.parametrize("shape", [(33, 47), (1080, 1920)])
+def test_scharr_matches_oracle(lib, orc, odt, shape):
+    src = rand_image(*shape, vi.U8, 1, border=3, seed=9, fill_border=True)
+    want = HostImage(*shape, odt, 2, border=3)
+    assert orc.orc_scharr(P(want.desc), P(src.desc)) == 0
+    d, o = DeviceImage.from_host(src), DeviceImage.from_host(want.like())
+    capi.check(lib.vpp_scharr(P(o.desc), P(d.desc), capi.stream_ptr()))
+    _sync(lib)
+    np.testing.assert_array_equal(o.download().raw, want.raw)
+
+
+def test_whole_pyramids_match_oracle(lib, orc):
+    """pyramid2d<uchar> + scharr + gradient pyramid, 1080p x 3 levels, border 3 (BASELINE config 4 shapes)."""
+    f = np.clip(np.rint(texture(1080, 1920, seed=5)), 0, 255).astype(np.uint8)
+    img = u8_image(f)
+    hp = pyr.host_pyramid(orc, img, 3, 3)
+    hg = pyr.host_grad_pyramid(orc, hp[0], 3, 3, vi.F32)
+    dp = pyr.device_pyramid(lib, DeviceImage.from_host(img), 3, 3)
+    dg = pyr.device_grad_pyramid(lib, dp[0], 3, 3, vi.F32)
+    _sync(lib)
+    assert [(l.nrows, l.ncols) for l in dp] == [(1080, 1920), (541, 961), (271, 481)]
+    for h, d in zip(hp + hg, dp + dg):
+        np.testing.assert_array_equal(d.download().raw, h.raw)
+
+
+# ---- FAST-9 ------------------------------------------------------------------------------------------------
+def gpu_detect(lib, dimg, th, mask=None, mode=0, bs=10, compat=0, cap=400000):
+    rc = torch.zeros((cap, 2), dtype=torch.int32, device="cuda")
+    sc = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    n = ctypes.c_int(0)
+    st = lib.vpp_fast9_detect(P(dimg.desc), th, P(mask.desc) if mask is not None else None, mode, bs, compat,
+                              ctypes.c_void_p(rc.data_ptr()), ctypes.c_void_p(sc.data_ptr()), cap, P(n), capi.stream_ptr())
+    capi.check(st)
+    return rc[:n.value].cpu().numpy(), sc[:n.value].cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", [(60, 90), (64, 64), (130, 257), (480, 640)])
+@pytest.mark.parametrize("compat", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_fast9_matches_oracle(lib, orc, shape, compat, mode):
+    im = u8_image(rects_image(*shape, seed=4), border=3)
+    orc.orc_fill_border(P(im.desc), 0, None)
+    want_rc, want_sc = run_detect(orc, im, 20, mode=mode, bs=10, compat=compat, cap=400000)
+    got_rc, got_sc = gpu_detect(lib, DeviceImage.from_host(im), 20, mode=mode, bs=10, compat=compat)
+    assert len(want_rc) > 0
+    np.testing.assert_array_equal(got_rc, want_rc)  # same keypoints, same (serial reference) order
+    np.testing.assert_array_equal(got_sc, want_sc)
+
+
+@pytest.mark.parametrize("mval", [255, 1, 16, 2])
+def test_fast9_mask_matches_oracle(lib, orc, mval):
+    im = u8_image(rects_image(200, 300, seed=14), border=3)
+    orc.orc_fill_border(P(im.desc), 0, None)
+    mask = HostImage(200, 300, vi.U8, 1, border=10)  # video_extruder.hpp:97-101 allocates the mask with a border
+    mask.view()[...] = mval
+    mask.view()[50:120, 100:250] = 0
+    for mode in (0, 2):
+        want_rc, want_sc = run_detect(orc, im, 10, mask=mask, mode=mode, bs=10)
+        got_rc, got_sc = gpu_detect(lib, DeviceImage.from_host(im), 10, mask=DeviceImage.from_host(mask), mode=mode, bs=10)
+        np.testing.assert_array_equal(got_rc, want_rc)
+        np.testing.assert_array_equal(got_sc, want_sc)
+
+
+def test_fast9_4k_all_modes(lib, orc):
+    """BASELINE config 3: 2160x3840, th 20, raw / local-max / blockwise(10), reference and corrected rings."""
+    im = u8_image(rects_image(2160, 3840, seed=4), border=3)
+    orc.orc_fill_border(P(im.desc), 0, None)
+    d = DeviceImage.from_host(im)
+    for compat in (0, 1):
+        for mode in (0, 1, 2):
+            want_rc, want_sc = run_detect(orc, im, 20, mode=mode, bs=10, compat=compat, cap=3000000)
+            got_rc, got_sc = gpu_detect(lib, d, 20, mode=mode, bs=10, compat=compat, cap=3000000)
+            assert len(want_rc) > 1000
+            np.testing.assert_array_equal(got_rc, want_rc)
+            np.testing.assert_array_equal(got_sc, want_sc)
+
+
+def test_fast9_scores_and_errors(lib, orc):
+    im = u8_image(rects_image(100, 100, seed=3), border=3)
+    orc.orc_fill_border(P(im.desc), 0, None)
+    d = DeviceImage.from_host(im)
+    rng = np.random.default_rng(1)
+    rc = rng.integers(0, 100, size=(500, 2)).astype(np.int32)
+    want = np.zeros(500, np.int32)
+    orc.orc_fast9_scores(P(im.desc), 15, rc.ctypes.data_as(ctypes.c_void_p), 500, want.ctypes.data_as(ctypes.c_void_p))
+    drc = torch.from_numpy(rc).cuda(); out = torch.zeros(500, dtype=torch.int32, device="cuda")
+    capi.check(lib.vpp_fast9_scores(P(d.desc), 15, ctypes.c_void_p(drc.data_ptr()), 500, ctypes.c_void_p(out.data_ptr()), capi.stream_ptr()))
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    small = DeviceImage(20, 20, vi.U8, 1, border=2)
+    n = ctypes.c_int(0)
+    assert lib.vpp_fast9_detect(P(small.desc), 20, None, 0, 10, 0, None, None, 0, P(n), None) == capi.ERR_BORDER_TOO_SMALL
+    assert b"border of 3px" in lib.vpp_last_error()  # the reference's exception text (fast.hpp:938)
+    tiny = torch.zeros((4, 2), dtype=torch.int32, device="cuda")
+    assert lib.vpp_fast9_detect(P(d.desc), 20, None, 0, 10, 0, ctypes.c_void_p(tiny.data_ptr()), None, 4, P(n), None) == capi.ERR_CAPACITY
+    assert n.value > 4
+
+
+# ---- Lucas-Kanade ----------------------------------------------------------------------------------------------
+def test_lucas_kanade_reference_golden_on_gpu(lib, orc):
+    """tests/pyrlk.cc through the C ABI: flow (2,2) +- 0.05 and bit-identical to the oracle."""
+    f1, f2 = pyrlk_cc_fixture()
+    i1, i2 = u8_image(f1), u8_image(f2)
+    ws, L = 5, 2
+    hp1, hp2 = pyr.host_pyramid(orc, i1, L, ws // 2), pyr.host_pyramid(orc, i2, L, ws // 2)
+    hg = pyr.host_grad_pyramid(orc, hp1[0], L, ws // 2, vi.I32)
+    pts = np.array([[50, 50], [48, 51], [52, 49]], np.float32)
+    want = np.zeros((3, 2), np.float32); wd = np.zeros(3, np.float32)
+    orc.orc_lucas_kanade(vi.desc_array(hp1), vi.desc_array(hg), vi.desc_array(hp2), L, pts.ctypes.data_as(ctypes.c_void_p), None, 3, ws, 0, 50, 0,
+                         want.ctypes.data_as(ctypes.c_void_p), wd.ctypes.data_as(ctypes.c_void_p))
+    dp1 = pyr.device_pyramid(lib, DeviceImage.from_host(i1), L, ws // 2)
+    dp2 = pyr.device_pyramid(lib, DeviceImage.from_host(i2), L, ws // 2)
+    dg = pyr.device_grad_pyramid(lib, dp1[0], L, ws // 2, vi.I32)
+    dpts = torch.from_numpy(pts).cuda(); flow = torch.zeros((3, 2), device="cuda"); dist = torch.zeros(3, device="cuda")
+    capi.check(lib.vpp_lucas_kanade(vi.desc_array(dp1), vi.desc_array(dg), vi.desc_array(dp2), L, ctypes.c_void_p(dpts.data_ptr()), None, 3, ws, 0, 50, 0,
+                                    ctypes.c_void_p(flow.data_ptr()), ctypes.c_void_p(dist.data_ptr()), capi.stream_ptr()))
+    got = flow.cpu().numpy()
+    assert np.linalg.norm(got[0] - [2.0, 2.0]) < 0.05, got
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    np.testing.assert_array_equal(dist.cpu().numpy().view(np.uint32), wd.view(np.uint32))
+
+
+def _run_pyrlk_both(lib, orc, f1, f2, kps, L=3, B=5, ws=7, min_ev=1e-4, max_err=500.0, max_it=30, delta=0.01):
+    i1, i2 = u8_image(f1), u8_image(f2)
+    hp1, hp2 = pyr.host_pyramid(orc, i1, L, B), pyr.host_pyramid(orc, i2, L, B)
+    hg = pyr.host_grad_pyramid(orc, hp1[0], L, B, vi.F32)
+    want = kps.copy(); wd = np.zeros(len(kps), np.float32)
+    assert orc.orc_pyrlk_match(vi.desc_array(hp1), vi.desc_array(hg), vi.desc_array(hp2), L, want.ctypes.data_as(ctypes.c_void_p), len(kps), ws,
+                               ctypes.c_float(min_ev), ctypes.c_float(max_err), max_it, ctypes.c_float(delta), 0, wd.ctypes.data_as(ctypes.c_void_p)) == 0
+    dp1 = pyr.device_pyramid(lib, DeviceImage.from_host(i1), L, B)
+    dp2 = pyr.device_pyramid(lib, DeviceImage.from_host(i2), L, B)
+    dg = pyr.device_grad_pyramid(lib, dp1[0], L, B, vi.F32)
+    dk = torch.from_numpy(kps.view(np.uint8).reshape(-1)).cuda()
+    dd = torch.zeros(len(kps), device="cuda")
+    capi.check(lib.vpp_pyrlk_match(vi.desc_array(dp1), vi.desc_array(dg), vi.desc_array(dp2), L, ctypes.c_void_p(dk.data_ptr()), len(kps), ws,
+                                   ctypes.c_float(min_ev), ctypes.c_float(max_err), max_it, ctypes.c_float(delta), 0, ctypes.c_void_p(dd.data_ptr()),
+                                   capi.stream_ptr()))
+    got = dk.cpu().numpy().view(pyr.KP_DTYPE)
+    return got, want, dd.cpu().numpy(), wd
+
+
+@pytest.mark.parametrize("ws", [5, 7, 9])
+def test_pyrlk_match_matches_oracle(lib, orc, ws):
+    f1, f2, kps = lk_scene(240, 320, 500)
+    kps["age"][::17] = 0  # dead keypoints are skipped (pyrlk_match.hh:27)
+    got, want, gd, wd = _run_pyrlk_both(lib, orc, f1, f2, kps, ws=ws)
+    np.testing.assert_array_equal(got["age"], want["age"])
+    alive = want["age"] > 0
+    assert alive.sum() > 300
+    for f in ("pos_r", "pos_c", "vel_r", "vel_c"):
+        # north-star tolerance: 1e-4 relative on float LK displacements; in practice bit-identical
+        np.testing.assert_allclose(got[f][alive], want[f][alive], rtol=1e-4, atol=1e-4)
+        assert (got[f].view(np.uint32) == want[f].view(np.uint32)).mean() > 0.999
+    np.testing.assert_allclose(gd[alive], wd[alive], rtol=1e-4)
+
+
+def test_pyrlk_1080p_10k_keypoints(lib, orc):
+    """BASELINE config 4 at full size: 1080x1920, 3 levels, 10k keypoints, 7x7, min_ev 1e-4, max_err 500, 30 it, delta 0.01."""
+    tex = texture(1080, 1920, seed=5)
+    f1 = np.clip(np.rint(tex), 0, 255).astype(np.uint8)
+    f2 = np.clip(np.rint(translate(tex, 1.5, -2.25)), 0, 255).astype(np.uint8)
+    kps = pyr.make_keypoints(pyr.grid_keypoints(1080, 1920, 10000, margin=32))
+    got, want, gd, wd = _run_pyrlk_both(lib, orc, f1, f2, kps, B=3)
+    np.testing.assert_array_equal(got["age"], want["age"])
+    alive = want["age"] > 0
+    assert alive.mean() > 0.9
+    for f in ("pos_r", "pos_c", "vel_r", "vel_c"):
+        np.testing.assert_allclose(got[f][alive], want[f][alive], rtol=1e-4, atol=1e-4)
+    vel = np.stack([got["vel_r"], got["vel_c"]], 1)[alive]
+    assert np.median(np.linalg.norm(vel - [1.5, -2.25], axis=1)) < 0.15  # size-independent property: recovers the translation

@@ -53,7 +53,7 @@ def test_add_4k_checker(lib):
             capi.check(lib.vpp_pixelwise_binary(0, P(da.desc), P(db.desc), P(dc.desc), capi.stream_ptr()))
             _sync(lib)
             np.testing.assert_array_equal(da.download().view(), b.view() + c.view())
-    lib.vpp_set_tuning(b"add.unroll", 4); lib.vpp_set_tuning(b"add.nt", 0)
+    lib.vpp_set_tuning(b"add.unroll", -1); lib.vpp_set_tuning(b"add.nt", -1)
 
 
 @pytest.mark.parametrize("dtype,ch,R,C,shape,border,align", [
@@ -75,7 +75,7 @@ def test_box_filter_matches_oracle(lib, orc, dtype, ch, R, C, shape, border, ali
     want = src.like(border=0)
     assert orc.orc_box_filter(P(want.desc), P(src.desc), R, C) == 0
     dsrc = DeviceImage.from_host(src)
-    for rows in ((4, 8, 16, 32) if (dtype == vi.U8 and R == 5 and C == 5) else (8,)):
+    for rows in ((8, 16, 32) if (dtype == vi.U8 and R == 5 and C == 5) else (16,)):
         lib.vpp_set_tuning(b"box.rows", rows)
         ddst = DeviceImage.from_host(src.like(border=0))
         capi.check(lib.vpp_box_filter(P(ddst.desc), P(dsrc.desc), R, C, capi.stream_ptr()))
@@ -85,7 +85,7 @@ def test_box_filter_matches_oracle(lib, orc, dtype, ch, R, C, shape, border, ali
             np.testing.assert_array_equal(got.view().view(np.uint32), want.view().view(np.uint32))
         else:
             np.testing.assert_array_equal(got.view(), want.view())
-    lib.vpp_set_tuning(b"box.rows", 8)
+    lib.vpp_set_tuning(b"box.rows", -1)
 
 
 def test_box_fast_equals_generic_on_device(lib):
@@ -126,7 +126,7 @@ def test_box_4k_vuchar3_checker(lib, orc):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("dtype,ch,shape,border", [(vi.U8, 1, (9, 13), 3), (vi.U8, 3, (40, 50), 2), (vi.F32, 2, (30, 20), 5), (vi.I32, 1, (7, 5), 10)])
+@pytest.mark.parametrize("dtype,ch,shape,border", [(vi.U8, 1, (9, 13), 3), (vi.U8, 3, (40, 50), 2), (vi.F32, 2, (30, 20), 5), (vi.I32, 1, (12, 11), 10)])
 def test_fill_border_matches_oracle(lib, orc, mode, dtype, ch, shape, border):
     im = rand_image(*shape, dtype, ch, border=border, seed=5)
     val = (ctypes.c_uint8 * 16)(*range(1, 17))

@@ -1,0 +1,43 @@
+"""Summarise rocprofv3 rocpd sqlite outputs: per-kernel duration stats (kernel trace) and per-kernel mean PMC values.
+usage: prof_summary.py <results.db> [...]   -> markdown tables on stdout"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n[: n.index("(")] if "(" in n else n
+
+
+for path in sys.argv[1:]:
+    con = sqlite3.connect(path)
+    rows = con.execute("select name, duration, vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x from kernels").fetchall()
+    agg = defaultdict(list)
+    meta = {}
+    for name, dur, vg, sg, lds, gx, wx in rows:
+        agg[short(name)].append(dur); meta[short(name)] = (vg, sg, lds, gx, wx)
+    print(f"### {path}\n\n| kernel | calls | avg us | min us | max us | vgpr | lds B | grid | wg |\n|---|---|---|---|---|---|---|---|---|")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        if "at::native" in k: continue
+        m = meta[k]
+        print(f"| {k} | {len(v)} | {sum(v)/len(v)/1e3:.2f} | {min(v)/1e3:.2f} | {max(v)/1e3:.2f} | {m[0]} | {m[2]} | {m[3]} | {m[4]} |")
+    try:
+        pm = con.execute("select k.name, p.counter_name, p.value from counters_collection p join kernels k on p.dispatch_id = k.dispatch_id").fetchall()
+    except Exception as e:  # noqa
+        try:
+            cols = [d[0] for d in con.execute("select * from counters_collection limit 1").description]
+            print("counters_collection columns:", cols)
+        except Exception as e2:  # noqa
+            print("no counters:", e2)
+        pm = []
+    if pm:
+        acc = defaultdict(lambda: defaultdict(list))
+        for name, c, v in pm:
+            acc[short(name)][c].append(v)
+        print("\n| kernel | counter | mean per dispatch |\n|---|---|---|")
+        for k, cs in acc.items():
+            if "at::native" in k: continue
+            for c, v in sorted(cs.items()):
+                print(f"| {k} | {c} | {sum(v)/len(v):.4g} |")
+    print()

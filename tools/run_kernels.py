@@ -1,0 +1,25 @@
+"""Launch a few box / add kernels (for rocprofv3 runs).  usage: run_kernels.py [box|add|all] [launches]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from util import P, rand_image, DeviceImage
+from vpp_amd import capi, image as vi
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
+NR, NC = 2160, 3840
+if which in ("box", "all"):
+    src_h = rand_image(NR, NC, vi.U8, 3, border=2, seed=3, align=16)
+    ns = 8
+    srcs = [DeviceImage.from_host(src_h) for _ in range(ns)]
+    dsts = [DeviceImage(NR, NC, vi.U8, 3, 0, 16) for _ in range(ns)]
+    for s in srcs: capi.check(lib.vpp_fill_border(P(s.desc), 0, None, st))
+    for i in range(n): capi.check(lib.vpp_box_filter(P(dsts[i % ns].desc), P(srcs[i % ns].desc), 5, 5, st))
+    torch.cuda.synchronize()
+if which in ("add", "all"):
+    b_h = rand_image(NR, NC, vi.I32, seed=2, lo=0, hi=2**30 - 1)
+    ns = 4
+    A = [DeviceImage(NR, NC, vi.I32) for _ in range(ns)]; B = [DeviceImage.from_host(b_h) for _ in range(ns)]; C = [DeviceImage.from_host(b_h) for _ in range(ns)]
+    for i in range(n): capi.check(lib.vpp_pixelwise_binary(0, P(A[i % ns].desc), P(B[i % ns].desc), P(C[i % ns].desc), st))
+    torch.cuda.synchronize()

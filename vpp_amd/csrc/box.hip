@@ -3,14 +3,16 @@
 // (nbh(dr,dc) = line[dr][col+dc]), kernel lambda of benchmarks/box_5x5_filter2.cc:73-80 / examples/box_filter.cc:23-32.
 //
 // Two kernels:
-//  * box5x5_u8_kernel<CH>  — the headline path (vuchar3 4K).  A row of CH-interleaved u8 pixels is a row of bytes in
+//  * box5x5_u8_lds_kernel<CH> — the headline path (vuchar3 4K).  A row of CH-interleaved u8 pixels is a row of bytes in
 //    which the horizontal neighbour sits CH bytes away, so the filter is a 1-channel 5x5 stencil with column stride CH.
-//    One lane owns 16 consecutive output bytes (one 16-B store per row) and marches down ROWS rows keeping, in registers,
-//    the running 5-row column sums of a 32-byte window as packed u16 pairs (even/odd bytes split with 0x00FF00FF masks).
-//    Horizontal taps are register selects + v_alignbit on those pairs; packed sums never exceed 25*255 = 6375 < 2^16 so
-//    plain 32-bit adds/subs act as two independent 16-bit lanes.  Exact truncating /25: (x * 671089) >> 24 for x <= 6375.
-//    HBM traffic: 1 read + 1 write per byte (6 B/px for vuchar3); the (ROWS+4)/ROWS vertical re-read and the 2x8 B
-//    horizontal halo are served by L2/MALL.  Row blocks are XCD-remapped so vertical neighbours share an L2.
+//    A 256-thread workgroup stages a (TH+4) x (1024+32) byte tile in LDS with 16-B coalesced loads issued all at once
+//    (one HBM round trip per workgroup, vertical halo shared by the four waves), then each wave produces TH/4 rows:
+//    one lane owns 16 consecutive output bytes (one 16-B store per row) and keeps the running 5-row column sums of its
+//    32-byte window as packed u16 pairs (even/odd bytes split with 0x00FF00FF masks); rows enter / leave the sum from
+//    LDS (ds_read_b64 + b128 + b64 per row).  Horizontal taps are register selects + v_alignbit on those pairs; packed
+//    sums never exceed 25*255 = 6375 < 2^16 so plain 32-bit adds/subs act as two independent 16-bit lanes.  Exact
+//    truncating /25: (x * 671089) >> 24 for x <= 6375.  HBM traffic: 1 read + 1 write per byte (6 B/px for vuchar3);
+//    the (TH+4)/TH vertical re-read is served by L2/MALL; row blocks are XCD-remapped so vertical neighbours share an L2.
 //  * box_generic_kernel<T,S> — any dtype / window: LDS tile (+halo), taps summed in row-major order in the promoted
 //    type (order matters for float), C++ `/ (R*C)`.
 #include "common.hpp"
@@ -23,32 +25,31 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- fast path -------------------------------------------------------------------------------------------
-struct Win { uint32_t e[8], o[8]; };  // packed u16 pairs: e[i] = bytes (4i, 4i+2), o[i] = bytes (4i+1, 4i+3) of the 32-B window
+// packed u16 pairs over the 32-B window: e[i] = bytes (4i, 4i+2), o[i] = bytes (4i+1, 4i+3)
 
-__device__ __forceinline__ uint32_t ld_bytes_guarded(const uint8_t* p, int off, int lo, int hi) {
-  // little-endian dword assembled from bytes p[off..off+3] that fall inside [lo, hi); others 0
+// Dword at byte offset `off` (multiple of 4) of a row whose addressable bytes are [lo, hi).  Fully inside: one
+// aligned load.  Straddling an end: branch-free byte loads from clamped addresses (all issued back to back).
+__device__ __forceinline__ uint32_t ld_dword_guarded(const uint8_t* __restrict__ p, int off, int lo, int hi) {
+  if (off >= lo && off + 4 <= hi) return *(const uint32_t*)(p + off);
   uint32_t v = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    int q = off + k;
-    if (q >= lo && q < hi) v |= (uint32_t)p[q] << (8 * k);
+    const int q = off + k;
+    const int qc = min(max(q, lo), hi - 1);
+    const uint32_t b = p[qc];
+    v |= (q >= lo && q < hi) ? (b << (8 * k)) : 0u;
   }
   return v;
 }
 
-// Loads the window bytes [x-8, x+24) of one row.  [lo, hi) = addressable bytes of the row relative to its pixel 0.
-// Each of the three pieces (8 B left halo, 16 B body, 8 B right halo) is one vector load when it lies inside [lo, hi),
-// else it is assembled from the bytes that do (only the first / last lane of a row, and ragged row ends).
-__device__ __forceinline__ void load_window(const uint8_t* row, int x, int lo, int hi, uint32_t w[8]) {
-  if (x - 8 >= lo) { u32x2 l = *(const u32x2*)(row + x - 8); w[0] = l.x; w[1] = l.y; }
-  else { w[0] = ld_bytes_guarded(row, x - 8, lo, hi); w[1] = ld_bytes_guarded(row, x - 4, lo, hi); }
-  if (x + 16 <= hi) { u32x4 m = *(const u32x4*)(row + x); w[2] = m.x; w[3] = m.y; w[4] = m.z; w[5] = m.w; }
-  else {
-#pragma unroll
-    for (int i = 0; i < 4; i++) w[2 + i] = ld_bytes_guarded(row, x + 4 * i, lo, hi);
-  }
-  if (x + 24 <= hi) { u32x2 r = *(const u32x2*)(row + x + 16); w[6] = r.x; w[7] = r.y; }
-  else { w[6] = ld_bytes_guarded(row, x + 16, lo, hi); w[7] = ld_bytes_guarded(row, x + 20, lo, hi); }
+// 16-byte chunk at byte offset gx of a row; GUARD: dwords not wholly inside [lo, hi) are assembled bytewise.
+template <bool GUARD>
+__device__ __forceinline__ u32x4 ld_chunk(const uint8_t* __restrict__ row, int gx, int lo, int hi) {
+  if (!GUARD || (gx >= lo && gx + 16 <= hi)) return *(const u32x4*)(row + gx);
+  u32x4 v;
+  v.x = ld_dword_guarded(row, gx, lo, hi); v.y = ld_dword_guarded(row, gx + 4, lo, hi);
+  v.z = ld_dword_guarded(row, gx + 8, lo, hi); v.w = ld_dword_guarded(row, gx + 12, lo, hi);
+  return v;
 }
 
 // packed pair (col[q], col[q+2]) of the window's column sums, q compile-time.
@@ -63,68 +64,125 @@ template <int Q> __device__ __forceinline__ uint32_t pair_at(const uint32_t* E, 
 template <int Q, int CH> __device__ __forceinline__ uint32_t hsum5(const uint32_t* E, const uint32_t* O) {
   return pair_at<Q - 2 * CH>(E, O) + pair_at<Q - CH>(E, O) + pair_at<Q>(E, O) + pair_at<Q + CH>(E, O) + pair_at<Q + 2 * CH>(E, O);
 }
-__device__ __forceinline__ uint32_t div25(uint32_t x) { return __umul24(x, 671089u) >> 24; }  // exact for x <= 6375
+// q*M with the exact quotient floor(x/25) in byte 3: x * 671089 < 2^32 and floor(x * 671089 / 2^24) == x / 25 for x <= 6375.
+__device__ __forceinline__ uint32_t mul25(uint32_t x) { return (uint32_t)__umul24(x, 671089u); }
 template <int I, int CH> __device__ __forceinline__ uint32_t out_dword(const uint32_t* E, const uint32_t* O) {
   // output bytes 4I..4I+3 of the lane's 16 (window positions 8+4I ..)
   const uint32_t se = hsum5<8 + 4 * I, CH>(E, O);      // sums for bytes (4I, 4I+2)
   const uint32_t so = hsum5<8 + 4 * I + 1, CH>(E, O);  // sums for bytes (4I+1, 4I+3)
-  return div25(se & 0xFFFFu) | (div25(so & 0xFFFFu) << 8) | (div25(se >> 16) << 16) | (div25(so >> 16) << 24);
+  const uint32_t qa = mul25(se & 0xFFFFu), qb = mul25(so & 0xFFFFu), qc = mul25(se >> 16), qd = mul25(so >> 16);
+  // gather byte 3 of each product: v_perm_b32 selects from {S0 = bytes 7..4, S1 = bytes 3..0}; 0x0c = constant 0
+  return __builtin_amdgcn_perm(qb, qa, 0x0c0c0703u) | __builtin_amdgcn_perm(qd, qc, 0x07030c0cu);
 }
 
-template <int CH, int ROWS>
-__global__ __launch_bounds__(256) void box5x5_u8_kernel(DImg dst, DImg src, int row_bytes, int nblk_x, int nblk_y) {
+constexpr int kTileW = 1024;               // output bytes per workgroup row = 64 lanes x 16 B
+constexpr int kLdsPitch = kTileW + 32;      // + 16 B halo chunk on each side
+constexpr int kChunksPerRow = kLdsPitch / 16;
+
+// Reading a few bytes past a row's border is safe whenever the row is not the first / last row of the allocation (the
+// neighbouring bytes belong to the adjacent row of the same buffer) and those bytes never feed the arithmetic (only
+// window positions [8-2CH, 24+2CH) do).  GUARD=true is used by the row blocks that touch the allocation's first / last
+// row when src.border == 2.
+template <int CH, int TH, bool NT, bool GUARD>
+__device__ __forceinline__ void box5x5_u8_tile(uint8_t* __restrict__ dp, const uint8_t* __restrict__ sp, int dpitch, int spitch,
+                                               int nrows, int row_bytes, int border_bytes, int x0, int r0, uint8_t* lds) {
+  constexpr int kRows = TH + 4;
+  constexpr int kTotal = kRows * kChunksPerRow;
+  constexpr int kIters = (kTotal + 255) / 256;
+  const int lo = -border_bytes, hi = row_bytes + border_bytes;
+  const int tid = threadIdx.x;
+  // ---- stage: all global loads first, then the LDS writes
+  u32x4 stage[kIters];
+#pragma unroll
+  for (int it = 0; it < kIters; it++) {
+    const int c = tid + it * 256;
+    const int rr = c / kChunksPerRow, cc = c - rr * kChunksPerRow;
+    const int gx = x0 - 16 + cc * 16;
+    const int r = r0 - 2 + rr;
+    stage[it] = u32x4{0, 0, 0, 0};
+    if (c < kTotal && r <= nrows + 1 && gx < row_bytes + 16)
+      stage[it] = ld_chunk<GUARD>(sp + (ptrdiff_t)r * spitch, gx, lo, hi);
+  }
+#pragma unroll
+  for (int it = 0; it < kIters; it++) {
+    const int c = tid + it * 256;
+    if (c < kTotal) *(u32x4*)(lds + c * 16) = stage[it];  // chunk c sits at row (c / 66), col16 (c % 66): linear
+  }
+  __syncthreads();
+
+  // ---- compute: wave w produces tile rows [w*RW, w*RW+RW)
+  constexpr int RW = TH / 4;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int x = x0 + lane * 16;
+  if (x >= row_bytes) return;
+  const bool full_store = x + 16 <= row_bytes;
+  const uint8_t* lw = lds + 8 + lane * 16;  // window byte 0 (= x-8) of tile row 0
+  auto load_unpack = [&](int t, uint32_t* e, uint32_t* o) {
+    const uint8_t* q = lw + t * kLdsPitch;
+    const u32x2 l = *(const u32x2*)q; const u32x4 m = *(const u32x4*)(q + 8); const u32x2 rr = *(const u32x2*)(q + 24);
+    const uint32_t w[8] = {l.x, l.y, m.x, m.y, m.z, m.w, rr.x, rr.y};
+#pragma unroll
+    for (int i = 0; i < 8; i++) { e[i] = __builtin_amdgcn_perm(0u, w[i], 0x0c020c00u); o[i] = __builtin_amdgcn_perm(0u, w[i], 0x0c030c01u); }
+  };
+  uint32_t E[8], O[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { E[i] = 0; O[i] = 0; }
+  const int j0 = wv * RW;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t e[8], o[8];
+    load_unpack(j0 + k, e, o);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { E[i] += e[i]; O[i] += o[i]; }
+  }
+#pragma unroll
+  for (int j = 0; j < RW; j++) {
+    const int r = r0 + j0 + j;
+    if (r >= nrows) break;
+    {
+      uint32_t e[8], o[8];
+      load_unpack(j0 + j + 4, e, o);
+#pragma unroll
+      for (int i = 0; i < 8; i++) { E[i] += e[i]; O[i] += o[i]; }
+    }
+    u32x4 res;
+    res.x = out_dword<0, CH>(E, O); res.y = out_dword<1, CH>(E, O); res.z = out_dword<2, CH>(E, O); res.w = out_dword<3, CH>(E, O);
+    uint8_t* drow = dp + (ptrdiff_t)r * dpitch + x;
+    if (full_store) {
+      if (NT) __builtin_nontemporal_store(res, (u32x4*)drow); else *(u32x4*)drow = res;
+    } else {
+      const int n = row_bytes - x;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const uint32_t d = k < 4 ? res.x : k < 8 ? res.y : k < 12 ? res.z : res.w;
+        if (k < n) drow[k] = (uint8_t)(d >> (8 * (k & 3)));
+      }
+    }
+    if (j + 1 < RW) {
+      uint32_t e[8], o[8];
+      load_unpack(j0 + j, e, o);  // the row leaving the 5-row window (re-read from LDS instead of a register ring)
+#pragma unroll
+      for (int i = 0; i < 8; i++) { E[i] -= e[i]; O[i] -= o[i]; }
+    }
+  }
+}
+
+template <int CH, int TH, bool NT>
+__global__ __launch_bounds__(256) void box5x5_u8_lds_kernel(uint8_t* __restrict__ dp, const uint8_t* __restrict__ sp, int dpitch,
+                                                            int spitch, int nrows, int row_bytes, int border_bytes, int nblk_x,
+                                                            int nblk_y, int guard_ends) {
   static_assert(CH >= 1 && CH <= 4, "window holds 2*CH <= 8 halo bytes");
+  static_assert(TH % 4 == 0, "four waves split the tile rows");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(TH + 4) * kLdsPitch];
   // logical block id, XCD-remapped so that vertically adjacent row blocks run on the same XCD / L2
   const unsigned nb = (unsigned)nblk_x * (unsigned)nblk_y;
   const unsigned lb = xcd_remap(blockIdx.x, nb);
   const int by = lb / nblk_x, bx = lb - by * nblk_x;
-  const int x = (bx * 256 + threadIdx.x) * 16;
-  if (x >= row_bytes) return;
-  const int r0 = by * ROWS;
-  const int lo = -src.border * CH, hi = row_bytes + src.border * CH;
-  const bool full_store = x + 16 <= row_bytes;
-
-  uint32_t ring_e[5][8], ring_o[5][8];  // unpacked rows r-2..r+2 (register ring, fully unrolled)
-  uint32_t E[8], O[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) { E[i] = 0; O[i] = 0; }
-
-  auto load_unpack = [&](int r, uint32_t* e, uint32_t* o) {
-    uint32_t w[8];
-    load_window(src.p0 + (ptrdiff_t)r * src.pitch, x, lo, hi, w);
-#pragma unroll
-    for (int i = 0; i < 8; i++) { e[i] = w[i] & 0x00FF00FFu; o[i] = (w[i] >> 8) & 0x00FF00FFu; }
-  };
-
-  // prologue: rows r0-2 .. r0+1
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    load_unpack(r0 - 2 + k, ring_e[k], ring_o[k]);
-#pragma unroll
-    for (int i = 0; i < 8; i++) { E[i] += ring_e[k][i]; O[i] += ring_o[k][i]; }
-  }
-#pragma unroll
-  for (int j = 0; j < ROWS; j++) {
-    const int r = r0 + j;
-    if (r >= dst.nr) break;
-    const int slot_new = (j + 4) % 5;  // slot of row r+2; it previously held row r-3
-    if (j > 0) {
-#pragma unroll
-      for (int i = 0; i < 8; i++) { E[i] -= ring_e[slot_new][i]; O[i] -= ring_o[slot_new][i]; }
-    }
-    load_unpack(r + 2, ring_e[slot_new], ring_o[slot_new]);
-#pragma unroll
-    for (int i = 0; i < 8; i++) { E[i] += ring_e[slot_new][i]; O[i] += ring_o[slot_new][i]; }
-
-    u32x4 res;
-    res.x = out_dword<0, CH>(E, O); res.y = out_dword<1, CH>(E, O); res.z = out_dword<2, CH>(E, O); res.w = out_dword<3, CH>(E, O);
-    uint8_t* drow = dst.p0 + (ptrdiff_t)r * dst.pitch + x;
-    if (full_store) *(u32x4*)drow = res;
-    else {
-      union { u32x4 v; uint8_t b[16]; } u; u.v = res;
-      for (int k = 0; k < row_bytes - x; k++) drow[k] = u.b[k];
-    }
-  }
+  const int x0 = bx * kTileW, r0 = by * TH;
+  if (guard_ends && (by == 0 || by == nblk_y - 1))
+    box5x5_u8_tile<CH, TH, NT, true>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x0, r0, lds);
+  else
+    box5x5_u8_tile<CH, TH, NT, false>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x0, r0, lds);
 }
 
 // ---- generic path ----------------------------------------------------------------------------------------
@@ -171,19 +229,24 @@ int launch_generic(const vpp_image_desc* dst, const vpp_image_desc* src, int R, 
 
 template <int CH> int launch_fast(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
   const int row_bytes = dst->ncols * CH;
-  const int rows = tuning("box.rows", 8);
-  const int nblk_x = (row_bytes + 256 * 16 - 1) / (256 * 16);
-  auto go = [&](auto RW) {
-    constexpr int ROWS = decltype(RW)::value;
-    const int nblk_y = (dst->nrows + ROWS - 1) / ROWS;
-    box5x5_u8_kernel<CH, ROWS><<<nblk_x * nblk_y, 256, 0, st>>>(dimg(dst), dimg(src), row_bytes, nblk_x, nblk_y);
+  const int th = tuning("box.rows", 8);
+  const int nt = tuning("box.nt", 1);
+  const int nblk_x = (row_bytes + kTileW - 1) / kTileW;
+  auto go = [&](auto RW, auto NTc) {
+    constexpr int TH = decltype(RW)::value; constexpr bool NT = decltype(NTc)::value;
+    const int nblk_y = (dst->nrows + TH - 1) / TH;
+    box5x5_u8_lds_kernel<CH, TH, NT><<<nblk_x * nblk_y, 256, 0, st>>>((uint8_t*)dst->first_pixel, (const uint8_t*)src->first_pixel, dst->pitch,
+                                                                      src->pitch, dst->nrows, row_bytes, src->border * CH, nblk_x, nblk_y,
+                                                                      src->border == 2 ? 1 : 0);
   };
-  switch (rows) {
-    case 4: go(std::integral_constant<int, 4>()); break;
-    case 16: go(std::integral_constant<int, 16>()); break;
-    case 32: go(std::integral_constant<int, 32>()); break;
-    default: go(std::integral_constant<int, 8>()); break;
-  }
+  auto pick = [&](auto NTc) {
+    switch (th) {
+      case 8: go(std::integral_constant<int, 8>(), NTc); break;
+      case 32: go(std::integral_constant<int, 32>(), NTc); break;
+      default: go(std::integral_constant<int, 16>(), NTc); break;
+    }
+  };
+  if (nt) pick(std::true_type()); else pick(std::false_type());
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }

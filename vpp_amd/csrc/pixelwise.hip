@@ -105,8 +105,8 @@ int launch_binary(const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_
   if (flat) {
     const size_t total = (size_t)row_bytes * dst->nrows;
     const size_t nvec = total >> 4;
-    const int unroll = tuning("add.unroll", 4);
-    const int nt = tuning("add.nt", 0);
+    const int unroll = tuning("add.unroll", 8);
+    const int nt = tuning("add.nt", 1);
     auto go = [&](auto U, auto NTc) {
       constexpr int UN = decltype(U)::value; constexpr bool N = decltype(NTc)::value;
       const size_t per_block = 256 * UN;
@@ -117,8 +117,8 @@ int launch_binary(const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_
       switch (unroll) {
         case 1: go(std::integral_constant<int, 1>(), NTc); break;
         case 2: go(std::integral_constant<int, 2>(), NTc); break;
-        case 8: go(std::integral_constant<int, 8>(), NTc); break;
-        default: go(std::integral_constant<int, 4>(), NTc); break;
+        case 4: go(std::integral_constant<int, 4>(), NTc); break;
+        default: go(std::integral_constant<int, 8>(), NTc); break;
       }
     };
     if (nt) pick(std::true_type()); else pick(std::false_type());

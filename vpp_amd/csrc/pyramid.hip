@@ -1,0 +1,115 @@
+// pyramid.hip — K4/K5: one step of pyramid::propagate_level0 for factor 2
+// (reference: vpp/core/pyramid.hh:12-59 antialiasing_lowpass_filter, :62-81 subsample2, :175-182 the per-level loop).
+//
+// Fused: only the even rows / columns that subsample2 keeps are ever computed.  Semantics restated per output
+// component (S = plus_promotion<V>, V() = conversion back to the element type, which truncates for integer V):
+//   H(rr, cc) = V((1*S(in(rr,cc-2)) + 4*S(in(rr,cc-1)) + 6*S(in(rr,cc)) + 4*S(in(rr,cc+1)) + 1*S(in(rr,cc+2))) / 16)   rr in [0,nr)
+//   H(-1)=H(0), H(-2)=H(1), H(nr)=H(nr-1), H(nr+1)=H(nr-2)                      (fill_border_mirror(tmp), pyramid.hh:36)
+//   L(r, cc)  = V((1*S(H(r-2,cc)) + 4*S(H(r-1,cc)) + 6*S(H(r,cc)) + 4*S(H(r+1,cc)) + 1*S(H(r+2,cc))) / 16)
+//   next(r,c) = (2r < nr && 2c < nc) ? L(2r, 2c) : 0        (the reference reads an unfilled temp border there)
+// then fill_border_mirror(next) (pyramid.hh:182) as a second launch of the K3 kernel.
+// Launch-latency bound at the sizes in play (<= 16.6 MB in, 4.1 MB out for the 1080p vfloat2 gradient pyramid).
+#include "common.hpp"
+using namespace vpp_amd;
+
+namespace vpp_amd { int launch_fill_border(const vpp_image_desc* img, int mode, const void* value, hipStream_t st); }
+
+namespace {
+
+template <class T> struct Promo { typedef int type; };
+template <> struct Promo<float> { typedef float type; };
+template <> struct Promo<uint32_t> { typedef uint32_t type; };
+
+template <class T, class S> __device__ __forceinline__ T tap5(S a, S b, S c, S d, S e) {
+  return (T)((1 * a + 4 * b + 6 * c + 4 * d + 1 * e) / 16);
+}
+template <class T, class S> __device__ __forceinline__ T hpass(const DImg& in, int rr, int comp, int ch) {
+  const T* i = in.row<T>(rr) + comp;
+  return tap5<T, S>((S)i[-2 * ch], (S)i[-ch], (S)i[0], (S)i[ch], (S)i[2 * ch]);
+}
+__device__ __forceinline__ int mirror_row(int r, int nr) { return r < 0 ? -r - 1 : (r >= nr ? 2 * nr - r - 1 : r); }
+
+template <class T, class S> __device__ __forceinline__ T lowpass_at(const DImg& in, int r, int comp, int ch) {
+  S h[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) h[k] = (S)hpass<T, S>(in, mirror_row(r - 2 + k, in.nr), comp, ch);
+  return tap5<T, S>(h[0], h[1], h[2], h[3], h[4]);
+}
+
+template <class T, class S>
+__global__ __launch_bounds__(256) void pyr_down_kernel(DImg next, DImg prev) {
+  const int ch = prev.ch;
+  const int comp = blockIdx.x * 256 + threadIdx.x;  // component index within the output row
+  const int r = blockIdx.y;
+  if (comp >= next.nc * ch) return;
+  const int c = comp / ch, k = comp - c * ch;
+  T v = 0;
+  if (2 * r < prev.nr && 2 * c < prev.nc) v = lowpass_at<T, S>(prev, 2 * r, 2 * c * ch + k, ch);
+  next.row<T>(r)[comp] = v;
+}
+
+template <class T, class S>
+__global__ __launch_bounds__(256) void lowpass_kernel(DImg out, DImg in) {
+  const int ch = in.ch;
+  const int comp = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;
+  if (comp >= in.nc * ch) return;
+  out.row<T>(r)[comp] = lowpass_at<T, S>(in, r, comp, ch);
+}
+
+template <class F> int by_dtype(int dtype, F f) {
+  switch (dtype) {
+    case VPP_U8: return f((uint8_t)0);
+    case VPP_I8: return f((int8_t)0);
+    case VPP_U16: return f((uint16_t)0);
+    case VPP_I16: return f((int16_t)0);
+    case VPP_I32: return f((int32_t)0);
+    case VPP_U32: return f((uint32_t)0);
+    case VPP_F32: return f((float)0);
+  }
+  return VPP_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vpp_pyr_down(const vpp_image_desc* next, const vpp_image_desc* prev, void* stream) {
+  VPP_REQUIRE(valid_desc(next) && valid_desc(prev), VPP_ERR_INVALID_ARG, "vpp_pyr_down: invalid descriptor");
+  VPP_REQUIRE(same_type(next, prev), VPP_ERR_INVALID_ARG, "vpp_pyr_down: element types differ");
+  VPP_REQUIRE(prev->border >= 2, VPP_ERR_BORDER_TOO_SMALL, "vpp_pyr_down: prev needs border >= 2 (has %d)", prev->border);
+  VPP_REQUIRE(next->nrows == 1 + prev->nrows / 2 && next->ncols == 1 + prev->ncols / 2, VPP_ERR_INVALID_ARG,
+              "vpp_pyr_down: next must be (1+nr/2, 1+nc/2) = (%d,%d), got (%d,%d) (pyramid.hh:140)", 1 + prev->nrows / 2, 1 + prev->ncols / 2,
+              next->nrows, next->ncols);
+  hipStream_t st = as_stream(stream);
+  dim3 grid((next->ncols * next->channels + 255) / 256, next->nrows);
+  DImg n = dimg(next), p = dimg(prev);
+  int rc = by_dtype(prev->dtype, [&](auto t) {
+    typedef decltype(t) T; typedef typename Promo<T>::type S;
+    pyr_down_kernel<T, S><<<grid, 256, 0, st>>>(n, p);
+    return (int)VPP_OK;
+  });
+  if (rc != VPP_OK) return rc;
+  VPP_LAUNCH_CHECK();
+  return launch_fill_border(next, VPP_BORDER_MIRROR, nullptr, st);
+}
+
+int vpp_lowpass5(const vpp_image_desc* out, const vpp_image_desc* in, void* stream) {
+  VPP_REQUIRE(valid_desc(out) && valid_desc(in), VPP_ERR_INVALID_ARG, "vpp_lowpass5: invalid descriptor");
+  VPP_REQUIRE(same_type(out, in) && same_domain(out, in), VPP_ERR_INVALID_ARG, "vpp_lowpass5: domain/type mismatch");
+  VPP_REQUIRE(in->border >= 2, VPP_ERR_BORDER_TOO_SMALL, "vpp_lowpass5: in needs border >= 2 (has %d)", in->border);
+  VPP_REQUIRE(out->first_pixel != in->first_pixel, VPP_ERR_INVALID_ARG, "vpp_lowpass5: in-place not supported");
+  hipStream_t st = as_stream(stream);
+  dim3 grid((in->ncols * in->channels + 255) / 256, in->nrows);
+  DImg o = dimg(out), i = dimg(in);
+  int rc = by_dtype(in->dtype, [&](auto t) {
+    typedef decltype(t) T; typedef typename Promo<T>::type S;
+    lowpass_kernel<T, S><<<grid, 256, 0, st>>>(o, i);
+    return (int)VPP_OK;
+  });
+  if (rc != VPP_OK) return rc;
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+}  // extern "C"

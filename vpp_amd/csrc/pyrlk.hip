@@ -1,0 +1,248 @@
+// pyrlk.hip — K10: pyramidal Lucas-Kanade.
+// Reference: vpp/algorithms/pyrlk/pyrlk_match.hh:15-55 (coarse-to-fine driver),
+//            vpp/algorithms/pyrlk/lk.hh:43-175 (lk_match_point_square_win<WS>::operator()),
+//            vpp/algorithms/lucas_kanade/lucas_kanade.hpp:12-131,159-183 (lk_internals::match + serial driver),
+//            vpp/core/imageNd.hpp:280-300 (linear_interpolate, result cast back to the pixel type),
+//            vpp/core/keypoint_container.hpp:136-167 (move / remove).
+//
+// Float parity: every sum runs over the window in the reference's row-major order with the reference's operation
+// order, compiled with -ffp-contract=off; IEEE add/mul/div/sqrt are correctly rounded on gfx950 (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt), so displacements are bit-identical to the serial oracle except for the
+// min-eigenvalue gate (closed form instead of Eigen's EigenSolver; only a threshold compare).
+//
+// Mapping: one lane per keypoint, all pyramid levels in one launch (keypoints are independent, pyrlk_match.hh:24).
+// The window cache gs[]/as[] of lk.hh:90-112 lives in registers (WS <= 7) or scratch.  Not bandwidth bound: ~1 KB
+// touched per keypoint-level, L2-resident; the metric is tracks/s.
+#include "common.hpp"
+#include <cfloat>
+using namespace vpp_amd;
+
+namespace {
+
+constexpr int kMaxLevels = 8;
+struct Pyr { DImg l[kMaxLevels]; };
+
+// imageNd::linear_interpolate (imageNd.hpp:280-300).  Reads (x, x+row, x+col, x+row+col) with no bounds check in the
+// reference; SAFE=false clamps the four taps into the bordered area so that a wandering estimate can never fault
+// (identical values whenever the reference's own read was inside the border).
+template <class T, int CH, bool SAFE>
+__device__ __forceinline__ void interp(const DImg& I, float p0, float p1, T* out) {
+  const int x0 = (int)p0, x1 = (int)p1;
+  const float a0 = p0 - x0, a1 = p1 - x1;
+  int r0 = x0, r1 = x0 + 1, c0 = x1, c1 = x1 + 1;
+  if (!SAFE) {
+    const int rlo = -I.border, rhi = I.nr + I.border - 1, clo = -I.border, chi = I.nc + I.border - 1;
+    r0 = min(max(r0, rlo), rhi); r1 = min(max(r1, rlo), rhi); c0 = min(max(c0, clo), chi); c1 = min(max(c1, clo), chi);
+  }
+  const T* l1 = I.row<T>(r0);
+  const T* l2 = I.row<T>(r1);
+  const float w00 = (1 - a0) * (1 - a1), w10 = a0 * (1 - a1), w01 = (1 - a0) * a1, w11 = a0 * a1;
+#pragma unroll
+  for (int k = 0; k < CH; k++) {
+    const float v = w00 * (float)l1[c0 * CH + k] + w10 * (float)l2[c0 * CH + k] + w01 * (float)l1[c1 * CH + k] + w11 * (float)l2[c1 * CH + k];
+    out[k] = (T)v;  // vpp::cast<V>: truncation for integer V
+  }
+}
+
+// true when every tap of a WS x WS window of bilinear reads centred on (v0,v1) stays inside the bordered area
+__device__ __forceinline__ bool window_inside(const DImg& I, float v0, float v1, int hws) {
+  const float m = (float)(hws + 2);
+  return v0 - m >= (float)(-I.border) && v0 + m <= (float)(I.nr + I.border - 1) && v1 - m >= (float)(-I.border) && v1 + m <= (float)(I.nc + I.border - 1);
+}
+
+struct Match { float f0, f1, err; };
+
+template <int WS, class GT, bool PYRLK>
+__device__ Match lk_match(float p0, float p1, float tr0, float tr1, const DImg& A, const DImg& B, const DImg& Ag, float min_ev_th,
+                          int max_it, float delta) {
+  constexpr int hws = WS / 2, N = WS * WS;
+  const bool a_safe = window_inside(A, p0, p1, hws);  // A and Ag share the domain and (by contract) the border
+  float G00 = 0, G01 = 0, G10 = 0, G11 = 0;
+  int cpt = 0;
+  float gs0[N], gs1[N];
+  int as[N];
+  // lk.hh:56-72 (structure tensor) and :99-112 (cache) visit the same offsets with the same predicate (A and Ag share
+  // their domain), so one pass fills both; unset cache entries are 0 (canonical value).
+#pragma unroll(N <= 49 ? N : 1)
+  for (int i = 0; i < N; i++) {
+    const int r = i / WS - hws, c = i % WS - hws;
+    const float n0 = p0 + (float)r, n1 = p1 + (float)c;
+    gs0[i] = 0.f; gs1[i] = 0.f; as[i] = 0;
+    if (A.has((int)n0, (int)n1)) {
+      GT g[2]; uint8_t a;
+      if (a_safe) { interp<GT, 2, true>(Ag, n0, n1, g); interp<uint8_t, 1, true>(A, n0, n1, &a); }
+      else { interp<GT, 2, false>(Ag, n0, n1, g); interp<uint8_t, 1, false>(A, n0, n1, &a); }
+      const float gx = (float)g[0], gy = (float)g[1];
+      G00 += gx * gx; G01 += gx * gy; G10 += gx * gy; G11 += gy * gy;
+      cpt++;
+      gs0[i] = gx; gs1[i] = gy; as[i] = (int)a;
+    }
+  }
+  {  // lk.hh:75-81, min |eigenvalue| of G / cpt (symmetric 2x2 closed form)
+    const float fc = (float)cpt;
+    const float a = G00 / fc, b = G01 / fc, d = G11 / fc;
+    const float hm = (a + d) * 0.5f, hd = (a - d) * 0.5f;
+    const float s = sqrtf(hd * hd + b * b);
+    const float e1 = fabsf(hm + s), e2 = fabsf(hm - s);
+    float min_ev = 99999.f;
+    if (e1 < min_ev) min_ev = e1;
+    if (e2 < min_ev) min_ev = e2;
+    if (min_ev < min_ev_th) return Match{-1.f, -1.f, FLT_MAX};
+  }
+  const float det = G00 * G11 - G10 * G01;  // lk.hh:83, Eigen 2x2 inverse
+  const float invdet = 1.f / det;
+  const float I00 = G11 * invdet, I10 = -G10 * invdet, I01 = -G01 * invdet, I11 = G00 * invdet;
+
+  float v0 = p0 + tr0, v1 = p1 + tr1;
+  float nk0 = 1.f, nk1 = 1.f;
+  for (int k = 0; k <= max_it && sqrtf(nk0 * nk0 + nk1 * nk1) >= delta; k++) {  // lk.hh:116
+    float bk0 = 0.f, bk1 = 0.f;
+    const bool b_safe = window_inside(B, v0, v1, hws);
+#pragma unroll(N <= 49 ? N : 1)
+    for (int i = 0; i < N; i++) {
+      const int r = i / WS - hws, c = i % WS - hws;
+      const float n0 = p0 + (float)r, n1 = p1 + (float)c;
+      if (A.has((int)n0, (int)n1)) {
+        uint8_t b;
+        if (b_safe) interp<uint8_t, 1, true>(B, v0 + (float)r, v1 + (float)c, &b);
+        else interp<uint8_t, 1, false>(B, v0 + (float)r, v1 + (float)c, &b);
+        const float dt = (float)as[i] - (float)b;  // lk.hh:130
+        bk0 += gs0[i] * dt; bk1 += gs1[i] * dt;
+      }
+    }
+    nk0 = I00 * bk0 + I01 * bk1;  // lk.hh:137
+    nk1 = I10 * bk0 + I11 * bk1;
+    v0 += nk0; v1 += nk1;
+    if (!B.has((int)v0, (int)v1)) return Match{0.f, 0.f, FLT_MAX};  // lk.hh:145-146
+  }
+  float err = 0.f, stddev = 1.f;
+  if (PYRLK) {  // lk.hh:151-159
+    float avg = 0.f;
+    stddev = 0.f;
+#pragma unroll(N <= 49 ? N : 1)
+    for (int i = 0; i < N; i++) avg += (float)as[i];
+    avg /= N;
+#pragma unroll(N <= 49 ? N : 1)
+    for (int i = 0; i < N; i++) stddev += fabsf(avg - (float)as[i]);
+    stddev /= N;
+  }
+  const bool b_safe = window_inside(B, v0, v1, hws);
+#pragma unroll(N <= 49 ? N : 1)
+  for (int i = 0; i < N; i++) {  // lk.hh:161-171 / lucas_kanade.hpp:116-126
+    const int r = i / WS - hws, c = i % WS - hws;
+    uint8_t b;
+    if (b_safe) interp<uint8_t, 1, true>(B, v0 + (float)r, v1 + (float)c, &b);
+    else interp<uint8_t, 1, false>(B, v0 + (float)r, v1 + (float)c, &b);
+    err += fabsf((float)(as[i] - (int)b));
+    cpt++;
+  }
+  if (PYRLK) return Match{v0 - p0, v1 - p1, err / (cpt * stddev)};  // lk.hh:173
+  return Match{v0 - p0, v1 - p1, err / (cpt)};                        // lucas_kanade.hpp:128
+}
+
+template <int WS>
+__global__ __launch_bounds__(64) void pyrlk_match_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, vpp_keypoint_f32* __restrict__ kps, int n,
+                                                         float min_ev, float max_err, int max_it, float delta, int min_scale,
+                                                         float* __restrict__ out_dist) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  vpp_keypoint_f32 kp = kps[i];
+  if (out_dist) out_dist[i] = 0.f;
+  if (!(kp.age > 0)) return;  // kp.alive(), pyrlk_match.hh:27
+  float tr0 = 0.f, tr1 = 0.f, dist = 0.f;
+  for (int S = nlevels - 1; S >= min_scale; S--) {  // pyrlk_match.hh:31-42
+    tr0 *= 2.f; tr1 *= 2.f;
+    const float sc = (float)(1 << S);
+    const Match m = lk_match<WS, float, true>(kp.pos_r / sc, kp.pos_c / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, max_it, delta);
+    if (m.err < max_err) { tr0 = m.f0; tr1 = m.f1; }
+    dist = m.err;
+  }
+  const float q0 = kp.pos_r + tr0, q1 = kp.pos_c + tr1;
+  if (out_dist) out_dist[i] = dist;
+  if (dist > max_err || !P.l[0].has((int)q0, (int)q1)) kp.age = 0;  // remove -> die(), pyrlk_match.hh:44-48
+  else { kp.vel_r = q0 - kp.pos_r; kp.vel_c = q1 - kp.pos_c; kp.pos_r = q0; kp.pos_c = q1; kp.age++; }  // move
+  kps[i] = kp;
+}
+
+template <int WS>
+__global__ __launch_bounds__(64) void lucas_kanade_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, const float* __restrict__ pts,
+                                                          const float* __restrict__ pred, int n, float min_ev, int niter, float delta,
+                                                          float* __restrict__ out_flow, float* __restrict__ out_dist) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const float k0 = pts[2 * i], k1 = pts[2 * i + 1];
+  const float d = (float)(1 << nlevels);
+  float tr0 = (pred ? pred[2 * i] : 0.f) / d, tr1 = (pred ? pred[2 * i + 1] : 0.f) / d;  // lucas_kanade.hpp:163
+  float dist = 0.f;
+  for (int S = nlevels - 1; S >= 0; S--) {  // :165-179
+    tr0 *= 2.f; tr1 *= 2.f;
+    const float sc = (float)(1 << S);  // kp / int(pow(2,S)) -> Eigen converts the int scalar to float
+    const Match m = lk_match<WS, int32_t, false>(k0 / sc, k1 / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, niter, delta);
+    tr0 = m.f0; tr1 = m.f1; dist = m.err;
+  }
+  out_flow[2 * i] = tr0; out_flow[2 * i + 1] = tr1;
+  if (out_dist) out_dist[i] = dist;
+}
+
+int check_pyramids(const char* fn, const vpp_image_desc* prev, const vpp_image_desc* grad, const vpp_image_desc* next, int nlevels,
+                   int grad_dtype, Pyr& P, Pyr& G, Pyr& N) {
+  VPP_REQUIRE(prev && grad && next && nlevels >= 1 && nlevels <= kMaxLevels, VPP_ERR_INVALID_ARG, "%s: need 1..%d pyramid levels", fn, kMaxLevels);
+  for (int l = 0; l < nlevels; l++) {
+    VPP_REQUIRE(valid_desc(prev + l) && valid_desc(grad + l) && valid_desc(next + l), VPP_ERR_INVALID_ARG, "%s: invalid descriptor at level %d", fn, l);
+    VPP_REQUIRE(prev[l].dtype == VPP_U8 && prev[l].channels == 1 && next[l].dtype == VPP_U8 && next[l].channels == 1, VPP_ERR_UNSUPPORTED,
+                "%s: frames must be u8 x1", fn);
+    VPP_REQUIRE(grad[l].dtype == grad_dtype && grad[l].channels == 2, VPP_ERR_UNSUPPORTED, "%s: gradient pyramid has the wrong element type", fn);
+    VPP_REQUIRE(same_domain(prev + l, grad + l) && same_domain(prev + l, next + l), VPP_ERR_INVALID_ARG, "%s: level %d domains differ", fn, l);
+    VPP_REQUIRE(prev[l].border >= 1 && grad[l].border >= 1 && next[l].border >= 1, VPP_ERR_BORDER_TOO_SMALL, "%s: level %d needs border >= 1", fn, l);
+    P.l[l] = dimg(prev + l); G.l[l] = dimg(grad + l); N.l[l] = dimg(next + l);
+    // the two images read with one `safe` flag must agree on how far a window may reach
+    G.l[l].border = P.l[l].border = (prev[l].border < grad[l].border ? prev[l].border : grad[l].border);
+  }
+  return VPP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, const vpp_image_desc* next, int nlevels,
+                    vpp_keypoint_f32* kps, int n, int winsize, float min_ev, float max_err, int max_iterations,
+                    float convergence_delta, int min_scale, float* out_dist, void* stream) {
+  Pyr P, G, N;
+  int rc = check_pyramids("vpp_pyrlk_match", prev, grad, next, nlevels, VPP_F32, P, G, N);
+  if (rc != VPP_OK) return rc;
+  VPP_REQUIRE(kps && n >= 0 && min_scale >= 0, VPP_ERR_INVALID_ARG, "vpp_pyrlk_match: invalid argument");
+  if (n == 0) return VPP_OK;
+  hipStream_t st = as_stream(stream);
+  const int blocks = (n + 63) / 64;
+#define VPP_LK_CASE(W) case W: pyrlk_match_kernel<W><<<blocks, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); break;
+  switch (winsize) {
+    VPP_LK_CASE(3) VPP_LK_CASE(5) VPP_LK_CASE(7) VPP_LK_CASE(9) VPP_LK_CASE(11) VPP_LK_CASE(15) VPP_LK_CASE(21)
+    default: set_error("vpp_pyrlk_match: unsupported window size %d (3,5,7,9,11,15,21)", winsize); return VPP_ERR_UNSUPPORTED;
+  }
+#undef VPP_LK_CASE
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+int vpp_lucas_kanade(const vpp_image_desc* prev, const vpp_image_desc* grad, const vpp_image_desc* next, int nlevels,
+                     const float* pts, const float* prediction, int n, int winsize, int min_ev, int niterations, int delta,
+                     float* out_flow, float* out_dist, void* stream) {
+  Pyr P, G, N;
+  int rc = check_pyramids("vpp_lucas_kanade", prev, grad, next, nlevels, VPP_I32, P, G, N);
+  if (rc != VPP_OK) return rc;
+  VPP_REQUIRE(pts && out_flow && n >= 0, VPP_ERR_INVALID_ARG, "vpp_lucas_kanade: invalid argument");
+  if (n == 0) return VPP_OK;
+  hipStream_t st = as_stream(stream);
+  const int blocks = (n + 63) / 64;
+#define VPP_LK_CASE(W) case W: lucas_kanade_kernel<W><<<blocks, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, (float)min_ev, niterations, (float)delta, out_flow, out_dist); break;
+  switch (winsize) {
+    VPP_LK_CASE(3) VPP_LK_CASE(5) VPP_LK_CASE(7) VPP_LK_CASE(9) VPP_LK_CASE(11) VPP_LK_CASE(15) VPP_LK_CASE(21)
+    default: set_error("vpp_lucas_kanade: unsupported window size %d (3,5,7,9,11,15,21)", winsize); return VPP_ERR_UNSUPPORTED;
+  }
+#undef VPP_LK_CASE
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+}  // extern "C"

@@ -28,7 +28,7 @@ const char* vpp_version(void) { return "vpp_amd 0.1 (gfx950)"; }
 int vpp_set_tuning(const char* name, int value) {
   VPP_REQUIRE(name, VPP_ERR_INVALID_ARG, "vpp_set_tuning: null name");
   std::lock_guard<std::mutex> l(g_tune_mu);
-  g_tune[name] = value;
+  if (value < 0) g_tune.erase(name); else g_tune[name] = value;  // negative = back to the built-in default
   return VPP_OK;
 }
 
