@@ -1,0 +1,74 @@
+"""GPU parity (bit-exact, integer) of semi_dense_optical_flow against the serial CPU oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from util import P, u8_image, DeviceImage, texture, translate
+from vpp_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def flow_scene(nr, nc, seed=6, spacing=5):
+    """C4 texture with 4 piecewise translations (quadrants), |flow| <= 6 px (BASELINE config 5, scaled)."""
+    tex = texture(nr, nc, seed=seed, sigma=1.5)
+    f1 = np.clip(np.rint(tex), 0, 255).astype(np.uint8)
+    f2 = f1.copy().astype(np.float64)
+    shifts = [(2.0, -3.0), (-4.0, 1.0), (5.0, 4.0), (0.0, -6.0)]
+    h, w = nr // 2, nc // 2
+    for (dr, dc), (r0, c0) in zip(shifts, [(0, 0), (0, w), (h, 0), (h, w)]):
+        f2[r0:r0 + h, c0:c0 + w] = translate(tex, dr, dc)[r0:r0 + h, c0:c0 + w]
+    f2 = np.clip(np.rint(f2), 0, 255).astype(np.uint8)
+    rr, cc = np.meshgrid(np.arange(spacing, nr - spacing, spacing), np.arange(spacing, nc - spacing, spacing), indexing="ij")
+    kps = np.stack([rr.ravel(), cc.ravel()], 1).astype(np.int32)
+    return f1, f2, kps
+
+
+def run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch):
+    i1, i2 = u8_image(f1, border=3), u8_image(f2, border=3)
+    n = len(kps)
+    wp = np.zeros((n, 2), np.int32); wd = np.zeros(n, np.int32); wv = np.zeros(n, np.uint8)
+    assert orc.orc_semi_dense_optical_flow(P(i1.desc), P(i2.desc), kps.ctypes.data_as(ctypes.c_void_p), n, ws, nscales, min_scale, prop, patch,
+                                           wp.ctypes.data_as(ctypes.c_void_p), wd.ctypes.data_as(ctypes.c_void_p), wv.ctypes.data_as(ctypes.c_void_p)) == 0
+    d1, d2 = DeviceImage.from_host(i1), DeviceImage.from_host(i2)
+    dk = torch.from_numpy(kps).cuda()
+    gp = torch.zeros((n, 2), dtype=torch.int32, device="cuda"); gd = torch.zeros(n, dtype=torch.int32, device="cuda"); gv = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    capi.check(lib.vpp_semi_dense_optical_flow(P(d1.desc), P(d2.desc), ctypes.c_void_p(dk.data_ptr()), n, ws, nscales, min_scale, prop, patch,
+                                               ctypes.c_void_p(gp.data_ptr()), ctypes.c_void_p(gd.data_ptr()), ctypes.c_void_p(gv.data_ptr()), capi.stream_ptr()))
+    torch.cuda.synchronize()
+    return (gp.cpu().numpy(), gd.cpu().numpy(), gv.cpu().numpy()), (wp, wd, wv)
+
+
+@pytest.mark.parametrize("shape,ws,nscales,min_scale,prop,patch", [
+    ((120, 160), 9, 3, 0, 2, 5),     # video_extruder defaults (video_extruder.hpp:35-41,54)
+    ((121, 163), 7, 4, 0, 2, 5),     # semi_dense_optical_flow defaults (semi_dense_optical_flow.hpp:57-61), odd sizes
+    ((120, 160), 9, 3, 1, 3, 5),     # min_scale 1, three sweeps (backward, forward, backward)
+    ((96, 128), 5, 2, 0, 0, 3),      # no propagation
+    ((270, 480), 9, 3, 0, 2, 5),
+])
+def test_sdof_matches_oracle(lib, orc, shape, ws, nscales, min_scale, prop, patch):
+    f1, f2, kps = flow_scene(*shape)
+    rng = np.random.default_rng(0)
+    extra = np.stack([rng.integers(0, shape[0], 300), rng.integers(0, shape[1], 300)], 1).astype(np.int32)  # several keypoints per cell
+    kps = np.concatenate([extra, kps])
+    got, want = run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch)
+    assert want[2].mean() > 0.9
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    moved = (want[0] != kps).any(axis=1).mean()
+    assert moved > 0.5  # the scene really moves
+
+
+def test_sdof_1080p_frame(lib, orc):
+    """One 1920x1080 frame pair with a keypoint every 10 px (video_extruder keypoint_spacing), defaults."""
+    f1, f2, kps = flow_scene(1080, 1920, spacing=10)
+    got, want = run_both(lib, orc, f1, f2, kps, 9, 3, 0, 2, 5)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    # size-independent property: the recovered flow equals one of the four planted translations for most keypoints
+    flow = want[0] - kps
+    planted = np.array([(2, -3), (-4, 1), (5, 4), (0, -6)])
+    ok = (np.abs(flow[:, None, :] - planted[None]).max(axis=2) <= 1).any(axis=1)
+    assert ok.mean() > 0.8, ok.mean()

@@ -1,0 +1,240 @@
+// sdof.hip — K11/K12: semi-dense optical flow (integer block matching + propagation).
+// Reference: vpp/algorithms/optical_flow/semi_dense_optical_flow.hpp:48-214 (driver), :18-42 (sad_distance),
+//            vpp/algorithms/optical_flow/gradient_descent.hh:10-89 (gradient_descent_match).
+// Epipolar options (:62-66,79-90) are not supported (optional in the reference, UB as written — SURVEY Q11).
+//
+// Serial-order semantics (what the reference's tests run; its OpenMP build is racy) made parallel:
+//   * cell claims (:114-143): the serial loop lets the LOWEST keypoint index that maps to a flow-map cell compute it.
+//     Kernel 1 takes atomicMin(index) per cell, kernel 2 runs the descent for the winners only: same result, any order.
+//   * propagation sweeps (:146-201) are in-place Gauss-Seidel scans in raster (Ki odd) / reverse raster (Ki even) order.
+//     Cell (i,j) depends on the already-updated (i-1,j-1),(i-1,j),(i-1,j+1),(i,j-1), so all cells with 2i+j = t are
+//     independent: one workgroup walks the skewed wavefront t = 0..2(NI-1)+(NJ-1) with a barrier per step — exactly the
+//     serial result, deterministic.
+// Integer arithmetic throughout: bit-exact.  SAD windows are L2-resident; the path is integer-VALU / latency bound.
+#include "common.hpp"
+#include <climits>
+using namespace vpp_amd;
+
+namespace vpp_amd { int launch_fill_border(const vpp_image_desc* img, int mode, const void* value, hipStream_t st); }
+
+namespace {
+
+constexpr int kMaxScales = 8;
+
+struct Maps { DImg flow, mark, dist; };  // i32x2, u8, i32 per flow-map cell
+
+// of_internals::sad_distance behind the domain test of the `distance` lambda (semi_dense_optical_flow.hpp:18-42,102-108)
+__device__ __forceinline__ int distance_fn(const DImg& i1, const DImg& i2, int a0, int a1, int b0, int b1, int ws, int th) {
+  if (!(i1.has(a0, a1) && i2.has(b0, b1))) return INT_MAX;
+  const uint8_t* row1 = i1.row<uint8_t>(a0 - ws / 2) + (a1 - ws / 2);
+  const uint8_t* row2 = i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2);
+  int err = 0;
+  for (int r = 0; r < ws && err <= th; r++) {
+    int err2 = 0;
+    for (int c = 0; c < ws; c++) err2 += abs((int)row1[c] - (int)row2[c]);
+    err += err2;
+    row1 += i1.pitch; row2 += i2.pitch;
+  }
+  return err;
+}
+
+struct GdMatch { int f0, f1, distance; };
+
+// gradient_descent_match (gradient_descent.hh:10-89), neighbour tables verbatim
+__device__ GdMatch gradient_descent_match(const DImg& i1, const DImg& i2, int ws, int p0, int p1, int pr0, int pr1, int max_iteration) {
+  int m0 = pr0, m1 = pr1;
+  int match_distance = distance_fn(i1, i2, p0, p1, pr0, pr1, ws, INT_MAX);
+  unsigned match_i = 8;
+  const int c8_it[9][2] = {{6, 3}, {0, 3}, {0, 5}, {2, 5}, {2, 7}, {4, 7}, {4, 1}, {6, 1}, {0, 0}};
+  const int c8[8][2] = {{-1, 1}, {0, 1}, {1, 1}, {-1, 0}, {1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+  for (int search = 0; search < max_iteration; search++) {
+    int i = c8_it[match_i][0];
+    const int end = c8_it[match_i][1];
+    {
+      const int n0 = pr0 + c8[i][0], n1 = pr1 + c8[i][1];
+      const int d = distance_fn(i1, i2, p0, p1, n0, n1, ws, match_distance);
+      if (d < match_distance) { m0 = n0; m1 = n1; match_i = i; match_distance = d; }
+      i = (i + 1) & 7;
+    }
+    for (; i != end; i = (i + 1) & 7) {
+      const int n0 = pr0 + c8[i][0], n1 = pr1 + c8[i][1];
+      const int d = distance_fn(i1, i2, p0, p1, n0, n1, ws, match_distance);
+      if (d < match_distance) { m0 = n0; m1 = n1; match_i = i; match_distance = d; }
+    }
+    if (pr0 == m0 && pr1 == m1) break;
+    pr0 = m0; pr1 = m1;
+  }
+  return GdMatch{m0 - p0, m1 - p1, match_distance};
+}
+
+__global__ __launch_bounds__(256) void sdof_claim_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, DImg owner) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int p0 = kps[2 * i] / scale_div, p1 = kps[2 * i + 1] / scale_div;
+  const int pf0 = p0 / patch, pf1 = p1 / patch;
+  if (!owner.has(pf0, pf1)) return;
+  atomicMin(owner.row<uint32_t>(pf0) + pf1, (uint32_t)i);
+}
+
+__global__ __launch_bounds__(64) void sdof_descent_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
+                                                          DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const int p0 = kps[2 * i] / scale_div, p1 = kps[2 * i + 1] / scale_div;  // :116
+  const int pf0 = p0 / patch, pf1 = p1 / patch;
+  if (!owner.has(pf0, pf1) || owner.row<uint32_t>(pf0)[pf1] != (uint32_t)i) return;  // :120 — first keypoint in index order claims
+  int pr0 = p0, pr1 = p1;
+  if (has_coarse) {  // multiscale prediction, :126-128
+    const int pfm0 = p0 / (2 * patch), pfm1 = p1 / (2 * patch);
+    if (coarse.mark.has(pfm0, pfm1) && coarse.mark.row<uint8_t>(pfm0)[pfm1]) {
+      const int32_t* f = coarse.flow.row<int32_t>(pfm0) + 2 * pfm1;
+      pr0 = p0 + f[0] * 2; pr1 = p1 + f[1] * 2;
+    }
+  }
+  const GdMatch m = gradient_descent_match(i1, i2, ws, p0, p1, pr0, pr1, 5);  // :132-134
+  int32_t* f = cur.flow.row<int32_t>(pf0) + 2 * pf1;
+  f[0] = m.f0; f[1] = m.f1;                       // :137-139
+  cur.dist.row<int32_t>(pf0)[pf1] = m.distance;  // :140
+  cur.mark.row<uint8_t>(pf0)[pf1] = 2;           // :141
+}
+
+__device__ __forceinline__ int inorm(int a, int b) { return (int)sqrt((double)(a * a + b * b)); }  // Eigen norm() on vint2
+
+// loop_body (:149-189) for cell (pf0, pf1) evaluated at image point (r, c)
+__device__ void propagate_cell(const DImg& i1, const DImg& i2, int ws, const Maps& m, int r, int c, int pf0, int pf1) {
+  if (!m.mark.row<uint8_t>(pf0)[pf1]) return;
+  int32_t* fpf = m.flow.row<int32_t>(pf0) + 2 * pf1;
+  const int prev0 = fpf[0], prev1 = fpf[1];
+  for (int dr = -1; dr <= 1; dr++)
+    for (int dc = -1; dc <= 1; dc++) {
+      if (!dr && !dc) continue;
+      const int q0 = pf0 + dr, q1 = pf1 + dc;
+      if (!(m.flow.has(q0, q1) && m.mark.row<uint8_t>(q0)[q1])) continue;
+      const int32_t* fq = m.flow.row<int32_t>(q0) + 2 * q1;
+      const int fq0 = fq[0], fq1 = fq[1];
+      if (inorm(fpf[0] - fq0, fpf[1] - fq1) > 2 && inorm(prev0 - fq0, prev1 - fq1) > 2) {
+        const int d1 = m.dist.row<int32_t>(pf0)[pf1];
+        const int d2 = distance_fn(i1, i2, r, c, r + fq0, c + fq1, ws, INT_MAX);
+        if (d2 < d1) {
+          const GdMatch g = gradient_descent_match(i1, i2, ws, r, c, r + fq0, c + fq1, 5);
+          if (g.distance < d1) {
+            m.mark.row<uint8_t>(pf0)[pf1] = 1;
+            fpf[0] = g.f0; fpf[1] = g.f1;
+            m.dist.row<int32_t>(pf0)[pf1] = g.distance;
+          }
+        }
+      }
+    }
+}
+
+// All `niters` sweeps of one scale in one launch of ONE workgroup (skewed wavefront, barrier per step).
+__global__ __launch_bounds__(1024) void sdof_propagate_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int niters) {
+  const int NI = (i1.nr - 1) / patch + 1, NJ = (i1.nc - 1) / patch + 1;  // cells visited by the loops at :192-200
+  for (int Ki = 0; Ki < niters; Ki++) {
+    const bool forward = (Ki % 2) != 0;  // :191
+    const int tmax = 2 * (NI - 1) + (NJ - 1);
+    for (int t = 0; t <= tmax; t++) {
+      const int lo = max(0, (t - (NJ - 1) + 1) >> 1), hi = min(NI - 1, t >> 1);
+      for (int iw = lo + (int)threadIdx.x; iw <= hi; iw += 1024) {
+        const int jw = t - 2 * iw;
+        int r, c;
+        if (forward) { r = iw * patch; c = jw * patch; }
+        else { r = i1.nr - 1 - iw * patch; c = i1.nc - 1 - jw * patch; }  // :198-200 start at nrows-1 / ncols-1
+        propagate_cell(i1, i2, ws, m, r, c, r / patch, c / patch);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sdof_readback_kernel(const int32_t* __restrict__ kps, int n, int div, int ms, Maps m,
+                                                            int32_t* __restrict__ out_pos, int32_t* __restrict__ out_dist, uint8_t* __restrict__ out_valid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k0 = kps[2 * i], k1 = kps[2 * i + 1];
+  const int q0 = k0 / div, q1 = k1 / div;  // :207-208
+  int o0 = k0, o1 = k1, d = 0; uint8_t v = 0;
+  if (m.mark.has(q0, q1) && m.mark.row<uint8_t>(q0)[q1]) {
+    const int32_t* f = m.flow.row<int32_t>(q0) + 2 * q1;
+    o0 = k0 + f[0] * ms; o1 = k1 + f[1] * ms; d = m.dist.row<int32_t>(q0)[q1]; v = 1;  // :210-211
+  }
+  out_pos[2 * i] = o0; out_pos[2 * i + 1] = o1; out_dist[i] = d; out_valid[i] = v;
+}
+
+struct Scratch {
+  void* p = nullptr; size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return VPP_OK;
+    if (p) { VPP_HIP_TRY(hipFree(p)); p = nullptr; cap = 0; }
+    VPP_HIP_TRY(hipMalloc(&p, bytes));
+    cap = bytes;
+    return VPP_OK;
+  }
+  ~Scratch() { if (p) (void)hipFree(p); }
+};
+thread_local Scratch g_scratch;
+
+struct Carver {
+  uint8_t* base; size_t off = 0;
+  vpp_image_desc image(int nr, int nc, int dtype, int ch, int border) {
+    int32_t pitch; size_t bytes, first;
+    vpp_image_layout(nr, nc, dtype_size(dtype) * ch, border, 32, &pitch, &bytes, &first);
+    vpp_image_desc d{base ? base + off + first : nullptr, nr, nc, pitch, border, dtype, ch};
+    off += (bytes + 255) / 256 * 256;
+    return d;
+  }
+};
+
+}  // namespace
+
+extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
+                                           int nscales, int min_scale, int propagation, int patchsize, int32_t* out_pos,
+                                           int32_t* out_dist, uint8_t* out_valid, void* stream) {
+  VPP_REQUIRE(valid_desc(i1) && valid_desc(i2) && same_domain(i1, i2), VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: invalid frames");
+  VPP_REQUIRE(i1->dtype == VPP_U8 && i1->channels == 1 && i2->dtype == VPP_U8 && i2->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_semi_dense_optical_flow: u8 x1 frames only");
+  VPP_REQUIRE(n >= 0 && (n == 0 || (kps && out_pos && out_dist && out_valid)), VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: null buffer");
+  VPP_REQUIRE(winsize > 0 && patchsize > 0 && nscales >= 1 && nscales <= kMaxScales && min_scale >= 0 && min_scale < nscales && propagation >= 0,
+              VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: bad parameters");
+  if (n == 0) return VPP_OK;
+  hipStream_t st = as_stream(stream);
+  // carve the scratch: two image pyramids (border 2*winsize, :72-73), flow / mark / distance pyramids (border nscales, :70-74), owners
+  vpp_image_desc P1[kMaxScales], P2[kMaxScales], FL[kMaxScales], MK[kMaxScales], DM[kMaxScales], OW[kMaxScales];
+  for (int pass = 0; pass < 2; pass++) {
+    Carver cv{pass ? (uint8_t*)g_scratch.p : nullptr};
+    int fr = i1->nrows / patchsize, fc = i1->ncols / patchsize, ir = i1->nrows, ic = i1->ncols;
+    VPP_REQUIRE(fr > 0 && fc > 0, VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: image smaller than one patch");
+    for (int s = 0; s < nscales; s++) {
+      P1[s] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize); P2[s] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize);
+      FL[s] = cv.image(fr, fc, VPP_I32, 2, nscales); MK[s] = cv.image(fr, fc, VPP_U8, 1, nscales); DM[s] = cv.image(fr, fc, VPP_I32, 1, nscales);
+      OW[s] = cv.image(fr, fc, VPP_U32, 1, 0);
+      fr = 1 + fr / 2; fc = 1 + fc / 2; ir = 1 + ir / 2; ic = 1 + ic / 2;  // pyramid.hh:154
+    }
+    if (!pass) { int rc = g_scratch.ensure(cv.off); if (rc != VPP_OK) return rc; }
+  }
+  auto build = [&](vpp_image_desc* P, const vpp_image_desc* in) -> int {  // pyramid::update, pyramid.hh:194-198
+    int rc = vpp_copy(&P[0], in, 0, stream); if (rc) return rc;
+    rc = launch_fill_border(&P[0], VPP_BORDER_MIRROR, nullptr, st); if (rc) return rc;
+    for (int s = 1; s < nscales; s++) { rc = vpp_pyr_down(&P[s], &P[s - 1], stream); if (rc) return rc; }
+    return VPP_OK;
+  };
+  int rc = build(P1, i1); if (rc) return rc;
+  rc = build(P2, i2); if (rc) return rc;
+  auto maps = [&](int s) { return Maps{dimg(&FL[s]), dimg(&MK[s]), dimg(&DM[s])}; };
+  for (int scale = nscales - 1; scale >= min_scale; scale--) {  // :92
+    const int scale_div = 1 << scale;
+    const uint8_t zero = 0;
+    rc = vpp_fill(&MK[scale], &zero, 1, stream); if (rc) return rc;  // fill_with_border(flow_map_mark, 0), :111
+    VPP_HIP_TRY(hipMemsetAsync(OW[scale].first_pixel, 0xFF, (size_t)OW[scale].pitch * OW[scale].nrows, st));
+    sdof_claim_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, scale_div, patchsize, dimg(&OW[scale]));
+    const bool has_coarse = scale < nscales - 1;
+    sdof_descent_kernel<<<(n + 63) / 64, 64, 0, st>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW[scale]), dimg(&P1[scale]), dimg(&P2[scale]),
+                                                     maps(scale), maps(has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0);
+    if (propagation > 0)
+      sdof_propagate_kernel<<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, propagation);
+    VPP_LAUNCH_CHECK();
+  }
+  const int ms = 1 << min_scale;
+  sdof_readback_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize * ms, ms, maps(min_scale), out_pos, out_dist, out_valid);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
