@@ -1,0 +1,55 @@
+"""Seeded inputs of the golden fixtures (tests/golden/*.npz, produced by tests/golden/make_golden.py from the reference)."""
+import zlib
+
+import numpy as np
+
+import pyr
+from test_oracle_algos import pyrlk_cc_fixture, lk_scene
+from util import rand_image, HostImage, rects_image, u8_image, texture, translate
+from vpp_amd import image as vi
+
+
+def crc(*arrs):
+    c = 0
+    for a in arrs:
+        c = zlib.crc32(np.ascontiguousarray(a).tobytes(), c)
+    return np.uint32(c)
+
+
+def box_case():
+    src = rand_image(48, 80, vi.U8, 3, border=2, seed=3, fill_border=True)
+    return src, src.like(border=0)
+
+
+def add_case():
+    b = rand_image(32, 48, vi.I32, seed=1, lo=0, hi=2**30 - 1)
+    c = rand_image(32, 48, vi.I32, seed=2, lo=0, hi=2**30 - 1)
+    return b, c, b.like()
+
+
+def pyramid_case():
+    img = rand_image(41, 56, vi.U8, 1, seed=7)
+    return img, [HostImage(nr, nc, vi.U8, 1, 3) for nr, nc in pyr.level_dims(41, 56, 3)]
+
+
+def fast_case():
+    im = u8_image(rects_image(96, 128, seed=4), border=3)
+    v = im.view(with_border=True)[..., 0]
+    v[...] = np.pad(im.view()[..., 0], 3, mode="symmetric")
+    return im
+
+
+def pyrlk_case():
+    f1, f2, kps = lk_scene(160, 200, 150)
+    return u8_image(f1), u8_image(f2), kps
+
+
+def lk_golden_case():
+    f1, f2 = pyrlk_cc_fixture()
+    return u8_image(f1), u8_image(f2), np.array([[50, 50], [48, 51], [52, 49], [50.5, 49.25]], np.float32)
+
+
+def sdof_case():
+    from test_gpu_sdof import flow_scene
+    f1, f2, kps = flow_scene(100, 140)
+    return u8_image(f1, border=3), u8_image(f2, border=3), kps, (9, 3, 0, 2, 5)

@@ -1,0 +1,123 @@
+"""Golden vectors produced by the reference itself (tests/golden/make_golden.py): the oracle must reproduce them on CPU
+and the HIP path (through the C ABI) on the GPU.  The input CRC guards against the seeded generators drifting."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as gc
+import pyr
+from util import P, DeviceImage
+from vpp_amd import image as vi
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+V = ctypes.c_void_p
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+# ---------------- CPU: oracle == reference golden ----------------
+def test_oracle_box_add(orc):
+    src, dst = gc.box_case(); g = load("box")
+    assert gc.crc(src.raw) == g["in_crc"]
+    orc.orc_box_filter(P(dst.desc), P(src.desc), 5, 5)
+    np.testing.assert_array_equal(dst.view(), g["out"])
+    b, c, a = gc.add_case(); g = load("add")
+    assert gc.crc(b.raw, c.raw) == g["in_crc"]
+    orc.orc_pixelwise_binary(0, P(a.desc), P(b.desc), P(c.desc))
+    np.testing.assert_array_equal(a.view(), g["out"])
+
+
+def test_oracle_pyramid(orc):
+    img, _ = gc.pyramid_case(); g = load("pyramid")
+    assert gc.crc(img.raw) == g["in_crc"]
+    for i, l in enumerate(pyr.host_pyramid(orc, img, 3, 3)):
+        np.testing.assert_array_equal(l.view(with_border=True), g[f"l{i}"])
+
+
+def test_oracle_fast9(orc):
+    from test_oracle_algos import run_detect
+    im = gc.fast_case(); g = load("fast9")
+    assert gc.crc(im.raw) == g["in_crc"]
+    for mode in (0, 1, 2):
+        rc, sc = run_detect(orc, im, 20, mode=mode, compat=0)
+        np.testing.assert_array_equal(rc, g[f"rc{mode}"]); np.testing.assert_array_equal(sc, g[f"sc{mode}"])
+
+
+def test_oracle_lk(orc):
+    i1, i2, kps = gc.pyrlk_case(); g = load("pyrlk")
+    assert gc.crc(i1.raw, i2.raw, kps.view(np.uint8)) == g["in_crc"]
+    hp1, hp2 = pyr.host_pyramid(orc, i1, 3, 5), pyr.host_pyramid(orc, i2, 3, 5)
+    hg = pyr.host_grad_pyramid(orc, hp1[0], 3, 5, vi.F32)
+    k = kps.copy()
+    orc.orc_pyrlk_match(vi.desc_array(hp1), vi.desc_array(hg), vi.desc_array(hp2), 3, k.ctypes.data_as(V), len(k), 7, ctypes.c_float(1e-4),
+                        ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None)
+    np.testing.assert_array_equal(k.view(np.uint8), g["kps"])
+    j1, j2, pts = gc.lk_golden_case(); g = load("lucas_kanade")
+    assert np.linalg.norm(g["flow"][0] - [2, 2]) < 0.05  # tests/pyrlk.cc:48-49, asserted on the reference's own output
+    hp1, hp2 = pyr.host_pyramid(orc, j1, 2, 2), pyr.host_pyramid(orc, j2, 2, 2)
+    hg = pyr.host_grad_pyramid(orc, hp1[0], 2, 2, vi.I32)
+    flow = np.zeros((len(pts), 2), np.float32); dist = np.zeros(len(pts), np.float32)
+    orc.orc_lucas_kanade(vi.desc_array(hp1), vi.desc_array(hg), vi.desc_array(hp2), 2, pts.ctypes.data_as(V), None, len(pts), 5, 0, 50, 0,
+                         flow.ctypes.data_as(V), dist.ctypes.data_as(V))
+    np.testing.assert_array_equal(flow.view(np.uint32), g["flow"].view(np.uint32))
+    np.testing.assert_array_equal(dist.view(np.uint32), g["dist"].view(np.uint32))
+
+
+def test_oracle_sdof(orc):
+    s1, s2, sk, par = gc.sdof_case(); g = load("sdof")
+    assert gc.crc(s1.raw, s2.raw, sk) == g["in_crc"]
+    p = np.zeros((len(sk), 2), np.int32); d = np.zeros(len(sk), np.int32); v = np.zeros(len(sk), np.uint8)
+    orc.orc_semi_dense_optical_flow(P(s1.desc), P(s2.desc), sk.ctypes.data_as(V), len(sk), *par, p.ctypes.data_as(V), d.ctypes.data_as(V), v.ctypes.data_as(V))
+    np.testing.assert_array_equal(p, g["pos"]); np.testing.assert_array_equal(d, g["dist"]); np.testing.assert_array_equal(v, g["valid"])
+
+
+# ---------------- GPU: HIP path == reference golden ----------------
+@pytest.mark.gpu
+def test_gpu_matches_reference_golden(lib):
+    import torch
+    from vpp_amd import capi
+    from test_gpu_algos import gpu_detect
+    st = capi.stream_ptr()
+    src, dst = gc.box_case()
+    dd = DeviceImage.from_host(dst)
+    capi.check(lib.vpp_box_filter(P(dd.desc), P(DeviceImage.from_host(src).desc), 5, 5, st))
+    np.testing.assert_array_equal(dd.download().view(), load("box")["out"])
+    b, c, a = gc.add_case()
+    da = DeviceImage.from_host(a)
+    capi.check(lib.vpp_pixelwise_binary(0, P(da.desc), P(DeviceImage.from_host(b).desc), P(DeviceImage.from_host(c).desc), st))
+    np.testing.assert_array_equal(da.download().view(), load("add")["out"])
+    img, _ = gc.pyramid_case(); g = load("pyramid")
+    for i, l in enumerate(pyr.device_pyramid(lib, DeviceImage.from_host(img), 3, 3)):
+        np.testing.assert_array_equal(l.download().view(with_border=True), g[f"l{i}"])
+    im = gc.fast_case(); g = load("fast9")
+    dim = DeviceImage.from_host(im)
+    for mode in (0, 1, 2):
+        rc, sc = gpu_detect(lib, dim, 20, mode=mode, compat=0)
+        np.testing.assert_array_equal(rc, g[f"rc{mode}"]); np.testing.assert_array_equal(sc, g[f"sc{mode}"])
+    i1, i2, kps = gc.pyrlk_case(); g = load("pyrlk")
+    dp1 = pyr.device_pyramid(lib, DeviceImage.from_host(i1), 3, 5); dp2 = pyr.device_pyramid(lib, DeviceImage.from_host(i2), 3, 5)
+    dg = pyr.device_grad_pyramid(lib, dp1[0], 3, 5, vi.F32)
+    dk = torch.from_numpy(kps.view(np.uint8).reshape(-1).copy()).cuda()
+    capi.check(lib.vpp_pyrlk_match(vi.desc_array(dp1), vi.desc_array(dg), vi.desc_array(dp2), 3, V(dk.data_ptr()), len(kps), 7, ctypes.c_float(1e-4),
+                                   ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None, st))
+    got = dk.cpu().numpy().view(pyr.KP_DTYPE); want = g["kps"].view(pyr.KP_DTYPE)
+    np.testing.assert_array_equal(got["age"], want["age"])
+    for f in ("pos_r", "pos_c", "vel_r", "vel_c"):
+        np.testing.assert_allclose(got[f], want[f], rtol=1e-4, atol=1e-4)  # north-star tolerance; observed bit-identical
+    j1, j2, pts = gc.lk_golden_case(); g = load("lucas_kanade")
+    dp1 = pyr.device_pyramid(lib, DeviceImage.from_host(j1), 2, 2); dp2 = pyr.device_pyramid(lib, DeviceImage.from_host(j2), 2, 2)
+    dg = pyr.device_grad_pyramid(lib, dp1[0], 2, 2, vi.I32)
+    dpts = torch.from_numpy(pts).cuda(); flow = torch.zeros((len(pts), 2), device="cuda"); dist = torch.zeros(len(pts), device="cuda")
+    capi.check(lib.vpp_lucas_kanade(vi.desc_array(dp1), vi.desc_array(dg), vi.desc_array(dp2), 2, V(dpts.data_ptr()), None, len(pts), 5, 0, 50, 0,
+                                    V(flow.data_ptr()), V(dist.data_ptr()), st))
+    np.testing.assert_allclose(flow.cpu().numpy(), g["flow"], rtol=1e-4, atol=1e-5)
+    s1, s2, sk, par = gc.sdof_case(); g = load("sdof")
+    dk = torch.from_numpy(sk).cuda(); n = len(sk)
+    gp = torch.zeros((n, 2), dtype=torch.int32, device="cuda"); gd = torch.zeros(n, dtype=torch.int32, device="cuda"); gv = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    capi.check(lib.vpp_semi_dense_optical_flow(P(DeviceImage.from_host(s1).desc), P(DeviceImage.from_host(s2).desc), V(dk.data_ptr()), n, *par,
+                                               V(gp.data_ptr()), V(gd.data_ptr()), V(gv.data_ptr()), st))
+    np.testing.assert_array_equal(gp.cpu().numpy(), g["pos"]); np.testing.assert_array_equal(gd.cpu().numpy(), g["dist"]); np.testing.assert_array_equal(gv.cpu().numpy(), g["valid"])

@@ -57,7 +57,8 @@ class HostImage(_ImageBase):
 
     def __init__(self, nrows, ncols, dtype=U8, channels=1, border=0, align=DEFAULT_ALIGN):
         self._setup(nrows, ncols, dtype, channels, border, align)
-        store = np.zeros(self.alloc_bytes + align, dtype=np.uint8)
+        # + 64: vpp's SIMD loops (fast.hpp:304-312) read whole 32-byte chunks past the last row's end
+        store = np.zeros(self.alloc_bytes + align + 64, dtype=np.uint8)
         shift = (-store.ctypes.data) % align
         self.raw = store[shift:shift + self.alloc_bytes]
         self._store = store
