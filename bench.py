@@ -58,7 +58,7 @@ def main():
 
     launch_mode = {"mode": "hipGraph"}
 
-    def timed(launch, steps, warmup):
+    def timed(launch, steps, warmup, graph=True):
         """EXACTLY `steps` launches between barrier+sync pairs; also HIP-event time on the launch stream.
         The K launches are captured once into a hipGraph (kernels of 8-18 us would otherwise be host-launch bound
         from Python); the timed region is the replay of that graph.  Falls back to eager launches if capture fails."""
@@ -66,7 +66,7 @@ def main():
             launch(i, st)
         torch.cuda.synchronize()
         g = None
-        if os.environ.get("VPP_BENCH_EAGER", "0") != "1":
+        if graph and os.environ.get("VPP_BENCH_EAGER", "0") != "1":
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -78,7 +78,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 sys.stderr.write(f"[bench] hipGraph capture failed ({e}); timing eager launches\n")
                 g = None
-        if g is None:
+        if g is None and graph:
             launch_mode["mode"] = "eager"
         barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -164,8 +164,10 @@ def main():
         for _ in range(iters):
             orc.orc_box_filter(P(dst_h.desc), P(src_h.desc), 5, 5)
         dt = (time.perf_counter() - t0) / iters
+        import bench_pyrlk as _bp
+        cpu_extra = _bp.cpu_baseline(orc)
         cpu = {"value": npx / dt / 1e9, "unit": "Gpixels/s", "cores": int(orc.orc_num_threads()), "kind": "port",
-               "sample": f"{iters} passes of the same 3840x2160 vuchar3 box5x5 after 1 warm-up, oracle/liboracle_omp.so (-O3 -fopenmp)"}
+               "sample": f"{iters} passes of the same 3840x2160 vuchar3 box5x5 after 1 warm-up, oracle/liboracle_omp.so (-O3 -fopenmp)", **cpu_extra}
 
     if rank == 0:
         out = {"metric": "Gpixels/s (4K box5x5 vuchar3)", "value": value, "unit": "Gpixels/s", "n_gpus": world, "steps": args.steps,

@@ -1,0 +1,120 @@
+"""pyrLK leg of bench.py (BASELINE.json configs[3]): 1920x1080, 3-level pyramids, 10 000 keypoints, 7x7 window,
+min_ev 1e-4, max_err 500, 30 iterations, delta 0.01.  Keypoints are sharded contiguously across ranks
+([g*N/G, (g+1)*N/G), pyrlk_match.hh:24 iterates independent keypoints); every rank holds both pyramids; one exchange:
+an RCCL all-gather of the 20-byte keypoint records.  Also the FAST-9 4K leg (configs[2], replicas)."""
+import ctypes
+import sys
+import time
+
+import numpy as np
+
+
+def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
+    import torch
+    import torch.distributed as dist
+    import pyr
+    from util import P, u8_image, DeviceImage, texture, translate, rects_image
+    from vpp_amd import capi, image as vi
+
+    V = ctypes.c_void_p
+    st = capi.stream_ptr()
+    NR, NC, L, B, WS, NK = 1080, 1920, 3, 3, 7, 10000
+    tex = texture(NR, NC, seed=5)
+    f1 = np.clip(np.rint(tex), 0, 255).astype(np.uint8)
+    f2 = np.clip(np.rint(translate(tex, 1.5, -2.25)), 0, 255).astype(np.uint8)
+    d1, d2 = DeviceImage.from_host(u8_image(f1), dev), DeviceImage.from_host(u8_image(f2), dev)
+    kps_h = pyr.make_keypoints(pyr.grid_keypoints(NR, NC, NK, margin=32))
+    lo, hi = rank * NK // world, (rank + 1) * NK // world
+    shard0 = torch.from_numpy(kps_h[lo:hi].view(np.uint8).reshape(-1).copy()).to(dev)
+    shard = shard0.clone()
+    n_local = hi - lo
+    gathered = torch.empty(NK * 20, dtype=torch.uint8, device=dev) if world > 1 else None
+    even = NK % world == 0
+
+    p1 = pyr.device_pyramid(lib, d1, L, B)
+    g1 = pyr.device_grad_pyramid(lib, p1[0], L, B, vi.F32)
+    p2 = pyr.device_pyramid(lib, d2, L, B)
+    dp1, dg1, dp2 = vi.desc_array(p1), vi.desc_array(g1), vi.desc_array(p2)
+    match = lib.vpp_pyrlk_match
+
+    def step_match(i, stream):
+        shard.copy_(shard0, non_blocking=True)  # restore the tracks: pyrlk_match moves them in place
+        match(dp1, dg1, dp2, L, V(shard.data_ptr()), n_local, WS, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None, stream)
+        if world > 1:
+            if even:
+                dist.all_gather_into_tensor(gathered, shard)
+            else:
+                parts = [torch.empty((((r + 1) * NK // world) - (r * NK // world)) * 20, dtype=torch.uint8, device=dev) for r in range(world)]
+                dist.all_gather(parts, shard)
+
+    wall, ev = timed(step_match, steps, warmup, graph=(world == 1))
+    res = {"workload": "pyrlk_match 1920x1080, 3 levels, 10k keypoints, 7x7, min_ev 1e-4, max_err 500, 30 it, delta 0.01",
+           "tracks_per_s": NK / (wall / steps), "ms_per_frame": wall / steps * 1e3, "keypoints_per_rank": n_local,
+           "exchange": "rccl all_gather of 20-byte keypoint records" if world > 1 else "none (1 GPU)"}
+
+    # pyramids + gradient of a frame pair (what a caller pays per new frame besides the match)
+    def step_pyr(i, stream):
+        lib.vpp_copy(P(p2[0].desc), P(d2.desc), 0, stream)
+        lib.vpp_fill_border(P(p2[0].desc), 0, None, stream)
+        for l in range(1, L):
+            lib.vpp_pyr_down(P(p2[l].desc), P(p2[l - 1].desc), stream)
+        lib.vpp_scharr(P(g1[0].desc), P(p1[0].desc), stream)
+        lib.vpp_fill_border(P(g1[0].desc), 0, None, stream)
+        for l in range(1, L):
+            lib.vpp_pyr_down(P(g1[l].desc), P(g1[l - 1].desc), stream)
+
+    pwall, _ = timed(step_pyr, steps, warmup, graph=True)
+    res["pyramids_ms_per_frame"] = pwall / steps * 1e3
+    res["tracks_per_s_incl_pyramids"] = NK / ((wall + pwall) / steps)
+
+    # FAST-9 on 4K (replicas): raw and blockwise(10); each call ends with the host read of the keypoint count
+    im = u8_image(rects_image(2160, 3840, seed=4), border=3)
+    v = im.view(with_border=True)[..., 0]
+    v[...] = np.pad(im.view()[..., 0], 3, mode="symmetric")
+    dim = DeviceImage.from_host(im, dev)
+    cap = 3000000
+    rc = torch.zeros((cap, 2), dtype=torch.int32, device=dev); sc = torch.zeros(cap, dtype=torch.int32, device=dev)
+    n = ctypes.c_int(0)
+    fast = {}
+    for name, mode in (("raw", 0), ("blockwise10", 2)):
+        for _ in range(3):
+            lib.vpp_fast9_detect(P(dim.desc), 20, None, mode, 10, 0, V(rc.data_ptr()), V(sc.data_ptr()), cap, P(n), st)
+        barrier()
+        t0 = time.perf_counter()
+        it = 20
+        for _ in range(it):
+            lib.vpp_fast9_detect(P(dim.desc), 20, None, mode, 10, 0, V(rc.data_ptr()), V(sc.data_ptr()), cap, P(n), st)
+        barrier()
+        dt = (time.perf_counter() - t0) / it
+        fast[name] = {"ms": dt * 1e3, "gpixels_per_s": 2160 * 3840 * world / dt / 1e9, "keypoints": n.value}
+    res["fast9_4k"] = fast
+    return res
+
+
+def cpu_baseline(orc):
+    """Oracle (OpenMP build) timed on the host: pyrlk_match on a 1000-keypoint sample of the same scene, and FAST-9 raw on one 4K frame."""
+    import pyr
+    from util import P, u8_image, texture, translate, rects_image
+    from vpp_amd import image as vi
+    V = ctypes.c_void_p
+    NR, NC, L, B = 1080, 1920, 3, 3
+    tex = texture(NR, NC, seed=5)
+    i1 = u8_image(np.clip(np.rint(tex), 0, 255).astype(np.uint8)); i2 = u8_image(np.clip(np.rint(translate(tex, 1.5, -2.25)), 0, 255).astype(np.uint8))
+    hp1, hp2 = pyr.host_pyramid(orc, i1, L, B), pyr.host_pyramid(orc, i2, L, B)
+    hg = pyr.host_grad_pyramid(orc, hp1[0], L, B, vi.F32)
+    kps = pyr.make_keypoints(pyr.grid_keypoints(NR, NC, 10000, margin=32))
+    k = kps.copy()
+    orc.orc_pyrlk_match(vi.desc_array(hp1), vi.desc_array(hg), vi.desc_array(hp2), L, k.ctypes.data_as(V), len(k), 7, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None)
+    t0 = time.perf_counter(); it = 3
+    for _ in range(it):
+        k = kps.copy()
+        orc.orc_pyrlk_match(vi.desc_array(hp1), vi.desc_array(hg), vi.desc_array(hp2), L, k.ctypes.data_as(V), len(k), 7, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None)
+    dt = (time.perf_counter() - t0) / it
+    out = {"pyrlk_tracks_per_s": len(kps) / dt, "pyrlk_sample": f"{it} passes over the same 10k keypoints (pyramids prebuilt)"}
+    im = u8_image(rects_image(2160, 3840, seed=4), border=3)
+    orc.orc_fill_border(P(im.desc), 0, None)
+    rc = np.zeros((3000000, 2), np.int32); n = ctypes.c_int(0)
+    t0 = time.perf_counter()
+    orc.orc_fast9_detect(P(im.desc), 20, None, 0, 10, 0, rc.ctypes.data_as(V), None, 3000000, P(n))
+    out["fast9_raw_gpixels_per_s"] = 2160 * 3840 / (time.perf_counter() - t0) / 1e9
+    return out

@@ -83,12 +83,12 @@ def test_gpu_matches_reference_golden(lib):
     from test_gpu_algos import gpu_detect
     st = capi.stream_ptr()
     src, dst = gc.box_case()
-    dd = DeviceImage.from_host(dst)
-    capi.check(lib.vpp_box_filter(P(dd.desc), P(DeviceImage.from_host(src).desc), 5, 5, st))
+    dd, ds = DeviceImage.from_host(dst), DeviceImage.from_host(src)  # keep every device buffer alive until the results are read
+    capi.check(lib.vpp_box_filter(P(dd.desc), P(ds.desc), 5, 5, st))
     np.testing.assert_array_equal(dd.download().view(), load("box")["out"])
     b, c, a = gc.add_case()
-    da = DeviceImage.from_host(a)
-    capi.check(lib.vpp_pixelwise_binary(0, P(da.desc), P(DeviceImage.from_host(b).desc), P(DeviceImage.from_host(c).desc), st))
+    da, db, dc = DeviceImage.from_host(a), DeviceImage.from_host(b), DeviceImage.from_host(c)
+    capi.check(lib.vpp_pixelwise_binary(0, P(da.desc), P(db.desc), P(dc.desc), st))
     np.testing.assert_array_equal(da.download().view(), load("add")["out"])
     img, _ = gc.pyramid_case(); g = load("pyramid")
     for i, l in enumerate(pyr.device_pyramid(lib, DeviceImage.from_host(img), 3, 3)):
@@ -118,6 +118,7 @@ def test_gpu_matches_reference_golden(lib):
     s1, s2, sk, par = gc.sdof_case(); g = load("sdof")
     dk = torch.from_numpy(sk).cuda(); n = len(sk)
     gp = torch.zeros((n, 2), dtype=torch.int32, device="cuda"); gd = torch.zeros(n, dtype=torch.int32, device="cuda"); gv = torch.zeros(n, dtype=torch.uint8, device="cuda")
-    capi.check(lib.vpp_semi_dense_optical_flow(P(DeviceImage.from_host(s1).desc), P(DeviceImage.from_host(s2).desc), V(dk.data_ptr()), n, *par,
+    ds1, ds2 = DeviceImage.from_host(s1), DeviceImage.from_host(s2)
+    capi.check(lib.vpp_semi_dense_optical_flow(P(ds1.desc), P(ds2.desc), V(dk.data_ptr()), n, *par,
                                                V(gp.data_ptr()), V(gd.data_ptr()), V(gv.data_ptr()), st))
     np.testing.assert_array_equal(gp.cpu().numpy(), g["pos"]); np.testing.assert_array_equal(gd.cpu().numpy(), g["dist"]); np.testing.assert_array_equal(gv.cpu().numpy(), g["valid"])

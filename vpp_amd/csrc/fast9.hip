@@ -7,10 +7,11 @@
 //                            Segment test per lane: saturated thresholds, 4 cardinal samples first (any 9-arc holds >= 2
 //                            of ring indices {0,4,8,12}), then 16-bit brighter/darker masks and a shift-and "9 circularly
 //                            contiguous" test.  corner = mask_byte & (0x10*B9 | 0x01*D9) != 0 (fast.hpp:120-126,312,333).
-//                            Corners are appended (wave ballot + one atomic per wave) to an unordered candidate list.
-//   2. fast9_score_kernel    one lane per candidate: fast9_score on the TRUE ring (fast.hpp:52-74) -> dense u16 map F
-//                            F(p) = score + 1 (0 = not a corner).  Mirrors the reference's scores_img scatter (:688-694).
-//   3. count / scan / write  per image row (RAW, LOCAL_MAXIMA) or per row of bs x bs blocks (BLOCKWISE): decisions are
+//                            Corner lanes then evaluate fast9_score on the TRUE ring (fast.hpp:52-74) from the same LDS tile
+//                            and every lane writes the dense u16 map F(p) = score + 1 (0 = not a corner) — the reference's
+//                            scores_img (:685-694) without the intermediate keypoint list (a single global append counter
+//                            saturates at ~90 atomics/us, which measured 790 us on a 4K frame; the dense write costs 16.6 MB).
+//   2. count / scan / write  per image row (RAW, LOCAL_MAXIMA) or per row of bs x bs blocks (BLOCKWISE): decisions are
 //                            recomputed in the write pass so the output is in the serial reference order (row-major
 //                            pixels / row-major blocks), which the OpenMP reference itself does not guarantee.
 // VALU-bound (the ring test is ~100 lane-ops per pixel against 1 B/px of HBM traffic); see DESIGN.md.
@@ -60,8 +61,7 @@ __device__ __forceinline__ bool nine_contiguous(uint32_t m16) {
 }
 
 template <bool REF>
-__global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int has_mask, int th, uint32_t* __restrict__ cand,
-                                                           uint32_t* __restrict__ cand_count) {
+__global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int has_mask, int th, DImg F) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[LROWS * LP];
   const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
   const int lo = -A.border, hi = A.nc + A.border;
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = c0 + lane;
+  if (c >= A.nc) return;
   const int thc = min(max(th, 0), 255);
 #pragma unroll 1
   for (int j = 0; j < TH / 4; j++) {
@@ -83,33 +84,35 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
     const int r = r0 + lr;
     if (r >= A.nr) break;
     const uint8_t* p = tile + (lr + HALO) * LP + lane + 4;
-    bool corner = false;
-    if (c < A.nc) {
-      const int v = p[0];
-      const int vhi = min(v + thc, 255), vlo = max(v - thc, 0);  // u_adds / u_subs (fast.hpp:322-324)
-      int x[16];
+    uint32_t f = 0;
+    const int v = p[0];
+    const int vhi = min(v + thc, 255), vlo = max(v - thc, 0);  // u_adds / u_subs (fast.hpp:322-324)
+    int x[16];
 #pragma unroll
-      for (int i = 0; i < 16; i += 4) x[i] = p[ring_dr<REF>(i) * LP + ring_dc(i)];
-      const int nb = (x[0] > vhi) + (x[4] > vhi) + (x[8] > vhi) + (x[12] > vhi);
-      const int nd = (x[0] < vlo) + (x[4] < vlo) + (x[8] < vlo) + (x[12] < vlo);
-      if (nb >= 2 || nd >= 2) {
+    for (int i = 0; i < 16; i += 4) x[i] = p[ring_dr<REF>(i) * LP + ring_dc(i)];
+    const int nb = (x[0] > vhi) + (x[4] > vhi) + (x[8] > vhi) + (x[12] > vhi);
+    const int nd = (x[0] < vlo) + (x[4] < vlo) + (x[8] < vlo) + (x[12] < vlo);
+    if (nb >= 2 || nd >= 2) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) if (i & 3) x[i] = p[ring_dr<REF>(i) * LP + ring_dc(i)];
-        uint32_t mb = 0, md = 0;
+      for (int i = 0; i < 16; i++) if (i & 3) x[i] = p[ring_dr<REF>(i) * LP + ring_dc(i)];
+      uint32_t mb = 0, md = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) { mb |= (uint32_t)(x[i] > vhi) << i; md |= (uint32_t)(x[i] < vlo) << i; }
-        int planes = (nine_contiguous(mb) ? 0x10 : 0) | (nine_contiguous(md) ? 0x01 : 0);
-        if (has_mask && planes) planes &= M.row<uint8_t>(r)[c];
-        corner = planes != 0;
+      for (int i = 0; i < 16; i++) { mb |= (uint32_t)(x[i] > vhi) << i; md |= (uint32_t)(x[i] < vlo) << i; }
+      int planes = (nine_contiguous(mb) ? 0x10 : 0) | (nine_contiguous(md) ? 0x01 : 0);
+      if (has_mask && planes) planes &= M.row<uint8_t>(r)[c];
+      if (planes) {  // fast9_score on the true ring (fast.hpp:38-77); only a4/a12 differ from the REF samples
+        if (REF) { x[4] = p[3]; x[12] = p[-3]; }
+        int sum_inf = 0, sum_sup = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int diff = v - x[i];
+          if (diff < -th) sum_inf -= diff;
+          else if (diff > th) sum_sup += diff;
+        }
+        f = (uint32_t)max(sum_sup, sum_inf) + 1u;
       }
     }
-    const unsigned long long bal = __ballot(corner);
-    if (bal) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(cand_count, (uint32_t)__popcll(bal));
-      base = __shfl(base, 0);
-      if (corner) cand[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)r << 16) | (uint32_t)c;
-    }
+    F.row<uint16_t>(r)[c] = (uint16_t)f;
   }
 }
 
@@ -124,16 +127,6 @@ __device__ __forceinline__ int fast9_score_px(const DImg& A, int r, int c, int t
     else if (diff > th) sum_sup += diff;
   }
   return max(sum_sup, sum_inf);
-}
-
-__global__ __launch_bounds__(256) void fast9_score_kernel(DImg A, int th, const uint32_t* __restrict__ cand,
-                                                          const uint32_t* __restrict__ cand_count, DImg F) {
-  const uint32_t n = *cand_count;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint32_t rc = cand[i];
-    const int r = rc >> 16, c = rc & 0xFFFF;
-    F.row<uint16_t>(r)[c] = (uint16_t)(fast9_score_px(A, r, c, th) + 1);
-  }
 }
 
 __global__ __launch_bounds__(256) void fast9_scores_list_kernel(DImg A, int th, const int32_t* __restrict__ rc, int n, int32_t* __restrict__ out) {
@@ -284,27 +277,27 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   }
   hipStream_t st = as_stream(stream);
   const int nr = src->nrows, nc = src->ncols;
-  // scratch layout: [counters: cand_count, total][F: u16 map with border 1][cand list][unit_count][unit_off]
+  // scratch layout: [counters: total][F: u16 map with border 1][unit_count][unit_off]
   int32_t fpitch; size_t fbytes, ffirst;
   vpp_image_layout(nr, nc, 2, 1, 16, &fpitch, &fbytes, &ffirst);
   const int nunits = mode == VPP_FAST9_BLOCKWISE ? (nr + block_size - 1) / block_size : nr;
-  const size_t off_f = 256, off_cand = off_f + align_up(fbytes, 256), off_uc = off_cand + align_up((size_t)nr * nc * 4, 256);
+  const size_t off_f = 256, off_uc = off_f + align_up(fbytes, 256);
   const size_t off_uo = off_uc + align_up((size_t)nunits * 4, 256), total_bytes = off_uo + align_up((size_t)nunits * 4, 256);
   int rc = g_scratch.ensure(total_bytes);
   if (rc != VPP_OK) return rc;
   uint8_t* base = (uint8_t*)g_scratch.p;
   uint32_t* counters = (uint32_t*)base;
   DImg F{base + off_f + ffirst, nr, nc, fpitch, 1, VPP_U16, 1};
-  uint32_t* cand = (uint32_t*)(base + off_cand);
   uint32_t* unit_count = (uint32_t*)(base + off_uc);
   uint32_t* unit_off = (uint32_t*)(base + off_uo);
-  VPP_HIP_TRY(hipMemsetAsync(base, 0, off_f + fbytes, st));  // counters + F (with its border) = 0
+  // zero the counters and F's 1-px border (the detect kernel writes every domain pixel): first / last row + the strips between rows
+  VPP_HIP_TRY(hipMemsetAsync(base, 0, off_f + (size_t)fpitch + ffirst, st));
+  VPP_HIP_TRY(hipMemsetAsync(base + off_f + (size_t)(nr + 1) * fpitch, 0, fpitch, st));
+  VPP_HIP_TRY(hipMemset2DAsync(base + off_f + ffirst + (size_t)nc * 2, fpitch, 0, (size_t)fpitch - (size_t)nc * 2, (size_t)nr, st));
   DImg A = dimg(src), M = mask ? dimg(mask) : A;
   dim3 grid((nc + TW - 1) / TW, (nr + TH - 1) / TH);
-  if (compat == VPP_FAST9_REFERENCE) fast9_detect_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, cand, counters);
-  else fast9_detect_kernel<false><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, cand, counters);
-  VPP_LAUNCH_CHECK();
-  fast9_score_kernel<<<1024, 256, 0, st>>>(A, th, cand, counters, F);
+  if (compat == VPP_FAST9_REFERENCE) fast9_detect_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F);
+  else fast9_detect_kernel<false><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F);
   VPP_LAUNCH_CHECK();
   if (mode == VPP_FAST9_BLOCKWISE) {
     const int nbc = (nc + block_size - 1) / block_size, K = (nbc + 255) / 256;
