@@ -1,0 +1,210 @@
+// The vpp-shaped C++ surface in a -DVPP_AMD_DEVICE build: tagged functors and algorithm front-ends run on the MI355X
+// through the C ABI and are checked against the CPU oracle (test infrastructure) on the same inputs.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include <vpp/vpp.hh>
+#include <vpp/algorithms/fast_detector/fast.hh>
+#include <vpp/algorithms/filters/scharr.hh>
+#include <vpp/algorithms/lucas_kanade.hh>
+#include <vpp/algorithms/optical_flow.hh>
+#include <vpp/algorithms/pyrlk/pyrlk_match.hh>
+#include <vpp/algorithms/video_extruder.hh>
+
+#include "../../oracle/oracle.h"
+
+using namespace vpp;
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
+
+template <class V> vpp_image_desc host_desc(const image2d<V>& i) {
+  typedef pixel_traits<V> PT;
+  return vpp_image_desc{(void*)&i(0, 0), i.nrows(), i.ncols(), i.pitch(), i.border(), device::dtype_of<typename PT::component>::value, PT::channels};
+}
+
+static std::mt19937 rng(5);
+static image2d<unsigned char> texture(int nr, int nc, float dr, float dc) {  // smooth random texture, optionally translated
+  static std::vector<float> base;
+  const int W = nc + 64, H = nr + 64;
+  if (base.empty()) {
+    std::vector<float> n(size_t(W) * H);
+    for (auto& x : n) x = float(rng() & 0xFFFF) / 65535.f;
+    base.assign(n.size(), 0.f);
+    for (int pass = 0; pass < 3; pass++) {  // three box blurs ~ gaussian
+      for (int r = 2; r < H - 2; r++) for (int c = 2; c < W - 2; c++) { float s = 0; for (int i = -2; i <= 2; i++) for (int j = -2; j <= 2; j++) s += n[size_t(r + i) * W + c + j]; base[size_t(r) * W + c] = s / 25; }
+      n = base;
+    }
+    float lo = 1e9, hi = -1e9; for (int r = 8; r < H - 8; r++) for (int c = 8; c < W - 8; c++) { lo = std::min(lo, base[size_t(r) * W + c]); hi = std::max(hi, base[size_t(r) * W + c]); }
+    for (auto& x : base) x = (x - lo) / (hi - lo) * 255.f;
+  }
+  image2d<unsigned char> img(nr, nc, _border = 3);
+  for (int r = 0; r < nr; r++) for (int c = 0; c < nc; c++) {
+    const float y = r + 32 - dr, x = c + 32 - dc; const int y0 = int(y), x0 = int(x); const float a = y - y0, b = x - x0;
+    const float v = (1 - a) * (1 - b) * base[size_t(y0) * W + x0] + a * (1 - b) * base[size_t(y0 + 1) * W + x0] + (1 - a) * b * base[size_t(y0) * W + x0 + 1] + a * b * base[size_t(y0 + 1) * W + x0 + 1];
+    img(r, c) = (unsigned char)std::min(255.f, std::max(0.f, std::round(v)));
+  }
+  return img;
+}
+
+static void test_pixel_wise_functors() {
+  image2d<int> A(1080, 1920), B(1080, 1920), C(1080, 1920);                  // BASELINE configs[0] shape
+  for (auto p : B.domain()) { B(p) = int(rng() >> 2); C(p) = int(rng() >> 2); }
+  pixel_wise(A, B, C) | ops::add();                                          // -> vpp_pixelwise_binary on the GPU
+  for (auto p : A.domain()) CHECK(A(p) == B(p) + C(p));                      // benchmarks/image_add.cc:21-28
+  pixel_wise(A, B, C) | ops::absdiff();
+  for (int r = 0; r < 1080; r += 7) for (int c = 0; c < 1920; c += 5) CHECK(A(r, c) == std::abs(B(r, c) - C(r, c)));
+
+  image2d<vuchar3> S(270, 480, _border = 2, _aligned = 16), D(270, 480, _aligned = 16), W(270, 480, _aligned = 16), D2(270, 480, _aligned = 16);
+  for (auto p : S.domain()) S(p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
+  fill_border_mirror(S);                                                     // device
+  pixel_wise(D, relative_access(S)) | ops::box_mean<5, 5>();                 // device, LDS-tiled kernel
+  pixel_wise(D2, box_nbh2d<vuchar3, 5, 5>(S)) | ops::box_mean<5, 5>();       // legacy spelling, same kernel
+  const vpp_image_desc ds = host_desc(S), dw = host_desc(W);
+  CHECK(orc_box_filter(&dw, &ds, 5, 5) == 0);
+  for (auto p : D.domain()) CHECK(D(p) == W(p) && D2(p) == W(p));
+  // the same functor evaluated by the host engine on an opaque lambda gives the same pixels
+  image2d<vuchar3> H(270, 480);
+  pixel_wise(H, relative_access(S)) | [](vuchar3& o, auto n) { ops::box_mean<5, 5>()(o, n); };
+  for (auto p : D.domain()) CHECK(H(p) == D(p));
+}
+
+static void test_fast9() {
+  image2d<unsigned char> img = texture(240, 320, 0, 0);
+  for (int k = 0; k < 60; k++) { int r = rng() % 200, c = rng() % 280, v = rng() & 255; for (int i = 0; i < 20; i++) for (int j = 0; j < 24; j++) img(r + i, c + j) = (unsigned char)v; }
+  fill_border_mirror(img);
+  const vpp_image_desc d = host_desc(img);
+  for (int mode = 0; mode < 3; mode++) {
+    std::vector<int> scores;
+    std::vector<vint2> kps = mode == 0 ? fast9(img, 20, _scores = &scores) : mode == 1 ? fast9(img, 20, _local_maxima, _scores = &scores) : fast9(img, 20, _blockwise, _block_size = 10, _scores = &scores);
+    std::vector<int32_t> rc(400000), sc(200000); int n = 0;
+    CHECK(orc_fast9_detect(&d, 20, nullptr, mode, 10, VPP_FAST9_REFERENCE, rc.data(), sc.data(), 200000, &n) == 0);
+    CHECK(n > 0 && int(kps.size()) == n);
+    for (int i = 0; i < n; i++) CHECK(kps[i][0] == rc[2 * i] && kps[i][1] == rc[2 * i + 1] && scores[i] == sc[i]);
+  }
+  CHECK(fast9_score(img, 20, vint2(100, 100)) >= 0);
+  image2d<unsigned char> small(20, 20, _border = 2);
+  bool thrown = false;
+  try { fast9(small, 20); } catch (const std::runtime_error& e) { thrown = std::string(e.what()) == "Image need a border of 3px at least for the FAST detector"; }
+  CHECK(thrown);                                                             // fast.hpp:937-938
+}
+
+static void test_pyrlk() {
+  const int nr = 240, nc = 320, L = 3;
+  image2d<unsigned char> f1 = texture(nr, nc, 0, 0), f2 = texture(nr, nc, 1.5f, -2.25f);
+  pyramid2d<unsigned char> pyr1(f1, L, 2, _border = 5), pyr2(f2, L, 2, _border = 5);   // benchmarks/pyrlk_opencv_comparison.cc:49-60
+  pyramid2d<vfloat2> grad(f1.domain(), L, 2, _border = 5);
+  scharr(pyr1[0], grad[0]);
+  grad.propagate_level0();
+  {  // the device-built pyramids equal the oracle's, level by level, borders included
+    int r_ = nr, c_ = nc;
+    std::vector<image2d<unsigned char>> o1; std::vector<image2d<vfloat2>> og;
+    for (int l = 0; l < L; l++) { o1.emplace_back(r_, c_, _border = 5); og.emplace_back(r_, c_, _border = 5); r_ = 1 + r_ / 2; c_ = 1 + c_ / 2; }
+    for (int r = 0; r < nr; r++) for (int c = 0; c < nc; c++) o1[0](r, c) = f1(r, c);
+    {  // and the next-frame pyramid
+      std::vector<image2d<unsigned char>> o2; int r2 = nr, c2 = nc;
+      for (int l = 0; l < L; l++) { o2.emplace_back(r2, c2, _border = 5); r2 = 1 + r2 / 2; c2 = 1 + c2 / 2; }
+      for (int r = 0; r < nr; r++) for (int c = 0; c < nc; c++) o2[0](r, c) = f2(r, c);
+      std::vector<vpp_image_desc> O2; for (int l = 0; l < L; l++) O2.push_back(host_desc(o2[l]));
+      CHECK(orc_fill_border(&O2[0], 0, nullptr) == 0);
+      for (int l = 1; l < L; l++) CHECK(orc_pyr_down(&O2[l], &O2[l - 1]) == 0);
+      for (int l = 0; l < L; l++) for (auto p : o2[l].domain_with_border())
+        if (!(pyr2[l](p) == o2[l](p))) { std::fprintf(stderr, "pyr2 level %d differs at (%d,%d): %d vs %d\n", l, p[0], p[1], int(pyr2[l](p)), int(o2[l](p))); std::exit(1); }
+    }
+    std::vector<vpp_image_desc> OP, OG;
+    for (int l = 0; l < L; l++) { OP.push_back(host_desc(o1[l])); OG.push_back(host_desc(og[l])); }
+    CHECK(orc_fill_border(&OP[0], 0, nullptr) == 0 && orc_scharr(&OG[0], &OP[0]) == 0 && orc_fill_border(&OG[0], 0, nullptr) == 0);
+    for (int l = 1; l < L; l++) CHECK(orc_pyr_down(&OP[l], &OP[l - 1]) == 0 && orc_pyr_down(&OG[l], &OG[l - 1]) == 0);
+    for (int l = 0; l < L; l++)
+      for (auto p : o1[l].domain_with_border()) {
+        if (!(pyr1[l](p) == o1[l](p))) { std::fprintf(stderr, "pyr1 level %d differs at (%d,%d): %d vs %d\n", l, p[0], p[1], int(pyr1[l](p)), int(o1[l](p))); std::exit(1); }
+        if (!(grad[l](p) == og[l](p))) { std::fprintf(stderr, "grad level %d differs at (%d,%d): (%g,%g) vs (%g,%g)\n", l, p[0], p[1], grad[l](p)[0], grad[l](p)[1], og[l](p)[0], og[l](p)[1]); std::exit(1); }
+      }
+  }
+  pyrlk_keypoint_container kc(f1.domain());
+  for (int r = 30; r < nr - 30; r += 11) for (int c = 30; c < nc - 30; c += 13) kc.add(vfloat2(r + 0.25f, c + 0.5f));
+  std::vector<vpp_keypoint_f32> want(kc.size());
+  for (int i = 0; i < kc.size(); i++) want[i] = vpp_keypoint_f32{kc[i].position[0], kc[i].position[1], 0, 0, 1};
+  // oracle on pyramids downloaded from the device (host accessors trigger the download)
+  std::vector<vpp_image_desc> P, G, N;
+  for (int l = 0; l < L; l++) { P.push_back(host_desc(pyr1[l])); G.push_back(host_desc(grad[l])); N.push_back(host_desc(pyr2[l])); }
+  CHECK(orc_pyrlk_match(P.data(), G.data(), N.data(), L, want.data(), int(want.size()), 7, 1e-4f, 500.f, 30, 0.01f, 0, nullptr) == 0);
+  pyrlk_match(pyr1, grad, pyr2, kc, lk_match_point_square_win<7>(), 1e-4f, 500.f, 30, 0.01f);
+  int alive = 0;
+  for (int i = 0; i < kc.size(); i++) {
+    CHECK(kc[i].age == want[i].age);
+    if (!kc[i].alive()) continue;
+    alive++;
+    CHECK(std::fabs(kc[i].position[0] - want[i].pos_r) <= 1e-4f * std::fabs(want[i].pos_r) && std::fabs(kc[i].position[1] - want[i].pos_c) <= 1e-4f * std::fabs(want[i].pos_c));
+    CHECK(kc.index2d()(cast<vint2>(kc[i].position)) >= 0);
+  }
+  CHECK(alive > kc.size() * 0.9);  // parity with the oracle is the assertion above; the scene only has to keep most tracks alive
+}
+
+static void test_lucas_kanade_golden() {  // tests/pyrlk.cc:17-50
+  image2d<unsigned char> raw[2] = {image2d<unsigned char>(100, 100), image2d<unsigned char>(100, 100)}, blur[2] = {image2d<unsigned char>(100, 100), image2d<unsigned char>(100, 100)};
+  auto gk = [](float s, float* k) { float t = 0; for (int i = 0; i < 9; i++) { k[i] = std::exp(-(i - 4) * (i - 4) / (2 * s * s)); t += k[i]; } for (int i = 0; i < 9; i++) k[i] /= t; };
+  float kx[9], ky[9]; gk(3, kx); gk(5, ky);
+  for (int f = 0; f < 2; f++) {
+    fill(raw[f], 0);
+    const int ctr = f ? 52 : 50;
+    for (int r = ctr - 2; r <= ctr + 2; r++) for (int c = ctr - 2; c <= ctr + 2; c++) raw[f](r, c) = 255;      // draw::square(_center, _width = 5, _fill = 255)
+    auto px = [&](int r, int c) { return float(raw[f](std::min(99, std::max(0, r)), std::min(99, std::max(0, c)))); };  // BORDER_REPLICATE
+    image2d<float> h(100, 100);
+    for (int r = 0; r < 100; r++) for (int c = 0; c < 100; c++) { double s = 0; for (int i = 0; i < 9; i++) s += kx[i] * px(r, c + i - 4); h(r, c) = float(s); }
+    for (int r = 0; r < 100; r++) for (int c = 0; c < 100; c++) { double s = 0; for (int i = 0; i < 9; i++) s += ky[i] * h(std::min(99, std::max(0, r + i - 4)), c); blur[f](r, c) = (unsigned char)std::lround(s); }
+  }
+  std::vector<vfloat2> keypoints; keypoints.push_back(vfloat2(50, 50));
+  int calls = 0;
+  lucas_kanade(blur[0], blur[1], _keypoints = keypoints, _niterations = 50, _winsize = 5, _min_ev = 0.001, _delta = 0.01, _nscales = 2,
+               _flow = [&](vfloat2 p, vfloat2 f, int) { CHECK(p == vfloat2(50.f, 50.f)); CHECK((f - vfloat2(2.f, 2.f)).norm() < 0.05); calls++; });
+  CHECK(calls == 1);
+}
+
+static void test_sdof_and_video_extruder() {
+  const int nr = 240, nc = 320;
+  image2d<unsigned char> f1 = texture(nr, nc, 0, 0), f2 = texture(nr, nc, 3.f, -2.f);
+  std::vector<vint2> kps;
+  for (int r = 10; r < nr - 10; r += 5) for (int c = 10; c < nc - 10; c += 5) kps.push_back(vint2(r, c));
+  std::vector<vint2> got(kps.size(), vint2(-1, -1)); std::vector<int> gd(kps.size(), -1);
+  semi_dense_optical_flow(kps, [&](int i, vint2 pos, int d) { got[i] = pos; gd[i] = d; }, f1, f2, _winsize = 9, _patchsize = 5, _propagation = 2, _nscales = 3);
+  std::vector<int32_t> wp(kps.size() * 2), wd(kps.size()); std::vector<uint8_t> wv(kps.size());
+  const vpp_image_desc d1 = host_desc(f1), d2 = host_desc(f2);
+  CHECK(orc_semi_dense_optical_flow(&d1, &d2, (const int32_t*)kps.data(), int(kps.size()), 9, 3, 0, 2, 5, wp.data(), wd.data(), wv.data()) == 0);
+  int moved = 0;
+  for (size_t i = 0; i < kps.size(); i++) {
+    if (wv[i]) { CHECK(got[i] == vint2(wp[2 * i], wp[2 * i + 1]) && gd[i] == wd[i]); moved += (got[i] - kps[i]) == vint2(3, -2); }
+    else CHECK(gd[i] == -1);
+  }
+  CHECK(moved > int(kps.size()) * 0.8);
+
+  // video_extruder over a short synthetic sequence translating by (1,2) px / frame (video_extruder.hpp:24-135)
+  video_extruder_ctx ctx = video_extruder_init(make_box2d(nr, nc));
+  image2d<unsigned char> prev = texture(nr, nc, 0, 0);
+  fill_border_mirror(prev);
+  for (int t = 1; t <= 6; t++) {
+    image2d<unsigned char> next = texture(nr, nc, 1.f * t, 2.f * t);
+    fill_border_mirror(next);
+    video_extruder_update(ctx, prev, next, _detector_th = 10, _keypoint_spacing = 10, _detector_period = 5, _nscales = 3, _winsize = 9);
+    prev = next;
+  }
+  CHECK(ctx.frame_id == 5 && ctx.keypoints.size() > 50 && ctx.trajectories.size() == size_t(ctx.keypoints.size()));
+  int good = 0, alive = 0;
+  for (int i = 0; i < ctx.keypoints.size(); i++) {
+    if (!ctx.keypoints[i].alive() || ctx.trajectories[i].size() < 3) continue;
+    alive++;
+    good += ctx.keypoints[i].velocity == vint2(1, 2);
+  }
+  CHECK(alive > 30 && good > alive * 0.8);
+}
+
+int main() {
+  CHECK(vpp_init(0) == 0);
+  test_pixel_wise_functors();
+  test_fast9();
+  test_pyrlk();
+  test_lucas_kanade_golden();
+  test_sdof_and_video_extruder();
+  std::puts("device_api_test ok");
+  return 0;
+}

@@ -1,0 +1,116 @@
+// Host-side contract of the vpp-shaped C++ surface, restating what the reference's own unit tests pin
+// (tests/pixel_wise.cc, tests/block_wise.cc, tests/border.cc, tests/imageNd.cc, tests/image2d.cc, tests/fill.cc,
+// tests/sum.cc, tests/cast.cc, tests/window.cc, tests/boxNd_iterator.cc, tests/box_nbh2d.cc).  No GPU involved:
+// opaque lambdas are evaluated on the host by design (BASELINE configs[0]).
+#include <cstdio>
+#include <cstdlib>
+#include <vpp/vpp.hh>
+
+using namespace vpp;
+
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
+
+static void test_layout_and_access() {
+  // offset formula and row table (tests/imageNd.cc:23-27, tests/image2d.cc:8-33)
+  image2d<int> img(6, 9, _border = 2);
+  CHECK(img.coords_to_offset(vint2(3, 4)) == img.pitch() * 3 + 4 * int(sizeof(int)));
+  for (int r = -2; r < 8; r++) for (int c = -2; c < 11; c++) CHECK(&img(r, c) == &img[r][c]);
+  // alignment 256 of first pixel and pitch (tests/imageNd.cc:45-50)
+  image2d<char> al(7, 13, _aligned = 256, _border = 1);
+  CHECK((reinterpret_cast<unsigned long>(&al(0, 0)) % 256) == 0 && al.pitch() % 256 == 0 && al.alignment() == 256);
+  // exact layouts (from imageNd.hpp:151-196)
+  image2d<vuchar3> box_src(2160, 3840, _border = 2, _aligned = 16);
+  CHECK(box_src.pitch() == 11552 && (char*)&box_src(0, 0) - (char*)box_src.data() == 23120);
+  image2d<unsigned char> fast_src(2160, 3840, _border = 3, _aligned = 32);
+  CHECK(fast_src.pitch() == 3904 && (char*)&fast_src(0, 0) - (char*)fast_src.data() == 11744);
+  CHECK(sizeof(vuchar3) == 3 && sizeof(vfloat2) == 8 && sizeof(vint2) == 8);
+  // shallow copies share pixels; clone does not (tests/imageNd.cc:58-71)
+  image2d<int> a(4, 4); fill(a, 1);
+  image2d<int> b = a; b(1, 1) = 7; CHECK(a(1, 1) == 7);
+  image2d<int> c = clone(a, _border = 3); c(1, 1) = 9; CHECK(a(1, 1) == 7 && c.border() == 3 && c(0, 0) == 1);
+  // sub-image (tests/imageNd.cc:74-83)
+  image2d<int> s = a | box2d(vint2(1, 1), vint2(2, 3));
+  CHECK(s.nrows() == 2 && s.ncols() == 3 && &s(0, 0) == &a(1, 1) && &s(1, 2) == &a(2, 3));
+  // external data is borrowed (README.md:102-116)
+  int raw[12] = {0};
+  image2d<int> ext(3, 4, _data = raw, _pitch = int(4 * sizeof(int)));
+  ext(2, 3) = 5; CHECK(raw[11] == 5);
+  // bilinear interpolation truncates back to the pixel type (tests/imageNd.cc:87-107)
+  image2d<vuchar1> t(2, 2, _border = 1);
+  t(0, 0)[0] = 0; t(0, 1)[0] = 10; t(1, 0)[0] = 20; t(1, 1)[0] = 30;
+  CHECK(t.linear_interpolate(vfloat2(0.5, 0.5))[0] == int((10 + 20 + 30) / 4.f));
+  // casts (tests/cast.cc:16-21)
+  vuchar1 m; m[0] = 2; CHECK(cast<vint1>(m)[0] == 2); CHECK(cast<int>(m) == 2); CHECK(cast<vfloat2>(vint2(1, 2))[1] == 2.f);
+  // box iteration in raster order (tests/boxNd_iterator.cc)
+  int k = 0; for (auto p : make_box2d(3, 4)) { CHECK(p[0] == k / 4 && p[1] == k % 4); k++; } CHECK(k == 12);
+  image3d<int> v3(2, 3, 4); v3(1, 2, 3) = 4; CHECK(v3(1, 2, 3) == 4 && v3.nslices() == 2);
+}
+
+static void test_pixel_wise() {
+  image2d<int> img(10, 12);
+  pixel_wise(img) | [](int& i) { i = 42; };                                  // tests/pixel_wise.cc:13-20
+  for (auto p : img.domain()) CHECK(img(p) == 42);
+  int cnt = 0;                                                               // raster order over a box with _no_threads (:23-28)
+  pixel_wise(img.domain())(_no_threads) | [&](vint2 p) { CHECK(p[0] * 12 + p[1] == cnt); cnt++; };
+  // the four traversal directions through in-place prefix sums with relative_access (:34-60)
+  auto run = [&](auto order, auto expect) {
+    image2d<int> a(10, 12, _border = 1);
+    fill_with_border(a, 0);
+    order(a);
+    for (auto p : a.domain()) CHECK(a(p) == expect(p));
+  };
+  run([](auto& a) { pixel_wise(relative_access(a))(_no_threads, _left_to_right) | [](auto n) { n(0, 0) = n(0, -1) + 1; }; }, [](vint2 p) { return p[1] + 1; });
+  run([](auto& a) { pixel_wise(relative_access(a))(_no_threads, _right_to_left) | [](auto n) { n(0, 0) = n(0, 1) + 1; }; }, [](vint2 p) { return 12 - p[1]; });
+  run([](auto& a) { pixel_wise(relative_access(a))(_no_threads, _top_to_bottom) | [](auto n) { n(0, 0) = n(-1, 0) + 1; }; }, [](vint2 p) { return p[0] + 1; });
+  run([](auto& a) { pixel_wise(relative_access(a))(_no_threads, _bottom_to_top) | [](auto n) { n(0, 0) = n(1, 0) + 1; }; }, [](vint2 p) { return 10 - p[0]; });
+  // a kernel that returns a value builds an image (:63-64)
+  image2d<int> A(5, 6), B(5, 6); fill(A, 3); fill(B, 4);
+  auto C = pixel_wise(A, B) | [](int& a, int& b) { return a * b; };
+  for (auto p : C.domain()) CHECK(C(p) == 12);
+  // the benchmark kernels as opaque lambdas and as tagged functors give the same pixels on the host
+  image2d<int> S(5, 6), S2(5, 6);
+  pixel_wise(S, A, B) | [](int& s, int& a, int& b) { s = a + b; };           // benchmarks/image_add.cc:53-56
+  pixel_wise(S2, A, B) | [](int& s, const int& a, const int& b) { ops::add()(s, a, b); };
+  for (auto p : S.domain()) CHECK(S(p) == 7 && S2(p) == 7);
+  // 5x5 mean through relative_access and through the legacy box_nbh2d spelling (benchmarks/box_5x5_filter.cc:163-172)
+  image2d<int> I(12, 14, _border = 2), O1(12, 14), O2(12, 14);
+  int seed = 1; for (int r = -2; r < 14; r++) for (int c = -2; c < 16; c++) { seed = seed * 1103515245 + 12345; I(r, c) = (seed >> 8) % 1000; }
+  pixel_wise(O1, relative_access(I)) | [](int& o, auto a) { int s = 0; for (int i = -2; i <= 2; i++) for (int j = -2; j <= 2; j++) s += a(i, j); o = s / 25; };
+  auto nb = box_nbh2d<int, 5, 5>(I);
+  pixel_wise(O2, nb) | [](int& o, auto& n) { int s = 0; n.for_all([&](int x) { s += x; }); o = s / 25; };
+  for (auto p : O1.domain()) CHECK(O1(p) == O2(p));
+  auto at = box_nbh2d<int, 3, 3>(I, vint2(4, 4));                            // tests/box_nbh2d.cc:9-18
+  CHECK(at.north() == I(3, 4) && at.south() == I(5, 4) && at.east() == I(4, 5) && at.west() == I(4, 3));
+}
+
+static void test_block_wise_and_fill() {
+  image2d<int> img(10, 10, _border = 1);                                     // tests/block_wise.cc:100-114
+  fill_border_with_value(img, 2);
+  fill(img, 0);
+  block_wise(vint2(3, 3), img) | [](auto si) { fill(si, 1); };
+  for (auto p : img.domain_with_border()) CHECK(img(p) == (img.has(p) ? 1 : 2));
+  std::vector<vint2> order;                                                   // block traversal order (:51-96)
+  block_wise(vint2(4, 4), img.domain())(_no_threads) | [&](box2d b) { order.push_back(b.p1()); };
+  CHECK(order.size() == 9 && order[0] == vint2(0, 0) && order[1] == vint2(0, 4) && order[3] == vint2(4, 0) && order[8] == vint2(8, 8));
+  int rows = 0; row_wise(img.domain())(_no_threads) | [&](box2d b) { CHECK(b.nrows() == 1 && b.ncols() == 10); rows++; }; CHECK(rows == 10);
+  // border fills (tests/border.cc:11-59; mirror semantics from fill.hh:48-83)
+  image2d<int> b(3, 4, _border = 2);
+  for (auto p : b.domain()) b(p) = p[0] * 10 + p[1];
+  fill_border_closest(b); CHECK(b(-2, -2) == 0 && b(-1, 2) == 2 && b(4, 5) == 23 && b(1, -1) == 10);
+  fill_border_mirror(b); CHECK(b(-1, 0) == 0 && b(-2, 0) == 10 && b(3, 1) == 21 && b(4, 1) == 11 && b(0, -2) == 1 && b(0, 5) == 2 && b(-1, -1) == 0 && b(-2, -2) == 11);
+  CHECK(sum(img) == 100);                                                     // tests/sum.cc
+  int n4 = 0; foreach(c4, [&](vint2 n) { n4 += std::abs(n[0]) + std::abs(n[1]); }); CHECK(n4 == 4);  // tests/window.cc
+  keypoint_container<keypoint<int>, int> kc(make_box2d(20, 20));
+  kc.add(keypoint<int>(vint2(3, 4))); kc.add(keypoint<int>(vint2(5, 6)));
+  CHECK(kc.has(vint2(3, 4)) && kc.index_of(*new vint2(5, 6)) == 1);
+  kc.move(0, vint2(4, 4)); CHECK(kc[0].velocity == vint2(1, 0) && kc[0].age == 2);
+  kc.remove(1); kc.compact(); CHECK(kc.size() == 1 && kc.has(vint2(4, 4)) && !kc.has(vint2(5, 6)));
+}
+
+int main() {
+  test_layout_and_access();
+  test_pixel_wise();
+  test_block_wise_and_fill();
+  std::puts("host_api_test ok");
+  return 0;
+}

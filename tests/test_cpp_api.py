@@ -1,0 +1,60 @@
+"""The vpp-shaped C++ drop-in surface (vpp_amd/include/vpp): host contract (reference unit tests restated) and, on the
+GPU box, the device build whose tagged functors / algorithm front-ends go through the C ABI."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+OUT = os.path.join(ROOT, "tests", "cpp", "_build")
+
+
+def _compile(src, exe, device):
+    os.makedirs(OUT, exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused", "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "vpp_amd", "include"), os.path.join(CPP, src), "-o", exe]
+    if device:
+        import __graft_entry__ as g
+        g.build()
+        cmd += ["-DVPP_AMD_DEVICE", "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "vpp_amd", "csrc"), "-lvpp_amd",
+                "-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "vpp_amd", "csrc"),
+                "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--allow-shlib-undefined"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_host_api_contract():
+    exe = _compile("host_api_test.cc", os.path.join(OUT, "host_api_test"), device=False)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "host_api_test ok" in out.stdout
+
+
+def test_host_api_contract_with_openmp():
+    """pixel_wise's row loop under OpenMP (the reference's benchmark build, benchmarks/CMakeLists.txt:10,18)."""
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, "host_api_test_omp")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-I" + os.path.join(ROOT, "vpp_amd", "include"), os.path.join(CPP, "host_api_test.cc"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS="4"))
+    assert out.returncode == 0, out.stderr
+
+
+def test_algorithm_headers_refuse_a_host_only_build():
+    """No CPU fallback: the algorithm front-ends do not compile without the device library."""
+    src = os.path.join(OUT, "no_device.cc")
+    os.makedirs(OUT, exist_ok=True)
+    open(src, "w").write("#include <vpp/vpp.hh>\n#include <vpp/algorithms/fast_detector/fast.hh>\nint main(){}\n")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "vpp_amd", "include"), src], capture_output=True, text=True)
+    assert r.returncode != 0 and "VPP_AMD_DEVICE" in r.stderr
+
+
+def test_device_api_links():
+    _compile("device_api_test.cc", os.path.join(OUT, "device_api_test"), device=True)
+
+
+@pytest.mark.gpu
+def test_device_api_on_gpu():
+    exe = _compile("device_api_test.cc", os.path.join(OUT, "device_api_test_gpu"), device=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "device_api_test ok" in out.stdout

@@ -1,0 +1,76 @@
+// fast.hh — FAST-9 front-ends (reference: vpp/algorithms/fast_detector/fast.hh:26-68, fast.hpp:643-707,745-799,889-955).
+// Same names, options and exception; keypoints come back in the serial reference order (row-major pixels, or row-major
+// blocks for _blockwise).  Extension options: _fast9_corrected_ring selects the true ring instead of the one
+// fast_detector9_simd samples; the default reproduces the reference.
+#pragma once
+#include <stdexcept>
+#include <vector>
+#include <vpp/algorithms/device_only.hh>
+#include <vpp/algorithms/symbols.hh>
+#include <vpp/core/image2d.hh>
+
+namespace vpp {
+namespace fast_internals {
+inline std::vector<vint2> detect(const image2d<unsigned char>& A, int th, const image2d<unsigned char>& mask, int mode, int block_size,
+                                 int compat, std::vector<int>* scores) {
+  const vpp_image_desc da = A.device_desc(false);
+  vpp_image_desc dm; const vpp_image_desc* pm = nullptr;
+  if (mask.has_data()) { dm = mask.device_desc(false); pm = &dm; }
+  int capacity = std::max(1024, (A.nrows() * A.ncols()) / 32), count = 0;
+  std::vector<vint2> kps;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    device::dbuf rc(size_t(capacity) * 8), sc(size_t(capacity) * 4);
+    const int st = vpp_fast9_detect(&da, th, pm, mode, block_size, compat, (int32_t*)rc.p, (int32_t*)sc.p, capacity, &count, device::stream());
+    if (st == VPP_ERR_CAPACITY) { capacity = count; continue; }
+    device::check(st, "vpp_fast9_detect");  // border < 3 -> std::runtime_error("Image need a border of 3px ...") like fast.hpp:937-938
+    kps.resize(count);
+    static_assert(sizeof(vint2) == 8, "vint2 must be two packed ints");
+    rc.download(kps.data(), size_t(count) * 8);
+    if (scores) { scores->resize(count); sc.download(scores->data(), size_t(count) * 4); }
+    break;
+  }
+  return kps;
+}
+}  // namespace fast_internals
+
+template <class V, class... OPTS> std::vector<vint2> fast9(const image2d<V>& A, int th, OPTS... opts_) {
+  static_assert(sizeof(V) == 1, "fast9: 8-bit single-channel images");
+  auto opts = opt::make(opts_...);
+  if (A.border() < 3) throw std::runtime_error("Image need a border of 3px at least for the FAST detector");
+  image2d<unsigned char> mask = opts.get(_mask, image2d<unsigned char>());
+  std::vector<int>* scores = opts.get(_scores, (std::vector<int>*)nullptr);
+  const int block_size = opts.get(_block_size, 10);
+  const int compat = opts.has(_fast9_corrected_ring) ? VPP_FAST9_CORRECTED : VPP_FAST9_REFERENCE;
+  const int mode = opts.has(_local_maxima) ? VPP_FAST9_LOCAL_MAXIMA : (opts.has(_blockwise) ? VPP_FAST9_BLOCKWISE : VPP_FAST9_RAW);
+  return fast_internals::detect(*(const image2d<unsigned char>*)&A, th, mask, mode, block_size, compat, scores);
+}
+
+template <class V, class KPS> void fast9_scores(const image2d<V>& A, int th, const KPS& keypoints, std::vector<int>& scores) {
+  const int n = int(keypoints.size());
+  scores.resize(n);
+  if (!n) return;
+  std::vector<vint2> pts(n);
+  for (int i = 0; i < n; i++) pts[i] = vint2(keypoints[i][0], keypoints[i][1]);
+  device::dbuf rc(size_t(n) * 8), sc(size_t(n) * 4);
+  rc.upload(pts.data(), size_t(n) * 8);
+  const vpp_image_desc da = A.device_desc(false);
+  device::check(vpp_fast9_scores(&da, th, (const int32_t*)rc.p, n, (int32_t*)sc.p, device::stream()), "vpp_fast9_scores");
+  sc.download(scores.data(), size_t(n) * 4);
+}
+template <class V> int fast9_score(const image2d<V>& A, int th, vint2 p) {
+  std::vector<vint2> k(1, p); std::vector<int> s;
+  fast9_scores(A, th, k, s);
+  return s[0];
+}
+
+// "old API" spellings (fast.hh:41-68)
+template <class V> std::vector<vint2> fast_detector9(const image2d<V>& A, int th, const image2d<unsigned char>& mask = image2d<unsigned char>(), std::vector<int>* scores = nullptr) {
+  return fast9(A, th, _mask = mask, _scores = scores);
+}
+template <class V> std::vector<vint2> fast_detector9_local_maxima(const image2d<V>& A, int th, const image2d<unsigned char>& mask = image2d<unsigned char>(), std::vector<int>* scores = nullptr) {
+  return fast9(A, th, _local_maxima, _mask = mask, _scores = scores);
+}
+template <class V> std::vector<vint2> fast_detector9_blockwise_maxima(const image2d<V>& A, int th, int block_size, const image2d<unsigned char>& mask = image2d<unsigned char>(), std::vector<int>* scores = nullptr) {
+  return fast9(A, th, _blockwise, _block_size = block_size, _mask = mask, _scores = scores);
+}
+}  // namespace vpp

@@ -1,0 +1,70 @@
+// video_extruder.hh — semi-dense keypoint tracker (reference: vpp/algorithms/video_extruder.hh:10-44,
+// video_extruder/video_extruder.hpp:24-135).  Flow, FAST scores and FAST re-detection run on the device; the keypoint
+// bookkeeping (merge, cull, trajectories) stays on the host as in the reference.
+#pragma once
+#include <vector>
+#include <vpp/algorithms/fast_detector/fast.hh>
+#include <vpp/algorithms/optical_flow.hh>
+#include <vpp/core/keypoint_container.hh>
+
+namespace vpp {
+struct video_extruder_ctx {
+  video_extruder_ctx(box2d domain) : keypoints(domain), frame_id(0) {}
+  keypoint_container<keypoint<int>, int> keypoints;
+  std::vector<keypoint_trajectory> trajectories;
+  int frame_id;
+};
+inline video_extruder_ctx video_extruder_init(box2d domain) { video_extruder_ctx res(domain); res.frame_id = -1; return res; }
+
+namespace ve_internals { struct position_view { const video_extruder_ctx* c; int size() const { return c->keypoints.size(); } vint2 operator[](int i) const { return c->keypoints[i].position; } }; }
+
+template <class... OPTS>
+void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>& frame1, const image2d<unsigned char>& frame2, OPTS... options) {
+  ctx.frame_id++;
+  auto opts = opt::make(options...);
+  const int detector_th = opts.get(_detector_th, 10), keypoint_spacing = opts.get(_keypoint_spacing, 10), detector_period = opts.get(_detector_period, 5);
+  const int max_trajectory_length = opts.get(_max_trajectory_length, 15), nscales = opts.get(_nscales, 3), winsize = opts.get(_winsize, 9);
+  const int regularisation_niters = opts.get(_propagation, 2);
+
+  ctx.keypoints.prepare_matching();  // :44-56
+  semi_dense_optical_flow(ve_internals::position_view{&ctx},
+                          [&](int i, vint2 pos, int) { if (frame1.has(pos)) ctx.keypoints.move(i, pos); else ctx.keypoints.remove(i); },
+                          frame1, frame2, _winsize = winsize, _patchsize = 5, _propagation = regularisation_niters, _nscales = nscales);
+  {  // merge particles that converged to the same cell, keep the older (:60-84)
+    image2d<int> idx(frame2.domain().nrows() / keypoint_spacing, frame2.domain().ncols() / keypoint_spacing, _border = 1);
+    fill_with_border(idx, -1);
+    for (int i = 0; i < ctx.keypoints.size(); i++) {
+      const vint2 pos = ctx.keypoints[i].position / keypoint_spacing;
+      if (idx(pos) >= 0) {
+        const auto other = ctx.keypoints[idx(pos)];
+        if (other.age < ctx.keypoints[i].age) { ctx.keypoints.remove(idx(pos)); idx(pos) = i; }
+        if (other.age > ctx.keypoints[i].age) ctx.keypoints.remove(i);
+      } else idx(pos) = i;
+    }
+  }
+  {  // drop points whose FAST score fell below 3 (:87-91); one batched device call instead of one per keypoint
+    std::vector<int> scores;
+    fast9_scores(frame2, detector_th, ve_internals::position_view{&ctx}, scores);
+    for (int i = 0; i < ctx.keypoints.size(); i++) if (scores[i] < 3) ctx.keypoints.remove(i);
+  }
+  if (!(ctx.frame_id % detector_period)) {  // re-detect away from the live keypoints (:94-119)
+    image2d<unsigned char> mask(frame2.domain().nrows(), frame2.domain().ncols(), _border = keypoint_spacing);
+    fill_with_border(mask, (unsigned char)1);
+    for (int i = 0; i < ctx.keypoints.size(); i++) {
+      const int r = ctx.keypoints[i].position[0], c = ctx.keypoints[i].position[1];
+      for (int dr = -keypoint_spacing; dr < keypoint_spacing; dr++)
+        for (int dc = -keypoint_spacing; dc < keypoint_spacing; dc++) mask[r + dr][c + dc] = 0;
+    }
+    auto kps = fast9(frame2, detector_th, _blockwise, _block_size = keypoint_spacing, _mask = mask);
+    for (auto kp : kps) ctx.keypoints.add(keypoint<int>(kp));
+    ctx.keypoints.compact();
+    ctx.keypoints.sync_attributes(ctx.trajectories, keypoint_trajectory(ctx.frame_id));
+  }
+  for (int i = 0; i < ctx.keypoints.size(); i++) {  // trajectories (:123-133)
+    if (ctx.keypoints[i].alive()) {
+      ctx.trajectories[i].move_to(ctx.keypoints[i].position.template cast<float>());
+      if (ctx.trajectories[i].size() > max_trajectory_length) ctx.trajectories[i].pop_oldest_position();
+    } else ctx.trajectories[i].die();
+  }
+}
+}  // namespace vpp

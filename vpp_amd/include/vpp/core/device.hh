@@ -1,0 +1,70 @@
+// device.hh — glue between the vpp-shaped C++ surface and the C ABI (include/vpp_amd.h) of the gfx950 engine.
+// With -DVPP_AMD_DEVICE every image owns (lazily) a mirror of its whole pitched buffer in HBM; the algorithm front-ends
+// and the tagged pixel_wise functors run there.  Without it the containers and the host expression engine still work
+// (BASELINE configs[0]: "plumbing, no GPU"), and every device-only entry point is a hard compile error — there is no CPU
+// re-implementation of the hot-path algorithms in these headers to fall back to.
+#pragma once
+#include <cstddef>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#ifdef VPP_AMD_DEVICE
+#include <vpp_amd.h>
+#endif
+
+namespace vpp {
+namespace device {
+
+#ifdef VPP_AMD_DEVICE
+inline void check(int status, const char* what) {
+  if (status == VPP_OK) return;
+  // the reference's only hot-path exception (fast.hpp:937-938) keeps its type and text
+  throw std::runtime_error(status == VPP_ERR_BORDER_TOO_SMALL ? std::string(vpp_last_error()) : std::string(what) + ": " + vpp_last_error());
+}
+inline void* stream() { return nullptr; }
+template <class T> struct dtype_of { static_assert(sizeof(T) == 0, "pixel component type not supported on the device"); };
+template <> struct dtype_of<unsigned char> { enum { value = VPP_U8 }; };
+template <> struct dtype_of<signed char> { enum { value = VPP_I8 }; };
+template <> struct dtype_of<char> { enum { value = VPP_I8 }; };
+template <> struct dtype_of<unsigned short> { enum { value = VPP_U16 }; };
+template <> struct dtype_of<short> { enum { value = VPP_I16 }; };
+template <> struct dtype_of<int> { enum { value = VPP_I32 }; };
+template <> struct dtype_of<unsigned int> { enum { value = VPP_U32 }; };
+template <> struct dtype_of<float> { enum { value = VPP_F32 }; };  // the null stream: calls are synchronous from the caller's point of view, like the reference
+#endif
+
+// One pitched host buffer and its HBM mirror.  state: 0 = host is authoritative (mirror stale or absent),
+// 1 = both valid, 2 = the mirror is newer.
+struct storage {
+  char* host = nullptr;
+  size_t bytes = 0;
+  int state = 0;
+  void* dev = nullptr;
+  ~storage() {
+#ifdef VPP_AMD_DEVICE
+    if (dev) vpp_free(dev);
+#endif
+  }
+  void to_host(bool for_write) {
+#ifdef VPP_AMD_DEVICE
+    if (state == 2) { check(vpp_memcpy_d2h(host, dev, bytes, stream()), "vpp_memcpy_d2h"); state = 1; }
+    if (for_write) state = 0;
+#else
+    (void)for_write;
+#endif
+  }
+#ifdef VPP_AMD_DEVICE
+  // pointer into the mirror corresponding to host address p; the mirror is brought up to date first
+  void* to_device(const void* p, bool will_write) {
+    if (!dev) check(vpp_malloc(bytes, &dev), "vpp_malloc");
+    if (state == 0) { check(vpp_memcpy_h2d(dev, host, bytes, stream()), "vpp_memcpy_h2d"); state = 1; }
+    if (will_write) state = 2;
+    return (char*)dev + ((const char*)p - host);
+  }
+#endif
+};
+
+}  // namespace device
+}  // namespace vpp

@@ -1,0 +1,188 @@
+// pixel_wise.hh — the expression engine: pixel_wise(ranges...)(options...) | kernel.
+// Reference: vpp/core/pixel_wise.hh:41-50, vpp/core/pixel_wise.hpp:14-217 (ranges = images, boxes, relative_access),
+// vpp/core/relative_accessor.hh:18-33; legacy box_nbh2d<V,R,C> (tests/box_nbh2d.cc:9-18, benchmarks/box_5x5_filter.cc:165-171).
+//
+// Two evaluation routes:
+//  * an opaque callable (any lambda) is applied on the host, row by row, exactly like the reference
+//    (OpenMP over rows unless _no_threads; the four traversal-order options are honoured);
+//  * a tagged functor from vpp::ops (add, sub, mul, min, max, absdiff, box_mean<R,C>) is, in a -DVPP_AMD_DEVICE build,
+//    dispatched through the C ABI to the hand-written gfx950 kernels (vpp_pixelwise_binary, vpp_box_filter).  A failing
+//    device call throws; it never silently re-runs on the host.
+#pragma once
+#include <tuple>
+#include <type_traits>
+#include <utility>
+
+#include <vpp/core/image2d.hh>
+
+namespace vpp {
+
+// ---- neighbourhood access ---------------------------------------------------------------------------------
+template <class V> struct relative_access_kernel {  // relative_accessor.hh:26-33
+  V* const* line; int col;
+  V& operator()(int dr, int dc) const { return line[dr][col + dc]; }
+  V& operator()(vint2 p) const { return line[p[0]][col + p[1]]; }
+};
+template <class V> relative_access_kernel<V> relative_accessor(const image2d<V>& img, vint2 p) {
+  return relative_access_kernel<V>{&img[p[0]], p[1]};
+}
+template <class I> struct relative_access_ {
+  I img;  // the (shallow, shared) handle itself — the reference keeps a dangling reference here
+  auto first_point_coordinates() const { return img.domain().p1(); }
+  auto last_point_coordinates() const { return img.domain().p2(); }
+};
+template <class I> relative_access_<I> relative_access(I i) { return relative_access_<I>{i}; }
+
+// legacy spelling: R x C neighbourhood of every pixel, usable as a pixel_wise range or built at a point
+template <class V, int R, int C> struct box_nbh2d {
+  image2d<V> img; V* const* line = nullptr; int col = 0;
+  explicit box_nbh2d(const image2d<V>& i) : img(i) {}
+  box_nbh2d(const image2d<V>& i, vint2 p) : img(i), line(&img[p[0]]), col(p[1]) {}
+  auto first_point_coordinates() const { return img.domain().p1(); }
+  auto last_point_coordinates() const { return img.domain().p2(); }
+  V& operator()(int dr, int dc) const { return line[dr][col + dc]; }
+  V& north() const { return (*this)(-1, 0); }
+  V& south() const { return (*this)(1, 0); }
+  V& east() const { return (*this)(0, 1); }
+  V& west() const { return (*this)(0, -1); }
+  template <class F> void for_all(F f) const {
+    for (int dr = -(R / 2); dr <= R / 2; dr++)
+      for (int dc = -(C / 2); dc <= C / 2; dc++) f((*this)(dr, dc));
+  }
+};
+
+// ---- tagged functors (device-dispatchable kernels; also plain callables on the host) ----------------------------
+namespace ops {
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_MIN = 3, OP_MAX = 4, OP_ABSDIFF = 5 };  // = vpp_binary_op
+template <int OP> struct binary {
+  template <class V> void operator()(V& a, const V& b, const V& c) const {
+    if (OP == OP_ADD) a = b + c; else if (OP == OP_SUB) a = b - c; else if (OP == OP_MUL) a = V(b * c);
+    else if (OP == OP_MIN) a = b < c ? b : c; else if (OP == OP_MAX) a = b > c ? b : c; else a = b > c ? V(b - c) : V(c - b);
+  }
+};
+typedef binary<OP_ADD> add; typedef binary<OP_SUB> sub; typedef binary<OP_MUL> mul;
+typedef binary<OP_MIN> min; typedef binary<OP_MAX> max; typedef binary<OP_ABSDIFF> absdiff;
+// out = mean of the R x C neighbourhood, per component, in the promoted type, truncating division
+// (benchmarks/box_5x5_filter2.cc:73-80, examples/box_filter.cc:23-32)
+template <int R, int C> struct box_mean {
+  template <class V, class NB> void operator()(V& out, NB nbh) const {
+    plus_promotion<V> sum = zero<plus_promotion<V>>();
+    for (int i = -(R / 2); i <= R / 2; i++)
+      for (int j = -(C / 2); j <= C / 2; j++) sum = sum + vpp::cast<plus_promotion<V>>(nbh(i, j));
+    out = vpp::cast<V>(sum / (R * C));
+  }
+};
+}  // namespace ops
+
+namespace pw {
+template <class V> struct image_row { V* row; V& operator()(int c) const { return row[c]; } };
+struct box_row { int r; vint2 operator()(int c) const { return vint2(r, c); } };
+template <class V> struct nbh_row { V* const* line; relative_access_kernel<V> operator()(int c) const { return relative_access_kernel<V>{line, c}; } };
+template <class V, int R, int C> struct box_nbh_row {
+  image2d<V> img; V* const* line;
+  box_nbh2d<V, R, C> operator()(int c) const { box_nbh2d<V, R, C> n(img); n.line = line; n.col = c; return n; }
+};
+template <class V> image_row<V> row_access(image2d<V>& img, int r) { return image_row<V>{img[r]}; }
+template <class V> image_row<const V> row_access(const image2d<V>& img, int r) { return image_row<const V>{img[r]}; }
+inline box_row row_access(const box2d&, int r) { return box_row{r}; }
+template <class V> nbh_row<V> row_access(const relative_access_<image2d<V>>& ra, int r) { return nbh_row<V>{&ra.img[r]}; }
+template <class V, int R, int C> box_nbh_row<V, R, C> row_access(const box_nbh2d<V, R, C>& n, int r) { return box_nbh_row<V, R, C>{n.img, &n.img[r]}; }
+
+// make the host copy current (and the mirror stale where the kernel may write) once, before raw row pointers are taken
+template <class V> void touch(image2d<V>& i) { i.host_write(); }
+template <class V> void touch(const image2d<V>& i) { i.host_read(); }
+inline void touch(const box2d&) {}
+template <class I> void touch(const relative_access_<I>& r) { r.img.host_write(); }
+template <class V, int R, int C> void touch(const box_nbh2d<V, R, C>& n) { n.img.host_write(); }
+
+template <class F, class... A> inline void call_lvalues(F& f, A&&... a) { f(a...); }  // kernels may take `auto&` accessors
+template <class F, class... ROWS> inline void process_row(bool right_to_left, F& f, int c0, int c1, ROWS... rows) {
+  if (!right_to_left) for (int c = c0; c <= c1; c++) call_lvalues(f, rows(c)...);
+  else for (int c = c1; c >= c0; c--) call_lvalues(f, rows(c)...);
+}
+template <class T> struct is_image2d : std::false_type {};
+template <class V> struct is_image2d<imageNd<V, 2>> : std::true_type { typedef V value_type; };
+}  // namespace pw
+
+template <class OPTS, class... R> class pixel_wise_impl {
+ public:
+  pixel_wise_impl(std::tuple<R...> t, OPTS o) : ranges_(t), options_(o) {}
+  template <class... A> auto operator()(A... o) const { auto n = opt::make(o...); return pixel_wise_impl<decltype(n), R...>(ranges_, n); }
+  template <class... B> auto operator()(opt::set<B...> n) const { return pixel_wise_impl<opt::set<B...>, R...>(ranges_, n); }
+
+  template <class F> using kernel_return_type = decltype(std::declval<F&>()(std::declval<decltype(pw::row_access(std::declval<R&>(), 0)(0))&>()...));
+
+  // opaque callable: host evaluation (pixel_wise.hpp:146-165,188-213)
+  template <class F> auto operator|(F fun) { return eval(fun, std::is_void<kernel_return_type<F>>()); }
+
+#ifdef VPP_AMD_DEVICE
+  // tagged functors: gfx950 kernels through the C ABI
+  template <int OP> void operator|(ops::binary<OP>) { device_binary(OP, std::index_sequence_for<R...>()); }
+  template <int RR, int CC> void operator|(ops::box_mean<RR, CC>) { device_box(RR, CC); }
+#endif
+
+ private:
+  template <class F> void eval(F& fun, std::true_type) { run(fun, std::index_sequence_for<R...>()); }
+  template <class F> auto eval(F& fun, std::false_type) {  // the kernel returns a pixel value: build an image (pixel_wise.hpp:196-211)
+    typedef typename std::decay<kernel_return_type<F>>::type value_type;
+    const auto p1 = std::get<0>(ranges_).first_point_coordinates();
+    const auto p2 = std::get<0>(ranges_).last_point_coordinates();
+    image2d<value_type> out(box2d(p1, p2));
+    auto all = std::tuple_cat(std::make_tuple(out), ranges_);
+    auto wrapper = [&fun](value_type& o, auto&... ps) { o = fun(ps...); };
+    pixel_wise_impl<OPTS, image2d<value_type>, R...> sub(all, options_);
+    sub.run(wrapper, std::make_index_sequence<sizeof...(R) + 1>());
+    return out;
+  }
+
+ public:
+  template <class F, std::size_t... I> void run(F& fun, std::index_sequence<I...>) {
+    const auto p1 = std::get<0>(ranges_).first_point_coordinates();
+    const auto p2 = std::get<0>(ranges_).last_point_coordinates();
+    const int r0 = p1[0], r1 = p2[0], c0 = p1[1], c1 = p2[1];
+    const bool rtl = OPTS::has(_right_to_left), btt = OPTS::has(_bottom_to_top);
+    (void)std::initializer_list<int>{(pw::touch(std::get<I>(ranges_)), 0)...};
+    if (OPTS::has(_no_threads)) {
+      if (!btt) for (int r = r0; r <= r1; r++) pw::process_row(rtl, fun, c0, c1, pw::row_access(std::get<I>(ranges_), r)...);
+      else for (int r = r1; r >= r0; r--) pw::process_row(rtl, fun, c0, c1, pw::row_access(std::get<I>(ranges_), r)...);
+    } else {
+      if (!btt) {
+#pragma omp parallel for
+        for (int r = r0; r <= r1; r++) pw::process_row(rtl, fun, c0, c1, pw::row_access(std::get<I>(ranges_), r)...);
+      } else {
+#pragma omp parallel for
+        for (int r = r1; r >= r0; r--) pw::process_row(rtl, fun, c0, c1, pw::row_access(std::get<I>(ranges_), r)...);
+      }
+    }
+  }
+
+ private:
+#ifdef VPP_AMD_DEVICE
+  template <std::size_t... I> void device_binary(int op, std::index_sequence<I...>) {
+    static_assert(sizeof...(R) == 3, "ops::binary needs pixel_wise(dst, a, b)");
+    auto& d = std::get<0>(ranges_); auto& a = std::get<1>(ranges_); auto& b = std::get<2>(ranges_);
+    const vpp_image_desc da = a.device_desc(false), db = b.device_desc(false), dd = d.device_desc(true);
+    device::check(vpp_pixelwise_binary(op, &dd, &da, &db, device::stream()), "vpp_pixelwise_binary");
+    device::check(vpp_sync(device::stream()), "vpp_sync");
+  }
+  void device_box(int rr, int cc) {
+    static_assert(sizeof...(R) == 2, "ops::box_mean needs pixel_wise(dst, relative_access(src)) or pixel_wise(dst, box_nbh2d(src))");
+    auto& d = std::get<0>(ranges_); auto& n = std::get<1>(ranges_);
+    const vpp_image_desc ds = n.img.device_desc(false), dd = d.device_desc(true);
+    device::check(vpp_box_filter(&dd, &ds, rr, cc, device::stream()), "vpp_box_filter");
+    device::check(vpp_sync(device::stream()), "vpp_sync");
+  }
+#endif
+  std::tuple<R...> ranges_;
+  OPTS options_;
+  template <class O2, class... R2> friend class pixel_wise_impl;
+};
+
+struct pixel_wise_caller {
+  template <class... T> auto operator()(T&&... t) const {
+    return pixel_wise_impl<opt::set<>, typename std::decay<T>::type...>(std::tuple<typename std::decay<T>::type...>(t...), opt::set<>());
+  }
+};
+static const pixel_wise_caller pixel_wise;
+
+}  // namespace vpp

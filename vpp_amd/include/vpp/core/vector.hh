@@ -1,0 +1,83 @@
+// vector.hh — small fixed-size vectors usable as pixel types (reference: vpp/core/vector.hh:10-109, which aliases
+// Eigen::Matrix<T,N,1>; this is a self-contained POD with the subset of that interface the vpp API exposes).
+// Layout: exactly N * sizeof(T) bytes (sizeof(vuchar3) == 3, sizeof(vfloat2) == 8) — pitches depend on it.
+#pragma once
+#include <cmath>
+#include <type_traits>
+
+namespace vpp {
+
+template <class T, unsigned N> struct vector {
+  typedef T Scalar;
+  enum { SizeAtCompileTime = N };
+  T v[N];
+
+  vector() = default;
+  template <class A, class B, unsigned M = N, class = typename std::enable_if<M == 2>::type> vector(A a, B b) { v[0] = T(a); v[1] = T(b); }
+  template <class A, class B, class C, unsigned M = N, class = typename std::enable_if<M == 3>::type> vector(A a, B b, C c) { v[0] = T(a); v[1] = T(b); v[2] = T(c); }
+  template <class A, class B, class C, class D, unsigned M = N, class = typename std::enable_if<M == 4>::type> vector(A a, B b, C c, D d) { v[0] = T(a); v[1] = T(b); v[2] = T(c); v[3] = T(d); }
+  explicit vector(const T* p) { for (unsigned i = 0; i < N; i++) v[i] = p[i]; }
+
+  static vector Zero() { vector r; for (unsigned i = 0; i < N; i++) r.v[i] = T(0); return r; }
+  static vector Ones() { vector r; for (unsigned i = 0; i < N; i++) r.v[i] = T(1); return r; }
+  static constexpr int size() { return N; }
+  T& operator[](int i) { return v[i]; }
+  const T& operator[](int i) const { return v[i]; }
+  T& operator()(int i) { return v[i]; }
+  const T& operator()(int i) const { return v[i]; }
+  template <class U> vector<U, N> cast() const { vector<U, N> r; for (unsigned i = 0; i < N; i++) r.v[i] = U(v[i]); return r; }
+  template <unsigned K> vector<T, K> segment(int start) const { vector<T, K> r; for (unsigned i = 0; i < K; i++) r.v[i] = v[start + i]; return r; }
+
+  vector operator-() const { vector r; for (unsigned i = 0; i < N; i++) r.v[i] = -v[i]; return r; }
+  vector& operator+=(const vector& o) { for (unsigned i = 0; i < N; i++) v[i] += o.v[i]; return *this; }
+  vector& operator-=(const vector& o) { for (unsigned i = 0; i < N; i++) v[i] -= o.v[i]; return *this; }
+  template <class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> vector& operator*=(S s) { for (unsigned i = 0; i < N; i++) v[i] *= T(s); return *this; }
+  template <class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> vector& operator/=(S s) { for (unsigned i = 0; i < N; i++) v[i] /= T(s); return *this; }
+  bool operator==(const vector& o) const { for (unsigned i = 0; i < N; i++) if (!(v[i] == o.v[i])) return false; return true; }
+  bool operator!=(const vector& o) const { return !(*this == o); }
+  T squaredNorm() const { T s = v[0] * v[0]; for (unsigned i = 1; i < N; i++) s += v[i] * v[i]; return s; }
+  T norm() const { return T(std::sqrt(squaredNorm())); }
+  T dot(const vector& o) const { T s = v[0] * o.v[0]; for (unsigned i = 1; i < N; i++) s += v[i] * o.v[i]; return s; }
+};
+
+template <class T, unsigned N> vector<T, N> operator+(vector<T, N> a, const vector<T, N>& b) { a += b; return a; }
+template <class T, unsigned N> vector<T, N> operator-(vector<T, N> a, const vector<T, N>& b) { a -= b; return a; }
+template <class T, unsigned N, class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> vector<T, N> operator*(vector<T, N> a, S s) { a *= s; return a; }
+template <class T, unsigned N, class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> vector<T, N> operator*(S s, vector<T, N> a) { for (unsigned i = 0; i < N; i++) a.v[i] = T(s) * a.v[i]; return a; }
+template <class T, unsigned N, class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> vector<T, N> operator/(vector<T, N> a, S s) { a /= s; return a; }
+
+#define VPP_ALIAS_DECL(T1, T2)            \
+  template <unsigned N> using v##T2 = vector<T1, N>; \
+  typedef v##T2<1> v##T2##1; typedef v##T2<2> v##T2##2; typedef v##T2<3> v##T2##3; typedef v##T2<4> v##T2##4; \
+  typedef v##T2<8> v##T2##8; typedef v##T2<16> v##T2##16;
+VPP_ALIAS_DECL(char, char) VPP_ALIAS_DECL(short, short) VPP_ALIAS_DECL(int, int) VPP_ALIAS_DECL(float, float) VPP_ALIAS_DECL(double, double)
+VPP_ALIAS_DECL(unsigned char, uchar) VPP_ALIAS_DECL(unsigned short, ushort) VPP_ALIAS_DECL(unsigned int, uint)
+#undef VPP_ALIAS_DECL
+
+// plus_promotion (vector.hh:36-50): the type of x + x, per component
+template <class T> struct plus_promotion_ { typedef decltype(T() + T()) type; };
+template <class X, unsigned N> struct plus_promotion_<vector<X, N>> { typedef vector<decltype(X() + X()), N> type; };
+template <class T> using plus_promotion = typename plus_promotion_<T>::type;
+
+template <class V> struct cast_to_float_ { typedef float ret; };
+template <class X, unsigned N> struct cast_to_float_<vector<X, N>> { typedef vector<float, N> ret; };
+template <class V> using cast_to_float = typename cast_to_float_<V>::ret;
+
+template <class V> struct zero { operator V() { return V(0); } };
+template <class X, unsigned N> struct zero<vector<X, N>> { operator vector<X, N>() { return vector<X, N>::Zero(); } };
+
+// cast<U>(v) (vector.hh:55-109): scalar<->scalar, vector<->vector of the same size, size-1 vector <-> scalar
+namespace detail {
+template <class T> struct is_vector : std::false_type {};
+template <class X, unsigned N> struct is_vector<vector<X, N>> : std::true_type {};
+}  // namespace detail
+template <class U, class V> typename std::enable_if<!detail::is_vector<U>::value && !detail::is_vector<V>::value, U>::type cast(const V& v) { return U(v); }
+template <class U, class X, unsigned N> typename std::enable_if<detail::is_vector<U>::value, U>::type cast(const vector<X, N>& v) { return v.template cast<typename U::Scalar>(); }
+template <class U, class X> typename std::enable_if<!detail::is_vector<U>::value, U>::type cast(const vector<X, 1>& v) { return U(v[0]); }
+template <class U, class V> typename std::enable_if<detail::is_vector<U>::value && !detail::is_vector<V>::value, U>::type cast(const V& v) { U r; r[0] = typename U::Scalar(v); return r; }
+
+// pixel-type traits used by the device glue: component type + channel count
+template <class V> struct pixel_traits { typedef V component; enum { channels = 1 }; };
+template <class X, unsigned N> struct pixel_traits<vector<X, N>> { typedef X component; enum { channels = N }; };
+
+}  // namespace vpp
