@@ -14,7 +14,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     import torch.distributed as dist
     import pyr
     from util import P, u8_image, DeviceImage, texture, translate, rects_image
-    from vpp_amd import capi, image as vi
+    from vpp_amd import capi, image as vi, multi_gpu as mg
 
     V = ctypes.c_void_p
     st = capi.stream_ptr()
@@ -24,12 +24,10 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     f2 = np.clip(np.rint(translate(tex, 1.5, -2.25)), 0, 255).astype(np.uint8)
     d1, d2 = DeviceImage.from_host(u8_image(f1), dev), DeviceImage.from_host(u8_image(f2), dev)
     kps_h = pyr.make_keypoints(pyr.grid_keypoints(NR, NC, NK, margin=32))
-    lo, hi = rank * NK // world, (rank + 1) * NK // world
+    lo, hi = mg.shard_bounds(NK, rank, world)
     shard0 = torch.from_numpy(kps_h[lo:hi].view(np.uint8).reshape(-1).copy()).to(dev)
     shard = shard0.clone()
     n_local = hi - lo
-    gathered = torch.empty(NK * 20, dtype=torch.uint8, device=dev) if world > 1 else None
-    even = NK % world == 0
 
     p1 = pyr.device_pyramid(lib, d1, L, B)
     g1 = pyr.device_grad_pyramid(lib, p1[0], L, B, vi.F32)
@@ -41,11 +39,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
         shard.copy_(shard0, non_blocking=True)  # restore the tracks: pyrlk_match moves them in place
         match(dp1, dg1, dp2, L, V(shard.data_ptr()), n_local, WS, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None, stream)
         if world > 1:
-            if even:
-                dist.all_gather_into_tensor(gathered, shard)
-            else:
-                parts = [torch.empty((((r + 1) * NK // world) - (r * NK // world)) * 20, dtype=torch.uint8, device=dev) for r in range(world)]
-                dist.all_gather(parts, shard)
+            mg.all_gather_records(shard, NK, rank, world)
 
     wall, ev = timed(step_match, steps, warmup, graph=(world == 1))
     res = {"workload": "pyrlk_match 1920x1080, 3 levels, 10k keypoints, 7x7, min_ev 1e-4, max_err 500, 30 it, delta 0.01",
