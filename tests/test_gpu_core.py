@@ -75,8 +75,9 @@ def test_box_filter_matches_oracle(lib, orc, dtype, ch, R, C, shape, border, ali
     want = src.like(border=0)
     assert orc.orc_box_filter(P(want.desc), P(src.desc), R, C) == 0
     dsrc = DeviceImage.from_host(src)
-    for rows in ((8, 16, 32) if (dtype == vi.U8 and R == 5 and C == 5) else (16,)):
-        lib.vpp_set_tuning(b"box.rows", rows)
+    fast = dtype == vi.U8 and R == 5 and C == 5
+    for impl, rows in (((1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (0, 8), (0, 16), (0, 32)) if fast else ((1, 2),)):
+        lib.vpp_set_tuning(b"box.impl", impl); lib.vpp_set_tuning(b"box.rows", rows)
         ddst = DeviceImage.from_host(src.like(border=0))
         capi.check(lib.vpp_box_filter(P(ddst.desc), P(dsrc.desc), R, C, capi.stream_ptr()))
         _sync(lib)
@@ -85,7 +86,7 @@ def test_box_filter_matches_oracle(lib, orc, dtype, ch, R, C, shape, border, ali
             np.testing.assert_array_equal(got.view().view(np.uint32), want.view().view(np.uint32))
         else:
             np.testing.assert_array_equal(got.view(), want.view())
-    lib.vpp_set_tuning(b"box.rows", -1)
+    lib.vpp_set_tuning(b"box.rows", -1); lib.vpp_set_tuning(b"box.impl", -1)
 
 
 def test_box_fast_equals_generic_on_device(lib):

@@ -39,11 +39,14 @@ nsets = 8
 srcs = [DeviceImage.from_host(src_h) for _ in range(nsets)]
 dsts = [DeviceImage(NR, NC, vi.U8, 3, 0, 16) for _ in range(nsets)]
 sd, dd = [s.desc for s in srcs], [d.desc for d in dsts]
-for rows, nt in ((8, 0), (16, 0), (32, 0), (8, 1), (16, 1), (32, 1)):
-    lib.vpp_set_tuning(b"box.nt", nt)
-    lib.vpp_set_tuning(b"box.rows", rows)
-    us = time_graph(lambda i, s: lib.vpp_box_filter(P(dd[i % nsets]), P(sd[i % nsets]), 5, 5, s))
-    res[f"box rows={rows} nt={nt}"] = (us, 6 * npx / us / 1e3)
+for impl, rows_list in ((1, (1, 2, 4, 8)), (0, (8, 16))):
+    lib.vpp_set_tuning(b"box.impl", impl)
+    for rows in rows_list:
+        for nt in (0, 1):
+            lib.vpp_set_tuning(b"box.nt", nt); lib.vpp_set_tuning(b"box.rows", rows)
+            us = time_graph(lambda i, s: lib.vpp_box_filter(P(dd[i % nsets]), P(sd[i % nsets]), 5, 5, s))
+            res[f"box impl={impl} rows={rows} nt={nt}"] = (us, 6 * npx / us / 1e3)
+lib.vpp_set_tuning(b"box.impl", -1)
 lib.vpp_set_tuning(b"box.rows", -1); lib.vpp_set_tuning(b"box.nt", -1)
 lib.vpp_set_tuning(b"box.force_generic", 1)
 us = time_graph(lambda i, s: lib.vpp_box_filter(P(dd[i % nsets]), P(sd[i % nsets]), 5, 5, s), 50)

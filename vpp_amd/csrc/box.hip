@@ -185,6 +185,99 @@ __global__ __launch_bounds__(256) void box5x5_u8_lds_kernel(uint8_t* __restrict_
     box5x5_u8_tile<CH, TH, NT, false>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x0, r0, lds);
 }
 
+// ---- streaming variant: no LDS, halo column sums exchanged between neighbouring lanes with DPP wave shifts ----------
+// One wave owns a strip of 64 x 16 input bytes; lanes 1..62 produce output (992 B per row), lanes 0 and 63 only feed
+// their neighbours.  Each lane keeps the 5-row column sums of ITS 16 bytes only (half the vertical work of a 32-byte
+// window) and reads the 8 halo pairs it needs from lane-1 / lane+1 (v_mov_b32_dpp wave_shr:1 / wave_shl:1).  All
+// RW+4 row loads of a wave are issued up front, so rows are consumed as they arrive and compute overlaps the stream.
+constexpr int kStripOut = 62 * 16;
+
+__device__ __forceinline__ uint32_t from_left(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, true); }   // lane i <- lane i-1
+__device__ __forceinline__ uint32_t from_right(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, true); }  // lane i <- lane i+1
+
+template <int CH, int RW, bool NT, bool GUARD, int PROBE>
+__device__ __forceinline__ void box5x5_u8_stream_body(uint8_t* __restrict__ dp, const uint8_t* __restrict__ sp, int dpitch, int spitch,
+                                                      int nrows, int row_bytes, int border_bytes, int x, int r0, bool writer) {
+  const int lo = -border_bytes, hi = row_bytes + border_bytes;
+  u32x4 raw[RW + 4];
+  const bool in_reach = x + 16 > lo && x < row_bytes + 16;
+#pragma unroll
+  for (int k = 0; k < RW + 4; k++) {
+    const int r = r0 - 2 + k;
+    raw[k] = u32x4{0, 0, 0, 0};
+    if (in_reach && r <= nrows + 1) raw[k] = ld_chunk<GUARD>(sp + (ptrdiff_t)r * spitch, x, lo, hi);
+  }
+  auto unpack = [](const u32x4& w, uint32_t* e, uint32_t* o) {
+    const uint32_t d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { e[i] = __builtin_amdgcn_perm(0u, d[i], 0x0c020c00u); o[i] = __builtin_amdgcn_perm(0u, d[i], 0x0c030c01u); }
+  };
+  uint32_t E[4] = {0, 0, 0, 0}, O[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t e[4], o[4];
+    unpack(raw[k], e, o);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { E[i] += e[i]; O[i] += o[i]; }
+  }
+  const bool full_store = x + 16 <= row_bytes;
+#pragma unroll
+  for (int j = 0; j < RW; j++) {
+    const int r = r0 + j;
+    if (r >= nrows) break;
+    {
+      uint32_t e[4], o[4];
+      unpack(raw[j + 4], e, o);
+#pragma unroll
+      for (int i = 0; i < 4; i++) { E[i] += e[i]; O[i] += o[i]; }
+    }
+    // 32-byte window of column sums: [left lane's bytes 8..15 | own 16 | right lane's bytes 0..7]
+    const uint32_t WE[8] = {from_left(E[2]), from_left(E[3]), E[0], E[1], E[2], E[3], from_right(E[0]), from_right(E[1])};
+    const uint32_t WO[8] = {from_left(O[2]), from_left(O[3]), O[0], O[1], O[2], O[3], from_right(O[0]), from_right(O[1])};
+    u32x4 res;
+    res.x = out_dword<0, CH>(WE, WO); res.y = out_dword<1, CH>(WE, WO); res.z = out_dword<2, CH>(WE, WO); res.w = out_dword<3, CH>(WE, WO);
+    if (PROBE == 1) res = raw[j + 2];  // measurement probe (tools/probe_box.py): same loads / stores, no arithmetic
+    if (writer) {
+      uint8_t* drow = dp + (ptrdiff_t)r * dpitch + x;
+      if (full_store) {
+        if (NT) __builtin_nontemporal_store(res, (u32x4*)drow); else *(u32x4*)drow = res;
+      } else {
+        const int n = row_bytes - x;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const uint32_t d = k < 4 ? res.x : k < 8 ? res.y : k < 12 ? res.z : res.w;
+          if (k < n) drow[k] = (uint8_t)(d >> (8 * (k & 3)));
+        }
+      }
+    }
+    if (j + 1 < RW) {
+      uint32_t e[4], o[4];
+      unpack(raw[j], e, o);  // the row leaving the window
+#pragma unroll
+      for (int i = 0; i < 4; i++) { E[i] -= e[i]; O[i] -= o[i]; }
+    }
+  }
+}
+
+template <int CH, int RW, bool NT, int PROBE>
+__global__ __launch_bounds__(256, (RW <= 2 ? 8 : RW <= 4 ? 6 : 4)) void box5x5_u8_stream_kernel(uint8_t* __restrict__ dp, const uint8_t* __restrict__ sp, int dpitch,
+                                                               int spitch, int nrows, int row_bytes, int border_bytes, int nstrips,
+                                                               int nblk_y, int guard_ends) {
+  static_assert(CH >= 1 && CH <= 4, "window holds 2*CH <= 8 halo bytes");
+  const unsigned nb = (unsigned)nstrips * (unsigned)nblk_y;
+  const unsigned lb = xcd_remap(blockIdx.x, nb);  // consecutive logical blocks = vertically adjacent row blocks of one strip
+  const int s = lb / nblk_y, by = lb - s * nblk_y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int x = s * kStripOut - 16 + lane * 16;
+  const int r0 = (by * 4 + wv) * RW;
+  if (r0 >= nrows) return;
+  const bool writer = lane >= 1 && lane <= 62 && x < row_bytes;
+  if (guard_ends && (r0 == 0 || r0 + RW >= nrows))
+    box5x5_u8_stream_body<CH, RW, NT, true, PROBE>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x, r0, writer);
+  else
+    box5x5_u8_stream_body<CH, RW, NT, false, PROBE>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x, r0, writer);
+}
+
 // ---- generic path ----------------------------------------------------------------------------------------
 // Tile of TW x TH output components; LDS holds (TH + R - 1) x (TW + (C-1)*ch) components in the promoted type.
 template <class T, class S, int TW, int TH>
@@ -229,24 +322,49 @@ int launch_generic(const vpp_image_desc* dst, const vpp_image_desc* src, int R, 
 
 template <int CH> int launch_fast(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
   const int row_bytes = dst->ncols * CH;
-  const int th = tuning("box.rows", 8);
+  const int th = tuning("box.rows", 2);
   const int nt = tuning("box.nt", 1);
-  const int nblk_x = (row_bytes + kTileW - 1) / kTileW;
-  auto go = [&](auto RW, auto NTc) {
-    constexpr int TH = decltype(RW)::value; constexpr bool NT = decltype(NTc)::value;
-    const int nblk_y = (dst->nrows + TH - 1) / TH;
-    box5x5_u8_lds_kernel<CH, TH, NT><<<nblk_x * nblk_y, 256, 0, st>>>((uint8_t*)dst->first_pixel, (const uint8_t*)src->first_pixel, dst->pitch,
-                                                                      src->pitch, dst->nrows, row_bytes, src->border * CH, nblk_x, nblk_y,
-                                                                      src->border == 2 ? 1 : 0);
-  };
-  auto pick = [&](auto NTc) {
-    switch (th) {
-      case 8: go(std::integral_constant<int, 8>(), NTc); break;
-      case 32: go(std::integral_constant<int, 32>(), NTc); break;
-      default: go(std::integral_constant<int, 16>(), NTc); break;
-    }
-  };
-  if (nt) pick(std::true_type()); else pick(std::false_type());
+  const int impl = tuning("box.impl", 1);  // 1 = streaming DPP kernel, 0 = LDS-staged tile kernel
+  uint8_t* dp = (uint8_t*)dst->first_pixel; const uint8_t* sp = (const uint8_t*)src->first_pixel;
+  const int guard = src->border == 2 ? 1 : 0;
+  if (impl == 1) {
+    const int nstrips = (row_bytes + kStripOut - 1) / kStripOut;
+    auto go = [&](auto RWc, auto NTc) {
+      constexpr int RW = decltype(RWc)::value; constexpr bool NT = decltype(NTc)::value;
+      const int nblk_y = (dst->nrows + 4 * RW - 1) / (4 * RW);
+      if (CH == 3 && tuning("box.probe", 0))  // data-movement probe, never used by the product path
+        box5x5_u8_stream_kernel<CH, RW, NT, 1><<<nstrips * nblk_y, 256, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
+      else
+        box5x5_u8_stream_kernel<CH, RW, NT, 0><<<nstrips * nblk_y, 256, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
+    };
+    auto pick = [&](auto NTc) {
+      switch (th) {
+        case 1: go(std::integral_constant<int, 1>(), NTc); break;
+        case 2: go(std::integral_constant<int, 2>(), NTc); break;
+        case 8: go(std::integral_constant<int, 8>(), NTc); break;
+        case 16: go(std::integral_constant<int, 16>(), NTc); break;
+        case 4: go(std::integral_constant<int, 4>(), NTc); break;
+        default: go(std::integral_constant<int, 2>(), NTc); break;
+      }
+    };
+    if (nt) pick(std::true_type()); else pick(std::false_type());
+  } else {
+    const int nblk_x = (row_bytes + kTileW - 1) / kTileW;
+    auto go = [&](auto RW, auto NTc) {
+      constexpr int TH = decltype(RW)::value; constexpr bool NT = decltype(NTc)::value;
+      const int nblk_y = (dst->nrows + TH - 1) / TH;
+      box5x5_u8_lds_kernel<CH, TH, NT><<<nblk_x * nblk_y, 256, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nblk_x,
+                                                                        nblk_y, guard);
+    };
+    auto pick = [&](auto NTc) {
+      switch (th) {
+        case 16: go(std::integral_constant<int, 16>(), NTc); break;
+        case 32: go(std::integral_constant<int, 32>(), NTc); break;
+        default: go(std::integral_constant<int, 8>(), NTc); break;
+      }
+    };
+    if (nt) pick(std::true_type()); else pick(std::false_type());
+  }
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }
