@@ -188,11 +188,18 @@ def _run_pyrlk_both(lib, orc, f1, f2, kps, L=3, B=5, ws=7, min_ev=1e-4, max_err=
     return got, want, dd.cpu().numpy(), wd
 
 
+@pytest.mark.parametrize("lpk", [1, 8, 16])
 @pytest.mark.parametrize("ws", [5, 7, 9])
-def test_pyrlk_match_matches_oracle(lib, orc, ws):
+def test_pyrlk_match_matches_oracle(lib, orc, ws, lpk):
     f1, f2, kps = lk_scene(240, 320, 500)
     kps["age"][::17] = 0  # dead keypoints are skipped (pyrlk_match.hh:27)
-    got, want, gd, wd = _run_pyrlk_both(lib, orc, f1, f2, kps, ws=ws)
+    kps["pos_r"][5], kps["pos_c"][5] = 1.5, 2.25      # windows that leave the image: partially valid offsets (lk.hh:62)
+    kps["pos_r"][6], kps["pos_c"][6] = 238.2, 317.9
+    lib.vpp_set_tuning(b"pyrlk.lpk", lpk)
+    try:
+        got, want, gd, wd = _run_pyrlk_both(lib, orc, f1, f2, kps, ws=ws)
+    finally:
+        lib.vpp_set_tuning(b"pyrlk.lpk", -1)
     np.testing.assert_array_equal(got["age"], want["age"])
     alive = want["age"] > 0
     assert alive.sum() > 300

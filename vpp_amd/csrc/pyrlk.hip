@@ -10,9 +10,13 @@
 // -fhip-fp32-correctly-rounded-divide-sqrt), so displacements are bit-identical to the serial oracle except for the
 // min-eigenvalue gate (closed form instead of Eigen's EigenSolver; only a threshold compare).
 //
-// Mapping: one lane per keypoint, all pyramid levels in one launch (keypoints are independent, pyrlk_match.hh:24).
-// The window cache gs[]/as[] of lk.hh:90-112 lives in registers (WS <= 7) or scratch.  Not bandwidth bound: ~1 KB
-// touched per keypoint-level, L2-resident; the metric is tracks/s.
+// Mapping: LPK lanes per keypoint (1, 8 or 16, chosen from the keypoint count), all pyramid levels in one launch
+// (keypoints are independent, pyrlk_match.hh:24).  With LPK > 1 each lane owns every LPK-th window offset: it does the
+// bilinear sampling for its offsets and stages the per-offset terms in LDS; every lane of the group then accumulates
+// ALL terms in the reference's row-major order, so each sum is the same left-to-right float chain as the serial code —
+// bit-identical results at ~1/LPK of the per-keypoint latency (10 k keypoints are only 157 waves at LPK = 1).
+// The window cache gs[]/as[] of lk.hh:90-112 lives in registers (or scratch for large windows at LPK = 1).
+// Not bandwidth bound: ~1 KB touched per keypoint-level, L2-resident; the metric is tracks/s.
 #include "common.hpp"
 #include <cfloat>
 using namespace vpp_amd;
@@ -140,6 +144,189 @@ __device__ Match lk_match(float p0, float p1, float tr0, float tr1, const DImg& 
   return Match{v0 - p0, v1 - p1, err / (cpt)};                        // lucas_kanade.hpp:128
 }
 
+// ---- LPK lanes per keypoint --------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in program order; this keeps the compiler from moving them across the hand-off
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int WS, class GT, bool PYRLK, int LPK>
+__device__ Match lk_match_group(  // WS*WS <= 64
+    float p0, float p1, float tr0, float tr1, const DImg& A, const DImg& B, const DImg& Ag, float min_ev_th,
+                                int max_it, float delta, float* lds, int gl) {
+  constexpr int hws = WS / 2, N = WS * WS, PPL = (N + LPK - 1) / LPK;
+  const bool a_safe = window_inside(A, p0, p1, hws);
+  float gs0[PPL], gs1[PPL];
+  int as[PPL];
+  unsigned long long mine = 0;  // validity bits of this lane's offsets
+#pragma unroll
+  for (int k = 0; k < PPL; k++) {
+    const int i = gl + k * LPK;
+    gs0[k] = 0.f; gs1[k] = 0.f; as[k] = 0;
+    if (i < N) {
+      const int r = i / WS - hws, c = i % WS - hws;
+      const float n0 = p0 + (float)r, n1 = p1 + (float)c;
+      if (A.has((int)n0, (int)n1)) {
+        GT g[2]; uint8_t a;
+        if (a_safe) { interp<GT, 2, true>(Ag, n0, n1, g); interp<uint8_t, 1, true>(A, n0, n1, &a); }
+        else { interp<GT, 2, false>(Ag, n0, n1, g); interp<uint8_t, 1, false>(A, n0, n1, &a); }
+        gs0[k] = (float)g[0]; gs1[k] = (float)g[1]; as[k] = (int)a;
+        mine |= 1ull << i;
+      }
+    }
+    lds[2 * i] = gs0[k]; lds[2 * i + 1] = gs1[k];
+  }
+  unsigned long long mask = mine;  // OR over the group's lanes (xor-butterfly stays inside aligned groups of LPK lanes)
+#pragma unroll
+  for (int d = 1; d < LPK; d <<= 1) {
+    const unsigned lo = __shfl_xor((unsigned)mask, d), hi = __shfl_xor((unsigned)(mask >> 32), d);
+    mask |= ((unsigned long long)hi << 32) | lo;
+  }
+  const bool all_valid = mask == ((1ull << N) - 1ull);
+  wave_lds_fence();
+  float G00 = 0, G01 = 0, G10 = 0, G11 = 0;
+  int cpt = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {  // lk.hh:56-72 in offset order
+    if (all_valid || ((mask >> i) & 1ull)) {
+      const float gx = lds[2 * i], gy = lds[2 * i + 1];
+      G00 += gx * gx; G01 += gx * gy; G10 += gx * gy; G11 += gy * gy;
+      cpt++;
+    }
+  }
+  {
+    const float fc = (float)cpt;
+    const float a = G00 / fc, b = G01 / fc, d = G11 / fc;
+    const float hm = (a + d) * 0.5f, hd = (a - d) * 0.5f;
+    const float s = sqrtf(hd * hd + b * b);
+    const float e1 = fabsf(hm + s), e2 = fabsf(hm - s);
+    float min_ev = 99999.f;
+    if (e1 < min_ev) min_ev = e1;
+    if (e2 < min_ev) min_ev = e2;
+    if (min_ev < min_ev_th) return Match{-1.f, -1.f, FLT_MAX};
+  }
+  const float det = G00 * G11 - G10 * G01;
+  const float invdet = 1.f / det;
+  const float I00 = G11 * invdet, I10 = -G10 * invdet, I01 = -G01 * invdet, I11 = G00 * invdet;
+
+  float v0 = p0 + tr0, v1 = p1 + tr1;
+  float nk0 = 1.f, nk1 = 1.f;
+  for (int k = 0; k <= max_it && sqrtf(nk0 * nk0 + nk1 * nk1) >= delta; k++) {  // lk.hh:116
+    const bool b_safe = window_inside(B, v0, v1, hws);
+    wave_lds_fence();  // the previous pass' reads are done before its terms are overwritten
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+      const int i = gl + q * LPK;
+      float t0 = 0.f, t1 = 0.f;
+      if (i < N && ((mine >> i) & 1ull)) {
+        const int r = i / WS - hws, c = i % WS - hws;
+        uint8_t b;
+        if (b_safe) interp<uint8_t, 1, true>(B, v0 + (float)r, v1 + (float)c, &b);
+        else interp<uint8_t, 1, false>(B, v0 + (float)r, v1 + (float)c, &b);
+        const float dt = (float)as[q] - (float)b;  // lk.hh:130
+        t0 = gs0[q] * dt; t1 = gs1[q] * dt;
+      }
+      lds[2 * i] = t0; lds[2 * i + 1] = t1;
+    }
+    wave_lds_fence();
+    float bk0 = 0.f, bk1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      if (all_valid || ((mask >> i) & 1ull)) { bk0 += lds[2 * i]; bk1 += lds[2 * i + 1]; }
+    nk0 = I00 * bk0 + I01 * bk1;  // lk.hh:137
+    nk1 = I10 * bk0 + I11 * bk1;
+    v0 += nk0; v1 += nk1;
+    if (!B.has((int)v0, (int)v1)) return Match{0.f, 0.f, FLT_MAX};  // lk.hh:145-146
+  }
+  // error: as[i] for every offset (unset entries are 0), |as[i] - B(v + offset)| for every offset (lk.hh:151-171)
+  const bool b_safe = window_inside(B, v0, v1, hws);
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < PPL; q++) {
+    const int i = gl + q * LPK;
+    float e = 0.f;
+    if (i < N) {
+      const int r = i / WS - hws, c = i % WS - hws;
+      uint8_t b;
+      if (b_safe) interp<uint8_t, 1, true>(B, v0 + (float)r, v1 + (float)c, &b);
+      else interp<uint8_t, 1, false>(B, v0 + (float)r, v1 + (float)c, &b);
+      e = fabsf((float)(as[q] - (int)b));
+    }
+    lds[2 * i] = (float)as[q]; lds[2 * i + 1] = e;
+  }
+  wave_lds_fence();
+  float err = 0.f, stddev = 1.f;
+  if (PYRLK) {
+    float avg = 0.f;
+    stddev = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; i++) avg += lds[2 * i];
+    avg /= N;
+#pragma unroll
+    for (int i = 0; i < N; i++) stddev += fabsf(avg - lds[2 * i]);
+    stddev /= N;
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) { err += lds[2 * i + 1]; cpt++; }
+  if (PYRLK) return Match{v0 - p0, v1 - p1, err / (cpt * stddev)};
+  return Match{v0 - p0, v1 - p1, err / (cpt)};
+}
+
+template <int WS, int LPK>
+__global__ __launch_bounds__(64) void pyrlk_match_group_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, vpp_keypoint_f32* __restrict__ kps, int n,
+                                                               float min_ev, float max_err, int max_it, float delta, int min_scale,
+                                                               float* __restrict__ out_dist) {
+  constexpr int N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
+  __shared__ float smem[(64 / LPK) * NS * 2];
+  const int gl = threadIdx.x % LPK, grp = threadIdx.x / LPK;
+  const int i = blockIdx.x * (64 / LPK) + grp;
+  if (i >= n) return;
+  float* lds = smem + grp * NS * 2;
+  vpp_keypoint_f32 kp = kps[i];
+  if (!(kp.age > 0)) { if (out_dist && gl == 0) out_dist[i] = 0.f; return; }
+  float tr0 = 0.f, tr1 = 0.f, dist = 0.f;
+  for (int S = nlevels - 1; S >= min_scale; S--) {
+    tr0 *= 2.f; tr1 *= 2.f;
+    const float sc = (float)(1 << S);
+    const Match m = lk_match_group<WS, float, true, LPK>(kp.pos_r / sc, kp.pos_c / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, max_it, delta, lds, gl);
+    if (m.err < max_err) { tr0 = m.f0; tr1 = m.f1; }
+    dist = m.err;
+  }
+  if (gl != 0) return;
+  const float q0 = kp.pos_r + tr0, q1 = kp.pos_c + tr1;
+  if (out_dist) out_dist[i] = dist;
+  if (dist > max_err || !P.l[0].has((int)q0, (int)q1)) kp.age = 0;
+  else { kp.vel_r = q0 - kp.pos_r; kp.vel_c = q1 - kp.pos_c; kp.pos_r = q0; kp.pos_c = q1; kp.age++; }
+  kps[i] = kp;
+}
+
+template <int WS, int LPK>
+__global__ __launch_bounds__(64) void lucas_kanade_group_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, const float* __restrict__ pts,
+                                                                const float* __restrict__ pred, int n, float min_ev, int niter, float delta,
+                                                                float* __restrict__ out_flow, float* __restrict__ out_dist) {
+  constexpr int N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
+  __shared__ float smem[(64 / LPK) * NS * 2];
+  const int gl = threadIdx.x % LPK, grp = threadIdx.x / LPK;
+  const int i = blockIdx.x * (64 / LPK) + grp;
+  if (i >= n) return;
+  float* lds = smem + grp * NS * 2;
+  const float k0 = pts[2 * i], k1 = pts[2 * i + 1];
+  const float d = (float)(1 << nlevels);
+  float tr0 = (pred ? pred[2 * i] : 0.f) / d, tr1 = (pred ? pred[2 * i + 1] : 0.f) / d;
+  float dist = 0.f;
+  for (int S = nlevels - 1; S >= 0; S--) {
+    tr0 *= 2.f; tr1 *= 2.f;
+    const float sc = (float)(1 << S);
+    const Match m = lk_match_group<WS, int32_t, false, LPK>(k0 / sc, k1 / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, niter, delta, lds, gl);
+    tr0 = m.f0; tr1 = m.f1; dist = m.err;
+  }
+  if (gl != 0) return;
+  out_flow[2 * i] = tr0; out_flow[2 * i + 1] = tr1;
+  if (out_dist) out_dist[i] = dist;
+}
+
 template <int WS>
 __global__ __launch_bounds__(64) void pyrlk_match_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, vpp_keypoint_f32* __restrict__ kps, int n,
                                                          float min_ev, float max_err, int max_it, float delta, int min_scale,
@@ -214,13 +401,25 @@ int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, cons
   VPP_REQUIRE(kps && n >= 0 && min_scale >= 0, VPP_ERR_INVALID_ARG, "vpp_pyrlk_match: invalid argument");
   if (n == 0) return VPP_OK;
   hipStream_t st = as_stream(stream);
-  const int blocks = (n + 63) / 64;
-#define VPP_LK_CASE(W) case W: pyrlk_match_kernel<W><<<blocks, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); break;
+  // lanes per keypoint: enough waves to cover the 1024 SIMDs a few times over, no more (total work grows with LPK)
+  int lpk = tuning("pyrlk.lpk", 0);
+  if (lpk == 0) lpk = n >= 200000 ? 1 : (n >= 40000 ? 8 : 16);
+  if (winsize > 7) lpk = 1;  // the group kernels keep a 64-bit validity mask (WS*WS <= 64); larger windows: one lane per keypoint
+#define VPP_LK_LAUNCH(W)                                                                                                                           \
+  if (lpk == 16) pyrlk_match_group_kernel<W, 16><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
+  else if (lpk == 8) pyrlk_match_group_kernel<W, 8><<<(n + 7) / 8, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
+  else pyrlk_match_kernel<W><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist);
   switch (winsize) {
-    VPP_LK_CASE(3) VPP_LK_CASE(5) VPP_LK_CASE(7) VPP_LK_CASE(9) VPP_LK_CASE(11) VPP_LK_CASE(15) VPP_LK_CASE(21)
+    case 3: VPP_LK_LAUNCH(3) break;
+    case 5: VPP_LK_LAUNCH(5) break;
+    case 7: VPP_LK_LAUNCH(7) break;
+    case 9: pyrlk_match_kernel<9><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); break;
+    case 11: pyrlk_match_kernel<11><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); break;
+    case 15: pyrlk_match_kernel<15><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); break;
+    case 21: pyrlk_match_kernel<21><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); break;
     default: set_error("vpp_pyrlk_match: unsupported window size %d (3,5,7,9,11,15,21)", winsize); return VPP_ERR_UNSUPPORTED;
   }
-#undef VPP_LK_CASE
+#undef VPP_LK_LAUNCH
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }
@@ -234,13 +433,25 @@ int vpp_lucas_kanade(const vpp_image_desc* prev, const vpp_image_desc* grad, con
   VPP_REQUIRE(pts && out_flow && n >= 0, VPP_ERR_INVALID_ARG, "vpp_lucas_kanade: invalid argument");
   if (n == 0) return VPP_OK;
   hipStream_t st = as_stream(stream);
-  const int blocks = (n + 63) / 64;
-#define VPP_LK_CASE(W) case W: lucas_kanade_kernel<W><<<blocks, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, (float)min_ev, niterations, (float)delta, out_flow, out_dist); break;
+  int lpk = tuning("pyrlk.lpk", 0);
+  if (lpk == 0) lpk = n >= 200000 ? 1 : (n >= 40000 ? 8 : 16);
+  if (winsize > 7) lpk = 1;
+  const float fev = (float)min_ev, fdelta = (float)delta;
+#define VPP_LK_LAUNCH(W)                                                                                                                           \
+  if (lpk == 16) lucas_kanade_group_kernel<W, 16><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
+  else if (lpk == 8) lucas_kanade_group_kernel<W, 8><<<(n + 7) / 8, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
+  else lucas_kanade_kernel<W><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist);
   switch (winsize) {
-    VPP_LK_CASE(3) VPP_LK_CASE(5) VPP_LK_CASE(7) VPP_LK_CASE(9) VPP_LK_CASE(11) VPP_LK_CASE(15) VPP_LK_CASE(21)
+    case 3: VPP_LK_LAUNCH(3) break;
+    case 5: VPP_LK_LAUNCH(5) break;
+    case 7: VPP_LK_LAUNCH(7) break;
+    case 9: lucas_kanade_kernel<9><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); break;
+    case 11: lucas_kanade_kernel<11><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); break;
+    case 15: lucas_kanade_kernel<15><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); break;
+    case 21: lucas_kanade_kernel<21><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); break;
     default: set_error("vpp_lucas_kanade: unsupported window size %d (3,5,7,9,11,15,21)", winsize); return VPP_ERR_UNSUPPORTED;
   }
-#undef VPP_LK_CASE
+#undef VPP_LK_LAUNCH
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }
