@@ -26,6 +26,12 @@ def load(omp=False):
     return lib
 
 
+def load_ref_video_extruder():
+    """The reference's video_extruder, built with -DNDEBUG (see oracle/ref/ref_video_extruder.cpp); None if never built."""
+    path = os.path.join(HERE, "_ref", "libvpp_ref_ve.so")
+    return ctypes.CDLL(path) if os.path.exists(path) else None
+
+
 def load_ref():
     """The reference's own headers compiled against shims; None when it was never built (no /root/reference)."""
     path = os.path.join(HERE, "_ref", "libvpp_ref.so")

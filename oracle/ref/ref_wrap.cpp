@@ -31,6 +31,7 @@ template <class V> void export_image(const image2d<V>& src, const vpp_image_desc
 bool is(const vpp_image_desc* d, int dtype, int ch) { return d->dtype == dtype && d->channels == ch; }
 }  // namespace
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 int ref_pixelwise_add(const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b) {
@@ -87,6 +88,7 @@ int ref_box_filter5x5(const vpp_image_desc* dst, const vpp_image_desc* src) {
 }
 
 }  // extern "C"
+#pragma GCC visibility pop
 template <class V> static int fill_border_t(const vpp_image_desc* d, int mode, const void* value) {
   auto I = wrap<V>(d);
   if (mode == VPP_BORDER_MIRROR) fill_border_mirror(I);
@@ -94,6 +96,7 @@ template <class V> static int fill_border_t(const vpp_image_desc* d, int mode, c
   else { V v; memcpy(&v, value, sizeof(V)); fill_border_with_value(I, v); }
   return 0;
 }
+#pragma GCC visibility push(default)
 extern "C" {
 int ref_fill_border(const vpp_image_desc* d, int mode, const void* value) {
   if (is(d, VPP_U8, 1)) return fill_border_t<unsigned char>(d, mode, value);
@@ -106,6 +109,7 @@ int ref_fill_border(const vpp_image_desc* d, int mode, const void* value) {
 
 // pyramid2d<V>(img, nlevels, 2, _border = border) (pyramid.hh:146-158): levels exported into caller images.
 }  // extern "C"
+#pragma GCC visibility pop
 template <class V> static int pyramid_t(const vpp_image_desc* img, int nlevels, int border, const vpp_image_desc* out) {
   auto I = wrap<V>(img);
   pyramid2d<V> pyr(I, nlevels, 2, _border = border);
@@ -115,6 +119,7 @@ template <class V> static int pyramid_t(const vpp_image_desc* img, int nlevels, 
   }
   return 0;
 }
+#pragma GCC visibility push(default)
 extern "C" {
 int ref_pyramid(const vpp_image_desc* img, int nlevels, int border, const vpp_image_desc* out) {
   if (is(img, VPP_U8, 1)) return pyramid_t<unsigned char>(img, nlevels, border, out);
@@ -172,6 +177,7 @@ int ref_lucas_kanade(const vpp_image_desc* i1, const vpp_image_desc* i2, const f
 
 // pyrlk_match with lk_match_point_square_win<WS> over pyramids built as benchmarks/pyrlk_opencv_comparison.cc:49-60 does.
 }  // extern "C"
+#pragma GCC visibility pop
 template <int WS>
 static int pyrlk_t(const vpp_image_desc* i1, const vpp_image_desc* i2, int nlevels, int border, vpp_keypoint_f32* kps, int n, float min_ev,
                    float max_err, int max_it, float delta, int min_scale) {
@@ -196,6 +202,7 @@ static int pyrlk_t(const vpp_image_desc* i1, const vpp_image_desc* i2, int nleve
   }
   return 0;
 }
+#pragma GCC visibility push(default)
 extern "C" {
 int ref_pyrlk_match(const vpp_image_desc* i1, const vpp_image_desc* i2, int nlevels, int border, vpp_keypoint_f32* kps, int n, int winsize,
                     float min_ev, float max_err, int max_it, float delta, int min_scale) {
@@ -219,3 +226,4 @@ int ref_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_image_desc* 
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

@@ -38,7 +38,7 @@ static image2d<unsigned char> texture(int nr, int nc, float dr, float dc) {  // 
     float lo = 1e9, hi = -1e9; for (int r = 8; r < H - 8; r++) for (int c = 8; c < W - 8; c++) { lo = std::min(lo, base[size_t(r) * W + c]); hi = std::max(hi, base[size_t(r) * W + c]); }
     for (auto& x : base) x = (x - lo) / (hi - lo) * 255.f;
   }
-  image2d<unsigned char> img(nr, nc, _border = 3);
+  image2d<unsigned char> img(nr, nc, _border = 3, _aligned = 32);  // 32: the reference's AVX2 FAST path uses aligned 256-bit loads (fast.hpp:131,312)
   for (int r = 0; r < nr; r++) for (int c = 0; c < nc; c++) {
     const float y = r + 32 - dr, x = c + 32 - dc; const int y0 = int(y), x0 = int(x); const float a = y - y0, b = x - x0;
     const float v = (1 - a) * (1 - b) * base[size_t(y0) * W + x0] + a * (1 - b) * base[size_t(y0 + 1) * W + x0] + (1 - a) * b * base[size_t(y0) * W + x0 + 1] + a * b * base[size_t(y0 + 1) * W + x0 + 1];
@@ -198,6 +198,46 @@ static void test_sdof_and_video_extruder() {
   CHECK(alive > 30 && good > alive * 0.8);
 }
 
+#ifdef HAVE_VPP_REF
+// the REAL reference (oracle/_ref: matt-42/vpp's own headers) run over the same frame sequence
+extern "C" int ref_video_extruder_run(const vpp_image_desc* frames, int nframes, int detector_th, int keypoint_spacing, int detector_period,
+                                      int max_trajectory_length, int nscales, int winsize, int propagation, int32_t* out, int32_t* traj_len,
+                                      int capacity, int* count, int* frame_id);
+static void test_video_extruder_vs_reference() {
+  const int nr = 240, nc = 320, T = 9;
+  std::vector<image2d<unsigned char>> frames;
+  for (int t = 0; t < T; t++) {
+    image2d<unsigned char> f = texture(nr, nc, 1.f * t, -2.f * t);
+    for (int k = 0; k < 25; k++) {  // moving high-contrast rectangles: plenty of FAST corners
+      const int r = 20 + (k * 37) % 180 + t, c = 30 + (k * 53) % 250 - 2 * t, v = (k * 71) & 255;
+      for (int i = 0; i < 14; i++) for (int j = 0; j < 18; j++) f(r + i, c + j) = (unsigned char)v;
+    }
+    fill_border_mirror(f);
+    frames.push_back(f);
+  }
+  std::vector<vpp_image_desc> descs;
+  for (auto& f : frames) descs.push_back(host_desc(f));  // host pointers (the accessor downloads the mirrored border)
+  std::vector<int32_t> want(5 * 100000), wlen(100000); int wn = 0, wfid = 0;
+  std::fprintf(stderr, "video_extruder: calling the reference\n");
+  CHECK(ref_video_extruder_run(descs.data(), T, 10, 10, 5, 15, 3, 9, 2, want.data(), wlen.data(), 100000, &wn, &wfid) == 0);
+  std::fprintf(stderr, "video_extruder: reference done (%d keypoints)\n", wn);
+  video_extruder_ctx ctx = video_extruder_init(make_box2d(nr, nc));
+  for (int t = 1; t < T; t++)
+    video_extruder_update(ctx, frames[t - 1], frames[t], _detector_th = 10, _keypoint_spacing = 10, _detector_period = 5, _max_trajectory_length = 15,
+                          _nscales = 3, _winsize = 9, _propagation = 2);
+  std::fprintf(stderr, "video_extruder: %d keypoints (reference %d), frame_id %d\n", ctx.keypoints.size(), wn, ctx.frame_id);
+  CHECK(ctx.frame_id == wfid && ctx.keypoints.size() == wn && wn > 100);
+  int alive = 0;
+  for (int i = 0; i < wn; i++) {
+    const auto& k = ctx.keypoints[i];
+    CHECK(k.position[0] == want[5 * i] && k.position[1] == want[5 * i + 1] && k.velocity[0] == want[5 * i + 2] && k.velocity[1] == want[5 * i + 3] && k.age == want[5 * i + 4]);
+    CHECK(ctx.trajectories[i].size() == wlen[i]);
+    alive += k.alive();
+  }
+  CHECK(alive > 50);
+}
+#endif
+
 int main() {
   CHECK(vpp_init(0) == 0);
   test_pixel_wise_functors();
@@ -205,6 +245,9 @@ int main() {
   test_pyrlk();
   test_lucas_kanade_golden();
   test_sdof_and_video_extruder();
+#ifdef HAVE_VPP_REF
+  test_video_extruder_vs_reference();
+#endif
   std::puts("device_api_test ok");
   return 0;
 }

@@ -19,6 +19,9 @@ def _compile(src, exe, device):
         cmd += ["-DVPP_AMD_DEVICE", "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "vpp_amd", "csrc"), "-lvpp_amd",
                 "-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "vpp_amd", "csrc"),
                 "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--allow-shlib-undefined"]
+        refdir = os.path.join(ROOT, "oracle", "_ref")
+        if os.path.exists(os.path.join(refdir, "libvpp_ref_ve.so")):  # the real reference, where it was built: video_extruder parity
+            cmd += ["-DHAVE_VPP_REF", "-L" + refdir, "-lvpp_ref_ve", "-Wl,-rpath," + refdir]
     subprocess.check_call(cmd)
     return exe
 
