@@ -48,7 +48,9 @@ def run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch):
     ((96, 128), 5, 2, 0, 0, 3),      # no propagation
     ((270, 480), 9, 3, 0, 2, 5),
 ])
-def test_sdof_matches_oracle(lib, orc, shape, ws, nscales, min_scale, prop, patch):
+@pytest.mark.parametrize("propagate_impl", [1, 2, 3])  # generic wavefront, LDS ring K=16, LDS ring K=8
+def test_sdof_matches_oracle(lib, orc, shape, ws, nscales, min_scale, prop, patch, propagate_impl):
+    lib.vpp_set_tuning(b"sdof.propagate", propagate_impl)
     f1, f2, kps = flow_scene(*shape)
     rng = np.random.default_rng(0)
     extra = np.stack([rng.integers(0, shape[0], 300), rng.integers(0, shape[1], 300)], 1).astype(np.int32)  # several keypoints per cell
@@ -57,6 +59,7 @@ def test_sdof_matches_oracle(lib, orc, shape, ws, nscales, min_scale, prop, patc
     assert want[2].mean() > 0.9
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
+    lib.vpp_set_tuning(b"sdof.propagate", -1)
     moved = (want[0] != kps).any(axis=1).mean()
     assert moved > 0.5  # the scene really moves
 

@@ -23,11 +23,49 @@ constexpr int kMaxScales = 8;
 
 struct Maps { DImg flow, mark, dist; };  // i32x2, u8, i32 per flow-map cell
 
-// of_internals::sad_distance behind the domain test of the `distance` lambda (semi_dense_optical_flow.hpp:18-42,102-108)
+// of_internals::sad_distance behind the domain test of the `distance` lambda (semi_dense_optical_flow.hpp:18-42,102-108).
+// The reference sums |a-b| row by row and stops after the first row that pushes the sum above `th`; here every row of
+// both windows is loaded up front as (unaligned) dwords — one memory round trip instead of WS dependent ones — the row
+// sums come from v_sad_u8 (4 pixels per instruction), and the same early-out rule is applied to them, so the returned
+// value is identical.  The dwords over-read at most 3 bytes past a window row: inside the 2*winsize border.
+template <int WS>
+__device__ __forceinline__ int sad_rows(const uint8_t* __restrict__ row1, const uint8_t* __restrict__ row2, int pitch1, int pitch2, int th) {
+  constexpr int ND = (WS + 3) / 4;
+  constexpr uint32_t tail_mask = (WS % 4) ? ((1u << (8 * (WS % 4))) - 1u) : 0xFFFFFFFFu;
+  uint32_t a[WS][ND], b[WS][ND];
+#pragma unroll
+  for (int r = 0; r < WS; r++)
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+      __builtin_memcpy(&a[r][d], row1 + (ptrdiff_t)r * pitch1 + 4 * d, 4);
+      __builtin_memcpy(&b[r][d], row2 + (ptrdiff_t)r * pitch2 + 4 * d, 4);
+    }
+  int err = 0;
+#pragma unroll
+  for (int r = 0; r < WS; r++) {
+    if (err <= th) {
+      uint32_t err2 = 0;
+#pragma unroll
+      for (int d = 0; d < ND; d++) {
+        const uint32_t m = d == ND - 1 ? tail_mask : 0xFFFFFFFFu;
+        err2 = __builtin_amdgcn_sad_u8(a[r][d] & m, b[r][d] & m, err2);
+      }
+      err += (int)err2;
+    }
+  }
+  return err;
+}
+
 __device__ __forceinline__ int distance_fn(const DImg& i1, const DImg& i2, int a0, int a1, int b0, int b1, int ws, int th) {
   if (!(i1.has(a0, a1) && i2.has(b0, b1))) return INT_MAX;
   const uint8_t* row1 = i1.row<uint8_t>(a0 - ws / 2) + (a1 - ws / 2);
   const uint8_t* row2 = i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2);
+  switch (ws) {
+    case 5: return sad_rows<5>(row1, row2, i1.pitch, i2.pitch, th);
+    case 7: return sad_rows<7>(row1, row2, i1.pitch, i2.pitch, th);
+    case 9: return sad_rows<9>(row1, row2, i1.pitch, i2.pitch, th);
+    case 11: return sad_rows<11>(row1, row2, i1.pitch, i2.pitch, th);
+  }
   int err = 0;
   for (int r = 0; r < ws && err <= th; r++) {
     int err2 = 0;
@@ -147,6 +185,190 @@ __global__ __launch_bounds__(1024) void sdof_propagate_kernel(DImg i1, DImg i2, 
   }
 }
 
+// ---- propagation: speculative (Jacobi) evaluation + ordered validation -------------------------------------------------
+// A sweep visits the cells in raster (or reverse raster) order and loop_body(cell) reads its 8 neighbours: the 4 visited
+// earlier hold their post-visit values, the 4 visited later their pre-sweep values.  Hence loop_body(cell) evaluated
+// against the PRE-sweep maps (all cells in parallel: sdof_jacobi_kernel) is exactly the sequential result unless one of
+// the 4 earlier neighbours was changed during this sweep.  The ordered pass (sdof_propagate_ring_kernel, skewed wavefront,
+// one barrier per step) therefore only checks four "changed" flags per cell and applies the precomputed outcome; it
+// re-runs loop_body in place (SADs and all) only for cells behind a neighbour that really changed.  Same result as the
+// serial reference, but the 81-pixel SADs no longer sit on the critical path of the wavefront.
+struct Cell { int f0, f1, dist, mark; };  // mark: low byte = flow_map_mark value, bit 8 = changed during this sweep
+constexpr int kChanged = 0x100;
+
+// Per (cell, neighbour) results of the costly calls of loop_body, keyed by the neighbour flow they were computed for.
+struct PairCache { int nf0, nf1, d2, gf0, gf1, gdist, flags, pad; };  // flags: 1 = entry valid, 2 = descent result present
+
+// loop_body (semi_dense_optical_flow.hpp:149-189) for the cell at image point (r, c); nbr(dr, dc) returns the neighbour
+// cell at flow-map offset (dr, dc) (mark 0 when outside the map).  distance() and gradient_descent_match() depend only on
+// (r, c) and on the neighbour's flow: RECORD stores them in pc[8] (Jacobi pass), otherwise pc[8] is consulted and a
+// result is recomputed only when the neighbour's flow is no longer the one it was computed for.  Returns true when the
+// cell was updated.
+template <bool RECORD, class NB>
+__device__ __forceinline__ bool loop_body(const DImg& i1, const DImg& i2, int ws, int r, int c, Cell& cur, NB nbr, PairCache* pc) {
+  const int prev0 = cur.f0, prev1 = cur.f1;
+  bool changed = false;
+  int k = -1;
+  for (int dr = -1; dr <= 1; dr++)
+    for (int dc = -1; dc <= 1; dc++) {
+      if (!dr && !dc) continue;
+      k++;
+      if (RECORD) pc[k].flags = 0;
+      const Cell nb = nbr(dr, dc);
+      if (!(nb.mark & 0xFF)) continue;
+      const int a0 = cur.f0 - nb.f0, a1 = cur.f1 - nb.f1, b0 = prev0 - nb.f0, b1 = prev1 - nb.f1;
+      if (a0 * a0 + a1 * a1 >= 9 && b0 * b0 + b1 * b1 >= 9) {  // Eigen's integer norm(): (int)sqrt(s) > 2  <=>  s >= 9
+        const int d1 = cur.dist;
+        PairCache e; e.flags = 0;
+        if (!RECORD) { e = pc[k]; if (!((e.flags & 1) && e.nf0 == nb.f0 && e.nf1 == nb.f1)) e.flags = 0; }
+        const int d2 = (e.flags & 1) ? e.d2 : distance_fn(i1, i2, r, c, r + nb.f0, c + nb.f1, ws, INT_MAX);
+        GdMatch g{0, 0, 0};
+        bool have_g = false;
+        if (d2 < d1) {
+          if (e.flags & 2) g = GdMatch{e.gf0, e.gf1, e.gdist};
+          else g = gradient_descent_match(i1, i2, ws, r, c, r + nb.f0, c + nb.f1, 5);
+          have_g = true;
+          if (g.distance < d1) { cur.mark = 1; cur.f0 = g.f0; cur.f1 = g.f1; cur.dist = g.distance; changed = true; }
+        }
+        if (RECORD) pc[k] = PairCache{nb.f0, nb.f1, d2, g.f0, g.f1, g.distance, have_g ? 3 : 1, 0};
+      }
+    }
+  return changed;
+}
+
+__device__ __forceinline__ Cell load_map_cell(const Maps& m, int ci, int cj) {
+  Cell c;
+  const int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
+  c.f0 = f[0]; c.f1 = f[1]; c.dist = m.dist.row<int32_t>(ci)[cj]; c.mark = m.mark.row<uint8_t>(ci)[cj];
+  return c;
+}
+
+__global__ __launch_bounds__(256) void sdof_jacobi_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int NI, int NJ, int forward,
+                                                          Cell* __restrict__ J, PairCache* __restrict__ pairs) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= NI * NJ) return;
+  const int ci = idx / NJ, cj = idx - ci * NJ;
+  Cell cur = load_map_cell(m, ci, cj);
+  if (cur.mark) {
+    int r, c;
+    if (forward) { r = ci * patch; c = cj * patch; } else { r = i1.nr - 1 - (NI - 1 - ci) * patch; c = i1.nc - 1 - (NJ - 1 - cj) * patch; }
+    auto nbr = [&](int dr, int dc) -> Cell {
+      const int q0 = ci + dr, q1 = cj + dc;
+      if (q0 < 0 || q1 < 0 || q0 >= NI || q1 >= NJ) return Cell{0, 0, 0, 0};
+      return load_map_cell(m, q0, q1);
+    };
+    if (loop_body<true>(i1, i2, ws, r, c, cur, nbr, pairs + (size_t)idx * 8)) cur.mark |= kChanged;
+  }
+  J[idx] = cur;
+}
+
+// Slow path of the ordered pass (a neighbour visited earlier was changed): loop_body against the ring.  Kept out of line so
+// that the per-step code stays small enough to be unrolled QD times (static register queue, counted vmcnt waits).
+template <int K>
+__device__ __noinline__ bool sweep_slow_path(const DImg& i1, const DImg& i2, int ws, int patch, int forward, int iw, int jw, int NI, int NJ,
+                                             const Cell* ring, Cell* cur_io, PairCache* pc) {
+  int r, c;
+  if (forward) { r = iw * patch; c = jw * patch; } else { r = i1.nr - 1 - iw * patch; c = i1.nc - 1 - jw * patch; }
+  Cell cur = *cur_io;
+  cur.mark &= 0xFF;
+  auto wnbr = [&](int drow, int col) -> Cell {
+    const int rr = iw + drow;
+    if (rr < 0 || rr >= NI || col < 0 || col >= NJ) return Cell{0, 0, 0, 0};
+    return ring[(size_t)rr * K + (col & (K - 1))];
+  };
+  // flow-map offset (dr,dc) -> wavefront offset: mirrored in the backward sweep
+  auto nbr = [&](int dr, int dc) -> Cell { return forward ? wnbr(dr, jw + dc) : wnbr(-dr, jw - dc); };
+  const bool changed = loop_body<false>(i1, i2, ws, r, c, cur, nbr, pc);
+  *cur_io = cur;
+  return changed;
+}
+
+// Ordered pass.  Thread = wavefront row: at step t it visits wavefront column t - 2*row, so data only flows between
+// adjacent threads.  Each row keeps a ring of K consecutive cells in LDS; cells are requested from global memory in
+// batches P columns ahead and land one batch later, before the row above first needs them, so the common path (no
+// earlier neighbour changed, Jacobi outcome "unchanged") touches LDS only.
+constexpr int kJChanged = 0x200;
+__device__ unsigned g_sweep_stats[4];  // [0] marked cells visited, [1] Jacobi outcomes applied, [2] slow-path recomputations, [3] slow-path changes  // ring-only flag: the Jacobi pass wants to change this cell
+
+template <int K>
+__global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward,
+                                                                   const Cell* __restrict__ J, PairCache* __restrict__ pairs, int stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Cell* ring = (Cell*)smem_raw;  // [NI][K]
+  // batch of QD columns, requested P columns ahead: the row above needs columns <= col+3+QD-1 during a batch (P >= QD+3)
+  // and a landing batch must only overwrite columns < col-3 (K >= P+3)
+  constexpr int QD = K >= 16 ? 6 : 2, P = K >= 16 ? 10 : 5;
+  static_assert(P >= QD + 3 && K >= P + 3, "ring too small for the prefetch distance");
+  const int NI = (i1.nr - 1) / patch + 1, NJ = (i1.nc - 1) / patch + 1;
+  const int iw = threadIdx.x;
+  const bool row_ok = iw < NI;
+  Cell* my = ring + (size_t)iw * K;
+  const int ci = forward ? iw : NI - 1 - iw;  // flow-map row of this thread
+  auto wnbr = [&](int drow, int jw) -> Cell {  // ring entry at wavefront row iw+drow, wavefront column jw; mark 0 outside
+    const int r = iw + drow;
+    if (r < 0 || r >= NI || jw < 0 || jw >= NJ) return Cell{0, 0, 0, 0};
+    return ring[(size_t)r * K + (jw & (K - 1))];
+  };
+  Cell q[QD];
+  int qjm[QD];
+  const int tmax = 2 * (NI - 1) + (NJ - 1);
+  const int t0 = -2 * QD;  // two warm-up batches: only prefetching
+  for (int tb = t0; tb <= tmax; tb += QD) {
+    // Batched prefetch, once every QD steps: first the QD cells requested one batch ago land in the ring, then the next QD
+    // are requested.  The only waits on global memory are therefore for loads that have had QD steps to arrive.
+    if (row_ok) {
+      const int jb = tb - 2 * iw;  // wavefront column of this thread at the first step of the batch
+      if (tb > t0) {
+#pragma unroll
+        for (int u = 0; u < QD; u++) {
+          const int lc = jb - QD + P + u;
+          if (lc >= 0 && lc < NJ) { Cell c = q[u]; if (qjm[u] & kChanged) c.mark |= kJChanged; my[lc & (K - 1)] = c; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < QD; u++) {
+        const int pc = jb + P + u;
+        if (pc >= 0 && pc < NJ) {
+          const int cj = forward ? pc : NJ - 1 - pc;
+          q[u] = load_map_cell(m, ci, cj);
+          qjm[u] = J[(size_t)ci * NJ + cj].mark;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < QD; u++) {
+      const int t = tb + u;
+      const int jw = t - 2 * iw;
+      if (row_ok) {
+        if (t >= 0 && jw >= 0 && jw < NJ) {
+          Cell cur = my[jw & (K - 1)];
+          if (cur.mark & 0xFF) {
+            // the four neighbours visited before this cell in the sweep
+            const int dirty = (wnbr(-1, jw - 1).mark | wnbr(-1, jw).mark | wnbr(-1, jw + 1).mark | wnbr(0, jw - 1).mark) & kChanged;
+            const int cj = forward ? jw : NJ - 1 - jw;
+            bool changed = false;
+            if (stats) atomicAdd(&g_sweep_stats[0], 1u);
+            if (!dirty) {
+              if (cur.mark & kJChanged) { cur = J[(size_t)ci * NJ + cj]; changed = true; if (stats) atomicAdd(&g_sweep_stats[1], 1u); }  // Jacobi outcome is the sequential one
+            } else {
+              changed = sweep_slow_path<K>(i1, i2, ws, patch, forward, iw, jw, NI, NJ, ring, &cur, pairs + ((size_t)ci * NJ + cj) * 8);
+              if (stats) { atomicAdd(&g_sweep_stats[2], 1u); if (changed) atomicAdd(&g_sweep_stats[3], 1u); }
+            }
+            if (changed) {
+              cur.mark = (cur.mark & 0xFF) | kChanged;
+              my[jw & (K - 1)] = cur;
+              int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
+              f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)(cur.mark & 0xFF);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void sdof_readback_kernel(const int32_t* __restrict__ kps, int n, int div, int ms, Maps m,
                                                             int32_t* __restrict__ out_pos, int32_t* __restrict__ out_dist, uint8_t* __restrict__ out_valid) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -199,6 +421,8 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
   hipStream_t st = as_stream(stream);
   // carve the scratch: two image pyramids (border 2*winsize, :72-73), flow / mark / distance pyramids (border nscales, :70-74), owners
   vpp_image_desc P1[kMaxScales], P2[kMaxScales], FL[kMaxScales], MK[kMaxScales], DM[kMaxScales], OW[kMaxScales];
+  Cell* jacobi = nullptr;
+  PairCache* pairs = nullptr;
   for (int pass = 0; pass < 2; pass++) {
     Carver cv{pass ? (uint8_t*)g_scratch.p : nullptr};
     int fr = i1->nrows / patchsize, fc = i1->ncols / patchsize, ir = i1->nrows, ic = i1->ncols;
@@ -208,6 +432,13 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
       FL[s] = cv.image(fr, fc, VPP_I32, 2, nscales); MK[s] = cv.image(fr, fc, VPP_U8, 1, nscales); DM[s] = cv.image(fr, fc, VPP_I32, 1, nscales);
       OW[s] = cv.image(fr, fc, VPP_U32, 1, 0);
       fr = 1 + fr / 2; fc = 1 + fc / 2; ir = 1 + ir / 2; ic = 1 + ic / 2;  // pyramid.hh:154
+    }
+    {  // Jacobi outcomes: one cell per flow-map cell of the finest scale
+      const size_t cells = (size_t)((i1->nrows - 1) / patchsize + 1) * ((i1->ncols - 1) / patchsize + 1);
+      jacobi = cv.base ? (Cell*)(cv.base + cv.off) : nullptr;
+      cv.off += (cells * sizeof(Cell) + 255) / 256 * 256;
+      pairs = cv.base ? (PairCache*)(cv.base + cv.off) : nullptr;
+      cv.off += (cells * 8 * sizeof(PairCache) + 255) / 256 * 256;
     }
     if (!pass) { int rc = g_scratch.ensure(cv.off); if (rc != VPP_OK) return rc; }
   }
@@ -229,12 +460,40 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
     const bool has_coarse = scale < nscales - 1;
     sdof_descent_kernel<<<(n + 63) / 64, 64, 0, st>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW[scale]), dimg(&P1[scale]), dimg(&P2[scale]),
                                                      maps(scale), maps(has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0);
-    if (propagation > 0)
-      sdof_propagate_kernel<<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, propagation);
+    if (propagation > 0) {
+      const int NI = (P1[scale].nrows - 1) / patchsize + 1;
+      const int threads = (NI + 63) / 64 * 64;
+      const int mode = tuning("sdof.propagate", 0);  // 0 auto, 1 generic, 2 ring K=16, 3 ring K=8
+      const int NJ = (P1[scale].ncols - 1) / patchsize + 1;
+      const bool ring16 = (mode == 0 || mode == 2) && NI <= 640, ring8 = !ring16 && (mode == 0 || mode == 3) && NI <= 1024;
+      if (ring16 || ring8) {
+        for (int Ki = 0; Ki < propagation; Ki++) {
+          sdof_jacobi_kernel<<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs);
+          if (ring16) {
+            const size_t lds = (size_t)NI * 16 * sizeof(Cell);
+            VPP_HIP_TRY(hipFuncSetAttribute((const void*)sdof_propagate_ring_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            sdof_propagate_ring_kernel<16><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, tuning("sdof.stats", 0));
+          } else {
+            const size_t lds = (size_t)NI * 8 * sizeof(Cell);
+            VPP_HIP_TRY(hipFuncSetAttribute((const void*)sdof_propagate_ring_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            sdof_propagate_ring_kernel<8><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, tuning("sdof.stats", 0));
+          }
+        }
+      } else
+        sdof_propagate_kernel<<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, propagation);
+    }
     VPP_LAUNCH_CHECK();
   }
   const int ms = 1 << min_scale;
   sdof_readback_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize * ms, ms, maps(min_scale), out_pos, out_dist, out_valid);
   VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+// diagnostics (not part of include/vpp_amd.h): counters of the ordered propagation pass, enabled by tuning "sdof.stats"
+extern "C" int vpp_debug_sdof_stats(unsigned* out4, int reset) {
+  VPP_HIP_TRY(hipDeviceSynchronize());
+  VPP_HIP_TRY(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sweep_stats), 4 * sizeof(unsigned)));
+  if (reset) { unsigned z[4] = {0, 0, 0, 0}; VPP_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_stats), z, sizeof z)); }
   return VPP_OK;
 }
