@@ -82,6 +82,28 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
         dt = (time.perf_counter() - t0) / it
         fast[name] = {"ms": dt * 1e3, "gpixels_per_s": 2160 * 3840 * world / dt / 1e9, "keypoints": n.value}
     res["fast9_4k"] = fast
+
+    # semi-dense optical flow on one 4K frame pair (BASELINE configs[4] on a single GPU): a keypoint every 10 px
+    # (video_extruder keypoint_spacing), winsize 9, 3 scales, propagation 2, patch 5 (video_extruder.hpp:35-41,54)
+    from test_gpu_sdof import flow_scene
+    s1, s2, sk = flow_scene(2160, 3840, spacing=10)
+    e1, e2 = DeviceImage.from_host(u8_image(s1, border=3), dev), DeviceImage.from_host(u8_image(s2, border=3), dev)
+    dk = torch.from_numpy(sk).to(dev); m = len(sk)
+    gp = torch.zeros((m, 2), dtype=torch.int32, device=dev); gd = torch.zeros(m, dtype=torch.int32, device=dev); gv = torch.zeros(m, dtype=torch.uint8, device=dev)
+
+    def sdof():
+        lib.vpp_semi_dense_optical_flow(P(e1.desc), P(e2.desc), V(dk.data_ptr()), m, 9, 3, 0, 2, 5, V(gp.data_ptr()), V(gd.data_ptr()), V(gv.data_ptr()), st)
+    for _ in range(2):
+        sdof()
+    barrier()
+    t0 = time.perf_counter()
+    it = 5
+    for _ in range(it):
+        sdof()
+    barrier()
+    dt = (time.perf_counter() - t0) / it
+    res["semi_dense_flow_4k"] = {"ms_per_frame_pair": dt * 1e3, "frame_pairs_per_s": world / dt, "keypoints": m,
+                                 "note": "one frame pair per GPU (replicas); serial-order semantics, bit-exact vs the oracle"}
     return res
 
 

@@ -27,7 +27,10 @@ template <class T, class S> __device__ __forceinline__ T hpass(const DImg& in, i
   const T* i = in.row<T>(rr) + comp;
   return tap5<T, S>((S)i[-2 * ch], (S)i[-ch], (S)i[0], (S)i[ch], (S)i[2 * ch]);
 }
-__device__ __forceinline__ int mirror_row(int r, int nr) { return r < 0 ? -r - 1 : (r >= nr ? 2 * nr - r - 1 : r); }
+__device__ __forceinline__ int mirror_row(int r, int nr) {
+  const int m = r < 0 ? -r - 1 : (r >= nr ? 2 * nr - r - 1 : r);
+  return min(max(m, 0), nr - 1);  // only differs for images of fewer than 2 rows, where the reference reads outside its buffer
+}
 
 template <class T, class S> __device__ __forceinline__ T lowpass_at(const DImg& in, int r, int comp, int ch) {
   S h[5];
