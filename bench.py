@@ -43,10 +43,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     multi = world > 1
+    # test hook: VPP_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 over gloo, so the N>1 code path can be exercised on a 1-GPU box
+    one_dev = os.environ.get("VPP_BENCH_ONE_DEVICE", "0") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if multi:
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
     lib = capi.lib()
     capi.check(lib.vpp_init(local_rank))
     st = capi.stream_ptr()
@@ -95,7 +102,7 @@ def main():
         t1 = time.perf_counter()
         wall = t1 - t0
         if multi:
-            t = torch.tensor([wall], dtype=torch.float64, device=dev)
+            t = torch.tensor([wall], dtype=torch.float64, device="cpu" if one_dev else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         return wall, e0.elapsed_time(e1) * 1e-3

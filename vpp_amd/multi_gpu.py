@@ -17,6 +17,8 @@ def all_gather_records(shard, n, rank, world, record_bytes=RECORD_BYTES):
     """shard: 1-D uint8 tensor holding this rank's records.  Returns the n*record_bytes tensor of all records, in index order."""
     if world == 1:
         return shard
+    if dist.get_backend() == "gloo" and shard.is_cuda:  # CPU tests / 1-GPU smoke runs: gloo gathers host tensors
+        return all_gather_records(shard.cpu(), n, rank, world, record_bytes).to(shard.device)
     sizes = [(shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0]) * record_bytes for r in range(world)]
     assert shard.numel() == sizes[rank]
     if len(set(sizes)) == 1:
