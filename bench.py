@@ -165,16 +165,23 @@ def main():
         orc = binding.load(omp=True)
         dst_h = src_h.like(border=0)
         orc.orc_fill_border(P(src_h.desc), 0, None)
-        orc.orc_box_filter(P(dst_h.desc), P(src_h.desc), 5, 5)  # warm-up (benchmarks/box_5x5_filter.cc:193-203 protocol)
-        iters = 5
+        refomp = binding.load_ref_omp()  # the reference's own pixel_wise + relative_access code, OpenMP build, where it was built
+        if refomp is not None:
+            run_cpu = lambda: refomp.ref_box_filter5x5(P(dst_h.desc), P(src_h.desc))
+            kind, what = "reference", "oracle/_ref/libvpp_ref_omp.so = matt-42/vpp headers, -O3 -fopenmp -DNDEBUG (benchmarks/CMakeLists.txt:10,18)"
+        else:
+            run_cpu = lambda: orc.orc_box_filter(P(dst_h.desc), P(src_h.desc), 5, 5)
+            kind, what = "port", "oracle/liboracle_omp.so (-O3 -fopenmp)"
+        run_cpu()  # warm-up (benchmarks/box_5x5_filter.cc:193-203 protocol: K timed iterations after one warm-up call)
+        iters = 10
         t0 = time.perf_counter()
         for _ in range(iters):
-            orc.orc_box_filter(P(dst_h.desc), P(src_h.desc), 5, 5)
+            run_cpu()
         dt = (time.perf_counter() - t0) / iters
         import bench_pyrlk as _bp
         cpu_extra = _bp.cpu_baseline(orc)
-        cpu = {"value": npx / dt / 1e9, "unit": "Gpixels/s", "cores": int(orc.orc_num_threads()), "kind": "port",
-               "sample": f"{iters} passes of the same 3840x2160 vuchar3 box5x5 after 1 warm-up, oracle/liboracle_omp.so (-O3 -fopenmp)", **cpu_extra}
+        cpu = {"value": npx / dt / 1e9, "unit": "Gpixels/s", "cores": os.cpu_count() if kind == "reference" else int(orc.orc_num_threads()), "kind": kind,
+               "sample": f"{iters} passes of the same 3840x2160 vuchar3 box5x5 after 1 warm-up, {what}", **cpu_extra}
 
     if rank == 0:
         out = {"metric": "Gpixels/s (4K box5x5 vuchar3)", "value": value, "unit": "Gpixels/s", "n_gpus": world, "steps": args.steps,

@@ -26,6 +26,12 @@ def load(omp=False):
     return lib
 
 
+def load_ref_omp():
+    """The reference's own headers built with its benchmark flags (-O3 -fopenmp -DNDEBUG): the CPU baseline of bench.py; None if never built."""
+    path = os.path.join(HERE, "_ref", "libvpp_ref_omp.so")
+    return ctypes.CDLL(path) if os.path.exists(path) else None
+
+
 def load_ref_video_extruder():
     """The reference's video_extruder, built with -DNDEBUG (see oracle/ref/ref_video_extruder.cpp); None if never built."""
     path = os.path.join(HERE, "_ref", "libvpp_ref_ve.so")
