@@ -188,7 +188,7 @@ def _run_pyrlk_both(lib, orc, f1, f2, kps, L=3, B=5, ws=7, min_ev=1e-4, max_err=
     return got, want, dd.cpu().numpy(), wd
 
 
-@pytest.mark.parametrize("lpk", [1, 8, 16])
+@pytest.mark.parametrize("lpk", [1, 8, 16, 32, 64])
 @pytest.mark.parametrize("ws", [5, 7, 9])
 def test_pyrlk_match_matches_oracle(lib, orc, ws, lpk):
     f1, f2, kps = lk_scene(240, 320, 500)

@@ -38,12 +38,15 @@ __device__ __forceinline__ void interp(const DImg& I, float p0, float p1, T* out
     const int rlo = -I.border, rhi = I.nr + I.border - 1, clo = -I.border, chi = I.nc + I.border - 1;
     r0 = min(max(r0, rlo), rhi); r1 = min(max(r1, rlo), rhi); c0 = min(max(c0, clo), chi); c1 = min(max(c1, clo), chi);
   }
-  const T* l1 = I.row<T>(r0);
-  const T* l2 = I.row<T>(r1);
+  // 32-bit byte offsets from the (wave-uniform) image base: one scalar base + vector offset per load instead of 64-bit
+  // pointer arithmetic per tap (images are far smaller than 2 GiB)
+  const int es = (int)sizeof(T) * CH;
+  const int o00 = r0 * I.pitch + c0 * es, o10 = r1 * I.pitch + c0 * es, o01 = r0 * I.pitch + c1 * es, o11 = r1 * I.pitch + c1 * es;
   const float w00 = (1 - a0) * (1 - a1), w10 = a0 * (1 - a1), w01 = (1 - a0) * a1, w11 = a0 * a1;
 #pragma unroll
   for (int k = 0; k < CH; k++) {
-    const float v = w00 * (float)l1[c0 * CH + k] + w10 * (float)l2[c0 * CH + k] + w01 * (float)l1[c1 * CH + k] + w11 * (float)l2[c1 * CH + k];
+    const float v = w00 * (float)((const T*)(I.p0 + o00))[k] + w10 * (float)((const T*)(I.p0 + o10))[k] + w01 * (float)((const T*)(I.p0 + o01))[k] +
+                    w11 * (float)((const T*)(I.p0 + o11))[k];
     out[k] = (T)v;  // vpp::cast<V>: truncation for integer V
   }
 }
@@ -188,12 +191,21 @@ __device__ Match lk_match_group(  // WS*WS <= 64
   wave_lds_fence();
   float G00 = 0, G01 = 0, G10 = 0, G11 = 0;
   int cpt = 0;
+  if (all_valid) {  // the common case, branch-free
 #pragma unroll
-  for (int i = 0; i < N; i++) {  // lk.hh:56-72 in offset order
-    if (all_valid || ((mask >> i) & 1ull)) {
+    for (int i = 0; i < N; i++) {  // lk.hh:56-72 in offset order
       const float gx = lds[2 * i], gy = lds[2 * i + 1];
       G00 += gx * gx; G01 += gx * gy; G10 += gx * gy; G11 += gy * gy;
-      cpt++;
+    }
+    cpt = N;
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < N; i++) {
+      if ((mask >> i) & 1ull) {
+        const float gx = lds[2 * i], gy = lds[2 * i + 1];
+        G00 += gx * gx; G01 += gx * gy; G10 += gx * gy; G11 += gy * gy;
+        cpt++;
+      }
     }
   }
   {
@@ -220,7 +232,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
     for (int q = 0; q < PPL; q++) {
       const int i = gl + q * LPK;
       float t0 = 0.f, t1 = 0.f;
-      if (i < N && ((mine >> i) & 1ull)) {
+      if (i < N && (all_valid || ((mine >> i) & 1ull))) {
         const int r = i / WS - hws, c = i % WS - hws;
         uint8_t b;
         if (b_safe) interp<uint8_t, 1, true>(B, v0 + (float)r, v1 + (float)c, &b);
@@ -232,9 +244,14 @@ __device__ Match lk_match_group(  // WS*WS <= 64
     }
     wave_lds_fence();
     float bk0 = 0.f, bk1 = 0.f;
+    if (all_valid) {
 #pragma unroll
-    for (int i = 0; i < N; i++)
-      if (all_valid || ((mask >> i) & 1ull)) { bk0 += lds[2 * i]; bk1 += lds[2 * i + 1]; }
+      for (int i = 0; i < N; i++) { bk0 += lds[2 * i]; bk1 += lds[2 * i + 1]; }
+    } else {
+#pragma unroll 1
+      for (int i = 0; i < N; i++)
+        if ((mask >> i) & 1ull) { bk0 += lds[2 * i]; bk1 += lds[2 * i + 1]; }
+    }
     nk0 = I00 * bk0 + I01 * bk1;  // lk.hh:137
     nk1 = I10 * bk0 + I11 * bk1;
     v0 += nk0; v1 += nk1;
@@ -403,10 +420,12 @@ int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, cons
   hipStream_t st = as_stream(stream);
   // lanes per keypoint: enough waves to cover the 1024 SIMDs a few times over, no more (total work grows with LPK)
   int lpk = tuning("pyrlk.lpk", 0);
-  if (lpk == 0) lpk = n >= 200000 ? 1 : (n >= 40000 ? 8 : 16);
+  if (lpk == 0) lpk = n >= 8000 ? 8 : (n >= 3500 ? 32 : 64);  // measured: tools/tune_pyrlk.py (LPK = 8 also beats 1 lane per keypoint at 400 k keypoints)
   if (winsize > 7) lpk = 1;  // the group kernels keep a 64-bit validity mask (WS*WS <= 64); larger windows: one lane per keypoint
 #define VPP_LK_LAUNCH(W)                                                                                                                           \
-  if (lpk == 16) pyrlk_match_group_kernel<W, 16><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
+  if (lpk == 64) pyrlk_match_group_kernel<W, 64><<<n, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
+  else if (lpk == 32) pyrlk_match_group_kernel<W, 32><<<(n + 1) / 2, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
+  else if (lpk == 16) pyrlk_match_group_kernel<W, 16><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
   else if (lpk == 8) pyrlk_match_group_kernel<W, 8><<<(n + 7) / 8, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
   else pyrlk_match_kernel<W><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist);
   switch (winsize) {
@@ -434,11 +453,13 @@ int vpp_lucas_kanade(const vpp_image_desc* prev, const vpp_image_desc* grad, con
   if (n == 0) return VPP_OK;
   hipStream_t st = as_stream(stream);
   int lpk = tuning("pyrlk.lpk", 0);
-  if (lpk == 0) lpk = n >= 200000 ? 1 : (n >= 40000 ? 8 : 16);
+  if (lpk == 0) lpk = n >= 8000 ? 8 : (n >= 3500 ? 32 : 64);  // measured: tools/tune_pyrlk.py (LPK = 8 also beats 1 lane per keypoint at 400 k keypoints)
   if (winsize > 7) lpk = 1;
   const float fev = (float)min_ev, fdelta = (float)delta;
 #define VPP_LK_LAUNCH(W)                                                                                                                           \
-  if (lpk == 16) lucas_kanade_group_kernel<W, 16><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
+  if (lpk == 64) lucas_kanade_group_kernel<W, 64><<<n, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
+  else if (lpk == 32) lucas_kanade_group_kernel<W, 32><<<(n + 1) / 2, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
+  else if (lpk == 16) lucas_kanade_group_kernel<W, 16><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
   else if (lpk == 8) lucas_kanade_group_kernel<W, 8><<<(n + 7) / 8, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
   else lucas_kanade_kernel<W><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist);
   switch (winsize) {
