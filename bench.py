@@ -132,6 +132,18 @@ def main():
             "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": 6 * npx, "avg_launch_us": box_kernel_s * 1e6}
     roof["frac"] = roof["achieved"] / roof["peak"]
 
+    def pmc_traffic(prefix):
+        """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json, tools/make_traffic_json.py:
+        FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate --pmc runs); None when no profile is present."""
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+            for k, v in json.load(open(path)).items():
+                if k.startswith(prefix):
+                    return v["hbm_bytes_per_launch"]
+        return None
+    roof["traffic"] = pmc_traffic("box5x5_u8_stream_kernel<3")
+    roof["traffic_source"] = "profiles/*_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled)"
+
     # ---------------- 4K int32 pixel_wise add ----------------
     nadd = 4  # 4 x 99.5 MB
     A = [DeviceImage(NR, NC, vi.I32, 1, 0, 32, dev) for _ in range(nadd)]
@@ -149,7 +161,7 @@ def main():
     add_s = aev / args.steps
     add4k = {"gpixels_per_s": npx * world / (awall / args.steps) / 1e9, "avg_launch_us": add_s * 1e6,
              "roofline": {"bound": "hbm", "kernel": "binary_flat_kernel<add,int>", "achieved": 12.0 * npx / add_s / 1e9,
-                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 12.0 * npx / add_s / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 12.0 * npx / add_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("binary_flat_kernel<0, int")}}
 
     extras = {}
     try:
