@@ -54,6 +54,23 @@ inline bool same_domain(const vpp_image_desc* a, const vpp_image_desc* b) { retu
 inline bool same_type(const vpp_image_desc* a, const vpp_image_desc* b) { return a->dtype == b->dtype && a->channels == b->channels; }
 inline bool aligned16(const vpp_image_desc* d) { return ((uintptr_t)d->first_pixel % 16) == 0 && (d->pitch % 16) == 0; }
 
+// Grow-only device scratch, one per host thread per user (the C ABI is re-entrant across host threads).  Work that uses it
+// is stream-ordered; if the same host thread comes back on a DIFFERENT stream while the previous call may still be
+// running, that stream is drained first so two in-flight calls never share the buffer.
+struct Scratch {
+  void* p = nullptr; size_t cap = 0; hipStream_t last = nullptr; bool used = false;
+  int ensure(size_t bytes, hipStream_t st) {
+    if (used && last != st) VPP_HIP_TRY(hipStreamSynchronize(last));
+    last = st; used = true;
+    if (bytes <= cap) return VPP_OK;
+    if (p) { VPP_HIP_TRY(hipStreamSynchronize(st)); VPP_HIP_TRY(hipFree(p)); p = nullptr; cap = 0; }
+    VPP_HIP_TRY(hipMalloc(&p, bytes));
+    cap = bytes;
+    return VPP_OK;
+  }
+  ~Scratch() { if (p) (void)hipFree(p); }
+};
+
 // blockIdx remap so that consecutive logical blocks share an XCD (hardware places block b on XCD b % 8;
 // MI355X_MICROARCH.md "Workgroup dispatch").  Speed only, never correctness.
 __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblocks) {

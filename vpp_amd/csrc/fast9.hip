@@ -232,19 +232,6 @@ __global__ __launch_bounds__(256) void scan_units_kernel(const uint32_t* __restr
   if (threadIdx.x == 0) *total = tot;
 }
 
-// grow-only device scratch, one per host thread (the C ABI is re-entrant across threads; calls on one thread serialise
-// on their stream anyway because the final count is read back synchronously)
-struct Scratch {
-  void* p = nullptr; size_t cap = 0;
-  int ensure(size_t bytes) {
-    if (bytes <= cap) return VPP_OK;
-    if (p) { VPP_HIP_TRY(hipFree(p)); p = nullptr; cap = 0; }
-    VPP_HIP_TRY(hipMalloc(&p, bytes));
-    cap = bytes;
-    return VPP_OK;
-  }
-  ~Scratch() { if (p) (void)hipFree(p); }
-};
 thread_local Scratch g_scratch;
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -283,7 +270,7 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   const int nunits = mode == VPP_FAST9_BLOCKWISE ? (nr + block_size - 1) / block_size : nr;
   const size_t off_f = 256, off_uc = off_f + align_up(fbytes, 256);
   const size_t off_uo = off_uc + align_up((size_t)nunits * 4, 256), total_bytes = off_uo + align_up((size_t)nunits * 4, 256);
-  int rc = g_scratch.ensure(total_bytes);
+  int rc = g_scratch.ensure(total_bytes, st);
   if (rc != VPP_OK) return rc;
   uint8_t* base = (uint8_t*)g_scratch.p;
   uint32_t* counters = (uint32_t*)base;

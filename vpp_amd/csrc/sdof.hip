@@ -383,17 +383,6 @@ __global__ __launch_bounds__(256) void sdof_readback_kernel(const int32_t* __res
   out_pos[2 * i] = o0; out_pos[2 * i + 1] = o1; out_dist[i] = d; out_valid[i] = v;
 }
 
-struct Scratch {
-  void* p = nullptr; size_t cap = 0;
-  int ensure(size_t bytes) {
-    if (bytes <= cap) return VPP_OK;
-    if (p) { VPP_HIP_TRY(hipFree(p)); p = nullptr; cap = 0; }
-    VPP_HIP_TRY(hipMalloc(&p, bytes));
-    cap = bytes;
-    return VPP_OK;
-  }
-  ~Scratch() { if (p) (void)hipFree(p); }
-};
 thread_local Scratch g_scratch;
 
 struct Carver {
@@ -440,7 +429,7 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
       pairs = cv.base ? (PairCache*)(cv.base + cv.off) : nullptr;
       cv.off += (cells * 8 * sizeof(PairCache) + 255) / 256 * 256;
     }
-    if (!pass) { int rc = g_scratch.ensure(cv.off); if (rc != VPP_OK) return rc; }
+    if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
   auto build = [&](vpp_image_desc* P, const vpp_image_desc* in) -> int {  // pyramid::update, pyramid.hh:194-198
     int rc = vpp_copy(&P[0], in, 0, stream); if (rc) return rc;
