@@ -28,9 +28,10 @@ srcs = [DeviceImage.from_host(src_h) for _ in range(ns)]; dsts = [DeviceImage(NR
 sd, dd = [s.desc for s in srcs], [d.desc for d in dsts]
 for probe in (0, 1):
     for rows in (1, 2, 4):
-        lib.vpp_set_tuning(b"box.probe", probe); lib.vpp_set_tuning(b"box.rows", rows)
-        us = time_graph(lambda i, s: lib.vpp_box_filter(P(dd[i % ns]), P(sd[i % ns]), 5, 5, s))
-        print(f"stream probe={probe} rows={rows}: {us:.2f} us")
+        for wpb in (1, 2, 4):
+            lib.vpp_set_tuning(b"box.probe", probe); lib.vpp_set_tuning(b"box.rows", rows); lib.vpp_set_tuning(b"box.waves_per_block", wpb)
+            us = time_graph(lambda i, s: lib.vpp_box_filter(P(dd[i % ns]), P(sd[i % ns]), 5, 5, s))
+            print(f"stream probe={probe} rows={rows} waves/block={wpb}: {us:.2f} us")
 a = [torch.empty(25_000_000, dtype=torch.uint8, device="cuda") for _ in range(ns)]; b = [torch.empty(25_000_000, dtype=torch.uint8, device="cuda") for _ in range(ns)]
 us = time_graph(lambda i, s: b[i % ns].copy_(a[i % ns]))
 print(f"torch copy 25 MB -> 25 MB: {us:.2f} us  ({50e6/us/1e6:.2f} TB/s)")

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, (RW <= 2 ? 8 : RW <= 4 ? 6 : 4)) void box5x5_u
   const int s = lb / nblk_y, by = lb - s * nblk_y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int x = s * kStripOut - 16 + lane * 16;
-  const int r0 = (by * 4 + wv) * RW;
+  const int r0 = (by * (int)(blockDim.x >> 6) + wv) * RW;
   if (r0 >= nrows) return;
   const bool writer = lane >= 1 && lane <= 62 && x < row_bytes;
   if (guard_ends && (r0 == 0 || r0 + RW >= nrows))
@@ -331,11 +331,13 @@ template <int CH> int launch_fast(const vpp_image_desc* dst, const vpp_image_des
     const int nstrips = (row_bytes + kStripOut - 1) / kStripOut;
     auto go = [&](auto RWc, auto NTc) {
       constexpr int RW = decltype(RWc)::value; constexpr bool NT = decltype(NTc)::value;
-      const int nblk_y = (dst->nrows + 4 * RW - 1) / (4 * RW);
+      int wpb = tuning("box.waves_per_block", 4);
+      if (wpb != 1 && wpb != 2) wpb = 4;
+      const int nblk_y = (dst->nrows + wpb * RW - 1) / (wpb * RW);
       if (CH == 3 && tuning("box.probe", 0))  // data-movement probe, never used by the product path
-        box5x5_u8_stream_kernel<CH, RW, NT, 1><<<nstrips * nblk_y, 256, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
+        box5x5_u8_stream_kernel<CH, RW, NT, 1><<<nstrips * nblk_y, 64 * wpb, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
       else
-        box5x5_u8_stream_kernel<CH, RW, NT, 0><<<nstrips * nblk_y, 256, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
+        box5x5_u8_stream_kernel<CH, RW, NT, 0><<<nstrips * nblk_y, 64 * wpb, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
     };
     auto pick = [&](auto NTc) {
       switch (th) {

@@ -60,6 +60,9 @@ __device__ __forceinline__ bool nine_contiguous(uint32_t m16) {
   return (y & 0xFFFFu) != 0;
 }
 
+// shift a comparison result into a ring mask without a compare: (m << 1) | (d < 0), one v_alignbit_b32
+__device__ __forceinline__ uint32_t push_sign(uint32_t m, int d) { return __builtin_amdgcn_alignbit(m, (uint32_t)d, 31); }
+
 template <bool REF>
 __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int has_mask, int th, DImg F) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[LROWS * LP];
@@ -90,26 +93,39 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
     int x[16];
 #pragma unroll
     for (int i = 0; i < 16; i += 4) x[i] = p[ring_dr<REF>(i) * LP + ring_dc(i)];
-    const int nb = (x[0] > vhi) + (x[4] > vhi) + (x[8] > vhi) + (x[12] > vhi);
-    const int nd = (x[0] < vlo) + (x[4] < vlo) + (x[8] < vlo) + (x[12] < vlo);
-    if (nb >= 2 || nd >= 2) {
+    // ring masks from sign bits, no compares: x brighter <=> (vhi - x) < 0, darker <=> (x - vlo) < 0; one v_alignbit shifts the
+    // sign into the mask.  First the four cardinal samples: any 9 contiguous ring positions contain two of {0, 4, 8, 12}.
+    uint32_t qb = 0, qd = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) { qb = push_sign(qb, vhi - x[i]); qd = push_sign(qd, x[i] - vlo); }
+    if ((qb & (qb - 1)) | (qd & (qd - 1))) {
 #pragma unroll
       for (int i = 0; i < 16; i++) if (i & 3) x[i] = p[ring_dr<REF>(i) * LP + ring_dc(i)];
       uint32_t mb = 0, md = 0;
 #pragma unroll
-      for (int i = 0; i < 16; i++) { mb |= (uint32_t)(x[i] > vhi) << i; md |= (uint32_t)(x[i] < vlo) << i; }
+      for (int i = 15; i >= 0; i--) { mb = push_sign(mb, vhi - x[i]); md = push_sign(md, x[i] - vlo); }
       int planes = (nine_contiguous(mb) ? 0x10 : 0) | (nine_contiguous(md) ? 0x01 : 0);
       if (has_mask && planes) planes &= M.row<uint8_t>(r)[c];
-      if (planes) {  // fast9_score on the true ring (fast.hpp:38-77); only a4/a12 differ from the REF samples
-        if (REF) { x[4] = p[3]; x[12] = p[-3]; }
-        int sum_inf = 0, sum_sup = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const int diff = v - x[i];
-          if (diff < -th) sum_inf -= diff;
-          else if (diff > th) sum_sup += diff;
+      if (planes) {
+        // fast9_score on the TRUE ring (fast.hpp:38-77), branch-free: sum over {d > th} of d = th * count + sum max(d - th, 0);
+        // the counts are popcounts of the true-ring masks (x < v - th <=> x < vlo, x > v + th <=> x > vhi for 0 <= th <= 255)
+        if (REF) {  // only a4 / a12 differ from the samples the detector used
+          x[4] = p[3]; x[12] = p[-3];
+          mb = (mb & ~0x1010u) | ((uint32_t)(vhi - x[4]) >> 31 << 4) | ((uint32_t)(vhi - x[12]) >> 31 << 12);
+          md = (md & ~0x1010u) | ((uint32_t)(x[4] - vlo) >> 31 << 4) | ((uint32_t)(x[12] - vlo) >> 31 << 12);
         }
-        f = (uint32_t)max(sum_sup, sum_inf) + 1u;
+        // sum max(dn - x, 0) = (sum |dn - x| + 16 dn - sum x) / 2 and sum max(x - up, 0) = (sum |x - up| + sum x - 16 up) / 2
+        // with dn, up clamped to a byte: three v_sad_u8 chains over the ring packed 4 samples per dword
+        const uint32_t dnc = (uint32_t)max(v - th, 0), upc = (uint32_t)min(v + th, 255);
+        const uint32_t dn4 = dnc * 0x01010101u, up4 = upc * 0x01010101u;
+        uint32_t sx = 0, sdn = 0, sup = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t X = (uint32_t)x[4 * q] | ((uint32_t)x[4 * q + 1] << 8) | ((uint32_t)x[4 * q + 2] << 16) | ((uint32_t)x[4 * q + 3] << 24);
+          sx = __builtin_amdgcn_sad_u8(X, 0u, sx); sdn = __builtin_amdgcn_sad_u8(X, dn4, sdn); sup = __builtin_amdgcn_sad_u8(X, up4, sup);
+        }
+        const int over_sup = (int)(sdn + 16u * dnc - sx) >> 1, over_inf = (int)(sup + sx - 16u * upc) >> 1;
+        f = (uint32_t)max(th * __popc(md) + over_sup, th * __popc(mb) + over_inf) + 1u;
       }
     }
     F.row<uint16_t>(r)[c] = (uint16_t)f;
