@@ -1,0 +1,21 @@
+"""Time vpp_fast9_detect (RAW / LOCAL_MAXIMA / BLOCKWISE) on a 4K frame; also the rocprofv3 target for the K7-K9 kernels."""
+import ctypes, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from util import P, u8_image, DeviceImage, rects_image
+from vpp_amd import capi
+V = ctypes.c_void_p
+lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
+im = u8_image(rects_image(2160, 3840, seed=4), border=3)
+im.view(with_border=True)[..., 0] = np.pad(im.view()[..., 0], 3, mode="symmetric")
+d = DeviceImage.from_host(im)
+cap = 3000000
+rc = torch.zeros((cap, 2), dtype=torch.int32, device="cuda"); sc = torch.zeros(cap, dtype=torch.int32, device="cuda"); n = ctypes.c_int(0)
+for mode in (0, 1, 2):
+    for _ in range(5):
+        capi.check(lib.vpp_fast9_detect(P(d.desc), 20, None, mode, 10, 0, V(rc.data_ptr()), V(sc.data_ptr()), cap, P(n), st))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50):
+        lib.vpp_fast9_detect(P(d.desc), 20, None, mode, 10, 0, V(rc.data_ptr()), V(sc.data_ptr()), cap, P(n), st)
+    torch.cuda.synchronize(); print("mode", mode, "n", n.value, (time.perf_counter() - t0) / 50 * 1e3, "ms/call")

@@ -11,9 +11,15 @@
 //                            and every lane writes the dense u16 map F(p) = score + 1 (0 = not a corner) — the reference's
 //                            scores_img (:685-694) without the intermediate keypoint list (a single global append counter
 //                            saturates at ~90 atomics/us, which measured 790 us on a 4K frame; the dense write costs 16.6 MB).
-//   2. count / scan / write  per image row (RAW, LOCAL_MAXIMA) or per row of bs x bs blocks (BLOCKWISE): decisions are
-//                            recomputed in the write pass so the output is in the serial reference order (row-major
-//                            pixels / row-major blocks), which the OpenMP reference itself does not guarantee.
+//                            Each wave also ballots its row of 64 flags into one u64 of a corner bitmap (1 bit / px) and the
+//                            edge tiles zero F's 1-px border, so no memset precedes the launch.
+//   2. count / scan / write  units in the reference's serial output order, one per thread: 16-px bitmap segments (RAW,
+//                            LOCAL_MAXIMA — the count pass rewrites a segment with the bits that survive the strict 8-neighbour
+//                            test on F) or bs x bs blocks (BLOCKWISE — one lane per block row walks the bitmap words, rows meet
+//                            in an LDS u64 max of score << 32 | ~position).  A flat exclusive scan of the unit counts gives
+//                            the output index, so the list comes out row-major (pixels / blocks) like the serial reference,
+//                            which the OpenMP reference itself does not guarantee.  4K, 454k corners: RAW
+//                            5 + 5 + 12 us, LOCAL 18 + 5 + 6 us, BLOCKWISE 13 + 5 + 6 us after the 44 us detect kernel.
 // VALU-bound (the ring test is ~100 lane-ops per pixel against 1 B/px of HBM traffic); see DESIGN.md.
 #include "common.hpp"
 #include <mutex>
@@ -64,7 +70,7 @@ __device__ __forceinline__ bool nine_contiguous(uint32_t m16) {
 __device__ __forceinline__ uint32_t push_sign(uint32_t m, int d) { return __builtin_amdgcn_alignbit(m, (uint32_t)d, 31); }
 
 template <bool REF>
-__global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int has_mask, int th, DImg F) {
+__global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int has_mask, int th, DImg F, uint64_t* __restrict__ bitmap, int ntc) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[LROWS * LP];
   const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
   const int lo = -A.border, hi = A.nc + A.border;
@@ -81,6 +87,13 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
   const int c = c0 + lane;
   if (c >= A.nc) return;
   const int thc = min(max(th, 0), 255);
+  // F's 1-px border (read by the local-maxima pass) is zeroed here instead of by separate memsets
+  if ((blockIdx.y == 0 && wv == 0) || (r0 + TH >= A.nr && wv == 1)) {
+    uint16_t* fb = F.row<uint16_t>(wv == 0 ? -1 : A.nr);
+    fb[c] = 0;
+    if (c == 0) fb[-1] = 0;
+    if (c == A.nc - 1) fb[A.nc] = 0;
+  }
 #pragma unroll 1
   for (int j = 0; j < TH / 4; j++) {
     const int lr = wv * (TH / 4) + j;
@@ -128,7 +141,12 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
         f = (uint32_t)max(th * __popc(md) + over_sup, th * __popc(mb) + over_inf) + 1u;
       }
     }
-    F.row<uint16_t>(r)[c] = (uint16_t)f;
+    uint16_t* fr = F.row<uint16_t>(r);
+    fr[c] = (uint16_t)f;
+    if (c == 0) fr[-1] = 0;
+    if (c == A.nc - 1) fr[A.nc] = 0;
+    const uint64_t corners = __ballot(f != 0);  // one 64-px word of the corner bitmap per wave and row
+    if (lane == 0) bitmap[(size_t)r * ntc + blockIdx.x] = corners;
   }
 }
 
@@ -151,6 +169,8 @@ __global__ __launch_bounds__(256) void fast9_scores_list_kernel(DImg A, int th, 
 }
 
 // ---- ordered selection -----------------------------------------------------------------------------------
+// Units are laid out in the reference's serial output order (row-major 64-px mask words for RAW / LOCAL_MAXIMA, row-major
+// blocks for BLOCKWISE), one unit per thread, so a flat exclusive scan of the per-unit counts is the output index.
 __device__ __forceinline__ uint32_t stored(uint32_t f) { return f ? (f - 1) >> 4 : 0; }  // scores_img value: score / 16 (fast.hpp:693)
 
 // exclusive prefix of `v` over the 256 threads of the block (thread order); total returned through *tot
@@ -169,71 +189,124 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* tot) {
   return off + inc - v;
 }
 
-// MODE 0 RAW, 1 LOCAL_MAXIMA: one workgroup per image row, thread t owns columns [t*K, t*K+K).
-template <int MODE, bool WRITE>
-__global__ __launch_bounds__(256) void fast9_select_rows_kernel(DImg F, int K, uint32_t* __restrict__ unit_count,
-                                                                const uint32_t* __restrict__ unit_off, int32_t* __restrict__ out_rc,
-                                                                int32_t* __restrict__ out_scores, int capacity) {
-  const int r = blockIdx.x;
-  const uint16_t* f0 = F.row<uint16_t>(r);
-  const int cbeg = threadIdx.x * K, cend = min(cbeg + K, F.nc);
-  auto decide = [&](int c, uint32_t& score) -> bool {
-    const uint32_t f = f0[c];
-    if (!f) return false;
-    if (MODE == 0) { score = f - 1; return true; }
-    const uint16_t *fm = F.row<uint16_t>(r - 1), *fp = F.row<uint16_t>(r + 1);
-    const uint32_t a = stored(f);
-    int is_max = 1;  // fast.hpp:907-921, strict >
+// RAW / LOCAL_MAXIMA unit: one 16-px segment of the corner bitmap (a u16 of the u64 word the detect wave wrote), so the
+// serial per-bit chains stay short and ~8k waves are in flight.
+constexpr int SEG = 16;
+
+// LOCAL_MAXIMA: keep the bits of a segment whose stored score is a strict maximum of its 8 neighbours (fast.hpp:907-921)
+__device__ __forceinline__ uint32_t refine_local_maxima(const DImg& F, int r, int cbase, uint32_t m) {
+  uint32_t keep = 0;
+  const uint16_t *fm = F.row<uint16_t>(r - 1), *f0 = F.row<uint16_t>(r), *fp = F.row<uint16_t>(r + 1);
+  while (m) {
+    const int b = __ffs(m) - 1;
+    m &= m - 1;
+    const int c = cbase + b;
+    const uint32_t a = stored(f0[c]);
+    int is_max = 1;
     is_max &= a > stored(fm[c - 1]); is_max &= a > stored(fm[c]); is_max &= a > stored(fm[c + 1]);
     is_max &= a > stored(f0[c - 1]); is_max &= a > stored(f0[c + 1]);
     is_max &= a > stored(fp[c - 1]); is_max &= a > stored(fp[c]); is_max &= a > stored(fp[c + 1]);
-    score = a;
-    return is_max != 0;
-  };
-  uint32_t cnt = 0, sc;
-  for (int c = cbeg; c < cend; c++) cnt += decide(c, sc) ? 1u : 0u;
-  uint32_t tot;
-  const uint32_t ex = block_exscan(cnt, &tot);
-  if (!WRITE) { if (threadIdx.x == 0) unit_count[r] = tot; return; }
-  uint32_t k = unit_off[r] + ex;
-  for (int c = cbeg; c < cend; c++)
-    if (decide(c, sc)) {
-      if ((int)k < capacity) { out_rc[2 * k] = r; out_rc[2 * k + 1] = c; if (out_scores) out_scores[k] = (int32_t)sc; }
-      k++;
-    }
+    if (is_max) keep |= 1u << b;
+  }
+  return keep;
 }
 
-// BLOCKWISE: one workgroup per row of bs x bs blocks; thread t owns block columns [t*K, t*K+K).
-template <bool WRITE>
-__global__ __launch_bounds__(256) void fast9_select_blocks_kernel(DImg F, int bs, int nbc, int K, uint32_t* __restrict__ unit_count,
-                                                                  const uint32_t* __restrict__ unit_off, int32_t* __restrict__ out_rc,
-                                                                  int32_t* __restrict__ out_scores, int capacity) {
-  const int r = blockIdx.x * bs;
-  const int bbeg = threadIdx.x * K, bend = min(bbeg + K, nbc);
-  auto decide = [&](int b, int& pr, int& pc, uint32_t& vmax) -> bool {  // fast.hpp:770-789: first strict max in scan order
-    const int c = b * bs;
-    vmax = 0; pr = 0; pc = 0;
-    for (int br = 0; br < bs; br++) {
-      if (r + br >= F.nr) break;
-      const uint16_t* f = F.row<uint16_t>(r + br);
-      for (int bc = c; bc < c + bs && bc < F.nc; bc++) {
-        const uint32_t v = stored(f[bc]);
-        if (v > vmax) { vmax = v; pr = br; pc = bc; }
+// pass 1, RAW / LOCAL_MAXIMA: per-segment keypoint count (LOCAL rewrites the segment with the surviving bits)
+template <int MODE>
+__global__ __launch_bounds__(256) void fast9_count_segs_kernel(DImg F, uint16_t* __restrict__ segs, int nsc, int nsegs,
+                                                               uint32_t* __restrict__ unit_count) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  uint32_t m = u < nsegs ? segs[u] : 0;
+  if (MODE == 1 && m) {
+    const int r = u / nsc, sc = u - r * nsc;
+    m = refine_local_maxima(F, r, sc * SEG, m);
+    segs[u] = (uint16_t)m;
+  }
+  uint32_t tot;
+  block_exscan((uint32_t)__popc(m), &tot);
+  if (threadIdx.x == 0) unit_count[blockIdx.x] = tot;
+}
+
+// pass 3, RAW / LOCAL_MAXIMA: ordered write
+template <int MODE>
+__global__ __launch_bounds__(256) void fast9_write_segs_kernel(DImg F, const uint16_t* __restrict__ segs, int nsc, int nsegs,
+                                                               const uint32_t* __restrict__ unit_off, int32_t* __restrict__ out_rc,
+                                                               int32_t* __restrict__ out_scores, int capacity) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  uint32_t m = u < nsegs ? segs[u] : 0;
+  uint32_t tot;
+  uint32_t k = unit_off[blockIdx.x] + block_exscan((uint32_t)__popc(m), &tot);
+  if (!m) return;
+  const int r = u / nsc, cbase = (u - r * nsc) * SEG;
+  const uint16_t* f0 = F.row<uint16_t>(r);
+  while (m) {
+    const int c = cbase + __ffs(m) - 1;
+    m &= m - 1;
+    if ((int)k < capacity) {
+      out_rc[2 * (size_t)k] = r; out_rc[2 * (size_t)k + 1] = c;
+      if (out_scores) out_scores[k] = MODE == 0 ? (int32_t)f0[c] - 1 : (int32_t)stored(f0[c]);
+    }
+    k++;
+  }
+}
+
+// pass 1, BLOCKWISE: first strict maximum of each bs x bs block in scan order (fast.hpp:770-789).  Only corner pixels (bits of
+// the detect bitmap) can raise the maximum, so a lane takes one block row through its mask words; the rows of a block meet in
+// an LDS max over the key (score << 32 | ~position): largest score first, then the earliest row-major position.
+// A workgroup owns G = 256 / RB consecutive blocks (RB = min(bs, 256) lanes per block).
+__global__ __launch_bounds__(256) void fast9_count_blocks_kernel(DImg F, const uint64_t* __restrict__ bitmap, int ntc, int bs, int nbc,
+                                                                 int nblocks, int RB, int G, uint2* __restrict__ blkres,
+                                                                 uint32_t* __restrict__ unit_count) {
+  __shared__ unsigned long long key[256];
+  key[threadIdx.x] = 0;
+  __syncthreads();
+  const int g = threadIdx.x / RB, row = threadIdx.x - g * RB;
+  const int b = blockIdx.x * G + g;
+  if (g < G && b < nblocks) {
+    const int br = b / nbc, bc = b - br * nbc;
+    const int r0 = br * bs, c0 = bc * bs, r1 = min(r0 + bs, F.nr), c1 = min(c0 + bs, F.nc);
+    const int w0 = c0 >> 6, w1 = (c1 - 1) >> 6;
+    unsigned long long best = 0;
+    for (int r = r0 + row; r < r1; r += RB) {
+      const uint16_t* f = F.row<uint16_t>(r);
+      for (int w = w0; w <= w1; w++) {
+        uint64_t m = bitmap[(size_t)r * ntc + w];
+        const int lo = max(c0 - w * 64, 0), hi = min(c1 - w * 64, 64);  // bit range [lo, hi) of this word
+        m >>= lo;
+        if (hi - lo < 64) m &= (1ull << (hi - lo)) - 1;
+        while (m) {
+          const int c = w * 64 + lo + __ffsll((unsigned long long)m) - 1;
+          m &= m - 1;
+          const unsigned long long k = ((unsigned long long)stored(f[c]) << 32) | (0xFFFFFFFFu - (((uint32_t)r << 16) | (uint32_t)c));
+          if ((k >> 32) && k > best) best = k;
+        }
       }
     }
-    return vmax > 0;
-  };
-  uint32_t cnt = 0, vm; int pr, pc;
-  for (int b = bbeg; b < bend; b++) cnt += decide(b, pr, pc, vm) ? 1u : 0u;
+    if (best) atomicMax(&key[g], best);
+  }
+  __syncthreads();
+  uint32_t has = 0;
+  if ((int)threadIdx.x < G && blockIdx.x * G + (int)threadIdx.x < nblocks) {
+    const unsigned long long k = key[threadIdx.x];
+    has = k ? 1u : 0u;
+    blkres[blockIdx.x * G + threadIdx.x] = make_uint2(0xFFFFFFFFu - (uint32_t)k, (uint32_t)(k >> 32));
+  }
   uint32_t tot;
-  const uint32_t ex = block_exscan(cnt, &tot);
-  if (!WRITE) { if (threadIdx.x == 0) unit_count[blockIdx.x] = tot; return; }
-  uint32_t k = unit_off[blockIdx.x] + ex;
-  for (int b = bbeg; b < bend; b++)
-    if (decide(b, pr, pc, vm)) {
-      if ((int)k < capacity) { out_rc[2 * k] = r + pr; out_rc[2 * k + 1] = pc; if (out_scores) out_scores[k] = (int32_t)vm; }
-      k++;
-    }
+  block_exscan(has, &tot);
+  if (threadIdx.x == 0) unit_count[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void fast9_write_blocks_kernel(const uint2* __restrict__ blkres, int nblocks, int G,
+                                                                 const uint32_t* __restrict__ unit_off, int32_t* __restrict__ out_rc,
+                                                                 int32_t* __restrict__ out_scores, int capacity) {
+  const int b = blockIdx.x * G + threadIdx.x;
+  const uint2 res = ((int)threadIdx.x < G && b < nblocks) ? blkres[b] : make_uint2(0, 0);
+  uint32_t tot;
+  const uint32_t k = unit_off[blockIdx.x] + block_exscan(res.y > 0 ? 1u : 0u, &tot);
+  if (res.y > 0 && (int)k < capacity) {
+    out_rc[2 * (size_t)k] = (int32_t)(res.x >> 16); out_rc[2 * (size_t)k + 1] = (int32_t)(res.x & 0xFFFFu);
+    if (out_scores) out_scores[k] = (int32_t)res.y;
+  }
 }
 
 // exclusive scan of n unit counts (single workgroup), total -> *total
@@ -280,48 +353,51 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   }
   hipStream_t st = as_stream(stream);
   const int nr = src->nrows, nc = src->ncols;
-  // scratch layout: [counters: total][F: u16 map with border 1][unit_count][unit_off]
+  // scratch layout: [total][F: u16 map with border 1][bitmap: one u64 per 64-px row segment][blkres][unit_count][unit_off]
   int32_t fpitch; size_t fbytes, ffirst;
   vpp_image_layout(nr, nc, 2, 1, 16, &fpitch, &fbytes, &ffirst);
-  const int nunits = mode == VPP_FAST9_BLOCKWISE ? (nr + block_size - 1) / block_size : nr;
-  const size_t off_f = 256, off_uc = off_f + align_up(fbytes, 256);
-  const size_t off_uo = off_uc + align_up((size_t)nunits * 4, 256), total_bytes = off_uo + align_up((size_t)nunits * 4, 256);
+  const int ntc = (nc + TW - 1) / TW, nwords = nr * ntc;
+  const int nbr = mode == VPP_FAST9_BLOCKWISE ? (nr + block_size - 1) / block_size : 0;
+  const int nbc = mode == VPP_FAST9_BLOCKWISE ? (nc + block_size - 1) / block_size : 0;
+  const long long nblocks_ll = (long long)nbr * nbc;
+  VPP_REQUIRE(nblocks_ll < (1ll << 31), VPP_ERR_UNSUPPORTED, "vpp_fast9_detect: too many blocks");
+  const int nblocks = (int)nblocks_ll;
+  const int RB = block_size < 256 ? (block_size > 0 ? block_size : 1) : 256, G = 256 / RB;   // BLOCKWISE: lanes per block, blocks per workgroup
+  const int nsc = ntc * (TW / SEG), nsegs = nr * nsc;                                        // RAW / LOCAL: 16-px segments
+  const int ngroups = mode == VPP_FAST9_BLOCKWISE ? (nblocks + G - 1) / G : (nsegs + 255) / 256;
+  const size_t off_f = 256, off_bm = off_f + align_up(fbytes, 256), off_br = off_bm + align_up((size_t)nwords * 8, 256);
+  const size_t off_uc = off_br + align_up((size_t)nblocks * 8, 256);
+  const size_t off_uo = off_uc + align_up((size_t)ngroups * 4, 256), total_bytes = off_uo + align_up((size_t)ngroups * 4, 256);
   int rc = g_scratch.ensure(total_bytes, st);
   if (rc != VPP_OK) return rc;
   uint8_t* base = (uint8_t*)g_scratch.p;
-  uint32_t* counters = (uint32_t*)base;
+  uint32_t* d_total = (uint32_t*)base;
   DImg F{base + off_f + ffirst, nr, nc, fpitch, 1, VPP_U16, 1};
+  uint64_t* bitmap = (uint64_t*)(base + off_bm);
+  uint2* blkres = (uint2*)(base + off_br);
   uint32_t* unit_count = (uint32_t*)(base + off_uc);
   uint32_t* unit_off = (uint32_t*)(base + off_uo);
-  // zero the counters and F's 1-px border (the detect kernel writes every domain pixel): first / last row + the strips between rows
-  VPP_HIP_TRY(hipMemsetAsync(base, 0, off_f + (size_t)fpitch + ffirst, st));
-  VPP_HIP_TRY(hipMemsetAsync(base + off_f + (size_t)(nr + 1) * fpitch, 0, fpitch, st));
-  VPP_HIP_TRY(hipMemset2DAsync(base + off_f + ffirst + (size_t)nc * 2, fpitch, 0, (size_t)fpitch - (size_t)nc * 2, (size_t)nr, st));
   DImg A = dimg(src), M = mask ? dimg(mask) : A;
-  dim3 grid((nc + TW - 1) / TW, (nr + TH - 1) / TH);
-  if (compat == VPP_FAST9_REFERENCE) fast9_detect_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F);
-  else fast9_detect_kernel<false><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F);
+  dim3 grid(ntc, (nr + TH - 1) / TH);
+  if (compat == VPP_FAST9_REFERENCE) fast9_detect_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
+  else fast9_detect_kernel<false><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
   VPP_LAUNCH_CHECK();
   if (mode == VPP_FAST9_BLOCKWISE) {
-    const int nbc = (nc + block_size - 1) / block_size, K = (nbc + 255) / 256;
-    fast9_select_blocks_kernel<false><<<nunits, 256, 0, st>>>(F, block_size, nbc, K, unit_count, unit_off, out_rc, out_scores, capacity);
-    scan_units_kernel<<<1, 256, 0, st>>>(unit_count, unit_off, nunits, counters + 1);
-    fast9_select_blocks_kernel<true><<<nunits, 256, 0, st>>>(F, block_size, nbc, K, unit_count, unit_off, out_rc, out_scores, capacity);
+    fast9_count_blocks_kernel<<<ngroups, 256, 0, st>>>(F, bitmap, ntc, block_size, nbc, nblocks, RB, G, blkres, unit_count);
+    scan_units_kernel<<<1, 256, 0, st>>>(unit_count, unit_off, ngroups, d_total);
+    fast9_write_blocks_kernel<<<ngroups, 256, 0, st>>>(blkres, nblocks, G, unit_off, out_rc, out_scores, capacity);
+  } else if (mode == VPP_FAST9_RAW) {
+    fast9_count_segs_kernel<0><<<ngroups, 256, 0, st>>>(F, (uint16_t*)bitmap, nsc, nsegs, unit_count);
+    scan_units_kernel<<<1, 256, 0, st>>>(unit_count, unit_off, ngroups, d_total);
+    fast9_write_segs_kernel<0><<<ngroups, 256, 0, st>>>(F, (const uint16_t*)bitmap, nsc, nsegs, unit_off, out_rc, out_scores, capacity);
   } else {
-    const int K = (nc + 255) / 256;
-    if (mode == VPP_FAST9_RAW) {
-      fast9_select_rows_kernel<0, false><<<nunits, 256, 0, st>>>(F, K, unit_count, unit_off, out_rc, out_scores, capacity);
-      scan_units_kernel<<<1, 256, 0, st>>>(unit_count, unit_off, nunits, counters + 1);
-      fast9_select_rows_kernel<0, true><<<nunits, 256, 0, st>>>(F, K, unit_count, unit_off, out_rc, out_scores, capacity);
-    } else {
-      fast9_select_rows_kernel<1, false><<<nunits, 256, 0, st>>>(F, K, unit_count, unit_off, out_rc, out_scores, capacity);
-      scan_units_kernel<<<1, 256, 0, st>>>(unit_count, unit_off, nunits, counters + 1);
-      fast9_select_rows_kernel<1, true><<<nunits, 256, 0, st>>>(F, K, unit_count, unit_off, out_rc, out_scores, capacity);
-    }
+    fast9_count_segs_kernel<1><<<ngroups, 256, 0, st>>>(F, (uint16_t*)bitmap, nsc, nsegs, unit_count);
+    scan_units_kernel<<<1, 256, 0, st>>>(unit_count, unit_off, ngroups, d_total);
+    fast9_write_segs_kernel<1><<<ngroups, 256, 0, st>>>(F, (const uint16_t*)bitmap, nsc, nsegs, unit_off, out_rc, out_scores, capacity);
   }
   VPP_LAUNCH_CHECK();
   uint32_t total = 0;
-  VPP_HIP_TRY(hipMemcpyAsync(&total, counters + 1, sizeof total, hipMemcpyDeviceToHost, st));
+  VPP_HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, st));
   VPP_HIP_TRY(hipStreamSynchronize(st));
   *count = (int)total;
   if ((int)total > capacity) {
