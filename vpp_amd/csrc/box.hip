@@ -27,19 +27,16 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // ---- fast path -------------------------------------------------------------------------------------------
 // packed u16 pairs over the 32-B window: e[i] = bytes (4i, 4i+2), o[i] = bytes (4i+1, 4i+3)
 
-// Dword at byte offset `off` (multiple of 4) of a row whose addressable bytes are [lo, hi).  Fully inside: one
-// aligned load.  Straddling an end: branch-free byte loads from clamped addresses (all issued back to back).
+// Dword at byte offset `off` of a row whose addressable bytes are [lo, hi), hi - lo >= 4: bytes outside read as 0.
+// Branch-free: one (possibly unaligned) dword load from the offset clamped into [lo, hi - 4], then the loaded bytes are
+// shifted to where they belong; a dword wholly outside shifts to 0.
 __device__ __forceinline__ uint32_t ld_dword_guarded(const uint8_t* __restrict__ p, int off, int lo, int hi) {
-  if (off >= lo && off + 4 <= hi) return *(const uint32_t*)(p + off);
-  uint32_t v = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int q = off + k;
-    const int qc = min(max(q, lo), hi - 1);
-    const uint32_t b = p[qc];
-    v |= (q >= lo && q < hi) ? (b << (8 * k)) : 0u;
-  }
-  return v;
+  const int a = min(max(off, lo), hi - 4);
+  uint32_t v;
+  __builtin_memcpy(&v, p + a, 4);
+  const int sh = a - off;                       // > 0: loaded later bytes -> move them up; < 0: loaded earlier bytes -> move down
+  const uint32_t up = sh >= 4 ? 0u : v << (8 * (sh & 3)), dn = sh <= -4 ? 0u : v >> (8 * (-sh & 3));
+  return sh >= 0 ? up : dn;
 }
 
 // 16-byte chunk at byte offset gx of a row; GUARD: dwords not wholly inside [lo, hi) are assembled bytewise.
