@@ -3,10 +3,13 @@ min_ev 1e-4, max_err 500, 30 iterations, delta 0.01.  Keypoints are sharded cont
 ([g*N/G, (g+1)*N/G), pyrlk_match.hh:24 iterates independent keypoints); every rank holds both pyramids; one exchange:
 an RCCL all-gather of the 20-byte keypoint records.  Also the FAST-9 4K leg (configs[2], replicas)."""
 import ctypes
+import os
 import sys
 import time
 
 import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
 def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
@@ -104,6 +107,30 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     dt = (time.perf_counter() - t0) / it
     res["semi_dense_flow_4k"] = {"ms_per_frame_pair": dt * 1e3, "frame_pairs_per_s": world / dt, "keypoints": m,
                                  "note": "one frame pair per GPU (replicas); serial-order semantics, bit-exact vs the oracle"}
+
+    # frame ingest: 4K vuchar3 frame -> gray with a mirror-filled border of 3 in one pass; 4 B/px algorithmic
+    from util import rand_image
+    nin = 8  # 8 x (24.9 + 8.3 MB) > 256 MiB
+    rgb_h = rand_image(2160, 3840, vi.U8, 3, border=0, seed=6)
+    rgbs = [DeviceImage.from_host(rgb_h, dev) for _ in range(nin)]; grays = [DeviceImage(2160, 3840, vi.U8, 1, 3, 32, dev) for _ in range(nin)]
+    rd, gdsc = [x.desc for x in rgbs], [x.desc for x in grays]
+    isteps = 1000
+    iwall, iev = timed(lambda i, s: lib.vpp_rgb_to_graylevel(P(gdsc[i % nin]), P(rd[i % nin]), 1, s), isteps, 100, graph=True)
+    ibytes = 2160 * 3840 * 4
+    res["ingest_4k"] = {"workload": "vuchar3 3840x2160 -> uchar + mirror border 3 (clone + fill_border_mirror + rgb_to_graylevel fused)",
+                        "us_per_frame": iev / isteps * 1e6, "gpixels_per_s": 2160 * 3840 * world / (iwall / isteps) / 1e9,
+                        "roofline": {"bound": "hbm", "achieved": ibytes / (iev / isteps) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": ibytes / (iev / isteps) / 1e9 / 8000.0}}
+
+    # video_extruder_update on 4K frames through the C++ drop-in surface (benchmarks/video_extruder_bench.cc), rank 0 only
+    exe = os.path.join(ROOT, "benchmarks", "video_extruder_bench")
+    if rank == 0 and os.path.exists(exe):
+        import json, subprocess
+        try:
+            out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+            res["video_extruder_4k"] = json.loads(out.stdout.strip().splitlines()[-1])
+            res["video_extruder_4k"].pop("per_update_ms", None)
+        except Exception as e:  # noqa: BLE001
+            res["video_extruder_4k"] = {"error": str(e)}
     return res
 
 

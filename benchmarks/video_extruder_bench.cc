@@ -1,0 +1,68 @@
+// video_extruder_bench.cc — frames/s of video_extruder_update on 4K frames (defaults of
+// video_extruder.hpp:35-41 — th 10, spacing 10, period 5, nscales 3, winsize 9, propagation 2), written against the
+// drop-in <vpp/...> surface exactly like the reference's examples/video_extruder.cc:44-58 loop.
+// usage: video_extruder_bench [nrows ncols nframes]   -> one JSON line on stdout
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#define VPP_AMD_TIMING 1
+#include <vpp/vpp.hh>
+#include <vpp/algorithms/video_extruder.hh>
+
+using namespace vpp;
+typedef std::chrono::steady_clock clk;
+static double ms(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+int main(int argc, char** argv) {
+  const int nr = argc > 1 ? std::atoi(argv[1]) : 2160, nc = argc > 2 ? std::atoi(argv[2]) : 3840, T = argc > 3 ? std::atoi(argv[3]) : 12;
+  // smooth random texture (3 box blurs of white noise) + high-contrast rectangles, translated by (1, 2) px per frame
+  const int W = nc + 2 * T + 32, H = nr + T + 32;
+  std::mt19937 rng(6);
+  std::vector<float> a(size_t(W) * H), b(a.size());
+  for (auto& x : a) x = float(rng() & 0xFFFF);
+  for (int pass = 0; pass < 3; pass++) {
+    for (int r = 0; r < H; r++) for (int c = 2; c < W - 2; c++) b[size_t(r) * W + c] = (a[size_t(r) * W + c - 2] + a[size_t(r) * W + c - 1] + a[size_t(r) * W + c] + a[size_t(r) * W + c + 1] + a[size_t(r) * W + c + 2]) / 5;
+    for (int r = 2; r < H - 2; r++) for (int c = 0; c < W; c++) a[size_t(r) * W + c] = (b[size_t(r - 2) * W + c] + b[size_t(r - 1) * W + c] + b[size_t(r) * W + c] + b[size_t(r + 1) * W + c] + b[size_t(r + 2) * W + c]) / 5;
+  }
+  float lo = 1e30f, hi = -1e30f;
+  for (int r = 8; r < H - 8; r++) for (int c = 8; c < W - 8; c++) { lo = std::min(lo, a[size_t(r) * W + c]); hi = std::max(hi, a[size_t(r) * W + c]); }
+  std::vector<unsigned char> scene(a.size());
+  for (size_t i = 0; i < a.size(); i++) scene[i] = (unsigned char)std::min(255.f, std::max(0.f, (a[i] - lo) / (hi - lo) * 255.f));
+  for (int k = 0; k < (nr / 40) * (nc / 40); k++) {
+    const int r = 8 + rng() % (H - 40), c = 8 + rng() % (W - 40), h = 6 + rng() % 18, w = 6 + rng() % 18, v = rng() & 255;
+    for (int i = 0; i < h; i++) for (int j = 0; j < w; j++) scene[size_t(r + i) * W + c + j] = (unsigned char)v;
+  }
+  std::vector<image2d<unsigned char>> frames;
+  for (int t = 0; t < T; t++) {
+    image2d<unsigned char> f(nr, nc, _border = 3);
+    for (int r = 0; r < nr; r++) for (int c = 0; c < nc; c++) f(r, c) = scene[size_t(r + 8 + (T - t)) * W + c + 8 + 2 * (T - t)];  // content moves by (+1, +2) per frame
+    fill_border_mirror(f);
+    frames.push_back(f);
+  }
+  video_extruder_ctx ctx = video_extruder_init(make_box2d(nr, nc));
+  std::vector<double> per;
+  std::vector<int> nk;
+  for (int t = 1; t < T; t++) {
+    const auto t0 = clk::now();
+    video_extruder_update(ctx, frames[t - 1], frames[t], _detector_th = 10, _keypoint_spacing = 10, _detector_period = 5, _max_trajectory_length = 15,
+                          _nscales = 3, _winsize = 9, _propagation = 2);
+    per.push_back(ms(t0, clk::now()));
+    nk.push_back(ctx.keypoints.size());
+    if (t == 1) ve_internals::timing() = ve_internals::timing_t();  // the first update only detects (no keypoints yet): excluded from the breakdown
+  }
+  int alive = 0, good = 0;
+  for (int i = 0; i < ctx.keypoints.size(); i++) if (ctx.keypoints[i].alive()) { alive++; good += ctx.keypoints[i].velocity == vint2(1, 2); }
+  double sum = 0; for (size_t i = 1; i < per.size(); i++) sum += per[i];
+  const double mean = sum / double(per.size() - 1);
+  const auto& tm = ve_internals::timing();
+  const double n = double(per.size() - 1);
+  std::printf("{\"workload\": \"video_extruder_update %dx%d uchar, defaults (th 10, spacing 10, period 5, 3 scales, winsize 9, 2 sweeps), %d updates after the detecting one\", "
+              "\"ms_per_update\": %.3f, \"frames_per_s\": %.2f, \"keypoints\": %d, \"alive\": %d, \"velocity_ok\": %d, "
+              "\"breakdown_ms\": {\"flow\": %.3f, \"merge\": %.3f, \"scores\": %.3f, \"redetect\": %.3f, \"trajectories\": %.3f}, \"per_update_ms\": [",
+              nr, nc, int(per.size() - 1), mean, 1000.0 / mean, ctx.keypoints.size(), alive, good, tm.flow / n, tm.merge / n, tm.scores / n, tm.redetect / n, tm.traj / n);
+  for (size_t i = 0; i < per.size(); i++) std::printf("%s%.2f", i ? ", " : "", per[i]);
+  std::printf("]}\n");
+  return alive > 0 && good > alive / 2 ? 0 : 1;
+}

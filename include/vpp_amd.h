@@ -148,6 +148,19 @@ int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_image_desc* 
                                 int winsize, int nscales, int min_scale, int propagation, int patchsize,
                                 int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, void* stream);
 
+/* ---- the steps either side of the algorithms in the reference's video loop (examples/video_extruder.cc:44-58) ---- */
+/* rgb_to_graylevel (vpp/core/colorspace_conversions.hh:10-33; 4-channel input :36-48 ignores the 4th component):
+ * dst (u8 x1) = (c0 + c1 + c2) / 3, integer.  mirror == 0: the reference call — mapped over the domain extended by
+ * min(dst.border, src.border) (the reference maps domain_with_border of equal-border images).  mirror != 0: frame
+ * ingest — dst's WHOLE border is written with the gray value of the mirrored source pixel, i.e. the result of
+ * `clone(frame, _border = b); fill_border_mirror(frame); rgb_to_graylevel<uchar>(frame)` in one pass; src's border
+ * is not read (it may be 0). */
+int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream);
+/* Re-detection mask of video_extruder (video_extruder/video_extruder.hpp:95-110): mask (u8 x1) = 1 over its domain
+ * with border, then 0 over [r - spacing, r + spacing) x [c - spacing, c + spacing) for each of the n (row, col) int32
+ * pairs in DEVICE memory (clipped to the mask's border). */
+int vpp_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -723,4 +723,51 @@ int orc_semi_dense_optical_flow(const vpp_image_desc* i1d, const vpp_image_desc*
   return VPP_OK;
 }
 
+// rgb_to_graylevel: `o = (i[0] + i[1] + i[2]) / 3` (colorspace_conversions.hh:10-20) mapped over domain_with_border
+// (:27-31; the 4-channel overload :41-45 takes segment<3>(0)).  uchar components promote to int, the quotient is stored
+// back into the uchar.  mirror != 0 restates the ingest chain literally (examples/video_extruder.cc:46-48):
+// clone(frame, _border = b) -> fill_border_mirror -> rgb_to_graylevel.
+int orc_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror) {
+  Img d(dst), s(src);
+  if (d.dtype != VPP_U8 || d.ch != 1 || s.dtype != VPP_U8 || (s.ch != 3 && s.ch != 4)) return VPP_ERR_UNSUPPORTED;
+  if (d.nr != s.nr || d.nc != s.nc) return VPP_ERR_INVALID_ARG;
+  OwnedImg tmp;
+  int ext = d.border < s.border ? d.border : s.border;
+  if (mirror) {
+    ext = d.border;
+    if (ext > d.nr || ext > d.nc) return VPP_ERR_INVALID_ARG;
+    tmp.alloc(s.nr, s.nc, VPP_U8, s.ch, ext);
+    for (int r = 0; r < s.nr; r++) std::memcpy(tmp.v.row<uint8_t>(r), s.row<uint8_t>(r), (size_t)s.nc * s.ch);  // clone: copy.hh:10-17
+    vpp_image_desc td = {tmp.v.p0, tmp.v.nr, tmp.v.nc, tmp.v.pitch, tmp.v.border, tmp.v.dtype, tmp.v.ch};
+    int st = orc_fill_border(&td, VPP_BORDER_MIRROR, nullptr);
+    if (st != VPP_OK) return st;
+    s = tmp.v;
+  }
+  for (int r = -ext; r < d.nr + ext; r++) {
+    const uint8_t* i = s.row<uint8_t>(r);
+    uint8_t* o = d.row<uint8_t>(r);
+    for (int c = -ext; c < d.nc + ext; c++) o[c] = (uint8_t)((i[c * s.ch] + i[c * s.ch + 1] + i[c * s.ch + 2]) / 3);
+  }
+  return VPP_OK;
+}
+
+// video_extruder.hpp:101-110: fill_with_border(mask, 1), then a 2s x 2s square of zeros per keypoint (every container
+// entry, dead ones included).  The reference does not clip (keypoints lie inside the domain and border == spacing);
+// writes outside the mask's border are dropped here.
+int orc_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing) {
+  Img m(mask);
+  if (m.dtype != VPP_U8 || m.ch != 1) return VPP_ERR_UNSUPPORTED;
+  if (spacing <= 0 || n < 0) return VPP_ERR_INVALID_ARG;
+  for (int r = -m.border; r < m.nr + m.border; r++) std::memset(m.row<uint8_t>(r) - m.border, 1, (size_t)m.nc + 2 * m.border);
+  for (int i = 0; i < n; i++) {
+    const int r = rc[2 * i], c = rc[2 * i + 1];
+    for (int dr = -spacing; dr < spacing; dr++)
+      for (int dc = -spacing; dc < spacing; dc++) {
+        const int y = r + dr, x = c + dc;
+        if (y >= -m.border && y < m.nr + m.border && x >= -m.border && x < m.nc + m.border) m.row<uint8_t>(y)[x] = 0;
+      }
+  }
+  return VPP_OK;
+}
+
 }  // extern "C"

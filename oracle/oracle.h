@@ -46,6 +46,11 @@ int orc_is_fast9_keypoint(const vpp_image_desc* src, int r, int c, int th);
  * value AFTER the cast back to V (so integers for integer V). */
 int orc_linear_interpolate(const vpp_image_desc* img, float pr, float pc, float* out);
 
+/* colorspace_conversions.hh:10-33,36-48 (+ the ingest chain of examples/video_extruder.cc:46-48 when mirror != 0) */
+int orc_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror);
+/* video_extruder/video_extruder.hpp:95-110 (rc: n host (row, col) pairs) */
+int orc_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing);
+
 #ifdef __cplusplus
 }
 #endif

@@ -225,5 +225,24 @@ int ref_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_image_desc* 
   return 0;
 }
 
+// rgb_to_graylevel<unsigned char>(image2d<vuchar3 | vuchar4>) (colorspace_conversions.hh:22-48); mirror != 0: the ingest chain of
+// examples/video_extruder.cc:46-48 — clone(frame, _border = b); fill_border_mirror(frame); rgb_to_graylevel<unsigned char>(frame).
+int ref_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror) {
+  if (!is(dst, VPP_U8, 1)) return VPP_ERR_UNSUPPORTED;
+  if (is(src, VPP_U8, 3)) {
+    auto S = wrap<vuchar3>(src);
+    if (mirror) { auto F = clone(S, _border = (int)dst->border); fill_border_mirror(F); export_image(rgb_to_graylevel<unsigned char>(F), dst); }
+    else export_image(rgb_to_graylevel<unsigned char>(S), dst);
+    return 0;
+  }
+  if (is(src, VPP_U8, 4)) {
+    auto S = wrap<vuchar4>(src);
+    if (mirror) { auto F = clone(S, _border = (int)dst->border); fill_border_mirror(F); export_image(rgb_to_graylevel<unsigned char>(F), dst); }
+    else export_image(rgb_to_graylevel<unsigned char>(S), dst);
+    return 0;
+  }
+  return VPP_ERR_UNSUPPORTED;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -238,8 +238,27 @@ static void test_video_extruder_vs_reference() {
 }
 #endif
 
+static void test_frame_ingest() {
+  // examples/video_extruder.cc:46-48: clone with border 3, mirror, gray — stepwise (device kernels) and fused
+  image2d<vuchar3> frame(135, 241);
+  for (auto p : frame.domain()) frame(p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
+  auto f = clone(frame, _border = 3);
+  fill_border_mirror(f);
+  image2d<unsigned char> stepwise = rgb_to_graylevel<unsigned char>(f);      // vpp_rgb_to_graylevel(mirror = 0)
+  image2d<unsigned char> fused = rgb_to_graylevel_mirror(frame, 3);          // vpp_rgb_to_graylevel(mirror = 1)
+  image2d<unsigned char> want(135, 241, _border = 3);
+  const vpp_image_desc dw = host_desc(want), dfr = host_desc(frame);
+  CHECK(orc_rgb_to_graylevel(&dw, &dfr, 1) == 0);
+  for (int r = -3; r < 138; r++) for (int c = -3; c < 244; c++) CHECK(stepwise(r, c) == want(r, c) && fused(r, c) == want(r, c));
+  // the same pixels from the host expression engine on the reference's lambda
+  image2d<unsigned char> host(f.domain(), _border = 3);
+  pixel_wise(f.domain_with_border(), f, host) | [](vint2, const vuchar3& i, unsigned char& o) { o = (i[0] + i[1] + i[2]) / 3; };
+  for (int r = -3; r < 138; r++) for (int c = -3; c < 244; c++) CHECK(host(r, c) == want(r, c));
+}
+
 int main() {
   CHECK(vpp_init(0) == 0);
+  test_frame_ingest();
   test_pixel_wise_functors();
   test_fast9();
   test_pyrlk();

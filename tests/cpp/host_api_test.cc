@@ -107,7 +107,24 @@ static void test_block_wise_and_fill() {
   kc.remove(1); kc.compact(); CHECK(kc.size() == 1 && kc.has(vint2(4, 4)) && !kc.has(vint2(5, 6)));
 }
 
+static void test_colorspace_conversions() {                                  // tests/colorspace_conversions.cc
+  image2d<vuchar3> i1(100, 100);
+  unsigned char i = 0;
+  for (vint2 p : i1.domain()) { i1(p) = vuchar3(i, i, i); i++; }
+  image2d<vuchar1> i2 = rgb_to_graylevel<vuchar1>(i1);
+  i = 0;
+  for (vint2 p : i1.domain()) { CHECK(i2(p)[0] == i); i++; }
+  image2d<vuchar4> i4(7, 9, _border = 2);
+  for (int r = -2; r < 9; r++) for (int c = -2; c < 11; c++) i4(r, c) = vuchar4(r + 10, 3 * c + 20, 200, 255);
+  image2d<unsigned char> g = rgb_to_graylevel<unsigned char>(i4);                // 4th component ignored, border mapped too
+  CHECK(g.border() == 2);
+  for (int r = -2; r < 9; r++) for (int c = -2; c < 11; c++) CHECK(g(r, c) == (r + 10 + 3 * c + 20 + 200) / 3);
+  image2d<vuchar3> back = graylevel_to_rgb<vuchar3>(g);
+  CHECK(back(3, 4) == vuchar3(g(3, 4), g(3, 4), g(3, 4)));
+}
+
 int main() {
+  test_colorspace_conversions();
   test_layout_and_access();
   test_pixel_wise();
   test_block_wise_and_fill();

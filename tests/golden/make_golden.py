@@ -62,6 +62,12 @@ p = np.zeros((len(sk), 2), np.int32); dd = np.zeros(len(sk), np.int32); vv = np.
 assert ref.ref_semi_dense_optical_flow(P(s1.desc), P(s2.desc), sk.ctypes.data_as(V), len(sk), *par, p.ctypes.data_as(V), dd.ctypes.data_as(V), vv.ctypes.data_as(V)) == 0
 out["sdof"] = dict(in_crc=crc(s1.raw, s2.raw, sk), pos=p, dist=dd, valid=vv)
 
+# frame ingest (clone + mirror + rgb_to_graylevel) and the plain 4-channel rgb_to_graylevel
+rgb, g1, rgba, g2 = gc.ingest_case()
+assert ref.ref_rgb_to_graylevel(P(g1.desc), P(rgb.desc), 1) == 0
+assert ref.ref_rgb_to_graylevel(P(g2.desc), P(rgba.desc), 0) == 0
+out["ingest"] = dict(in_crc=crc(rgb.raw, rgba.raw), gray_mirror=g1.view(with_border=True).copy(), gray_rgba=g2.view(with_border=True).copy())
+
 for name, d in out.items():
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
     print(name, {k: getattr(v, "shape", v) for k, v in d.items()})

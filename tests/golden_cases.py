@@ -53,3 +53,10 @@ def sdof_case():
     from test_gpu_sdof import flow_scene
     f1, f2, kps = flow_scene(100, 140)
     return u8_image(f1, border=3), u8_image(f2, border=3), kps, (9, 3, 0, 2, 5)
+
+
+def ingest_case():
+    """rgb frame (no border) -> gray with border 3, the examples/video_extruder.cc:46-48 chain; plus the plain 4-channel call."""
+    rgb = rand_image(45, 70, vi.U8, 3, border=0, seed=21)
+    rgba = rand_image(33, 52, vi.U8, 4, border=2, seed=22, fill_border=True)
+    return rgb, HostImage(45, 70, vi.U8, 1, 3), rgba, HostImage(33, 52, vi.U8, 1, 2)

@@ -75,6 +75,13 @@ def test_oracle_sdof(orc):
     np.testing.assert_array_equal(p, g["pos"]); np.testing.assert_array_equal(d, g["dist"]); np.testing.assert_array_equal(v, g["valid"])
 
 
+def test_oracle_ingest(orc):
+    rgb, g1, rgba, g2 = gc.ingest_case(); g = load("ingest")
+    assert gc.crc(rgb.raw, rgba.raw) == g["in_crc"]
+    orc.orc_rgb_to_graylevel(P(g1.desc), P(rgb.desc), 1); orc.orc_rgb_to_graylevel(P(g2.desc), P(rgba.desc), 0)
+    np.testing.assert_array_equal(g1.view(with_border=True), g["gray_mirror"]); np.testing.assert_array_equal(g2.view(with_border=True), g["gray_rgba"])
+
+
 # ---------------- GPU: HIP path == reference golden ----------------
 @pytest.mark.gpu
 def test_gpu_matches_reference_golden(lib):
@@ -122,3 +129,8 @@ def test_gpu_matches_reference_golden(lib):
     capi.check(lib.vpp_semi_dense_optical_flow(P(ds1.desc), P(ds2.desc), V(dk.data_ptr()), n, *par,
                                                V(gp.data_ptr()), V(gd.data_ptr()), V(gv.data_ptr()), st))
     np.testing.assert_array_equal(gp.cpu().numpy(), g["pos"]); np.testing.assert_array_equal(gd.cpu().numpy(), g["dist"]); np.testing.assert_array_equal(gv.cpu().numpy(), g["valid"])
+    rgb, g1, rgba, g2 = gc.ingest_case(); g = load("ingest")
+    drgb, dg1, drgba, dg2 = DeviceImage.from_host(rgb), DeviceImage.from_host(g1), DeviceImage.from_host(rgba), DeviceImage.from_host(g2)
+    capi.check(lib.vpp_rgb_to_graylevel(P(dg1.desc), P(drgb.desc), 1, st)); capi.check(lib.vpp_rgb_to_graylevel(P(dg2.desc), P(drgba.desc), 0, st))
+    np.testing.assert_array_equal(dg1.download().view(with_border=True), g["gray_mirror"])
+    np.testing.assert_array_equal(dg2.download().view(with_border=True), g["gray_rgba"])

@@ -1,0 +1,62 @@
+"""GPU parity (through the C ABI) of the steps either side of the algorithms in the reference's video loop: rgb_to_graylevel,
+the fused frame ingest, and video_extruder's re-detection mask.  Bit-exact against the CPU oracle; 4K through properties."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from util import P, rand_image, HostImage, DeviceImage
+from vpp_amd import image as vi
+from vpp_amd import capi
+
+pytestmark = pytest.mark.gpu
+V = ctypes.c_void_p
+
+
+@pytest.mark.parametrize("ch", [3, 4])
+@pytest.mark.parametrize("shape,sborder,dborder,mirror,align", [
+    ((37, 53), 3, 3, 0, 32), ((37, 53), 0, 0, 0, 32), ((64, 128), 2, 1, 0, 16), ((1, 1), 0, 0, 0, 16), ((3, 5), 2, 2, 0, 1),
+    ((40, 64), 0, 3, 1, 32), ((19, 23), 0, 5, 1, 16), ((100, 100), 2, 2, 1, 32), ((7, 9), 0, 7, 1, 4), ((270, 481), 0, 3, 1, 32),
+])
+def test_rgb_to_graylevel_matches_oracle(lib, orc, ch, shape, sborder, dborder, mirror, align):
+    src = rand_image(*shape, vi.U8, ch, border=sborder, seed=31, fill_border=True, align=align)
+    want = HostImage(*shape, vi.U8, 1, dborder, align); want.raw[:] = 0xA5
+    assert orc.orc_rgb_to_graylevel(P(want.desc), P(src.desc), mirror) == 0
+    got = HostImage(*shape, vi.U8, 1, dborder, align); got.raw[:] = 0xA5
+    ds, dd = DeviceImage.from_host(src), DeviceImage.from_host(got)
+    capi.check(lib.vpp_rgb_to_graylevel(P(dd.desc), P(ds.desc), mirror, capi.stream_ptr()))
+    np.testing.assert_array_equal(dd.download().raw, want.raw)  # bit-exact, nothing outside the mapped region touched
+
+
+def test_ingest_4k_properties(lib):
+    """4K vuchar3 -> gray, border 3: interior = integer mean, border = symmetric mirror of the interior."""
+    src = rand_image(2160, 3840, vi.U8, 3, border=0, seed=32)
+    ds, dd = DeviceImage.from_host(src), DeviceImage(2160, 3840, vi.U8, 1, 3)
+    capi.check(lib.vpp_rgb_to_graylevel(P(dd.desc), P(ds.desc), 1, capi.stream_ptr()))
+    g = dd.download().view(with_border=True)[..., 0]
+    s = src.view().astype(np.int32)
+    inner = ((s[..., 0] + s[..., 1] + s[..., 2]) // 3).astype(np.uint8)
+    np.testing.assert_array_equal(g, np.pad(inner, 3, mode="symmetric"))
+
+
+def test_rgb_to_graylevel_rejects_bad_arguments(lib):
+    a, b = DeviceImage(8, 8, vi.U8, 3), DeviceImage(8, 8, vi.U8, 1)
+    assert lib.vpp_rgb_to_graylevel(P(a.desc), P(a.desc), 0, None) != 0            # dst must be x1
+    assert lib.vpp_rgb_to_graylevel(P(b.desc), P(b.desc), 0, None) != 0            # src must be x3 / x4
+    c = DeviceImage(9, 8, vi.U8, 1)
+    assert lib.vpp_rgb_to_graylevel(P(c.desc), P(a.desc), 0, None) != 0            # domain mismatch
+    d = DeviceImage(2, 2, vi.U8, 1, 3)
+    assert lib.vpp_rgb_to_graylevel(P(d.desc), P(DeviceImage(2, 2, vi.U8, 3).desc), 1, None) != 0  # mirror border > image
+
+
+@pytest.mark.parametrize("shape,border,spacing,n", [((60, 80), 10, 10, 4), ((2160, 3840), 10, 10, 80000), ((50, 50), 3, 5, 40), ((20, 20), 10, 10, 0)])
+def test_keypoint_mask_matches_oracle(lib, orc, shape, border, spacing, n):
+    rng = np.random.default_rng(33)
+    rc = np.stack([rng.integers(0, shape[0], n), rng.integers(0, shape[1], n)], 1).astype(np.int32)
+    want = HostImage(*shape, vi.U8, 1, border)
+    assert orc.orc_keypoint_mask(P(want.desc), rc.ctypes.data_as(V), n, spacing) == 0
+    dm = DeviceImage(*shape, vi.U8, 1, border)
+    drc = torch.from_numpy(rc.reshape(-1).copy()).cuda() if n else None
+    capi.check(lib.vpp_keypoint_mask(P(dm.desc), V(drc.data_ptr()) if n else None, n, spacing, capi.stream_ptr()))
+    np.testing.assert_array_equal(dm.download().view(with_border=True), want.view(with_border=True))

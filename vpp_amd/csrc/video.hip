@@ -1,0 +1,113 @@
+// video.hip — K13/K14: the steps either side of the algorithms in the reference's video loop.
+//  * rgb_to_graylevel (vpp/core/colorspace_conversions.hh:10-33 for 3 channels, :36-48 for 4): o = (i0 + i1 + i2) / 3 in int,
+//    mapped over domain_with_border.  The ingest form (mirror = 1) fuses the reference's
+//    `clone(frame, _border = b); fill_border_mirror(frame); rgb_to_graylevel<uchar>(frame)` (examples/video_extruder.cc:46-48)
+//    into one pass: a border pixel of dst is the gray value of the mirrored source pixel, which is exactly what the three
+//    separate steps produce (gray is per-pixel, so it commutes with the mirror copy).
+//    HBM-bound: CH bytes read + 1 written per pixel; one lane = 16 output pixels (CH 16-B loads, one 16-B store).
+//  * keypoint mask of video_extruder's re-detection (video_extruder/video_extruder.hpp:95-110): mask = 1 over the domain with
+//    border, then the [r - s, r + s) x [c - s, c + s) square of every keypoint is zeroed.
+#include "common.hpp"
+#include <cstring>
+using namespace vpp_amd;
+
+namespace {
+
+__device__ __forceinline__ int mirror_index(int x, int n) { return x < 0 ? -x - 1 : (x >= n ? 2 * n - x - 1 : x); }  // fill.hh:60-83
+__device__ __forceinline__ uint32_t div3(uint32_t s) { return (s * 43691u) >> 17; }  // exact for s <= 765 (43691 * 3 = 2^17 + 1)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kGrayChunk = 16;  // output pixels per lane: CH x 16 B loaded, one 16-B store
+
+// byte k of a little-endian dword array
+__device__ __forceinline__ uint32_t byte_at(const uint32_t* w, int k) { return (w[k >> 2] >> (8 * (k & 3))) & 255u; }
+
+template <int CH, bool MIRROR>
+__global__ __launch_bounds__(256) void rgb_to_gray_kernel(DImg dst, DImg src, int ext, int c_start, int nchunks, int vec_ok) {
+  const int chunk = blockIdx.x * 256 + threadIdx.x;
+  if (chunk >= nchunks) return;
+  const int r = (int)blockIdx.y - ext, c0 = c_start + kGrayChunk * chunk;
+  const int sr = MIRROR ? mirror_index(r, src.nr) : r;
+  const uint8_t* srow = src.row<uint8_t>(sr);
+  uint8_t* drow = dst.row<uint8_t>(r);
+  const int lo = MIRROR ? 0 : -ext, hi = MIRROR ? src.nc : src.nc + ext;  // source columns that map to themselves
+  if (c0 >= lo && c0 + kGrayChunk <= hi) {
+    uint32_t w[4 * CH];
+    // default cache policy: the CH loads of a lane (and of its neighbours) share cache lines; non-temporal loads measured 25 % slower
+    __builtin_memcpy(w, srow + (ptrdiff_t)c0 * CH, 16 * CH);   // CH (possibly unaligned) 16-B loads
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      uint32_t g[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int px = 4 * q + k;
+        g[k] = div3(byte_at(w, px * CH) + byte_at(w, px * CH + 1) + byte_at(w, px * CH + 2));
+      }
+      o[q] = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+    }
+    if (vec_ok & 1) __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, (u32x4*)(drow + c0));
+    else {
+#pragma unroll
+      for (int k = 0; k < kGrayChunk; k++) drow[c0 + k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));
+    }
+    return;
+  }
+  for (int k = 0; k < kGrayChunk; k++) {
+    const int c = c0 + k;
+    if (c < -ext || c >= dst.nc + ext) continue;
+    const uint8_t* p = srow + (ptrdiff_t)(MIRROR ? mirror_index(c, src.nc) : c) * CH;
+    drow[c] = (uint8_t)div3((uint32_t)p[0] + p[1] + p[2]);
+  }
+}
+
+__global__ __launch_bounds__(256) void keypoint_mask_kernel(DImg mask, const int32_t* __restrict__ rc, int n, int s) {
+  // one thread per (keypoint, square row): 2s byte stores
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = (int)(t / (2 * s)), dr = (int)(t - (long long)k * 2 * s) - s;
+  if (k >= n) return;
+  const int r = rc[2 * k] + dr, c = rc[2 * k + 1];
+  if (r < -mask.border || r >= mask.nr + mask.border) return;
+  uint8_t* row = mask.row<uint8_t>(r);
+  const int cb = max(c - s, -mask.border), ce = min(c + s, mask.nc + mask.border);
+  for (int x = cb; x < ce; x++) row[x] = 0;
+}
+
+}  // namespace
+
+extern "C" int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream) {
+  VPP_REQUIRE(valid_desc(dst) && valid_desc(src) && same_domain(dst, src), VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel: invalid descriptors / domain mismatch");
+  VPP_REQUIRE(dst->dtype == VPP_U8 && dst->channels == 1 && src->dtype == VPP_U8 && (src->channels == 3 || src->channels == 4), VPP_ERR_UNSUPPORTED,
+              "vpp_rgb_to_graylevel: u8 x3 / x4 -> u8 x1 only");
+  VPP_REQUIRE(dst->first_pixel != src->first_pixel, VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel: in-place not supported");
+  const int ext = mirror ? dst->border : (dst->border < src->border ? dst->border : src->border);
+  VPP_REQUIRE(!mirror || (ext <= dst->nrows && ext <= dst->ncols), VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel: border larger than the image");
+  const int c_start = -((ext + kGrayChunk - 1) / kGrayChunk) * kGrayChunk;   // chunks are 16-B aligned relative to dst's first pixel
+  const int nchunks = (dst->ncols + ext - c_start + kGrayChunk - 1) / kGrayChunk;
+  const int dword_ok = aligned16(dst) ? 1 : 0;
+  dim3 grid((nchunks + 255) / 256, dst->nrows + 2 * ext);
+  hipStream_t st = as_stream(stream);
+  DImg d = dimg(dst), s = dimg(src);
+  if (src->channels == 3) {
+    if (mirror) rgb_to_gray_kernel<3, true><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, dword_ok);
+    else rgb_to_gray_kernel<3, false><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, dword_ok);
+  } else {
+    if (mirror) rgb_to_gray_kernel<4, true><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, dword_ok);
+    else rgb_to_gray_kernel<4, false><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, dword_ok);
+  }
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+extern "C" int vpp_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, void* stream) {
+  VPP_REQUIRE(valid_desc(mask) && n >= 0 && (rc || n == 0) && spacing > 0, VPP_ERR_INVALID_ARG, "vpp_keypoint_mask: invalid argument");
+  VPP_REQUIRE(mask->dtype == VPP_U8 && mask->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_keypoint_mask: u8 x1 mask only");
+  const uint8_t one = 1;
+  int st = vpp_fill(mask, &one, 1, stream);
+  if (st != VPP_OK) return st;
+  if (n == 0) return VPP_OK;
+  const long long threads = (long long)n * 2 * spacing;
+  keypoint_mask_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, as_stream(stream)>>>(dimg(mask), rc, n, spacing);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}

@@ -2,6 +2,7 @@
 // video_extruder/video_extruder.hpp:24-135).  Flow, FAST scores and FAST re-detection run on the device; the keypoint
 // bookkeeping (merge, cull, trajectories) stays on the host as in the reference.
 #pragma once
+#include <chrono>
 #include <vector>
 #include <vpp/algorithms/fast_detector/fast.hh>
 #include <vpp/algorithms/optical_flow.hh>
@@ -16,6 +17,17 @@ struct video_extruder_ctx {
 };
 inline video_extruder_ctx video_extruder_init(box2d domain) { video_extruder_ctx res(domain); res.frame_id = -1; return res; }
 
+namespace ve_internals {
+// optional wall-clock breakdown of video_extruder_update (benchmarks/video_extruder_bench.cc defines VPP_AMD_TIMING)
+struct timing_t { double flow = 0, merge = 0, scores = 0, redetect = 0, traj = 0; };
+inline timing_t& timing() { static timing_t t; return t; }
+#ifdef VPP_AMD_TIMING
+struct stopwatch { double& acc; std::chrono::steady_clock::time_point t0; explicit stopwatch(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+                   ~stopwatch() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
+#else
+struct stopwatch { explicit stopwatch(double&) {} };
+#endif
+}
 namespace ve_internals { struct position_view { const video_extruder_ctx* c; int size() const { return c->keypoints.size(); } vint2 operator[](int i) const { return c->keypoints[i].position; } }; }
 
 template <class... OPTS>
@@ -26,11 +38,15 @@ void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>
   const int max_trajectory_length = opts.get(_max_trajectory_length, 15), nscales = opts.get(_nscales, 3), winsize = opts.get(_winsize, 9);
   const int regularisation_niters = opts.get(_propagation, 2);
 
+  {
+  ve_internals::stopwatch sw(ve_internals::timing().flow);
   ctx.keypoints.prepare_matching();  // :44-56
   semi_dense_optical_flow(ve_internals::position_view{&ctx},
                           [&](int i, vint2 pos, int) { if (frame1.has(pos)) ctx.keypoints.move(i, pos); else ctx.keypoints.remove(i); },
                           frame1, frame2, _winsize = winsize, _patchsize = 5, _propagation = regularisation_niters, _nscales = nscales);
+  }
   {  // merge particles that converged to the same cell, keep the older (:60-84)
+    ve_internals::stopwatch sw(ve_internals::timing().merge);
     image2d<int> idx(frame2.domain().nrows() / keypoint_spacing, frame2.domain().ncols() / keypoint_spacing, _border = 1);
     fill_with_border(idx, -1);
     for (int i = 0; i < ctx.keypoints.size(); i++) {
@@ -43,23 +59,29 @@ void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>
     }
   }
   {  // drop points whose FAST score fell below 3 (:87-91); one batched device call instead of one per keypoint
+    ve_internals::stopwatch sw(ve_internals::timing().scores);
     std::vector<int> scores;
     fast9_scores(frame2, detector_th, ve_internals::position_view{&ctx}, scores);
     for (int i = 0; i < ctx.keypoints.size(); i++) if (scores[i] < 3) ctx.keypoints.remove(i);
   }
   if (!(ctx.frame_id % detector_period)) {  // re-detect away from the live keypoints (:94-119)
+    ve_internals::stopwatch sw(ve_internals::timing().redetect);
     image2d<unsigned char> mask(frame2.domain().nrows(), frame2.domain().ncols(), _border = keypoint_spacing);
-    fill_with_border(mask, (unsigned char)1);
-    for (int i = 0; i < ctx.keypoints.size(); i++) {
-      const int r = ctx.keypoints[i].position[0], c = ctx.keypoints[i].position[1];
-      for (int dr = -keypoint_spacing; dr < keypoint_spacing; dr++)
-        for (int dc = -keypoint_spacing; dc < keypoint_spacing; dc++) mask[r + dr][c + dc] = 0;
+    {  // fill_with_border(mask, 1) + the 2s x 2s zero square of every container entry (:101-110), built in HBM
+      const int n = ctx.keypoints.size();
+      std::vector<vint2> pts(n);
+      for (int i = 0; i < n; i++) pts[i] = ctx.keypoints[i].position;
+      device::dbuf rc(size_t(n) * 8);
+      rc.upload(pts.data(), size_t(n) * 8);
+      const vpp_image_desc dm = mask.device_desc(true, true);
+      device::check(vpp_keypoint_mask(&dm, (const int32_t*)rc.p, n, keypoint_spacing, device::stream()), "vpp_keypoint_mask");
     }
     auto kps = fast9(frame2, detector_th, _blockwise, _block_size = keypoint_spacing, _mask = mask);
     for (auto kp : kps) ctx.keypoints.add(keypoint<int>(kp));
     ctx.keypoints.compact();
     ctx.keypoints.sync_attributes(ctx.trajectories, keypoint_trajectory(ctx.frame_id));
   }
+  ve_internals::stopwatch sw(ve_internals::timing().traj);
   for (int i = 0; i < ctx.keypoints.size(); i++) {  // trajectories (:123-133)
     if (ctx.keypoints[i].alive()) {
       ctx.trajectories[i].move_to(ctx.keypoints[i].position.template cast<float>());

@@ -57,9 +57,10 @@ struct storage {
   }
 #ifdef VPP_AMD_DEVICE
   // pointer into the mirror corresponding to host address p; the mirror is brought up to date first
-  void* to_device(const void* p, bool will_write) {
+  // discard: the caller overwrites every pixel (domain and border), so a stale mirror is not refreshed from the host first
+  void* to_device(const void* p, bool will_write, bool discard = false) {
     if (!dev) check(vpp_malloc(bytes, &dev), "vpp_malloc");
-    if (state == 0) { check(vpp_memcpy_h2d(dev, host, bytes, stream()), "vpp_memcpy_h2d"); state = 1; }
+    if (state == 0 && !(discard && will_write)) { check(vpp_memcpy_h2d(dev, host, bytes, stream()), "vpp_memcpy_h2d"); state = 1; }
     if (will_write) state = 2;
     return (char*)dev + ((const char*)p - host);
   }

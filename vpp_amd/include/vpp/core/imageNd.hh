@@ -147,12 +147,13 @@ template <class V, unsigned N> class imageNd {
   }
 #ifdef VPP_AMD_DEVICE
   // C-ABI descriptor of this image in HBM (vpp_image_desc); the mirror is uploaded if stale.  will_write marks the
-  // mirror as the newer copy: the next host access downloads it.
-  vpp_image_desc device_desc(bool will_write) const {
+  // mirror as the newer copy: the next host access downloads it; discard (with will_write) skips the upload of a stale
+  // mirror when the callee overwrites the whole image, border included.
+  vpp_image_desc device_desc(bool will_write, bool discard = false) const {
     static_assert(N == 2, "device evaluation handles image2d");
     typedef pixel_traits<V> PT;
     vpp_image_desc d;
-    d.first_pixel = ptr_->store_->to_device(ptr_->begin_, will_write);
+    d.first_pixel = ptr_->store_->to_device(ptr_->begin_, will_write, discard);
     d.nrows = nrows(); d.ncols = ncols(); d.pitch = pitch(); d.border = border();
     d.dtype = device::dtype_of<typename PT::component>::value; d.channels = PT::channels;
     return d;

@@ -12,6 +12,7 @@
 #include <vpp/core/clone.hh>
 #include <vpp/core/fill.hh>
 #include <vpp/core/sum.hh>
+#include <vpp/core/colorspace_conversions.hh>
 #include <vpp/core/keypoint_container.hh>
 #include <vpp/core/keypoint_trajectory.hh>
 #include <vpp/core/pyramid.hh>
