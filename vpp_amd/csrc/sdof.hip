@@ -195,6 +195,7 @@ __global__ __launch_bounds__(1024) void sdof_propagate_kernel(DImg i1, DImg i2, 
 // serial reference, but the 81-pixel SADs no longer sit on the critical path of the wavefront.
 struct Cell { int f0, f1, dist, mark; };  // mark: low byte = flow_map_mark value, bit 8 = changed during this sweep
 constexpr int kChanged = 0x100;
+constexpr int kJChanged = 0x200;  // skewed-copy-only flag: the Jacobi pass wants to change this cell
 
 // Per (cell, neighbour) results of the costly calls of loop_body, keyed by the neighbour flow they were computed for.
 struct PairCache { int nf0, nf1, d2, gf0, gf1, gdist, flags, pad; };  // flags: 1 = entry valid, 2 = descent result present
@@ -244,11 +245,12 @@ __device__ __forceinline__ Cell load_map_cell(const Maps& m, int ci, int cj) {
 }
 
 __global__ __launch_bounds__(256) void sdof_jacobi_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int NI, int NJ, int forward,
-                                                          Cell* __restrict__ J, PairCache* __restrict__ pairs) {
+                                                          Cell* __restrict__ J, PairCache* __restrict__ pairs, Cell* __restrict__ skew, int NIp) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= NI * NJ) return;
   const int ci = idx / NJ, cj = idx - ci * NJ;
   Cell cur = load_map_cell(m, ci, cj);
+  Cell pre = cur;
   if (cur.mark) {
     int r, c;
     if (forward) { r = ci * patch; c = cj * patch; } else { r = i1.nr - 1 - (NI - 1 - ci) * patch; c = i1.nc - 1 - (NJ - 1 - cj) * patch; }
@@ -257,110 +259,105 @@ __global__ __launch_bounds__(256) void sdof_jacobi_kernel(DImg i1, DImg i2, int 
       if (q0 < 0 || q1 < 0 || q0 >= NI || q1 >= NJ) return Cell{0, 0, 0, 0};
       return load_map_cell(m, q0, q1);
     };
-    if (loop_body<true>(i1, i2, ws, r, c, cur, nbr, pairs + (size_t)idx * 8)) cur.mark |= kChanged;
+    if (loop_body<true>(i1, i2, ws, r, c, cur, nbr, pairs + (size_t)idx * 8)) { cur.mark |= kChanged; pre.mark |= kJChanged; }
   }
   J[idx] = cur;
+  // the pre-sweep cell (+ "Jacobi wants to change it") in the ordered pass's visiting layout: step-major, wavefront row minor,
+  // so that at every step the rows of the wavefront read one contiguous run of 16-byte records
+  const int iw = forward ? ci : NI - 1 - ci, jw = forward ? cj : NJ - 1 - cj;
+  skew[(size_t)(2 * iw + jw) * NIp + iw] = pre;
+}
+
+// LDS ring of the ordered pass: slot (2 * row + column) & (K - 1), wavefront row minor — the cells visited at one step are
+// contiguous (conflict-free 16-byte accesses across a wave) and a slot is a straight copy of one row of the skewed array.
+template <int K> __device__ __forceinline__ const Cell* ring_cell(const Cell* ring, int NIp, int row, int col) {
+  return ring + (size_t)((2 * row + col) & (K - 1)) * NIp + row;
 }
 
 // Slow path of the ordered pass (a neighbour visited earlier was changed): loop_body against the ring.  Kept out of line so
-// that the per-step code stays small enough to be unrolled QD times (static register queue, counted vmcnt waits).
+// that the per-step code stays small; the cell travels by value (a pointer would pin the caller's copy in scratch memory).
+struct SlowResult { Cell cell; int changed; };
 template <int K>
-__device__ __noinline__ bool sweep_slow_path(const DImg& i1, const DImg& i2, int ws, int patch, int forward, int iw, int jw, int NI, int NJ,
-                                             const Cell* ring, Cell* cur_io, PairCache* pc) {
+__device__ __noinline__ SlowResult sweep_slow_path(const DImg& i1, const DImg& i2, int ws, int patch, int forward, int iw, int jw, int NI, int NJ,
+                                                   int NIp, const Cell* ring, Cell cur, PairCache* pc) {
   int r, c;
   if (forward) { r = iw * patch; c = jw * patch; } else { r = i1.nr - 1 - iw * patch; c = i1.nc - 1 - jw * patch; }
-  Cell cur = *cur_io;
   cur.mark &= 0xFF;
   auto wnbr = [&](int drow, int col) -> Cell {
     const int rr = iw + drow;
     if (rr < 0 || rr >= NI || col < 0 || col >= NJ) return Cell{0, 0, 0, 0};
-    return ring[(size_t)rr * K + (col & (K - 1))];
+    return *ring_cell<K>(ring, NIp, rr, col);
   };
   // flow-map offset (dr,dc) -> wavefront offset: mirrored in the backward sweep
   auto nbr = [&](int dr, int dc) -> Cell { return forward ? wnbr(dr, jw + dc) : wnbr(-dr, jw - dc); };
   const bool changed = loop_body<false>(i1, i2, ws, r, c, cur, nbr, pc);
-  *cur_io = cur;
-  return changed;
+  return SlowResult{cur, changed ? 1 : 0};
 }
 
 // Ordered pass.  Thread = wavefront row: at step t it visits wavefront column t - 2*row, so data only flows between
-// adjacent threads.  Each row keeps a ring of K consecutive cells in LDS; cells are requested from global memory in
-// batches P columns ahead and land one batch later, before the row above first needs them, so the common path (no
-// earlier neighbour changed, Jacobi outcome "unchanged") touches LDS only.
-constexpr int kJChanged = 0x200;
-__device__ unsigned g_sweep_stats[4];  // [0] marked cells visited, [1] Jacobi outcomes applied, [2] slow-path recomputations, [3] slow-path changes  // ring-only flag: the Jacobi pass wants to change this cell
+// adjacent threads.  The pre-sweep cells (+ the Jacobi verdict) of step t are row t of the skewed array written by
+// sdof_jacobi_kernel; they are copied into ring slot t & (K-1) by LDS-direct loads (global_load_lds_dwordx4: no VGPR
+// destination, so no register of the step code ever waits on them), issued P steps ahead in batches of QD and awaited
+// once per batch.  Slot t is read during steps t-3 .. t+3 (t+1 .. t+3 only by the slow path), hence P >= QD + 3 (landed in
+// time) and P + QD <= K - 3 (the slot being overwritten is no longer read).  The common path (no earlier neighbour changed,
+// Jacobi verdict "unchanged") is five conflict-free LDS reads and a barrier.
+__device__ unsigned g_sweep_stats[4];  // [0] marked cells visited, [1] Jacobi outcomes applied, [2] slow-path recomputations, [3] slow-path changes
 
 template <int K>
 __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward,
-                                                                   const Cell* __restrict__ J, PairCache* __restrict__ pairs, int stats) {
+                                                                   const Cell* __restrict__ J, PairCache* __restrict__ pairs,
+                                                                   const Cell* __restrict__ skew, int NIp, int stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Cell* ring = (Cell*)smem_raw;  // [NI][K]
-  // batch of QD columns, requested P columns ahead: the row above needs columns <= col+3+QD-1 during a batch (P >= QD+3)
-  // and a landing batch must only overwrite columns < col-3 (K >= P+3)
-  constexpr int QD = K >= 16 ? 6 : 2, P = K >= 16 ? 10 : 5;
-  static_assert(P >= QD + 3 && K >= P + 3, "ring too small for the prefetch distance");
+  Cell* ring = (Cell*)smem_raw;  // [K][NIp]
+  constexpr int QD = K >= 16 ? 5 : 1, P = K >= 16 ? 8 : 4;
+  static_assert(P >= QD + 3 && P + QD <= K - 3, "ring too small for the prefetch distance");
   const int NI = (i1.nr - 1) / patch + 1, NJ = (i1.nc - 1) / patch + 1;
   const int iw = threadIdx.x;
   const bool row_ok = iw < NI;
-  Cell* my = ring + (size_t)iw * K;
   const int ci = forward ? iw : NI - 1 - iw;  // flow-map row of this thread
-  auto wnbr = [&](int drow, int jw) -> Cell {  // ring entry at wavefront row iw+drow, wavefront column jw; mark 0 outside
-    const int r = iw + drow;
-    if (r < 0 || r >= NI || jw < 0 || jw >= NJ) return Cell{0, 0, 0, 0};
-    return ring[(size_t)r * K + (jw & (K - 1))];
-  };
-  Cell q[QD];
-  int qjm[QD];
   const int tmax = 2 * (NI - 1) + (NJ - 1);
-  const int t0 = -2 * QD;  // two warm-up batches: only prefetching
-  for (int tb = t0; tb <= tmax; tb += QD) {
-    // Batched prefetch, once every QD steps: first the QD cells requested one batch ago land in the ring, then the next QD
-    // are requested.  The only waits on global memory are therefore for loads that have had QD steps to arrive.
-    if (row_ok) {
-      const int jb = tb - 2 * iw;  // wavefront column of this thread at the first step of the batch
-      if (tb > t0) {
-#pragma unroll
-        for (int u = 0; u < QD; u++) {
-          const int lc = jb - QD + P + u;
-          if (lc >= 0 && lc < NJ) { Cell c = q[u]; if (qjm[u] & kChanged) c.mark |= kJChanged; my[lc & (K - 1)] = c; }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < QD; u++) {
-        const int pc = jb + P + u;
-        if (pc >= 0 && pc < NJ) {
-          const int cj = forward ? pc : NJ - 1 - pc;
-          q[u] = load_map_cell(m, ci, cj);
-          qjm[u] = J[(size_t)ci * NJ + cj].mark;
-        }
-      }
-    }
+  const int wave_base = (int)threadIdx.x & ~63;
+  auto issue = [&](int t) {  // t is uniform; each wave copies its 64 rows of step t (lane L lands at dst + 16 L)
+    if (t < 0 || t > tmax) return;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(skew + (size_t)t * NIp + threadIdx.x),
+                                     (__attribute__((address_space(3))) void*)(ring + (size_t)(t & (K - 1)) * NIp + wave_base), 16, 0, 0);
+  };
+  auto mark_of = [&](int drow, int col) -> int {  // mark word of the ring cell at wavefront (iw + drow, col); 0 outside the map
+    const int r = iw + drow;
+    if (r < 0 || r >= NI || col < 0 || col >= NJ) return 0;
+    return ring_cell<K>(ring, NIp, r, col)->mark;
+  };
+  for (int t = 0; t < P; t++) issue(t);
+  for (int tb = 0; tb <= tmax; tb += QD) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the slots requested one batch ago (and the warm-up) are in LDS
     __syncthreads();
+#pragma unroll
+    for (int u = 0; u < QD; u++) issue(tb + P + u);
 #pragma unroll
     for (int u = 0; u < QD; u++) {
       const int t = tb + u;
       const int jw = t - 2 * iw;
-      if (row_ok) {
-        if (t >= 0 && jw >= 0 && jw < NJ) {
-          Cell cur = my[jw & (K - 1)];
-          if (cur.mark & 0xFF) {
-            // the four neighbours visited before this cell in the sweep
-            const int dirty = (wnbr(-1, jw - 1).mark | wnbr(-1, jw).mark | wnbr(-1, jw + 1).mark | wnbr(0, jw - 1).mark) & kChanged;
-            const int cj = forward ? jw : NJ - 1 - jw;
-            bool changed = false;
-            if (stats) atomicAdd(&g_sweep_stats[0], 1u);
-            if (!dirty) {
-              if (cur.mark & kJChanged) { cur = J[(size_t)ci * NJ + cj]; changed = true; if (stats) atomicAdd(&g_sweep_stats[1], 1u); }  // Jacobi outcome is the sequential one
-            } else {
-              changed = sweep_slow_path<K>(i1, i2, ws, patch, forward, iw, jw, NI, NJ, ring, &cur, pairs + ((size_t)ci * NJ + cj) * 8);
-              if (stats) { atomicAdd(&g_sweep_stats[2], 1u); if (changed) atomicAdd(&g_sweep_stats[3], 1u); }
-            }
-            if (changed) {
-              cur.mark = (cur.mark & 0xFF) | kChanged;
-              my[jw & (K - 1)] = cur;
-              int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
-              f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)(cur.mark & 0xFF);
-            }
+      if (row_ok && t <= tmax && jw >= 0 && jw < NJ) {
+        Cell* myp = ring + (size_t)(t & (K - 1)) * NIp + iw;
+        Cell cur = *myp;
+        if (cur.mark & 0xFF) {
+          // the four neighbours visited before this cell in the sweep
+          const int dirty = (mark_of(-1, jw - 1) | mark_of(-1, jw) | mark_of(-1, jw + 1) | mark_of(0, jw - 1)) & kChanged;
+          const int cj = forward ? jw : NJ - 1 - jw;
+          bool changed = false;
+          if (stats & 1) atomicAdd(&g_sweep_stats[0], 1u);
+          if (!dirty || (stats & 2)) {
+            if (cur.mark & kJChanged) { cur = J[(size_t)ci * NJ + cj]; changed = true; if (stats & 1) atomicAdd(&g_sweep_stats[1], 1u); }  // Jacobi outcome is the sequential one
+          } else {
+            const SlowResult sr = sweep_slow_path<K>(i1, i2, ws, patch, forward, iw, jw, NI, NJ, NIp, ring, cur, pairs + ((size_t)ci * NJ + cj) * 8);
+            cur = sr.cell; changed = sr.changed != 0;
+            if (stats & 1) { atomicAdd(&g_sweep_stats[2], 1u); if (changed) atomicAdd(&g_sweep_stats[3], 1u); }
+          }
+          if (changed) {
+            cur.mark = (cur.mark & 0xFF) | kChanged;
+            *myp = cur;
+            int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
+            f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)(cur.mark & 0xFF);
           }
         }
       }
@@ -410,7 +407,7 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
   hipStream_t st = as_stream(stream);
   // carve the scratch: two image pyramids (border 2*winsize, :72-73), flow / mark / distance pyramids (border nscales, :70-74), owners
   vpp_image_desc P1[kMaxScales], P2[kMaxScales], FL[kMaxScales], MK[kMaxScales], DM[kMaxScales], OW[kMaxScales];
-  Cell* jacobi = nullptr;
+  Cell *jacobi = nullptr, *skew = nullptr;
   PairCache* pairs = nullptr;
   for (int pass = 0; pass < 2; pass++) {
     Carver cv{pass ? (uint8_t*)g_scratch.p : nullptr};
@@ -428,6 +425,9 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
       cv.off += (cells * sizeof(Cell) + 255) / 256 * 256;
       pairs = cv.base ? (PairCache*)(cv.base + cv.off) : nullptr;
       cv.off += (cells * 8 * sizeof(PairCache) + 255) / 256 * 256;
+      const size_t ni = (size_t)(i1->nrows - 1) / patchsize + 1, nj = (size_t)(i1->ncols - 1) / patchsize + 1;
+      skew = cv.base ? (Cell*)(cv.base + cv.off) : nullptr;   // [2 (NI - 1) + NJ wavefront steps][NI rows rounded up to whole waves]
+      cv.off += ((2 * (ni - 1) + nj) * ((ni + 63) / 64 * 64) * sizeof(Cell) + 255) / 256 * 256;
     }
     if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
@@ -457,15 +457,15 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
       const bool ring16 = (mode == 0 || mode == 2) && NI <= 640, ring8 = !ring16 && (mode == 0 || mode == 3) && NI <= 1024;
       if (ring16 || ring8) {
         for (int Ki = 0; Ki < propagation; Ki++) {
-          sdof_jacobi_kernel<<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs);
+          sdof_jacobi_kernel<<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs, skew, threads);
           if (ring16) {
-            const size_t lds = (size_t)NI * 16 * sizeof(Cell);
+            const size_t lds = (size_t)threads * 16 * sizeof(Cell);
             VPP_HIP_TRY(hipFuncSetAttribute((const void*)sdof_propagate_ring_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            sdof_propagate_ring_kernel<16><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, tuning("sdof.stats", 0));
+            sdof_propagate_ring_kernel<16><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0) | (tuning("sdof.skip_slow", 0) ? 2 : 0));
           } else {
-            const size_t lds = (size_t)NI * 8 * sizeof(Cell);
+            const size_t lds = (size_t)threads * 8 * sizeof(Cell);
             VPP_HIP_TRY(hipFuncSetAttribute((const void*)sdof_propagate_ring_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            sdof_propagate_ring_kernel<8><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, tuning("sdof.stats", 0));
+            sdof_propagate_ring_kernel<8><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0) | (tuning("sdof.skip_slow", 0) ? 2 : 0));
           }
         }
       } else
