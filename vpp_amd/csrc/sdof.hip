@@ -346,7 +346,7 @@ __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg
           const int cj = forward ? jw : NJ - 1 - jw;
           bool changed = false;
           if (stats & 1) atomicAdd(&g_sweep_stats[0], 1u);
-          if (!dirty || (stats & 2)) {
+          if (!dirty) {
             if (cur.mark & kJChanged) { cur = J[(size_t)ci * NJ + cj]; changed = true; if (stats & 1) atomicAdd(&g_sweep_stats[1], 1u); }  // Jacobi outcome is the sequential one
           } else {
             const SlowResult sr = sweep_slow_path<K>(i1, i2, ws, patch, forward, iw, jw, NI, NJ, NIp, ring, cur, pairs + ((size_t)ci * NJ + cj) * 8);
@@ -461,11 +461,11 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
           if (ring16) {
             const size_t lds = (size_t)threads * 16 * sizeof(Cell);
             VPP_HIP_TRY(hipFuncSetAttribute((const void*)sdof_propagate_ring_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            sdof_propagate_ring_kernel<16><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0) | (tuning("sdof.skip_slow", 0) ? 2 : 0));
+            sdof_propagate_ring_kernel<16><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
           } else {
             const size_t lds = (size_t)threads * 8 * sizeof(Cell);
             VPP_HIP_TRY(hipFuncSetAttribute((const void*)sdof_propagate_ring_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            sdof_propagate_ring_kernel<8><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0) | (tuning("sdof.skip_slow", 0) ? 2 : 0));
+            sdof_propagate_ring_kernel<8><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
           }
         }
       } else
