@@ -60,8 +60,10 @@ int main(int argc, char** argv) {
   const double n = double(per.size() - 1);
   std::printf("{\"workload\": \"video_extruder_update %dx%d uchar, defaults (th 10, spacing 10, period 5, 3 scales, winsize 9, 2 sweeps), %d updates after the detecting one\", "
               "\"ms_per_update\": %.3f, \"frames_per_s\": %.2f, \"keypoints\": %d, \"alive\": %d, \"velocity_ok\": %d, "
-              "\"breakdown_ms\": {\"flow\": %.3f, \"merge\": %.3f, \"scores\": %.3f, \"redetect\": %.3f, \"trajectories\": %.3f}, \"per_update_ms\": [",
-              nr, nc, int(per.size() - 1), mean, 1000.0 / mean, ctx.keypoints.size(), alive, good, tm.flow / n, tm.merge / n, tm.scores / n, tm.redetect / n, tm.traj / n);
+              "\"breakdown_ms\": {\"flow\": %.3f, \"merge\": %.3f, \"scores\": %.3f, \"redetect\": %.3f, \"trajectories\": %.3f, "
+              "\"redetect_mask\": %.3f, \"redetect_fast9\": %.3f, \"redetect_add\": %.3f, \"redetect_compact\": %.3f, \"redetect_sync\": %.3f}, \"per_update_ms\": [",
+              nr, nc, int(per.size() - 1), mean, 1000.0 / mean, ctx.keypoints.size(), alive, good, tm.flow / n, tm.merge / n, tm.scores / n, tm.redetect / n, tm.traj / n,
+              tm.redetect_mask / n, tm.redetect_fast9 / n, tm.redetect_add / n, tm.redetect_compact / n, tm.redetect_sync / n);
   for (size_t i = 0; i < per.size(); i++) std::printf("%s%.2f", i ? ", " : "", per[i]);
   std::printf("]}\n");
   return alive > 0 && good > alive / 2 ? 0 : 1;

@@ -105,6 +105,24 @@ static void test_block_wise_and_fill() {
   CHECK(kc.has(vint2(3, 4)) && kc.index_of(*new vint2(5, 6)) == 1);
   kc.move(0, vint2(4, 4)); CHECK(kc[0].velocity == vint2(1, 0) && kc[0].age == 2);
   kc.remove(1); kc.compact(); CHECK(kc.size() == 1 && kc.has(vint2(4, 4)) && !kc.has(vint2(5, 6)));
+  // sync_attributes (keypoint_container.hpp:64-112): survivors keep their attribute at the compacted index, dead ones go
+  // through die_fun, keypoints added since the last sync get new_value — as video_extruder.hpp:114-118 uses it
+  keypoint_container<keypoint<int>, int> k2(make_box2d(40, 40));
+  std::vector<keypoint_trajectory> traj;
+  for (int i = 0; i < 6; i++) k2.add(keypoint<int>(vint2(2 * i + 1, 3 * i + 1)));
+  k2.sync_attributes(traj, keypoint_trajectory(7));                          // no compact yet: plain resize
+  CHECK(traj.size() == 6 && traj[5].start_frame() == 7);
+  for (int i = 0; i < 6; i++) traj[i].move_to(vfloat2(float(i), 0.f));
+  k2.prepare_matching();
+  k2.remove(1); k2.remove(4);
+  k2.add(keypoint<int>(vint2(30, 30))); k2.add(keypoint<int>(vint2(31, 35)));
+  k2.compact();
+  std::vector<keypoint_trajectory> dead;
+  k2.sync_attributes(traj, keypoint_trajectory(9), dead);
+  CHECK(k2.size() == 6 && traj.size() == 6 && dead.size() == 2);
+  CHECK(traj[0].position()[0] == 0.f && traj[1].position()[0] == 2.f && traj[2].position()[0] == 3.f && traj[3].position()[0] == 5.f);
+  CHECK(traj[4].size() == 0 && traj[4].start_frame() == 9 && traj[5].start_frame() == 9);
+  CHECK(dead[0].position()[0] == 1.f && dead[1].position()[0] == 4.f);
 }
 
 static void test_colorspace_conversions() {                                  // tests/colorspace_conversions.cc

@@ -10,7 +10,10 @@
 
 namespace vpp {
 struct video_extruder_ctx {
-  video_extruder_ctx(box2d domain) : keypoints(domain), frame_id(0) {}
+  video_extruder_ctx(box2d domain) : keypoints(domain), frame_id(0) {
+    // a std::vector<keypoint_trajectory> that reallocates COPIES every std::deque (libstdc++'s deque move is not noexcept): 24 ms at 75 k keypoints
+    trajectories.reserve(size_t(domain.nrows()) * domain.ncols() / 50);
+  }
   keypoint_container<keypoint<int>, int> keypoints;
   std::vector<keypoint_trajectory> trajectories;
   int frame_id;
@@ -19,7 +22,7 @@ inline video_extruder_ctx video_extruder_init(box2d domain) { video_extruder_ctx
 
 namespace ve_internals {
 // optional wall-clock breakdown of video_extruder_update (benchmarks/video_extruder_bench.cc defines VPP_AMD_TIMING)
-struct timing_t { double flow = 0, merge = 0, scores = 0, redetect = 0, traj = 0; };
+struct timing_t { double flow = 0, merge = 0, scores = 0, redetect = 0, traj = 0, redetect_mask = 0, redetect_fast9 = 0, redetect_add = 0, redetect_compact = 0, redetect_sync = 0; };
 inline timing_t& timing() { static timing_t t; return t; }
 #ifdef VPP_AMD_TIMING
 struct stopwatch { double& acc; std::chrono::steady_clock::time_point t0; explicit stopwatch(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
@@ -67,7 +70,8 @@ void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>
   if (!(ctx.frame_id % detector_period)) {  // re-detect away from the live keypoints (:94-119)
     ve_internals::stopwatch sw(ve_internals::timing().redetect);
     image2d<unsigned char> mask(frame2.domain().nrows(), frame2.domain().ncols(), _border = keypoint_spacing);
-    {  // fill_with_border(mask, 1) + the 2s x 2s zero square of every container entry (:101-110), built in HBM
+    {  ve_internals::stopwatch sw2(ve_internals::timing().redetect_mask);
+       // fill_with_border(mask, 1) + the 2s x 2s zero square of every container entry (:101-110), built in HBM
       const int n = ctx.keypoints.size();
       std::vector<vint2> pts(n);
       for (int i = 0; i < n; i++) pts[i] = ctx.keypoints[i].position;
@@ -76,10 +80,11 @@ void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>
       const vpp_image_desc dm = mask.device_desc(true, true);
       device::check(vpp_keypoint_mask(&dm, (const int32_t*)rc.p, n, keypoint_spacing, device::stream()), "vpp_keypoint_mask");
     }
-    auto kps = fast9(frame2, detector_th, _blockwise, _block_size = keypoint_spacing, _mask = mask);
-    for (auto kp : kps) ctx.keypoints.add(keypoint<int>(kp));
-    ctx.keypoints.compact();
-    ctx.keypoints.sync_attributes(ctx.trajectories, keypoint_trajectory(ctx.frame_id));
+    std::vector<vint2> kps;
+    { ve_internals::stopwatch sw2(ve_internals::timing().redetect_fast9); kps = fast9(frame2, detector_th, _blockwise, _block_size = keypoint_spacing, _mask = mask); }
+    { ve_internals::stopwatch sw2(ve_internals::timing().redetect_add); for (auto kp : kps) ctx.keypoints.add(keypoint<int>(kp)); }
+    { ve_internals::stopwatch sw2(ve_internals::timing().redetect_compact); ctx.keypoints.compact(); }
+    { ve_internals::stopwatch sw2(ve_internals::timing().redetect_sync); ctx.keypoints.sync_attributes(ctx.trajectories, keypoint_trajectory(ctx.frame_id)); }
   }
   ve_internals::stopwatch sw(ve_internals::timing().traj);
   for (int i = 0; i < ctx.keypoints.size(); i++) {  // trajectories (:123-133)

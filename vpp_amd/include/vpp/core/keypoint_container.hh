@@ -54,13 +54,19 @@ template <class P, class F> struct keypoint_container {
   template <class T, class D = no_op> void sync_attributes(T& v, typename T::value_type new_value = typename T::value_type(), D die_fun = D()) const {
     const size_t nparts = keypoint_vector_.size();
     if (compact_has_run_) {
-      T tmp(nparts, new_value);
-      for (size_t i = 0; i < matches_.size(); i++) {
+      // compact() maps survivors to increasing new indices ni <= i, so the attributes are compacted in place with swaps
+      // (the reference builds a second vector of nparts copies of new_value and moves into it — for trajectories that is
+      // two heap allocations per std::deque; the resulting vector is the same)
+      using std::swap;
+      const size_t n_old = v.size() < matches_.size() ? v.size() : matches_.size();
+      size_t survivors = 0;
+      for (size_t i = 0; i < n_old; i++) {
         const int ni = matches_[i];
-        if (ni >= 0) { if (i < v.size()) tmp[ni] = std::move(v[i]); }
-        else if (i < v.size()) die_fun(v[i]);
+        if (ni >= 0) { assert(size_t(ni) == survivors && size_t(ni) <= i); if (size_t(ni) != i) swap(v[ni], v[i]); survivors++; }
+        else die_fun(v[i]);
       }
-      v.swap(tmp);
+      v.resize(survivors);            // drop the dead tail ...
+      v.resize(nparts, new_value);    // ... and give every keypoint added since the last sync a fresh attribute
     } else v.resize(nparts, new_value);
   }
   template <class T, class U> void sync_attributes(T& c, typename T::value_type new_value, std::vector<U>& dead) const {
@@ -125,6 +131,8 @@ struct keypoint_trajectory {
   const std::deque<vfloat2>& positions() const { return history_; }
   int start_frame() const { return start_frame_; }
   int end_frame() const { return start_frame_ + int(history_.size()) - 1; }
+  void swap(keypoint_trajectory& o) { std::swap(start_frame_, o.start_frame_); std::swap(alive_, o.alive_); history_.swap(o.history_); }
+  friend void swap(keypoint_trajectory& a, keypoint_trajectory& b) { a.swap(b); }
  private:
   int start_frame_;
   bool alive_;
