@@ -64,20 +64,25 @@ def test_add_4k_checker(lib):
     (vi.U8, 2, 5, 5, (50, 300), 2, 32),
     (vi.U8, 4, 5, 5, (50, 300), 5, 32),
     (vi.U8, 3, 3, 3, (31, 45), 1, 32),      # generic kernel
-    (vi.I32, 1, 5, 5, (100, 200), 2, 32),   # the reference benchmark's own element type
+    (vi.I32, 1, 5, 5, (100, 200), 2, 32),   # the reference benchmark's own element type (32-bit streaming kernel)
+    (vi.I32, 1, 5, 5, (67, 131), 2, 16),    # ragged row end, border exactly 2
+    (vi.I32, 1, 5, 5, (33, 1000), 3, 32),   # several strips
+    (vi.U32, 1, 5, 5, (50, 249), 2, 32),
+    (vi.I32, 2, 5, 5, (20, 30), 2, 32),     # vint2 -> generic kernel
     (vi.F32, 1, 5, 5, (64, 64), 2, 32),
     (vi.U8, 3, 7, 5, (30, 40), 3, 32),
     (vi.I16, 2, 3, 5, (30, 40), 2, 32),
 ])
 def test_box_filter_matches_oracle(lib, orc, dtype, ch, R, C, shape, border, align):
-    lo, hi = (0, 999) if dtype == vi.I32 else (None, None)
+    lo, hi = (0, 999) if dtype in (vi.I32, vi.U32) else (None, None)
     src = rand_image(*shape, dtype, ch, border=border, seed=3, lo=lo, hi=hi, align=align, fill_border=True)
     want = src.like(border=0)
     assert orc.orc_box_filter(P(want.desc), P(src.desc), R, C) == 0
     dsrc = DeviceImage.from_host(src)
     fast = dtype == vi.U8 and R == 5 and C == 5
-    for impl, rows in (((1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (0, 8), (0, 16), (0, 32)) if fast else ((1, 2),)):
-        lib.vpp_set_tuning(b"box.impl", impl); lib.vpp_set_tuning(b"box.rows", rows)
+    w32 = dtype in (vi.I32, vi.U32) and ch == 1 and R == 5 and C == 5
+    for impl, rows in (((1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (0, 8), (0, 16), (0, 32)) if fast else ((1, 1), (1, 2), (1, 4), (1, 8)) if w32 else ((1, 2),)):
+        lib.vpp_set_tuning(b"box.impl", impl); lib.vpp_set_tuning(b"box.rows", rows); lib.vpp_set_tuning(b"box.rows32", rows)
         ddst = DeviceImage.from_host(src.like(border=0))
         capi.check(lib.vpp_box_filter(P(ddst.desc), P(dsrc.desc), R, C, capi.stream_ptr()))
         _sync(lib)
@@ -86,7 +91,25 @@ def test_box_filter_matches_oracle(lib, orc, dtype, ch, R, C, shape, border, ali
             np.testing.assert_array_equal(got.view().view(np.uint32), want.view().view(np.uint32))
         else:
             np.testing.assert_array_equal(got.view(), want.view())
-    lib.vpp_set_tuning(b"box.rows", -1); lib.vpp_set_tuning(b"box.impl", -1)
+    lib.vpp_set_tuning(b"box.rows", -1); lib.vpp_set_tuning(b"box.impl", -1); lib.vpp_set_tuning(b"box.rows32", -1)
+
+
+def test_box_int32_4k_matches_generic(lib):
+    """The reference's own benchmark type at 4K (box_5x5_filter.cc:187-191: values % 1000): streaming kernel == generic kernel."""
+    src = rand_image(2160, 3840, vi.I32, 1, border=2, seed=12, lo=0, hi=999, fill_border=True, align=16)
+    dsrc = DeviceImage.from_host(src)
+    outs = []
+    for g in (0, 1):
+        lib.vpp_set_tuning(b"box.force_generic", g)
+        d = DeviceImage(2160, 3840, vi.I32, 1, 0, 16)
+        capi.check(lib.vpp_box_filter(P(d.desc), P(dsrc.desc), 5, 5, capi.stream_ptr()))
+        _sync(lib)
+        outs.append(d.download().view().copy())
+    lib.vpp_set_tuning(b"box.force_generic", 0)
+    np.testing.assert_array_equal(outs[0], outs[1])
+    s = src.view(with_border=True)[..., 0].astype(np.int64)
+    r, c = 1000, 2000  # one inline check against numpy (box_5x5_filter.cc:26-41)
+    assert outs[0][r, c, 0] == int(s[r:r + 5, c:c + 5].sum()) // 25
 
 
 def test_box_fast_equals_generic_on_device(lib):

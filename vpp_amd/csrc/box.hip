@@ -275,6 +275,99 @@ __global__ __launch_bounds__(256, (RW <= 2 ? 8 : RW <= 4 ? 6 : 4)) void box5x5_u
     box5x5_u8_stream_body<CH, RW, NT, false, PROBE>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x, r0, writer);
 }
 
+// ---- 32-bit integer 5x5 (the element type of the reference's own benchmark, benchmarks/box_5x5_filter.cc:165-171,187-191) ----
+// Same shape as the u8 streaming kernel with one pixel per dword: a lane owns 4 consecutive pixels (16 B), keeps their
+// 5-row column sums (integer adds are order-independent, so the running add / subtract is exact, wrap-around included),
+// takes the two halo sums of each side from lane -1 / +1 over DPP, and lanes 1..62 store 4 truncating quotients (`/ 25` in T).
+// All RW + 4 row loads are issued up front.  Elements outside [-border, ncols + border) x [-border, nrows + border) are
+// never read (a straddling chunk takes predicated dword loads), so border == 2 needs no separate guarded body.
+constexpr int kW32StripOut = 62 * 4;
+
+template <class T, int RW, bool NT>
+__global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ dp, const T* __restrict__ sp, int dpitch, int spitch,
+                                                                int nrows, int ncols, int border, int nstrips, int nblk_y) {
+  const unsigned nb = (unsigned)nstrips * (unsigned)nblk_y;
+  const unsigned lb = xcd_remap(blockIdx.x, nb);  // consecutive logical blocks = vertically adjacent row blocks of one strip
+  const int s = lb / nblk_y, by = lb - s * nblk_y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int x = s * kW32StripOut - 4 + lane * 4;   // first pixel of this lane's chunk
+  const int r0 = (by * (int)(blockDim.x >> 6) + wv) * RW;
+  if (r0 >= nrows) return;
+  const int lo = -border, hi = ncols + border;
+  const bool in_reach = x + 4 > lo && x < ncols + 4, inside = x >= lo && x + 4 <= hi;
+  const bool writer = lane >= 1 && lane <= 62 && x < ncols;
+  typedef typename std::make_unsigned<T>::type U;  // sums wrap like the hardware's int adds (no signed-overflow UB in the source)
+  U raw[RW + 4][4];
+#pragma unroll
+  for (int k = 0; k < RW + 4; k++) {
+    const int r = r0 - 2 + k;
+    raw[k][0] = raw[k][1] = raw[k][2] = raw[k][3] = 0;
+    if (in_reach && r <= nrows - 1 + border && r >= -border) {
+      const U* row = (const U*)((const uint8_t*)sp + (ptrdiff_t)r * spitch);
+      if (inside) { const u32x4 v = *(const u32x4*)(row + x); raw[k][0] = v.x; raw[k][1] = v.y; raw[k][2] = v.z; raw[k][3] = v.w; }
+      else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int c = x + i; const U v = row[min(max(c, lo), hi - 1)]; raw[k][i] = (c >= lo && c < hi) ? v : 0; }
+      }
+    }
+  }
+  U V[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) V[i] += raw[k][i];
+  const bool full_store = x + 4 <= ncols;
+#pragma unroll
+  for (int j = 0; j < RW; j++) {
+    const int r = r0 + j;
+    if (r >= nrows) break;
+#pragma unroll
+    for (int i = 0; i < 4; i++) V[i] += raw[j + 4][i];
+    const U W[8] = {from_left(V[2]), from_left(V[3]), V[0], V[1], V[2], V[3], from_right(V[0]), from_right(V[1])};
+    U out[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = (U)((T)(W[i] + W[i + 1] + W[i + 2] + W[i + 3] + W[i + 4]) / (T)25);
+    if (writer) {
+      U* drow = (U*)((uint8_t*)dp + (ptrdiff_t)r * dpitch) + x;
+      if (full_store) {
+        const u32x4 v = {out[0], out[1], out[2], out[3]};
+        if (NT) __builtin_nontemporal_store(v, (u32x4*)drow); else *(u32x4*)drow = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (x + i < ncols) drow[i] = out[i];
+      }
+    }
+    if (j + 1 < RW) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) V[i] -= raw[j][i];
+    }
+  }
+}
+
+template <class T> int launch_w32(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
+  const int rows = tuning("box.rows32", 4), nt = tuning("box.nt", 1);   // measured 4K int: 1 -> 20.4, 2 -> 17.4, 4 -> 16.6, 8 -> 21.8 us
+  int wpb = tuning("box.waves_per_block", 4);
+  if (wpb != 1 && wpb != 2) wpb = 4;
+  const int nstrips = (dst->ncols + kW32StripOut - 1) / kW32StripOut;
+  auto go = [&](auto RWc, auto NTc) {
+    constexpr int RW = decltype(RWc)::value; constexpr bool NT = decltype(NTc)::value;
+    const int nblk_y = (dst->nrows + wpb * RW - 1) / (wpb * RW);
+    box5x5_w32_stream_kernel<T, RW, NT><<<nstrips * nblk_y, 64 * wpb, 0, st>>>((T*)dst->first_pixel, (const T*)src->first_pixel, dst->pitch, src->pitch,
+                                                                              dst->nrows, dst->ncols, src->border, nstrips, nblk_y);
+  };
+  auto pick = [&](auto NTc) {
+    switch (rows) {
+      case 1: go(std::integral_constant<int, 1>(), NTc); break;
+      case 2: go(std::integral_constant<int, 2>(), NTc); break;
+      case 8: go(std::integral_constant<int, 8>(), NTc); break;
+      default: go(std::integral_constant<int, 4>(), NTc); break;
+    }
+  };
+  if (nt) pick(std::true_type()); else pick(std::false_type());
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
 // ---- generic path ----------------------------------------------------------------------------------------
 // Tile of TW x TH output components; LDS holds (TH + R - 1) x (TW + (C-1)*ch) components in the promoted type.
 template <class T, class S, int TW, int TH>
@@ -385,6 +478,9 @@ extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* s
       case 4: return launch_fast<4>(dst, src, st);
     }
   }
+  if ((dst->dtype == VPP_I32 || dst->dtype == VPP_U32) && dst->channels == 1 && R == 5 && C == 5 && aligned16(dst) && aligned16(src) &&
+      !tuning("box.force_generic", 0))
+    return dst->dtype == VPP_I32 ? launch_w32<int32_t>(dst, src, st) : launch_w32<uint32_t>(dst, src, st);
   switch (dst->dtype) {
     case VPP_U8: return launch_generic<uint8_t, int>(dst, src, R, C, st);
     case VPP_I8: return launch_generic<int8_t, int>(dst, src, R, C, st);
