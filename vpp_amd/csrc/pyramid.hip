@@ -8,7 +8,8 @@
 //   L(r, cc)  = V((1*S(H(r-2,cc)) + 4*S(H(r-1,cc)) + 6*S(H(r,cc)) + 4*S(H(r+1,cc)) + 1*S(H(r+2,cc))) / 16)
 //   next(r,c) = (2r < nr && 2c < nc) ? L(2r, 2c) : 0        (the reference reads an unfilled temp border there)
 // then fill_border_mirror(next) (pyramid.hh:182) as a second launch of the K3 kernel.
-// Launch-latency bound at the sizes in play (<= 16.6 MB in, 4.1 MB out for the 1080p vfloat2 gradient pyramid).
+// L1-bound on its 5-tap gathers; each thread marches down 4 or 8 output rows so that the H pass of an input row is evaluated
+// once per output column instead of up to three times.
 #include "common.hpp"
 using namespace vpp_amd;
 
@@ -39,16 +40,37 @@ template <class T, class S> __device__ __forceinline__ T lowpass_at(const DImg& 
   return tap5<T, S>(h[0], h[1], h[2], h[3], h[4]);
 }
 
-template <class T, class S>
+// One thread = one output component marching down TH output rows: consecutive output rows share three of their five
+// H-pass rows (input rows 2r-2 .. 2r+2), so only two new H values are evaluated per row after the first.
+template <class T, class S, int TH>
 __global__ __launch_bounds__(256) void pyr_down_kernel(DImg next, DImg prev) {
   const int ch = prev.ch;
   const int comp = blockIdx.x * 256 + threadIdx.x;  // component index within the output row
-  const int r = blockIdx.y;
   if (comp >= next.nc * ch) return;
   const int c = comp / ch, k = comp - c * ch;
-  T v = 0;
-  if (2 * r < prev.nr && 2 * c < prev.nc) v = lowpass_at<T, S>(prev, 2 * r, 2 * c * ch + k, ch);
-  next.row<T>(r)[comp] = v;
+  const int r0 = blockIdx.y * TH;
+  const bool col_ok = 2 * c < prev.nc;
+  const int icomp = 2 * c * ch + k;
+  S h[5];
+  if (col_ok && 2 * r0 < prev.nr) {
+#pragma unroll
+    for (int j = 0; j < 5; j++) h[j] = (S)hpass<T, S>(prev, mirror_row(2 * r0 - 2 + j, prev.nr), icomp, ch);
+  }
+#pragma unroll
+  for (int j = 0; j < TH; j++) {
+    const int r = r0 + j;
+    if (r >= next.nr) break;
+    T v = 0;
+    if (col_ok && 2 * r < prev.nr) {
+      if (j > 0) {
+        h[0] = h[2]; h[1] = h[3]; h[2] = h[4];
+        h[3] = (S)hpass<T, S>(prev, mirror_row(2 * r + 1, prev.nr), icomp, ch);
+        h[4] = (S)hpass<T, S>(prev, mirror_row(2 * r + 2, prev.nr), icomp, ch);
+      }
+      v = tap5<T, S>(h[0], h[1], h[2], h[3], h[4]);
+    }
+    next.row<T>(r)[comp] = v;
+  }
 }
 
 template <class T, class S>
@@ -85,11 +107,13 @@ int vpp_pyr_down(const vpp_image_desc* next, const vpp_image_desc* prev, void* s
               "vpp_pyr_down: next must be (1+nr/2, 1+nc/2) = (%d,%d), got (%d,%d) (pyramid.hh:140)", 1 + prev->nrows / 2, 1 + prev->ncols / 2,
               next->nrows, next->ncols);
   hipStream_t st = as_stream(stream);
-  dim3 grid((next->ncols * next->channels + 255) / 256, next->nrows);
+  const int gx = (next->ncols * next->channels + 255) / 256;
+  const bool tall = tuning("pyr.rows", (long long)next->nrows * next->ncols >= (1 << 20) ? 8 : 4) == 8;  // enough waves either way
   DImg n = dimg(next), p = dimg(prev);
   int rc = by_dtype(prev->dtype, [&](auto t) {
     typedef decltype(t) T; typedef typename Promo<T>::type S;
-    pyr_down_kernel<T, S><<<grid, 256, 0, st>>>(n, p);
+    if (tall) pyr_down_kernel<T, S, 8><<<dim3(gx, (next->nrows + 7) / 8), 256, 0, st>>>(n, p);
+    else pyr_down_kernel<T, S, 4><<<dim3(gx, (next->nrows + 3) / 4), 256, 0, st>>>(n, p);
     return (int)VPP_OK;
   });
   if (rc != VPP_OK) return rc;
