@@ -297,18 +297,22 @@ __global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ 
   const bool in_reach = x + 4 > lo && x < ncols + 4, inside = x >= lo && x + 4 <= hi;
   const bool writer = lane >= 1 && lane <= 62 && x < ncols;
   typedef typename std::make_unsigned<T>::type U;  // sums wrap like the hardware's int adds (no signed-overflow UB in the source)
+  // Every load is unconditional so that the RW + 4 rows are requested back to back: rows past the bottom border are clamped
+  // (they only feed output rows >= nrows, which are not stored), lanes outside the strip's reach read a valid chunk that
+  // nobody consumes, and only the waves that contain a chunk straddling a row end (first / last strip) take the
+  // per-element form (clamped address + select), as a wave-uniform choice.
+  const bool vector_wave = __all(inside || !in_reach);
   U raw[RW + 4][4];
 #pragma unroll
   for (int k = 0; k < RW + 4; k++) {
-    const int r = r0 - 2 + k;
-    raw[k][0] = raw[k][1] = raw[k][2] = raw[k][3] = 0;
-    if (in_reach && r <= nrows - 1 + border && r >= -border) {
-      const U* row = (const U*)((const uint8_t*)sp + (ptrdiff_t)r * spitch);
-      if (inside) { const u32x4 v = *(const u32x4*)(row + x); raw[k][0] = v.x; raw[k][1] = v.y; raw[k][2] = v.z; raw[k][3] = v.w; }
-      else {
+    const int r = min(r0 - 2 + k, nrows - 1 + border);
+    const U* row = (const U*)((const uint8_t*)sp + (ptrdiff_t)r * spitch);
+    if (vector_wave) {
+      const u32x4 v = *(const u32x4*)(row + (in_reach ? x : 0));
+      raw[k][0] = v.x; raw[k][1] = v.y; raw[k][2] = v.z; raw[k][3] = v.w;
+    } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const int c = x + i; const U v = row[min(max(c, lo), hi - 1)]; raw[k][i] = (c >= lo && c < hi) ? v : 0; }
-      }
+      for (int i = 0; i < 4; i++) { const int c = x + i; const U v = row[min(max(c, lo), hi - 1)]; raw[k][i] = (c >= lo && c < hi) ? v : 0; }
     }
   }
   U V[4] = {0, 0, 0, 0};
