@@ -51,8 +51,9 @@ typedef struct vpp_image_desc {
  *      vpp/core/imageNd.hpp:177-180, and hangs the device mirror's deleter beside it) ---- */
 int vpp_init(int device);                       /* hipSetDevice + warm the context */
 int vpp_device_count(int* n);
-int vpp_malloc(size_t bytes, void** dptr);
+int vpp_malloc(size_t bytes, void** dptr);        /* freed blocks are cached per device and reused by size (no hipFree sync per frame) */
 int vpp_free(void* dptr);
+int vpp_release_cached_memory(void);             /* hipFree everything vpp_free is holding on the current device */
 int vpp_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int vpp_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int vpp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);

@@ -20,6 +20,26 @@ int tuning(const char* name, int dflt) {
 }  // namespace vpp_amd
 using namespace vpp_amd;
 
+namespace {
+struct DevicePool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;   // rounded size -> block
+  std::map<void*, size_t> live;               // every block handed out, with its rounded size
+  size_t cached_bytes = 0;
+};
+DevicePool& pool_of_current_device() {
+  static std::mutex mu;
+  static std::map<int, DevicePool*> pools;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> l(mu);
+  DevicePool*& p = pools[dev];
+  if (!p) p = new DevicePool();   // intentionally never destroyed: the HIP runtime may already be gone at exit
+  return *p;
+}
+inline size_t round_block(size_t bytes) { return ((bytes ? bytes : 1) + 255) / 256 * 256; }
+}  // namespace
+
 extern "C" {
 
 const char* vpp_last_error(void) { return g_err; }
@@ -42,12 +62,66 @@ int vpp_init(int device) {
   VPP_HIP_TRY(hipFree(nullptr));
   return VPP_OK;
 }
+// vpp_malloc / vpp_free keep freed blocks in per-device, exact-size free lists instead of returning them to the driver:
+// hipMalloc / hipFree cost 0.1-0.3 ms each and hipFree synchronises the device, which a per-frame caller (keypoint lists,
+// result buffers, image mirrors of the same shapes every frame) would pay several times per frame.  A cached block is handed
+// out again without synchronisation: callers order their work on streams, exactly as they would around a real allocation
+// that returns recently freed memory.  Cap: tuning "runtime.pool_mb" (default 2048 MiB per device, 0 disables the cache).
 int vpp_malloc(size_t bytes, void** dptr) {
   VPP_REQUIRE(dptr, VPP_ERR_INVALID_ARG, "vpp_malloc: null out pointer");
-  VPP_HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+  const size_t rb = round_block(bytes);
+  DevicePool& P = pool_of_current_device();
+  {
+    std::lock_guard<std::mutex> l(P.mu);
+    auto it = P.free_blocks.find(rb);
+    if (it != P.free_blocks.end()) {
+      *dptr = it->second;
+      P.free_blocks.erase(it);
+      P.cached_bytes -= rb;
+      P.live[*dptr] = rb;
+      return VPP_OK;
+    }
+  }
+  hipError_t e = hipMalloc(dptr, rb);
+  if (e != hipSuccess) {  // out of memory: give the cached blocks back to the driver and retry once
+    (void)hipGetLastError();
+    vpp_release_cached_memory();
+    e = hipMalloc(dptr, rb);
+  }
+  if (e != hipSuccess) { set_error("vpp_malloc: hipMalloc(%zu) failed: %s", rb, hipGetErrorString(e)); return VPP_ERR_HIP; }
+  std::lock_guard<std::mutex> l(P.mu);
+  P.live[*dptr] = rb;
   return VPP_OK;
 }
-int vpp_free(void* dptr) { VPP_HIP_TRY(hipFree(dptr)); return VPP_OK; }
+
+int vpp_free(void* dptr) {
+  if (!dptr) return VPP_OK;
+  DevicePool& P = pool_of_current_device();
+  const size_t cap = (size_t)tuning("runtime.pool_mb", 2048) << 20;
+  {
+    std::lock_guard<std::mutex> l(P.mu);
+    auto it = P.live.find(dptr);
+    if (it != P.live.end()) {
+      const size_t rb = it->second;
+      P.live.erase(it);
+      if (P.cached_bytes + rb <= cap) { P.free_blocks.emplace(rb, dptr); P.cached_bytes += rb; return VPP_OK; }
+    }
+  }
+  VPP_HIP_TRY(hipFree(dptr));
+  return VPP_OK;
+}
+
+int vpp_release_cached_memory(void) {
+  DevicePool& P = pool_of_current_device();
+  std::multimap<size_t, void*> blocks;
+  {
+    std::lock_guard<std::mutex> l(P.mu);
+    blocks.swap(P.free_blocks);
+    P.cached_bytes = 0;
+  }
+  for (auto& b : blocks) VPP_HIP_TRY(hipFree(b.second));
+  return VPP_OK;
+}
 int vpp_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
   VPP_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
   VPP_HIP_TRY(hipStreamSynchronize(as_stream(stream)));  // src is pageable host memory the caller may reuse

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(1024) void sdof_propagate_kernel(DImg i1, DImg i2, 
 // re-runs loop_body in place (SADs and all) only for cells behind a neighbour that really changed.  Same result as the
 // serial reference, but the 81-pixel SADs no longer sit on the critical path of the wavefront.
 struct Cell { int f0, f1, dist, mark; };  // mark: low byte = flow_map_mark value, bit 8 = changed during this sweep
-constexpr int kChanged = 0x100;
+constexpr int kChanged = 0x100;  // Jacobi result array only: the Jacobi pass changed this cell
+constexpr int kDirty = 0x400;    // ring only: an earlier neighbour changed during this sweep, the Jacobi outcome does not apply
 constexpr int kJChanged = 0x200;  // skewed-copy-only flag: the Jacobi pass wants to change this cell
 
 // Per (cell, neighbour) results of the costly calls of loop_body, keyed by the neighbour flow they were computed for.
@@ -299,8 +300,9 @@ __device__ __noinline__ SlowResult sweep_slow_path(const DImg& i1, const DImg& i
 // sdof_jacobi_kernel; they are copied into ring slot t & (K-1) by LDS-direct loads (global_load_lds_dwordx4: no VGPR
 // destination, so no register of the step code ever waits on them), issued P steps ahead in batches of QD and awaited
 // once per batch.  Slot t is read during steps t-3 .. t+3 (t+1 .. t+3 only by the slow path), hence P >= QD + 3 (landed in
-// time) and P + QD <= K - 3 (the slot being overwritten is no longer read).  The common path (no earlier neighbour changed,
-// Jacobi verdict "unchanged") is five conflict-free LDS reads and a barrier.
+// time) and P + QD <= K - 3 (the slot being overwritten is no longer read).  A cell that changes flags its four later
+// neighbours dirty (LDS atomic OR) instead of every cell gathering the flags of its four earlier neighbours, so the common
+// path (not dirty, Jacobi verdict "unchanged") is ONE conflict-free 16-byte LDS read and a barrier per step.
 __device__ unsigned g_sweep_stats[4];  // [0] marked cells visited, [1] Jacobi outcomes applied, [2] slow-path recomputations, [3] slow-path changes
 
 template <int K>
@@ -322,10 +324,9 @@ __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(skew + (size_t)t * NIp + threadIdx.x),
                                      (__attribute__((address_space(3))) void*)(ring + (size_t)(t & (K - 1)) * NIp + wave_base), 16, 0, 0);
   };
-  auto mark_of = [&](int drow, int col) -> int {  // mark word of the ring cell at wavefront (iw + drow, col); 0 outside the map
+  auto flag_dirty = [&](int drow, int col) {  // two rows can flag the same cell in one step: LDS atomic
     const int r = iw + drow;
-    if (r < 0 || r >= NI || col < 0 || col >= NJ) return 0;
-    return ring_cell<K>(ring, NIp, r, col)->mark;
+    if (r < NI && col >= 0 && col < NJ) atomicOr(&const_cast<Cell*>(ring_cell<K>(ring, NIp, r, col))->mark, kDirty);
   };
   for (int t = 0; t < P; t++) issue(t);
   for (int tb = 0; tb <= tmax; tb += QD) {
@@ -341,23 +342,23 @@ __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg
         Cell* myp = ring + (size_t)(t & (K - 1)) * NIp + iw;
         Cell cur = *myp;
         if (cur.mark & 0xFF) {
-          // the four neighbours visited before this cell in the sweep
-          const int dirty = (mark_of(-1, jw - 1) | mark_of(-1, jw) | mark_of(-1, jw + 1) | mark_of(0, jw - 1)) & kChanged;
           const int cj = forward ? jw : NJ - 1 - jw;
           bool changed = false;
-          if (stats & 1) atomicAdd(&g_sweep_stats[0], 1u);
-          if (!dirty) {
-            if (cur.mark & kJChanged) { cur = J[(size_t)ci * NJ + cj]; changed = true; if (stats & 1) atomicAdd(&g_sweep_stats[1], 1u); }  // Jacobi outcome is the sequential one
+          if (stats) atomicAdd(&g_sweep_stats[0], 1u);
+          if (!(cur.mark & kDirty)) {  // none of the four neighbours visited earlier changed: the Jacobi outcome is the sequential one
+            if (cur.mark & kJChanged) { cur = J[(size_t)ci * NJ + cj]; changed = true; if (stats) atomicAdd(&g_sweep_stats[1], 1u); }
           } else {
             const SlowResult sr = sweep_slow_path<K>(i1, i2, ws, patch, forward, iw, jw, NI, NJ, NIp, ring, cur, pairs + ((size_t)ci * NJ + cj) * 8);
             cur = sr.cell; changed = sr.changed != 0;
-            if (stats & 1) { atomicAdd(&g_sweep_stats[2], 1u); if (changed) atomicAdd(&g_sweep_stats[3], 1u); }
+            if (stats) { atomicAdd(&g_sweep_stats[2], 1u); if (changed) atomicAdd(&g_sweep_stats[3], 1u); }
           }
           if (changed) {
-            cur.mark = (cur.mark & 0xFF) | kChanged;
+            cur.mark &= 0xFF;
             *myp = cur;
             int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
-            f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)(cur.mark & 0xFF);
+            f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)cur.mark;
+            // tell the four cells that are visited later and read this one (steps t+1 .. t+3, slots already resident)
+            flag_dirty(0, jw + 1); flag_dirty(1, jw - 1); flag_dirty(1, jw); flag_dirty(1, jw + 1);
           }
         }
       }
