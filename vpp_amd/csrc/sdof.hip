@@ -211,7 +211,9 @@ __device__ __forceinline__ bool loop_body(const DImg& i1, const DImg& i2, int ws
   const int prev0 = cur.f0, prev1 = cur.f1;
   bool changed = false;
   int k = -1;
+#pragma unroll
   for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
     for (int dc = -1; dc <= 1; dc++) {
       if (!dr && !dc) continue;
       k++;
@@ -291,7 +293,12 @@ __device__ __noinline__ SlowResult sweep_slow_path(const DImg& i1, const DImg& i
   };
   // flow-map offset (dr,dc) -> wavefront offset: mirrored in the backward sweep
   auto nbr = [&](int dr, int dc) -> Cell { return forward ? wnbr(dr, jw + dc) : wnbr(-dr, jw - dc); };
-  const bool changed = loop_body<false>(i1, i2, ws, r, c, cur, nbr, pc);
+  // the eight pair-cache entries of the cell in one memory round trip (read one by one inside loop_body they were eight
+  // dependent L2 misses on the critical path of the wavefront)
+  PairCache loc[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) loc[k] = pc[k];
+  const bool changed = loop_body<false>(i1, i2, ws, r, c, cur, nbr, loc);
   return SlowResult{cur, changed ? 1 : 0};
 }
 
