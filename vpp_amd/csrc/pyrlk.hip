@@ -43,6 +43,16 @@ __device__ __forceinline__ void interp(const DImg& I, float p0, float p1, T* out
   const int es = (int)sizeof(T) * CH;
   const int o00 = r0 * I.pitch + c0 * es, o10 = r1 * I.pitch + c0 * es, o01 = r0 * I.pitch + c1 * es, o11 = r1 * I.pitch + c1 * es;
   const float w00 = (1 - a0) * (1 - a1), w10 = a0 * (1 - a1), w01 = (1 - a0) * a1, w11 = a0 * a1;
+  if constexpr (SAFE && sizeof(T) == 1 && CH == 1) {
+    // the two taps of a row are adjacent bytes: one (unaligned) 16-bit load per row instead of two byte loads — the kernel
+    // issues ~2700 tap loads per wave and is bound by how fast the texture path takes them, not by bytes
+    uint16_t t0, t1;
+    __builtin_memcpy(&t0, I.p0 + o00, 2);
+    __builtin_memcpy(&t1, I.p0 + o10, 2);
+    const float v = w00 * (float)(T)(t0 & 255) + w10 * (float)(T)(t1 & 255) + w01 * (float)(T)(t0 >> 8) + w11 * (float)(T)(t1 >> 8);
+    out[0] = (T)v;
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < CH; k++) {
     const float v = w00 * (float)((const T*)(I.p0 + o00))[k] + w10 * (float)((const T*)(I.p0 + o10))[k] + w01 * (float)((const T*)(I.p0 + o01))[k] +
@@ -420,7 +430,7 @@ int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, cons
   hipStream_t st = as_stream(stream);
   // lanes per keypoint: enough waves to cover the 1024 SIMDs a few times over, no more (total work grows with LPK)
   int lpk = tuning("pyrlk.lpk", 0);
-  if (lpk == 0) lpk = n >= 8000 ? 8 : (n >= 3500 ? 32 : 64);  // measured: tools/tune_pyrlk.py (LPK = 8 also beats 1 lane per keypoint at 400 k keypoints)
+  if (lpk == 0) lpk = n >= 20000 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));  // measured: tools/tune_pyrlk.py (LPK = 8 also beats 1 lane per keypoint at 400 k keypoints)
   if (winsize > 7) lpk = 1;  // the group kernels keep a 64-bit validity mask (WS*WS <= 64); larger windows: one lane per keypoint
 #define VPP_LK_LAUNCH(W)                                                                                                                           \
   if (lpk == 64) pyrlk_match_group_kernel<W, 64><<<n, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
@@ -453,7 +463,7 @@ int vpp_lucas_kanade(const vpp_image_desc* prev, const vpp_image_desc* grad, con
   if (n == 0) return VPP_OK;
   hipStream_t st = as_stream(stream);
   int lpk = tuning("pyrlk.lpk", 0);
-  if (lpk == 0) lpk = n >= 8000 ? 8 : (n >= 3500 ? 32 : 64);  // measured: tools/tune_pyrlk.py (LPK = 8 also beats 1 lane per keypoint at 400 k keypoints)
+  if (lpk == 0) lpk = n >= 20000 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));  // measured: tools/tune_pyrlk.py (LPK = 8 also beats 1 lane per keypoint at 400 k keypoints)
   if (winsize > 7) lpk = 1;
   const float fev = (float)min_ev, fdelta = (float)delta;
 #define VPP_LK_LAUNCH(W)                                                                                                                           \
