@@ -66,6 +66,9 @@ __device__ __forceinline__ bool nine_contiguous(uint32_t m16) {
   return (y & 0xFFFFu) != 0;
 }
 
+// LDS hand-off inside one wave: make this wave's LDS writes visible to its own later reads (no workgroup barrier needed)
+__device__ __forceinline__ void wave_fence_lds() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
 // shift a comparison result into a ring mask without a compare: (m << 1) | (d < 0), one v_alignbit_b32
 __device__ __forceinline__ uint32_t push_sign(uint32_t m, int d) { return __builtin_amdgcn_alignbit(m, (uint32_t)d, 31); }
 
@@ -147,6 +150,108 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
     if (c == A.nc - 1) fr[A.nc] = 0;
     const uint64_t corners = __ballot(f != 0);  // one 64-px word of the corner bitmap per wave and row
     if (lane == 0) bitmap[(size_t)r * ntc + blockIdx.x] = corners;
+  }
+}
+
+// Two-phase variant of the detect kernel.  In the kernel above a wave pays the full ring test whenever ANY of its 64 lanes
+// passes the four-sample pre-test, and on natural images nearly every wave has such a lane.  Here phase 1 runs the pre-test for
+// every pixel of the wave's 16 rows without divergence, writes F = 0 rows (coalesced) and appends the survivors to a per-wave
+// LDS list (ballot + mbcnt prefix); phase 2 runs the ring test and the score on the list, 64 candidates per pass, so its lanes
+// are all busy; corners overwrite their F entry and set their bit in a per-wave LDS copy of the 16 bitmap words.
+template <bool REF>
+__global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int has_mask, int th, DImg F, uint64_t* __restrict__ bitmap, int ntc) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[LROWS * LP];
+  __shared__ uint16_t cand[4][TH / 4 * TW];          // per wave: (row in the wave's band) * 64 + column
+  __shared__ unsigned long long words[4][TH / 4];    // per wave: corner bitmap words of its 16 rows
+  const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
+  const int lo = -A.border, hi = A.nc + A.border;
+  const bool aligned = (((uintptr_t)A.p0 | (uintptr_t)A.pitch) & 3) == 0;
+  for (int i = threadIdx.x; i < LROWS * LDW; i += 256) {
+    const int lr = i / LDW, ld = i - lr * LDW;
+    const int r = r0 - HALO + lr;
+    uint32_t v = 0;
+    if (r < A.nr + A.border) v = ld_dword_guarded_px(A.p0 + (ptrdiff_t)r * A.pitch, c0 - 4 + 4 * ld, lo, hi, aligned);
+    ((uint32_t*)tile)[i] = v;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane < TH / 4) words[wv][lane] = 0;
+  __syncthreads();
+  const int c = c0 + lane;
+  const bool col_ok = c < A.nc;
+  const int thc = min(max(th, 0), 255);
+  if (col_ok && ((blockIdx.y == 0 && wv == 0) || (r0 + TH >= A.nr && wv == 1))) {
+    uint16_t* fb = F.row<uint16_t>(wv == 0 ? -1 : A.nr);
+    fb[c] = 0;
+    if (c == 0) fb[-1] = 0;
+    if (c == A.nc - 1) fb[A.nc] = 0;
+  }
+  // ---- phase 1: pre-test on the four cardinal samples (any 9 contiguous ring positions contain two of {0, 4, 8, 12}) ----
+  int ncand = 0;
+#pragma unroll 4
+  for (int j = 0; j < TH / 4; j++) {
+    const int lr = wv * (TH / 4) + j;
+    const int r = r0 + lr;
+    bool pass = false;
+    if (col_ok && r < A.nr) {
+      const uint8_t* p = tile + (lr + HALO) * LP + lane + 4;
+      const int v = p[0];
+      const int vhi = min(v + thc, 255), vlo = max(v - thc, 0);
+      uint32_t qb = 0, qd = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) { const int x = p[ring_dr<REF>(i) * LP + ring_dc(i)]; qb = push_sign(qb, vhi - x); qd = push_sign(qd, x - vlo); }
+      pass = ((qb & (qb - 1)) | (qd & (qd - 1))) != 0;
+      uint16_t* fr = F.row<uint16_t>(r);
+      fr[c] = 0;
+      if (c == 0) fr[-1] = 0;
+      if (c == A.nc - 1) fr[A.nc] = 0;
+    }
+    const unsigned long long m = __ballot(pass);
+    if (pass) cand[wv][ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(j * TW + lane);
+    ncand += __popcll(m);
+  }
+  wave_fence_lds();
+  // ---- phase 2: ring test + score on the compacted candidates ----
+  for (int base = 0; base < ncand; base += 64) {
+    const int k = base + lane;
+    if (k < ncand) {
+      const int id = cand[wv][k], j = id / TW, col = id - j * TW;
+      const int lr = wv * (TH / 4) + j;
+      const uint8_t* p = tile + (lr + HALO) * LP + col + 4;
+      const int v = p[0];
+      const int vhi = min(v + thc, 255), vlo = max(v - thc, 0);
+      int x[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) x[i] = p[ring_dr<REF>(i) * LP + ring_dc(i)];
+      uint32_t mb = 0, md = 0;
+#pragma unroll
+      for (int i = 15; i >= 0; i--) { mb = push_sign(mb, vhi - x[i]); md = push_sign(md, x[i] - vlo); }
+      int planes = (nine_contiguous(mb) ? 0x10 : 0) | (nine_contiguous(md) ? 0x01 : 0);
+      if (has_mask && planes) planes &= M.row<uint8_t>(r0 + lr)[c0 + col];
+      if (planes) {
+        if (REF) {  // only a4 / a12 differ from the samples the detector used
+          x[4] = p[3]; x[12] = p[-3];
+          mb = (mb & ~0x1010u) | ((uint32_t)(vhi - x[4]) >> 31 << 4) | ((uint32_t)(vhi - x[12]) >> 31 << 12);
+          md = (md & ~0x1010u) | ((uint32_t)(x[4] - vlo) >> 31 << 4) | ((uint32_t)(x[12] - vlo) >> 31 << 12);
+        }
+        const uint32_t dnc = (uint32_t)max(v - th, 0), upc = (uint32_t)min(v + th, 255);
+        const uint32_t dn4 = dnc * 0x01010101u, up4 = upc * 0x01010101u;
+        uint32_t sx = 0, sdn = 0, sup = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t X = (uint32_t)x[4 * q] | ((uint32_t)x[4 * q + 1] << 8) | ((uint32_t)x[4 * q + 2] << 16) | ((uint32_t)x[4 * q + 3] << 24);
+          sx = __builtin_amdgcn_sad_u8(X, 0u, sx); sdn = __builtin_amdgcn_sad_u8(X, dn4, sdn); sup = __builtin_amdgcn_sad_u8(X, up4, sup);
+        }
+        const int over_sup = (int)(sdn + 16u * dnc - sx) >> 1, over_inf = (int)(sup + sx - 16u * upc) >> 1;
+        const uint32_t f = (uint32_t)max(th * __popc(md) + over_sup, th * __popc(mb) + over_inf) + 1u;
+        F.row<uint16_t>(r0 + lr)[c0 + col] = (uint16_t)f;
+        atomicOr(&words[wv][j], 1ull << col);
+      }
+    }
+  }
+  wave_fence_lds();
+  if (lane < TH / 4) {
+    const int r = r0 + wv * (TH / 4) + lane;
+    if (r < A.nr) bitmap[(size_t)r * ntc + blockIdx.x] = words[wv][lane];
   }
 }
 
@@ -379,7 +484,10 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   uint32_t* unit_off = (uint32_t*)(base + off_uo);
   DImg A = dimg(src), M = mask ? dimg(mask) : A;
   dim3 grid(ntc, (nr + TH - 1) / TH);
-  if (compat == VPP_FAST9_REFERENCE) fast9_detect_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
+  if (tuning("fast9.impl", 2) == 2) {  // 2 = two-phase (compacted candidates), 1 = one lane per pixel all the way
+    if (compat == VPP_FAST9_REFERENCE) fast9_detect2_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
+    else fast9_detect2_kernel<false><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
+  } else if (compat == VPP_FAST9_REFERENCE) fast9_detect_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
   else fast9_detect_kernel<false><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
   VPP_LAUNCH_CHECK();
   if (mode == VPP_FAST9_BLOCKWISE) {
