@@ -42,7 +42,9 @@ template <class T, class S> __device__ __forceinline__ T lowpass_at(const DImg& 
 
 // One thread = one output component marching down TH output rows: consecutive output rows share three of their five
 // H-pass rows (input rows 2r-2 .. 2r+2), so only two new H values are evaluated per row after the first.
-template <class T, class S, int TH>
+// FUSE: the thread also writes the mirrored copies of its pixel into next's border (fill_border_mirror(next), pyramid.hh:182),
+// which saves the separate border launch; used when the border is not wider than the level itself.
+template <class T, class S, int TH, bool FUSE>
 __global__ __launch_bounds__(256) void pyr_down_kernel(DImg next, DImg prev) {
   const int ch = prev.ch;
   const int comp = blockIdx.x * 256 + threadIdx.x;  // component index within the output row
@@ -70,6 +72,18 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(DImg next, DImg prev) {
       v = tap5<T, S>(h[0], h[1], h[2], h[3], h[4]);
     }
     next.row<T>(r)[comp] = v;
+    if (FUSE) {  // border pixel (-k, c) <- (k-1, c), (nr-1+k, c) <- (nr-k, c), same for columns, corners in both axes (fill.hh:60-83)
+      const int b = next.border;
+      const int mr = r < b ? -r - 1 : (r >= next.nr - b ? 2 * next.nr - r - 1 : r);
+      const int mr2 = (r < b && r >= next.nr - b) ? 2 * next.nr - r - 1 : mr;          // a row within b of both ends mirrors both ways
+      const int mc = c < b ? -c - 1 : (c >= next.nc - b ? 2 * next.nc - c - 1 : c);
+      const int mc2 = (c < b && c >= next.nc - b) ? 2 * next.nc - c - 1 : mc;
+      const int mcomp = mc * ch + k, mcomp2 = mc2 * ch + k;
+      if (mc != c) next.row<T>(r)[mcomp] = v;
+      if (mc2 != mc) next.row<T>(r)[mcomp2] = v;
+      if (mr != r) { next.row<T>(mr)[comp] = v; if (mc != c) next.row<T>(mr)[mcomp] = v; if (mc2 != mc) next.row<T>(mr)[mcomp2] = v; }
+      if (mr2 != mr) { next.row<T>(mr2)[comp] = v; if (mc != c) next.row<T>(mr2)[mcomp] = v; if (mc2 != mc) next.row<T>(mr2)[mcomp2] = v; }
+    }
   }
 }
 
@@ -108,17 +122,23 @@ int vpp_pyr_down(const vpp_image_desc* next, const vpp_image_desc* prev, void* s
               next->nrows, next->ncols);
   hipStream_t st = as_stream(stream);
   const int gx = (next->ncols * next->channels + 255) / 256;
+  const bool fuse = next->border <= next->nrows && next->border <= next->ncols && tuning("pyr.fuse_border", 1);
   const bool tall = tuning("pyr.rows", (long long)next->nrows * next->ncols >= (1 << 20) ? 8 : 4) == 8;  // enough waves either way
   DImg n = dimg(next), p = dimg(prev);
   int rc = by_dtype(prev->dtype, [&](auto t) {
     typedef decltype(t) T; typedef typename Promo<T>::type S;
-    if (tall) pyr_down_kernel<T, S, 8><<<dim3(gx, (next->nrows + 7) / 8), 256, 0, st>>>(n, p);
-    else pyr_down_kernel<T, S, 4><<<dim3(gx, (next->nrows + 3) / 4), 256, 0, st>>>(n, p);
+    if (fuse) {
+      if (tall) pyr_down_kernel<T, S, 8, true><<<dim3(gx, (next->nrows + 7) / 8), 256, 0, st>>>(n, p);
+      else pyr_down_kernel<T, S, 4, true><<<dim3(gx, (next->nrows + 3) / 4), 256, 0, st>>>(n, p);
+    } else {
+      if (tall) pyr_down_kernel<T, S, 8, false><<<dim3(gx, (next->nrows + 7) / 8), 256, 0, st>>>(n, p);
+      else pyr_down_kernel<T, S, 4, false><<<dim3(gx, (next->nrows + 3) / 4), 256, 0, st>>>(n, p);
+    }
     return (int)VPP_OK;
   });
   if (rc != VPP_OK) return rc;
   VPP_LAUNCH_CHECK();
-  return launch_fill_border(next, VPP_BORDER_MIRROR, nullptr, st);
+  return fuse ? (int)VPP_OK : launch_fill_border(next, VPP_BORDER_MIRROR, nullptr, st);
 }
 
 int vpp_lowpass5(const vpp_image_desc* out, const vpp_image_desc* in, void* stream) {
