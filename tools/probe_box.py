@@ -39,3 +39,9 @@ print(f"torch copy 25 MB -> 25 MB: {us:.2f} us  ({50e6/us/1e6:.2f} TB/s)")
 x = [torch.empty(100_000_000, dtype=torch.uint8, device="cuda") for _ in range(4)]; y = [torch.empty(100_000_000, dtype=torch.uint8, device="cuda") for _ in range(4)]
 us = time_graph(lambda i, s: y[i % 4].copy_(x[i % 4]), 100)
 print(f"torch copy 100 MB -> 100 MB: {us:.2f} us  ({200e6/us/1e6:.2f} TB/s)")
+
+# a 1:1 read/write stream of the box's byte counts through the runtime's own device-to-device copy
+import ctypes
+ha = [torch.empty(25_000_000, dtype=torch.uint8, device="cuda") for _ in range(ns)]; hb = [torch.empty(25_000_000, dtype=torch.uint8, device="cuda") for _ in range(ns)]
+us = time_graph(lambda i, s: lib.vpp_memcpy_d2d(ctypes.c_void_p(hb[i % ns].data_ptr()), ctypes.c_void_p(ha[i % ns].data_ptr()), 25_000_000, s))
+print(f"hipMemcpyDtoDAsync 25 MB -> 25 MB: {us:.2f} us  ({50e6/us/1e6:.2f} TB/s)")
