@@ -49,6 +49,21 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
            "tracks_per_s": NK / (wall / steps), "ms_per_frame": wall / steps * 1e3, "keypoints_per_rank": n_local,
            "exchange": "rccl all_gather of 20-byte keypoint records" if world > 1 else "none (1 GPU)"}
 
+    if world > 1:
+        # weak scaling in keypoints: NK keypoints PER rank (a denser keypoint set on the same frame pair, rank g owning the slice
+        # [g*NK, (g+1)*NK) of world*NK), the all-gather carries all world*NK records
+        full0 = torch.from_numpy(kps_h.view(np.uint8).reshape(-1).copy()).to(dev)
+        full = full0.clone()
+
+        def step_weak(i, stream):
+            full.copy_(full0, non_blocking=True)
+            match(dp1, dg1, dp2, L, V(full.data_ptr()), NK, WS, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None, stream)
+            mg.all_gather_records(full, NK * world, rank, world)
+
+        wwall, _ = timed(step_weak, steps, warmup, graph=False)
+        res["weak_scaling"] = {"keypoints_per_rank": NK, "tracks_per_s": NK * world / (wwall / steps), "ms_per_frame": wwall / steps * 1e3,
+                               "exchange": f"rccl all_gather of {NK * world} 20-byte records"}
+
     # pyramids + gradient of a frame pair (what a caller pays per new frame besides the match)
     def step_pyr(i, stream):
         lib.vpp_copy(P(p2[0].desc), P(d2.desc), 0, stream)
