@@ -25,6 +25,10 @@ def _sync(lib):
     (vi.F32, 2, (33, 47), 1, 32),
     (vi.I16, 1, (17, 19), 0, 2),          # unaligned -> scalar kernel
     (vi.U8, 1, (5, 7), 0, 1),
+    (vi.I8, 3, (64, 100), 0, 16),         # packed signed bytes
+    (vi.U16, 1, (33, 64), 0, 32),         # packed 16-bit
+    (vi.I16, 2, (40, 56), 1, 32),
+    (vi.U8, 3, (270, 480), 0, 16),        # flat path, packed bytes
 ])
 def test_pixelwise_binary_matches_oracle(lib, orc, op, dtype, ch, shape, border, align):
     lo, hi = (0, 2**30 - 1) if dtype == vi.I32 and op != 2 else (None, None)

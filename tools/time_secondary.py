@@ -39,6 +39,10 @@ box(vi.U8, 4, 5, 5, 2, 4)
 box(vi.F32, 1, 5, 5, 2, 4)
 box(vi.U8, 3, 3, 3, 1, 3)
 box(vi.U8, 3, 7, 7, 3, 3)
+# pixel_wise on 8-bit images (packed-byte arithmetic): 3 x 24.9 MB per launch
+for op, name in ((0, 'add'), (3, 'min'), (5, 'absdiff')):
+    A = [DeviceImage(NR, NC, vi.U8, 3, 0, 16) for _ in range(ns)]; B = [DeviceImage.from_host(rand_image(NR, NC, vi.U8, 3, seed=1, align=16)) for _ in range(2 * ns)]
+    us = time_graph(lambda i, s: lib.vpp_pixelwise_binary(op, P(A[i % ns].desc), P(B[2 * (i % ns)].desc), P(B[2 * (i % ns) + 1].desc), s)); print(f"pixel_wise {name} vuchar3 4K: {us:.2f} us  ({3 * NR * NC * 3 / us / 1e3:.1f} GB/s)")
 # border fill, pyramid level, scharr at 1080p / 4K
 for (nr, nc) in ((1080, 1920), (2160, 3840)):
     im = rand_image(nr, nc, vi.U8, 1, border=3, seed=4)

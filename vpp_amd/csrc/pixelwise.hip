@@ -40,13 +40,53 @@ template <int OP, class T> __device__ __forceinline__ T op_scalar(T a, T b) {
   }
 }
 
+// ---- 8-bit elements, four per dword, without unpacking to scalars (the per-byte form is ~4 VALU ops per byte and turns the
+// stream VALU-bound at 2.7 TB/s).  Results are modulo 256, exactly the conversion back to T of op_scalar. ----
+template <int OP, bool SIGNED> __device__ __forceinline__ uint32_t op_bytes(uint32_t x, uint32_t y) {
+  constexpr uint32_t H = 0x80808080u, L = 0x7f7f7f7fu, E = 0x00ff00ffu;
+  if constexpr (OP == VPP_OP_ADD) return ((x & L) + (y & L)) ^ ((x ^ y) & H);             // carries cannot cross a byte
+  else if constexpr (OP == VPP_OP_SUB) return ((x | H) - (y & L)) ^ ((x ^ ~y) & H);       // borrows cannot cross a byte
+  else {
+    if constexpr (SIGNED && OP != VPP_OP_MUL) { x ^= H; y ^= H; }                         // order-preserving map to unsigned bytes
+    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+    union { uint32_t u; u16x2 v; } xe, xo, ye, yo, re, ro;
+    xe.u = x & E; xo.u = (x >> 8) & E; ye.u = y & E; yo.u = (y >> 8) & E;                  // even / odd bytes as packed u16 pairs
+    if constexpr (OP == VPP_OP_MUL) { re.v = xe.v * ye.v; ro.v = xo.v * yo.v; }
+    else if constexpr (OP == VPP_OP_MIN) { re.v = __builtin_elementwise_min(xe.v, ye.v); ro.v = __builtin_elementwise_min(xo.v, yo.v); }
+    else if constexpr (OP == VPP_OP_MAX) { re.v = __builtin_elementwise_max(xe.v, ye.v); ro.v = __builtin_elementwise_max(xo.v, yo.v); }
+    else { re.v = __builtin_elementwise_max(xe.v, ye.v) - __builtin_elementwise_min(xe.v, ye.v);
+           ro.v = __builtin_elementwise_max(xo.v, yo.v) - __builtin_elementwise_min(xo.v, yo.v); }
+    uint32_t r = (re.u & E) | ((ro.u & E) << 8);
+    if constexpr (SIGNED && (OP == VPP_OP_MIN || OP == VPP_OP_MAX)) r ^= H;
+    return r;
+  }
+}
+
 template <int OP, class T> __device__ __forceinline__ u32x4 op_vec(u32x4 a, u32x4 b) {
-  constexpr int N = 16 / sizeof(T);
-  union { u32x4 v; T e[N]; } ua, ub, ur;
-  ua.v = a; ub.v = b;
+  if constexpr (sizeof(T) == 1) {
+    constexpr bool S = std::is_signed<T>::value;
+    return u32x4{op_bytes<OP, S>(a.x, b.x), op_bytes<OP, S>(a.y, b.y), op_bytes<OP, S>(a.z, b.z), op_bytes<OP, S>(a.w, b.w)};
+  } else if constexpr (sizeof(T) == 2) {  // packed 16-bit VALU ops (v_pk_add_u16, v_pk_min_i16, ...)
+    typedef T t16x8 __attribute__((ext_vector_type(8)));
+    typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+    union { u32x4 v; t16x8 t; u16x8 u; } ua, ub, ur;
+    ua.v = a; ub.v = b;
+    if constexpr (OP == VPP_OP_ADD) ur.u = ua.u + ub.u;
+    else if constexpr (OP == VPP_OP_SUB) ur.u = ua.u - ub.u;
+    else if constexpr (OP == VPP_OP_MUL) ur.u = ua.u * ub.u;
+    else if constexpr (OP == VPP_OP_MIN) ur.t = __builtin_elementwise_min(ua.t, ub.t);
+    else if constexpr (OP == VPP_OP_MAX) ur.t = __builtin_elementwise_max(ua.t, ub.t);
+    else { const t16x8 hi = __builtin_elementwise_max(ua.t, ub.t), lo = __builtin_elementwise_min(ua.t, ub.t);
+           union { t16x8 t; u16x8 u; } h, l; h.t = hi; l.t = lo; ur.u = h.u - l.u; }
+    return ur.v;
+  } else {
+    constexpr int N = 16 / sizeof(T);
+    union { u32x4 v; T e[N]; } ua, ub, ur;
+    ua.v = a; ub.v = b;
 #pragma unroll
-  for (int i = 0; i < N; i++) ur.e[i] = op_scalar<OP, T>(ua.e[i], ub.e[i]);
-  return ur.v;
+    for (int i = 0; i < N; i++) ur.e[i] = op_scalar<OP, T>(ua.e[i], ub.e[i]);
+    return ur.v;
+  }
 }
 
 // Flat range of nvec 16-byte vectors (+ tail bytes handled by the scalar kernel).
