@@ -390,7 +390,31 @@ __global__ __launch_bounds__(256) void box_generic_kernel(DImg dst, DImg src, in
   }
   __syncthreads();
   const int div = R * C;
-  for (int idx = threadIdx.x; idx < TW * TH; idx += 256) {
+  if constexpr (!std::is_floating_point<S>::value) {
+    // integer sums do not depend on the order of the taps: R-row column sums first (one thread per tile column, running
+    // down the tile), then C of them per output — R + C LDS reads per output instead of R * C
+    S* vs = tile + lds_w * lds_h;  // [TH][lds_w]
+    for (int lx = threadIdx.x; lx < lds_w; lx += 256) {
+      S run = 0;
+      for (int dr = 0; dr < R - 1; dr++) run += tile[dr * lds_w + lx];
+      for (int ty = 0; ty < TH; ty++) {
+        run += tile[(ty + R - 1) * lds_w + lx];
+        vs[ty * lds_w + lx] = run;
+        run -= tile[ty * lds_w + lx];
+      }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TW * TH; idx += 256) {
+      const int ty = idx / TW, tx = idx - ty * TW;
+      const int r = r0 + ty, c = c0 + tx;
+      if (r >= dst.nr || c >= ncomp) continue;
+      S sum = 0;
+      for (int dc = 0; dc < C; dc++) sum += vs[ty * lds_w + tx + dc * ch];
+      dst.row<T>(r)[c] = (T)(sum / div);
+    }
+    return;
+  }
+  for (int idx = threadIdx.x; idx < TW * TH; idx += 256) {  // float: taps in the reference's row-major order
     const int ty = idx / TW, tx = idx - ty * TW;
     const int r = r0 + ty, c = c0 + tx;
     if (r >= dst.nr || c >= ncomp) continue;
@@ -406,7 +430,7 @@ int launch_generic(const vpp_image_desc* dst, const vpp_image_desc* src, int R, 
   constexpr int TW = 128, TH = 16;
   const int ncomp = dst->ncols * dst->channels;
   const int lds_w = TW + (C - 1) * dst->channels;
-  const size_t smem = (size_t)lds_w * (TH + R - 1) * sizeof(S);
+  const size_t smem = (size_t)lds_w * (TH + R - 1 + (std::is_floating_point<S>::value ? 0 : TH)) * sizeof(S);
   VPP_REQUIRE(smem <= 64 * 1024, VPP_ERR_UNSUPPORTED, "vpp_box_filter: window %dx%d too large for the LDS tile", R, C);
   dim3 grid((ncomp + TW - 1) / TW, (dst->nrows + TH - 1) / TH);
   box_generic_kernel<T, S, TW, TH><<<grid, 256, smem, st>>>(dimg(dst), dimg(src), R, C, ncomp, lds_w);
