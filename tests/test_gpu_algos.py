@@ -48,10 +48,11 @@ def test_lowpass5_matches_oracle(lib, orc):
 
 
 @pytest.mark.parametrize("odt", [vi.F32, vi.I32])
-@pytest.mark.parametrize("shape", [(33, 47), (1080, 1920)])
-def test_scharr_matches_oracle(lib, orc, odt, shape):
-    src = rand_image(*shape, vi.U8, 1, border=3, seed=9, fill_border=True)
-    want = HostImage(*shape, odt, 2, border=3)
+@pytest.mark.parametrize("shape,border", [((33, 47), 3), ((33, 47), 1), ((64, 130), 2), ((1080, 1920), 3)])
+def test_scharr_matches_oracle(lib, orc, odt, shape, border):
+    """border >= 3 takes the 4-pixels-per-lane kernel, smaller borders the per-pixel one."""
+    src = rand_image(*shape, vi.U8, 1, border=border, seed=9, fill_border=True)
+    want = HostImage(*shape, odt, 2, border=border)
     assert orc.orc_scharr(P(want.desc), P(src.desc)) == 0
     d, o = DeviceImage.from_host(src), DeviceImage.from_host(want.like())
     capi.check(lib.vpp_scharr(P(o.desc), P(d.desc), capi.stream_ptr()))

@@ -20,6 +20,47 @@ __global__ __launch_bounds__(256) void scharr_kernel(DImg out, DImg in) {
   V* o = out.row<V>(r) + 2 * c;
   o[0] = (V)g0; o[1] = (V)g1;
 }
+// Four pixels per lane: three (possibly unaligned) 8-byte row loads cover columns c-1 .. c+6, the four results leave as two
+// 16-byte stores; the 3x3 sums are the same small exact integers in float or int as in the per-pixel form.
+template <class V>
+__global__ __launch_bounds__(256) void scharr4_kernel(DImg out, DImg in) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4, r = blockIdx.y;
+  if (c >= out.nc) return;
+  if (c + 4 > out.nc) {  // ragged row end: per pixel
+    for (int x = c; x < out.nc; x++) {
+      const uint8_t *row1 = in.row<uint8_t>(r - 1), *row2 = in.row<uint8_t>(r), *row3 = in.row<uint8_t>(r + 1);
+      const V a1 = (V)row1[x - 1], b1 = (V)row1[x], c1 = (V)row1[x + 1], a2 = (V)row2[x - 1], c2 = (V)row2[x + 1];
+      const V a3 = (V)row3[x - 1], b3 = (V)row3[x], c3 = (V)row3[x + 1];
+      V* o = out.row<V>(r) + 2 * x;
+      o[0] = (V)((3 * a3 + 10 * b3 + 3 * c3 - 3 * a1 - 10 * b1 - 3 * c1) / 32.f);
+      o[1] = (V)((3 * c1 + 10 * c2 + 3 * c3 - 3 * a1 - 10 * a2 - 3 * a3) / 32.f);
+    }
+    return;
+  }
+  uint64_t w1, w2, w3;  // bytes c-1 .. c+6 of the three rows (c+5, c+6 unused: <= 2 bytes past the last needed pixel, inside the row pitch or the border)
+  __builtin_memcpy(&w1, in.row<uint8_t>(r - 1) + c - 1, 8);
+  __builtin_memcpy(&w2, in.row<uint8_t>(r) + c - 1, 8);
+  __builtin_memcpy(&w3, in.row<uint8_t>(r + 1) + c - 1, 8);
+  V res[8];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const V a1 = (V)(uint8_t)(w1 >> (8 * k)), b1 = (V)(uint8_t)(w1 >> (8 * k + 8)), c1 = (V)(uint8_t)(w1 >> (8 * k + 16));
+    const V a2 = (V)(uint8_t)(w2 >> (8 * k)), c2 = (V)(uint8_t)(w2 >> (8 * k + 16));
+    const V a3 = (V)(uint8_t)(w3 >> (8 * k)), b3 = (V)(uint8_t)(w3 >> (8 * k + 8)), c3 = (V)(uint8_t)(w3 >> (8 * k + 16));
+    res[2 * k] = (V)((3 * a3 + 10 * b3 + 3 * c3 - 3 * a1 - 10 * b1 - 3 * c1) / 32.f);
+    res[2 * k + 1] = (V)((3 * c1 + 10 * c2 + 3 * c3 - 3 * a1 - 10 * a2 - 3 * a3) / 32.f);
+  }
+  V* o = out.row<V>(r) + 2 * c;
+  if ((((uintptr_t)o) & 15) == 0) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v0, v1;
+    __builtin_memcpy(&v0, res, 16); __builtin_memcpy(&v1, res + 4, 16);
+    __builtin_nontemporal_store(v0, (u32x4*)o); __builtin_nontemporal_store(v1, (u32x4*)o + 1);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = res[k];
+  }
+}
 }  // namespace
 
 extern "C" int vpp_scharr(const vpp_image_desc* out, const vpp_image_desc* in, void* stream) {
@@ -28,9 +69,17 @@ extern "C" int vpp_scharr(const vpp_image_desc* out, const vpp_image_desc* in, v
   VPP_REQUIRE(out->channels == 2 && (out->dtype == VPP_F32 || out->dtype == VPP_I32), VPP_ERR_UNSUPPORTED, "vpp_scharr: output must be f32 x2 or i32 x2");
   VPP_REQUIRE(in->border >= 1, VPP_ERR_BORDER_TOO_SMALL, "vpp_scharr: input needs border >= 1 (scharr.hh:48)");
   VPP_REQUIRE(out->nrows <= in->nrows && out->ncols <= in->ncols, VPP_ERR_INVALID_ARG, "vpp_scharr: output larger than input");
-  dim3 grid((out->ncols + 255) / 256, out->nrows);
-  if (out->dtype == VPP_F32) scharr_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in));
-  else scharr_kernel<int><<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in));
+  // the 8-byte row loads reach column nc + 2 of the input: only when the border holds it
+  const bool wide = in->border >= 3 && tuning("scharr.wide", 1);
+  if (wide) {
+    dim3 grid(((out->ncols + 3) / 4 + 255) / 256, out->nrows);
+    if (out->dtype == VPP_F32) scharr4_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in));
+    else scharr4_kernel<int><<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in));
+  } else {
+    dim3 grid((out->ncols + 255) / 256, out->nrows);
+    if (out->dtype == VPP_F32) scharr_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in));
+    else scharr_kernel<int><<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in));
+  }
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }
