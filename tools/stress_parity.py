@@ -1,0 +1,61 @@
+"""One-off randomized parity sweep (GPU vs the CPU oracle) over shapes / parameters the fixed tests do not enumerate:
+FAST-9 (all modes, masks, thresholds), semi-dense flow (window sizes, scales, sweeps, patch sizes), box filters, rgb->gray.
+usage: python tools/stress_parity.py [n_cases] [seed]      (needs a GPU; exits non-zero on the first mismatch)"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from util import P, rand_image, HostImage, DeviceImage, u8_image, rects_image
+from test_gpu_sdof import flow_scene, run_both
+from test_oracle_algos import run_detect
+from test_gpu_algos import gpu_detect
+from vpp_amd import capi, image as vi
+from oracle import binding
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+lib = capi.lib(); capi.check(lib.vpp_init(0)); orc = binding.load()
+V = ctypes.c_void_p
+bad = 0
+for case in range(N):
+    # FAST-9
+    nr, nc = int(rng.integers(8, 300)), int(rng.integers(8, 400))
+    img = rects_image(nr, nc, seed=int(rng.integers(1 << 30)))
+    im = u8_image(img, border=3)
+    im.view(with_border=True)[..., 0] = np.pad(im.view()[..., 0], 3, mode="symmetric")
+    th, mode, bs, compat = int(rng.integers(1, 60)), int(rng.integers(0, 3)), int(rng.integers(2, 24)), int(rng.integers(0, 2))
+    mask = None
+    if rng.integers(0, 2):
+        mask = u8_image(rng.choice(np.array([0, 1, 16, 17, 255], np.uint8), size=(nr, nc)), border=0)
+    want = run_detect(orc, im, th, mode=mode, bs=bs, compat=compat, mask=mask)
+    dim = DeviceImage.from_host(im); dmask = DeviceImage.from_host(mask) if mask is not None else None
+    got = gpu_detect(lib, dim, th, mode=mode, bs=bs, compat=compat, mask=dmask)
+    ok = all(np.array_equal(g, w) for g, w in zip(got, want))
+    print(f"fast9 {nr}x{nc} th={th} mode={mode} bs={bs} compat={compat} mask={mask is not None}: n={len(want[0])} {'ok' if ok else 'MISMATCH'}"); bad += not ok
+    # semi-dense flow
+    ws = int(rng.choice([5, 7, 9, 11])); nscales = int(rng.integers(1, 4)); min_scale = int(rng.integers(0, nscales)); prop = int(rng.integers(0, 4)); patch = int(rng.choice([3, 5, 7]))
+    shape = (int(rng.integers(60, 200)), int(rng.integers(60, 260)))
+    f1, f2, kps = flow_scene(*shape, seed=int(rng.integers(1 << 30)), spacing=int(rng.integers(3, 9)))
+    for impl in (2, 3):
+        lib.vpp_set_tuning(b"sdof.propagate", impl)
+        got, want = run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch)
+        ok = all(np.array_equal(g, w) for g, w in zip(got, want))
+        print(f"sdof {shape} ws={ws} nscales={nscales} min={min_scale} prop={prop} patch={patch} impl={impl}: valid={int(want[2].sum())} {'ok' if ok else 'MISMATCH'}"); bad += not ok
+    lib.vpp_set_tuning(b"sdof.propagate", -1)
+    # box 5x5 on u8 x ch and int32, rgb->gray ingest
+    ch = int(rng.integers(1, 5)); border = int(rng.integers(2, 5)); nr, nc = int(rng.integers(1, 200)), int(rng.integers(1, 1500))
+    for dtype, c in ((vi.U8, ch), (vi.I32, 1)):
+        src = rand_image(nr, nc, dtype, c, border=border, seed=int(rng.integers(1 << 30)), lo=0 if dtype == vi.I32 else None, hi=999 if dtype == vi.I32 else None, align=16, fill_border=True)
+        want = src.like(border=0); orc.orc_box_filter(P(want.desc), P(src.desc), 5, 5)
+        ds, dd = DeviceImage.from_host(src), DeviceImage.from_host(src.like(border=0))
+        capi.check(lib.vpp_box_filter(P(dd.desc), P(ds.desc), 5, 5, capi.stream_ptr())); capi.check(lib.vpp_sync(capi.stream_ptr()))
+        ok = np.array_equal(dd.download().view(), want.view())
+        print(f"box5x5 dtype={dtype} x{c} {nr}x{nc} border={border}: {'ok' if ok else 'MISMATCH'}"); bad += not ok
+    gb = int(rng.integers(0, 6)); rgb = rand_image(nr, nc, vi.U8, int(rng.choice([3, 4])), border=0, seed=int(rng.integers(1 << 30)))
+    if gb <= nr and gb <= nc:
+        want = HostImage(nr, nc, vi.U8, 1, gb); orc.orc_rgb_to_graylevel(P(want.desc), P(rgb.desc), 1)
+        dr, dg = DeviceImage.from_host(rgb), DeviceImage(nr, nc, vi.U8, 1, gb)
+        capi.check(lib.vpp_rgb_to_graylevel(P(dg.desc), P(dr.desc), 1, capi.stream_ptr())); capi.check(lib.vpp_sync(capi.stream_ptr()))
+        ok = np.array_equal(dg.download().view(with_border=True), want.view(with_border=True))
+        print(f"ingest {nr}x{nc} border={gb}: {'ok' if ok else 'MISMATCH'}"); bad += not ok
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
