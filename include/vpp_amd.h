@@ -162,6 +162,10 @@ int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, i
  * pairs in DEVICE memory (clipped to the mask's border). */
 int vpp_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, void* stream);
 
+/* lbp_transform (vpp/algorithms/lbp/lbp_transform.hh:6-38): out(r,c) bit k = (k-th neighbour > centre), neighbours in
+ * row-major order without the centre; u8 x1 -> u8 x1, in needs border >= 1. */
+int vpp_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

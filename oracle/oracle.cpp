@@ -770,4 +770,22 @@ int orc_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int 
   return VPP_OK;
 }
 
+// lbp_transform (lbp_transform.hh:6-38): curB[i] = sum of ((neighbour > rows[1][i]) << k), k in row-major neighbour order.
+int orc_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in) {
+  Img o(out), a(in);
+  if (o.dtype != VPP_U8 || o.ch != 1 || a.dtype != VPP_U8 || a.ch != 1) return VPP_ERR_UNSUPPORTED;
+  if (o.nr != a.nr || o.nc != a.nc) return VPP_ERR_INVALID_ARG;
+  if (a.border < 1) return VPP_ERR_BORDER_TOO_SMALL;
+  for (int r = 0; r < a.nr; r++) {
+    uint8_t* curB = o.row<uint8_t>(r);
+    const uint8_t* rows[3];
+    for (int i = -1; i <= 1; i++) rows[i + 1] = a.row<uint8_t>(r + i);
+    for (int i = 0; i < a.nc; i++)
+      curB[i] = (uint8_t)(((rows[0][i - 1] > rows[1][i]) << 0) + ((rows[0][i] > rows[1][i]) << 1) + ((rows[0][i + 1] > rows[1][i]) << 2) +
+                          ((rows[1][i - 1] > rows[1][i]) << 3) + ((rows[1][i + 1] > rows[1][i]) << 4) +
+                          ((rows[2][i - 1] > rows[1][i]) << 5) + ((rows[2][i] > rows[1][i]) << 6) + ((rows[2][i + 1] > rows[1][i]) << 7));
+  }
+  return VPP_OK;
+}
+
 }  // extern "C"

@@ -51,6 +51,9 @@ int orc_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, i
 /* video_extruder/video_extruder.hpp:95-110 (rc: n host (row, col) pairs) */
 int orc_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing);
 
+/* vpp/algorithms/lbp/lbp_transform.hh:6-38 */
+int orc_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
 #include <vpp/algorithms/fast_detector/fast.hh>
 #include <vpp/algorithms/pyrlk/pyrlk_match.hh>
 #include <vpp/algorithms/lucas_kanade.hh>
+#include <vpp/algorithms/lbp/lbp_transform.hh>
 #include <iod/array_view.hh>
 #include <vpp/algorithms/optical_flow/semi_dense_optical_flow.hpp>
 
@@ -242,6 +243,14 @@ int ref_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, i
     return 0;
   }
   return VPP_ERR_UNSUPPORTED;
+}
+
+// lbp_transform(A, B) (vpp/algorithms/lbp/lbp_transform.hh:6-38)
+int ref_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in) {
+  if (!is(out, VPP_U8, 1) || !is(in, VPP_U8, 1)) return VPP_ERR_UNSUPPORTED;
+  auto A = wrap<unsigned char>(in); auto B = wrap<unsigned char>(out);
+  lbp_transform(A, B);
+  return 0;
 }
 
 }  // extern "C"

@@ -12,6 +12,8 @@
 #include <vpp/algorithms/optical_flow.hh>
 #include <vpp/algorithms/pyrlk/pyrlk_match.hh>
 #include <vpp/algorithms/video_extruder.hh>
+#include <vpp/algorithms/lbp/lbp_transform.hh>
+#include <vpp/algorithms/lbp/lbp_distance.hh>
 
 #include "../../oracle/oracle.h"
 
@@ -256,8 +258,17 @@ static void test_frame_ingest() {
   for (int r = -3; r < 138; r++) for (int c = -3; c < 244; c++) CHECK(host(r, c) == want(r, c));
 }
 
+static void test_lbp() {                                                    // tests/lbp.cc
+  image2d<unsigned char> V(3, 3, _border = 1), lbp(3, 3);
+  V(1, 1) = 1; V(0, 0) = 0; V(0, 1) = 2; V(0, 2) = 2; V(1, 0) = 2; V(1, 2) = 0; V(2, 0) = 2; V(2, 1) = 0; V(2, 2) = 2;
+  lbp_transform(V, lbp);
+  CHECK(lbp(1, 1) == 0b10101110);
+  CHECK(lbp_hamming_distance(0b01010101, 0b01010101) == 0 && lbp_hamming_distance(0b11010101, 0b01010101) == 1 && lbp_hamming_distance(0b11111111, 0b00000000) == 8);
+}
+
 int main() {
   CHECK(vpp_init(0) == 0);
+  test_lbp();
   test_frame_ingest();
   test_pixel_wise_functors();
   test_fast9();

@@ -60,3 +60,14 @@ def test_keypoint_mask_matches_oracle(lib, orc, shape, border, spacing, n):
     drc = torch.from_numpy(rc.reshape(-1).copy()).cuda() if n else None
     capi.check(lib.vpp_keypoint_mask(P(dm.desc), V(drc.data_ptr()) if n else None, n, spacing, capi.stream_ptr()))
     np.testing.assert_array_equal(dm.download().view(with_border=True), want.view(with_border=True))
+
+
+@pytest.mark.parametrize("shape,border,align", [((3, 3), 1, 32), ((37, 53), 1, 32), ((40, 64), 3, 16), ((129, 1001), 3, 32), ((64, 130), 3, 1), ((1, 7), 2, 32), ((2160, 3840), 3, 32)])
+def test_lbp_transform_matches_oracle(lib, orc, shape, border, align):
+    src = rand_image(*shape, vi.U8, 1, border=border, seed=34, fill_border=True, align=align)
+    want = HostImage(*shape, vi.U8, 1, 0, align)
+    assert orc.orc_lbp_transform(P(want.desc), P(src.desc)) == 0
+    ds, dd = DeviceImage.from_host(src), DeviceImage(*shape, vi.U8, 1, 0, align)
+    capi.check(lib.vpp_lbp_transform(P(dd.desc), P(ds.desc), capi.stream_ptr()))
+    np.testing.assert_array_equal(dd.download().view(), want.view())
+    assert lib.vpp_lbp_transform(P(dd.desc), P(DeviceImage(*shape, vi.U8, 1, 0).desc), None) != 0   # border 0: refused

@@ -55,3 +55,29 @@ def test_keypoint_mask(orc):
     for r, c in rc:
         want[r + 10 - 10:r + 10 + 10, c + 10 - 10:c + 10 + 10] = 0
     np.testing.assert_array_equal(m.view(with_border=True)[..., 0], want)
+
+
+def test_lbp_reference_unit_test_restated(orc):
+    """tests/lbp.cc: the 3x3 pattern around V(1,1) = 1 gives 0b10101110."""
+    v = HostImage(3, 3, vi.U8, 1, 1)
+    a = v.view()[..., 0]
+    a[...] = [[0, 2, 2], [2, 1, 0], [2, 0, 2]]
+    out = HostImage(3, 3, vi.U8, 1)
+    assert orc.orc_lbp_transform(P(out.desc), P(v.desc)) == 0
+    assert out.view()[1, 1, 0] == 0b10101110
+
+
+@pytest.mark.parametrize("shape,border", [((3, 3), 1), ((37, 53), 1), ((40, 64), 3), ((1, 7), 2)])
+def test_lbp_oracle_is_the_reference(orc, ref, shape, border):
+    src = rand_image(*shape, vi.U8, 1, border=border, seed=14, fill_border=True)
+    a, b = HostImage(*shape, vi.U8, 1), HostImage(*shape, vi.U8, 1)
+    assert ref.ref_lbp_transform(P(a.desc), P(src.desc)) == 0
+    assert orc.orc_lbp_transform(P(b.desc), P(src.desc)) == 0
+    np.testing.assert_array_equal(a.view(), b.view())
+    s = src.view(with_border=True)[..., 0].astype(np.int32)
+    bb = border
+    c = s[bb:bb + shape[0], bb:bb + shape[1]]
+    want = np.zeros(shape, np.int32)
+    for k, (dr, dc) in enumerate([(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]):
+        want += (s[bb + dr:bb + dr + shape[0], bb + dc:bb + dc + shape[1]] > c) << k
+    np.testing.assert_array_equal(b.view()[..., 0], want.astype(np.uint8))

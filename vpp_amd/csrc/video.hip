@@ -5,6 +5,7 @@
 //    into one pass: a border pixel of dst is the gray value of the mirrored source pixel, which is exactly what the three
 //    separate steps produce (gray is per-pixel, so it commutes with the mirror copy).
 //    HBM-bound: CH bytes read + 1 written per pixel; one lane = 16 output pixels (CH 16-B loads, one 16-B store).
+//  * lbp_transform (vpp/algorithms/lbp/lbp_transform.hh:6-38), a 3x3 stencil on the same machinery.
 //  * keypoint mask of video_extruder's re-detection (video_extruder/video_extruder.hpp:95-110): mask = 1 over the domain with
 //    border, then the [r - s, r + s) x [c - s, c + s) square of every keypoint is zeroed.
 #include "common.hpp"
@@ -61,6 +62,34 @@ __global__ __launch_bounds__(256) void rgb_to_gray_kernel(DImg dst, DImg src, in
   }
 }
 
+// lbp_transform (vpp/algorithms/lbp/lbp_transform.hh:6-38): bit k of B(r, c) = neighbour k > centre, neighbours in row-major
+// order without the centre ((-1,-1) = bit 0 ... (1,1) = bit 7).  Four pixels per lane: three 8-byte row loads (columns
+// c-1 .. c+6), one dword store; ragged row ends per pixel.
+__global__ __launch_bounds__(256) void lbp_kernel(DImg out, DImg in, int wide) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4, r = blockIdx.y;
+  if (c >= out.nc) return;
+  const uint8_t *r0 = in.row<uint8_t>(r - 1), *r1 = in.row<uint8_t>(r), *r2 = in.row<uint8_t>(r + 1);
+  auto code = [](uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t v, uint32_t b2, uint32_t c0, uint32_t c1, uint32_t c2) -> uint32_t {
+    return (a0 > v ? 1u : 0u) | (a1 > v ? 2u : 0u) | (a2 > v ? 4u : 0u) | (b0 > v ? 8u : 0u) | (b2 > v ? 16u : 0u) | (c0 > v ? 32u : 0u) |
+           (c1 > v ? 64u : 0u) | (c2 > v ? 128u : 0u);
+  };
+  uint8_t* o = out.row<uint8_t>(r) + c;
+  if (!wide || c + 4 > out.nc) {
+    for (int x = c; x < min(c + 4, out.nc); x++) o[x - c] = (uint8_t)code(r0[x - 1], r0[x], r0[x + 1], r1[x - 1], r1[x], r1[x + 1], r2[x - 1], r2[x], r2[x + 1]);
+    return;
+  }
+  uint64_t w0, w1, w2;
+  __builtin_memcpy(&w0, r0 + c - 1, 8); __builtin_memcpy(&w1, r1 + c - 1, 8); __builtin_memcpy(&w2, r2 + c - 1, 8);
+  uint32_t res = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    auto b = [&](uint64_t w, int j) { return (uint32_t)(uint8_t)(w >> (8 * (k + j))); };
+    res |= code(b(w0, 0), b(w0, 1), b(w0, 2), b(w1, 0), b(w1, 1), b(w1, 2), b(w2, 0), b(w2, 1), b(w2, 2)) << (8 * k);
+  }
+  if ((((uintptr_t)o) & 3) == 0) *(uint32_t*)o = res;
+  else { o[0] = (uint8_t)res; o[1] = (uint8_t)(res >> 8); o[2] = (uint8_t)(res >> 16); o[3] = (uint8_t)(res >> 24); }
+}
+
 __global__ __launch_bounds__(256) void keypoint_mask_kernel(DImg mask, const int32_t* __restrict__ rc, int n, int s) {
   // one thread per (keypoint, square row): 2s byte stores
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -108,6 +137,17 @@ extern "C" int vpp_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, 
   if (n == 0) return VPP_OK;
   const long long threads = (long long)n * 2 * spacing;
   keypoint_mask_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, as_stream(stream)>>>(dimg(mask), rc, n, spacing);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+extern "C" int vpp_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in, void* stream) {
+  VPP_REQUIRE(valid_desc(out) && valid_desc(in) && same_domain(out, in), VPP_ERR_INVALID_ARG, "vpp_lbp_transform: invalid descriptors / domain mismatch");
+  VPP_REQUIRE(out->dtype == VPP_U8 && out->channels == 1 && in->dtype == VPP_U8 && in->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_lbp_transform: u8 x1 only");
+  VPP_REQUIRE(in->border >= 1, VPP_ERR_BORDER_TOO_SMALL, "vpp_lbp_transform: input needs border >= 1 (lbp_transform.hh:17-19 reads rows r-1 .. r+1, columns -1 .. nc)");
+  VPP_REQUIRE(out->first_pixel != in->first_pixel, VPP_ERR_INVALID_ARG, "vpp_lbp_transform: in-place not supported");
+  dim3 grid(((out->ncols + 3) / 4 + 255) / 256, out->nrows);
+  lbp_kernel<<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in), in->border >= 3 ? 1 : 0);  // the 8-byte loads reach column nc + 2
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }
