@@ -166,6 +166,18 @@ int vpp_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int 
  * row-major order without the centre; u8 x1 -> u8 x1, in needs border >= 1. */
 int vpp_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in, void* stream);
 
+/* ---- multi-GPU: the one exchange step of the keypoint-sharded path (no reference counterpart: the reference is a
+ *      single OpenMP process; pyrlk_match.hh:24-51 iterates independent keypoints).  One process per GPU: rank 0 obtains
+ *      the 128-byte id and ships it to the other ranks out of band (launcher, file, socket), every rank calls
+ *      vpp_comm_init after vpp_init(local device).  vpp_allgather_tracks: each rank contributes n_per_rank records
+ *      (pad the last shard), `all` receives nranks * n_per_rank records in rank order — an RCCL all-gather over xGMI on
+ *      `stream`.  RCCL is loaded at first use; VPP_ERR_UNSUPPORTED when no librccl can be found. ---- */
+typedef struct vpp_comm vpp_comm;
+int vpp_comm_unique_id(void* id128);
+int vpp_comm_init(vpp_comm** comm, int nranks, const void* id128, int rank);
+int vpp_comm_destroy(vpp_comm* comm);
+int vpp_allgather_tracks(vpp_comm* comm, const vpp_keypoint_f32* shard, int n_per_rank, vpp_keypoint_f32* all, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

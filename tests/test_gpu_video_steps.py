@@ -71,3 +71,21 @@ def test_lbp_transform_matches_oracle(lib, orc, shape, border, align):
     capi.check(lib.vpp_lbp_transform(P(dd.desc), P(ds.desc), capi.stream_ptr()))
     np.testing.assert_array_equal(dd.download().view(), want.view())
     assert lib.vpp_lbp_transform(P(dd.desc), P(DeviceImage(*shape, vi.U8, 1, 0).desc), None) != 0   # border 0: refused
+
+
+def test_allgather_tracks_single_rank(lib):
+    """The C-ABI exchange step on a 1-rank communicator: the all-gather of 20-byte keypoint records returns the shard itself.
+    (World sizes > 1 are covered on CPU with gloo in test_multi_gpu_cpu.py and run on the 8-GPU node by bench.py --gpus N.)"""
+    import pyr
+    idbuf = (ctypes.c_char * 128)()
+    capi.check(lib.vpp_comm_unique_id(idbuf))
+    comm = ctypes.c_void_p()
+    capi.check(lib.vpp_comm_init(ctypes.byref(comm), 1, idbuf, 0))
+    kps = pyr.make_keypoints(pyr.grid_keypoints(480, 640, 1000, margin=16))
+    shard = torch.from_numpy(kps.view(np.uint8).reshape(-1).copy()).cuda()
+    out = torch.zeros_like(shard)
+    capi.check(lib.vpp_allgather_tracks(comm, V(shard.data_ptr()), len(kps), V(out.data_ptr()), capi.stream_ptr()))
+    capi.check(lib.vpp_sync(capi.stream_ptr()))
+    assert torch.equal(out, shard)
+    capi.check(lib.vpp_comm_destroy(comm))
+    assert lib.vpp_comm_init(ctypes.byref(comm), 1, idbuf, 3) != 0   # rank out of range
