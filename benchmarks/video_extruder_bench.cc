@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
                           _nscales = 3, _winsize = 9, _propagation = 2);
     per.push_back(ms(t0, clk::now()));
     nk.push_back(ctx.keypoints.size());
-    if (t == 1) ve_internals::timing() = ve_internals::timing_t();  // the first update only detects (no keypoints yet): excluded from the breakdown
+    if (t == 1) { ve_internals::timing() = ve_internals::timing_t(); for (int q = 0; q < 4; q++) of_internals::timing()[q] = 0; }  // the first update only detects (no keypoints yet): excluded from the breakdown
   }
   int alive = 0, good = 0;
   for (int i = 0; i < ctx.keypoints.size(); i++) if (ctx.keypoints[i].alive()) { alive++; good += ctx.keypoints[i].velocity == vint2(1, 2); }
@@ -61,9 +61,11 @@ int main(int argc, char** argv) {
   std::printf("{\"workload\": \"video_extruder_update %dx%d uchar, defaults (th 10, spacing 10, period 5, 3 scales, winsize 9, 2 sweeps), %d updates after the detecting one\", "
               "\"ms_per_update\": %.3f, \"frames_per_s\": %.2f, \"keypoints\": %d, \"alive\": %d, \"velocity_ok\": %d, "
               "\"breakdown_ms\": {\"flow\": %.3f, \"merge\": %.3f, \"scores\": %.3f, \"redetect\": %.3f, \"trajectories\": %.3f, "
-              "\"redetect_mask\": %.3f, \"redetect_fast9\": %.3f, \"redetect_add\": %.3f, \"redetect_compact\": %.3f, \"redetect_sync\": %.3f}, \"per_update_ms\": [",
+              "\"redetect_mask\": %.3f, \"redetect_fast9\": %.3f, \"redetect_add\": %.3f, \"redetect_compact\": %.3f, \"redetect_sync\": %.3f, "
+              "\"flow_gather_upload\": %.3f, \"flow_device\": %.3f, \"flow_download\": %.3f, \"flow_callbacks\": %.3f}, \"per_update_ms\": [",
               nr, nc, int(per.size() - 1), mean, 1000.0 / mean, ctx.keypoints.size(), alive, good, tm.flow / n, tm.merge / n, tm.scores / n, tm.redetect / n, tm.traj / n,
-              tm.redetect_mask / n, tm.redetect_fast9 / n, tm.redetect_add / n, tm.redetect_compact / n, tm.redetect_sync / n);
+              tm.redetect_mask / n, tm.redetect_fast9 / n, tm.redetect_add / n, tm.redetect_compact / n, tm.redetect_sync / n,
+              of_internals::timing()[0] / n, of_internals::timing()[1] / n, of_internals::timing()[2] / n, of_internals::timing()[3] / n);
   for (size_t i = 0; i < per.size(); i++) std::printf("%s%.2f", i ? ", " : "", per[i]);
   std::printf("]}\n");
   return alive > 0 && good > alive / 2 ? 0 : 1;

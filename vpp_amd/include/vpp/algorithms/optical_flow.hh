@@ -1,12 +1,24 @@
 // optical_flow.hh — semi-dense optical flow (reference: vpp/algorithms/optical_flow.hh:6-35,
 // optical_flow/semi_dense_optical_flow.hpp:48-214).  The epipolar options are not supported.
 #pragma once
+#include <chrono>
 #include <vector>
 #include <vpp/algorithms/device_only.hh>
 #include <vpp/algorithms/symbols.hh>
 #include <vpp/core/image2d.hh>
 
 namespace vpp {
+namespace of_internals {
+// optional wall-clock breakdown (benchmarks define VPP_AMD_TIMING): [0] keypoint gather + upload, [1] device call incl. frame
+// upload, [2] result download, [3] match callbacks
+inline double* timing() { static double t[4] = {0, 0, 0, 0}; return t; }
+#ifdef VPP_AMD_TIMING
+struct stopwatch { double& acc; std::chrono::steady_clock::time_point t0; explicit stopwatch(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+                   ~stopwatch() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
+#else
+struct stopwatch { explicit stopwatch(double&) {} };
+#endif
+}
 template <class K, class MC, class... OPTS>
 void semi_dense_optical_flow(const K& keypoints, MC match_callback, const image2d<unsigned char>& i1, const image2d<unsigned char>& i2, OPTS... options) {
   auto opts = opt::make(options...);
@@ -14,16 +26,27 @@ void semi_dense_optical_flow(const K& keypoints, MC match_callback, const image2
   const int propagation_niters = opts.get(_propagation, 2), patchsize = opts.get(_patchsize, 5);
   const int n = int(keypoints.size());
   if (!n) return;
-  std::vector<vint2> kps(n), pos(n);
-  std::vector<int> dist(n);
-  std::vector<unsigned char> valid(n);
-  for (int i = 0; i < n; i++) { auto k = keypoints[i]; kps[i] = vint2(k[0], k[1]); }
+  // host staging kept across calls (per thread): the runtime pins the pages of a pageable copy's host side, which is costly for
+  // a never-seen address range and nearly free for the one it saw on the previous frame
+  static thread_local std::vector<vint2> kps, pos;
+  static thread_local std::vector<int> dist;
+  static thread_local std::vector<unsigned char> valid;
+  kps.resize(n); pos.resize(n); dist.resize(n); valid.resize(n);
   device::dbuf dk(size_t(n) * 8), dp(size_t(n) * 8), dd(size_t(n) * 4), dv{size_t(n)};
-  dk.upload(kps.data(), dk.bytes);
-  const vpp_image_desc d1 = i1.device_desc(false), d2 = i2.device_desc(false);
-  device::check(vpp_semi_dense_optical_flow(&d1, &d2, (const int32_t*)dk.p, n, winsize, nscales, min_scale, propagation_niters, patchsize, (int32_t*)dp.p,
-                                            (int32_t*)dd.p, (uint8_t*)dv.p, device::stream()), "vpp_semi_dense_optical_flow");
-  dp.download(pos.data(), dp.bytes); dd.download(dist.data(), dd.bytes); dv.download(valid.data(), dv.bytes);
+  {
+    of_internals::stopwatch sw(of_internals::timing()[0]);
+    for (int i = 0; i < n; i++) { auto k = keypoints[i]; kps[i] = vint2(k[0], k[1]); }
+    dk.upload(kps.data(), dk.bytes);
+  }
+  {
+    of_internals::stopwatch sw(of_internals::timing()[1]);
+    const vpp_image_desc d1 = i1.device_desc(false), d2 = i2.device_desc(false);
+    device::check(vpp_semi_dense_optical_flow(&d1, &d2, (const int32_t*)dk.p, n, winsize, nscales, min_scale, propagation_niters, patchsize, (int32_t*)dp.p,
+                                              (int32_t*)dd.p, (uint8_t*)dv.p, device::stream()), "vpp_semi_dense_optical_flow");
+    dv.download(valid.data(), dv.bytes);   // first read-back: waits for the flow
+  }
+  { of_internals::stopwatch sw(of_internals::timing()[2]); dp.download(pos.data(), dp.bytes); dd.download(dist.data(), dd.bytes); }
+  of_internals::stopwatch sw(of_internals::timing()[3]);
   for (int i = 0; i < n; i++) if (valid[i]) match_callback(i, pos[i], dist[i]);  // semi_dense_optical_flow.hpp:205-212
 }
 }  // namespace vpp
