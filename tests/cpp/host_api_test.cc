@@ -141,7 +141,30 @@ static void test_colorspace_conversions() {                                  // 
   CHECK(back(3, 4) == vuchar3(g(3, 4), g(3, 4), g(3, 4)));
 }
 
+static void test_image3d_and_iterators() {
+  image3d<int> img1(make_box3d(10, 20, 30));                                  // tests/image3d.cc
+  image3d<int> img2(10, 20, 30);
+  CHECK(img1.domain() == img2.domain());
+  CHECK(img1.nslices() == 10 && img1.nrows() == 20 && img1.ncols() == 30);
+  for (int s = 0; s < img1.nslices(); s++)
+    for (int r = 0; r < img1.nrows(); r++)
+      for (int c = 0; c < img1.ncols(); c++) { img1(s, r, c) = s * r * c; CHECK(img1(s, r, c) == s * r * c); }
+  {
+    auto s1 = img1 | box3d(vint3(2, 3, 4), vint3(5, 6, 7));
+    CHECK(&s1(0, 0, 0) == &img1(vint3(2, 3, 4)));
+    CHECK(&s1(0, 1, 1) == &img1(vint3(2, 3, 4) + vint3(0, 1, 1)));
+    CHECK(&s1(1, 1, 1) == &img1(vint3(2, 3, 4) + vint3(1, 1, 1)));
+    CHECK(&s1(2, 2, 2) == &img1(vint3(2, 3, 4) + vint3(2, 2, 2)));
+  }
+  image2d<int> img(3, 3, _border = 1);                                        // tests/imageNd_iterator.cc
+  const vint2 ref[] = {vint2(0, 0), vint2(0, 1), vint2(0, 2), vint2(1, 0), vint2(1, 1), vint2(1, 2), vint2(2, 0), vint2(2, 1), vint2(2, 2)};
+  int i = 0;
+  for (auto& p : img) { CHECK(&p == &img(ref[i])); i++; }
+  CHECK(i == 9);
+}
+
 int main() {
+  test_image3d_and_iterators();
   test_colorspace_conversions();
   test_layout_and_access();
   test_pixel_wise();
