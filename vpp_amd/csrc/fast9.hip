@@ -3,7 +3,8 @@
 // :676-707 (fast_detector9_maxima), :745-799 (blockwise maxima), :889-928 (local maxima), :931-955 (front end fast9).
 //
 // Pipeline (all on one stream, no host round trip until the final count):
-//   1. fast9_detect_kernel   LDS tile (64x64 px + 3 px halo, dword loads), one lane per pixel column marching down 16 rows.
+//   1. fast9_detect2_kernel  (default; fast9_detect_kernel = the single-phase form, tuning fast9.impl = 1)
+//                            LDS tile (64x64 px + 3 px halo, dword loads), one lane per pixel column marching down 16 rows.
 //                            Segment test per lane: saturated thresholds, 4 cardinal samples first (any 9-arc holds >= 2
 //                            of ring indices {0,4,8,12}), then 16-bit brighter/darker masks and a shift-and "9 circularly
 //                            contiguous" test.  corner = mask_byte & (0x10*B9 | 0x01*D9) != 0 (fast.hpp:120-126,312,333).
@@ -12,14 +13,16 @@
 //                            scores_img (:685-694) without the intermediate keypoint list (a single global append counter
 //                            saturates at ~90 atomics/us, which measured 790 us on a 4K frame; the dense write costs 16.6 MB).
 //                            Each wave also ballots its row of 64 flags into one u64 of a corner bitmap (1 bit / px) and the
-//                            edge tiles zero F's 1-px border, so no memset precedes the launch.
+//                            edge tiles zero F's 1-px border, so no memset precedes the launch.  The default kernel splits this in
+//                            two phases per wave — pre-test for every pixel, then ring test + score on an LDS-compacted list of
+//                            the survivors — so that the lanes of the expensive part are all busy (see fast9_detect2_kernel).
 //   2. count / scan / write  units in the reference's serial output order, one per thread: 16-px bitmap segments (RAW,
 //                            LOCAL_MAXIMA — the count pass rewrites a segment with the bits that survive the strict 8-neighbour
 //                            test on F) or bs x bs blocks (BLOCKWISE — one lane per block row walks the bitmap words, rows meet
 //                            in an LDS u64 max of score << 32 | ~position).  A flat exclusive scan of the unit counts gives
 //                            the output index, so the list comes out row-major (pixels / blocks) like the serial reference,
 //                            which the OpenMP reference itself does not guarantee.  4K, 454k corners: RAW
-//                            5 + 5 + 12 us, LOCAL 18 + 5 + 6 us, BLOCKWISE 13 + 5 + 6 us after the 44 us detect kernel.
+//                            5 + 5 + 12 us, LOCAL 18 + 5 + 6 us, BLOCKWISE 13 + 5 + 6 us after the 30 us detect kernel.
 // VALU-bound (the ring test is ~100 lane-ops per pixel against 1 B/px of HBM traffic); see DESIGN.md.
 #include "common.hpp"
 #include <mutex>
