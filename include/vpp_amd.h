@@ -53,7 +53,9 @@ int vpp_init(int device);                       /* hipSetDevice + warm the conte
 int vpp_device_count(int* n);
 int vpp_malloc(size_t bytes, void** dptr);        /* freed blocks are cached per device and reused by size (no hipFree sync per frame) */
 int vpp_free(void* dptr);
-int vpp_release_cached_memory(void);             /* hipFree everything vpp_free is holding on the current device */
+int vpp_malloc_host(size_t bytes, void** hptr);   /* pinned host staging memory (hipHostMalloc), cached by size on vpp_free_host */
+int vpp_free_host(void* hptr);
+int vpp_release_cached_memory(void);             /* give everything vpp_free / vpp_free_host are holding back to the driver */
 int vpp_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int vpp_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int vpp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);

@@ -37,7 +37,8 @@ DevicePool& pool_of_current_device() {
   if (!p) p = new DevicePool();   // intentionally never destroyed: the HIP runtime may already be gone at exit
   return *p;
 }
-inline size_t round_block(size_t bytes) { return ((bytes ? bytes : 1) + 255) / 256 * 256; }
+// size classes: 256 B granules, 4 KiB above 64 KiB — per-frame buffers whose element count drifts by a few entries keep hitting the same class
+inline size_t round_block(size_t bytes) { const size_t g = bytes >= (64u << 10) ? 4096 : 256; return ((bytes ? bytes : 1) + g - 1) / g * g; }
 }  // namespace
 
 extern "C" {
@@ -111,7 +112,41 @@ int vpp_free(void* dptr) {
   return VPP_OK;
 }
 
+// Pinned (page-locked) host staging memory, cached by size like the device blocks: a copy between HBM and pageable memory makes
+// the runtime pin the host pages first, which costs ~1 ms for a range it has not seen recently; per-frame result buffers
+// (keypoint lists, flow results) come from here instead.
+namespace { struct HostPool { std::mutex mu; std::multimap<size_t, void*> free_blocks; std::map<void*, size_t> live; }; HostPool g_host_pool; }
+
+int vpp_malloc_host(size_t bytes, void** hptr) {
+  VPP_REQUIRE(hptr, VPP_ERR_INVALID_ARG, "vpp_malloc_host: null out pointer");
+  const size_t rb = ((bytes ? bytes : 1) + 4095) / 4096 * 4096;
+  {
+    std::lock_guard<std::mutex> l(g_host_pool.mu);
+    auto it = g_host_pool.free_blocks.find(rb);
+    if (it != g_host_pool.free_blocks.end()) { *hptr = it->second; g_host_pool.free_blocks.erase(it); g_host_pool.live[*hptr] = rb; return VPP_OK; }
+  }
+  VPP_HIP_TRY(hipHostMalloc(hptr, rb, hipHostMallocDefault));
+  std::lock_guard<std::mutex> l(g_host_pool.mu);
+  g_host_pool.live[*hptr] = rb;
+  return VPP_OK;
+}
+
+int vpp_free_host(void* hptr) {
+  if (!hptr) return VPP_OK;
+  std::lock_guard<std::mutex> l(g_host_pool.mu);
+  auto it = g_host_pool.live.find(hptr);
+  VPP_REQUIRE(it != g_host_pool.live.end(), VPP_ERR_INVALID_ARG, "vpp_free_host: not a vpp_malloc_host block");
+  g_host_pool.free_blocks.emplace(it->second, hptr);
+  g_host_pool.live.erase(it);
+  return VPP_OK;
+}
+
 int vpp_release_cached_memory(void) {
+  {
+    std::multimap<size_t, void*> hb;
+    { std::lock_guard<std::mutex> l(g_host_pool.mu); hb.swap(g_host_pool.free_blocks); }
+    for (auto& b : hb) VPP_HIP_TRY(hipHostFree(b.second));
+  }
   DevicePool& P = pool_of_current_device();
   std::multimap<size_t, void*> blocks;
   {

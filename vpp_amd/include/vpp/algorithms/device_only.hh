@@ -15,4 +15,15 @@ struct dbuf {
   void upload(const void* h, size_t n) { if (n) check(vpp_memcpy_h2d(p, h, n, stream()), "vpp_memcpy_h2d"); }
   void download(void* h, size_t n) const { if (n) check(vpp_memcpy_d2h(h, p, n, stream()), "vpp_memcpy_d2h"); }
 };
+// pinned host staging of n elements of T (keypoint lists / results moved to and from HBM every frame)
+template <class T> struct hbuf {
+  T* p = nullptr; size_t n = 0;
+  explicit hbuf(size_t count) : n(count) { void* v = nullptr; check(vpp_malloc_host((count ? count : 1) * sizeof(T), &v), "vpp_malloc_host"); p = (T*)v; }
+  ~hbuf() { if (p) vpp_free_host(p); }
+  hbuf(const hbuf&) = delete; hbuf& operator=(const hbuf&) = delete;
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* data() { return p; }
+  size_t bytes() const { return n * sizeof(T); }
+};
 } }

@@ -26,13 +26,13 @@ void semi_dense_optical_flow(const K& keypoints, MC match_callback, const image2
   const int propagation_niters = opts.get(_propagation, 2), patchsize = opts.get(_patchsize, 5);
   const int n = int(keypoints.size());
   if (!n) return;
-  // host staging kept across calls (per thread): the runtime pins the pages of a pageable copy's host side, which is costly for
-  // a never-seen address range and nearly free for the one it saw on the previous frame
-  static thread_local std::vector<vint2> kps, pos;
-  static thread_local std::vector<int> dist;
-  static thread_local std::vector<unsigned char> valid;
-  kps.resize(n); pos.resize(n); dist.resize(n); valid.resize(n);
-  device::dbuf dk(size_t(n) * 8), dp(size_t(n) * 8), dd(size_t(n) * 4), dv{size_t(n)};
+  // The results are written by the read-back kernel straight into pinned host memory (device-visible: vpp_malloc_host), so no
+  // device-to-host copy follows the flow.  (Measured: the first SDMA copy of more than a few 100 KB after the 2.5 ms of flow
+  // kernels takes ~0.8 ms — the copy engine waking up — while 1 MB of kernel stores over the link cost ~20 us.)
+  device::hbuf<vint2> kps(n), pos(n);
+  device::hbuf<int> dist(n);
+  device::hbuf<unsigned char> valid(n);
+  device::dbuf dk(size_t(n) * 8);
   {
     of_internals::stopwatch sw(of_internals::timing()[0]);
     for (int i = 0; i < n; i++) { auto k = keypoints[i]; kps[i] = vint2(k[0], k[1]); }
@@ -41,11 +41,10 @@ void semi_dense_optical_flow(const K& keypoints, MC match_callback, const image2
   {
     of_internals::stopwatch sw(of_internals::timing()[1]);
     const vpp_image_desc d1 = i1.device_desc(false), d2 = i2.device_desc(false);
-    device::check(vpp_semi_dense_optical_flow(&d1, &d2, (const int32_t*)dk.p, n, winsize, nscales, min_scale, propagation_niters, patchsize, (int32_t*)dp.p,
-                                              (int32_t*)dd.p, (uint8_t*)dv.p, device::stream()), "vpp_semi_dense_optical_flow");
-    dv.download(valid.data(), dv.bytes);   // first read-back: waits for the flow
+    device::check(vpp_semi_dense_optical_flow(&d1, &d2, (const int32_t*)dk.p, n, winsize, nscales, min_scale, propagation_niters, patchsize,
+                                              (int32_t*)pos.data(), dist.data(), valid.data(), device::stream()), "vpp_semi_dense_optical_flow");
+    device::check(vpp_sync(device::stream()), "vpp_sync");
   }
-  { of_internals::stopwatch sw(of_internals::timing()[2]); dp.download(pos.data(), dp.bytes); dd.download(dist.data(), dd.bytes); }
   of_internals::stopwatch sw(of_internals::timing()[3]);
   for (int i = 0; i < n; i++) if (valid[i]) match_callback(i, pos[i], dist[i]);  // semi_dense_optical_flow.hpp:205-212
 }
