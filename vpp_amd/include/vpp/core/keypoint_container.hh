@@ -46,7 +46,8 @@ template <class P, class F> struct keypoint_container {
   }
   void prepare_matching() {
     compact_has_run_ = false;
-    for (const vint2& p : touched_) index2d_(p) = -1;
+    if (!idx_base_ && !touched_.empty()) { idx_base_ = (char*)&index2d_(0, 0); idx_pitch_ = index2d_.pitch(); }
+    for (const vint2& p : touched_) *(int*)(idx_base_ + (ptrdiff_t)p[0] * idx_pitch_ + (ptrdiff_t)p[1] * (ptrdiff_t)sizeof(int)) = -1;
     touched_.clear();
     std::fill(matches_.begin(), matches_.end(), -1);
   }
@@ -108,7 +109,14 @@ template <class P, class F> struct keypoint_container {
   bool has(vint2 p) const { return index2d_(p) >= 0; }
 
  private:
-  void set_index(const vint2& p, int i) { index2d_(p) = i; touched_.push_back(p); }
+  // index2d_ lives on the host only: its cells are addressed through a cached base pointer / pitch (the generic accessor re-checks
+  // the device-mirror state on every call, which shows at ~100 k updates per frame)
+  void set_index(const vint2& p, int i) {
+    if (!idx_base_) { idx_base_ = (char*)&index2d_(0, 0); idx_pitch_ = index2d_.pitch(); }
+    *(int*)(idx_base_ + (ptrdiff_t)p[0] * idx_pitch_ + (ptrdiff_t)p[1] * (ptrdiff_t)sizeof(int)) = i;
+    touched_.push_back(p);
+  }
+  char* idx_base_ = nullptr; ptrdiff_t idx_pitch_ = 0;
   std::vector<int> matches_;
   std::vector<vint2> touched_;
   image2d<int> index2d_;
