@@ -195,8 +195,9 @@ __global__ __launch_bounds__(1024) void sdof_propagate_kernel(DImg i1, DImg i2, 
 // serial reference, but the 81-pixel SADs no longer sit on the critical path of the wavefront.
 struct Cell { int f0, f1, dist, mark; };  // mark: low byte = flow_map_mark value, bit 8 = changed during this sweep
 constexpr int kChanged = 0x100;  // Jacobi result array only: the Jacobi pass changed this cell
-constexpr int kDirty = 0x400;    // ring only: an earlier neighbour changed during this sweep, the Jacobi outcome does not apply
-constexpr int kJChanged = 0x200;  // skewed-copy-only flag: the Jacobi pass wants to change this cell
+constexpr int kJChanged = 0x200;  // Jacobi kernel only: its pass wants to change this cell
+// flag byte of a cell in the skewed array / the LDS ring of the ordered pass
+constexpr int kFlagMarked = 1, kFlagJChanged = 2, kFlagDirty = 4;
 
 // Per (cell, neighbour) results of the costly calls of loop_body, keyed by the neighbour flow they were computed for.
 struct PairCache { int nf0, nf1, d2, gf0, gf1, gdist, flags, pad; };  // flags: 1 = entry valid, 2 = descent result present
@@ -248,7 +249,7 @@ __device__ __forceinline__ Cell load_map_cell(const Maps& m, int ci, int cj) {
 }
 
 __global__ __launch_bounds__(256) void sdof_jacobi_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int NI, int NJ, int forward,
-                                                          Cell* __restrict__ J, PairCache* __restrict__ pairs, Cell* __restrict__ skew, int NIp) {
+                                                          Cell* __restrict__ J, PairCache* __restrict__ pairs, uint8_t* __restrict__ skew, int NIp) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= NI * NJ) return;
   const int ci = idx / NJ, cj = idx - ci * NJ;
@@ -268,108 +269,145 @@ __global__ __launch_bounds__(256) void sdof_jacobi_kernel(DImg i1, DImg i2, int 
   // the pre-sweep cell (+ "Jacobi wants to change it") in the ordered pass's visiting layout: step-major, wavefront row minor,
   // so that at every step the rows of the wavefront read one contiguous run of 16-byte records
   const int iw = forward ? ci : NI - 1 - ci, jw = forward ? cj : NJ - 1 - cj;
-  skew[(size_t)(2 * iw + jw) * NIp + iw] = pre;
+  const int t = 2 * iw + jw;
+  skew[((size_t)(t >> 4) * NIp + iw) * 16 + (t & 15)] = (uint8_t)(((pre.mark & 0xFF) ? kFlagMarked : 0) | ((pre.mark & kJChanged) ? kFlagJChanged : 0));
 }
 
-// LDS ring of the ordered pass: slot (2 * row + column) & (K - 1), wavefront row minor — the cells visited at one step are
-// contiguous (conflict-free 16-byte accesses across a wave) and a slot is a straight copy of one row of the skewed array.
-template <int K> __device__ __forceinline__ const Cell* ring_cell(const Cell* ring, int NIp, int row, int col) {
-  return ring + (size_t)((2 * row + col) & (K - 1)) * NIp + row;
+// The ordered pass keeps ONE flag byte per cell in LDS (marked? Jacobi wants to change it? dirty?) — all the common path needs.
+// Sixteen consecutive wavefront steps of a row share a 16-byte record, [step / 16][row][step % 16], so that one LDS-direct
+// dwordx4 load per wave brings the flags of its 64 rows for 16 steps: the cost of a step used to be the LDS-DMA instruction
+// itself (~100 cycles each, one per wave and step, serialised on the CU), and before that the 7 KB of whole cells per step
+// that the one CU running the pass had to pull (a single CU draws only ~10 B/cycle from beyond its L2).
+constexpr int kGroupSteps = 16, kRingGroups = 4;
+__device__ __forceinline__ int flag_byte_index(int NIp, int row, int t) { return (((t >> 4) & (kRingGroups - 1)) * NIp + row) * kGroupSteps + (t & 15); }
+
+// A cell of the flow maps as the other waves of this workgroup left it: changed cells are written to the global maps at their
+// step and their stores have completed before the step's barrier, so an L1-bypassing (agent-scope) load after the barrier sees
+// them; cells not yet visited in this sweep hold their pre-sweep values — exactly what loop_body must read.
+__device__ __forceinline__ Cell load_map_cell_coherent(const Maps& m, int ci, int cj) {
+  Cell c;
+  const int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
+  c.f0 = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  c.f1 = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  c.dist = __hip_atomic_load(m.dist.row<int32_t>(ci) + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  c.mark = __hip_atomic_load(m.mark.row<uint8_t>(ci) + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return c;
 }
 
-// Slow path of the ordered pass (a neighbour visited earlier was changed): loop_body against the ring.  Kept out of line so
-// that the per-step code stays small; the cell travels by value (a pointer would pin the caller's copy in scratch memory).
+// Slow path of the ordered pass (a neighbour visited earlier was changed): loop_body against the current maps.  Kept out of
+// line so that the per-step code stays small.  The cell, its eight neighbours and its eight pair-cache entries are fetched
+// up front, back to back: one memory round trip instead of dependent ones on the critical path of the wavefront.
 struct SlowResult { Cell cell; int changed; };
-template <int K>
-__device__ __noinline__ SlowResult sweep_slow_path(const DImg& i1, const DImg& i2, int ws, int patch, int forward, int iw, int jw, int NI, int NJ,
-                                                   int NIp, const Cell* ring, Cell cur, PairCache* pc) {
+__device__ __noinline__ SlowResult sweep_slow_path(const DImg& i1, const DImg& i2, int ws, int patch, int forward, int ci, int cj, int NI, int NJ,
+                                                   const Maps& m, const PairCache* pc) {
   int r, c;
-  if (forward) { r = iw * patch; c = jw * patch; } else { r = i1.nr - 1 - iw * patch; c = i1.nc - 1 - jw * patch; }
-  cur.mark &= 0xFF;
-  auto wnbr = [&](int drow, int col) -> Cell {
-    const int rr = iw + drow;
-    if (rr < 0 || rr >= NI || col < 0 || col >= NJ) return Cell{0, 0, 0, 0};
-    return *ring_cell<K>(ring, NIp, rr, col);
-  };
-  // flow-map offset (dr,dc) -> wavefront offset: mirrored in the backward sweep
-  auto nbr = [&](int dr, int dc) -> Cell { return forward ? wnbr(dr, jw + dc) : wnbr(-dr, jw - dc); };
-  // the eight pair-cache entries of the cell in one memory round trip (read one by one inside loop_body they were eight
-  // dependent L2 misses on the critical path of the wavefront)
+  if (forward) { r = ci * patch; c = cj * patch; } else { r = i1.nr - 1 - (NI - 1 - ci) * patch; c = i1.nc - 1 - (NJ - 1 - cj) * patch; }
+  Cell nb8[8];
+  int k = 0;
+#pragma unroll
+  for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
+    for (int dc = -1; dc <= 1; dc++) {
+      if (!dr && !dc) continue;
+      const int q0 = ci + dr, q1 = cj + dc;
+      nb8[k] = Cell{0, 0, 0, 0};
+      if (q0 >= 0 && q1 >= 0 && q0 < NI && q1 < NJ) nb8[k] = load_map_cell_coherent(m, q0, q1);
+      k++;
+    }
+  Cell cur = load_map_cell_coherent(m, ci, cj);
   PairCache loc[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) loc[k] = pc[k];
+  for (int q = 0; q < 8; q++) loc[q] = pc[q];
+  auto nbr = [&](int dr, int dc) -> Cell { return nb8[(dr + 1) * 3 + (dc + 1) - ((dr > 0 || (dr == 0 && dc > 0)) ? 1 : 0)]; };
   const bool changed = loop_body<false>(i1, i2, ws, r, c, cur, nbr, loc);
   return SlowResult{cur, changed ? 1 : 0};
 }
 
 // Ordered pass.  Thread = wavefront row: at step t it visits wavefront column t - 2*row, so data only flows between
-// adjacent threads.  The pre-sweep cells (+ the Jacobi verdict) of step t are row t of the skewed array written by
-// sdof_jacobi_kernel; they are copied into ring slot t & (K-1) by LDS-direct loads (global_load_lds_dwordx4: no VGPR
-// destination, so no register of the step code ever waits on them), issued P steps ahead in batches of QD and awaited
-// once per batch.  Slot t is read during steps t-3 .. t+3 (t+1 .. t+3 only by the slow path), hence P >= QD + 3 (landed in
-// time) and P + QD <= K - 3 (the slot being overwritten is no longer read).  A cell that changes flags its four later
-// neighbours dirty (LDS atomic OR) instead of every cell gathering the flags of its four earlier neighbours, so the common
-// path (not dirty, Jacobi verdict "unchanged") is ONE conflict-free 16-byte LDS read and a barrier per step.
-__device__ unsigned g_sweep_stats[4];  // [0] marked cells visited, [1] Jacobi outcomes applied, [2] slow-path recomputations, [3] slow-path changes
+// adjacent threads.  The flag bytes of steps 16g .. 16g+15 are group g of the skewed array written by sdof_jacobi_kernel; a
+// group is copied into ring slot g & 3 by one LDS-direct load per wave (global_load_lds_dwordx4: no VGPR destination), two
+// groups ahead.  A cell that changes writes the global maps and flags its four later neighbours dirty (steps t+1 .. t+3: at
+// most one group ahead, already resident).  A 16-step group in which no row has a cell to apply or recompute is skipped
+// whole (one 16-byte LDS read, one barrier); only the other groups are walked step by step with a barrier per step.
+__device__ unsigned g_sweep_stats[4];  // [0] unused, [1] Jacobi outcomes applied, [2] slow-path recomputations, [3] slow-path changes
 
-template <int K>
 __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward,
                                                                    const Cell* __restrict__ J, PairCache* __restrict__ pairs,
-                                                                   const Cell* __restrict__ skew, int NIp, int stats) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Cell* ring = (Cell*)smem_raw;  // [K][NIp]
-  constexpr int QD = K >= 16 ? 5 : 1, P = K >= 16 ? 8 : 4;
-  static_assert(P >= QD + 3 && P + QD <= K - 3, "ring too small for the prefetch distance");
+                                                                   const uint8_t* __restrict__ skew, int NIp, int stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [kRingGroups][NIp][16]
   const int NI = (i1.nr - 1) / patch + 1, NJ = (i1.nc - 1) / patch + 1;
   const int iw = threadIdx.x;
   const bool row_ok = iw < NI;
   const int ci = forward ? iw : NI - 1 - iw;  // flow-map row of this thread
-  const int tmax = 2 * (NI - 1) + (NJ - 1);
+  const int tmax = 2 * (NI - 1) + (NJ - 1), gmax = tmax >> 4;
   const int wave_base = (int)threadIdx.x & ~63;
-  auto issue = [&](int t) {  // t is uniform; each wave copies its 64 rows of step t (lane L lands at dst + 16 L)
-    if (t < 0 || t > tmax) return;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(skew + (size_t)t * NIp + threadIdx.x),
-                                     (__attribute__((address_space(3))) void*)(ring + (size_t)(t & (K - 1)) * NIp + wave_base), 16, 0, 0);
+  auto issue = [&](int g) {  // g is uniform; each wave copies the 16-byte records of its 64 rows (lane L lands at dst + 16 L)
+    if (g > gmax) return;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(skew + ((size_t)g * NIp + threadIdx.x) * kGroupSteps),
+                                     (__attribute__((address_space(3))) void*)(ring + ((size_t)(g & (kRingGroups - 1)) * NIp + wave_base) * kGroupSteps), 16, 0, 0);
   };
-  auto flag_dirty = [&](int drow, int col) {  // two rows can flag the same cell in one step: LDS atomic
+  auto flag_dirty = [&](int drow, int col) {  // two rows can flag the same cell in one step, and a word holds four cells: LDS atomic
     const int r = iw + drow;
-    if (r < NI && col >= 0 && col < NJ) atomicOr(&const_cast<Cell*>(ring_cell<K>(ring, NIp, r, col))->mark, kDirty);
+    if (r < NI && col >= 0 && col < NJ) {
+      const int b = flag_byte_index(NIp, r, 2 * r + col);
+      atomicOr((uint32_t*)(ring + (b & ~3)), (uint32_t)kFlagDirty << (8 * (b & 3)));
+    }
   };
-  for (int t = 0; t < P; t++) issue(t);
-  for (int tb = 0; tb <= tmax; tb += QD) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the slots requested one batch ago (and the warm-up) are in LDS
+  __shared__ int noisy_word[3];  // rotating "some cell of this group needs work" flags (zeroed two groups ahead of their use)
+  if (threadIdx.x < 3) noisy_word[threadIdx.x] = 0;
+  issue(0); issue(1);
+  for (int g = 0; g <= gmax; g++) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): group g + 1 (requested one group ago) and the warm-up are in LDS
     __syncthreads();
+    issue(g + 2);                         // replaces group g - 2, last read at step 16 (g - 2) + 15
+    // Quiet group test: a marked cell does something only if the Jacobi pass wants to change it or an earlier neighbour made it
+    // dirty; a group of 16 steps in which no row has such a cell changes nothing and flags nothing, so it is skipped whole —
+    // one barrier per 16 steps.  (Dirty flags for this group were all set during earlier steps, i.e. before the barrier above.)
+    {
+      bool noisy = false;
+      if (row_ok) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 rec = *(const u32x4*)(ring + ((size_t)(g & (kRingGroups - 1)) * NIp + iw) * kGroupSteps);
+        const uint32_t d[4] = {rec.x, rec.y, rec.z, rec.w};
 #pragma unroll
-    for (int u = 0; u < QD; u++) issue(tb + P + u);
-#pragma unroll
-    for (int u = 0; u < QD; u++) {
-      const int t = tb + u;
+        for (int u = 0; u < kGroupSteps; u++) {
+          const int jw = g * kGroupSteps + u - 2 * iw;
+          const uint32_t b = (d[u >> 2] >> (8 * (u & 3))) & 0xFFu;
+          noisy |= jw >= 0 && jw < NJ && (b & kFlagMarked) && (b & (kFlagJChanged | kFlagDirty));
+        }
+      }
+      if (threadIdx.x == 0) noisy_word[(g + 1) % 3] = 0;
+      if (__ballot(noisy) != 0 && (threadIdx.x & 63) == 0) atomicOr(&noisy_word[g % 3], 1);
+      __syncthreads();
+      if (noisy_word[g % 3] == 0) continue;
+    }
+#pragma unroll 4
+    for (int u = 0; u < kGroupSteps; u++) {
+      const int t = g * kGroupSteps + u;
       const int jw = t - 2 * iw;
       if (row_ok && t <= tmax && jw >= 0 && jw < NJ) {
-        Cell* myp = ring + (size_t)(t & (K - 1)) * NIp + iw;
-        Cell cur = *myp;
-        if (cur.mark & 0xFF) {
+        const int w = ring[flag_byte_index(NIp, iw, t)];
+        if ((w & kFlagMarked) && (w & (kFlagJChanged | kFlagDirty))) {
           const int cj = forward ? jw : NJ - 1 - jw;
+          Cell cur = Cell{0, 0, 0, 0};
           bool changed = false;
-          if (stats) atomicAdd(&g_sweep_stats[0], 1u);
-          if (!(cur.mark & kDirty)) {  // none of the four neighbours visited earlier changed: the Jacobi outcome is the sequential one
-            if (cur.mark & kJChanged) { cur = J[(size_t)ci * NJ + cj]; changed = true; if (stats) atomicAdd(&g_sweep_stats[1], 1u); }
+          if (!(w & kFlagDirty)) {  // none of the four neighbours visited earlier changed: the Jacobi outcome is the sequential one
+            cur = J[(size_t)ci * NJ + cj]; changed = true;
+            if (stats) atomicAdd(&g_sweep_stats[1], 1u);
           } else {
-            const SlowResult sr = sweep_slow_path<K>(i1, i2, ws, patch, forward, iw, jw, NI, NJ, NIp, ring, cur, pairs + ((size_t)ci * NJ + cj) * 8);
+            const SlowResult sr = sweep_slow_path(i1, i2, ws, patch, forward, ci, cj, NI, NJ, m, pairs + ((size_t)ci * NJ + cj) * 8);
             cur = sr.cell; changed = sr.changed != 0;
             if (stats) { atomicAdd(&g_sweep_stats[2], 1u); if (changed) atomicAdd(&g_sweep_stats[3], 1u); }
           }
           if (changed) {
-            cur.mark &= 0xFF;
-            *myp = cur;
             int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
-            f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)cur.mark;
-            // tell the four cells that are visited later and read this one (steps t+1 .. t+3, slots already resident)
+            f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)(cur.mark & 0xFF);
+            // tell the four cells that are visited later and read this one
             flag_dirty(0, jw + 1); flag_dirty(1, jw - 1); flag_dirty(1, jw); flag_dirty(1, jw + 1);
           }
         }
       }
-      __syncthreads();
+      __syncthreads();  // includes s_waitcnt vmcnt(0): the stores of a changed cell have completed before anyone reads them
     }
   }
 }
@@ -415,7 +453,8 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
   hipStream_t st = as_stream(stream);
   // carve the scratch: two image pyramids (border 2*winsize, :72-73), flow / mark / distance pyramids (border nscales, :70-74), owners
   vpp_image_desc P1[kMaxScales], P2[kMaxScales], FL[kMaxScales], MK[kMaxScales], DM[kMaxScales], OW[kMaxScales];
-  Cell *jacobi = nullptr, *skew = nullptr;
+  Cell* jacobi = nullptr;
+  uint8_t* skew = nullptr;
   PairCache* pairs = nullptr;
   for (int pass = 0; pass < 2; pass++) {
     Carver cv{pass ? (uint8_t*)g_scratch.p : nullptr};
@@ -434,8 +473,8 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
       pairs = cv.base ? (PairCache*)(cv.base + cv.off) : nullptr;
       cv.off += (cells * 8 * sizeof(PairCache) + 255) / 256 * 256;
       const size_t ni = (size_t)(i1->nrows - 1) / patchsize + 1, nj = (size_t)(i1->ncols - 1) / patchsize + 1;
-      skew = cv.base ? (Cell*)(cv.base + cv.off) : nullptr;   // [2 (NI - 1) + NJ wavefront steps][NI rows rounded up to whole waves]
-      cv.off += ((2 * (ni - 1) + nj) * ((ni + 63) / 64 * 64) * sizeof(Cell) + 255) / 256 * 256;
+      skew = cv.base ? (uint8_t*)(cv.base + cv.off) : nullptr;   // flag bytes, [(2 (NI - 1) + NJ wavefront steps) / 16][NI rows rounded up to whole waves][16]
+      cv.off += (((2 * (ni - 1) + nj) / 16 + 1) * ((ni + 63) / 64 * 64) * 16 + 255) / 256 * 256;
     }
     if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
@@ -460,21 +499,13 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
     if (propagation > 0) {
       const int NI = (P1[scale].nrows - 1) / patchsize + 1;
       const int threads = (NI + 63) / 64 * 64;
-      const int mode = tuning("sdof.propagate", 0);  // 0 auto, 1 generic, 2 ring K=16, 3 ring K=8
+      const int mode = tuning("sdof.propagate", 0);  // 0 / 2 / 3: Jacobi + ordered flag pass, 1: generic wavefront kernel
       const int NJ = (P1[scale].ncols - 1) / patchsize + 1;
-      const bool ring16 = (mode == 0 || mode == 2) && NI <= 640, ring8 = !ring16 && (mode == 0 || mode == 3) && NI <= 1024;
-      if (ring16 || ring8) {
+      if (mode != 1 && NI <= 1024) {  // mode 1: the generic one-kernel wavefront (also the fallback for maps taller than 1024 cells)
+        const size_t lds = (size_t)kRingGroups * threads * kGroupSteps;
         for (int Ki = 0; Ki < propagation; Ki++) {
           sdof_jacobi_kernel<<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs, skew, threads);
-          if (ring16) {
-            const size_t lds = (size_t)threads * 16 * sizeof(Cell);
-            VPP_HIP_TRY(hipFuncSetAttribute((const void*)sdof_propagate_ring_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            sdof_propagate_ring_kernel<16><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
-          } else {
-            const size_t lds = (size_t)threads * 8 * sizeof(Cell);
-            VPP_HIP_TRY(hipFuncSetAttribute((const void*)sdof_propagate_ring_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            sdof_propagate_ring_kernel<8><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
-          }
+          sdof_propagate_ring_kernel<<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
         }
       } else
         sdof_propagate_kernel<<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, propagation);
