@@ -341,6 +341,7 @@ __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg
   const int ci = forward ? iw : NI - 1 - iw;  // flow-map row of this thread
   const int tmax = 2 * (NI - 1) + (NJ - 1), gmax = tmax >> 4;
   const int wave_base = (int)threadIdx.x & ~63;
+  __shared__ int noisy_word[3];  // per group: bit u = step 16 g + u has a cell to apply or recompute (rotating, zeroed one group ahead of their first use)
   auto issue = [&](int g) {  // g is uniform; each wave copies the 16-byte records of its 64 rows (lane L lands at dst + 16 L)
     if (g > gmax) return;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(skew + ((size_t)g * NIp + threadIdx.x) * kGroupSteps),
@@ -349,22 +350,23 @@ __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg
   auto flag_dirty = [&](int drow, int col) {  // two rows can flag the same cell in one step, and a word holds four cells: LDS atomic
     const int r = iw + drow;
     if (r < NI && col >= 0 && col < NJ) {
-      const int b = flag_byte_index(NIp, r, 2 * r + col);
+      const int tt = 2 * r + col, b = flag_byte_index(NIp, r, tt);
       atomicOr((uint32_t*)(ring + (b & ~3)), (uint32_t)kFlagDirty << (8 * (b & 3)));
+      atomicOr(&noisy_word[(tt >> 4) % 3], 1 << (tt & 15));  // that step (this group or the next) now has work
     }
   };
-  __shared__ int noisy_word[3];  // rotating "some cell of this group needs work" flags (zeroed two groups ahead of their use)
   if (threadIdx.x < 3) noisy_word[threadIdx.x] = 0;
   issue(0); issue(1);
   for (int g = 0; g <= gmax; g++) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): group g + 1 (requested one group ago) and the warm-up are in LDS
     __syncthreads();
     issue(g + 2);                         // replaces group g - 2, last read at step 16 (g - 2) + 15
-    // Quiet group test: a marked cell does something only if the Jacobi pass wants to change it or an earlier neighbour made it
-    // dirty; a group of 16 steps in which no row has such a cell changes nothing and flags nothing, so it is skipped whole —
-    // one barrier per 16 steps.  (Dirty flags for this group were all set during earlier steps, i.e. before the barrier above.)
+    // Step mask of the group: a marked cell does something only if the Jacobi pass wants to change it or an earlier neighbour
+    // made it dirty; a step at which no row has such a cell changes nothing and flags nothing and is not executed at all — a quiet
+    // group costs one 16-byte LDS read and one barrier.  (Dirty flags set during earlier groups are already in the ring and in
+    // the mask word.)
     {
-      bool noisy = false;
+      int mine = 0;
       if (row_ok) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 rec = *(const u32x4*)(ring + ((size_t)(g & (kRingGroups - 1)) * NIp + iw) * kGroupSteps);
@@ -373,16 +375,20 @@ __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg
         for (int u = 0; u < kGroupSteps; u++) {
           const int jw = g * kGroupSteps + u - 2 * iw;
           const uint32_t b = (d[u >> 2] >> (8 * (u & 3))) & 0xFFu;
-          noisy |= jw >= 0 && jw < NJ && (b & kFlagMarked) && (b & (kFlagJChanged | kFlagDirty));
+          if (jw >= 0 && jw < NJ && (b & kFlagMarked) && (b & (kFlagJChanged | kFlagDirty))) mine |= 1 << u;
         }
       }
-      if (threadIdx.x == 0) noisy_word[(g + 1) % 3] = 0;
-      if (__ballot(noisy) != 0 && (threadIdx.x & 63) == 0) atomicOr(&noisy_word[g % 3], 1);
+      if (threadIdx.x == 0) noisy_word[(g + 2) % 3] = 0;   // group g + 2's word: last read during group g - 1, first flagged during g + 1
+      if (mine) atomicOr(&noisy_word[g % 3], mine);
       __syncthreads();
-      if (noisy_word[g % 3] == 0) continue;
     }
-#pragma unroll 4
-    for (int u = 0; u < kGroupSteps; u++) {
+    // Walk only the steps that have work.  A step's changes can add steps u+1 .. u+3 (or the first steps of the next group) to the
+    // mask, never the step being executed or an earlier one, so every thread derives the same sequence from its own reads.
+    int u = 0;
+    while (true) {
+      const int rem = (noisy_word[g % 3] >> u) << u;
+      if (!rem) break;
+      u = __ffs(rem) - 1;
       const int t = g * kGroupSteps + u;
       const int jw = t - 2 * iw;
       if (row_ok && t <= tmax && jw >= 0 && jw < NJ) {
@@ -408,6 +414,7 @@ __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg
         }
       }
       __syncthreads();  // includes s_waitcnt vmcnt(0): the stores of a changed cell have completed before anyone reads them
+      u++;
     }
   }
 }
