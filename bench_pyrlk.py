@@ -175,4 +175,15 @@ def cpu_baseline(orc):
     t0 = time.perf_counter()
     orc.orc_fast9_detect(P(im.desc), 20, None, 0, 10, 0, rc.ctypes.data_as(V), None, 3000000, P(n))
     out["fast9_raw_gpixels_per_s"] = 2160 * 3840 / (time.perf_counter() - t0) / 1e9
+    # semi-dense flow on the same 4K frame pair as the GPU leg, one pass of the serial restatement (the reference's sweeps are
+    # sequential by construction and its OpenMP claim loop is racy, SURVEY Q9: one thread is the reference's defined behaviour)
+    from test_gpu_sdof import flow_scene
+    s1, s2, sk = flow_scene(2160, 3840, spacing=10)
+    e1, e2 = u8_image(s1, border=3), u8_image(s2, border=3)
+    m = len(sk)
+    gp = np.zeros((m, 2), np.int32); gd = np.zeros(m, np.int32); gv = np.zeros(m, np.uint8)
+    t0 = time.perf_counter()
+    orc.orc_semi_dense_optical_flow(P(e1.desc), P(e2.desc), sk.ctypes.data_as(V), m, 9, 3, 0, 2, 5, gp.ctypes.data_as(V), gd.ctypes.data_as(V), gv.ctypes.data_as(V))
+    out["semi_dense_flow_4k_frame_pairs_per_s"] = 1.0 / (time.perf_counter() - t0)
+    out["semi_dense_flow_sample"] = "1 pass, 1 thread (serial semantics), same frame pair and keypoints as the GPU leg"
     return out
