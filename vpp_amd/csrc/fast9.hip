@@ -479,7 +479,10 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   int rc = g_scratch.ensure(total_bytes, st);
   if (rc != VPP_OK) return rc;
   uint8_t* base = (uint8_t*)g_scratch.p;
-  uint32_t* d_total = (uint32_t*)base;
+  // the keypoint total lands in a pinned, device-visible host word (one per host thread): a stream sync replaces the 4-byte D2H copy
+  thread_local uint32_t* t_total = nullptr;
+  if (!t_total) { void* h = nullptr; int hs = vpp_malloc_host(64, &h); if (hs != VPP_OK) return hs; t_total = (uint32_t*)h; }
+  uint32_t* d_total = t_total;
   DImg F{base + off_f + ffirst, nr, nc, fpitch, 1, VPP_U16, 1};
   uint64_t* bitmap = (uint64_t*)(base + off_bm);
   uint2* blkres = (uint2*)(base + off_br);
@@ -507,9 +510,8 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
     fast9_write_segs_kernel<1><<<ngroups, 256, 0, st>>>(F, (const uint16_t*)bitmap, nsc, nsegs, unit_off, out_rc, out_scores, capacity);
   }
   VPP_LAUNCH_CHECK();
-  uint32_t total = 0;
-  VPP_HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, st));
-  VPP_HIP_TRY(hipStreamSynchronize(st));
+  VPP_HIP_TRY(hipStreamSynchronize(st));   // the total was written straight into pinned host memory by the scan kernel: no copy
+  const uint32_t total = *(volatile uint32_t*)d_total;
   *count = (int)total;
   if ((int)total > capacity) {
     set_error("vpp_fast9_detect: %u keypoints found, output capacity %d", total, capacity);
