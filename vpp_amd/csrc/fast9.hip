@@ -19,8 +19,8 @@
 //   2. count / scan / write  units in the reference's serial output order, one per thread: 16-px bitmap segments (RAW,
 //                            LOCAL_MAXIMA — the count pass rewrites a segment with the bits that survive the strict 8-neighbour
 //                            test on F) or bs x bs blocks (BLOCKWISE — one lane per block row walks the bitmap words, rows meet
-//                            in an LDS u64 max of score << 32 | ~position).  A flat exclusive scan of the unit counts gives
-//                            the output index, so the list comes out row-major (pixels / blocks) like the serial reference,
+//                            in an LDS u64 max of score << 32 | ~position).  A flat exclusive scan of the unit counts (each write
+//                            workgroup sums the per-workgroup counts before it: no scan launch) gives the output index, so the list comes out row-major (pixels / blocks) like the serial reference,
 //                            which the OpenMP reference itself does not guarantee.  4K, 454k corners: RAW
 //                            5 + 5 + 12 us, LOCAL 18 + 5 + 6 us, BLOCKWISE 13 + 5 + 6 us after the 30 us detect kernel.
 // VALU-bound (the ring test is ~100 lane-ops per pixel against 1 B/px of HBM traffic); see DESIGN.md.
@@ -297,6 +297,21 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* tot) {
   return off + inc - v;
 }
 
+// Output offset of workgroup `nb` = sum of the per-workgroup counts before it.  Every write workgroup sums them itself (the
+// array is a few KB and sits in L2), which replaces a separate single-workgroup scan launch between the two passes.
+__device__ __forceinline__ uint32_t group_offset(const uint32_t* __restrict__ unit_count, int nb) {
+  __shared__ uint32_t gsum[4];
+  uint32_t s = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += unit_count[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if ((threadIdx.x & 63) == 0) gsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const uint32_t r = gsum[0] + gsum[1] + gsum[2] + gsum[3];
+  __syncthreads();
+  return r;
+}
+
 // RAW / LOCAL_MAXIMA unit: one 16-px segment of the corner bitmap (a u16 of the u64 word the detect wave wrote), so the
 // serial per-bit chains stay short and ~8k waves are in flight.
 constexpr int SEG = 16;
@@ -338,12 +353,14 @@ __global__ __launch_bounds__(256) void fast9_count_segs_kernel(DImg F, uint16_t*
 // pass 3, RAW / LOCAL_MAXIMA: ordered write
 template <int MODE>
 __global__ __launch_bounds__(256) void fast9_write_segs_kernel(DImg F, const uint16_t* __restrict__ segs, int nsc, int nsegs,
-                                                               const uint32_t* __restrict__ unit_off, int32_t* __restrict__ out_rc,
-                                                               int32_t* __restrict__ out_scores, int capacity) {
+                                                               const uint32_t* __restrict__ unit_count, uint32_t* __restrict__ total,
+                                                               int32_t* __restrict__ out_rc, int32_t* __restrict__ out_scores, int capacity) {
   const int u = blockIdx.x * 256 + threadIdx.x;
   uint32_t m = u < nsegs ? segs[u] : 0;
   uint32_t tot;
-  uint32_t k = unit_off[blockIdx.x] + block_exscan((uint32_t)__popc(m), &tot);
+  const uint32_t base = group_offset(unit_count, blockIdx.x);
+  uint32_t k = base + block_exscan((uint32_t)__popc(m), &tot);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = base + tot;
   if (!m) return;
   const int r = u / nsc, cbase = (u - r * nsc) * SEG;
   const uint16_t* f0 = F.row<uint16_t>(r);
@@ -405,28 +422,18 @@ __global__ __launch_bounds__(256) void fast9_count_blocks_kernel(DImg F, const u
 }
 
 __global__ __launch_bounds__(256) void fast9_write_blocks_kernel(const uint2* __restrict__ blkres, int nblocks, int G,
-                                                                 const uint32_t* __restrict__ unit_off, int32_t* __restrict__ out_rc,
-                                                                 int32_t* __restrict__ out_scores, int capacity) {
+                                                                 const uint32_t* __restrict__ unit_count, uint32_t* __restrict__ total,
+                                                                 int32_t* __restrict__ out_rc, int32_t* __restrict__ out_scores, int capacity) {
   const int b = blockIdx.x * G + threadIdx.x;
   const uint2 res = ((int)threadIdx.x < G && b < nblocks) ? blkres[b] : make_uint2(0, 0);
   uint32_t tot;
-  const uint32_t k = unit_off[blockIdx.x] + block_exscan(res.y > 0 ? 1u : 0u, &tot);
+  const uint32_t base = group_offset(unit_count, blockIdx.x);
+  const uint32_t k = base + block_exscan(res.y > 0 ? 1u : 0u, &tot);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = base + tot;
   if (res.y > 0 && (int)k < capacity) {
     out_rc[2 * (size_t)k] = (int32_t)(res.x >> 16); out_rc[2 * (size_t)k + 1] = (int32_t)(res.x & 0xFFFFu);
     if (out_scores) out_scores[k] = (int32_t)res.y;
   }
-}
-
-// exclusive scan of n unit counts (single workgroup), total -> *total
-__global__ __launch_bounds__(256) void scan_units_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, int n, uint32_t* __restrict__ total) {
-  const int per = (n + 255) / 256;
-  const int b = threadIdx.x * per, e = min(b + per, n);
-  uint32_t s = 0;
-  for (int i = b; i < e; i++) s += cnt[i];
-  uint32_t tot;
-  uint32_t ex = block_exscan(s, &tot);
-  for (int i = b; i < e; i++) { off[i] = ex; ex += cnt[i]; }
-  if (threadIdx.x == 0) *total = tot;
 }
 
 thread_local Scratch g_scratch;
@@ -461,7 +468,7 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   }
   hipStream_t st = as_stream(stream);
   const int nr = src->nrows, nc = src->ncols;
-  // scratch layout: [total][F: u16 map with border 1][bitmap: one u64 per 64-px row segment][blkres][unit_count][unit_off]
+  // scratch layout: [total][F: u16 map with border 1][bitmap: one u64 per 64-px row segment][blkres][unit_count]
   int32_t fpitch; size_t fbytes, ffirst;
   vpp_image_layout(nr, nc, 2, 1, 16, &fpitch, &fbytes, &ffirst);
   const int ntc = (nc + TW - 1) / TW, nwords = nr * ntc;
@@ -475,7 +482,7 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   const int ngroups = mode == VPP_FAST9_BLOCKWISE ? (nblocks + G - 1) / G : (nsegs + 255) / 256;
   const size_t off_f = 256, off_bm = off_f + align_up(fbytes, 256), off_br = off_bm + align_up((size_t)nwords * 8, 256);
   const size_t off_uc = off_br + align_up((size_t)nblocks * 8, 256);
-  const size_t off_uo = off_uc + align_up((size_t)ngroups * 4, 256), total_bytes = off_uo + align_up((size_t)ngroups * 4, 256);
+  const size_t total_bytes = off_uc + align_up((size_t)ngroups * 4, 256);
   int rc = g_scratch.ensure(total_bytes, st);
   if (rc != VPP_OK) return rc;
   uint8_t* base = (uint8_t*)g_scratch.p;
@@ -487,7 +494,6 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   uint64_t* bitmap = (uint64_t*)(base + off_bm);
   uint2* blkres = (uint2*)(base + off_br);
   uint32_t* unit_count = (uint32_t*)(base + off_uc);
-  uint32_t* unit_off = (uint32_t*)(base + off_uo);
   DImg A = dimg(src), M = mask ? dimg(mask) : A;
   dim3 grid(ntc, (nr + TH - 1) / TH);
   if (tuning("fast9.impl", 2) == 2) {  // 2 = two-phase (compacted candidates), 1 = one lane per pixel all the way
@@ -498,16 +504,13 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   VPP_LAUNCH_CHECK();
   if (mode == VPP_FAST9_BLOCKWISE) {
     fast9_count_blocks_kernel<<<ngroups, 256, 0, st>>>(F, bitmap, ntc, block_size, nbc, nblocks, RB, G, blkres, unit_count);
-    scan_units_kernel<<<1, 256, 0, st>>>(unit_count, unit_off, ngroups, d_total);
-    fast9_write_blocks_kernel<<<ngroups, 256, 0, st>>>(blkres, nblocks, G, unit_off, out_rc, out_scores, capacity);
+    fast9_write_blocks_kernel<<<ngroups, 256, 0, st>>>(blkres, nblocks, G, unit_count, d_total, out_rc, out_scores, capacity);
   } else if (mode == VPP_FAST9_RAW) {
     fast9_count_segs_kernel<0><<<ngroups, 256, 0, st>>>(F, (uint16_t*)bitmap, nsc, nsegs, unit_count);
-    scan_units_kernel<<<1, 256, 0, st>>>(unit_count, unit_off, ngroups, d_total);
-    fast9_write_segs_kernel<0><<<ngroups, 256, 0, st>>>(F, (const uint16_t*)bitmap, nsc, nsegs, unit_off, out_rc, out_scores, capacity);
+    fast9_write_segs_kernel<0><<<ngroups, 256, 0, st>>>(F, (const uint16_t*)bitmap, nsc, nsegs, unit_count, d_total, out_rc, out_scores, capacity);
   } else {
     fast9_count_segs_kernel<1><<<ngroups, 256, 0, st>>>(F, (uint16_t*)bitmap, nsc, nsegs, unit_count);
-    scan_units_kernel<<<1, 256, 0, st>>>(unit_count, unit_off, ngroups, d_total);
-    fast9_write_segs_kernel<1><<<ngroups, 256, 0, st>>>(F, (const uint16_t*)bitmap, nsc, nsegs, unit_off, out_rc, out_scores, capacity);
+    fast9_write_segs_kernel<1><<<ngroups, 256, 0, st>>>(F, (const uint16_t*)bitmap, nsc, nsegs, unit_count, d_total, out_rc, out_scores, capacity);
   }
   VPP_LAUNCH_CHECK();
   VPP_HIP_TRY(hipStreamSynchronize(st));   // the total was written straight into pinned host memory by the scan kernel: no copy
