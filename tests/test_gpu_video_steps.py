@@ -89,3 +89,23 @@ def test_allgather_tracks_single_rank(lib):
     assert torch.equal(out, shard)
     capi.check(lib.vpp_comm_destroy(comm))
     assert lib.vpp_comm_init(ctypes.byref(comm), 1, idbuf, 3) != 0   # rank out of range
+
+
+def test_runtime_pools(lib):
+    """vpp_malloc / vpp_free keep freed blocks by size class; vpp_malloc_host hands out pinned, device-visible staging memory."""
+    p1, p2 = ctypes.c_void_p(), ctypes.c_void_p()
+    capi.check(lib.vpp_malloc(1000000, ctypes.byref(p1)))
+    capi.check(lib.vpp_free(p1))
+    capi.check(lib.vpp_malloc(1000001, ctypes.byref(p2)))           # same 4 KiB size class: the cached block comes back
+    assert p1.value == p2.value
+    capi.check(lib.vpp_free(p2))
+    capi.check(lib.vpp_release_cached_memory())
+    h = ctypes.c_void_p()
+    capi.check(lib.vpp_malloc_host(4096, ctypes.byref(h)))
+    host = (ctypes.c_uint8 * 4096).from_address(h.value)
+    src = torch.arange(4096, dtype=torch.int32, device="cuda").to(torch.uint8)
+    capi.check(lib.vpp_memcpy_d2d(h, V(src.data_ptr()), 4096, capi.stream_ptr()))   # a device-side copy INTO the pinned block
+    capi.check(lib.vpp_sync(capi.stream_ptr()))
+    assert bytes(host[:16]) == bytes(range(16))
+    capi.check(lib.vpp_free_host(h))
+    assert lib.vpp_free_host(ctypes.c_void_p(12345)) != 0          # not one of ours
