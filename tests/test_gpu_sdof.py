@@ -75,3 +75,15 @@ def test_sdof_1080p_frame(lib, orc):
     planted = np.array([(2, -3), (-4, 1), (5, 4), (0, -6)])
     ok = (np.abs(flow[:, None, :] - planted[None]).max(axis=2) <= 1).any(axis=1)
     assert ok.mean() > 0.8, ok.mean()
+
+
+def test_sdof_4k_bench_scene_matches_oracle(lib, orc):
+    """The exact frame pair and keypoint set bench_pyrlk.py times (BASELINE configs[4] shapes): 81 748 keypoints, winsize 9, 3 scales,
+    2 sweeps.  Its middle scale holds a chain of ~900 dependent recomputations along the motion boundaries — the hard case of the
+    ordered pass."""
+    lib.vpp_set_tuning(b"sdof.propagate", -1)
+    f1, f2, kps = flow_scene(2160, 3840, spacing=10)
+    got, want = run_both(lib, orc, f1, f2, kps, 9, 3, 0, 2, 5)
+    assert want[2].mean() > 0.9
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
