@@ -73,7 +73,10 @@ def test_add_4k_checker(lib):
     (vi.I32, 1, 5, 5, (33, 1000), 3, 32),   # several strips
     (vi.U32, 1, 5, 5, (50, 249), 2, 32),
     (vi.I32, 2, 5, 5, (20, 30), 2, 32),     # vint2 -> generic kernel
-    (vi.F32, 1, 5, 5, (64, 64), 2, 32),
+    (vi.F32, 1, 5, 5, (64, 64), 2, 32),      # float: taps in the reference's order (32-bit streaming kernel)
+    (vi.F32, 1, 5, 5, (67, 131), 2, 16),
+    (vi.F32, 1, 5, 5, (33, 1000), 3, 32),
+    (vi.F32, 2, 5, 5, (20, 30), 2, 32),      # vfloat2 -> generic kernel
     (vi.U8, 3, 7, 5, (30, 40), 3, 32),
     (vi.I16, 2, 3, 5, (30, 40), 2, 32),
 ])
@@ -84,7 +87,7 @@ def test_box_filter_matches_oracle(lib, orc, dtype, ch, R, C, shape, border, ali
     assert orc.orc_box_filter(P(want.desc), P(src.desc), R, C) == 0
     dsrc = DeviceImage.from_host(src)
     fast = dtype == vi.U8 and R == 5 and C == 5
-    w32 = dtype in (vi.I32, vi.U32) and ch == 1 and R == 5 and C == 5
+    w32 = dtype in (vi.I32, vi.U32, vi.F32) and ch == 1 and R == 5 and C == 5
     for impl, rows in (((1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (0, 8), (0, 16), (0, 32)) if fast else ((1, 1), (1, 2), (1, 4), (1, 8)) if w32 else ((1, 2),)):
         lib.vpp_set_tuning(b"box.impl", impl); lib.vpp_set_tuning(b"box.rows", rows); lib.vpp_set_tuning(b"box.rows32", rows)
         ddst = DeviceImage.from_host(src.like(border=0))

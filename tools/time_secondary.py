@@ -36,7 +36,9 @@ for rows in (1, 2, 4, 8):
 lib.vpp_set_tuning(b"box.rows32", -1)
 box(vi.U8, 1, 5, 5, 2, 1)
 box(vi.U8, 4, 5, 5, 2, 4)
-box(vi.F32, 1, 5, 5, 2, 4)
+for rows in (1, 2, 4):
+    lib.vpp_set_tuning(b"box.rows32", rows); print("rows32", rows, end=": "); box(vi.F32, 1, 5, 5, 2, 4)
+lib.vpp_set_tuning(b"box.rows32", -1)
 box(vi.U8, 3, 3, 3, 1, 3)
 box(vi.U8, 3, 7, 7, 3, 3)
 # pixel_wise on 8-bit images (packed-byte arithmetic): 3 x 24.9 MB per launch

@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256, (RW <= 2 ? 8 : RW <= 4 ? 6 : 4)) void box5x5_u
     box5x5_u8_stream_body<CH, RW, NT, false, PROBE>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x, r0, writer);
 }
 
-// ---- 32-bit integer 5x5 (the element type of the reference's own benchmark, benchmarks/box_5x5_filter.cc:165-171,187-191) ----
+// ---- 32-bit 5x5: int / unsigned (the element type of the reference's own benchmark, benchmarks/box_5x5_filter.cc:165-171,187-191)
+//      and float (taps added in the reference's order) ----
 // Same shape as the u8 streaming kernel with one pixel per dword: a lane owns 4 consecutive pixels (16 B), keeps their
 // 5-row column sums (integer adds are order-independent, so the running add / subtract is exact, wrap-around included),
 // takes the two halo sums of each side from lane -1 / +1 over DPP, and lanes 1..62 store 4 truncating quotients (`/ 25` in T).
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ 
   const int lo = -border, hi = ncols + border;
   const bool in_reach = x + 4 > lo && x < ncols + 4, inside = x >= lo && x + 4 <= hi;
   const bool writer = lane >= 1 && lane <= 62 && x < ncols;
-  typedef typename std::make_unsigned<T>::type U;  // sums wrap like the hardware's int adds (no signed-overflow UB in the source)
+  typedef uint32_t U;  // raw dwords: integer sums wrap like the hardware's adds (no signed-overflow UB in the source); floats are bit-cast
   // Every load is unconditional so that the RW + 4 rows are requested back to back: rows past the bottom border are clamped
   // (they only feed output rows >= nrows, which are not stored), lanes outside the strip's reach read a valid chunk that
   // nobody consumes, and only the waves that contain a chunk straddling a row end (first / last strip) take the
@@ -315,12 +316,49 @@ __global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ 
       for (int i = 0; i < 4; i++) { const int c = x + i; const U v = row[min(max(c, lo), hi - 1)]; raw[k][i] = (c >= lo && c < hi) ? v : 0; }
     }
   }
+  const bool full_store = x + 4 <= ncols;
+  if constexpr (std::is_floating_point<T>::value) {
+    // float: the 25 taps are added one by one in the reference's row-major order (the sum is not associative), starting from 0;
+    // each input row's halo (2 pixels per side) is exchanged once, the window of an output row is then 5 x 8 registers
+    float win[RW + 4][8];
+#pragma unroll
+    for (int k = 0; k < RW + 4; k++) {
+      const U w8[8] = {from_left(raw[k][2]), from_left(raw[k][3]), raw[k][0], raw[k][1], raw[k][2], raw[k][3], from_right(raw[k][0]), from_right(raw[k][1])};
+#pragma unroll
+      for (int i = 0; i < 8; i++) win[k][i] = __builtin_bit_cast(float, w8[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < RW; j++) {
+      const int r = r0 + j;
+      if (r >= nrows) break;
+      U out[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float sum = 0.f;
+#pragma unroll
+        for (int dr = 0; dr < 5; dr++)
+#pragma unroll
+          for (int dc = 0; dc < 5; dc++) sum += win[j + dr][i + dc];
+        out[i] = __builtin_bit_cast(U, sum / 25);   // C++ `/ (R*C)` on the promoted type: float / int -> IEEE float division
+      }
+      if (writer) {
+        U* drow = (U*)((uint8_t*)dp + (ptrdiff_t)r * dpitch) + x;
+        if (full_store) {
+          const u32x4 v = {out[0], out[1], out[2], out[3]};
+          if (NT) __builtin_nontemporal_store(v, (u32x4*)drow); else *(u32x4*)drow = v;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) if (x + i < ncols) drow[i] = out[i];
+        }
+      }
+    }
+    return;
+  }
   U V[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 4; k++)
 #pragma unroll
     for (int i = 0; i < 4; i++) V[i] += raw[k][i];
-  const bool full_store = x + 4 <= ncols;
 #pragma unroll
   for (int j = 0; j < RW; j++) {
     const int r = r0 + j;
@@ -506,9 +544,9 @@ extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* s
       case 4: return launch_fast<4>(dst, src, st);
     }
   }
-  if ((dst->dtype == VPP_I32 || dst->dtype == VPP_U32) && dst->channels == 1 && R == 5 && C == 5 && aligned16(dst) && aligned16(src) &&
+  if ((dst->dtype == VPP_I32 || dst->dtype == VPP_U32 || dst->dtype == VPP_F32) && dst->channels == 1 && R == 5 && C == 5 && aligned16(dst) && aligned16(src) &&
       !tuning("box.force_generic", 0))
-    return dst->dtype == VPP_I32 ? launch_w32<int32_t>(dst, src, st) : launch_w32<uint32_t>(dst, src, st);
+    return dst->dtype == VPP_I32 ? launch_w32<int32_t>(dst, src, st) : dst->dtype == VPP_U32 ? launch_w32<uint32_t>(dst, src, st) : launch_w32<float>(dst, src, st);
   switch (dst->dtype) {
     case VPP_U8: return launch_generic<uint8_t, int>(dst, src, R, C, st);
     case VPP_I8: return launch_generic<int8_t, int>(dst, src, R, C, st);
