@@ -120,6 +120,12 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
                      int compat, int32_t* out_rc, int32_t* out_scores, int capacity, int* count, void* stream);
 /* fast9_scores (fast.hpp:643-652): n (row,col) pairs in device memory -> n int32 full scores. */
 int vpp_fast9_scores(const vpp_image_desc* src, int th, const int32_t* rc, int n, int32_t* out_scores, void* stream);
+/* The score cull of video_extruder_update (video_extruder/video_extruder.hpp:44-56,87-91) queued behind the flow instead of
+ * after a host round trip: keypoint i is scored at rc_moved[i] when that lies inside src's domain (the match callback moved it
+ * there), else at rc_prev[i] (the callback removed it, or never ran: its position is unchanged).  All three arrays are
+ * device-visible (HBM or vpp_malloc_host memory); no synchronisation. */
+int vpp_fast9_scores_moved(const vpp_image_desc* src, int th, const int32_t* rc_moved, const int32_t* rc_prev, int n,
+                           int32_t* out_scores, void* stream);
 
 /* ---- pyramidal Lucas-Kanade ----
  * vpp_pyrlk_match = pyrlk_match (vpp/algorithms/pyrlk/pyrlk_match.hh:15-55) with matcher

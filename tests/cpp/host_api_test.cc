@@ -163,7 +163,53 @@ static void test_image3d_and_iterators() {
   CHECK(i == 9);
 }
 
+// The container writes its 2-D index lazily (a log replayed on the first look-up): every interleaving of add / move / remove /
+// compact / prepare_matching / look-ups must read exactly what the reference's eager stores produce (keypoint_container.hpp:22-167).
+static void test_keypoint_index_is_the_eager_one() {
+  const int NR = 24, NC = 31;
+  unsigned rng = 12345u;
+  auto next = [&](unsigned m) { rng = rng * 1664525u + 1013904223u; return (rng >> 8) % m; };
+  for (int round = 0; round < 20; round++) {
+    keypoint_container<keypoint<int>, int> kc(make_box2d(NR, NC));
+    std::vector<int> model(NR * NC, -1);                                      // the eager index
+    std::vector<vint2> pos; std::vector<int> age;
+    auto cell = [&](vint2 p) -> int& { return model[p[0] * NC + p[1]]; };
+    for (int step = 0; step < 400; step++) {
+      const unsigned op = next(100);
+      if (op < 30 || pos.empty()) {                                           // add
+        vint2 p(next(NR), next(NC)); kc.add(keypoint<int>(p)); cell(p) = int(pos.size()); pos.push_back(p); age.push_back(1);
+      } else if (op < 60) {                                                   // move
+        int i = next(unsigned(pos.size())); vint2 p(next(NR), next(NC)); kc.move(i, p); pos[i] = p; age[i]++; cell(p) = i;
+      } else if (op < 75) {                                                   // remove(int)
+        int i = next(unsigned(pos.size())); kc.remove(i); age[i] = 0; if (cell(pos[i]) == i) cell(pos[i]) = -1;
+      } else if (op < 80) {                                                   // prepare_matching
+        kc.prepare_matching(); std::fill(model.begin(), model.end(), -1);
+      } else if (op < 85) {                                                   // compact
+        kc.compact();
+        size_t w = 0;
+        for (size_t i = 0; i < pos.size(); i++) if (age[i] > 0) { pos[w] = pos[i]; age[w] = age[i]; cell(pos[w]) = int(w); w++; }
+        pos.resize(w); age.resize(w);
+      } else if (op < 90) {                                                   // remove(position) when the cell is occupied
+        vint2 p(next(NR), next(NC));
+        if (cell(p) >= 0) { CHECK(kc.has(p)); int i = cell(p); kc.remove(p); age[i] = 0; if (cell(pos[i]) == i) cell(pos[i]) = -1; }
+        else CHECK(!kc.has(p));
+      } else if (op < 97) {                                                   // point look-ups
+        vint2 p(next(NR), next(NC)); CHECK(kc.has(p) == (cell(p) >= 0)); CHECK(kc.index_of(p) == cell(p));
+      } else {                                                                // whole image
+        const keypoint_container<keypoint<int>, int>& ck = kc;
+        for (int r = 0; r < NR; r++) for (int c = 0; c < NC; c++) CHECK(ck.index2d()(r, c) == model[r * NC + c]);
+      }
+      CHECK(kc.size() == int(pos.size()));
+    }
+    for (int r = 0; r < NR; r++) for (int c = 0; c < NC; c++) CHECK(kc.index2d()(r, c) == model[r * NC + c]);
+    for (size_t i = 0; i < pos.size(); i++) CHECK(kc[i].position == pos[i] && kc[i].age == age[i]);
+    // the mutable image may be written behind the container's back: the next prepare_matching must still clear it
+    kc.index2d()(3, 3) = 77; kc.prepare_matching(); CHECK(!kc.has(vint2(3, 3)));
+  }
+}
+
 int main() {
+  test_keypoint_index_is_the_eager_one();
   test_image3d_and_iterators();
   test_colorspace_conversions();
   test_layout_and_access();

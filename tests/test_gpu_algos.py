@@ -146,6 +146,26 @@ def test_fast9_scores_and_errors(lib, orc):
     assert n.value > 4
 
 
+def test_fast9_scores_moved_scores_where_the_callback_leaves_the_keypoint(lib, orc):
+    """video_extruder.hpp:44-56,87-91: a keypoint matched outside the frame is removed where it was, so it is scored there."""
+    im = u8_image(rects_image(90, 120, seed=5), border=3)
+    orc.orc_fill_border(P(im.desc), 0, None)
+    d = DeviceImage.from_host(im)
+    rng = np.random.default_rng(2)
+    prev = np.stack([rng.integers(0, 90, 800), rng.integers(0, 120, 800)], 1).astype(np.int32)
+    moved = prev + rng.integers(-40, 41, size=prev.shape).astype(np.int32)
+    inside = (moved[:, 0] >= 0) & (moved[:, 0] < 90) & (moved[:, 1] >= 0) & (moved[:, 1] < 120)
+    assert 50 < inside.sum() < 750
+    at = np.ascontiguousarray(np.where(inside[:, None], moved, prev).astype(np.int32))
+    want = np.zeros(800, np.int32)
+    orc.orc_fast9_scores(P(im.desc), 12, at.ctypes.data_as(ctypes.c_void_p), 800, want.ctypes.data_as(ctypes.c_void_p))
+    dm = torch.from_numpy(moved).cuda(); dp = torch.from_numpy(prev).cuda(); out = torch.zeros(800, dtype=torch.int32, device="cuda")
+    capi.check(lib.vpp_fast9_scores_moved(P(d.desc), 12, ctypes.c_void_p(dm.data_ptr()), ctypes.c_void_p(dp.data_ptr()), 800,
+                                          ctypes.c_void_p(out.data_ptr()), capi.stream_ptr()))
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    assert lib.vpp_fast9_scores_moved(P(d.desc), 12, None, ctypes.c_void_p(dp.data_ptr()), 800, ctypes.c_void_p(out.data_ptr()), None) == capi.ERR_INVALID_ARG
+
+
 # ---- Lucas-Kanade ----------------------------------------------------------------------------------------------
 def test_lucas_kanade_reference_golden_on_gpu(lib, orc):
     """tests/pyrlk.cc through the C ABI: flow (2,2) +- 0.05 and bit-identical to the oracle."""

@@ -276,6 +276,15 @@ __global__ __launch_bounds__(256) void fast9_scores_list_kernel(DImg A, int th, 
   if (i < n) out[i] = fast9_score_px(A, rc[2 * i], rc[2 * i + 1], th);  // fast.hpp:643-652
 }
 
+__global__ __launch_bounds__(256) void fast9_scores_moved_kernel(DImg A, int th, const int32_t* __restrict__ moved, const int32_t* __restrict__ prev,
+                                                                 int n, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int r = moved[2 * i], c = moved[2 * i + 1];
+  if (!A.has(r, c)) { r = prev[2 * i]; c = prev[2 * i + 1]; }  // video_extruder.hpp:50-53: an out-of-frame match removes the keypoint where it was
+  out[i] = fast9_score_px(A, r, c, th);
+}
+
 // ---- ordered selection -----------------------------------------------------------------------------------
 // Units are laid out in the reference's serial output order (row-major 64-px mask words for RAW / LOCAL_MAXIMA, row-major
 // blocks for BLOCKWISE), one unit per thread, so a flat exclusive scan of the per-unit counts is the output index.
@@ -450,6 +459,16 @@ int vpp_fast9_scores(const vpp_image_desc* src, int th, const int32_t* rc, int n
   VPP_REQUIRE(src->border >= 3, VPP_ERR_BORDER_TOO_SMALL, "Image need a border of 3px at least for the FAST detector");
   if (n == 0) return VPP_OK;
   fast9_scores_list_kernel<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(dimg(src), th, rc, n, out_scores);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+int vpp_fast9_scores_moved(const vpp_image_desc* src, int th, const int32_t* rc_moved, const int32_t* rc_prev, int n, int32_t* out_scores, void* stream) {
+  VPP_REQUIRE(valid_desc(src) && rc_moved && rc_prev && out_scores && n >= 0, VPP_ERR_INVALID_ARG, "vpp_fast9_scores_moved: invalid argument");
+  VPP_REQUIRE(src->dtype == VPP_U8 && src->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_fast9_scores_moved: u8 x1 only");
+  VPP_REQUIRE(src->border >= 3, VPP_ERR_BORDER_TOO_SMALL, "Image need a border of 3px at least for the FAST detector");
+  if (n == 0) return VPP_OK;
+  fast9_scores_moved_kernel<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(dimg(src), th, rc_moved, rc_prev, n, out_scores);
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }

@@ -1,10 +1,15 @@
 // keypoint_container.hh — keypoints + features with a 2-D index (reference: vpp/core/keypoint_container.hh:13-90,
 // keypoint_container.hpp:11-167) and trajectories (vpp/core/keypoint_trajectory.hh:11-72).  Host-side bookkeeping.
 // The index image is refilled only over the cells that were set (the reference memsets the whole frame-sized image on
-// every prepare_matching: 8-33 MB per frame); observable behaviour is the same.
+// every prepare_matching: 8-33 MB per frame), and it is written LAZILY: move / add / remove / compact append
+// (cell, value) records to a log that is replayed, in order, the first time the index is looked at (has, operator()(pos),
+// index2d(), index_of, remove(pos)).  A tracker that only moves and culls keypoints never pays the ~100 k scattered
+// stores per frame into a frame-sized image (1.3 ms of a 4K video_extruder update); observable behaviour is the same.
 #pragma once
+#include <atomic>
 #include <cassert>
 #include <deque>
+#include <mutex>
 #include <vector>
 #include <vpp/core/fill.hh>
 #include <vpp/core/image2d.hh>
@@ -46,9 +51,9 @@ template <class P, class F> struct keypoint_container {
   }
   void prepare_matching() {
     compact_has_run_ = false;
-    if (!idx_base_ && !touched_.empty()) { idx_base_ = (char*)&index2d_(0, 0); idx_pitch_ = index2d_.pitch(); }
-    for (const vint2& p : touched_) *(int*)(idx_base_ + (ptrdiff_t)p[0] * idx_pitch_ + (ptrdiff_t)p[1] * (ptrdiff_t)sizeof(int)) = -1;
-    touched_.clear();
+    log_.clear();               // whatever was pending is overwritten by the fill
+    reset_pending_ = true;
+    lazy_.dirty.store(true, std::memory_order_release);
     std::fill(matches_.begin(), matches_.end(), -1);
   }
   struct no_op { template <class T> void operator()(T&) {} };
@@ -81,10 +86,9 @@ template <class P, class F> struct keypoint_container {
   void remove(int i) {
     assert(i < size());
     keypoint_vector_[i].die();
-    int& index = index2d_(cast<vint2>(keypoint_vector_[i].position));
-    if (index == i) index = -1;
+    log_op(cast<vint2>(keypoint_vector_[i].position), ~i);  // "if (index == i) index = -1"
   }
-  void remove(vint2 pos) { assert(has(pos)); remove(index2d_(pos)); }
+  void remove(vint2 pos) { assert(has(pos)); remove(cell(pos)); }
   template <class T> void move(int i, T position) {
     assert(i >= 0 && i < size());
     auto& kp = keypoint_vector_[i];
@@ -98,27 +102,62 @@ template <class P, class F> struct keypoint_container {
 
   keypoint_vector_type& keypoints() { return keypoint_vector_; }
   const keypoint_vector_type& keypoints() const { return keypoint_vector_; }
-  image2d<int>& index2d() { return index2d_; }
-  const image2d<int>& index2d() const { return index2d_; }
-  int index_of(vint2& p) const { return index2d_(p); }
+  // a caller holding the mutable image may write cells this container does not know about: the next prepare_matching refills it whole
+  image2d<int>& index2d() { materialise(); refill_whole_ = true; return index2d_; }
+  const image2d<int>& index2d() const { materialise(); return index2d_; }
+  int index_of(vint2& p) const { return cell(p); }
   keypoint_type& operator[](unsigned i) { return keypoint_vector_[i]; }
   const keypoint_type& operator[](unsigned i) const { return keypoint_vector_[i]; }
-  keypoint_type& operator()(vint2 p) { return keypoint_vector_[index2d_(p)]; }
-  const keypoint_type& operator()(vint2 p) const { return keypoint_vector_[index2d_(p)]; }
+  keypoint_type& operator()(vint2 p) { return keypoint_vector_[cell(p)]; }
+  const keypoint_type& operator()(vint2 p) const { return keypoint_vector_[cell(p)]; }
   int size() const { return int(keypoint_vector_.size()); }
-  bool has(vint2 p) const { return index2d_(p) >= 0; }
+  bool has(vint2 p) const { return cell(p) >= 0; }
 
  private:
-  // index2d_ lives on the host only: its cells are addressed through a cached base pointer / pitch (the generic accessor re-checks
-  // the device-mirror state on every call, which shows at ~100 k updates per frame)
-  void set_index(const vint2& p, int i) {
-    if (!idx_base_) { idx_base_ = (char*)&index2d_(0, 0); idx_pitch_ = index2d_.pitch(); }
-    *(int*)(idx_base_ + (ptrdiff_t)p[0] * idx_pitch_ + (ptrdiff_t)p[1] * (ptrdiff_t)sizeof(int)) = i;
-    touched_.push_back(p);
+  // One pending write to the index image: i >= 0 sets the cell to i, i < 0 clears it if it holds ~i (remove(int)).
+  struct index_op { int r, c, i; };
+  // const look-ups may come from several threads at once (the reference's were plain reads): the first one replays the log under a mutex
+  struct lazy_state {
+    std::atomic<bool> dirty{false}; std::mutex m;
+    lazy_state() {}
+    lazy_state(const lazy_state& o) : dirty(o.dirty.load()) {}
+    lazy_state& operator=(const lazy_state& o) { dirty.store(o.dirty.load()); return *this; }
+  };
+  void set_index(const vint2& p, int i) { log_op(p, i); }
+  void log_op(const vint2& p, int i) {
+    log_.push_back(index_op{p[0], p[1], i});
+    lazy_.dirty.store(true, std::memory_order_release);
+    if (log_.size() > (size_t(1) << 22)) materialise();  // bound the log of a caller that never looks at the index
   }
-  char* idx_base_ = nullptr; ptrdiff_t idx_pitch_ = 0;
+  int& cell_ref(int r, int c) const { return *(int*)(idx_base_ + (ptrdiff_t)r * idx_pitch_ + (ptrdiff_t)c * (ptrdiff_t)sizeof(int)); }
+  int cell(const vint2& p) const { materialise(); return cell_ref(p[0], p[1]); }
+  void materialise() const {
+    if (!lazy_.dirty.load(std::memory_order_acquire) && idx_base_) return;
+    std::lock_guard<std::mutex> lock(lazy_.m);
+    // index2d_ lives on the host only: its cells are addressed through a cached base pointer / pitch (the generic accessor
+    // re-checks the device-mirror state on every call)
+    if (!idx_base_) { idx_base_ = (char*)&const_cast<image2d<int>&>(index2d_)(0, 0); idx_pitch_ = index2d_.pitch(); }
+    if (!lazy_.dirty.load(std::memory_order_relaxed)) return;
+    if (reset_pending_) {
+      if (refill_whole_) { fill_with_border(const_cast<image2d<int>&>(index2d_), -1); refill_whole_ = false; }
+      else for (const vint2& p : touched_) cell_ref(p[0], p[1]) = -1;
+      touched_.clear();
+      reset_pending_ = false;
+    }
+    for (const index_op& o : log_) {
+      int& c = cell_ref(o.r, o.c);
+      if (o.i >= 0) { c = o.i; touched_.push_back(vint2(o.r, o.c)); }
+      else if (c == ~o.i) c = -1;
+    }
+    log_.clear();
+    lazy_.dirty.store(false, std::memory_order_release);
+  }
+  mutable char* idx_base_ = nullptr; mutable ptrdiff_t idx_pitch_ = 0;
   std::vector<int> matches_;
-  std::vector<vint2> touched_;
+  mutable std::vector<index_op> log_;
+  mutable std::vector<vint2> touched_;
+  mutable bool reset_pending_ = false, refill_whole_ = false;
+  mutable lazy_state lazy_;
   image2d<int> index2d_;
   keypoint_vector_type keypoint_vector_;
   feature_vector_type feature_vector_;
