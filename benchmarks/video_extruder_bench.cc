@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
   const double n = double(per.size() - 1);
   std::printf("{\"workload\": \"video_extruder_update %dx%d uchar, defaults (th 10, spacing 10, period 5, 3 scales, winsize 9, 2 sweeps), %d updates after the detecting one\", "
               "\"ms_per_update\": %.3f, \"frames_per_s\": %.2f, \"keypoints\": %d, \"alive\": %d, \"velocity_ok\": %d, "
-              "\"breakdown_ms\": {\"flow\": %.3f, \"merge\": %.3f, \"scores\": %.3f, \"redetect\": %.3f, \"trajectories\": %.3f, "
+              "\"breakdown_ms\": {\"flow\": %.3f, \"apply_moves_merge_cull\": %.3f, \"scores\": %.3f, \"redetect\": %.3f, \"trajectories\": %.3f, "
               "\"redetect_mask\": %.3f, \"redetect_fast9\": %.3f, \"redetect_add\": %.3f, \"redetect_compact\": %.3f, \"redetect_sync\": %.3f, "
               "\"flow_gather_upload\": %.3f, \"flow_device\": %.3f, \"flow_download\": %.3f, \"flow_callbacks\": %.3f}, \"per_update_ms\": [",
               nr, nc, int(per.size() - 1), mean, 1000.0 / mean, ctx.keypoints.size(), alive, good, tm.flow / n, tm.merge / n, tm.scores / n, tm.redetect / n, tm.traj / n,

@@ -169,6 +169,14 @@ int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, i
  * with border, then 0 over [r - spacing, r + spacing) x [c - spacing, c + spacing) for each of the n (row, col) int32
  * pairs in DEVICE memory (clipped to the mask's border). */
 int vpp_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, void* stream);
+/* The merge step of video_extruder_update (video_extruder/video_extruder.hpp:60-84), queued behind the flow like
+ * vpp_fast9_scores_moved.  Keypoint i sits at rc_moved[i] with age age_prev[i] + 1 when matched[i] != 0 and rc_moved[i] lies
+ * inside the nrows x ncols frame (move, :51); at rc_prev[i] with age 0 when matched but outside (remove, :52); at rc_prev[i]
+ * with age_prev[i] when unmatched.  removed[i] = 1 iff the reference's serial loop over i (one champion per
+ * spacing x spacing cell; a strictly older newcomer evicts the champion, a strictly younger one is removed, a tie keeps both
+ * and the champion) calls remove(i).  All arrays device-visible; positions must be inside the frame; no synchronisation. */
+int vpp_keypoint_merge(const int32_t* rc_moved, const int32_t* rc_prev, const uint8_t* matched, const int32_t* age_prev, int n,
+                       int nrows, int ncols, int spacing, uint8_t* removed, void* stream);
 
 /* lbp_transform (vpp/algorithms/lbp/lbp_transform.hh:6-38): out(r,c) bit k = (k-th neighbour > centre), neighbours in
  * row-major order without the centre; u8 x1 -> u8 x1, in needs border >= 1. */

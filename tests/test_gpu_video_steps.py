@@ -109,3 +109,45 @@ def test_runtime_pools(lib):
     assert bytes(host[:16]) == bytes(range(16))
     capi.check(lib.vpp_free_host(h))
     assert lib.vpp_free_host(ctypes.c_void_p(12345)) != 0          # not one of ours
+
+
+def _merge_model(pos, age, spacing, nr, nc):
+    """video_extruder.hpp:60-84 restated literally: the serial champion loop over an (nr/s) x (nc/s) index image."""
+    idx = {}
+    age = age.copy()
+    removed = np.zeros(len(age), np.uint8)
+    for i in range(len(age)):
+        cell = (int(pos[i, 0]) // spacing, int(pos[i, 1]) // spacing)
+        if cell in idx:
+            o = idx[cell]
+            other_age = int(age[o])
+            if other_age < age[i]:
+                removed[o] = 1; age[o] = 0; idx[cell] = i
+            if other_age > age[i]:
+                removed[i] = 1; age[i] = 0
+        else:
+            idx[cell] = i
+    return removed
+
+
+@pytest.mark.parametrize("n,nr,nc,spacing,max_age", [(4000, 90, 130, 10, 4), (20000, 211, 317, 7, 30), (3000, 40, 40, 10, 2), (1, 50, 50, 10, 3), (5000, 64, 64, 64, 6)])
+def test_keypoint_merge_matches_the_serial_champion_loop(lib, n, nr, nc, spacing, max_age):
+    rng = np.random.default_rng(n + spacing)
+    prev = np.stack([rng.integers(0, nr, n), rng.integers(0, nc, n)], 1).astype(np.int32)
+    moved = (prev + rng.integers(-12, 13, size=prev.shape)).astype(np.int32)
+    matched = (rng.random(n) < 0.8).astype(np.uint8)
+    moved[matched == 0] = prev[matched == 0]                      # the read-back kernel leaves unmatched keypoints where they were
+    age_prev = rng.integers(0, max_age + 1, n).astype(np.int32)   # 0 = a keypoint that died earlier and is still in the container
+    inside = (moved[:, 0] >= 0) & (moved[:, 0] < nr) & (moved[:, 1] >= 0) & (moved[:, 1] < nc)
+    pos = np.where(((matched == 1) & inside)[:, None], moved, prev)
+    age = np.where(matched == 1, np.where(inside, age_prev + 1, 0), age_prev).astype(np.int32)
+    want = _merge_model(pos, age, spacing, nr, nc)
+    assert n < 10 or 0 < want.sum() < n
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dm, dp, dmt, da = t(moved), t(prev), t(matched), t(age_prev)
+    out = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+    for _ in range(2):  # twice: the scratch list heads are reset on every call
+        capi.check(lib.vpp_keypoint_merge(ctypes.c_void_p(dm.data_ptr()), ctypes.c_void_p(dp.data_ptr()), ctypes.c_void_p(dmt.data_ptr()),
+                                          ctypes.c_void_p(da.data_ptr()), n, nr, nc, spacing, ctypes.c_void_p(out.data_ptr()), capi.stream_ptr()))
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+    assert lib.vpp_keypoint_merge(None, None, None, None, 5, nr, nc, spacing, None, None) == capi.ERR_INVALID_ARG

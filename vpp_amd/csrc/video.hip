@@ -141,6 +141,63 @@ extern "C" int vpp_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, 
   return VPP_OK;
 }
 
+// ---- video_extruder merge (video_extruder.hpp:60-84) ------------------------------------------------------------
+// The serial loop keeps one champion per cell: the first keypoint of the cell, replaced by any later one that is strictly
+// older (which removes the champion); a later keypoint strictly younger than the champion is removed; a tie changes nothing.
+// The champion's age is therefore the running maximum of the cell, and with E = max age of the earlier keypoints of the cell
+// and L = max age of the later ones:   first of its cell or age > E  ->  it becomes champion, removed iff L > age
+//                                       age == E -> kept (ties never become champion, so nothing evicts them);  age < E -> removed.
+// Pass 1 threads every keypoint onto a per-cell list (atomic exchange of the list head); pass 2 walks the list of its cell —
+// a handful of entries — and compares indices, so the unordered list gives the ordered answer.
+__global__ __launch_bounds__(256) void merge_link_kernel(const int32_t* __restrict__ moved, const int32_t* __restrict__ prev, const uint8_t* __restrict__ matched,
+                                                         const int32_t* __restrict__ age_prev, int n, int nr, int nc, int spacing, int gr, int gc,
+                                                         int32_t* __restrict__ head, int32_t* __restrict__ next, int32_t* __restrict__ age_now, int32_t* __restrict__ cell_of) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int r = moved[2 * i], c = moved[2 * i + 1], age = age_prev[i];
+  if (matched[i]) {
+    if (r >= 0 && c >= 0 && r < nr && c < nc) age++;        // keypoint_container::move (:51)
+    else { age = 0; r = prev[2 * i]; c = prev[2 * i + 1]; } // remove (:52): dies where it was
+  } else { r = prev[2 * i]; c = prev[2 * i + 1]; }
+  const int cell = min(max(r / spacing, 0), gr - 1) * gc + min(max(c / spacing, 0), gc - 1);
+  age_now[i] = age; cell_of[i] = cell;
+  next[i] = atomicExch(&head[cell], i);
+}
+__global__ __launch_bounds__(256) void merge_fate_kernel(int n, const int32_t* __restrict__ head, const int32_t* __restrict__ next, const int32_t* __restrict__ age_now,
+                                                         const int32_t* __restrict__ cell_of, uint8_t* __restrict__ removed) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int a = age_now[i];
+  int E = -1, L = -1;  // ages are >= 0
+  bool earlier = false;
+  for (int j = head[cell_of[i]]; j >= 0; j = next[j]) {
+    if (j < i) { earlier = true; E = max(E, age_now[j]); }
+    else if (j > i) L = max(L, age_now[j]);
+  }
+  removed[i] = (earlier && a <= E) ? (a < E) : (L > a);
+}
+
+extern "C" int vpp_keypoint_merge(const int32_t* rc_moved, const int32_t* rc_prev, const uint8_t* matched, const int32_t* age_prev, int n,
+                                  int nrows, int ncols, int spacing, uint8_t* removed, void* stream) {
+  VPP_REQUIRE(n >= 0 && nrows > 0 && ncols > 0 && spacing > 0 && (n == 0 || (rc_moved && rc_prev && matched && age_prev && removed)), VPP_ERR_INVALID_ARG,
+              "vpp_keypoint_merge: invalid argument");
+  if (n == 0) return VPP_OK;
+  const int gr = nrows / spacing + 1, gc = ncols / spacing + 1;  // the reference's idx image is (nrows/s) x (ncols/s) with border 1 (:63-64)
+  const size_t cells = (size_t)gr * gc;
+  static thread_local Scratch scratch;  // per host thread, like the FAST / flow scratch
+  hipStream_t st = as_stream(stream);
+  size_t want = 1 << 20;  // grown in powers of two: the keypoint count creeps up at every re-detection
+  while (want < (cells + 3 * (size_t)n) * sizeof(int32_t)) want <<= 1;
+  const int rc = scratch.ensure(want, st);
+  if (rc != VPP_OK) return rc;
+  int32_t *head = (int32_t*)scratch.p, *next = head + cells, *age_now = next + n, *cell_of = age_now + n;
+  VPP_HIP_TRY(hipMemsetAsync(head, 0xFF, cells * sizeof(int32_t), st));
+  merge_link_kernel<<<(n + 255) / 256, 256, 0, st>>>(rc_moved, rc_prev, matched, age_prev, n, nrows, ncols, spacing, gr, gc, head, next, age_now, cell_of);
+  merge_fate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, head, next, age_now, cell_of, removed);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
 extern "C" int vpp_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in, void* stream) {
   VPP_REQUIRE(valid_desc(out) && valid_desc(in) && same_domain(out, in), VPP_ERR_INVALID_ARG, "vpp_lbp_transform: invalid descriptors / domain mismatch");
   VPP_REQUIRE(out->dtype == VPP_U8 && out->channels == 1 && in->dtype == VPP_U8 && in->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_lbp_transform: u8 x1 only");

@@ -1,6 +1,7 @@
 // video_extruder.hh — semi-dense keypoint tracker (reference: vpp/algorithms/video_extruder.hh:10-44,
 // video_extruder/video_extruder.hpp:24-135).  Flow, FAST scores and FAST re-detection run on the device; the keypoint
-// bookkeeping (merge, cull, trajectories) stays on the host as in the reference.
+// merge (which particles converged to the same cell) is decided on the device; applying it, the cull and the trajectories stay on
+// the host as in the reference.
 #pragma once
 #include <chrono>
 #include <vector>
@@ -41,42 +42,33 @@ void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>
   const int max_trajectory_length = opts.get(_max_trajectory_length, 15), nscales = opts.get(_nscales, 3), winsize = opts.get(_winsize, 9);
   const int regularisation_niters = opts.get(_propagation, 2);
 
-  // One device submission per update: the flow, then the FAST scores of the keypoints where the match callback is about to
-  // leave them (:44-56, :87-91), one wait.  The cull itself happens after the merge, in the reference's order.
+  // One device submission per update: the flow, then — on the keypoints as the match callback is about to leave them — the
+  // merge of particles that converged to the same cell (:60-84) and the FAST scores (:87-91); one wait.  The host then
+  // applies move / remove per keypoint in one pass (the three loops of the reference only interact through `age`, which the
+  // merge kernel reconstructs; the index log replays to the same image whether a removal follows its own move or all moves).
   const int n = ctx.keypoints.size();
-  device::hbuf<int> scores(n);
+  ctx.keypoints.prepare_matching();
   if (n) {
-    ve_internals::stopwatch sw(ve_internals::timing().flow);
-    ctx.keypoints.prepare_matching();
-    const of_internals::flow_params fp{winsize, nscales, 0, regularisation_niters, 5};
+    device::hbuf<int> scores(n), ages(n);
+    device::hbuf<unsigned char> merged(n);
     of_internals::flow_buffers b(n);
-    of_internals::run(ve_internals::position_view{&ctx}, frame1, frame2, fp, b, [&] {
-      const vpp_image_desc d2 = frame2.device_desc(false);
-      device::check(vpp_fast9_scores_moved(&d2, detector_th, (const int32_t*)b.pos.data(), (const int32_t*)b.dk.p, n, scores.data(), device::stream()),
-                    "vpp_fast9_scores_moved");
-    });
-    of_internals::stopwatch swc(of_internals::timing()[3]);
-    for (int i = 0; i < n; i++)
-      if (b.valid[i]) { if (frame1.has(b.pos[i])) ctx.keypoints.move(i, b.pos[i]); else ctx.keypoints.remove(i); }
-  } else ctx.keypoints.prepare_matching();
-  {  // merge particles that converged to the same cell, keep the older (:60-84)
-    ve_internals::stopwatch sw(ve_internals::timing().merge);
-    image2d<int> idx(frame2.domain().nrows() / keypoint_spacing, frame2.domain().ncols() / keypoint_spacing, _border = 1);
-    fill_with_border(idx, -1);
-    char* const base = (char*)&idx(0, 0); const ptrdiff_t pitch = idx.pitch();  // host-only scratch: skip the per-access mirror checks
-    for (int i = 0; i < ctx.keypoints.size(); i++) {
-      const vint2 pos = ctx.keypoints[i].position / keypoint_spacing;
-      int& champion = *(int*)(base + pos[0] * pitch + pos[1] * (ptrdiff_t)sizeof(int));
-      if (champion >= 0) {
-        const auto other = ctx.keypoints[champion];
-        if (other.age < ctx.keypoints[i].age) { ctx.keypoints.remove(champion); champion = i; }
-        if (other.age > ctx.keypoints[i].age) ctx.keypoints.remove(i);
-      } else champion = i;
+    {
+      ve_internals::stopwatch sw(ve_internals::timing().flow);
+      for (int i = 0; i < n; i++) ages[i] = ctx.keypoints[i].age;
+      const of_internals::flow_params fp{winsize, nscales, 0, regularisation_niters, 5};
+      of_internals::run(ve_internals::position_view{&ctx}, frame1, frame2, fp, b, [&] {
+        const vpp_image_desc d2 = frame2.device_desc(false);
+        device::check(vpp_keypoint_merge((const int32_t*)b.pos.data(), (const int32_t*)b.dk.p, b.valid.data(), ages.data(), n, frame2.nrows(), frame2.ncols(),
+                                         keypoint_spacing, merged.data(), device::stream()), "vpp_keypoint_merge");
+        device::check(vpp_fast9_scores_moved(&d2, detector_th, (const int32_t*)b.pos.data(), (const int32_t*)b.dk.p, n, scores.data(), device::stream()),
+                      "vpp_fast9_scores_moved");
+      });
     }
-  }
-  {  // drop points whose FAST score fell below 3 (:87-91)
-    ve_internals::stopwatch sw(ve_internals::timing().scores);
-    for (int i = 0; i < n; i++) if (scores[i] < 3) ctx.keypoints.remove(i);
+    ve_internals::stopwatch sw(ve_internals::timing().merge);
+    for (int i = 0; i < n; i++) {
+      if (b.valid[i]) { if (frame1.has(b.pos[i])) ctx.keypoints.move(i, b.pos[i]); else ctx.keypoints.remove(i); }  // :50-53
+      if (merged[i] || scores[i] < 3) ctx.keypoints.remove(i);                                                        // :60-84, :87-91
+    }
   }
   if (!(ctx.frame_id % detector_period)) {  // re-detect away from the live keypoints (:94-119)
     ve_internals::stopwatch sw(ve_internals::timing().redetect);
