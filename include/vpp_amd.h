@@ -120,6 +120,13 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
                      int compat, int32_t* out_rc, int32_t* out_scores, int capacity, int* count, void* stream);
 /* fast9_scores (fast.hpp:643-652): n (row,col) pairs in device memory -> n int32 full scores. */
 int vpp_fast9_scores(const vpp_image_desc* src, int th, const int32_t* rc, int n, int32_t* out_scores, void* stream);
+/* FAST_internals::fast_detector9(A, B, th) (fast.hpp:511-551): dst(r,c) = 1 where 9 contiguous pixels of the TRUE 16-pixel
+ * ring are all > src + th or all < src - th (plain int compares, fast9_check_code fast.hpp:25-35), else 0.  src u8 x1 with
+ * border >= 3, dst u8 or int32 x1, same domain. */
+int vpp_fast9_dense(const vpp_image_desc* dst, const vpp_image_desc* src, int th, void* stream);
+/* blockwise_maxima_filter(A, block_size) (fast.hpp:577-614), in place on a scalar image: per block_size x block_size block
+ * (clipped to the domain) only the first strict maximum > 0 in row-major order survives, every other pixel becomes 0. */
+int vpp_blockwise_maxima_filter(const vpp_image_desc* img, int block_size, void* stream);
 /* The score cull of video_extruder_update (video_extruder/video_extruder.hpp:44-56,87-91) queued behind the flow instead of
  * after a host round trip: keypoint i is scored at rc_moved[i] when that lies inside src's domain (the match callback moved it
  * there), else at rc_prev[i] (the callback removed it, or never ran: its position is unchanged).  All three arrays are

@@ -788,4 +788,68 @@ int orc_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in) {
   return VPP_OK;
 }
 
+// FAST_internals::fast_detector9(A, B, th) (fast.hpp:511-551) with fast9_check_code (fast.hpp:25-35), restated literally: the
+// 2-bit codes of the 16 TRUE ring pixels at the reference's bit positions, doubled to 64 bits, and-shifted by 8, 4, 2 and 2.
+int orc_fast9_dense(const vpp_image_desc* out, const vpp_image_desc* in, int th) {
+  Img o(out), a(in);
+  if (a.dtype != VPP_U8 || a.ch != 1 || o.ch != 1 || (o.dtype != VPP_U8 && o.dtype != VPP_I32)) return VPP_ERR_UNSUPPORTED;
+  if (o.nr != a.nr || o.nc != a.nc) return VPP_ERR_INVALID_ARG;
+  if (a.border < 3) return VPP_ERR_BORDER_TOO_SMALL;
+  static const int pos[16][3] = {{3, -1, 20}, {3, 0, 18}, {3, 1, 16}, {2, -2, 22}, {2, 2, 14}, {1, -3, 24}, {1, 3, 12}, {0, -3, 26},
+                                 {0, 3, 10}, {-1, -3, 28}, {-1, 3, 8}, {-2, -2, 30}, {-2, 2, 6}, {-3, -1, 0}, {-3, 0, 2}, {-3, 1, 4}};
+  for (int r = 0; r < a.nr; r++)
+    for (int c = 0; c < a.nc; c++) {
+      const int v = a.row<uint8_t>(r)[c];
+      unsigned x = 0;
+      for (int k = 0; k < 16; k++) {
+        const int n = a.row<uint8_t>(r + pos[k][0])[c + pos[k][1]];
+        const unsigned f = (unsigned)(((n > v + th) << 1) ^ (n < v - th));  // fast.hpp:518
+        x += f << pos[k][2];
+      }
+      uint64_t code48 = x;
+      code48 |= code48 << 32;
+      code48 &= code48 << 8;
+      code48 &= code48 << 4;
+      code48 &= code48 << 2;
+      const bool corner = (code48 & (code48 << 2)) != 0;
+      if (o.dtype == VPP_U8) o.row<uint8_t>(r)[c] = corner; else o.row<int32_t>(r)[c] = corner;
+    }
+  return VPP_OK;
+}
+
+// blockwise_maxima_filter (fast.hpp:577-614), in place.  PARITY UNPINNED: the reference template does not compile when
+// instantiated (it stores &A(r + i, 0) of a const image into V* rows[], fast.hpp:590), so no reference output exists for it.
+extern "C++" {
+template <class V> static void blockwise_maxima_t(Img a, int bs) {
+  for (int r = 0; r < a.nr; r += bs)
+    for (int c = 0; c < a.nc; c += bs) {
+      int pr = 0, pc = 0; V vmax = 0;
+      for (int br = 0; br < bs; br++)
+        for (int bc = c; bc < c + bs; bc++)
+          if (r + br < a.nr && bc < a.nc) {
+            const V v = a.row<V>(r + br)[bc];
+            a.row<V>(r + br)[bc] = 0;
+            if (v > vmax) { vmax = v; pr = br; pc = bc; }
+          }
+      if (vmax > 0) a.row<V>(r + pr)[pc] = vmax;
+    }
+}
+}  // extern "C++"
+int orc_blockwise_maxima_filter(const vpp_image_desc* img, int bs) {
+  Img a(img);
+  if (a.ch != 1) return VPP_ERR_UNSUPPORTED;
+  if (bs <= 0) return VPP_ERR_INVALID_ARG;
+  switch (a.dtype) {
+    case VPP_U8: blockwise_maxima_t<uint8_t>(a, bs); break;
+    case VPP_I8: blockwise_maxima_t<int8_t>(a, bs); break;
+    case VPP_U16: blockwise_maxima_t<uint16_t>(a, bs); break;
+    case VPP_I16: blockwise_maxima_t<int16_t>(a, bs); break;
+    case VPP_I32: blockwise_maxima_t<int32_t>(a, bs); break;
+    case VPP_U32: blockwise_maxima_t<uint32_t>(a, bs); break;
+    case VPP_F32: blockwise_maxima_t<float>(a, bs); break;
+    default: return VPP_ERR_UNSUPPORTED;
+  }
+  return VPP_OK;
+}
+
 }  // extern "C"

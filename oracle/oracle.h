@@ -53,6 +53,10 @@ int orc_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int 
 
 /* vpp/algorithms/lbp/lbp_transform.hh:6-38 */
 int orc_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in);
+/* fast_detector/fast.hpp:511-551 (dense detector on the true ring, fast9_check_code :25-35) */
+int orc_fast9_dense(const vpp_image_desc* out, const vpp_image_desc* in, int th);
+/* fast_detector/fast.hpp:577-614 (in place) */
+int orc_blockwise_maxima_filter(const vpp_image_desc* img, int block_size);
 
 #ifdef __cplusplus
 }

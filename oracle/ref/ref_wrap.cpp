@@ -253,5 +253,16 @@ int ref_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in) {
   return 0;
 }
 
+// FAST_internals::fast_detector9(A, B, th) (vpp/algorithms/fast_detector/fast.hpp:511-551)
+// (blockwise_maxima_filter, fast.hpp:577-614, cannot be wrapped: instantiating it fails to compile — it takes `const image2d<V>&`
+// and stores `&A(r + i, 0)` into `V* rows[]`, fast.hpp:590 — so the reference never ran it; the oracle restatement of it is unpinned.)
+int ref_fast9_dense(const vpp_image_desc* out, const vpp_image_desc* in, int th) {
+  if (!is(in, VPP_U8, 1)) return VPP_ERR_UNSUPPORTED;
+  auto A = wrap<unsigned char>(in);
+  if (is(out, VPP_U8, 1)) { auto B = wrap<unsigned char>(out); FAST_internals::fast_detector9(A, B, th); return 0; }
+  if (is(out, VPP_I32, 1)) { auto B = wrap<int>(out); FAST_internals::fast_detector9(A, B, th); return 0; }
+  return VPP_ERR_UNSUPPORTED;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

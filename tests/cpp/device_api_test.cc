@@ -266,8 +266,29 @@ static void test_lbp() {                                                    // t
   CHECK(lbp_hamming_distance(0b01010101, 0b01010101) == 0 && lbp_hamming_distance(0b11010101, 0b01010101) == 1 && lbp_hamming_distance(0b11111111, 0b00000000) == 8);
 }
 
+// FAST_internals::fast_detector9(A, B, th) (fast.hpp:511-551) and blockwise_maxima_filter (fast.hpp:577-614) through the headers
+static void test_dense_fast_and_blockwise_maxima() {
+  image2d<unsigned char> A(40, 50, _border = 3);
+  fill_with_border(A, (unsigned char)10);
+  for (int r = 10; r < 30; r++) for (int c = 15; c < 35; c++) A(r, c) = 200;   // a bright square: its four corners are FAST-9 corners
+  image2d<unsigned char> B(A.domain());
+  FAST_internals::fast_detector9(A, B, 20);
+  CHECK(B(10, 15) == 1 && B(29, 34) == 1 && B(10, 34) == 1 && B(29, 15) == 1);
+  CHECK(B(20, 25) == 0 && B(0, 0) == 0 && B(10, 25) == 0);                     // inside, far away, on a straight edge
+  auto kps = fast9(A, 20, _fast9_corrected_ring);                             // the sparse detector on the same (true) ring agrees
+  int flagged = 0; for (auto p : B.domain()) flagged += B(p);
+  CHECK(flagged == int(kps.size()));
+  for (auto p : kps) CHECK(B(p) == 1);
+  image2d<int> S(20, 20);
+  fill(S, 0);
+  S(3, 4) = 7; S(5, 5) = 7; S(2, 2) = 3; S(12, 13) = 2; S(15, 3) = -4;
+  blockwise_maxima_filter(S, 10);
+  CHECK(S(3, 4) == 7 && S(5, 5) == 0 && S(2, 2) == 0 && S(12, 13) == 2 && S(15, 3) == 0);
+}
+
 int main() {
   CHECK(vpp_init(0) == 0);
+  test_dense_fast_and_blockwise_maxima();
   test_lbp();
   test_frame_ingest();
   test_pixel_wise_functors();

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import golden_cases as gc  # noqa: E402
 from oracle import binding  # noqa: E402
-from util import P  # noqa: E402
+from util import P, HostImage  # noqa: E402
 from vpp_amd import image as vi  # noqa: E402
 
 ref = binding.load_ref()
@@ -67,6 +67,16 @@ rgb, g1, rgba, g2 = gc.ingest_case()
 assert ref.ref_rgb_to_graylevel(P(g1.desc), P(rgb.desc), 1) == 0
 assert ref.ref_rgb_to_graylevel(P(g2.desc), P(rgba.desc), 0) == 0
 out["ingest"] = dict(in_crc=crc(rgb.raw, rgba.raw), gray_mirror=g1.view(with_border=True).copy(), gray_rgba=g2.view(with_border=True).copy())
+
+# dense FAST_internals::fast_detector9(A, B, th)
+fim, ths = gc.fast_dense_case()
+dense = {}
+for th in ths:
+    o8, o32 = HostImage(fim.nrows, fim.ncols, vi.U8, 1), HostImage(fim.nrows, fim.ncols, vi.I32, 1)
+    assert ref.ref_fast9_dense(P(o8.desc), P(fim.desc), th) == 0 and ref.ref_fast9_dense(P(o32.desc), P(fim.desc), th) == 0
+    assert (o8.view()[..., 0] == o32.view()[..., 0]).all()
+    dense["th_%d" % th] = np.packbits(o8.view()[..., 0].astype(bool), axis=1)
+out["fast_dense"] = dict(in_crc=crc(fim.raw), **dense)
 
 for name, d in out.items():
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)

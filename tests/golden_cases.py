@@ -60,3 +60,8 @@ def ingest_case():
     rgb = rand_image(45, 70, vi.U8, 3, border=0, seed=21)
     rgba = rand_image(33, 52, vi.U8, 4, border=2, seed=22, fill_border=True)
     return rgb, HostImage(45, 70, vi.U8, 1, 3), rgba, HostImage(33, 52, vi.U8, 1, 2)
+
+
+def fast_dense_case():
+    """FAST_internals::fast_detector9(A, B, th) on the FAST fixture; thresholds incl. 0 and a negative one (plain int compares)."""
+    return fast_case(), (20, 7, 0, -3)

@@ -8,7 +8,7 @@ import pytest
 
 import golden_cases as gc
 import pyr
-from util import P, DeviceImage
+from util import P, DeviceImage, HostImage
 from vpp_amd import image as vi
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -82,6 +82,17 @@ def test_oracle_ingest(orc):
     np.testing.assert_array_equal(g1.view(with_border=True), g["gray_mirror"]); np.testing.assert_array_equal(g2.view(with_border=True), g["gray_rgba"])
 
 
+def test_oracle_fast_dense(orc):
+    fim, ths = gc.fast_dense_case(); g = load("fast_dense")
+    assert gc.crc(fim.raw) == g["in_crc"]
+    for th in ths:
+        for dt in (vi.U8, vi.I32):
+            o = HostImage(fim.nrows, fim.ncols, dt, 1)
+            assert orc.orc_fast9_dense(P(o.desc), P(fim.desc), th) == 0
+            np.testing.assert_array_equal(np.packbits(o.view()[..., 0].astype(bool), axis=1), g["th_%d" % th])
+    assert 0 < np.unpackbits(g["th_20"]).sum() < np.unpackbits(g["th_0"]).sum()
+
+
 # ---------------- GPU: HIP path == reference golden ----------------
 @pytest.mark.gpu
 def test_gpu_matches_reference_golden(lib):
@@ -129,6 +140,13 @@ def test_gpu_matches_reference_golden(lib):
     capi.check(lib.vpp_semi_dense_optical_flow(P(ds1.desc), P(ds2.desc), V(dk.data_ptr()), n, *par,
                                                V(gp.data_ptr()), V(gd.data_ptr()), V(gv.data_ptr()), st))
     np.testing.assert_array_equal(gp.cpu().numpy(), g["pos"]); np.testing.assert_array_equal(gd.cpu().numpy(), g["dist"]); np.testing.assert_array_equal(gv.cpu().numpy(), g["valid"])
+    fim, ths = gc.fast_dense_case(); g = load("fast_dense")
+    dfim = DeviceImage.from_host(fim)
+    for th in ths:
+        for dt in (vi.U8, vi.I32):
+            do = DeviceImage(fim.nrows, fim.ncols, dt, 1)
+            capi.check(lib.vpp_fast9_dense(P(do.desc), P(dfim.desc), th, st))
+            np.testing.assert_array_equal(np.packbits(do.download().view()[..., 0].astype(bool), axis=1), g["th_%d" % th])
     rgb, g1, rgba, g2 = gc.ingest_case(); g = load("ingest")
     drgb, dg1, drgba, dg2 = DeviceImage.from_host(rgb), DeviceImage.from_host(g1), DeviceImage.from_host(rgba), DeviceImage.from_host(g2)
     capi.check(lib.vpp_rgb_to_graylevel(P(dg1.desc), P(drgb.desc), 1, st)); capi.check(lib.vpp_rgb_to_graylevel(P(dg2.desc), P(drgba.desc), 0, st))

@@ -151,3 +151,61 @@ def test_keypoint_merge_matches_the_serial_champion_loop(lib, n, nr, nc, spacing
                                           ctypes.c_void_p(da.data_ptr()), n, nr, nc, spacing, ctypes.c_void_p(out.data_ptr()), capi.stream_ptr()))
         np.testing.assert_array_equal(out.cpu().numpy(), want)
     assert lib.vpp_keypoint_merge(None, None, None, None, 5, nr, nc, spacing, None, None) == capi.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("shape,th,border", [((30, 41), 20, 3), ((64, 64), 5, 3), ((7, 9), 0, 4), ((50, 33), -2, 3), ((129, 200), 12, 5), ((1, 1), 3, 3)])
+def test_fast9_dense_matches_oracle(lib, orc, shape, th, border):
+    from util import rects_image, u8_image
+    src = u8_image(rects_image(*shape, seed=shape[0] + th), border=border)
+    src.view(with_border=True)[..., 0] = np.pad(src.view()[..., 0], border, mode="symmetric")
+    ds = DeviceImage.from_host(src)
+    for dt in (vi.U8, vi.I32):
+        want = HostImage(*shape, dt, 1)
+        assert orc.orc_fast9_dense(P(want.desc), P(src.desc), th) == 0
+        out = DeviceImage(*shape, dt, 1, border=1)
+        capi.check(lib.vpp_fast9_dense(P(out.desc), P(ds.desc), th, capi.stream_ptr()))
+        np.testing.assert_array_equal(out.download().view(), want.view())
+    small = DeviceImage(*shape, vi.U8, 1, border=2)
+    assert lib.vpp_fast9_dense(P(out.desc), P(small.desc), th, None) == capi.ERR_BORDER_TOO_SMALL
+
+
+def test_fast9_dense_4k_is_the_corrected_ring_detector(lib):
+    """Size-independent property at the BASELINE frame size: the dense flags are exactly the keypoints vpp_fast9_detect reports
+    on the true ring (compat = corrected, raw mode, no mask) — two independent kernels, one definition (fast.hpp:84-112)."""
+    from util import rects_image, u8_image
+    from test_gpu_algos import gpu_detect
+    src = u8_image(rects_image(2160, 3840, seed=31), border=3)
+    src.view(with_border=True)[..., 0] = np.pad(src.view()[..., 0], 3, mode="symmetric")
+    ds = DeviceImage.from_host(src)
+    out = DeviceImage(2160, 3840, vi.U8, 1)
+    capi.check(lib.vpp_fast9_dense(P(out.desc), P(ds.desc), 20, capi.stream_ptr()))
+    flags = out.download().view()[..., 0]
+    rc, _ = gpu_detect(lib, ds, 20, mode=0, bs=10, compat=1, cap=4000000)
+    assert len(rc) > 10000
+    want = np.zeros((2160, 3840), np.uint8)
+    want[rc[:, 0], rc[:, 1]] = 1
+    np.testing.assert_array_equal(flags, want)
+
+
+@pytest.mark.parametrize("dtype", [vi.U8, vi.I8, vi.U16, vi.I16, vi.I32, vi.U32, vi.F32])
+@pytest.mark.parametrize("shape,bs", [((20, 30), 10), ((23, 31), 10), ((9, 9), 4), ((5, 40), 7), ((16, 16), 1), ((70, 300), 300)])
+def test_blockwise_maxima_filter_matches_oracle(lib, orc, dtype, shape, bs):
+    signed = dtype in (vi.I8, vi.I16, vi.I32, vi.F32)
+    img = rand_image(*shape, dtype, 1, border=2, seed=bs + shape[1], lo=-3 if signed else 0, hi=6, fill_border=True)
+    d = DeviceImage.from_host(img)
+    assert orc.orc_blockwise_maxima_filter(P(img.desc), bs) == 0
+    capi.check(lib.vpp_blockwise_maxima_filter(P(d.desc), bs, capi.stream_ptr()))
+    np.testing.assert_array_equal(d.download().view(with_border=True), img.view(with_border=True))  # the border is not touched
+
+
+def test_blockwise_maxima_filter_4k_properties(lib):
+    img = rand_image(2160, 3840, vi.U8, 1, seed=8)
+    a = img.view()[..., 0].copy()
+    d = DeviceImage.from_host(img)
+    capi.check(lib.vpp_blockwise_maxima_filter(P(d.desc), 10, capi.stream_ptr()))
+    once = d.download().view()[..., 0].copy()
+    blocks = once.reshape(216, 10, 384, 10)
+    assert ((blocks != 0).sum(axis=(1, 3)) <= 1).all()                                          # at most one survivor per block
+    np.testing.assert_array_equal(blocks.max(axis=(1, 3)), a.reshape(216, 10, 384, 10).max(axis=(1, 3)))  # and it is the block maximum
+    capi.check(lib.vpp_blockwise_maxima_filter(P(d.desc), 10, capi.stream_ptr()))
+    np.testing.assert_array_equal(d.download().view()[..., 0], once)                            # idempotent

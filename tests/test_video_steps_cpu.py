@@ -81,3 +81,36 @@ def test_lbp_oracle_is_the_reference(orc, ref, shape, border):
     for k, (dr, dc) in enumerate([(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]):
         want += (s[bb + dr:bb + dr + shape[0], bb + dc:bb + dc + shape[1]] > c) << k
     np.testing.assert_array_equal(b.view()[..., 0], want.astype(np.uint8))
+
+
+@pytest.mark.parametrize("shape,th,border", [((30, 41), 20, 3), ((64, 64), 5, 3), ((7, 9), 0, 4), ((50, 33), -2, 3), ((40, 70), 300, 3)])
+def test_fast9_dense_oracle_is_the_reference(orc, ref, shape, th, border):
+    """FAST_internals::fast_detector9(A, B, th) (fast.hpp:511-551): restatement == the reference template, u8 and int outputs."""
+    from util import rects_image, u8_image
+    src = u8_image(rects_image(*shape, seed=shape[0] + th), border=border)
+    src.view(with_border=True)[..., 0] = np.pad(src.view()[..., 0], border, mode="symmetric")
+    for dt in (vi.U8, vi.I32):
+        a, b = HostImage(*shape, dt, 1), HostImage(*shape, dt, 1)
+        assert ref.ref_fast9_dense(P(a.desc), P(src.desc), th) == 0
+        assert orc.orc_fast9_dense(P(b.desc), P(src.desc), th) == 0
+        np.testing.assert_array_equal(a.view(), b.view())
+        assert set(np.unique(b.view())) <= {0, 1}
+    small = HostImage(*shape, vi.U8, 1, 2)
+    assert orc.orc_fast9_dense(P(b.desc), P(small.desc), th) != 0  # the ring needs a border of 3
+
+
+@pytest.mark.parametrize("dtype", [vi.U8, vi.I32, vi.F32, vi.I16])
+@pytest.mark.parametrize("shape,bs", [((20, 30), 10), ((23, 31), 10), ((9, 9), 4), ((5, 40), 7), ((16, 16), 1)])
+def test_blockwise_maxima_filter_oracle(orc, dtype, shape, bs):
+    """fast.hpp:577-614 against an independent numpy statement: per block, zero everything but the first strict maximum > 0."""
+    img = rand_image(*shape, dtype, 1, border=1, seed=bs + shape[1], lo=-3 if dtype in (vi.I32, vi.F32, vi.I16) else 0, hi=6)
+    a = img.view()[..., 0].copy()
+    assert orc.orc_blockwise_maxima_filter(P(img.desc), bs) == 0
+    want = np.zeros_like(a)
+    for r in range(0, shape[0], bs):
+        for c in range(0, shape[1], bs):
+            blk = a[r:r + bs, c:c + bs]
+            if blk.max() > 0:
+                k = int(np.argmax(blk))  # first occurrence of the maximum in row-major order
+                want[r + k // blk.shape[1], c + k % blk.shape[1]] = blk.max()
+    np.testing.assert_array_equal(img.view()[..., 0], want)

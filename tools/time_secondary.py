@@ -58,3 +58,13 @@ for (nr, nc) in ((1080, 1920), (2160, 3840)):
     us = time_graph(lambda i, s: lib.vpp_copy(P(c[i % ns].desc), P(d[i % ns].desc), 0, s)); print(f"copy u8 {nr}x{nc}: {us:.2f} us  ({nr * nc * 2 / us / 1e3:.1f} GB/s)")
     gn = [DeviceImage(1 + nr // 2, 1 + nc // 2, vi.F32, 2, 3) for _ in range(ns)]
     us = time_graph(lambda i, s: lib.vpp_pyr_down(P(gn[i % ns].desc), P(g[i % ns].desc), s)); print(f"pyr_down f32x2 {nr}x{nc}: {us:.2f} us  ({nr * nc * 8 * 1.25 / us / 1e3:.1f} GB/s)")
+# dense FAST flags and the blockwise maxima filter at 4K
+from util import rects_image, u8_image
+import numpy as np
+fim = u8_image(rects_image(NR, NC, seed=31), border=3)
+fim.view(with_border=True)[..., 0] = np.pad(fim.view()[..., 0], 3, mode="symmetric")
+fd = [DeviceImage.from_host(fim) for _ in range(ns)]; fo = [DeviceImage(NR, NC, vi.U8, 1) for _ in range(ns)]
+us = time_graph(lambda i, s: lib.vpp_fast9_dense(P(fo[i % ns].desc), P(fd[i % ns].desc), 20, s)); print(f"fast9_dense u8 4K: {us:.2f} us  ({NR * NC * 2 / us / 1e3:.1f} GB/s, {NR * NC / us / 1e3:.1f} Gpx/s)")
+us = time_graph(lambda i, s: lib.vpp_blockwise_maxima_filter(P(fd[i % ns].desc), 10, s)); print(f"blockwise_maxima_filter u8 4K bs 10: {us:.2f} us  ({NR * NC * 2 / us / 1e3:.1f} GB/s)")
+lb = [DeviceImage(NR, NC, vi.U8, 1) for _ in range(ns)]
+us = time_graph(lambda i, s: lib.vpp_lbp_transform(P(lb[i % ns].desc), P(fd[i % ns].desc), s)); print(f"lbp_transform u8 4K: {us:.2f} us  ({NR * NC * 2 / us / 1e3:.1f} GB/s)")

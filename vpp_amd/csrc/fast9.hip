@@ -445,6 +445,46 @@ __global__ __launch_bounds__(256) void fast9_write_blocks_kernel(const uint2* __
   }
 }
 
+// ---- FAST_internals::fast_detector9(A, B, th) (fast.hpp:511-551): dense corner flags on the TRUE ring, plain int compares ----
+// (a > v + th) / (a < v - th) without saturation; the reference's 2-bit interleaved code + fast9_check_code (fast.hpp:25-35) is
+// "9 contiguous of 16, circular" on each plane, which is what nine_contiguous tests on the two 16-bit masks.
+template <class U>
+__global__ __launch_bounds__(256) void fast9_dense_kernel(DImg B, DImg A, int th) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (c >= A.nc || r >= A.nr) return;
+  const uint8_t* p = A.row<uint8_t>(r) + c;
+  const int v = p[0], hi = v + th, lo = v - th;
+  uint32_t mb = 0, md = 0;
+#pragma unroll
+  for (int i = 15; i >= 0; i--) {
+    const int a = p[(ptrdiff_t)ring_dr<false>(i) * A.pitch + ring_dc(i)];
+    mb = push_sign(mb, hi - a);  // a > v + th
+    md = push_sign(md, a - lo);  // a < v - th
+  }
+  B.row<U>(r)[c] = (U)((nine_contiguous(mb) || nine_contiguous(md)) ? 1 : 0);
+}
+
+// ---- blockwise_maxima_filter(A, block_size) (fast.hpp:577-614), in place: every pixel of a block is zeroed, then the FIRST
+// strict maximum (> 0, row-major scan of the block) is written back.  One thread per block.
+template <class V>
+__global__ __launch_bounds__(256) void blockwise_maxima_kernel(DImg A, int bs, int nbr, int nbc) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nbr * nbc) return;
+  const int br = b / nbc, bc = b - br * nbc;
+  const int r0 = br * bs, c0 = bc * bs, r1 = min(r0 + bs, A.nr), c1 = min(c0 + bs, A.nc);
+  V vmax = 0; int pr = 0, pc = 0;
+  for (int r = r0; r < r1; r++) {
+    V* row = A.row<V>(r);
+    for (int c = c0; c < c1; c++) {
+      const V v = row[c];
+      row[c] = 0;
+      if (v > vmax) { vmax = v; pr = r; pc = c; }
+    }
+  }
+  if (vmax > 0) A.row<V>(pr)[pc] = vmax;
+}
+
 thread_local Scratch g_scratch;
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -459,6 +499,40 @@ int vpp_fast9_scores(const vpp_image_desc* src, int th, const int32_t* rc, int n
   VPP_REQUIRE(src->border >= 3, VPP_ERR_BORDER_TOO_SMALL, "Image need a border of 3px at least for the FAST detector");
   if (n == 0) return VPP_OK;
   fast9_scores_list_kernel<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(dimg(src), th, rc, n, out_scores);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+int vpp_fast9_dense(const vpp_image_desc* dst, const vpp_image_desc* src, int th, void* stream) {
+  VPP_REQUIRE(valid_desc(dst) && valid_desc(src) && same_domain(dst, src), VPP_ERR_INVALID_ARG, "vpp_fast9_dense: invalid descriptors / domain mismatch");
+  VPP_REQUIRE(src->dtype == VPP_U8 && src->channels == 1 && dst->channels == 1 && (dst->dtype == VPP_U8 || dst->dtype == VPP_I32), VPP_ERR_UNSUPPORTED,
+              "vpp_fast9_dense: u8 x1 source, u8 or int32 x1 destination");
+  VPP_REQUIRE(src->border >= 3, VPP_ERR_BORDER_TOO_SMALL, "vpp_fast9_dense: the ring reads 3 px beyond the domain (fast.hpp:520-541), border is %d", src->border);
+  VPP_REQUIRE(th > -(1 << 30) && th < (1 << 30), VPP_ERR_INVALID_ARG, "vpp_fast9_dense: threshold out of range");
+  dim3 grid((src->ncols + 63) / 64, (src->nrows + 3) / 4);
+  if (dst->dtype == VPP_U8) fast9_dense_kernel<uint8_t><<<grid, 256, 0, as_stream(stream)>>>(dimg(dst), dimg(src), th);
+  else fast9_dense_kernel<int32_t><<<grid, 256, 0, as_stream(stream)>>>(dimg(dst), dimg(src), th);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+int vpp_blockwise_maxima_filter(const vpp_image_desc* img, int block_size, void* stream) {
+  VPP_REQUIRE(valid_desc(img) && block_size > 0, VPP_ERR_INVALID_ARG, "vpp_blockwise_maxima_filter: invalid argument");
+  VPP_REQUIRE(img->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_blockwise_maxima_filter: scalar images only");
+  const int nbr = (img->nrows + block_size - 1) / block_size, nbc = (img->ncols + block_size - 1) / block_size;
+  const unsigned grid = (unsigned)(((long long)nbr * nbc + 255) / 256);
+  DImg A = dimg(img);
+  hipStream_t st = as_stream(stream);
+  switch (img->dtype) {
+    case VPP_U8: blockwise_maxima_kernel<uint8_t><<<grid, 256, 0, st>>>(A, block_size, nbr, nbc); break;
+    case VPP_I8: blockwise_maxima_kernel<int8_t><<<grid, 256, 0, st>>>(A, block_size, nbr, nbc); break;
+    case VPP_U16: blockwise_maxima_kernel<uint16_t><<<grid, 256, 0, st>>>(A, block_size, nbr, nbc); break;
+    case VPP_I16: blockwise_maxima_kernel<int16_t><<<grid, 256, 0, st>>>(A, block_size, nbr, nbc); break;
+    case VPP_I32: blockwise_maxima_kernel<int32_t><<<grid, 256, 0, st>>>(A, block_size, nbr, nbc); break;
+    case VPP_U32: blockwise_maxima_kernel<uint32_t><<<grid, 256, 0, st>>>(A, block_size, nbr, nbc); break;
+    case VPP_F32: blockwise_maxima_kernel<float><<<grid, 256, 0, st>>>(A, block_size, nbr, nbc); break;
+    default: VPP_REQUIRE(false, VPP_ERR_UNSUPPORTED, "vpp_blockwise_maxima_filter: unsupported dtype %d", img->dtype);
+  }
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }

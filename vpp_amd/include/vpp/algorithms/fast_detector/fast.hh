@@ -4,6 +4,7 @@
 // fast_detector9_simd samples; the default reproduces the reference.
 #pragma once
 #include <stdexcept>
+#include <type_traits>
 #include <vector>
 #include <vpp/algorithms/device_only.hh>
 #include <vpp/algorithms/symbols.hh>
@@ -61,6 +62,24 @@ template <class V> int fast9_score(const image2d<V>& A, int th, vint2 p) {
   std::vector<vint2> k(1, p); std::vector<int> s;
   fast9_scores(A, th, k, s);
   return s[0];
+}
+
+// Dense detector on the true ring (fast.hpp:511-551): B(p) = 1 where 9 contiguous ring pixels are all brighter than A(p) + th or
+// all darker than A(p) - th, else 0.  A needs a border of 3.
+namespace FAST_internals {
+template <class V, class U> void fast_detector9(const image2d<V>& A, image2d<U>& B, int th) {
+  static_assert(sizeof(V) == 1, "fast_detector9: 8-bit single-channel source");
+  static_assert(std::is_same<U, unsigned char>::value || std::is_same<U, int>::value, "fast_detector9: unsigned char or int flags");
+  const vpp_image_desc da = A.device_desc(false), db = B.device_desc(true, B.border() == 0);
+  device::check(vpp_fast9_dense(&db, &da, th, device::stream()), "vpp_fast9_dense");
+}
+}  // namespace FAST_internals
+
+// blockwise_maxima_filter (fast.hpp:577-614), in place: per block only the first strict maximum > 0 survives.  (The reference
+// declares it on a const image and does not compile when instantiated; it is callable here.)
+template <class V> void blockwise_maxima_filter(const image2d<V>& A, int block_size) {
+  const vpp_image_desc da = A.device_desc(true);
+  device::check(vpp_blockwise_maxima_filter(&da, block_size, device::stream()), "vpp_blockwise_maxima_filter");
 }
 
 // "old API" spellings (fast.hh:41-68)
