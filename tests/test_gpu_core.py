@@ -101,6 +101,44 @@ def test_box_filter_matches_oracle(lib, orc, dtype, ch, R, C, shape, border, ali
     lib.vpp_set_tuning(b"box.rows", -1); lib.vpp_set_tuning(b"box.impl", -1); lib.vpp_set_tuning(b"box.rows32", -1)
 
 
+@pytest.mark.parametrize("R,C", [(3, 3), (3, 5), (5, 3), (7, 3), (7, 5), (3, 7), (5, 7), (7, 7)])
+@pytest.mark.parametrize("ch", [1, 2, 3, 4])
+def test_box_u8_streamed_windows_match_oracle(lib, orc, R, C, ch):
+    """Odd windows up to 7 x 7 on 8-bit images go through the streaming kernel when (C/2) * channels <= 8 halo bytes (else the
+    generic LDS kernel): bit-exact either way; border exactly the reach and larger, ragged widths, all-255 images (largest sums)."""
+    reach = max(R, C) // 2
+    for shape, border, align in (((37, 61), reach, 16), ((23, 1111), reach + 2, 32), ((9, 16), reach, 32), ((2, 3), reach + 1, 16)):
+        src = rand_image(*shape, vi.U8, ch, border=border, seed=R * 10 + C + ch, align=align, fill_border=True)
+        if shape == (9, 16):
+            src.raw[...] = 255
+        want = src.like(border=0)
+        assert orc.orc_box_filter(P(want.desc), P(src.desc), R, C) == 0
+        dsrc = DeviceImage.from_host(src); ddst = DeviceImage.from_host(src.like(border=0))
+        capi.check(lib.vpp_box_filter(P(ddst.desc), P(dsrc.desc), R, C, capi.stream_ptr()))
+        _sync(lib)
+        np.testing.assert_array_equal(ddst.download().raw, want.raw)   # and nothing outside the domain was written
+
+
+def test_box_u8_windows_4k_streamed_equal_generic(lib):
+    """BASELINE frame size: the streamed 3x3 / 7x7 / 5x3 results equal the generic kernel's, and one pixel equals the numpy mean."""
+    src = rand_image(2160, 3840, vi.U8, 3, border=3, seed=12, fill_border=True)
+    dsrc = DeviceImage.from_host(src)
+    s = src.view(with_border=True).astype(np.int64)
+    for R, C in ((3, 3), (5, 3), (7, 5)):
+        outs = []
+        for g in (0, 1):
+            lib.vpp_set_tuning(b"box.force_generic", g)
+            d = DeviceImage.from_host(src.like(border=0))
+            capi.check(lib.vpp_box_filter(P(d.desc), P(dsrc.desc), R, C, capi.stream_ptr()))
+            _sync(lib)
+            outs.append(d.download().view().copy())
+        lib.vpp_set_tuning(b"box.force_generic", 0)
+        np.testing.assert_array_equal(outs[0], outs[1])
+        r, c = 1234, 2345
+        win = s[3 + r - R // 2:3 + r + R // 2 + 1, 3 + c - C // 2:3 + c + C // 2 + 1]
+        np.testing.assert_array_equal(outs[0][r, c], win.sum(axis=(0, 1)) // (R * C))
+
+
 def test_box_int32_4k_matches_generic(lib):
     """The reference's own benchmark type at 4K (box_5x5_filter.cc:187-191: values % 1000): streaming kernel == generic kernel."""
     src = rand_image(2160, 3840, vi.I32, 1, border=2, seed=12, lo=0, hi=999, fill_border=True, align=16)

@@ -68,3 +68,10 @@ us = time_graph(lambda i, s: lib.vpp_fast9_dense(P(fo[i % ns].desc), P(fd[i % ns
 us = time_graph(lambda i, s: lib.vpp_blockwise_maxima_filter(P(fd[i % ns].desc), 10, s)); print(f"blockwise_maxima_filter u8 4K bs 10: {us:.2f} us  ({NR * NC * 2 / us / 1e3:.1f} GB/s)")
 lb = [DeviceImage(NR, NC, vi.U8, 1) for _ in range(ns)]
 us = time_graph(lambda i, s: lib.vpp_lbp_transform(P(lb[i % ns].desc), P(fd[i % ns].desc), s)); print(f"lbp_transform u8 4K: {us:.2f} us  ({NR * NC * 2 / us / 1e3:.1f} GB/s)")
+for (R, C, b) in ((3, 3, 1), (7, 5, 3), (3, 5, 2)):
+    src_h = rand_image(NR, NC, vi.U8, 3, border=b, seed=3, align=16)
+    srcs = [DeviceImage.from_host(src_h) for _ in range(ns)]; dsts = [DeviceImage(NR, NC, vi.U8, 3, 0, 16) for _ in range(ns)]
+    for g in (0, 1):
+        lib.vpp_set_tuning(b"box.force_generic", g)
+        us = time_graph(lambda i, s: lib.vpp_box_filter(P(dsts[i % ns].desc), P(srcs[i % ns].desc), R, C, s)); print(f"box {R}x{C} vuchar3 4K {'generic' if g else 'streamed'}: {us:.2f} us ({2 * NR * NC * 3 / us / 1e3:.0f} GB/s)")
+    lib.vpp_set_tuning(b"box.force_generic", 0)

@@ -58,16 +58,24 @@ template <int Q> __device__ __forceinline__ uint32_t pair_at(const uint32_t* E, 
   else if constexpr (Q % 4 == 2) return __builtin_amdgcn_alignbit(E[m + 1], E[m], 16);
   else return __builtin_amdgcn_alignbit(O[m + 1], O[m], 16);
 }
-template <int Q, int CH> __device__ __forceinline__ uint32_t hsum5(const uint32_t* E, const uint32_t* O) {
-  return pair_at<Q - 2 * CH>(E, O) + pair_at<Q - CH>(E, O) + pair_at<Q>(E, O) + pair_at<Q + CH>(E, O) + pair_at<Q + 2 * CH>(E, O);
+// horizontal sum of KC taps at stride CH around window position Q (packed pairs)
+template <int Q, int CH, int KC = 5, int T = 0> __device__ __forceinline__ uint32_t hsum(const uint32_t* E, const uint32_t* O) {
+  if constexpr (T == KC) return 0u;
+  else return pair_at<Q + (T - KC / 2) * CH>(E, O) + hsum<Q, CH, KC, T + 1>(E, O);
 }
-// q*M with the exact quotient floor(x/25) in byte 3: x * 671089 < 2^32 and floor(x * 671089 / 2^24) == x / 25 for x <= 6375.
-__device__ __forceinline__ uint32_t mul25(uint32_t x) { return (uint32_t)__umul24(x, 671089u); }
-template <int I, int CH> __device__ __forceinline__ uint32_t out_dword(const uint32_t* E, const uint32_t* O) {
+// x * M with the exact quotient floor(x / N) in byte 3, N = window area: M = ceil(2^24 / N); for x <= 255 N the product stays
+// below 2^32 and floor(x M / 2^24) == x / N (checked exhaustively for N = 3, 5, 7, 9, 15, 21, 25, 35, 49; N = 25: 671089).
+template <int N> __device__ __forceinline__ uint32_t mul_div(uint32_t x) {
+  constexpr uint32_t M = ((1u << 24) + N - 1) / N;
+  static_assert((unsigned long long)M * N - (1ull << 24) < (1ull << 24) / (255ull * N), "rounding error of the reciprocal reaches the quotient");
+  static_assert(255ull * N * M < (1ull << 32) && M < (1u << 24), "product overflows");
+  return (uint32_t)__umul24(x, M);
+}
+template <int I, int CH, int KC = 5, int N = 25> __device__ __forceinline__ uint32_t out_dword(const uint32_t* E, const uint32_t* O) {
   // output bytes 4I..4I+3 of the lane's 16 (window positions 8+4I ..)
-  const uint32_t se = hsum5<8 + 4 * I, CH>(E, O);      // sums for bytes (4I, 4I+2)
-  const uint32_t so = hsum5<8 + 4 * I + 1, CH>(E, O);  // sums for bytes (4I+1, 4I+3)
-  const uint32_t qa = mul25(se & 0xFFFFu), qb = mul25(so & 0xFFFFu), qc = mul25(se >> 16), qd = mul25(so >> 16);
+  const uint32_t se = hsum<8 + 4 * I, CH, KC>(E, O);      // sums for bytes (4I, 4I+2)
+  const uint32_t so = hsum<8 + 4 * I + 1, CH, KC>(E, O);  // sums for bytes (4I+1, 4I+3)
+  const uint32_t qa = mul_div<N>(se & 0xFFFFu), qb = mul_div<N>(so & 0xFFFFu), qc = mul_div<N>(se >> 16), qd = mul_div<N>(so >> 16);
   // gather byte 3 of each product: v_perm_b32 selects from {S0 = bytes 7..4, S1 = bytes 3..0}; 0x0c = constant 0
   return __builtin_amdgcn_perm(qb, qa, 0x0c0c0703u) | __builtin_amdgcn_perm(qd, qc, 0x07030c0cu);
 }
@@ -192,17 +200,19 @@ constexpr int kStripOut = 62 * 16;
 __device__ __forceinline__ uint32_t from_left(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, true); }   // lane i <- lane i-1
 __device__ __forceinline__ uint32_t from_right(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, true); }  // lane i <- lane i+1
 
-template <int CH, int RW, bool NT, bool GUARD, int PROBE>
-__device__ __forceinline__ void box5x5_u8_stream_body(uint8_t* __restrict__ dp, const uint8_t* __restrict__ sp, int dpitch, int spitch,
-                                                      int nrows, int row_bytes, int border_bytes, int x, int r0, bool writer) {
+template <int CH, int KR, int KC, int RW, bool NT, bool GUARD, int PROBE>
+__device__ __forceinline__ void box_u8_stream_body(uint8_t* __restrict__ dp, const uint8_t* __restrict__ sp, int dpitch, int spitch,
+                                                   int nrows, int row_bytes, int border_bytes, int x, int r0, bool writer) {
+  static_assert((KR & 1) && (KC & 1) && KR <= 7 && (KC / 2) * CH <= 8, "the 32-byte window holds 8 halo bytes per side; 7 rows of 255 fit a u16 column sum");
+  constexpr int HR = KR / 2;
   const int lo = -border_bytes, hi = row_bytes + border_bytes;
-  u32x4 raw[RW + 4];
+  u32x4 raw[RW + KR - 1];
   const bool in_reach = x + 16 > lo && x < row_bytes + 16;
 #pragma unroll
-  for (int k = 0; k < RW + 4; k++) {
-    const int r = r0 - 2 + k;
+  for (int k = 0; k < RW + KR - 1; k++) {
+    const int r = r0 - HR + k;
     raw[k] = u32x4{0, 0, 0, 0};
-    if (in_reach && r <= nrows + 1) raw[k] = ld_chunk<GUARD>(sp + (ptrdiff_t)r * spitch, x, lo, hi);
+    if (in_reach && r <= nrows - 1 + HR) raw[k] = ld_chunk<GUARD>(sp + (ptrdiff_t)r * spitch, x, lo, hi);
   }
   auto unpack = [](const u32x4& w, uint32_t* e, uint32_t* o) {
     const uint32_t d[4] = {w.x, w.y, w.z, w.w};
@@ -211,7 +221,7 @@ __device__ __forceinline__ void box5x5_u8_stream_body(uint8_t* __restrict__ dp, 
   };
   uint32_t E[4] = {0, 0, 0, 0}, O[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < KR - 1; k++) {
     uint32_t e[4], o[4];
     unpack(raw[k], e, o);
 #pragma unroll
@@ -224,7 +234,7 @@ __device__ __forceinline__ void box5x5_u8_stream_body(uint8_t* __restrict__ dp, 
     if (r >= nrows) break;
     {
       uint32_t e[4], o[4];
-      unpack(raw[j + 4], e, o);
+      unpack(raw[j + KR - 1], e, o);
 #pragma unroll
       for (int i = 0; i < 4; i++) { E[i] += e[i]; O[i] += o[i]; }
     }
@@ -232,8 +242,9 @@ __device__ __forceinline__ void box5x5_u8_stream_body(uint8_t* __restrict__ dp, 
     const uint32_t WE[8] = {from_left(E[2]), from_left(E[3]), E[0], E[1], E[2], E[3], from_right(E[0]), from_right(E[1])};
     const uint32_t WO[8] = {from_left(O[2]), from_left(O[3]), O[0], O[1], O[2], O[3], from_right(O[0]), from_right(O[1])};
     u32x4 res;
-    res.x = out_dword<0, CH>(WE, WO); res.y = out_dword<1, CH>(WE, WO); res.z = out_dword<2, CH>(WE, WO); res.w = out_dword<3, CH>(WE, WO);
-    if (PROBE == 1) res = raw[j + 2];  // measurement probe (tools/probe_box.py): same loads / stores, no arithmetic
+    res.x = out_dword<0, CH, KC, KR * KC>(WE, WO); res.y = out_dword<1, CH, KC, KR * KC>(WE, WO);
+    res.z = out_dword<2, CH, KC, KR * KC>(WE, WO); res.w = out_dword<3, CH, KC, KR * KC>(WE, WO);
+    if (PROBE == 1) res = raw[j + HR];  // measurement probe (tools/probe_box.py): same loads / stores, no arithmetic
     if (writer) {
       uint8_t* drow = dp + (ptrdiff_t)r * dpitch + x;
       if (full_store) {
@@ -256,8 +267,8 @@ __device__ __forceinline__ void box5x5_u8_stream_body(uint8_t* __restrict__ dp, 
   }
 }
 
-template <int CH, int RW, bool NT, int PROBE>
-__global__ __launch_bounds__(256, (RW <= 2 ? 8 : RW <= 4 ? 6 : 4)) void box5x5_u8_stream_kernel(uint8_t* __restrict__ dp, const uint8_t* __restrict__ sp, int dpitch,
+template <int CH, int KR, int KC, int RW, bool NT, int PROBE>
+__global__ __launch_bounds__(256, (RW <= 2 ? 8 : RW <= 4 ? 6 : 4)) void box_u8_stream_kernel(uint8_t* __restrict__ dp, const uint8_t* __restrict__ sp, int dpitch,
                                                                int spitch, int nrows, int row_bytes, int border_bytes, int nstrips,
                                                                int nblk_y, int guard_ends) {
   static_assert(CH >= 1 && CH <= 4, "window holds 2*CH <= 8 halo bytes");
@@ -270,9 +281,9 @@ __global__ __launch_bounds__(256, (RW <= 2 ? 8 : RW <= 4 ? 6 : 4)) void box5x5_u
   if (r0 >= nrows) return;
   const bool writer = lane >= 1 && lane <= 62 && x < row_bytes;
   if (guard_ends && (r0 == 0 || r0 + RW >= nrows))
-    box5x5_u8_stream_body<CH, RW, NT, true, PROBE>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x, r0, writer);
+    box_u8_stream_body<CH, KR, KC, RW, NT, true, PROBE>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x, r0, writer);
   else
-    box5x5_u8_stream_body<CH, RW, NT, false, PROBE>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x, r0, writer);
+    box_u8_stream_body<CH, KR, KC, RW, NT, false, PROBE>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x, r0, writer);
 }
 
 // ---- 32-bit 5x5: int / unsigned (the element type of the reference's own benchmark, benchmarks/box_5x5_filter.cc:165-171,187-191)
@@ -491,9 +502,9 @@ template <int CH> int launch_fast(const vpp_image_desc* dst, const vpp_image_des
       if (wpb != 1 && wpb != 2) wpb = 4;
       const int nblk_y = (dst->nrows + wpb * RW - 1) / (wpb * RW);
       if (CH == 3 && tuning("box.probe", 0))  // data-movement probe, never used by the product path
-        box5x5_u8_stream_kernel<CH, RW, NT, 1><<<nstrips * nblk_y, 64 * wpb, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
+        box_u8_stream_kernel<CH, 5, 5, RW, NT, 1><<<nstrips * nblk_y, 64 * wpb, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
       else
-        box5x5_u8_stream_kernel<CH, RW, NT, 0><<<nstrips * nblk_y, 64 * wpb, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
+        box_u8_stream_kernel<CH, 5, 5, RW, NT, 0><<<nstrips * nblk_y, 64 * wpb, 0, st>>>(dp, sp, dst->pitch, src->pitch, dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
     };
     auto pick = [&](auto NTc) {
       switch (th) {
@@ -529,6 +540,37 @@ template <int CH> int launch_fast(const vpp_image_desc* dst, const vpp_image_des
 
 }  // namespace
 
+// other odd windows up to 7 x 7 on 8-bit images through the same streaming kernel (2 output rows per wave, non-temporal stores)
+template <int CH, int KR, int KC> int launch_stream_window(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
+  const int row_bytes = dst->ncols * CH;
+  const int nstrips = (row_bytes + kStripOut - 1) / kStripOut;
+  constexpr int RW = 2, WPB = 4;
+  const int nblk_y = (dst->nrows + WPB * RW - 1) / (WPB * RW);
+  const int guard = src->border == KR / 2 ? 1 : 0;  // the window's first / last row is the allocation's: no slack before / after it
+  box_u8_stream_kernel<CH, KR, KC, RW, true, 0><<<nstrips * nblk_y, 64 * WPB, 0, st>>>((uint8_t*)dst->first_pixel, (const uint8_t*)src->first_pixel, dst->pitch, src->pitch,
+                                                                                      dst->nrows, row_bytes, src->border * CH, nstrips, nblk_y, guard);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+template <int CH> int launch_stream_windows(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, hipStream_t st) {
+  const int key = R * 10 + C;
+  switch (key) {
+    case 33: return launch_stream_window<CH, 3, 3>(dst, src, st);
+    case 35: return launch_stream_window<CH, 3, 5>(dst, src, st);
+    case 53: return launch_stream_window<CH, 5, 3>(dst, src, st);
+    case 73: return launch_stream_window<CH, 7, 3>(dst, src, st);
+    case 75: return launch_stream_window<CH, 7, 5>(dst, src, st);
+  }
+  if constexpr (CH <= 2) {  // 7 taps at stride CH reach 3 CH <= 8 halo bytes
+    switch (key) {
+      case 37: return launch_stream_window<CH, 3, 7>(dst, src, st);
+      case 57: return launch_stream_window<CH, 5, 7>(dst, src, st);
+      case 77: return launch_stream_window<CH, 7, 7>(dst, src, st);
+    }
+  }
+  return -1;  // not a streaming window: the caller falls back to the LDS-tiled generic kernel
+}
+
 extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream) {
   VPP_REQUIRE(valid_desc(dst) && valid_desc(src), VPP_ERR_INVALID_ARG, "vpp_box_filter: invalid descriptor");
   VPP_REQUIRE(same_domain(dst, src) && same_type(dst, src), VPP_ERR_INVALID_ARG, "vpp_box_filter: domain/type mismatch");
@@ -543,6 +585,16 @@ extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* s
       case 3: return launch_fast<3>(dst, src, st);
       case 4: return launch_fast<4>(dst, src, st);
     }
+  }
+  if (dst->dtype == VPP_U8 && R <= 7 && C <= 7 && R > 1 && C > 1 && dst->channels <= 4 && aligned16(dst) && aligned16(src) && !tuning("box.force_generic", 0)) {
+    int rc = -1;
+    switch (dst->channels) {
+      case 1: rc = launch_stream_windows<1>(dst, src, R, C, st); break;
+      case 2: rc = launch_stream_windows<2>(dst, src, R, C, st); break;
+      case 3: rc = launch_stream_windows<3>(dst, src, R, C, st); break;
+      case 4: rc = launch_stream_windows<4>(dst, src, R, C, st); break;
+    }
+    if (rc >= 0) return rc;
   }
   if ((dst->dtype == VPP_I32 || dst->dtype == VPP_U32 || dst->dtype == VPP_F32) && dst->channels == 1 && R == 5 && C == 5 && aligned16(dst) && aligned16(src) &&
       !tuning("box.force_generic", 0))
