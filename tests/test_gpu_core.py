@@ -119,6 +119,23 @@ def test_box_u8_streamed_windows_match_oracle(lib, orc, R, C, ch):
         np.testing.assert_array_equal(ddst.download().raw, want.raw)   # and nothing outside the domain was written
 
 
+@pytest.mark.parametrize("R,C", [(3, 3), (3, 5), (5, 3), (7, 3), (7, 5), (5, 7)])
+@pytest.mark.parametrize("dtype", [vi.I32, vi.U32, vi.F32])
+def test_box_32bit_streamed_windows_match_oracle(lib, orc, dtype, R, C):
+    """32-bit single-channel images: windows up to 7 rows x 5 columns stream (5 x 7 falls to the generic kernel); integers exact,
+    floats bit-identical (taps added in the reference's row-major order)."""
+    reach = max(R, C) // 2
+    for shape, border, align in (((37, 61), reach, 16), ((23, 1111), reach + 2, 32), ((2, 3), reach + 1, 16), ((40, 256), reach, 32)):
+        lo, hi = (0, 999) if dtype != vi.F32 else (None, None)
+        src = rand_image(*shape, dtype, 1, border=border, seed=R * 10 + C, lo=lo, hi=hi, align=align, fill_border=True)
+        want = src.like(border=0)
+        assert orc.orc_box_filter(P(want.desc), P(src.desc), R, C) == 0
+        dsrc = DeviceImage.from_host(src); ddst = DeviceImage.from_host(src.like(border=0))
+        capi.check(lib.vpp_box_filter(P(ddst.desc), P(dsrc.desc), R, C, capi.stream_ptr()))
+        _sync(lib)
+        np.testing.assert_array_equal(ddst.download().raw.view(np.uint8), want.raw.view(np.uint8))
+
+
 def test_box_u8_windows_4k_streamed_equal_generic(lib):
     """BASELINE frame size: the streamed 3x3 / 7x7 / 5x3 results equal the generic kernel's, and one pixel equals the numpy mean."""
     src = rand_image(2160, 3840, vi.U8, 3, border=3, seed=12, fill_border=True)

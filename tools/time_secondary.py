@@ -75,3 +75,10 @@ for (R, C, b) in ((3, 3, 1), (7, 5, 3), (3, 5, 2)):
         lib.vpp_set_tuning(b"box.force_generic", g)
         us = time_graph(lambda i, s: lib.vpp_box_filter(P(dsts[i % ns].desc), P(srcs[i % ns].desc), R, C, s)); print(f"box {R}x{C} vuchar3 4K {'generic' if g else 'streamed'}: {us:.2f} us ({2 * NR * NC * 3 / us / 1e3:.0f} GB/s)")
     lib.vpp_set_tuning(b"box.force_generic", 0)
+for dt, nm in ((vi.I32, "int"), (vi.F32, "float")):
+    src_h = rand_image(NR, NC, dt, 1, border=1, seed=3, align=16, lo=0 if dt == vi.I32 else None, hi=999 if dt == vi.I32 else None)
+    srcs = [DeviceImage.from_host(src_h) for _ in range(ns)]; dsts = [DeviceImage(NR, NC, dt, 1, 0, 16) for _ in range(ns)]
+    for g in (0, 1):
+        lib.vpp_set_tuning(b"box.force_generic", g)
+        us = time_graph(lambda i, s: lib.vpp_box_filter(P(dsts[i % ns].desc), P(srcs[i % ns].desc), 3, 3, s)); print(f"box 3x3 {nm} 4K {'generic' if g else 'streamed'}: {us:.2f} us ({2 * NR * NC * 4 / us / 1e3:.0f} GB/s)")
+    lib.vpp_set_tuning(b"box.force_generic", 0)

@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256, (RW <= 2 ? 8 : RW <= 4 ? 6 : 4)) void box_u8_s
 // never read (a straddling chunk takes predicated dword loads), so border == 2 needs no separate guarded body.
 constexpr int kW32StripOut = 62 * 4;
 
-template <class T, int RW, bool NT>
-__global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ dp, const T* __restrict__ sp, int dpitch, int spitch,
+template <class T, int KR, int KC, int RW, bool NT>
+__global__ __launch_bounds__(256) void box_w32_stream_kernel(T* __restrict__ dp, const T* __restrict__ sp, int dpitch, int spitch,
                                                                 int nrows, int ncols, int border, int nstrips, int nblk_y) {
   const unsigned nb = (unsigned)nstrips * (unsigned)nblk_y;
   const unsigned lb = xcd_remap(blockIdx.x, nb);  // consecutive logical blocks = vertically adjacent row blocks of one strip
@@ -305,6 +305,8 @@ __global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ 
   const int x = s * kW32StripOut - 4 + lane * 4;   // first pixel of this lane's chunk
   const int r0 = (by * (int)(blockDim.x >> 6) + wv) * RW;
   if (r0 >= nrows) return;
+  static_assert((KR & 1) && (KC & 1) && KR <= 7 && KC <= 5, "two halo pixels per side come over DPP");
+  constexpr int HR = KR / 2, C0 = 2 - KC / 2;  // first window column of output pixel 0 within the 8-pixel register window
   const int lo = -border, hi = ncols + border;
   const bool in_reach = x + 4 > lo && x < ncols + 4, inside = x >= lo && x + 4 <= hi;
   const bool writer = lane >= 1 && lane <= 62 && x < ncols;
@@ -314,10 +316,10 @@ __global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ 
   // nobody consumes, and only the waves that contain a chunk straddling a row end (first / last strip) take the
   // per-element form (clamped address + select), as a wave-uniform choice.
   const bool vector_wave = __all(inside || !in_reach);
-  U raw[RW + 4][4];
+  U raw[RW + KR - 1][4];
 #pragma unroll
-  for (int k = 0; k < RW + 4; k++) {
-    const int r = min(r0 - 2 + k, nrows - 1 + border);
+  for (int k = 0; k < RW + KR - 1; k++) {
+    const int r = min(r0 - HR + k, nrows - 1 + border);
     const U* row = (const U*)((const uint8_t*)sp + (ptrdiff_t)r * spitch);
     if (vector_wave) {
       const u32x4 v = *(const u32x4*)(row + (in_reach ? x : 0));
@@ -331,9 +333,9 @@ __global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ 
   if constexpr (std::is_floating_point<T>::value) {
     // float: the 25 taps are added one by one in the reference's row-major order (the sum is not associative), starting from 0;
     // each input row's halo (2 pixels per side) is exchanged once, the window of an output row is then 5 x 8 registers
-    float win[RW + 4][8];
+    float win[RW + KR - 1][8];
 #pragma unroll
-    for (int k = 0; k < RW + 4; k++) {
+    for (int k = 0; k < RW + KR - 1; k++) {
       const U w8[8] = {from_left(raw[k][2]), from_left(raw[k][3]), raw[k][0], raw[k][1], raw[k][2], raw[k][3], from_right(raw[k][0]), from_right(raw[k][1])};
 #pragma unroll
       for (int i = 0; i < 8; i++) win[k][i] = __builtin_bit_cast(float, w8[i]);
@@ -347,10 +349,10 @@ __global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ 
       for (int i = 0; i < 4; i++) {
         float sum = 0.f;
 #pragma unroll
-        for (int dr = 0; dr < 5; dr++)
+        for (int dr = 0; dr < KR; dr++)
 #pragma unroll
-          for (int dc = 0; dc < 5; dc++) sum += win[j + dr][i + dc];
-        out[i] = __builtin_bit_cast(U, sum / 25);   // C++ `/ (R*C)` on the promoted type: float / int -> IEEE float division
+          for (int dc = 0; dc < KC; dc++) sum += win[j + dr][i + C0 + dc];
+        out[i] = __builtin_bit_cast(U, sum / (KR * KC));   // C++ `/ (R*C)` on the promoted type: float / int -> IEEE float division
       }
       if (writer) {
         U* drow = (U*)((uint8_t*)dp + (ptrdiff_t)r * dpitch) + x;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ 
   }
   U V[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int k = 0; k < 4; k++)
+  for (int k = 0; k < KR - 1; k++)
 #pragma unroll
     for (int i = 0; i < 4; i++) V[i] += raw[k][i];
 #pragma unroll
@@ -375,11 +377,16 @@ __global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ 
     const int r = r0 + j;
     if (r >= nrows) break;
 #pragma unroll
-    for (int i = 0; i < 4; i++) V[i] += raw[j + 4][i];
+    for (int i = 0; i < 4; i++) V[i] += raw[j + KR - 1][i];
     const U W[8] = {from_left(V[2]), from_left(V[3]), V[0], V[1], V[2], V[3], from_right(V[0]), from_right(V[1])};
     U out[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = (U)((T)(W[i] + W[i + 1] + W[i + 2] + W[i + 3] + W[i + 4]) / (T)25);
+    for (int i = 0; i < 4; i++) {
+      U hs = 0;
+#pragma unroll
+      for (int t = 0; t < KC; t++) hs += W[i + C0 + t];
+      out[i] = (U)((T)hs / (T)(KR * KC));
+    }
     if (writer) {
       U* drow = (U*)((uint8_t*)dp + (ptrdiff_t)r * dpitch) + x;
       if (full_store) {
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256) void box5x5_w32_stream_kernel(T* __restrict__ 
   }
 }
 
-template <class T> int launch_w32(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
+template <class T, int KR = 5, int KC = 5> int launch_w32(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
   const int rows = tuning("box.rows32", 4), nt = tuning("box.nt", 1);   // measured 4K int: 1 -> 20.4, 2 -> 17.4, 4 -> 16.6, 8 -> 21.8 us
   int wpb = tuning("box.waves_per_block", 4);
   if (wpb != 1 && wpb != 2) wpb = 4;
@@ -405,20 +412,35 @@ template <class T> int launch_w32(const vpp_image_desc* dst, const vpp_image_des
   auto go = [&](auto RWc, auto NTc) {
     constexpr int RW = decltype(RWc)::value; constexpr bool NT = decltype(NTc)::value;
     const int nblk_y = (dst->nrows + wpb * RW - 1) / (wpb * RW);
-    box5x5_w32_stream_kernel<T, RW, NT><<<nstrips * nblk_y, 64 * wpb, 0, st>>>((T*)dst->first_pixel, (const T*)src->first_pixel, dst->pitch, src->pitch,
+    box_w32_stream_kernel<T, KR, KC, RW, NT><<<nstrips * nblk_y, 64 * wpb, 0, st>>>((T*)dst->first_pixel, (const T*)src->first_pixel, dst->pitch, src->pitch,
                                                                               dst->nrows, dst->ncols, src->border, nstrips, nblk_y);
   };
   auto pick = [&](auto NTc) {
-    switch (rows) {
-      case 1: go(std::integral_constant<int, 1>(), NTc); break;
-      case 2: go(std::integral_constant<int, 2>(), NTc); break;
-      case 8: go(std::integral_constant<int, 8>(), NTc); break;
-      default: go(std::integral_constant<int, 4>(), NTc); break;
+    if constexpr (KR == 5 && KC == 5) {
+      switch (rows) {
+        case 1: go(std::integral_constant<int, 1>(), NTc); return;
+        case 2: go(std::integral_constant<int, 2>(), NTc); return;
+        case 8: go(std::integral_constant<int, 8>(), NTc); return;
+      }
     }
+    go(std::integral_constant<int, 4>(), NTc);  // the other windows: 4 rows per wave only
   };
-  if (nt) pick(std::true_type()); else pick(std::false_type());
+  if constexpr (KR == 5 && KC == 5) { if (nt) pick(std::true_type()); else pick(std::false_type()); }
+  else pick(std::true_type());
   VPP_LAUNCH_CHECK();
   return VPP_OK;
+}
+// 32-bit single-channel images: odd windows up to 7 rows x 5 columns through the streaming kernel; -1 = not one of them
+template <class T> int launch_w32_windows(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, hipStream_t st) {
+  switch (R * 10 + C) {
+    case 33: return launch_w32<T, 3, 3>(dst, src, st);
+    case 35: return launch_w32<T, 3, 5>(dst, src, st);
+    case 53: return launch_w32<T, 5, 3>(dst, src, st);
+    case 55: return launch_w32<T, 5, 5>(dst, src, st);
+    case 73: return launch_w32<T, 7, 3>(dst, src, st);
+    case 75: return launch_w32<T, 7, 5>(dst, src, st);
+  }
+  return -1;
 }
 
 // ---- generic path ----------------------------------------------------------------------------------------
@@ -596,9 +618,11 @@ extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* s
     }
     if (rc >= 0) return rc;
   }
-  if ((dst->dtype == VPP_I32 || dst->dtype == VPP_U32 || dst->dtype == VPP_F32) && dst->channels == 1 && R == 5 && C == 5 && aligned16(dst) && aligned16(src) &&
-      !tuning("box.force_generic", 0))
-    return dst->dtype == VPP_I32 ? launch_w32<int32_t>(dst, src, st) : dst->dtype == VPP_U32 ? launch_w32<uint32_t>(dst, src, st) : launch_w32<float>(dst, src, st);
+  if ((dst->dtype == VPP_I32 || dst->dtype == VPP_U32 || dst->dtype == VPP_F32) && dst->channels == 1 && aligned16(dst) && aligned16(src) && !tuning("box.force_generic", 0)) {
+    const int rc = dst->dtype == VPP_I32 ? launch_w32_windows<int32_t>(dst, src, R, C, st)
+                 : dst->dtype == VPP_U32 ? launch_w32_windows<uint32_t>(dst, src, R, C, st) : launch_w32_windows<float>(dst, src, R, C, st);
+    if (rc >= 0) return rc;
+  }
   switch (dst->dtype) {
     case VPP_U8: return launch_generic<uint8_t, int>(dst, src, R, C, st);
     case VPP_I8: return launch_generic<int8_t, int>(dst, src, R, C, st);
