@@ -174,22 +174,40 @@ __device__ Match lk_match_group(  // WS*WS <= 64
   float gs0[PPL], gs1[PPL];
   int as[PPL];
   unsigned long long mine = 0;  // validity bits of this lane's offsets
+  float off_r[PPL], off_c[PPL];  // this lane's window offsets (a lane past the window repeats the window's last offset)
 #pragma unroll
-  for (int k = 0; k < PPL; k++) {
-    const int i = gl + k * LPK;
-    gs0[k] = 0.f; gs1[k] = 0.f; as[k] = 0;
-    if (i < N) {
-      const int r = i / WS - hws, c = i % WS - hws;
-      const float n0 = p0 + (float)r, n1 = p1 + (float)c;
-      if (A.has((int)n0, (int)n1)) {
-        GT g[2]; uint8_t a;
-        if (a_safe) { interp<GT, 2, true>(Ag, n0, n1, g); interp<uint8_t, 1, true>(A, n0, n1, &a); }
-        else { interp<GT, 2, false>(Ag, n0, n1, g); interp<uint8_t, 1, false>(A, n0, n1, &a); }
-        gs0[k] = (float)g[0]; gs1[k] = (float)g[1]; as[k] = (int)a;
-        mine |= 1ull << i;
-      }
+  for (int q = 0; q < PPL; q++) {
+    const int i = gl + q * LPK, ii = i < N ? i : N - 1;
+    off_r[q] = (float)(ii / WS - hws); off_c[q] = (float)(ii % WS - hws);
+  }
+  if (a_safe) {  // every tap lies in the bordered area: request all rounds before using any (one round trip, no branch around the loads)
+    GT g[PPL][2]; uint8_t a[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; k++) { interp<GT, 2, true>(Ag, p0 + off_r[k], p1 + off_c[k], g[k]); interp<uint8_t, 1, true>(A, p0 + off_r[k], p1 + off_c[k], &a[k]); }
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+      const int i = gl + k * LPK;
+      const bool ok = i < N && A.has((int)(p0 + off_r[k]), (int)(p1 + off_c[k]));
+      gs0[k] = ok ? (float)g[k][0] : 0.f; gs1[k] = ok ? (float)g[k][1] : 0.f; as[k] = ok ? (int)a[k] : 0;
+      if (ok) mine |= 1ull << i;
+      lds[2 * i] = gs0[k]; lds[2 * i + 1] = gs1[k];
     }
-    lds[2 * i] = gs0[k]; lds[2 * i + 1] = gs1[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+      const int i = gl + k * LPK;
+      gs0[k] = 0.f; gs1[k] = 0.f; as[k] = 0;
+      if (i < N) {
+        const float n0 = p0 + off_r[k], n1 = p1 + off_c[k];
+        if (A.has((int)n0, (int)n1)) {
+          GT g[2]; uint8_t a;
+          interp<GT, 2, false>(Ag, n0, n1, g); interp<uint8_t, 1, false>(A, n0, n1, &a);
+          gs0[k] = (float)g[0]; gs1[k] = (float)g[1]; as[k] = (int)a;
+          mine |= 1ull << i;
+        }
+      }
+      lds[2 * i] = gs0[k]; lds[2 * i + 1] = gs1[k];
+    }
   }
   unsigned long long mask = mine;  // OR over the group's lanes (xor-butterfly stays inside aligned groups of LPK lanes)
 #pragma unroll
@@ -238,19 +256,33 @@ __device__ Match lk_match_group(  // WS*WS <= 64
   for (int k = 0; k <= max_it && sqrtf(nk0 * nk0 + nk1 * nk1) >= delta; k++) {  // lk.hh:116
     const bool b_safe = window_inside(B, v0, v1, hws);
     wave_lds_fence();  // the previous pass' reads are done before its terms are overwritten
+    if (b_safe && all_valid) {
+      // The common case without a branch around the loads: all PPL rounds of taps are requested back to back and the lane pays
+      // ONE memory round trip per iteration instead of PPL dependent ones (a lane past the window samples the window's last
+      // offset and stages a term nobody reads).
+      uint8_t b[PPL];
 #pragma unroll
-    for (int q = 0; q < PPL; q++) {
-      const int i = gl + q * LPK;
-      float t0 = 0.f, t1 = 0.f;
-      if (i < N && (all_valid || ((mine >> i) & 1ull))) {
-        const int r = i / WS - hws, c = i % WS - hws;
-        uint8_t b;
-        if (b_safe) interp<uint8_t, 1, true>(B, v0 + (float)r, v1 + (float)c, &b);
-        else interp<uint8_t, 1, false>(B, v0 + (float)r, v1 + (float)c, &b);
-        const float dt = (float)as[q] - (float)b;  // lk.hh:130
-        t0 = gs0[q] * dt; t1 = gs1[q] * dt;
+      for (int q = 0; q < PPL; q++) interp<uint8_t, 1, true>(B, v0 + off_r[q], v1 + off_c[q], &b[q]);
+#pragma unroll
+      for (int q = 0; q < PPL; q++) {
+        const int i = gl + q * LPK;
+        const float dt = (float)as[q] - (float)b[q];  // lk.hh:130
+        lds[2 * i] = gs0[q] * dt; lds[2 * i + 1] = gs1[q] * dt;
       }
-      lds[2 * i] = t0; lds[2 * i + 1] = t1;
+    } else {
+#pragma unroll
+      for (int q = 0; q < PPL; q++) {
+        const int i = gl + q * LPK;
+        float t0 = 0.f, t1 = 0.f;
+        if (i < N && (all_valid || ((mine >> i) & 1ull))) {
+          uint8_t b;
+          if (b_safe) interp<uint8_t, 1, true>(B, v0 + off_r[q], v1 + off_c[q], &b);
+          else interp<uint8_t, 1, false>(B, v0 + off_r[q], v1 + off_c[q], &b);
+          const float dt = (float)as[q] - (float)b;  // lk.hh:130
+          t0 = gs0[q] * dt; t1 = gs1[q] * dt;
+        }
+        lds[2 * i] = t0; lds[2 * i + 1] = t1;
+      }
     }
     wave_lds_fence();
     float bk0 = 0.f, bk1 = 0.f;
@@ -270,18 +302,27 @@ __device__ Match lk_match_group(  // WS*WS <= 64
   // error: as[i] for every offset (unset entries are 0), |as[i] - B(v + offset)| for every offset (lk.hh:151-171)
   const bool b_safe = window_inside(B, v0, v1, hws);
   wave_lds_fence();
+  if (b_safe) {
+    uint8_t b[PPL];
 #pragma unroll
-  for (int q = 0; q < PPL; q++) {
-    const int i = gl + q * LPK;
-    float e = 0.f;
-    if (i < N) {
-      const int r = i / WS - hws, c = i % WS - hws;
-      uint8_t b;
-      if (b_safe) interp<uint8_t, 1, true>(B, v0 + (float)r, v1 + (float)c, &b);
-      else interp<uint8_t, 1, false>(B, v0 + (float)r, v1 + (float)c, &b);
-      e = fabsf((float)(as[q] - (int)b));
+    for (int q = 0; q < PPL; q++) interp<uint8_t, 1, true>(B, v0 + off_r[q], v1 + off_c[q], &b[q]);
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+      const int i = gl + q * LPK;
+      lds[2 * i] = (float)as[q]; lds[2 * i + 1] = fabsf((float)(as[q] - (int)b[q]));
     }
-    lds[2 * i] = (float)as[q]; lds[2 * i + 1] = e;
+  } else {
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+      const int i = gl + q * LPK;
+      float e = 0.f;
+      if (i < N) {
+        uint8_t b;
+        interp<uint8_t, 1, false>(B, v0 + off_r[q], v1 + off_c[q], &b);
+        e = fabsf((float)(as[q] - (int)b));
+      }
+      lds[2 * i] = (float)as[q]; lds[2 * i + 1] = e;
+    }
   }
   wave_lds_fence();
   float err = 0.f, stddev = 1.f;
