@@ -38,25 +38,28 @@ __device__ __forceinline__ void interp(const DImg& I, float p0, float p1, T* out
     const int rlo = -I.border, rhi = I.nr + I.border - 1, clo = -I.border, chi = I.nc + I.border - 1;
     r0 = min(max(r0, rlo), rhi); r1 = min(max(r1, rlo), rhi); c0 = min(max(c0, clo), chi); c1 = min(max(c1, clo), chi);
   }
-  // 32-bit byte offsets from the (wave-uniform) image base: one scalar base + vector offset per load instead of 64-bit
-  // pointer arithmetic per tap (images are far smaller than 2 GiB)
+  // Unsigned 32-bit byte offsets from the start of the bordered area (wave-uniform base, every tap of either form lies at or
+  // after it): a load is `global_load v, v_offset, s[base]` with no 64-bit address arithmetic per tap, and the row product is
+  // one 24-bit multiply-add (rows < 2^23, pitch < 2^23).
   const int es = (int)sizeof(T) * CH;
-  const int o00 = r0 * I.pitch + c0 * es, o10 = r1 * I.pitch + c0 * es, o01 = r0 * I.pitch + c1 * es, o11 = r1 * I.pitch + c1 * es;
+  const uint8_t* base = I.p0 - ((ptrdiff_t)I.border * I.pitch + (ptrdiff_t)I.border * es);
+  const uint32_t o00 = (uint32_t)(__mul24(r0 + I.border, I.pitch) + (c0 + I.border) * es), o10 = (uint32_t)(__mul24(r1 + I.border, I.pitch) + (c0 + I.border) * es);
+  const uint32_t o01 = (uint32_t)(__mul24(r0 + I.border, I.pitch) + (c1 + I.border) * es), o11 = (uint32_t)(__mul24(r1 + I.border, I.pitch) + (c1 + I.border) * es);
   const float w00 = (1 - a0) * (1 - a1), w10 = a0 * (1 - a1), w01 = (1 - a0) * a1, w11 = a0 * a1;
   if constexpr (SAFE && sizeof(T) == 1 && CH == 1) {
     // the two taps of a row are adjacent bytes: one (unaligned) 16-bit load per row instead of two byte loads — the kernel
     // issues ~2700 tap loads per wave and is bound by how fast the texture path takes them, not by bytes
     uint16_t t0, t1;
-    __builtin_memcpy(&t0, I.p0 + o00, 2);
-    __builtin_memcpy(&t1, I.p0 + o10, 2);
+    __builtin_memcpy(&t0, base + o00, 2);
+    __builtin_memcpy(&t1, base + o10, 2);
     const float v = w00 * (float)(T)(t0 & 255) + w10 * (float)(T)(t1 & 255) + w01 * (float)(T)(t0 >> 8) + w11 * (float)(T)(t1 >> 8);
     out[0] = (T)v;
     return;
   }
 #pragma unroll
   for (int k = 0; k < CH; k++) {
-    const float v = w00 * (float)((const T*)(I.p0 + o00))[k] + w10 * (float)((const T*)(I.p0 + o10))[k] + w01 * (float)((const T*)(I.p0 + o01))[k] +
-                    w11 * (float)((const T*)(I.p0 + o11))[k];
+    const float v = w00 * (float)((const T*)(base + o00))[k] + w10 * (float)((const T*)(base + o10))[k] + w01 * (float)((const T*)(base + o01))[k] +
+                    w11 * (float)((const T*)(base + o11))[k];
     out[k] = (T)v;  // vpp::cast<V>: truncation for integer V
   }
 }
