@@ -170,9 +170,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 template <int WS, class GT, bool PYRLK, int LPK>
 __device__ Match lk_match_group(  // WS*WS <= 64
-    float p0, float p1, float tr0, float tr1, const DImg& A, const DImg& B, const DImg& Ag, float min_ev_th,
+    float p0, float p1, float tr0, float tr1, const DImg& A_, const DImg& B_, const DImg& Ag_, float min_ev_th,
                                 int max_it, float delta, float* lds, int gl) {
   constexpr int hws = WS / 2, N = WS * WS, PPL = (N + LPK - 1) / LPK;
+  // the level's descriptors by value: the callers index a kernel-argument array with the (runtime) level, and through the
+  // references every use inside the iteration loop was a fresh scalar load + wait
+  const DImg A = A_, B = B_, Ag = Ag_;
   const bool a_safe = window_inside(A, p0, p1, hws);
   float gs0[PPL], gs1[PPL];
   int as[PPL];
