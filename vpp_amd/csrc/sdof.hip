@@ -12,6 +12,7 @@
 //     serial result, deterministic.
 // Integer arithmetic throughout: bit-exact.  SAD windows are L2-resident; the path is integer-VALU / latency bound.
 #include "common.hpp"
+#include <type_traits>
 #include <climits>
 using namespace vpp_amd;
 
@@ -56,16 +57,15 @@ __device__ __forceinline__ int sad_rows(const uint8_t* __restrict__ row1, const 
   return err;
 }
 
+// WS: the window size when it is one of the register-window sizes (5, 7, 9, 11), else 0 = the generic loop over the runtime
+// `ws`.  Every kernel of this file is instantiated per WS: with a runtime switch at each of the ~30 inlined call sites the
+// out-of-line recomputation alone was 84 KB of code, more than the instruction cache, on the critical path of the ordered sweep.
+template <int WS>
 __device__ __forceinline__ int distance_fn(const DImg& i1, const DImg& i2, int a0, int a1, int b0, int b1, int ws, int th) {
   if (!(i1.has(a0, a1) && i2.has(b0, b1))) return INT_MAX;
   const uint8_t* row1 = i1.row<uint8_t>(a0 - ws / 2) + (a1 - ws / 2);
   const uint8_t* row2 = i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2);
-  switch (ws) {
-    case 5: return sad_rows<5>(row1, row2, i1.pitch, i2.pitch, th);
-    case 7: return sad_rows<7>(row1, row2, i1.pitch, i2.pitch, th);
-    case 9: return sad_rows<9>(row1, row2, i1.pitch, i2.pitch, th);
-    case 11: return sad_rows<11>(row1, row2, i1.pitch, i2.pitch, th);
-  }
+  if constexpr (WS != 0) return sad_rows<WS>(row1, row2, i1.pitch, i2.pitch, th);
   int err = 0;
   for (int r = 0; r < ws && err <= th; r++) {
     int err2 = 0;
@@ -79,30 +79,35 @@ __device__ __forceinline__ int distance_fn(const DImg& i1, const DImg& i2, int a
 struct GdMatch { int f0, f1, distance; };
 
 // gradient_descent_match (gradient_descent.hh:10-89), neighbour tables verbatim
-__device__ GdMatch gradient_descent_match(const DImg& i1, const DImg& i2, int ws, int p0, int p1, int pr0, int pr1, int max_iteration) {
+template <int WS, class DF>
+__device__ __forceinline__ GdMatch gradient_descent_impl(DF distance_of, int p0, int p1, int pr0, int pr1, int max_iteration) {
   int m0 = pr0, m1 = pr1;
-  int match_distance = distance_fn(i1, i2, p0, p1, pr0, pr1, ws, INT_MAX);
+  int match_distance = distance_of(pr0, pr1, INT_MAX);
   unsigned match_i = 8;
-  const int c8_it[9][2] = {{6, 3}, {0, 3}, {0, 5}, {2, 5}, {2, 7}, {4, 7}, {4, 1}, {6, 1}, {0, 0}};
-  const int c8[8][2] = {{-1, 1}, {0, 1}, {1, 1}, {-1, 0}, {1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+  // The reference's tables (gradient_descent.hh:28-38), packed into immediates: indexed by a per-lane value, the arrays would be
+  // loads from constant memory in the dependency chain of every candidate.
+  //   c8_it[9][2] = {{6,3},{0,3},{0,5},{2,5},{2,7},{4,7},{4,1},{6,1},{0,0}}  (first candidate, one-past-last; 3 bits each)
+  //   c8[8][2]    = {{-1,1},{0,1},{1,1},{-1,0},{1,0},{-1,-1},{0,-1},{1,-1}}    (offset + 1; 2 bits each)
+  constexpr unsigned kFirst = 0xd22406u, kEnd = 0x27fb5bu, kDr = 0x9224u, kDc = 0x16au;
+#pragma nounroll
   for (int search = 0; search < max_iteration; search++) {
-    int i = c8_it[match_i][0];
-    const int end = c8_it[match_i][1];
-    {
-      const int n0 = pr0 + c8[i][0], n1 = pr1 + c8[i][1];
-      const int d = distance_fn(i1, i2, p0, p1, n0, n1, ws, match_distance);
+    unsigned i = (kFirst >> (3 * match_i)) & 7u;
+    const unsigned end = (kEnd >> (3 * match_i)) & 7u;
+#pragma nounroll
+    do {  // the first candidate unconditionally, then up to `end` (the reference's peeled first step + for loop)
+      const int n0 = pr0 + (int)((kDr >> (2 * i)) & 3u) - 1, n1 = pr1 + (int)((kDc >> (2 * i)) & 3u) - 1;
+      const int d = distance_of(n0, n1, match_distance);
       if (d < match_distance) { m0 = n0; m1 = n1; match_i = i; match_distance = d; }
-      i = (i + 1) & 7;
-    }
-    for (; i != end; i = (i + 1) & 7) {
-      const int n0 = pr0 + c8[i][0], n1 = pr1 + c8[i][1];
-      const int d = distance_fn(i1, i2, p0, p1, n0, n1, ws, match_distance);
-      if (d < match_distance) { m0 = n0; m1 = n1; match_i = i; match_distance = d; }
-    }
+      i = (i + 1) & 7u;
+    } while (i != end);
     if (pr0 == m0 && pr1 == m1) break;
     pr0 = m0; pr1 = m1;
   }
   return GdMatch{m0 - p0, m1 - p1, match_distance};
+}
+template <int WS>
+__device__ __forceinline__ GdMatch gradient_descent_match(const DImg& i1, const DImg& i2, int ws, int p0, int p1, int pr0, int pr1, int max_iteration) {
+  return gradient_descent_impl<WS>([&](int n0, int n1, int th) { return distance_fn<WS>(i1, i2, p0, p1, n0, n1, ws, th); }, p0, p1, pr0, pr1, max_iteration);
 }
 
 __global__ __launch_bounds__(256) void sdof_claim_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, DImg owner) {
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(256) void sdof_claim_kernel(const int32_t* __restri
   atomicMin(owner.row<uint32_t>(pf0) + pf1, (uint32_t)i);
 }
 
+template <int WS>
 __global__ __launch_bounds__(64) void sdof_descent_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
                                                           DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse) {
   const int i = blockIdx.x * 64 + threadIdx.x;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(64) void sdof_descent_kernel(const int32_t* __restr
       pr0 = p0 + f[0] * 2; pr1 = p1 + f[1] * 2;
     }
   }
-  const GdMatch m = gradient_descent_match(i1, i2, ws, p0, p1, pr0, pr1, 5);  // :132-134
+  const GdMatch m = gradient_descent_match<WS>(i1, i2, ws, p0, p1, pr0, pr1, 5);  // :132-134
   int32_t* f = cur.flow.row<int32_t>(pf0) + 2 * pf1;
   f[0] = m.f0; f[1] = m.f1;                       // :137-139
   cur.dist.row<int32_t>(pf0)[pf1] = m.distance;  // :140
@@ -139,6 +145,7 @@ __global__ __launch_bounds__(64) void sdof_descent_kernel(const int32_t* __restr
 __device__ __forceinline__ int inorm(int a, int b) { return (int)sqrt((double)(a * a + b * b)); }  // Eigen norm() on vint2
 
 // loop_body (:149-189) for cell (pf0, pf1) evaluated at image point (r, c)
+template <int WS>
 __device__ void propagate_cell(const DImg& i1, const DImg& i2, int ws, const Maps& m, int r, int c, int pf0, int pf1) {
   if (!m.mark.row<uint8_t>(pf0)[pf1]) return;
   int32_t* fpf = m.flow.row<int32_t>(pf0) + 2 * pf1;
@@ -152,9 +159,9 @@ __device__ void propagate_cell(const DImg& i1, const DImg& i2, int ws, const Map
       const int fq0 = fq[0], fq1 = fq[1];
       if (inorm(fpf[0] - fq0, fpf[1] - fq1) > 2 && inorm(prev0 - fq0, prev1 - fq1) > 2) {
         const int d1 = m.dist.row<int32_t>(pf0)[pf1];
-        const int d2 = distance_fn(i1, i2, r, c, r + fq0, c + fq1, ws, INT_MAX);
+        const int d2 = distance_fn<WS>(i1, i2, r, c, r + fq0, c + fq1, ws, INT_MAX);
         if (d2 < d1) {
-          const GdMatch g = gradient_descent_match(i1, i2, ws, r, c, r + fq0, c + fq1, 5);
+          const GdMatch g = gradient_descent_match<WS>(i1, i2, ws, r, c, r + fq0, c + fq1, 5);
           if (g.distance < d1) {
             m.mark.row<uint8_t>(pf0)[pf1] = 1;
             fpf[0] = g.f0; fpf[1] = g.f1;
@@ -166,6 +173,7 @@ __device__ void propagate_cell(const DImg& i1, const DImg& i2, int ws, const Map
 }
 
 // All `niters` sweeps of one scale in one launch of ONE workgroup (skewed wavefront, barrier per step).
+template <int WS>
 __global__ __launch_bounds__(1024) void sdof_propagate_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int niters) {
   const int NI = (i1.nr - 1) / patch + 1, NJ = (i1.nc - 1) / patch + 1;  // cells visited by the loops at :192-200
   for (int Ki = 0; Ki < niters; Ki++) {
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(1024) void sdof_propagate_kernel(DImg i1, DImg i2, 
         int r, c;
         if (forward) { r = iw * patch; c = jw * patch; }
         else { r = i1.nr - 1 - iw * patch; c = i1.nc - 1 - jw * patch; }  // :198-200 start at nrows-1 / ncols-1
-        propagate_cell(i1, i2, ws, m, r, c, r / patch, c / patch);
+        propagate_cell<WS>(i1, i2, ws, m, r, c, r / patch, c / patch);
       }
       __syncthreads();
     }
@@ -207,8 +215,10 @@ struct PairCache { int nf0, nf1, d2, gf0, gf1, gdist, flags, pad; };  // flags: 
 // (r, c) and on the neighbour's flow: RECORD stores them in pc[8] (Jacobi pass), otherwise pc[8] is consulted and a
 // result is recomputed only when the neighbour's flow is no longer the one it was computed for.  Returns true when the
 // cell was updated.
-template <bool RECORD, class NB>
-__device__ __forceinline__ bool loop_body(const DImg& i1, const DImg& i2, int ws, int r, int c, Cell& cur, NB nbr, PairCache* pc) {
+// DIST(r2, c2) = distance(p, (r2, c2)) with th = INT_MAX, GD(r2, c2) = gradient_descent_match(p, prediction (r2, c2), 5): the
+// Jacobi pass inlines them, the recomputation of the ordered sweep calls its out-of-line copies.
+template <bool RECORD, class NB, class DIST, class GD>
+__device__ __forceinline__ bool loop_body(int r, int c, Cell& cur, NB nbr, PairCache* pc, DIST dist, GD gd) {
   const int prev0 = cur.f0, prev1 = cur.f1;
   bool changed = false;
   int k = -1;
@@ -226,12 +236,12 @@ __device__ __forceinline__ bool loop_body(const DImg& i1, const DImg& i2, int ws
         const int d1 = cur.dist;
         PairCache e; e.flags = 0;
         if (!RECORD) { e = pc[k]; if (!((e.flags & 1) && e.nf0 == nb.f0 && e.nf1 == nb.f1)) e.flags = 0; }
-        const int d2 = (e.flags & 1) ? e.d2 : distance_fn(i1, i2, r, c, r + nb.f0, c + nb.f1, ws, INT_MAX);
+        const int d2 = (e.flags & 1) ? e.d2 : dist(r + nb.f0, c + nb.f1);
         GdMatch g{0, 0, 0};
         bool have_g = false;
         if (d2 < d1) {
           if (e.flags & 2) g = GdMatch{e.gf0, e.gf1, e.gdist};
-          else g = gradient_descent_match(i1, i2, ws, r, c, r + nb.f0, c + nb.f1, 5);
+          else g = gd(r + nb.f0, c + nb.f1);
           have_g = true;
           if (g.distance < d1) { cur.mark = 1; cur.f0 = g.f0; cur.f1 = g.f1; cur.dist = g.distance; changed = true; }
         }
@@ -248,6 +258,7 @@ __device__ __forceinline__ Cell load_map_cell(const Maps& m, int ci, int cj) {
   return c;
 }
 
+template <int WS>
 __global__ __launch_bounds__(256) void sdof_jacobi_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int NI, int NJ, int forward,
                                                           Cell* __restrict__ J, PairCache* __restrict__ pairs, uint8_t* __restrict__ skew, int NIp) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -263,7 +274,9 @@ __global__ __launch_bounds__(256) void sdof_jacobi_kernel(DImg i1, DImg i2, int 
       if (q0 < 0 || q1 < 0 || q0 >= NI || q1 >= NJ) return Cell{0, 0, 0, 0};
       return load_map_cell(m, q0, q1);
     };
-    if (loop_body<true>(i1, i2, ws, r, c, cur, nbr, pairs + (size_t)idx * 8)) { cur.mark |= kChanged; pre.mark |= kJChanged; }
+    auto dist = [&](int r2, int c2) { return distance_fn<WS>(i1, i2, r, c, r2, c2, ws, INT_MAX); };
+    auto gd = [&](int r2, int c2) { return gradient_descent_match<WS>(i1, i2, ws, r, c, r2, c2, 5); };
+    if (loop_body<true>(r, c, cur, nbr, pairs + (size_t)idx * 8, dist, gd)) { cur.mark |= kChanged; pre.mark |= kJChanged; }
   }
   J[idx] = cur;
   // the pre-sweep cell (+ "Jacobi wants to change it") in the ordered pass's visiting layout: step-major, wavefront row minor,
@@ -298,10 +311,111 @@ __device__ __forceinline__ Cell load_map_cell_coherent(const Maps& m, int ci, in
 // line so that the per-step code stays small.  The cell, its eight neighbours and its eight pair-cache entries are fetched
 // up front, back to back: one memory round trip instead of dependent ones on the critical path of the wavefront.
 struct SlowResult { Cell cell; int changed; };
-__device__ __noinline__ SlowResult sweep_slow_path(const DImg& i1, const DImg& i2, int ws, int patch, int forward, int ci, int cj, int NI, int NJ,
-                                                   const Maps& m, const PairCache* pc) {
-  int r, c;
-  if (forward) { r = ci * patch; c = cj * patch; } else { r = i1.nr - 1 - (NI - 1 - ci) * patch; c = i1.nc - 1 - (NJ - 1 - cj) * patch; }
+// Arguments of the out-of-line functions are small structs BY VALUE (registers) holding global-address-space pointers: through
+// `const DImg&` every call began with a round trip to the caller's stack for the descriptor fields and every pixel load was a
+// flat_load; the recomputation chain is latency, not throughput.
+#define VPP_GLOBAL __attribute__((address_space(1)))
+typedef const VPP_GLOBAL uint8_t* gcu8;
+struct FramePair { gcu8 p1, p2; int pitch1, pitch2, nr1, nc1, nr2, nc2; };
+struct MapsG { const VPP_GLOBAL int32_t* flow; const VPP_GLOBAL uint8_t* mark; const VPP_GLOBAL int32_t* dist; int fpitch, mpitch, dpitch; };
+struct __attribute__((packed)) PackedU32 { uint32_t v; };
+
+// sad_rows / distance_fn on a FramePair (same arithmetic, global loads)
+template <int WS>
+__device__ __forceinline__ int distance_g(const FramePair& f, int a0, int a1, int b0, int b1, int ws, int th) {
+  if (!(a0 >= 0 && a1 >= 0 && a0 < f.nr1 && a1 < f.nc1 && b0 >= 0 && b1 >= 0 && b0 < f.nr2 && b1 < f.nc2)) return INT_MAX;
+  gcu8 row1 = f.p1 + (ptrdiff_t)(a0 - ws / 2) * f.pitch1 + (a1 - ws / 2);
+  gcu8 row2 = f.p2 + (ptrdiff_t)(b0 - ws / 2) * f.pitch2 + (b1 - ws / 2);
+  if constexpr (WS != 0) {
+    constexpr int ND = (WS + 3) / 4;
+    constexpr uint32_t tail_mask = (WS % 4) ? ((1u << (8 * (WS % 4))) - 1u) : 0xFFFFFFFFu;
+    uint32_t a[WS][ND], b[WS][ND];
+#pragma unroll
+    for (int r = 0; r < WS; r++)
+#pragma unroll
+      for (int d = 0; d < ND; d++) {
+        a[r][d] = ((const VPP_GLOBAL PackedU32*)(row1 + (ptrdiff_t)r * f.pitch1 + 4 * d))->v;
+        b[r][d] = ((const VPP_GLOBAL PackedU32*)(row2 + (ptrdiff_t)r * f.pitch2 + 4 * d))->v;
+      }
+    int err = 0;
+#pragma unroll
+    for (int r = 0; r < WS; r++) {
+      if (err <= th) {
+        uint32_t err2 = 0;
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+          const uint32_t m = d == ND - 1 ? tail_mask : 0xFFFFFFFFu;
+          err2 = __builtin_amdgcn_sad_u8(a[r][d] & m, b[r][d] & m, err2);
+        }
+        err += (int)err2;
+      }
+    }
+    return err;
+  } else {
+    int err = 0;
+    for (int r = 0; r < ws && err <= th; r++) {
+      int err2 = 0;
+      for (int c = 0; c < ws; c++) err2 += abs((int)row1[c] - (int)row2[c]);
+      err += err2;
+      row1 += f.pitch1; row2 += f.pitch2;
+    }
+    return err;
+  }
+}
+template <int WS>
+__device__ __noinline__ int distance_outlined(FramePair f, int a0, int a1, int b0, int b1, int ws, int th) { return distance_g<WS>(f, a0, a1, b0, b1, ws, th); }
+template <int WS>
+__device__ __noinline__ GdMatch gradient_descent_outlined(FramePair f, int ws, int p0, int p1, int pr0, int pr1, int max_iteration) {
+  if constexpr (WS != 0) {
+    // every candidate of the descent is compared with the same window of frame 1: it is loaded once, a candidate costs the
+    // loads of its frame-2 window only (the loads, not the arithmetic, are what a single-lane SAD waits for)
+    constexpr int ND = (WS + 3) / 4;
+    constexpr uint32_t tail_mask = (WS % 4) ? ((1u << (8 * (WS % 4))) - 1u) : 0xFFFFFFFFu;
+    const bool a_ok = p0 >= 0 && p1 >= 0 && p0 < f.nr1 && p1 < f.nc1;
+    uint32_t a[WS][ND];
+    gcu8 row1 = f.p1 + (ptrdiff_t)(p0 - WS / 2) * f.pitch1 + (p1 - WS / 2);
+#pragma unroll
+    for (int r = 0; r < WS; r++)
+#pragma unroll
+      for (int d = 0; d < ND; d++) a[r][d] = a_ok ? ((const VPP_GLOBAL PackedU32*)(row1 + (ptrdiff_t)r * f.pitch1 + 4 * d))->v & (d == ND - 1 ? tail_mask : 0xFFFFFFFFu) : 0u;
+    auto distance_of = [&](int n0, int n1, int th) -> int {
+      if (!(a_ok && n0 >= 0 && n1 >= 0 && n0 < f.nr2 && n1 < f.nc2)) return INT_MAX;
+      gcu8 row2 = f.p2 + (ptrdiff_t)(n0 - WS / 2) * f.pitch2 + (n1 - WS / 2);
+      uint32_t b[WS][ND];
+#pragma unroll
+      for (int r = 0; r < WS; r++)
+#pragma unroll
+        for (int d = 0; d < ND; d++) b[r][d] = ((const VPP_GLOBAL PackedU32*)(row2 + (ptrdiff_t)r * f.pitch2 + 4 * d))->v;
+      int err = 0;
+#pragma unroll
+      for (int r = 0; r < WS; r++) {
+        if (err <= th) {
+          uint32_t err2 = 0;
+#pragma unroll
+          for (int d = 0; d < ND; d++) err2 = __builtin_amdgcn_sad_u8(a[r][d], b[r][d] & (d == ND - 1 ? tail_mask : 0xFFFFFFFFu), err2);
+          err += (int)err2;
+        }
+      }
+      return err;
+    };
+    return gradient_descent_impl<WS>(distance_of, p0, p1, pr0, pr1, max_iteration);
+  } else {
+    return gradient_descent_impl<WS>([&](int n0, int n1, int th) { return distance_g<WS>(f, p0, p1, n0, n1, ws, th); }, p0, p1, pr0, pr1, max_iteration);
+  }
+}
+
+__device__ __forceinline__ Cell load_map_cell_coherent(const MapsG& m, int ci, int cj) {
+  Cell c;
+  const VPP_GLOBAL int32_t* f = (const VPP_GLOBAL int32_t*)((gcu8)m.flow + (ptrdiff_t)ci * m.fpitch) + 2 * cj;
+  c.f0 = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  c.f1 = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  c.dist = __hip_atomic_load((const VPP_GLOBAL int32_t*)((gcu8)m.dist + (ptrdiff_t)ci * m.dpitch) + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  c.mark = __hip_atomic_load(m.mark + (ptrdiff_t)ci * m.mpitch + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return c;
+}
+
+template <int WS>
+__device__ __noinline__ SlowResult sweep_slow_path(FramePair f, MapsG m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc) {
   Cell nb8[8];
   int k = 0;
 #pragma unroll
@@ -317,9 +431,14 @@ __device__ __noinline__ SlowResult sweep_slow_path(const DImg& i1, const DImg& i
   Cell cur = load_map_cell_coherent(m, ci, cj);
   PairCache loc[8];
 #pragma unroll
-  for (int q = 0; q < 8; q++) loc[q] = pc[q];
+  for (int q = 0; q < 8; q++) {
+    const VPP_GLOBAL int* e = (const VPP_GLOBAL int*)pc + 8 * q;
+    loc[q] = PairCache{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]};
+  }
   auto nbr = [&](int dr, int dc) -> Cell { return nb8[(dr + 1) * 3 + (dc + 1) - ((dr > 0 || (dr == 0 && dc > 0)) ? 1 : 0)]; };
-  const bool changed = loop_body<false>(i1, i2, ws, r, c, cur, nbr, loc);
+  auto dist = [&](int r2, int c2) { return distance_outlined<WS>(f, r, c, r2, c2, ws, INT_MAX); };
+  auto gd = [&](int r2, int c2) { return gradient_descent_outlined<WS>(f, ws, r, c, r2, c2, 5); };
+  const bool changed = loop_body<false>(r, c, cur, nbr, loc, dist, gd);
   return SlowResult{cur, changed ? 1 : 0};
 }
 
@@ -331,6 +450,7 @@ __device__ __noinline__ SlowResult sweep_slow_path(const DImg& i1, const DImg& i
 // whole (one 16-byte LDS read, one barrier); only the other groups are walked step by step with a barrier per step.
 __device__ unsigned g_sweep_stats[4];  // [0] unused, [1] Jacobi outcomes applied, [2] slow-path recomputations, [3] slow-path changes
 
+template <int WS>
 __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward,
                                                                    const Cell* __restrict__ J, PairCache* __restrict__ pairs,
                                                                    const uint8_t* __restrict__ skew, int NIp, int stats) {
@@ -401,7 +521,10 @@ __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg
             cur = J[(size_t)ci * NJ + cj]; changed = true;
             if (stats) atomicAdd(&g_sweep_stats[1], 1u);
           } else {
-            const SlowResult sr = sweep_slow_path(i1, i2, ws, patch, forward, ci, cj, NI, NJ, m, pairs + ((size_t)ci * NJ + cj) * 8);
+            const int pr = forward ? ci * patch : i1.nr - 1 - (NI - 1 - ci) * patch, pcol = forward ? cj * patch : i1.nc - 1 - (NJ - 1 - cj) * patch;
+            const SlowResult sr = sweep_slow_path<WS>(FramePair{(gcu8)i1.p0, (gcu8)i2.p0, i1.pitch, i2.pitch, i1.nr, i1.nc, i2.nr, i2.nc},
+                                                      MapsG{(const VPP_GLOBAL int32_t*)m.flow.p0, (const VPP_GLOBAL uint8_t*)m.mark.p0, (const VPP_GLOBAL int32_t*)m.dist.p0, m.flow.pitch, m.mark.pitch, m.dist.pitch},
+                                                      ws, pr, pcol, ci, cj, NI, NJ, (const VPP_GLOBAL PairCache*)(pairs + ((size_t)ci * NJ + cj) * 8));
             cur = sr.cell; changed = sr.changed != 0;
             if (stats) { atomicAdd(&g_sweep_stats[2], 1u); if (changed) atomicAdd(&g_sweep_stats[3], 1u); }
           }
@@ -501,21 +624,32 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
     VPP_HIP_TRY(hipMemsetAsync(OW[scale].first_pixel, 0xFF, (size_t)OW[scale].pitch * OW[scale].nrows, st));
     sdof_claim_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, scale_div, patchsize, dimg(&OW[scale]));
     const bool has_coarse = scale < nscales - 1;
-    sdof_descent_kernel<<<(n + 63) / 64, 64, 0, st>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW[scale]), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                     maps(scale), maps(has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0);
-    if (propagation > 0) {
-      const int NI = (P1[scale].nrows - 1) / patchsize + 1;
-      const int threads = (NI + 63) / 64 * 64;
-      const int mode = tuning("sdof.propagate", 0);  // 0 / 2 / 3: Jacobi + ordered flag pass, 1: generic wavefront kernel
-      const int NJ = (P1[scale].ncols - 1) / patchsize + 1;
-      if (mode != 1 && NI <= 1024) {  // mode 1: the generic one-kernel wavefront (also the fallback for maps taller than 1024 cells)
-        const size_t lds = (size_t)kRingGroups * threads * kGroupSteps;
-        for (int Ki = 0; Ki < propagation; Ki++) {
-          sdof_jacobi_kernel<<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs, skew, threads);
-          sdof_propagate_ring_kernel<<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
-        }
-      } else
-        sdof_propagate_kernel<<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, propagation);
+    // every kernel that evaluates SAD windows exists once per register-window size (WS = 0: any other size, generic loop)
+    auto launch_scale = [&](auto WSc) {
+      constexpr int WS = decltype(WSc)::value;
+      sdof_descent_kernel<WS><<<(n + 63) / 64, 64, 0, st>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW[scale]), dimg(&P1[scale]), dimg(&P2[scale]),
+                                                           maps(scale), maps(has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0);
+      if (propagation > 0) {
+        const int NI = (P1[scale].nrows - 1) / patchsize + 1;
+        const int threads = (NI + 63) / 64 * 64;
+        const int mode = tuning("sdof.propagate", 0);  // 0 / 2 / 3: Jacobi + ordered flag pass, 1: generic wavefront kernel
+        const int NJ = (P1[scale].ncols - 1) / patchsize + 1;
+        if (mode != 1 && NI <= 1024) {  // mode 1: the generic one-kernel wavefront (also the fallback for maps taller than 1024 cells)
+          const size_t lds = (size_t)kRingGroups * threads * kGroupSteps;
+          for (int Ki = 0; Ki < propagation; Ki++) {
+            sdof_jacobi_kernel<WS><<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs, skew, threads);
+            sdof_propagate_ring_kernel<WS><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
+          }
+        } else
+          sdof_propagate_kernel<WS><<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, propagation);
+      }
+    };
+    switch (winsize) {
+      case 5: launch_scale(std::integral_constant<int, 5>()); break;
+      case 7: launch_scale(std::integral_constant<int, 7>()); break;
+      case 9: launch_scale(std::integral_constant<int, 9>()); break;
+      case 11: launch_scale(std::integral_constant<int, 11>()); break;
+      default: launch_scale(std::integral_constant<int, 0>()); break;
     }
     VPP_LAUNCH_CHECK();
   }
