@@ -128,7 +128,7 @@ def main():
     ms_per_step = wall / args.steps * 1e3
     value = npx * world / (wall / args.steps) / 1e9
     box_kernel_s = ev / args.steps
-    roof = {"bound": "hbm", "kernel": "box5x5_u8_stream_kernel<3,2>", "achieved": 6.0 * npx / box_kernel_s / 1e9, "peak": HBM_PEAK_GBS,
+    roof = {"bound": "hbm", "kernel": "box_u8_stream_kernel<3, 5, 5, 2, true, 0>", "achieved": 6.0 * npx / box_kernel_s / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": 6 * npx, "avg_launch_us": box_kernel_s * 1e6}
     roof["frac"] = roof["achieved"] / roof["peak"]
 
@@ -141,7 +141,7 @@ def main():
                 if k.startswith(prefix):
                     return v["hbm_bytes_per_launch"]
         return None
-    roof["traffic"] = pmc_traffic("box5x5_u8_stream_kernel<3")
+    roof["traffic"] = pmc_traffic("box_u8_stream_kernel<3, 5, 5")
     roof["traffic_source"] = "profiles/*_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled)"
 
     # ---------------- 4K int32 pixel_wise add ----------------
