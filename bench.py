@@ -169,6 +169,9 @@ def main():
         extras["pyrlk"] = bench_pyrlk.run(lib, dev, rank, world, timed, barrier)
     except ImportError:
         pass
+    except Exception as e:  # noqa: BLE001 — the secondary legs must never cost the headline line
+        import traceback
+        extras["pyrlk"] = {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().strip().splitlines()[-3:]}
 
     # ---------------- CPU baseline: the oracle restatement on the host cores (rank 0, N=1 only) ----------------
     cpu = None
