@@ -57,5 +57,47 @@ for case in range(N):
         capi.check(lib.vpp_rgb_to_graylevel(P(dg.desc), P(dr.desc), 1, capi.stream_ptr())); capi.check(lib.vpp_sync(capi.stream_ptr()))
         ok = np.array_equal(dg.download().view(with_border=True), want.view(with_border=True))
         print(f"ingest {nr}x{nc} border={gb}: {'ok' if ok else 'MISMATCH'}"); bad += not ok
+    # box windows other than 5x5 (streamed up to 7x7 / 7x5, generic beyond), all element types
+    R, C = int(rng.choice([1, 3, 5, 7, 9])), int(rng.choice([1, 3, 5, 7, 9]))
+    dtype = int(rng.choice([vi.U8, vi.I8, vi.U16, vi.I16, vi.I32, vi.U32, vi.F32])); c = int(rng.integers(1, 5)) if dtype == vi.U8 else int(rng.integers(1, 3))
+    reach = max(R, C) // 2; border = reach + int(rng.integers(0, 3)); nr, nc = int(rng.integers(1, 120)), int(rng.integers(1, 900))
+    wide = dtype in (vi.I32, vi.U32)
+    src = rand_image(nr, nc, dtype, c, border=border, seed=int(rng.integers(1 << 30)), lo=0 if wide else None, hi=999 if wide else None, align=int(rng.choice([16, 32])), fill_border=True)
+    want = src.like(border=0)
+    if orc.orc_box_filter(P(want.desc), P(src.desc), R, C) == 0:
+        ds, dd = DeviceImage.from_host(src), DeviceImage.from_host(src.like(border=0))
+        capi.check(lib.vpp_box_filter(P(dd.desc), P(ds.desc), R, C, capi.stream_ptr())); capi.check(lib.vpp_sync(capi.stream_ptr()))
+        ok = np.array_equal(dd.download().raw.view(np.uint8), want.raw.view(np.uint8))
+        print(f"box {R}x{C} dtype={dtype} x{c} {nr}x{nc} border={border}: {'ok' if ok else 'MISMATCH'}"); bad += not ok
+    # dense FAST flags and the blockwise maxima filter
+    nr, nc = int(rng.integers(1, 200)), int(rng.integers(1, 300)); th = int(rng.integers(-5, 80)); fb = int(rng.integers(3, 6))
+    fim = u8_image(rects_image(nr, nc, seed=int(rng.integers(1 << 30))), border=fb)
+    fim.view(with_border=True)[..., 0] = np.pad(fim.view()[..., 0], fb, mode="symmetric")
+    odt = int(rng.choice([vi.U8, vi.I32]))
+    want = HostImage(nr, nc, odt, 1); orc.orc_fast9_dense(P(want.desc), P(fim.desc), th)
+    dfi, dfo = DeviceImage.from_host(fim), DeviceImage(nr, nc, odt, 1)
+    capi.check(lib.vpp_fast9_dense(P(dfo.desc), P(dfi.desc), th, capi.stream_ptr())); capi.check(lib.vpp_sync(capi.stream_ptr()))
+    ok = np.array_equal(dfo.download().view(), want.view())
+    print(f"fast9_dense {nr}x{nc} th={th} out={odt}: {'ok' if ok else 'MISMATCH'}"); bad += not ok
+    bdt = int(rng.choice([vi.U8, vi.I16, vi.I32, vi.F32])); bs = int(rng.integers(1, 40))
+    bim = rand_image(nr, nc, bdt, 1, border=1, seed=int(rng.integers(1 << 30)), lo=-3 if bdt != vi.U8 else 0, hi=9)
+    dbi = DeviceImage.from_host(bim); orc.orc_blockwise_maxima_filter(P(bim.desc), bs)
+    capi.check(lib.vpp_blockwise_maxima_filter(P(dbi.desc), bs, capi.stream_ptr())); capi.check(lib.vpp_sync(capi.stream_ptr()))
+    ok = np.array_equal(dbi.download().raw.view(np.uint8), bim.raw.view(np.uint8))
+    print(f"blockwise_maxima {nr}x{nc} dtype={bdt} bs={bs}: {'ok' if ok else 'MISMATCH'}"); bad += not ok
+    # video_extruder's merge against the serial champion loop
+    from test_gpu_video_steps import _merge_model
+    n, mr, mc, sp = int(rng.integers(1, 6000)), int(rng.integers(8, 300)), int(rng.integers(8, 300)), int(rng.integers(1, 40))
+    prev = np.stack([rng.integers(0, mr, n), rng.integers(0, mc, n)], 1).astype(np.int32)
+    moved = (prev + rng.integers(-9, 10, size=prev.shape)).astype(np.int32); matched = (rng.random(n) < 0.8).astype(np.uint8); moved[matched == 0] = prev[matched == 0]
+    age_prev = rng.integers(0, int(rng.integers(1, 12)) + 1, n).astype(np.int32)
+    inside = (moved[:, 0] >= 0) & (moved[:, 0] < mr) & (moved[:, 1] >= 0) & (moved[:, 1] < mc)
+    pos = np.where(((matched == 1) & inside)[:, None], moved, prev); age = np.where(matched == 1, np.where(inside, age_prev + 1, 0), age_prev).astype(np.int32)
+    want = _merge_model(pos, age, sp, mr, mc)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dm, dp, dmt, da = t(moved), t(prev), t(matched), t(age_prev); out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    capi.check(lib.vpp_keypoint_merge(V(dm.data_ptr()), V(dp.data_ptr()), V(dmt.data_ptr()), V(da.data_ptr()), n, mr, mc, sp, V(out.data_ptr()), capi.stream_ptr()))
+    ok = np.array_equal(out.cpu().numpy(), want)
+    print(f"merge n={n} {mr}x{mc} spacing={sp}: removed={int(want.sum())} {'ok' if ok else 'MISMATCH'}"); bad += not ok
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

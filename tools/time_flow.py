@@ -7,6 +7,7 @@ from util import P, u8_image, DeviceImage
 from vpp_amd import capi
 from test_gpu_sdof import flow_scene
 V = ctypes.c_void_p
+if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]  # A/B timing of two builds in ONE gpurun call (boxes differ by ~10 %)
 lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
 s1, s2, sk = flow_scene(2160, 3840, spacing=10)
 e1, e2 = DeviceImage.from_host(u8_image(s1, border=3)), DeviceImage.from_host(u8_image(s2, border=3))

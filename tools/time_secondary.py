@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from util import P, rand_image, DeviceImage
 from vpp_amd import capi, image as vi
+if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]  # A/B timing of two builds in ONE gpurun call (boxes differ by ~10 %)
 lib = capi.lib(); capi.check(lib.vpp_init(0))
 def time_graph(launch, steps=200):
     for i in range(10): launch(i, capi.stream_ptr())

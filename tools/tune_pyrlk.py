@@ -7,6 +7,7 @@ import pyr
 from util import P, u8_image, DeviceImage, texture, translate
 from vpp_amd import capi, image as vi
 V = ctypes.c_void_p
+if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]  # A/B timing of two builds in ONE gpurun call (boxes differ by ~10 %)
 lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
 NR, NC, L, B = 1080, 1920, 3, 3
 tex = texture(NR, NC, seed=5)
