@@ -362,9 +362,9 @@ __device__ __forceinline__ int distance_g(const FramePair& f, int a0, int a1, in
     return err;
   }
 }
-template <int WS>
+template <int WS, int MAXT>
 __device__ __noinline__ int distance_outlined(FramePair f, int a0, int a1, int b0, int b1, int ws, int th) { return distance_g<WS>(f, a0, a1, b0, b1, ws, th); }
-template <int WS>
+template <int WS, int MAXT>
 __device__ __noinline__ GdMatch gradient_descent_outlined(FramePair f, int ws, int p0, int p1, int pr0, int pr1, int max_iteration) {
   if constexpr (WS != 0) {
     // every candidate of the descent is compared with the same window of frame 1: it is loaded once, a candidate costs the
@@ -414,7 +414,7 @@ __device__ __forceinline__ Cell load_map_cell_coherent(const MapsG& m, int ci, i
   return c;
 }
 
-template <int WS>
+template <int WS, int MAXT>
 __device__ __noinline__ SlowResult sweep_slow_path(FramePair f, MapsG m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc) {
   Cell nb8[8];
   int k = 0;
@@ -436,8 +436,8 @@ __device__ __noinline__ SlowResult sweep_slow_path(FramePair f, MapsG m, int ws,
     loc[q] = PairCache{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]};
   }
   auto nbr = [&](int dr, int dc) -> Cell { return nb8[(dr + 1) * 3 + (dc + 1) - ((dr > 0 || (dr == 0 && dc > 0)) ? 1 : 0)]; };
-  auto dist = [&](int r2, int c2) { return distance_outlined<WS>(f, r, c, r2, c2, ws, INT_MAX); };
-  auto gd = [&](int r2, int c2) { return gradient_descent_outlined<WS>(f, ws, r, c, r2, c2, 5); };
+  auto dist = [&](int r2, int c2) { return distance_outlined<WS, MAXT>(f, r, c, r2, c2, ws, INT_MAX); };
+  auto gd = [&](int r2, int c2) { return gradient_descent_outlined<WS, MAXT>(f, ws, r, c, r2, c2, 5); };
   const bool changed = loop_body<false>(r, c, cur, nbr, loc, dist, gd);
   return SlowResult{cur, changed ? 1 : 0};
 }
@@ -450,8 +450,8 @@ __device__ __noinline__ SlowResult sweep_slow_path(FramePair f, MapsG m, int ws,
 // whole (one 16-byte LDS read, one barrier); only the other groups are walked step by step with a barrier per step.
 __device__ unsigned g_sweep_stats[4];  // [0] unused, [1] Jacobi outcomes applied, [2] slow-path recomputations, [3] slow-path changes
 
-template <int WS>
-__global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward,
+template <int WS, int MAXT>
+__global__ __launch_bounds__(MAXT) void sdof_propagate_ring_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward,
                                                                    const Cell* __restrict__ J, PairCache* __restrict__ pairs,
                                                                    const uint8_t* __restrict__ skew, int NIp, int stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [kRingGroups][NIp][16]
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(1024) void sdof_propagate_ring_kernel(DImg i1, DImg
             if (stats) atomicAdd(&g_sweep_stats[1], 1u);
           } else {
             const int pr = forward ? ci * patch : i1.nr - 1 - (NI - 1 - ci) * patch, pcol = forward ? cj * patch : i1.nc - 1 - (NJ - 1 - cj) * patch;
-            const SlowResult sr = sweep_slow_path<WS>(FramePair{(gcu8)i1.p0, (gcu8)i2.p0, i1.pitch, i2.pitch, i1.nr, i1.nc, i2.nr, i2.nc},
+            const SlowResult sr = sweep_slow_path<WS, MAXT>(FramePair{(gcu8)i1.p0, (gcu8)i2.p0, i1.pitch, i2.pitch, i1.nr, i1.nc, i2.nr, i2.nc},
                                                       MapsG{(const VPP_GLOBAL int32_t*)m.flow.p0, (const VPP_GLOBAL uint8_t*)m.mark.p0, (const VPP_GLOBAL int32_t*)m.dist.p0, m.flow.pitch, m.mark.pitch, m.dist.pitch},
                                                       ws, pr, pcol, ci, cj, NI, NJ, (const VPP_GLOBAL PairCache*)(pairs + ((size_t)ci * NJ + cj) * 8));
             cur = sr.cell; changed = sr.changed != 0;
@@ -638,7 +638,10 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
           const size_t lds = (size_t)kRingGroups * threads * kGroupSteps;
           for (int Ki = 0; Ki < propagation; Ki++) {
             sdof_jacobi_kernel<WS><<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs, skew, threads);
-            sdof_propagate_ring_kernel<WS><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
+            // a workgroup of at most 512 threads may use 256 registers per lane: the out-of-line recomputation then keeps its cells and
+            // pair-cache entries in registers instead of scratch memory (4K frames: 448 threads)
+            if (threads <= 512) sdof_propagate_ring_kernel<WS, 512><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
+            else sdof_propagate_ring_kernel<WS, 1024><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
           }
         } else
           sdof_propagate_kernel<WS><<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, propagation);
