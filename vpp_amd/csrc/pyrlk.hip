@@ -160,6 +160,21 @@ __device__ Match lk_match(float p0, float p1, float tr0, float tr1, const DImg& 
   return Match{v0 - p0, v1 - p1, err / (cpt)};                        // lucas_kanade.hpp:128
 }
 
+// The iteration test `norm(nk) >= delta` (lk.hh:116, Eigen: sqrt of the squared norm) without the square root: sqrtf is
+// correctly rounded and monotonic, so { x : sqrtf(x) >= delta } is [T, inf) for the smallest such float T, found once per
+// launch by stepping from delta * delta over its neighbours (T = NaN-safe: a NaN delta makes every comparison false, as in the
+// literal form; delta <= 0 gives T = 0).
+__device__ __forceinline__ float norm_threshold(float delta) {
+  if (!(delta > 0.f)) return delta <= 0.f ? 0.f : delta;
+  float t = delta * delta;
+  for (int k = 0; k < 8 && sqrtf(t) < delta && t < INFINITY; k++) t = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, t) + 1u);
+  for (int k = 0; k < 8 && t > 0.f; k++) {
+    const float p = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, t) - 1u);
+    if (sqrtf(p) >= delta) t = p; else break;
+  }
+  return t;  // delta * delta is within two ulps of T: the eight steps each way always settle (checked over 2000 random and the extreme deltas)
+}
+
 // ---- LPK lanes per keypoint --------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in program order; this keeps the compiler from moving them across the hand-off
@@ -171,7 +186,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <int WS, class GT, bool PYRLK, int LPK>
 __device__ Match lk_match_group(  // WS*WS <= 64
     float p0, float p1, float tr0, float tr1, const DImg& A_, const DImg& B_, const DImg& Ag_, float min_ev_th,
-                                int max_it, float delta, float* lds, int gl) {
+                                int max_it, float delta, float* lds, int gl, float norm_T) {
   constexpr int hws = WS / 2, N = WS * WS, PPL = (N + LPK - 1) / LPK;
   // the level's descriptors by value: the callers index a kernel-argument array with the (runtime) level, and through the
   // references every use inside the iteration loop was a fresh scalar load + wait
@@ -259,7 +274,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
 
   float v0 = p0 + tr0, v1 = p1 + tr1;
   float nk0 = 1.f, nk1 = 1.f;
-  for (int k = 0; k <= max_it && sqrtf(nk0 * nk0 + nk1 * nk1) >= delta; k++) {  // lk.hh:116
+  for (int k = 0; k <= max_it && (nk0 * nk0 + nk1 * nk1) >= norm_T; k++) {  // lk.hh:116 (norm >= delta, see norm_threshold)
     const bool b_safe = window_inside(B, v0, v1, hws);
     wave_lds_fence();  // the previous pass' reads are done before its terms are overwritten
     if (b_safe && all_valid) {
@@ -361,10 +376,11 @@ __global__ __launch_bounds__(64) void pyrlk_match_group_kernel(Pyr P, Pyr G, Pyr
   vpp_keypoint_f32 kp = kps[i];
   if (!(kp.age > 0)) { if (out_dist && gl == 0) out_dist[i] = 0.f; return; }
   float tr0 = 0.f, tr1 = 0.f, dist = 0.f;
+  const float norm_T = norm_threshold(delta);
   for (int S = nlevels - 1; S >= min_scale; S--) {
     tr0 *= 2.f; tr1 *= 2.f;
     const float sc = (float)(1 << S);
-    const Match m = lk_match_group<WS, float, true, LPK>(kp.pos_r / sc, kp.pos_c / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, max_it, delta, lds, gl);
+    const Match m = lk_match_group<WS, float, true, LPK>(kp.pos_r / sc, kp.pos_c / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, max_it, delta, lds, gl, norm_T);
     if (m.err < max_err) { tr0 = m.f0; tr1 = m.f1; }
     dist = m.err;
   }
@@ -390,10 +406,11 @@ __global__ __launch_bounds__(64) void lucas_kanade_group_kernel(Pyr P, Pyr G, Py
   const float d = (float)(1 << nlevels);
   float tr0 = (pred ? pred[2 * i] : 0.f) / d, tr1 = (pred ? pred[2 * i + 1] : 0.f) / d;
   float dist = 0.f;
+  const float norm_T = norm_threshold(delta);
   for (int S = nlevels - 1; S >= 0; S--) {
     tr0 *= 2.f; tr1 *= 2.f;
     const float sc = (float)(1 << S);
-    const Match m = lk_match_group<WS, int32_t, false, LPK>(k0 / sc, k1 / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, niter, delta, lds, gl);
+    const Match m = lk_match_group<WS, int32_t, false, LPK>(k0 / sc, k1 / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, niter, delta, lds, gl, norm_T);
     tr0 = m.f0; tr1 = m.f1; dist = m.err;
   }
   if (gl != 0) return;
