@@ -6,6 +6,7 @@ import numpy as np, torch
 from util import P, u8_image, DeviceImage, rects_image
 from vpp_amd import capi
 V = ctypes.c_void_p
+if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]
 lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
 im = u8_image(rects_image(2160, 3840, seed=4), border=3)
 im.view(with_border=True)[..., 0] = np.pad(im.view()[..., 0], 3, mode="symmetric")
