@@ -286,8 +286,24 @@ static void test_dense_fast_and_blockwise_maxima() {
   CHECK(S(3, 4) == 7 && S(5, 5) == 0 && S(2, 2) == 0 && S(12, 13) == 2 && S(15, 3) == 0);
 }
 
+// antialiasing_lowpass_filter / subsample2 / antialias_subsample2 (pyramid.hh:12-123) against the fused pyramid step
+static void test_pyramid_free_functions() {
+  image2d<unsigned char> in(37, 52, _border = 2);
+  unsigned x = 7u;
+  for (auto p : in.domain()) { x = x * 1664525u + 1013904223u; in(p) = (unsigned char)(x >> 24); }
+  fill_border_mirror(in);
+  pyramid2d<unsigned char> pyr(in, 2, 2, _border = 2);
+  image2d<unsigned char> low(in.domain(), _border = 1), half(1 + 37 / 2, 1 + 52 / 2);  // subsample2 reads low(2r, 2c) up to (36, 52): one column into the border, like the reference
+  antialiasing_lowpass_filter(in, low);
+  subsample2(low, half);   // reads low(2r, 2c): inside the domain for 2r < 37, 2c < 52
+  image2d<unsigned char> as2 = antialias_subsample2(in);
+  CHECK(as2.nrows() == 19 && as2.ncols() == 27 && as2.border() == 2);
+  for (int r = 0; 2 * r < 37; r++) for (int c = 0; 2 * c < 52; c++) { CHECK(half(r, c) == pyr[1](r, c)); CHECK(as2(r, c) == pyr[1](r, c)); }
+}
+
 int main() {
   CHECK(vpp_init(0) == 0);
+  test_pyramid_free_functions();
   test_dense_fast_and_blockwise_maxima();
   test_lbp();
   test_frame_ingest();

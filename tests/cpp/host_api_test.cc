@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vpp/vpp.hh>
+#include <vpp/algorithms/optical_flow/gradient_descent.hh>
 
 using namespace vpp;
 
@@ -208,7 +209,27 @@ static void test_keypoint_index_is_the_eager_one() {
   }
 }
 
+// gradient_descent_match with an opaque distance (gradient_descent.hh:10-89) and the pyramid's sampling helpers (pyramid.hh:62-103)
+static void test_gradient_descent_and_samplers() {
+  const vint2 target(7, -3);
+  int calls = 0;
+  auto dist = [&](vint2, vint2 q, int) { calls++; const vint2 d = q - target; return std::abs(d[0]) + std::abs(d[1]); };
+  auto m = gradient_descent_match(vint2(0, 0), vint2(5, -1), dist, 10);
+  CHECK(m.flow == target && m.distance == 0);                                  // two diagonal moves, then a round without improvement
+  auto far = gradient_descent_match(vint2(0, 0), vint2(0, 0), dist, 3);
+  CHECK(far.distance == 4 && far.flow == vint2(3, -3));                       // limited to three rounds: one diagonal step per round
+  auto flat = gradient_descent_match(vint2(2, 2), vint2(9, 9), [](vint2, vint2, int) { return 5; }, 10);
+  CHECK(flat.flow == vint2(7, 7) && flat.distance == 5);                      // no strict improvement anywhere: stays on the prediction
+  image2d<int> big(6, 8, _border = 1), half(3, 4), third(2, 3);
+  for (auto p : big.domain()) big(p) = p[0] * 10 + p[1];
+  subsample2(big, half);
+  CHECK(half(0, 0) == 0 && half(1, 3) == 26 && half(2, 1) == 42);
+  subsample(big, third, 2.5f);
+  CHECK(third(0, 0) == 0 && third(1, 2) == 25 && third(1, 1) == 22);          // int(1 * 2.5) = 2, int(2 * 2.5) = 5
+}
+
 int main() {
+  test_gradient_descent_and_samplers();
   test_keypoint_index_is_the_eager_one();
   test_image3d_and_iterators();
   test_colorspace_conversions();

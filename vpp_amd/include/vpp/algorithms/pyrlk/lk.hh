@@ -3,4 +3,6 @@
 #pragma once
 namespace vpp {
 template <unsigned WS> struct lk_match_point_square_win { enum { window_size = WS }; };
+// the direction-constrained variant of the reference (lk.hh:24-41,181-): no algorithm on the replaced path uses it; a tag only
+template <unsigned WS> struct oriented_lk_match_point_square_win { enum { window_size = WS }; };
 }  // namespace vpp

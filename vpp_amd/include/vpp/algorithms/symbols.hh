@@ -8,6 +8,10 @@ VPP_DEFINE_SYMBOL(scores)
 VPP_DEFINE_SYMBOL(local_maxima)
 VPP_DEFINE_SYMBOL(blockwise)
 VPP_DEFINE_SYMBOL(max_points_per_block)
+// accepted for source compatibility; the epipolar variants of semi_dense_optical_flow are not implemented
+VPP_DEFINE_SYMBOL(fundamental_matrix)
+VPP_DEFINE_SYMBOL(epipolar_flow)
+VPP_DEFINE_SYMBOL(epipolar_filter)
 VPP_DEFINE_SYMBOL(keypoints)
 VPP_DEFINE_SYMBOL(niterations)
 VPP_DEFINE_SYMBOL(winsize)

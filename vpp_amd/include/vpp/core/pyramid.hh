@@ -2,11 +2,42 @@
 // update / propagate_level0 protocol are the reference's; the per-level work (5-tap binomial low-pass + subsample2 +
 // mirror border, pyramid.hh:12-81) is the gfx950 kernel behind vpp_pyr_down.  Factor 2 only (what the hot path uses).
 #pragma once
+#include <algorithm>
 #include <vector>
+#include <vpp/core/clone.hh>
 #include <vpp/core/copy.hh>
 #include <vpp/core/fill.hh>
 
 namespace vpp {
+
+// The free functions the pyramid is made of (pyramid.hh:12-123).  The low-pass runs on the device (vpp_lowpass5: both passes and
+// the mirror of the temporary in one kernel); the two samplers are plain index maps evaluated by the host engine like any other
+// opaque pixel_wise kernel (the pyramid itself never calls them: vpp_pyr_down computes only the samples subsample2 keeps).
+template <class V> void antialiasing_lowpass_filter(const image2d<V>& in, image2d<V>& out) {  // :12-59, `in` needs a border of 2
+#ifdef VPP_AMD_DEVICE
+  const vpp_image_desc di = in.device_desc(false), dout = out.device_desc(true);
+  device::check(vpp_lowpass5(&dout, &di, device::stream()), "vpp_lowpass5");
+#else
+  static_assert(sizeof(V) == 0, "antialiasing_lowpass_filter runs on the device: build with -DVPP_AMD_DEVICE and link libvpp_amd");
+#endif
+}
+template <class V> void subsample2(const image2d<V>& in, image2d<V>& out) {  // :62-81: out(r, c) = in(2r, 2c), no bounds check in the reference either
+  for (int r = 0; r < out.nrows(); r++) for (int c = 0; c < out.ncols(); c++) out(r, c) = in(r * 2, c * 2);
+}
+template <class V> void subsample(const image2d<V>& in, image2d<V>& out, float factor) {  // :84-103
+  for (int r = 0; r < out.nrows(); r++) for (int c = 0; c < out.ncols(); c++) out(r, c) = in(int(r * factor), int(c * factor));
+}
+template <class V> image2d<V> antialias_subsample2(const image2d<V>& in) {  // :105-123
+  auto tmp = clone(in, _border = std::max(in.border(), 1));
+  fill_border_mirror(tmp);
+  image2d<V> in2 = in;
+  if (in2.border() < 2) { in2 = clone(in2, _border = 2); fill_border_mirror(in2); }
+  antialiasing_lowpass_filter(in2, tmp);
+  image2d<V> tmp2(1 + (in.nrows() / 2), 1 + (in.ncols() / 2), _border = std::max(in.border(), 0));
+  subsample2(tmp, tmp2);
+  fill_border_mirror(tmp2);
+  return tmp2;
+}
 
 template <class V, unsigned N> struct pyramid {
   typedef imageNd<V, N> image_type;
