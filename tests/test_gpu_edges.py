@@ -91,3 +91,32 @@ def test_sdof_single_and_duplicate_keypoints(lib, orc):
         got, want = run_both(lib, orc, f1, f2, kps, 7, 3, 0, 2, 5)
         for g, w in zip(got, want):
             np.testing.assert_array_equal(g, w)
+
+
+def test_8k_frames_box_add_ingest(lib):
+    """Twice the BASELINE frame size in each direction (7680 x 4320): index arithmetic and grid sizes beyond the bench shapes.
+    Checked through properties: sampled pixels against numpy, row sums, and the fused ingest against its two steps' definition."""
+    nr, nc = 4320, 7680
+    rng = np.random.default_rng(3)
+    src = rand_image(nr, nc, vi.U8, 3, border=2, seed=41, fill_border=True)
+    dsrc = DeviceImage.from_host(src); ddst = DeviceImage(nr, nc, vi.U8, 3)
+    capi.check(lib.vpp_box_filter(P(ddst.desc), P(dsrc.desc), 5, 5, capi.stream_ptr()))
+    capi.check(lib.vpp_sync(capi.stream_ptr()))
+    out = ddst.download().view()
+    s = src.view(with_border=True).astype(np.int64)
+    for r, c in [(0, 0), (nr - 1, nc - 1), (0, nc - 1), (nr - 1, 0)] + [(int(rng.integers(nr)), int(rng.integers(nc))) for _ in range(200)]:
+        np.testing.assert_array_equal(out[r, c], s[r:r + 5, c:c + 5].sum(axis=(0, 1)) // 25)
+    # int32 add: A = B + C everywhere (image_add.cc:21-28)
+    b = rand_image(nr, nc, vi.I32, seed=5, lo=0, hi=2**30 - 1)
+    db = DeviceImage.from_host(b); da = DeviceImage(nr, nc, vi.I32)
+    capi.check(lib.vpp_pixelwise_binary(0, P(da.desc), P(db.desc), P(db.desc), capi.stream_ptr()))
+    capi.check(lib.vpp_sync(capi.stream_ptr()))
+    np.testing.assert_array_equal(da.download().view(), b.view() * 2)
+    # frame ingest: gray = (r + g + b) / 3, border = gray of the mirrored pixel
+    dg = DeviceImage(nr, nc, vi.U8, 1, border=3)
+    rgb = rand_image(nr, nc, vi.U8, 3, border=0, seed=43)
+    drgb = DeviceImage.from_host(rgb)
+    capi.check(lib.vpp_rgb_to_graylevel(P(dg.desc), P(drgb.desc), 1, capi.stream_ptr()))
+    capi.check(lib.vpp_sync(capi.stream_ptr()))
+    want = (rgb.view().astype(np.int32).sum(axis=2) // 3).astype(np.uint8)
+    np.testing.assert_array_equal(dg.download().view(with_border=True)[..., 0], np.pad(want, 3, mode="symmetric"))
