@@ -120,3 +120,16 @@ def test_8k_frames_box_add_ingest(lib):
     capi.check(lib.vpp_sync(capi.stream_ptr()))
     want = (rgb.view().astype(np.int32).sum(axis=2) // 3).astype(np.uint8)
     np.testing.assert_array_equal(dg.download().view(with_border=True)[..., 0], np.pad(want, 3, mode="symmetric"))
+
+
+def test_8k_fast9_matches_oracle(lib, orc):
+    """FAST-9 on a 7680 x 4320 frame (four times the BASELINE frame), raw and blockwise, bit-exact against the oracle."""
+    im = u8_image(rects_image(4320, 7680, seed=9), border=3)
+    im.view(with_border=True)[..., 0] = np.pad(im.view()[..., 0], 3, mode="symmetric")
+    d = DeviceImage.from_host(im)
+    for mode in (0, 2):
+        want_rc, want_sc = run_detect(orc, im, 25, mode=mode, bs=10, compat=0, cap=8000000)
+        got_rc, got_sc = gpu_detect(lib, d, 25, mode=mode, bs=10, compat=0, cap=8000000)
+        assert len(want_rc) > 10000
+        np.testing.assert_array_equal(got_rc, want_rc)
+        np.testing.assert_array_equal(got_sc, want_sc)

@@ -87,3 +87,15 @@ def test_sdof_4k_bench_scene_matches_oracle(lib, orc):
     assert want[2].mean() > 0.9
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
+
+
+@pytest.mark.parametrize("ws", [7, 9])
+def test_sdof_tall_map_uses_the_1024_thread_instance(lib, orc, ws):
+    """A flow map taller than 512 cells (1700 rows at patchsize 3: 567 cells) runs the ordered sweep in its 1024-thread instance
+    (out-of-line recomputation, 128 registers per lane) instead of the 512-thread one every smaller frame uses; taller than 1024
+    cells (patchsize 1 would be) falls to the generic wavefront kernel, covered by sdof.propagate = 1 elsewhere."""
+    f1, f2, kps = flow_scene(1700, 90, seed=11 + ws, spacing=3)
+    got, want = run_both(lib, orc, f1, f2, kps, ws, 2, 0, 2, 3)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    assert int(want[2].sum()) > 1000
