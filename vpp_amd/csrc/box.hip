@@ -286,6 +286,171 @@ __global__ __launch_bounds__(256, (RW <= 2 ? 8 : RW <= 4 ? 6 : 4)) void box_u8_s
     box_u8_stream_body<CH, KR, KC, RW, NT, false, PROBE>(dp, sp, dpitch, spitch, nrows, row_bytes, border_bytes, x, r0, writer);
 }
 
+// ---- line-aligned variant of the streaming kernel ------------------------------------------------------------------
+// Same arithmetic, different geometry: a wave owns 1024 OUTPUT bytes per row (all 64 lanes store 16 B, so every wave-row
+// store covers eight whole 128-B lines of an aligned destination instead of splitting a sector with the neighbouring
+// strip).  The 8 halo bytes the edge lanes miss come from one extra 8-B load per input row issued by lanes 0 and 63 only
+// (the line belongs to the neighbouring wave of the same workgroup, which requests it at the same time); their column
+// sums live in the same two register pairs (left halo in lane 0, right halo in lane 63) and enter the window as the
+// `old` operand of the DPP wave shifts, which lane 0 / lane 63 keep because their source lane does not exist.
+// A workgroup is WX waves side by side x 4/WX row blocks; ORDER 0 walks the block grid row-major (the WX-wide blocks
+// of one row band run together on one XCD), ORDER 1 strip-major like the kernel above.
+__device__ __forceinline__ uint32_t from_left_or(uint32_t old, uint32_t v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t from_right_or(uint32_t old, uint32_t v) { return __builtin_amdgcn_update_dpp(old, v, 0x130, 0xf, 0xf, false); }
+
+enum { kStoreDefault = 0, kStoreNT = 1, kStoreSC1 = 2, kStoreSC01 = 3, kStoreNTSC1 = 4 };
+// cache-policy bits of the buffer instructions (aux operand): sc0 = 1, nt = 2, sc1 = 16
+enum { kAuxDefault = 0, kAuxSC0 = 1, kAuxNT = 2, kAuxSC1 = 16 };
+
+// Buffer descriptors instead of flat pointers: (1) the row term of every address is a scalar offset and the lane term ONE
+// 32-bit register shared by all row loads — no 64-bit address arithmetic or address register pairs; (2) the hardware range
+// check (gfx950: per dword, scalar offset included, a negative offset reads as 0 — tools/buftest.hip) replaces every guard:
+// the source descriptor spans exactly [16 bytes before the first addressable row, end of the last addressable 16-byte
+// granule], so rows below the bottom border and chunks past the last row read as 0 and never fault, and there is no
+// separate code path for the row blocks that touch the allocation's first / last row.
+struct BoxGeom {
+  const uint8_t* sbase;   // 16 bytes before byte 0 of row -border
+  uint8_t* dbase;         // byte 0 of row 0
+  uint32_t sbytes, dbytes;
+  int spitch, dpitch, nrows, row_bytes, srow0;  // srow0: first addressable row (-border) as a row index offset: row r sits at (r + srow0) * spitch + 16
+  int nbx, nby, nhi, order;
+};
+
+// HALO = true: 1024-B line-aligned strips with halo loads (above); HALO = false: the 992-B strips of the first streaming
+// kernel (lanes 0 / 63 only feed their neighbours).  `rw` <= RW is the number of output rows of THIS wave (wave-uniform):
+// the launcher mixes row blocks of RW and RW - 1 rows so that the whole grid is resident in one round.
+template <int CH, int KR, int KC, int RW, int SAUX, int LAUX, bool HALO, int PROBE>
+__device__ __forceinline__ void box_u8_wide_body(const BoxGeom& g, int x0, int r0, int rw, int lane) {
+  constexpr int HR = KR / 2, NR = RW + KR - 1;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.sbase, 0, g.sbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)g.dbase, 0, g.dbytes, 0x00020000);
+  const int x = HALO ? x0 + lane * 16 : x0 - 16 + lane * 16;
+  const uint32_t vo = (uint32_t)(min(x, (g.row_bytes + 15) & ~15) + 16);   // lanes past the chunk that holds the right border re-read it (their sums feed nobody)
+  const int srow = (r0 - HR + g.srow0) * g.spitch;               // scalar offset of the wave's first input row
+  u32x4 raw[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    if (k < NR - 1 || rw == RW) raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, srow + k * g.spitch, LAUX);   // the last row only feeds output row RW - 1
+    else raw[k] = u32x4{0, 0, 0, 0};
+  }
+  u32x2 hraw[HALO ? NR : 1];
+  if constexpr (HALO) {
+    // halo chunk of the edge lanes: bytes [x0 - 8, x0) for lane 0, [x0 + 1024, x0 + 1032) for lane 63
+    const int hx = lane == 0 ? x0 - 8 : x0 + 1024;
+    const bool halo_lane = PROBE != 2 && (lane == 0 || lane == 63) && hx < g.row_bytes + 8;
+#pragma unroll
+    for (int k = 0; k < NR; k++) hraw[k] = u32x2{0, 0};
+    if (halo_lane) {
+#pragma unroll
+      for (int k = 0; k < NR; k++) hraw[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)(hx + 16), srow + k * g.spitch, 0);
+    }
+  }
+  auto unpack = [](const u32x4& w, uint32_t* e, uint32_t* o) {
+    const uint32_t d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { e[i] = __builtin_amdgcn_perm(0u, d[i], 0x0c020c00u); o[i] = __builtin_amdgcn_perm(0u, d[i], 0x0c030c01u); }
+  };
+  auto unpack2 = [](const u32x2& w, uint32_t* e, uint32_t* o) {
+    e[0] = __builtin_amdgcn_perm(0u, w.x, 0x0c020c00u); o[0] = __builtin_amdgcn_perm(0u, w.x, 0x0c030c01u);
+    e[1] = __builtin_amdgcn_perm(0u, w.y, 0x0c020c00u); o[1] = __builtin_amdgcn_perm(0u, w.y, 0x0c030c01u);
+  };
+  uint32_t E[4] = {0, 0, 0, 0}, O[4] = {0, 0, 0, 0}, HE[2] = {0, 0}, HO[2] = {0, 0};
+#pragma unroll
+  for (int k = 0; k < KR - 1; k++) {
+    uint32_t e[4], o[4];
+    unpack(raw[k], e, o);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { E[i] += e[i]; O[i] += o[i]; }
+    if constexpr (HALO) {
+      uint32_t he[2], ho[2];
+      unpack2(hraw[k], he, ho);
+#pragma unroll
+      for (int i = 0; i < 2; i++) { HE[i] += he[i]; HO[i] += ho[i]; }
+    }
+  }
+  const bool writer = HALO ? x < g.row_bytes : (lane >= 1 && lane <= 62 && x < g.row_bytes);
+  const bool full_store = x + 16 <= g.row_bytes;
+#pragma unroll
+  for (int j = 0; j < RW; j++) {
+    const int r = r0 + j;
+    if (j >= rw || r >= g.nrows) break;
+    {
+      uint32_t e[4], o[4];
+      unpack(raw[j + KR - 1], e, o);
+#pragma unroll
+      for (int i = 0; i < 4; i++) { E[i] += e[i]; O[i] += o[i]; }
+      if constexpr (HALO) {
+        uint32_t he[2], ho[2];
+        unpack2(hraw[j + KR - 1], he, ho);
+#pragma unroll
+        for (int i = 0; i < 2; i++) { HE[i] += he[i]; HO[i] += ho[i]; }
+      }
+    }
+    // 32-byte window of column sums: [left neighbour's bytes 8..15 (lane 0: its halo) | own 16 | right neighbour's bytes 0..7 (lane 63: its halo)]
+    uint32_t WE[8], WO[8];
+    if constexpr (HALO) {
+      WE[0] = from_left_or(HE[0], E[2]); WE[1] = from_left_or(HE[1], E[3]); WE[6] = from_right_or(HE[0], E[0]); WE[7] = from_right_or(HE[1], E[1]);
+      WO[0] = from_left_or(HO[0], O[2]); WO[1] = from_left_or(HO[1], O[3]); WO[6] = from_right_or(HO[0], O[0]); WO[7] = from_right_or(HO[1], O[1]);
+    } else {
+      WE[0] = from_left(E[2]); WE[1] = from_left(E[3]); WE[6] = from_right(E[0]); WE[7] = from_right(E[1]);
+      WO[0] = from_left(O[2]); WO[1] = from_left(O[3]); WO[6] = from_right(O[0]); WO[7] = from_right(O[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { WE[2 + i] = E[i]; WO[2 + i] = O[i]; }
+    u32x4 res;
+    res.x = out_dword<0, CH, KC, KR * KC>(WE, WO); res.y = out_dword<1, CH, KC, KR * KC>(WE, WO);
+    res.z = out_dword<2, CH, KC, KR * KC>(WE, WO); res.w = out_dword<3, CH, KC, KR * KC>(WE, WO);
+    if (PROBE == 1) res = raw[j + HR];  // measurement probes: 1 = copy (the unused row loads are dropped by the compiler), 2 = arithmetic without the halo loads, 3 = all loads, no arithmetic
+    if (PROBE == 3) { res = raw[j + HR]; for (int k = 0; k < NR; k++) { res.x ^= raw[k].y; if constexpr (HALO) res.x ^= hraw[k].x ^ hraw[k].y; } }
+    if (writer) {
+      if (full_store) __builtin_amdgcn_raw_buffer_store_b128(res, rd, (uint32_t)x, r * g.dpitch, SAUX);
+      else {  // the row's last, partial chunk (row_bytes % 16 != 0): dwords, then bytes
+        const int n = g.row_bytes - x;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t d = k == 0 ? res.x : k == 1 ? res.y : k == 2 ? res.z : res.w;
+          if (4 * k + 4 <= n) __builtin_amdgcn_raw_buffer_store_b32(d, rd, (uint32_t)(x + 4 * k), r * g.dpitch, 0);
+          else
+            for (int b = 0; b < 3; b++)
+              if (4 * k + b < n) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(d >> (8 * b)), rd, (uint32_t)(x + 4 * k + b), r * g.dpitch, 0);
+        }
+      }
+    }
+    if (j + 1 < RW) {
+      uint32_t e[4], o[4];
+      unpack(raw[j], e, o);  // the row leaving the window
+#pragma unroll
+      for (int i = 0; i < 4; i++) { E[i] -= e[i]; O[i] -= o[i]; }
+      if constexpr (HALO) {
+        uint32_t he[2], ho[2];
+        unpack2(hraw[j], he, ho);
+#pragma unroll
+        for (int i = 0; i < 2; i++) { HE[i] -= he[i]; HO[i] -= ho[i]; }
+      }
+    }
+  }
+}
+
+// nby row blocks per strip: the first nhi have RW rows, the others RW - 1 (nhi == nby: all RW)
+template <int CH, int KR, int KC, int RW, int WX, int SAUX, int LAUX, bool HALO, int OCC, int PROBE>
+__global__ __launch_bounds__(256, OCC) void box_u8_wide_kernel(const BoxGeom g) {
+  static_assert(CH >= 1 && CH <= 4 && (WX == 1 || WX == 2 || WX == 4), "window holds 2*CH <= 8 halo bytes; 4 waves per workgroup");
+  constexpr int WY = 4 / WX;
+  const unsigned nb = (unsigned)g.nbx * (unsigned)g.nby;
+  const unsigned lb = (g.order & 2) ? blockIdx.x : xcd_remap(blockIdx.x, nb);
+  int bx, by;
+  if ((g.order & 1) == 0) { by = lb / g.nbx; bx = lb - by * g.nbx; } else { bx = lb / g.nby; by = lb - bx * g.nby; }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wx = wv % WX, wy = wv / WX;
+  // the wave id is uniform but the compiler cannot prove it: readfirstlane keeps everything derived from it in SGPRs
+  const int x0 = __builtin_amdgcn_readfirstlane((bx * WX + wx) * (HALO ? 1024 : kStripOut));
+  const int yb = __builtin_amdgcn_readfirstlane(by * WY + wy);       // row block of this wave
+  const int r0 = yb * (RW - 1) + min(yb, g.nhi);
+  const int rw = yb < g.nhi ? RW : RW - 1;
+  if (x0 >= g.row_bytes || r0 >= g.nrows) return;
+  box_u8_wide_body<CH, KR, KC, RW, SAUX, LAUX, HALO, PROBE>(g, x0, r0, rw, lane);
+}
+
 // ---- 32-bit 5x5: int / unsigned (the element type of the reference's own benchmark, benchmarks/box_5x5_filter.cc:165-171,187-191)
 //      and float (taps added in the reference's order) ----
 // Same shape as the u8 streaming kernel with one pixel per dword: a lane owns 4 consecutive pixels (16 B), keeps their
@@ -509,13 +674,91 @@ int launch_generic(const vpp_image_desc* dst, const vpp_image_desc* src, int R, 
   return VPP_OK;
 }
 
+// second streaming kernel (5x5): geometry and cache policy from the tuning knobs; the lab build (tools/boxlab.hip,
+// -DVPP_BOX_LAB) instantiates the sweep for CH == 3, the product only the configuration the sweep picked.
+// rows: RW rows per wave; mix = 1: row blocks of RW and RW - 1 rows mixed so that nstrips * nblocks <= `slots` waves (the whole
+// grid resident in one round: slots = CUs x 32 wave slots at 8 waves / SIMD).
+inline bool fits_descriptor(const vpp_image_desc* dst, const vpp_image_desc* src) {
+  const size_t lim = 0xFFFFFF00u;
+  return (size_t)(src->nrows + 2 * src->border) * (size_t)src->pitch + 64 < lim && (size_t)dst->nrows * (size_t)dst->pitch < lim;
+}
+template <int CH, int RW, int WX, int SAUX, bool HALO, int OCC, int PROBE, int KR = 5, int KC = 5>
+void launch_wide_cfg(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st, int order, int mix, int slots) {
+  const int row_bytes = dst->ncols * CH, strip = HALO ? 1024 : kStripOut, WY = 4 / WX, bb = src->border * CH;
+  const int nstrips = (row_bytes + strip - 1) / strip;
+  BoxGeom g;
+  g.nbx = (nstrips + WX - 1) / WX;
+  int nblk = (dst->nrows + RW - 1) / RW;  // row blocks per strip, all of RW rows
+  g.nhi = nblk;
+  if (mix && RW > 1) {
+    // as few blocks as keep the grid within `slots` waves, but never more than RW rows per block: nblk blocks of RW - 1 or RW rows
+    const int want = max(1, slots / (g.nbx * WX));
+    const int lo_blocks = (dst->nrows + RW - 1) / RW, hi_blocks = (dst->nrows + RW - 2) / (RW - 1);
+    nblk = min(max(want / WY * WY, lo_blocks), hi_blocks);
+    g.nhi = dst->nrows - nblk * (RW - 1);                   // nhi * RW + (nblk - nhi) * (RW - 1) == nrows
+  }
+  g.nby = (nblk + WY - 1) / WY;
+  g.order = order;
+  g.sbase = (const uint8_t*)src->first_pixel - (ptrdiff_t)src->border * src->pitch - 16;
+  g.dbase = (uint8_t*)dst->first_pixel;
+  g.sbytes = (uint32_t)((size_t)(dst->nrows - 1 + 2 * src->border) * src->pitch + 16 + (size_t)((row_bytes + bb + 15) & ~15));
+  g.dbytes = (uint32_t)((size_t)(dst->nrows - 1) * dst->pitch + row_bytes);
+  g.spitch = src->pitch; g.dpitch = dst->pitch; g.nrows = dst->nrows; g.row_bytes = row_bytes; g.srow0 = src->border;
+  box_u8_wide_kernel<CH, KR, KC, RW, WX, SAUX, kAuxDefault, HALO, OCC, PROBE><<<g.nbx * g.nby, 256, 0, st>>>(g);
+}
+template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
+  // measured on MI355X (tools/boxlab, 4K vuchar3): 992-B strips, 2 rows per wave, workgroup = 4 strips side by side, block grid
+  // walked row-major per XCD, non-temporal stores: 8.6 us; strip-major order 8.9, one strip per workgroup 9.4, no XCD remap 15.5
+  const int rows = tuning("box.rows", 2), wx = tuning("box.wx", 4), sp = tuning("box.sp", kAuxNT), order = tuning("box.order", 0);
+  const int halo = tuning("box.halo", 0), mix = tuning("box.mix", 0), slots = tuning("box.slots", 8192);
+#ifdef VPP_BOX_LAB
+  const int probe = tuning("box.probe", 0), occ = tuning("box.occ", 8);
+  bool done = false;
+  auto try_cfg = [&](auto RWc, auto WXc, auto SPc, auto HALOc, auto OCCc, auto PRc) {
+    if (!done && rows == decltype(RWc)::value && wx == decltype(WXc)::value && sp == decltype(SPc)::value && halo == (int)decltype(HALOc)::value && occ == decltype(OCCc)::value && probe == decltype(PRc)::value) {
+      launch_wide_cfg<CH, decltype(RWc)::value, decltype(WXc)::value, decltype(SPc)::value, decltype(HALOc)::value, decltype(OCCc)::value, decltype(PRc)::value>(dst, src, st, order, mix, slots);
+      done = true;
+    }
+  };
+  auto for_rw = [&](auto WXc, auto SPc, auto HALOc, auto OCCc, auto PRc) {
+    try_cfg(std::integral_constant<int, 2>(), WXc, SPc, HALOc, OCCc, PRc); try_cfg(std::integral_constant<int, 3>(), WXc, SPc, HALOc, OCCc, PRc);
+    try_cfg(std::integral_constant<int, 4>(), WXc, SPc, HALOc, OCCc, PRc); try_cfg(std::integral_constant<int, 5>(), WXc, SPc, HALOc, OCCc, PRc);
+    try_cfg(std::integral_constant<int, 6>(), WXc, SPc, HALOc, OCCc, PRc);
+  };
+  auto for_wx = [&](auto SPc, auto HALOc, auto OCCc, auto PRc) {
+    for_rw(std::integral_constant<int, 1>(), SPc, HALOc, OCCc, PRc); for_rw(std::integral_constant<int, 2>(), SPc, HALOc, OCCc, PRc); for_rw(std::integral_constant<int, 4>(), SPc, HALOc, OCCc, PRc);
+  };
+  auto for_occ = [&](auto SPc, auto HALOc, auto PRc) {
+    for_wx(SPc, HALOc, std::integral_constant<int, 8>(), PRc); for_wx(SPc, HALOc, std::integral_constant<int, 6>(), PRc); for_wx(SPc, HALOc, std::integral_constant<int, 4>(), PRc);
+  };
+  if constexpr (CH == 3) {
+    for_occ(std::integral_constant<int, kAuxNT>(), std::false_type(), std::integral_constant<int, 0>());
+    for_occ(std::integral_constant<int, kAuxNT>(), std::true_type(), std::integral_constant<int, 0>());
+    for_occ(std::integral_constant<int, kAuxNT>(), std::false_type(), std::integral_constant<int, 1>());
+    for_occ(std::integral_constant<int, kAuxNT>(), std::false_type(), std::integral_constant<int, 3>());
+    for_occ(std::integral_constant<int, kAuxNT>(), std::true_type(), std::integral_constant<int, 3>());
+    for_occ(std::integral_constant<int, kAuxNT | kAuxSC1>(), std::false_type(), std::integral_constant<int, 0>());
+  }
+  if (!done) { set_error("boxlab: configuration rows=%d wx=%d sp=%d halo=%d occ=%d probe=%d not instantiated", rows, wx, sp, halo, occ, probe); return VPP_ERR_UNSUPPORTED; }
+#else
+  (void)rows; (void)wx; (void)sp; (void)halo;
+  launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0>(dst, src, st, order, mix, slots);
+#endif
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
 template <int CH> int launch_fast(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
   const int row_bytes = dst->ncols * CH;
   const int th = tuning("box.rows", 2);
   const int nt = tuning("box.nt", 1);
-  const int impl = tuning("box.impl", 1);  // 1 = streaming DPP kernel, 0 = LDS-staged tile kernel
+  // 2 = streaming DPP kernel on buffer descriptors (default), 1 = its flat-pointer predecessor (also the fallback when a
+  // descriptor's 32-bit byte count cannot span the image), 0 = LDS-staged tile kernel
+  int impl = tuning("box.impl", 2);
+  if (impl == 2 && !fits_descriptor(dst, src)) impl = 1;
   uint8_t* dp = (uint8_t*)dst->first_pixel; const uint8_t* sp = (const uint8_t*)src->first_pixel;
   const int guard = src->border == 2 ? 1 : 0;
+  if (impl == 2) return launch_wide<CH>(dst, src, st);
   if (impl == 1) {
     const int nstrips = (row_bytes + kStripOut - 1) / kStripOut;
     auto go = [&](auto RWc, auto NTc) {
@@ -564,6 +807,11 @@ template <int CH> int launch_fast(const vpp_image_desc* dst, const vpp_image_des
 
 // other odd windows up to 7 x 7 on 8-bit images through the same streaming kernel (2 output rows per wave, non-temporal stores)
 template <int CH, int KR, int KC> int launch_stream_window(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
+  if (fits_descriptor(dst, src)) {
+    launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0, KR, KC>(dst, src, st, 0, 0, 0);
+    VPP_LAUNCH_CHECK();
+    return VPP_OK;
+  }
   const int row_bytes = dst->ncols * CH;
   const int nstrips = (row_bytes + kStripOut - 1) / kStripOut;
   constexpr int RW = 2, WPB = 4;
