@@ -19,7 +19,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -30,13 +29,15 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of exactly --steps launches each; the median one (by wall clock) is reported, all are listed")
+    ap.add_argument("--preheat", type=float, default=0.3, help="seconds of untimed, reported replays before each headline timed region (clock ramp)")
     ap.add_argument("--workload", default="box5x5", choices=["box5x5"])
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    from util import P, rand_image, DeviceImage
+    from vpp_amd.synth import P, rand_image, DeviceImage
     from vpp_amd import capi, image as vi
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,47 +66,109 @@ def main():
 
     launch_mode = {"mode": "hipGraph"}
 
-    def timed(launch, steps, warmup, graph=True):
-        """EXACTLY `steps` launches between barrier+sync pairs; also HIP-event time on the launch stream.
-        The K launches are captured once into a hipGraph (kernels of 8-18 us would otherwise be host-launch bound
-        from Python); the timed region is the replay of that graph.  Falls back to eager launches if capture fails."""
+    preheat = {"ms": 0.0, "launches": 0}
+    region_log = []
+    side = torch.cuda.Stream()   # the stream the C-ABI launch graphs are recorded and replayed on
+
+    def timed(launch, steps, warmup, graph=True, preheat_s=0.0, c_graph=False):
+        """Regions of EXACTLY `steps` launches between barrier+sync pairs (wall clock), each also timed by HIP events on the
+        launch stream.  The K launches are recorded once into a launch graph (kernels of 8-18 us would otherwise be
+        host-launch bound from Python) and a region is one replay of it.
+          c_graph=True (launches that only call the C ABI): vpp_graph_* with event-record nodes in front of the first and
+            behind the last recorded kernel, so the event time brackets the K kernels on the device clock and excludes the
+            host's graph-submission latency (~9 us, i.e. 5 % of a K = 20 region); falls back to stream events around the replay.
+          otherwise: torch.cuda.CUDAGraph (the launch also queues torch work), stream events around the replay.
+        preheat_s > 0: untimed, REPORTED replays for that long right before the timed regions (the GPU clocks ramp over the
+        first few hundred microseconds of work after an idle period such as the CPU-baseline leg).
+        args.regions regions are timed; the one reported is the median by wall clock, all are listed in the JSON line."""
         for i in range(warmup):
             launch(i, st)
         torch.cuda.synchronize()
-        g = None
-        if graph and os.environ.get("VPP_BENCH_EAGER", "0") != "1":
+        mode, replay, elapsed_in_graph, stream = "eager", None, None, torch.cuda.current_stream()
+        use_graph = graph and os.environ.get("VPP_BENCH_EAGER", "0") != "1"
+        if use_graph and c_graph:
+            sp = ctypes.c_void_p(side.cuda_stream)
+            for want_nodes in (1, 0):
+                gh = ctypes.c_void_p()
+                capi.check(lib.vpp_graph_begin(sp))
+                for i in range(steps):
+                    launch(i, sp)
+                rc = lib.vpp_graph_end(sp, want_nodes, ctypes.byref(gh))
+                if rc == capi.OK:
+                    replay = lambda gh=gh, sp=sp: capi.check(lib.vpp_graph_launch(gh, sp))
+                    stream = side
+                    mode = "vpp_graph (hipGraph recorded through the C ABI)"
+                    if want_nodes:
+                        def elapsed_in_graph(gh=gh):
+                            ms = ctypes.c_float(0)
+                            capi.check(lib.vpp_graph_elapsed_ms(gh, ctypes.byref(ms)))
+                            return ms.value * 1e-3
+                    break
+                sys.stderr.write(f"[bench] vpp_graph_end(timed={want_nodes}) -> {rc}: {lib.vpp_last_error().decode()}\n")
+        if use_graph and replay is None:
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     cs = capi.stream_ptr()  # the capture stream
                     for i in range(steps):
                         launch(i, cs)
-                g.replay()  # one untimed replay (graph upload)
-                torch.cuda.synchronize()
+                replay, mode = g.replay, "torch.cuda.CUDAGraph"
             except Exception as e:  # noqa: BLE001
                 sys.stderr.write(f"[bench] hipGraph capture failed ({e}); timing eager launches\n")
-                g = None
-        if g is None and graph:
-            launch_mode["mode"] = "eager"
-        barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        if g is not None:
-            g.replay()
-        else:
-            for i in range(steps):
-                launch(i, st)
-        e1.record()
+        if replay is None:
+            def replay():
+                for i in range(steps):
+                    launch(i, st)
+        replay()  # one untimed replay (graph upload)
         torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        wall = t1 - t0
-        if multi:
-            t = torch.tensor([wall], dtype=torch.float64, device="cpu" if one_dev else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall = float(t.item())
-        return wall, e0.elapsed_time(e1) * 1e-3
+        launch_mode["mode"] = mode
+        launch_mode["events"] = "event-record nodes inside the graph (in front of the first / behind the last kernel)" if elapsed_in_graph else "stream events around the replay"
+        if preheat_s > 0:
+            t_pre = time.perf_counter()
+            n_pre = 0
+            batch = max(1, 4000 // max(steps, 1))  # replays queued back to back between host syncs: the GPU must stay busy to hold its clocks
+            while time.perf_counter() - t_pre < preheat_s:
+                for _ in range(batch):
+                    replay()
+                n_pre += steps * batch
+                torch.cuda.synchronize()
+            preheat["ms"] += (time.perf_counter() - t_pre) * 1e3
+            preheat["launches"] += n_pre
+        regions = []
+        for _ in range(max(1, args.regions)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            t0 = time.perf_counter()
+            e0.record(stream)
+            replay()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            wall = t1 - t0
+            if multi:
+                t = torch.tensor([wall], dtype=torch.float64, device="cpu" if one_dev else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                wall = float(t.item())
+            regions.append((wall, elapsed_in_graph() if elapsed_in_graph else e0.elapsed_time(e1) * 1e-3))
+        # kernel-duration sample for the roofline: the event pair around ONE K-launch region carries ~8 us of fixed marker /
+        # command-processor latency (K = 20: 9.0 us per launch inside the bracket where rocprofv3's per-dispatch durations of the
+        # same run average 8.55), so the same graph is replayed back to back until >= 2000 launches sit between one event pair
+        reps = max(1, -(-2000 // max(steps, 1)))
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s0.record(stream)
+        for _ in range(reps):
+            replay()
+        s1.record(stream)
+        torch.cuda.synchronize()
+        sample = {"launches": reps * steps, "us_per_launch": s0.elapsed_time(s1) * 1e3 / (reps * steps),
+                  "how": f"{reps} back-to-back replays of the {steps}-launch graph between one HIP event pair on the launch stream"}
+        # every region times exactly `steps` launches; the reported one is the median by wall clock (all of them are listed in "timed_regions")
+        order = sorted(range(len(regions)), key=lambda k: regions[k][0])
+        wall, ev = regions[order[len(order) // 2]]
+        region_log.append({"wall_ms": [round(r[0] * 1e3, 4) for r in regions], "event_ms": [round(r[1] * 1e3, 4) for r in regions], "sample": sample})
+        return wall, ev
 
     # ---------------- box5x5 on 4K vuchar3 (headline) ----------------
     NR, NC = 2160, 3840
@@ -124,12 +187,15 @@ def main():
         k = i % nsets
         box(P(ddesc[k]), P(sdesc[k]), 5, 5, stream)
 
-    wall, ev = timed(launch_box, args.steps, args.warmup)
+    wall, ev = timed(launch_box, args.steps, args.warmup, preheat_s=args.preheat, c_graph=True)
+    box_mode = dict(launch_mode)
+    box_regions = region_log[-1]
     ms_per_step = wall / args.steps * 1e3
     value = npx * world / (wall / args.steps) / 1e9
-    box_kernel_s = ev / args.steps
-    roof = {"bound": "hbm", "kernel": "box_u8_stream_kernel<3, 5, 5, 2, true, 0>", "achieved": 6.0 * npx / box_kernel_s / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": 6 * npx, "avg_launch_us": box_kernel_s * 1e6}
+    box_kernel_s = box_regions["sample"]["us_per_launch"] * 1e-6
+    roof = {"bound": "hbm", "kernel": "box_u8_wide_kernel<3, 5, 5, 2, 4, ...>", "achieved": 6.0 * npx / box_kernel_s / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": 6 * npx, "avg_launch_us": box_kernel_s * 1e6,
+            "avg_launch_us_in_region": ev / args.steps * 1e6, "sample": box_regions["sample"]}
     roof["frac"] = roof["achieved"] / roof["peak"]
 
     def pmc_traffic(prefix):
@@ -141,7 +207,7 @@ def main():
                 if k.startswith(prefix):
                     return v["hbm_bytes_per_launch"]
         return None
-    roof["traffic"] = pmc_traffic("box_u8_stream_kernel<3, 5, 5")
+    roof["traffic"] = pmc_traffic("box_u8_wide_kernel<3, 5, 5")
     roof["traffic_source"] = "profiles/*_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled)"
 
     # ---------------- 4K int32 pixel_wise add ----------------
@@ -157,9 +223,9 @@ def main():
         k = i % nadd
         add(0, P(ad[k]), P(bd[k]), P(cd[k]), stream)
 
-    awall, aev = timed(launch_add, args.steps, args.warmup)
-    add_s = aev / args.steps
-    add4k = {"gpixels_per_s": npx * world / (awall / args.steps) / 1e9, "avg_launch_us": add_s * 1e6,
+    awall, aev = timed(launch_add, args.steps, args.warmup, preheat_s=args.preheat, c_graph=True)
+    add_s = region_log[-1]["sample"]["us_per_launch"] * 1e-6
+    add4k = {"gpixels_per_s": npx * world / (awall / args.steps) / 1e9, "avg_launch_us": add_s * 1e6, "avg_launch_us_in_region": aev / args.steps * 1e6,
              "roofline": {"bound": "hbm", "kernel": "binary_flat_kernel<add,int>", "achieved": 12.0 * npx / add_s / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 12.0 * npx / add_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("binary_flat_kernel<0, int")}}
 
@@ -203,7 +269,9 @@ def main():
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
                "config": {"workload": "box_nbh2d 5x5 mean on 3840x2160 vuchar3 (BASELINE configs[1]), border 2 mirror-filled, "
-                                      f"{nsets} rotating frame sets (>256 MiB)", "parallelism": f"replicas x{world}", "launch": launch_mode["mode"]},
+                                      f"{nsets} rotating frame sets (>256 MiB)", "parallelism": f"replicas x{world}", "launch": box_mode["mode"], "events": box_mode["events"], "timed_regions": {"count": max(1, args.regions), "reported": "median by wall clock", "wall_ms": box_regions["wall_ms"], "event_ms": box_regions["event_ms"]},
+                          "preheat": {"untimed_ms": round(preheat["ms"], 1), "untimed_launches": preheat["launches"],
+                                      "note": "replays of the same graphs before the timed regions (clock ramp); not part of steps / value"}},
                "roofline": roof, "cpu_baseline": cpu, "add4k": add4k}
         out.update(extras)
         print(json.dumps(out))

@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     import torch
     import torch.distributed as dist
-    import pyr
-    from util import P, u8_image, DeviceImage, texture, translate, rects_image
+    from vpp_amd import pyr
+    from vpp_amd.synth import P, u8_image, DeviceImage, texture, translate, rects_image
     from vpp_amd import capi, image as vi, multi_gpu as mg
 
     V = ctypes.c_void_p
@@ -103,7 +103,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
 
     # semi-dense optical flow on one 4K frame pair (BASELINE configs[4] on a single GPU): a keypoint every 10 px
     # (video_extruder keypoint_spacing), winsize 9, 3 scales, propagation 2, patch 5 (video_extruder.hpp:35-41,54)
-    from test_gpu_sdof import flow_scene
+    from vpp_amd.synth import flow_scene
     s1, s2, sk = flow_scene(2160, 3840, spacing=10)
     e1, e2 = DeviceImage.from_host(u8_image(s1, border=3), dev), DeviceImage.from_host(u8_image(s2, border=3), dev)
     dk = torch.from_numpy(sk).to(dev); m = len(sk)
@@ -124,7 +124,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
                                  "note": "one frame pair per GPU (replicas); serial-order semantics, bit-exact vs the oracle"}
 
     # frame ingest: 4K vuchar3 frame -> gray with a mirror-filled border of 3 in one pass; 4 B/px algorithmic
-    from util import rand_image
+    from vpp_amd.synth import rand_image
     nin = 8  # 8 x (24.9 + 8.3 MB) > 256 MiB
     rgb_h = rand_image(2160, 3840, vi.U8, 3, border=0, seed=6)
     rgbs = [DeviceImage.from_host(rgb_h, dev) for _ in range(nin)]; grays = [DeviceImage(2160, 3840, vi.U8, 1, 3, 32, dev) for _ in range(nin)]
@@ -151,15 +151,16 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
 
 def cpu_baseline(orc):
     """Oracle (OpenMP build) timed on the host: pyrlk_match on a 1000-keypoint sample of the same scene, and FAST-9 raw on one 4K frame."""
-    import pyr
-    from util import P, u8_image, texture, translate, rects_image
+    from vpp_amd import pyr
+    from oracle import pyramid as opyr
+    from vpp_amd.synth import P, u8_image, texture, translate, rects_image
     from vpp_amd import image as vi
     V = ctypes.c_void_p
     NR, NC, L, B = 1080, 1920, 3, 3
     tex = texture(NR, NC, seed=5)
     i1 = u8_image(np.clip(np.rint(tex), 0, 255).astype(np.uint8)); i2 = u8_image(np.clip(np.rint(translate(tex, 1.5, -2.25)), 0, 255).astype(np.uint8))
-    hp1, hp2 = pyr.host_pyramid(orc, i1, L, B), pyr.host_pyramid(orc, i2, L, B)
-    hg = pyr.host_grad_pyramid(orc, hp1[0], L, B, vi.F32)
+    hp1, hp2 = opyr.host_pyramid(orc, i1, L, B), opyr.host_pyramid(orc, i2, L, B)
+    hg = opyr.host_grad_pyramid(orc, hp1[0], L, B, vi.F32)
     kps = pyr.make_keypoints(pyr.grid_keypoints(NR, NC, 10000, margin=32))
     k = kps.copy()
     orc.orc_pyrlk_match(vi.desc_array(hp1), vi.desc_array(hg), vi.desc_array(hp2), L, k.ctypes.data_as(V), len(k), 7, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None)
@@ -177,7 +178,7 @@ def cpu_baseline(orc):
     out["fast9_raw_gpixels_per_s"] = 2160 * 3840 / (time.perf_counter() - t0) / 1e9
     # semi-dense flow on the same 4K frame pair as the GPU leg, one pass of the serial restatement (the reference's sweeps are
     # sequential by construction and its OpenMP claim loop is racy, SURVEY Q9: one thread is the reference's defined behaviour)
-    from test_gpu_sdof import flow_scene
+    from vpp_amd.synth import flow_scene
     s1, s2, sk = flow_scene(2160, 3840, spacing=10)
     e1, e2 = u8_image(s1, border=3), u8_image(s2, border=3)
     m = len(sk)

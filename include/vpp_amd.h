@@ -61,6 +61,26 @@ int vpp_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int vpp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 int vpp_memset(void* dst, int byte, size_t bytes, void* stream);
 int vpp_sync(void* stream);
+/* Launch graphs (no reference counterpart: the reference's frame loops call the algorithms directly, e.g.
+ * examples/video_extruder.cc:40-60; on a stream the per-launch host cost is what a graph removes).  Everything queued on
+ * `stream` between vpp_graph_begin and vpp_graph_end is recorded instead of run; vpp_graph_launch replays it with one
+ * submission.  timed != 0 adds an event-record node in front of the first and behind the last recorded node (the reference
+ * times with clock_gettime around host calls, benchmarks/get_time.hh:2-7): vpp_graph_elapsed_ms then returns the device-clock
+ * duration of the last replay.  VPP_ERR_UNSUPPORTED when the runtime has no event-record nodes (retry with timed = 0). */
+typedef struct vpp_graph vpp_graph;
+int vpp_graph_begin(void* stream);
+int vpp_graph_end(void* stream, int timed, vpp_graph** graph);
+int vpp_graph_launch(vpp_graph* graph, void* stream);
+int vpp_graph_elapsed_ms(vpp_graph* graph, float* ms);
+int vpp_graph_destroy(vpp_graph* graph);
+/* Stream gate (no reference counterpart; batching / measurement aid): vpp_gate_wait queues a one-thread kernel that holds `stream`
+ * until vpp_gate_open is called from the host (or ~50 ms pass), so that a batch of launches can be queued completely before the
+ * first of them starts. */
+typedef struct vpp_gate vpp_gate;
+int vpp_gate_create(vpp_gate** gate);
+int vpp_gate_wait(vpp_gate* gate, void* stream);
+int vpp_gate_open(vpp_gate* gate);
+int vpp_gate_destroy(vpp_gate* gate);
 const char* vpp_last_error(void);
 const char* vpp_version(void);
 /* runtime tuning knob (launch geometry variants; used by bench/tuning scripts, never changes results) */

@@ -5,25 +5,11 @@ import numpy as np
 import pytest
 import torch
 
+from util import flow_scene  # noqa: F401
 from util import P, u8_image, DeviceImage, texture, translate
 from vpp_amd import capi
 
 pytestmark = pytest.mark.gpu
-
-
-def flow_scene(nr, nc, seed=6, spacing=5):
-    """C4 texture with 4 piecewise translations (quadrants), |flow| <= 6 px (BASELINE config 5, scaled)."""
-    tex = texture(nr, nc, seed=seed, sigma=1.5)
-    f1 = np.clip(np.rint(tex), 0, 255).astype(np.uint8)
-    f2 = f1.copy().astype(np.float64)
-    shifts = [(2.0, -3.0), (-4.0, 1.0), (5.0, 4.0), (0.0, -6.0)]
-    h, w = nr // 2, nc // 2
-    for (dr, dc), (r0, c0) in zip(shifts, [(0, 0), (0, w), (h, 0), (h, w)]):
-        f2[r0:r0 + h, c0:c0 + w] = translate(tex, dr, dc)[r0:r0 + h, c0:c0 + w]
-    f2 = np.clip(np.rint(f2), 0, 255).astype(np.uint8)
-    rr, cc = np.meshgrid(np.arange(spacing, nr - spacing, spacing), np.arange(spacing, nc - spacing, spacing), indexing="ij")
-    kps = np.stack([rr.ravel(), cc.ravel()], 1).astype(np.int32)
-    return f1, f2, kps
 
 
 def run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch):

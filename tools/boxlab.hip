@@ -155,6 +155,13 @@ int main(int argc, char** argv) {
     cfgs.push_back("impl=2,halo=0,wx=4,order=0,rows=2,mix=0,occ=8,probe=1");
     cfgs.push_back("impl=2,halo=0,wx=4,order=0,rows=2,mix=0,occ=8,probe=3");
     cfgs.push_back("impl=2,halo=0,wx=4,order=0,rows=2,mix=0,occ=8");
+  } else if (mode == "sweep5") {
+    cfgs.push_back("impl=2");
+    for (int shape : {1, 2, 3, 4, 5, 6}) { char b[160]; snprintf(b, sizeof b, "impl=2,shape=%d,rows=2", shape); cfgs.push_back(b); }
+    cfgs.push_back("impl=2,shape=1,rows=3");
+    for (int laux : {0, 1, 2, 16})
+      for (int sp : {0, 1, 2, 3, 16, 17, 18, 19}) { if (laux == 0 && sp == 2) continue; char b[160]; snprintf(b, sizeof b, "impl=2,sp=%d,laux=%d", sp, laux); cfgs.push_back(b); }
+    cfgs.push_back("impl=2");
   } else if (mode == "sweep2") {
     for (int wx : {1, 4})
       for (int probe : {0, 1, 2, 3})

@@ -2,7 +2,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from util import P, rand_image, DeviceImage
+from vpp_amd.synth import P, rand_image, DeviceImage
 from vpp_amd import capi, image as vi
 from oracle import binding
 lib = capi.lib(); capi.check(lib.vpp_init(0)); orc = binding.load()

@@ -1,8 +1,8 @@
 import ctypes, os, sys
 ROOT="/root/repo"; sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-import pyr
-from util import P, u8_image, DeviceImage, texture, translate
+from vpp_amd import pyr
+from vpp_amd.synth import P, u8_image, DeviceImage, texture, translate
 from vpp_amd import capi, image as vi
 if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]
 V = ctypes.c_void_p

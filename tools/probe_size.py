@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from util import P, DeviceImage
+from vpp_amd.synth import P, DeviceImage
 from vpp_amd import capi, image as vi
 lib = capi.lib(); capi.check(lib.vpp_init(0))
 def time_graph(launch, steps=200):

@@ -1,17 +1,37 @@
 #!/bin/bash
-# Round profile: rocprofv3 kernel trace of bench.py itself + separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) over the
-# headline kernels.  Run on the GPU box from the repo root: bash tools/profile_round.sh <tag>; outputs under gpurun_out/prof_<tag>.
+# Round profile: rocprofv3 kernel trace of bench.py itself (default flags and the driver's --steps 20 --warmup 5) + separate PMC
+# passes over the headline kernels (tools/run_kernels.py) and the algorithm kernels (tools/run_algos.py): HBM traffic
+# (FETCH_SIZE / WRITE_SIZE), SQ instruction counts, SQ busy / wait cycles, and the L2 (TCC) request mix.
+# Run on the GPU box from the repo root: bash tools/profile_round.sh <tag>; outputs under gpurun_out/prof_<tag>.
+# Every rocprofv3 run is its own process with --kernel-trace + --pmc only (no other trace domains) and a timeout.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python $R/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
-rocprofv3 --kernel-trace --stats -d $OUT/kt_algos -o algos -- python $R/tools/run_algos.py > $OUT/run_algos.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python $R/tools/run_kernels.py all 16 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python $R/tools/run_kernels.py all 16 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/pmc_sq -o p -- python $R/tools/run_kernels.py all 16 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES -d $OUT/pmc_sq_algos -o p -- python $R/tools/run_algos.py > /dev/null 2>&1
+T="timeout 300"
+$T rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python $R/bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+$T rocprofv3 --kernel-trace --stats -d $OUT/kt20 -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $OUT/bench_s20_under_rocprof.json 2> $OUT/bench_s20_under_rocprof.err
+$T rocprofv3 --kernel-trace --stats -d $OUT/kt_algos -o algos -- python $R/tools/run_algos.py > $OUT/run_algos.log 2>&1
+pmc() {  # pmc <dir> <script> <counters...>
+  local d=$1 s=$2; shift 2
+  $T rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$d -o p -- python $R/tools/${s%% *} ${s#* } > $OUT/$d.log 2>&1 || echo "pass $d failed / timed out" >> $OUT/failed.txt
+}
+pmc pmc_fetch "run_kernels.py all 16" FETCH_SIZE
+pmc pmc_write "run_kernels.py all 16" WRITE_SIZE
+pmc pmc_sq "run_kernels.py all 16" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+pmc pmc_busy "run_kernels.py all 16" SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU
+pmc pmc_wait "run_kernels.py all 16" SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS
+pmc pmc_wait2 "run_kernels.py all 16" SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+pmc pmc_sq_algos "run_algos.py x" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
+pmc pmc_busy_algos "run_algos.py x" SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU
+pmc pmc_wait_algos "run_algos.py x" SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS
+pmc pmc_wait2_algos "run_algos.py x" SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+# L2 request mix, one counter per pass (a multi-counter TCC pass hung the profiler in round 1)
+for c in TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum; do
+  pmc pmc_tcc_$c "run_kernels.py box 16" $c
+done
 cd $R
 find $OUT -name "*_results.db" | sort
+cat $OUT/failed.txt 2>/dev/null

@@ -3,7 +3,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from util import P, rand_image, DeviceImage
+from vpp_amd.synth import P, rand_image, DeviceImage
 from vpp_amd import capi, image as vi
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20

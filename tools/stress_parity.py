@@ -5,7 +5,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from util import P, rand_image, HostImage, DeviceImage, u8_image, rects_image
+from vpp_amd.synth import P, rand_image, HostImage, DeviceImage, u8_image, rects_image
 from test_gpu_sdof import flow_scene, run_both
 from test_oracle_algos import run_detect
 from test_gpu_algos import gpu_detect

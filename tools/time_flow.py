@@ -3,7 +3,7 @@ import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from util import P, u8_image, DeviceImage
+from vpp_amd.synth import P, u8_image, DeviceImage
 from vpp_amd import capi
 from test_gpu_sdof import flow_scene
 V = ctypes.c_void_p

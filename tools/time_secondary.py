@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from util import P, rand_image, DeviceImage
+from vpp_amd.synth import P, rand_image, DeviceImage
 from vpp_amd import capi, image as vi
 if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]  # A/B timing of two builds in ONE gpurun call (boxes differ by ~10 %)
 lib = capi.lib(); capi.check(lib.vpp_init(0))
@@ -60,7 +60,7 @@ for (nr, nc) in ((1080, 1920), (2160, 3840)):
     gn = [DeviceImage(1 + nr // 2, 1 + nc // 2, vi.F32, 2, 3) for _ in range(ns)]
     us = time_graph(lambda i, s: lib.vpp_pyr_down(P(gn[i % ns].desc), P(g[i % ns].desc), s)); print(f"pyr_down f32x2 {nr}x{nc}: {us:.2f} us  ({nr * nc * 8 * 1.25 / us / 1e3:.1f} GB/s)")
 # dense FAST flags and the blockwise maxima filter at 4K
-from util import rects_image, u8_image
+from vpp_amd.synth import rects_image, u8_image
 import numpy as np
 fim = u8_image(rects_image(NR, NC, seed=31), border=3)
 fim.view(with_border=True)[..., 0] = np.pad(fim.view()[..., 0], 3, mode="symmetric")

@@ -7,7 +7,7 @@ import json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from util import P, rand_image, DeviceImage
+from vpp_amd.synth import P, rand_image, DeviceImage
 from vpp_amd import capi, image as vi
 
 lib = capi.lib(); capi.check(lib.vpp_init(0))

@@ -3,8 +3,8 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-import pyr
-from util import P, u8_image, DeviceImage, texture, translate
+from vpp_amd import pyr
+from vpp_amd.synth import P, u8_image, DeviceImage, texture, translate
 from vpp_amd import capi, image as vi
 V = ctypes.c_void_p
 if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]  # A/B timing of two builds in ONE gpurun call (boxes differ by ~10 %)

@@ -432,10 +432,10 @@ __device__ __forceinline__ void box_u8_wide_body(const BoxGeom& g, int x0, int r
 }
 
 // nby row blocks per strip: the first nhi have RW rows, the others RW - 1 (nhi == nby: all RW)
-template <int CH, int KR, int KC, int RW, int WX, int SAUX, int LAUX, bool HALO, int OCC, int PROBE>
-__global__ __launch_bounds__(256, OCC) void box_u8_wide_kernel(const BoxGeom g) {
-  static_assert(CH >= 1 && CH <= 4 && (WX == 1 || WX == 2 || WX == 4), "window holds 2*CH <= 8 halo bytes; 4 waves per workgroup");
-  constexpr int WY = 4 / WX;
+template <int CH, int KR, int KC, int RW, int WX, int SAUX, int LAUX, bool HALO, int OCC, int PROBE, int NW = 4>
+__global__ __launch_bounds__(64 * NW, OCC * 4 / NW) void box_u8_wide_kernel(const BoxGeom g) {
+  static_assert(CH >= 1 && CH <= 4 && NW % WX == 0, "window holds 2*CH <= 8 halo bytes; NW waves per workgroup, WX of them side by side");
+  constexpr int WY = NW / WX;
   const unsigned nb = (unsigned)g.nbx * (unsigned)g.nby;
   const unsigned lb = (g.order & 2) ? blockIdx.x : xcd_remap(blockIdx.x, nb);
   int bx, by;
@@ -682,9 +682,9 @@ inline bool fits_descriptor(const vpp_image_desc* dst, const vpp_image_desc* src
   const size_t lim = 0xFFFFFF00u;
   return (size_t)(src->nrows + 2 * src->border) * (size_t)src->pitch + 64 < lim && (size_t)dst->nrows * (size_t)dst->pitch < lim;
 }
-template <int CH, int RW, int WX, int SAUX, bool HALO, int OCC, int PROBE, int KR = 5, int KC = 5>
+template <int CH, int RW, int WX, int SAUX, bool HALO, int OCC, int PROBE, int KR = 5, int KC = 5, int NW = 4, int LAUX = kAuxDefault>
 void launch_wide_cfg(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st, int order, int mix, int slots) {
-  const int row_bytes = dst->ncols * CH, strip = HALO ? 1024 : kStripOut, WY = 4 / WX, bb = src->border * CH;
+  const int row_bytes = dst->ncols * CH, strip = HALO ? 1024 : kStripOut, WY = NW / WX, bb = src->border * CH;
   const int nstrips = (row_bytes + strip - 1) / strip;
   BoxGeom g;
   g.nbx = (nstrips + WX - 1) / WX;
@@ -704,7 +704,7 @@ void launch_wide_cfg(const vpp_image_desc* dst, const vpp_image_desc* src, hipSt
   g.sbytes = (uint32_t)((size_t)(dst->nrows - 1 + 2 * src->border) * src->pitch + 16 + (size_t)((row_bytes + bb + 15) & ~15));
   g.dbytes = (uint32_t)((size_t)(dst->nrows - 1) * dst->pitch + row_bytes);
   g.spitch = src->pitch; g.dpitch = dst->pitch; g.nrows = dst->nrows; g.row_bytes = row_bytes; g.srow0 = src->border;
-  box_u8_wide_kernel<CH, KR, KC, RW, WX, SAUX, kAuxDefault, HALO, OCC, PROBE><<<g.nbx * g.nby, 256, 0, st>>>(g);
+  box_u8_wide_kernel<CH, KR, KC, RW, WX, SAUX, LAUX, HALO, OCC, PROBE, NW><<<g.nbx * g.nby, 64 * NW, 0, st>>>(g);
 }
 template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
   // measured on MI355X (tools/boxlab, 4K vuchar3): 992-B strips, 2 rows per wave, workgroup = 4 strips side by side, block grid
@@ -738,6 +738,31 @@ template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_des
     for_occ(std::integral_constant<int, kAuxNT>(), std::false_type(), std::integral_constant<int, 3>());
     for_occ(std::integral_constant<int, kAuxNT>(), std::true_type(), std::integral_constant<int, 3>());
     for_occ(std::integral_constant<int, kAuxNT | kAuxSC1>(), std::false_type(), std::integral_constant<int, 0>());
+  }
+  const int shape = tuning("box.shape", 0), laux = tuning("box.laux", 0);
+  if (CH == 3 && !done && (shape || laux || (sp != kAuxNT && sp != (kAuxNT | kAuxSC1)))) {
+    // policy / workgroup-shape sweep around the chosen geometry (992-B strips, 2 rows per wave)
+    auto pol = [&](auto SPc, auto LAc) {
+      if (!done && shape == 0 && sp == decltype(SPc)::value && laux == decltype(LAc)::value) { launch_wide_cfg<CH, 2, 4, decltype(SPc)::value, false, 8, 0, 5, 5, 4, decltype(LAc)::value>(dst, src, st, order, mix, slots); done = true; }
+    };
+    auto pols = [&](auto LAc) {
+      pol(std::integral_constant<int, 0>(), LAc); pol(std::integral_constant<int, 1>(), LAc); pol(std::integral_constant<int, 2>(), LAc); pol(std::integral_constant<int, 3>(), LAc);
+      pol(std::integral_constant<int, 16>(), LAc); pol(std::integral_constant<int, 17>(), LAc); pol(std::integral_constant<int, 18>(), LAc); pol(std::integral_constant<int, 19>(), LAc);
+    };
+    pols(std::integral_constant<int, 0>()); pols(std::integral_constant<int, 1>()); pols(std::integral_constant<int, 2>()); pols(std::integral_constant<int, 16>());
+    if (!done && sp == kAuxNT && laux == 0) {
+      done = true;
+      switch (shape * 10 + rows) {
+        case 12: launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0, 5, 5, 8>(dst, src, st, order, mix, slots); break;   // 512 threads: 4 strips x 2 row blocks
+        case 13: launch_wide_cfg<CH, 3, 4, kAuxNT, false, 8, 0, 5, 5, 8>(dst, src, st, order, mix, slots); break;
+        case 22: launch_wide_cfg<CH, 2, 6, kAuxNT, false, 8, 0, 5, 5, 6>(dst, src, st, order, mix, slots); break;   // 384 threads: 6 strips side by side
+        case 32: launch_wide_cfg<CH, 2, 12, kAuxNT, false, 8, 0, 5, 5, 12>(dst, src, st, order, mix, slots); break; // 768 threads: a whole 4K row
+        case 42: launch_wide_cfg<CH, 2, 3, kAuxNT, false, 8, 0, 5, 5, 3>(dst, src, st, order, mix, slots); break;   // 192 threads: 3 strips
+        case 52: launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0, 5, 5, 16>(dst, src, st, order, mix, slots); break;  // 1024 threads: 4 strips x 4 row blocks
+        case 62: launch_wide_cfg<CH, 2, 2, kAuxNT, false, 8, 0, 5, 5, 8>(dst, src, st, order, mix, slots); break;   // 512 threads: 2 strips x 4 row blocks
+        default: done = false;
+      }
+    }
   }
   if (!done) { set_error("boxlab: configuration rows=%d wx=%d sp=%d halo=%d occ=%d probe=%d not instantiated", rows, wx, sp, halo, occ, probe); return VPP_ERR_UNSUPPORTED; }
 #else

@@ -4,6 +4,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 namespace vpp_amd {
 static thread_local char g_err[512] = "";
@@ -176,6 +177,110 @@ int vpp_memset(void* dst, int byte, size_t bytes, void* stream) {
   return VPP_OK;
 }
 int vpp_sync(void* stream) { VPP_HIP_TRY(hipStreamSynchronize(as_stream(stream))); return VPP_OK; }
+
+// Launch graphs for C / C++ hosts: every entry point of this ABI is stream-ordered and allocation-free on its fast paths, so a
+// frame loop (or K benchmark launches) can be recorded once and replayed with one submission.  With `timed`, the graph gets an
+// event-record node in front of its root nodes and one behind its leaves: the pair brackets the recorded kernels on the
+// device's own clock at every replay, excluding the host's submission latency.
+struct vpp_graph { hipGraph_t g = nullptr; hipGraphExec_t exec = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; bool timed = false; };
+int vpp_graph_begin(void* stream) {
+  VPP_HIP_TRY(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
+  return VPP_OK;
+}
+int vpp_graph_end(void* stream, int timed, vpp_graph** out) {
+  VPP_REQUIRE(out, VPP_ERR_INVALID_ARG, "vpp_graph_end: null");
+  vpp_graph* gr = new vpp_graph();
+  hipError_t e = hipStreamEndCapture(as_stream(stream), &gr->g);
+  if (e != hipSuccess || !gr->g) { delete gr; set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return VPP_ERR_HIP; }
+  if (timed) {
+    size_t nn = 0, ne = 0;
+    bool ok = hipGraphGetNodes(gr->g, nullptr, &nn) == hipSuccess && nn > 0 && hipGraphGetEdges(gr->g, nullptr, nullptr, &ne) == hipSuccess;
+    std::vector<hipGraphNode_t> nodes(nn), from(ne), to(ne);
+    ok = ok && hipGraphGetNodes(gr->g, nodes.data(), &nn) == hipSuccess && (ne == 0 || hipGraphGetEdges(gr->g, from.data(), to.data(), &ne) == hipSuccess);
+    // device-scope release: the default (system-scope) record writes the L2 back before it takes its timestamp, which lands inside the bracket
+    ok = ok && hipEventCreateWithFlags(&gr->e0, hipEventReleaseToDevice) == hipSuccess && hipEventCreateWithFlags(&gr->e1, hipEventReleaseToDevice) == hipSuccess;
+    if (ok) {
+      std::vector<hipGraphNode_t> roots, leaves;
+      for (hipGraphNode_t n : nodes) {
+        bool has_in = false, has_out = false;
+        for (size_t k = 0; k < ne; k++) { has_in |= to[k] == n; has_out |= from[k] == n; }
+        if (!has_in) roots.push_back(n);
+        if (!has_out) leaves.push_back(n);
+      }
+      hipGraphNode_t n0 = nullptr, n1 = nullptr;
+      ok = hipGraphAddEventRecordNode(&n0, gr->g, nullptr, 0, gr->e0) == hipSuccess;
+      for (hipGraphNode_t r : roots) ok = ok && hipGraphAddDependencies(gr->g, &n0, &r, 1) == hipSuccess;
+      ok = ok && hipGraphAddEventRecordNode(&n1, gr->g, leaves.data(), leaves.size(), gr->e1) == hipSuccess;
+    }
+    (void)hipGetLastError();
+    if (!ok) { set_error("vpp_graph_end: event-record nodes are not supported by this runtime"); (void)hipGraphDestroy(gr->g); if (gr->e0) (void)hipEventDestroy(gr->e0); if (gr->e1) (void)hipEventDestroy(gr->e1); delete gr; return VPP_ERR_UNSUPPORTED; }
+    gr->timed = true;
+  }
+  e = hipGraphInstantiate(&gr->exec, gr->g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); (void)hipGraphDestroy(gr->g); delete gr; return VPP_ERR_HIP; }
+  *out = gr;
+  return VPP_OK;
+}
+int vpp_graph_launch(vpp_graph* gr, void* stream) {
+  VPP_REQUIRE(gr && gr->exec, VPP_ERR_INVALID_ARG, "vpp_graph_launch: null");
+  VPP_HIP_TRY(hipGraphLaunch(gr->exec, as_stream(stream)));
+  return VPP_OK;
+}
+int vpp_graph_elapsed_ms(vpp_graph* gr, float* ms) {  // of the last completed replay; waits for it
+  VPP_REQUIRE(gr && ms && gr->timed, VPP_ERR_INVALID_ARG, "vpp_graph_elapsed_ms: not a timed graph");
+  VPP_HIP_TRY(hipEventSynchronize(gr->e1));
+  VPP_HIP_TRY(hipEventElapsedTime(ms, gr->e0, gr->e1));
+  return VPP_OK;
+}
+int vpp_graph_destroy(vpp_graph* gr) {
+  if (!gr) return VPP_OK;
+  if (gr->exec) (void)hipGraphExecDestroy(gr->exec);
+  if (gr->g) (void)hipGraphDestroy(gr->g);
+  if (gr->e0) (void)hipEventDestroy(gr->e0);
+  if (gr->e1) (void)hipEventDestroy(gr->e1);
+  delete gr;
+  return VPP_OK;
+}
+
+// Stream gate: a one-thread kernel that holds `stream` until the host opens the gate, so that a batch of launches (or a
+// graph replay and the events around it) can be queued completely before the first of them starts — the events then
+// bracket the kernels themselves, not the host's submission latency.  The wait gives up after ~50 ms so that a gate that
+// is never opened cannot hang the device.
+struct vpp_gate { volatile uint32_t* flag; };
+__global__ void gate_wait_kernel(volatile uint32_t* flag) {
+  const unsigned long long t0 = wall_clock64();       // constant 100 MHz counter
+  while (__hip_atomic_load((const uint32_t*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+    if (wall_clock64() - t0 > 5000000ull) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+int vpp_gate_create(vpp_gate** gate) {
+  VPP_REQUIRE(gate, VPP_ERR_INVALID_ARG, "vpp_gate_create: null");
+  void* p = nullptr;
+  VPP_HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  *(volatile uint32_t*)p = 0u;
+  *gate = new vpp_gate{(volatile uint32_t*)p};
+  return VPP_OK;
+}
+int vpp_gate_wait(vpp_gate* gate, void* stream) {   // closes the gate and queues the wait on `stream`
+  VPP_REQUIRE(gate, VPP_ERR_INVALID_ARG, "vpp_gate_wait: null");
+  *gate->flag = 0u;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  gate_wait_kernel<<<1, 1, 0, as_stream(stream)>>>(gate->flag);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+int vpp_gate_open(vpp_gate* gate) {
+  VPP_REQUIRE(gate, VPP_ERR_INVALID_ARG, "vpp_gate_open: null");
+  __atomic_store_n((uint32_t*)gate->flag, 1u, __ATOMIC_SEQ_CST);
+  return VPP_OK;
+}
+int vpp_gate_destroy(vpp_gate* gate) {
+  if (!gate) return VPP_OK;
+  (void)hipHostFree((void*)gate->flag);
+  delete gate;
+  return VPP_OK;
+}
 
 int vpp_image_layout(int nrows, int ncols, int elem_bytes, int border, int align, int32_t* pitch, size_t* alloc_bytes,
                      size_t* first_pixel_offset) {
