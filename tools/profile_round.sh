@@ -35,3 +35,8 @@ done
 cd $R
 find $OUT -name "*_results.db" | sort
 cat $OUT/failed.txt 2>/dev/null
+# summarise on the box (the rocpd databases are too large to travel back), then drop the raw outputs
+PUB=$R/gpurun_out/pub_$TAG
+mkdir -p $PUB
+bash tools/publish_profiles.sh $TAG $PUB
+rm -rf $OUT/*/ 
