@@ -103,22 +103,28 @@ template <class T, class S> void box_filter_t(const Img& d, const Img& s, int R,
 void fill_border_generic(const Img& im, int es, int mode, const void* value) {
   const int b = im.border, nr = im.nr, nc = im.nc;
   auto px = [&](int r, int c) { return im.p0 + (ptrdiff_t)r * im.pitch + (ptrdiff_t)c * es; };
-  for (int r = -b; r < nr + b; r++)
-    for (int c = -b; c < nc + b; c++) {
-      if (r >= 0 && r < nr && c >= 0 && c < nc) { c = nc - 1; continue; }
-      const uint8_t* src;
-      if (mode == VPP_BORDER_VALUE) src = (const uint8_t*)value;
-      else if (mode == VPP_BORDER_MIRROR) {  // fill.hh:60-83: (-k) <- (k-1), (n-1+k) <- (n-k)
-        int sr = r < 0 ? -r - 1 : (r >= nr ? 2 * nr - r - 1 : r);
-        int sc = c < 0 ? -c - 1 : (c >= nc ? 2 * nc - c - 1 : c);
-        src = px(sr, sc);
-      } else {  // closest, fill.hh:86-122
-        int sr = r < 0 ? 0 : (r >= nr ? nr - 1 : r);
-        int sc = c < 0 ? 0 : (c >= nc ? nc - 1 : c);
-        src = px(sr, sc);
+  // The reference fills eight regions one after the other (fill.hh:56-82: corners 1 3 6 8, then edges 2 7 4 5), each a serial
+  // row-major pixel_wise.  The order only shows when border > nrows or border > ncols: a mirrored source position then lies in
+  // another region of the border, which holds that region's new pixels if it was filled earlier and its old bytes otherwise.
+  struct Region { int r0, r1, c0, c1; };
+  const Region regions[8] = {{-b, -1, -b, -1}, {-b, -1, nc, nc + b - 1}, {nr, nr + b - 1, -b, -1}, {nr, nr + b - 1, nc, nc + b - 1},
+                             {-b, -1, 0, nc - 1}, {nr, nr + b - 1, 0, nc - 1}, {0, nr - 1, -b, -1}, {0, nr - 1, nc, nc + b - 1}};
+  for (const Region& g : regions)
+    for (int r = g.r0; r <= g.r1; r++)
+      for (int c = g.c0; c <= g.c1; c++) {
+        const uint8_t* src;
+        if (mode == VPP_BORDER_VALUE) src = (const uint8_t*)value;
+        else if (mode == VPP_BORDER_MIRROR) {  // fill.hh:60-83: (-k) <- (k-1), (n-1+k) <- (n-k)
+          int sr = r < 0 ? -r - 1 : (r >= nr ? 2 * nr - r - 1 : r);
+          int sc = c < 0 ? -c - 1 : (c >= nc ? 2 * nc - c - 1 : c);
+          src = px(sr, sc);
+        } else {  // closest, fill.hh:86-122
+          int sr = r < 0 ? 0 : (r >= nr ? nr - 1 : r);
+          int sc = c < 0 ? 0 : (c >= nc ? nc - 1 : c);
+          src = px(sr, sc);
+        }
+        memcpy(px(r, c), src, es);
       }
-      memcpy(px(r, c), src, es);
-    }
 }
 
 // antialiasing_lowpass_filter (vpp/core/pyramid.hh:12-59).  T component type, S = plus_promotion.

@@ -223,6 +223,19 @@ def test_fill_border_matches_oracle(lib, orc, mode, dtype, ch, shape, border):
     np.testing.assert_array_equal(dim.download().raw, im.raw)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape,border", [((3, 23), 5), ((19, 2), 4), ((2, 3), 7), ((1, 1), 3), ((4, 4), 18)])
+def test_fill_border_wider_than_the_image_matches_oracle(lib, orc, mode, shape, border):
+    """border > nrows / ncols: the mirror reads other border regions, the eight regions run in the reference's order (fill.hh:56-82);
+    random pre-existing border bytes so that a stale read would show (oracle pinned to the reference in test_ref_pins_oracle.py)."""
+    im = rand_image(*shape, vi.U8, 1, border=border, seed=7, fill_border=True)
+    dim = DeviceImage.from_host(im)
+    assert orc.orc_fill_border(P(im.desc), mode, None) == 0
+    capi.check(lib.vpp_fill_border(P(dim.desc), mode, None, capi.stream_ptr()))
+    _sync(lib)
+    np.testing.assert_array_equal(dim.download().raw, im.raw)
+
+
 def test_copy_and_fill(lib, orc):
     src = rand_image(33, 21, vi.U8, 3, border=2, seed=6, fill_border=True)
     for wb in (0, 1):

@@ -44,6 +44,18 @@ def test_fill_border(orc, ref, mode, dtype, ch, border):
     np.testing.assert_array_equal(a.raw, b.raw)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape,border", [((3, 23), 5), ((19, 2), 4), ((2, 3), 7), ((1, 1), 3)])
+def test_fill_border_wider_than_the_image(orc, ref, mode, shape, border):
+    """border > nrows or > ncols: mirrored sources lie in other border regions, so the reference's region order (fill.hh:56-82)
+    shows; the pre-existing border bytes are random so that stale reads show too."""
+    a = rand_image(*shape, vi.U8, 1, border=border, seed=7, fill_border=True)
+    b = a.like(); b.raw[:] = a.raw
+    assert ref.ref_fill_border(P(a.desc), mode, None) == 0
+    assert orc.orc_fill_border(P(b.desc), mode, None) == 0
+    np.testing.assert_array_equal(a.raw, b.raw)
+
+
 @pytest.mark.parametrize("shape", [(40, 56), (41, 57), (135, 240)])
 @pytest.mark.parametrize("dtype,ch", [(vi.U8, 1), (vi.I32, 2), (vi.F32, 2)])
 def test_pyramid(orc, ref, shape, dtype, ch):

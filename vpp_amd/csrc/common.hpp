@@ -54,21 +54,54 @@ inline bool same_domain(const vpp_image_desc* a, const vpp_image_desc* b) { retu
 inline bool same_type(const vpp_image_desc* a, const vpp_image_desc* b) { return a->dtype == b->dtype && a->channels == b->channels; }
 inline bool aligned16(const vpp_image_desc* d) { return ((uintptr_t)d->first_pixel % 16) == 0 && (d->pitch % 16) == 0; }
 
-// Grow-only device scratch, one per host thread per user (the C ABI is re-entrant across host threads).  Work that uses it
-// is stream-ordered; if the same host thread comes back on a DIFFERENT stream while the previous call may still be
-// running, that stream is drained first so two in-flight calls never share the buffer.
+// Grow-only device scratch, per host thread and per user (the C ABI is re-entrant across host threads), one buffer per
+// (device, stream): work that uses it is stream-ordered, so calls on one stream reuse one buffer and calls on different streams
+// (several frame pairs in flight) or devices never share one — no cross-stream synchronisation, nothing that is illegal under
+// stream capture (a capture must not be the FIRST call on its stream at a given size: growing allocates).  At most kSlots
+// buffers are kept; the least recently used one is released (after a device synchronise) when another stream shows up, which
+// also retires the buffers of destroyed streams.
 struct Scratch {
-  void* p = nullptr; size_t cap = 0; hipStream_t last = nullptr; bool used = false;
+  static constexpr int kSlots = 8;
+  struct Slot { void* p = nullptr; size_t cap = 0; int dev = -1; hipStream_t st = nullptr; unsigned long long used = 0; };
+  Slot slots[kSlots];
+  unsigned long long tick = 0;
+  void* p = nullptr;   // the buffer of the last ensure()
   int ensure(size_t bytes, hipStream_t st) {
-    if (used && last != st) VPP_HIP_TRY(hipStreamSynchronize(last));
-    last = st; used = true;
-    if (bytes <= cap) return VPP_OK;
-    if (p) { VPP_HIP_TRY(hipStreamSynchronize(st)); VPP_HIP_TRY(hipFree(p)); p = nullptr; cap = 0; }
-    VPP_HIP_TRY(hipMalloc(&p, bytes));
-    cap = bytes;
+    int dev = 0;
+    VPP_HIP_TRY(hipGetDevice(&dev));
+    Slot* s = nullptr;
+    for (Slot& c : slots) if (c.p && c.dev == dev && c.st == st) { s = &c; break; }
+    if (!s) {
+      for (Slot& c : slots) if (!c.p) { s = &c; break; }
+      if (!s) {  // evict the least recently used buffer; it may still be in use by queued work, or belong to another device
+        s = &slots[0];
+        for (Slot& c : slots) if (c.used < s->used) s = &c;
+        if (release(*s) != VPP_OK) return VPP_ERR_HIP;
+      }
+      s->dev = dev; s->st = st;
+    }
+    s->used = ++tick;
+    if (bytes > s->cap) {
+      if (s->p) { VPP_HIP_TRY(hipStreamSynchronize(st)); VPP_HIP_TRY(hipFree(s->p)); s->p = nullptr; s->cap = 0; }
+      VPP_HIP_TRY(hipMalloc(&s->p, bytes));
+      s->cap = bytes;
+    }
+    p = s->p;
     return VPP_OK;
   }
-  ~Scratch() { if (p) (void)hipFree(p); }
+  static int release(Slot& c) {
+    if (!c.p) return VPP_OK;
+    int cur = 0;
+    VPP_HIP_TRY(hipGetDevice(&cur));
+    if (cur != c.dev) VPP_HIP_TRY(hipSetDevice(c.dev));
+    (void)hipDeviceSynchronize();
+    const hipError_t e = hipFree(c.p);
+    if (cur != c.dev) VPP_HIP_TRY(hipSetDevice(cur));
+    c = Slot();
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("scratch: hipFree failed: %s", hipGetErrorString(e)); return VPP_ERR_HIP; }
+    return VPP_OK;
+  }
+  ~Scratch() { for (Slot& c : slots) if (c.p) (void)hipFree(c.p); }
 };
 
 // blockIdx remap so that consecutive logical blocks share an XCD (hardware places block b on XCD b % 8;

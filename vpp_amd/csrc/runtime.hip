@@ -28,15 +28,21 @@ struct DevicePool {
   std::map<void*, size_t> live;               // every block handed out, with its rounded size
   size_t cached_bytes = 0;
 };
+std::mutex g_pools_mu;
+std::map<int, DevicePool*> g_pools;
 DevicePool& pool_of_current_device() {
-  static std::mutex mu;
-  static std::map<int, DevicePool*> pools;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  std::lock_guard<std::mutex> l(mu);
-  DevicePool*& p = pools[dev];
+  std::lock_guard<std::mutex> l(g_pools_mu);
+  DevicePool*& p = g_pools[dev];
   if (!p) p = new DevicePool();   // intentionally never destroyed: the HIP runtime may already be gone at exit
   return *p;
+}
+std::vector<DevicePool*> all_pools() {
+  std::lock_guard<std::mutex> l(g_pools_mu);
+  std::vector<DevicePool*> v;
+  for (auto& kv : g_pools) v.push_back(kv.second);
+  return v;
 }
 // size classes: 256 B granules, 4 KiB above 64 KiB — per-frame buffers whose element count drifts by a few entries keep hitting the same class
 inline size_t round_block(size_t bytes) { const size_t g = bytes >= (64u << 10) ? 4096 : 256; return ((bytes ? bytes : 1) + g - 1) / g * g; }
@@ -98,33 +104,46 @@ int vpp_malloc(size_t bytes, void** dptr) {
 
 int vpp_free(void* dptr) {
   if (!dptr) return VPP_OK;
-  DevicePool& P = pool_of_current_device();
   const size_t cap = (size_t)tuning("runtime.pool_mb", 2048) << 20;
-  {
-    std::lock_guard<std::mutex> l(P.mu);
-    auto it = P.live.find(dptr);
-    if (it != P.live.end()) {
-      const size_t rb = it->second;
-      P.live.erase(it);
-      if (P.cached_bytes + rb <= cap) { P.free_blocks.emplace(rb, dptr); P.cached_bytes += rb; return VPP_OK; }
-    }
+  // the block goes back to the pool of the device it was allocated on, whichever device is current now
+  DevicePool* P = nullptr;
+  size_t rb = 0;
+  for (DevicePool* cand : all_pools()) {
+    std::lock_guard<std::mutex> l(cand->mu);
+    auto it = cand->live.find(dptr);
+    if (it == cand->live.end()) continue;
+    rb = it->second;
+    cand->live.erase(it);
+    if (cand->cached_bytes + rb <= cap) { cand->free_blocks.emplace(rb, dptr); cand->cached_bytes += rb; return VPP_OK; }
+    P = cand;
+    break;
   }
-  VPP_HIP_TRY(hipFree(dptr));
+  (void)P;
+  VPP_HIP_TRY(hipFree(dptr));   // hipFree takes any device's pointer
   return VPP_OK;
 }
 
 // Pinned (page-locked) host staging memory, cached by size like the device blocks: a copy between HBM and pageable memory makes
 // the runtime pin the host pages first, which costs ~1 ms for a range it has not seen recently; per-frame result buffers
 // (keypoint lists, flow results) come from here instead.
-namespace { struct HostPool { std::mutex mu; std::multimap<size_t, void*> free_blocks; std::map<void*, size_t> live; }; HostPool g_host_pool; }
+namespace { struct HostPool { std::mutex mu; std::multimap<size_t, void*> free_blocks; std::map<void*, size_t> live; size_t cached_bytes = 0; }; HostPool g_host_pool; }
 
+// A request is served by the smallest cached block that holds it and is at most twice its size (per-frame buffers sized by a
+// drifting keypoint count keep landing in one block instead of adding a size class per frame); the cache is capped by the
+// tuning "runtime.host_pool_mb" (default 512 MiB of page-locked memory), beyond which freed blocks go back to the driver.
 int vpp_malloc_host(size_t bytes, void** hptr) {
   VPP_REQUIRE(hptr, VPP_ERR_INVALID_ARG, "vpp_malloc_host: null out pointer");
   const size_t rb = ((bytes ? bytes : 1) + 4095) / 4096 * 4096;
   {
     std::lock_guard<std::mutex> l(g_host_pool.mu);
-    auto it = g_host_pool.free_blocks.find(rb);
-    if (it != g_host_pool.free_blocks.end()) { *hptr = it->second; g_host_pool.free_blocks.erase(it); g_host_pool.live[*hptr] = rb; return VPP_OK; }
+    auto it = g_host_pool.free_blocks.lower_bound(rb);
+    if (it != g_host_pool.free_blocks.end() && it->first <= 2 * rb) {
+      *hptr = it->second;
+      g_host_pool.live[*hptr] = it->first;
+      g_host_pool.cached_bytes -= it->first;
+      g_host_pool.free_blocks.erase(it);
+      return VPP_OK;
+    }
   }
   VPP_HIP_TRY(hipHostMalloc(hptr, rb, hipHostMallocDefault));
   std::lock_guard<std::mutex> l(g_host_pool.mu);
@@ -134,18 +153,23 @@ int vpp_malloc_host(size_t bytes, void** hptr) {
 
 int vpp_free_host(void* hptr) {
   if (!hptr) return VPP_OK;
-  std::lock_guard<std::mutex> l(g_host_pool.mu);
-  auto it = g_host_pool.live.find(hptr);
-  VPP_REQUIRE(it != g_host_pool.live.end(), VPP_ERR_INVALID_ARG, "vpp_free_host: not a vpp_malloc_host block");
-  g_host_pool.free_blocks.emplace(it->second, hptr);
-  g_host_pool.live.erase(it);
+  const size_t cap = (size_t)tuning("runtime.host_pool_mb", 512) << 20;
+  {
+    std::lock_guard<std::mutex> l(g_host_pool.mu);
+    auto it = g_host_pool.live.find(hptr);
+    VPP_REQUIRE(it != g_host_pool.live.end(), VPP_ERR_INVALID_ARG, "vpp_free_host: not a vpp_malloc_host block");
+    const size_t rb = it->second;
+    g_host_pool.live.erase(it);
+    if (g_host_pool.cached_bytes + rb <= cap) { g_host_pool.free_blocks.emplace(rb, hptr); g_host_pool.cached_bytes += rb; return VPP_OK; }
+  }
+  VPP_HIP_TRY(hipHostFree(hptr));
   return VPP_OK;
 }
 
 int vpp_release_cached_memory(void) {
   {
     std::multimap<size_t, void*> hb;
-    { std::lock_guard<std::mutex> l(g_host_pool.mu); hb.swap(g_host_pool.free_blocks); }
+    { std::lock_guard<std::mutex> l(g_host_pool.mu); hb.swap(g_host_pool.free_blocks); g_host_pool.cached_bytes = 0; }
     for (auto& b : hb) VPP_HIP_TRY(hipHostFree(b.second));
   }
   DevicePool& P = pool_of_current_device();

@@ -3,6 +3,8 @@
 // blocks for _blockwise).  Extension options: _fast9_corrected_ring selects the true ring instead of the one
 // fast_detector9_simd samples; the default reproduces the reference.
 #pragma once
+#include <algorithm>
+#include <stdexcept>
 #include <stdexcept>
 #include <type_traits>
 #include <vector>
@@ -22,7 +24,11 @@ inline std::vector<vint2> detect(const image2d<unsigned char>& A, int th, const 
   for (int attempt = 0; attempt < 2; attempt++) {
     device::dbuf rc(size_t(capacity) * 8), sc(size_t(capacity) * 4);
     const int st = vpp_fast9_detect(&da, th, pm, mode, block_size, compat, (int32_t*)rc.p, (int32_t*)sc.p, capacity, &count, device::stream());
-    if (st == VPP_ERR_CAPACITY) { capacity = count; continue; }
+    if (st == VPP_ERR_CAPACITY) {
+      if (attempt == 1) throw std::runtime_error("fast9: the detector reported more keypoints than the capacity it had just asked for");
+      capacity = count;
+      continue;
+    }
     device::check(st, "vpp_fast9_detect");  // border < 3 -> std::runtime_error("Image need a border of 3px ...") like fast.hpp:937-938
     kps.resize(count);
     static_assert(sizeof(vint2) == 8, "vint2 must be two packed ints");

@@ -57,7 +57,11 @@ template <class V, unsigned N> struct pyramid {
     if (factor_ != 2.f) throw std::runtime_error("pyramid: only factor 2 is implemented on the device");
     fill_border_mirror(levels_[0]);
     for (size_t i = 1; i < levels_.size(); i++) {
-      const vpp_image_desc prev = levels_[i - 1].device_desc(false), next = levels_[i].device_desc(true);
+      // the low-pass reads 2 pixels past each edge: the reference filters from a border-2 copy whatever the level's own border
+      // is (pyramid.hh:15-36), so a pyramid built with _border < 2 (or none) gets a mirror-filled border-2 temporary here
+      image_type src = levels_[i - 1];
+      if (src.border() < 2) { src = clone(src, _border = 2); fill_border_mirror(src); }
+      const vpp_image_desc prev = src.device_desc(false), next = levels_[i].device_desc(true);
       device::check(vpp_pyr_down(&next, &prev, device::stream()), "vpp_pyr_down");
     }
     device::check(vpp_sync(device::stream()), "vpp_sync");
