@@ -61,3 +61,28 @@ def test_device_api_on_gpu():
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "device_api_test ok" in out.stdout
+
+
+def _compile_single_source(exe):
+    """The user's translation unit compiled by hipcc: -DVPP_AMD_DEVICE -DVPP_AMD_HIPCC turns opaque pixel_wise lambdas into gfx950 kernels."""
+    import __graft_entry__ as g
+    g.build()
+    os.makedirs(OUT, exist_ok=True)
+    subprocess.check_call(["hipcc", "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-result", "-Wno-unused-command-line-argument", "-DVPP_AMD_DEVICE", "-DVPP_AMD_HIPCC",
+                           "-I" + os.path.join(ROOT, "vpp_amd", "include"), "-I" + os.path.join(ROOT, "include"), os.path.join(CPP, "device_lambda_test.cc"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "vpp_amd", "csrc"), "-lvpp_amd", "-Wl,-rpath," + os.path.join(ROOT, "vpp_amd", "csrc")])
+    return exe
+
+
+def test_single_source_lambdas_compile():
+    """benchmarks/image_add.cc:51-57 and benchmarks/box_5x5_filter2.cc:71-81, pasted unmodified, compile for gfx950 against the drop-in headers."""
+    _compile_single_source(os.path.join(OUT, "device_lambda_test"))
+
+
+@pytest.mark.gpu
+def test_single_source_lambdas_on_gpu():
+    exe = _compile_single_source(os.path.join(OUT, "device_lambda_test_gpu"))
+    out = subprocess.run([exe, "time"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "device_lambda_test ok" in out.stdout
+    print(out.stdout)

@@ -133,6 +133,7 @@ template <class V, unsigned N> class imageNd {
   }
   const self const_subimage(const boxNd<N>& d) const { return subimage(d); }
 
+  const void* storage_id() const { return ptr_ ? (const void*)ptr_->store_.get() : nullptr; }  // identity of the pixel buffer (shared by sub-images)
   void set_external_data_holder(void* data, void (*deleter)(void*)) { ptr_->data_sptr_ = std::shared_ptr<void>(data, deleter); }
   void swap(imageNd& o) { o.ptr_.swap(ptr_); }
 

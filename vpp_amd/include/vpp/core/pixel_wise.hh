@@ -2,9 +2,13 @@
 // Reference: vpp/core/pixel_wise.hh:41-50, vpp/core/pixel_wise.hpp:14-217 (ranges = images, boxes, relative_access),
 // vpp/core/relative_accessor.hh:18-33; legacy box_nbh2d<V,R,C> (tests/box_nbh2d.cc:9-18, benchmarks/box_5x5_filter.cc:165-171).
 //
-// Two evaluation routes:
+// Three evaluation routes:
 //  * an opaque callable (any lambda) is applied on the host, row by row, exactly like the reference
 //    (OpenMP over rows unless _no_threads; the four traversal-order options are honoured);
+//  * the same callable in a translation unit compiled by hipcc with -DVPP_AMD_DEVICE -DVPP_AMD_HIPCC is the body of a generic
+//    gfx950 kernel (vpp/core/pixel_wise_device.hh) when it carries no state (a by-reference capture would hold host addresses;
+//    `_device` vouches for a by-value one), the traversal options are the defaults and the ranges do not alias; `_host` keeps a
+//    call on the host (a callable that uses host-only functions such as rand() must say so, since it cannot be compiled for the GPU);
 //  * a tagged functor from vpp::ops (add, sub, mul, min, max, absdiff, box_mean<R,C>) is, in a -DVPP_AMD_DEVICE build,
 //    dispatched through the C ABI to the hand-written gfx950 kernels (vpp_pixelwise_binary, vpp_box_filter).  A failing
 //    device call throws; it never silently re-runs on the host.
@@ -14,6 +18,7 @@
 #include <utility>
 
 #include <vpp/core/image2d.hh>
+#include <vpp/core/pixel_wise_device.hh>
 
 namespace vpp {
 
@@ -100,6 +105,23 @@ template <class F, class... ROWS> inline void process_row(bool right_to_left, F&
   if (!right_to_left) for (int c = c0; c <= c1; c++) call_lvalues(f, rows(c)...);
   else for (int c = c1; c >= c0; c--) call_lvalues(f, rows(c)...);
 }
+#if defined(VPP_AMD_DEVICE) && defined(__HIPCC__)
+// ranges the generic device kernel can address, their accessors (mirror pointers; the mirror becomes the newer copy: the kernel
+// may write through any reference it is handed) and the storage they live in (for the aliasing test)
+template <class T> struct device_range : std::false_type {};
+template <class V> struct device_range<imageNd<V, 2>> : std::is_trivially_copyable<V> {};
+template <> struct device_range<box2d> : std::true_type {};
+template <class V> struct device_range<relative_access_<imageNd<V, 2>>> : std::is_trivially_copyable<V> {};
+template <class V, int R, int C> struct device_range<box_nbh2d<V, R, C>> : std::is_trivially_copyable<V> {};
+template <class V> pwdev::image_acc<V> device_accessor(const image2d<V>& i) { const vpp_image_desc d = i.device_desc(true); return pwdev::image_acc<V>{(V*)d.first_pixel, d.pitch}; }
+inline pwdev::box_acc device_accessor(const box2d&) { return pwdev::box_acc{}; }
+template <class V> pwdev::nbh_acc<V> device_accessor(const relative_access_<image2d<V>>& r) { const vpp_image_desc d = r.img.device_desc(true); return pwdev::nbh_acc<V>{(V*)d.first_pixel, d.pitch}; }
+template <class V, int R, int C> pwdev::boxnbh_acc<V, R, C> device_accessor(const box_nbh2d<V, R, C>& n) { const vpp_image_desc d = n.img.device_desc(true); return pwdev::boxnbh_acc<V, R, C>{(V*)d.first_pixel, d.pitch}; }
+template <class V> const void* storage_of(const image2d<V>& i) { return i.storage_id(); }
+inline const void* storage_of(const box2d&) { return nullptr; }
+template <class V> const void* storage_of(const relative_access_<image2d<V>>& r) { return r.img.storage_id(); }
+template <class V, int R, int C> const void* storage_of(const box_nbh2d<V, R, C>& n) { return n.img.storage_id(); }
+#endif
 template <class T> struct is_image2d : std::false_type {};
 template <class V> struct is_image2d<imageNd<V, 2>> : std::true_type { typedef V value_type; };
 }  // namespace pw
@@ -112,13 +134,52 @@ template <class OPTS, class... R> class pixel_wise_impl {
 
   template <class F> using kernel_return_type = decltype(std::declval<F&>()(std::declval<decltype(pw::row_access(std::declval<R&>(), 0)(0))&>()...));
 
-  // opaque callable: host evaluation (pixel_wise.hpp:146-165,188-213)
-  template <class F> auto operator|(F fun) { return eval(fun, std::is_void<kernel_return_type<F>>()); }
+  // opaque callable (pixel_wise.hpp:146-165,188-213): host evaluation, or — single-source hipcc build — the generic device kernel
+  template <class F> auto operator|(F fun) {
+#if defined(VPP_AMD_DEVICE) && defined(__HIPCC__) && defined(VPP_AMD_HIPCC)
+    if constexpr (device_eligible<F>()) {
+      if (!ranges_alias(std::index_sequence_for<R...>())) return eval_device(fun, std::is_void<kernel_return_type<F>>());
+    }
+#endif
+    return eval(fun, std::is_void<kernel_return_type<F>>());
+  }
 
 #ifdef VPP_AMD_DEVICE
   // tagged functors: gfx950 kernels through the C ABI
   template <int OP> void operator|(ops::binary<OP>) { device_binary(OP, std::index_sequence_for<R...>()); }
   template <int RR, int CC> void operator|(ops::box_mean<RR, CC>) { device_box(RR, CC); }
+#endif
+
+#if defined(VPP_AMD_DEVICE) && defined(__HIPCC__) && defined(VPP_AMD_HIPCC)
+  template <class F> static constexpr bool device_eligible() {
+    return std::is_trivially_copyable<F>::value && (std::is_empty<F>::value || OPTS::has(_device)) && !OPTS::has(_host) && !OPTS::has(_no_threads) &&
+           !OPTS::has(_right_to_left) && !OPTS::has(_bottom_to_top) && !OPTS::has(_left_to_right) && !OPTS::has(_top_to_bottom) &&
+           !OPTS::has(_mem_forward) && !OPTS::has(_mem_backward) && (pw::device_range<R>::value && ...);
+  }
+  template <std::size_t... I> bool ranges_alias(std::index_sequence<I...>) const {
+    const void* st[] = {pw::storage_of(std::get<I>(ranges_))...};
+    for (std::size_t a = 0; a < sizeof...(I); a++)
+      for (std::size_t b = a + 1; b < sizeof...(I); b++)
+        if (st[a] && st[a] == st[b]) return true;
+    return false;
+  }
+  template <class F, std::size_t... I> void run_device(F& fun, std::index_sequence<I...>) {
+    const auto p1 = std::get<0>(ranges_).first_point_coordinates();
+    const auto p2 = std::get<0>(ranges_).last_point_coordinates();
+    pwdev::launch(fun, p1[0], p1[1], p2[0] - p1[0] + 1, p2[1] - p1[1] + 1, pw::device_accessor(std::get<I>(ranges_))...);
+  }
+  template <class F> void eval_device(F& fun, std::true_type) { run_device(fun, std::index_sequence_for<R...>()); }
+  template <class F> auto eval_device(F& fun, std::false_type) {
+    typedef typename std::decay<kernel_return_type<F>>::type value_type;
+    const auto p1 = std::get<0>(ranges_).first_point_coordinates();
+    const auto p2 = std::get<0>(ranges_).last_point_coordinates();
+    image2d<value_type> out(box2d(p1, p2));
+    auto all = std::tuple_cat(std::make_tuple(out), ranges_);
+    auto wrapper = [fun](value_type& o, auto&... ps) mutable { o = fun(ps...); };
+    pixel_wise_impl<OPTS, image2d<value_type>, R...> sub(all, options_);
+    sub.run_device(wrapper, std::make_index_sequence<sizeof...(R) + 1>());
+    return out;
+  }
 #endif
 
  private:

@@ -1,0 +1,160 @@
+// pixel_wise_device.hh — GPU evaluation of pixel_wise(ranges...) | <opaque callable> when the USER's translation unit is
+// compiled by hipcc (single-source mode: -DVPP_AMD_DEVICE, --offload-arch=gfx950).  Included by pixel_wise.hh.
+// Reference semantics: vpp/core/pixel_wise.hpp:68-105 (process_row), :146-165 (run), :188-213 (operator|); call sites such as
+// benchmarks/image_add.cc:51-57 and benchmarks/box_5x5_filter2.cc:71-81 compile unchanged.
+//
+// hipcc makes a plain C++ lambda callable from device code, so the callable itself is the kernel body: one generic, hand-written
+// __global__ function templated on the callable and on one accessor per range.
+//  * image ranges: a lane owns NPX consecutive pixels of a row — as many as make every range's chunk a multiple of 16 bytes —
+//    loads them with 16-byte accesses into registers, applies the callable to references to those registers and writes a chunk
+//    back with 16-byte stores unless the compiler can prove the callable left it untouched (so `a = b + c` moves 12 B / px: a
+//    chunk that is overwritten without being read is not loaded, one that is only read is not stored);
+//  * relative_access / box_nbh2d ranges: a functor over global memory (row pitch + column offset), L1/L2 serve the overlap;
+//  * box2d ranges: the coordinates.
+// What stays on the host (pixel_wise.hh decides): callables with state (a by-reference capture would hold host addresses; use
+// vpp::ops tags or the _device option to vouch for a by-value capture), non-default traversal options (_no_threads, _right_to_left,
+// _bottom_to_top... imply an order), ranges that alias each other's storage, pixel types that are not trivially copyable.
+#pragma once
+#if defined(VPP_AMD_DEVICE) && defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#include <tuple>
+#include <type_traits>
+
+namespace vpp {
+namespace pwdev {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- device-side accessors, built on the host from the ranges (mirror pointers) ----------------------------------
+template <class V> struct image_acc { V* p0; int pitch; };                    // p0 = pixel (0, 0) in HBM
+struct box_acc {};
+template <class V> struct nbh_acc { V* p0; int pitch; };
+template <class V, int R, int C> struct boxnbh_acc { V* p0; int pitch; };
+
+template <class V> struct nbh_px {  // relative_access_kernel on the device (relative_accessor.hh:26-33)
+  V* p; int pitch;
+  __device__ V& operator()(int dr, int dc) const { return *(V*)((char*)p + (ptrdiff_t)dr * pitch + (ptrdiff_t)dc * (int)sizeof(V)); }
+  __device__ V& operator()(vint2 d) const { return (*this)(d[0], d[1]); }
+};
+template <class V, int R, int C> struct boxnbh_px {  // box_nbh2d<V,R,C> at a point
+  V* p; int pitch;
+  __device__ V& operator()(int dr, int dc) const { return *(V*)((char*)p + (ptrdiff_t)dr * pitch + (ptrdiff_t)dc * (int)sizeof(V)); }
+  __device__ V& north() const { return (*this)(-1, 0); }
+  __device__ V& south() const { return (*this)(1, 0); }
+  __device__ V& east() const { return (*this)(0, 1); }
+  __device__ V& west() const { return (*this)(0, -1); }
+  template <class F> __device__ void for_all(F f) const {
+    for (int dr = -(R / 2); dr <= R / 2; dr++)
+      for (int dc = -(C / 2); dc <= C / 2; dc++) f((*this)(dr, dc));
+  }
+};
+
+template <class A> struct is_image_acc : std::false_type {};
+template <class V> struct is_image_acc<image_acc<V>> : std::true_type {};
+
+// per-lane staging of one range: NPX pixels of an image in registers; nothing for the other range kinds
+template <class A, int NPX> struct stage { __device__ void load(const A&, int, int) {} __device__ void store(const A&, int, int) {} };
+template <class V, int NPX> struct stage<image_acc<V>, NPX> {
+  typedef typename std::remove_const<V>::type T;
+  static constexpr int kBytes = NPX * (int)sizeof(T);
+  static constexpr bool kVec = kBytes % 16 == 0;   // NPX > 1 chunks are 16-byte multiples and 16-byte aligned (the launcher checks)
+  union buf { T px[NPX]; u32x4 q[(kBytes + 15) / 16]; unsigned char b[kBytes]; __device__ buf() {} } now, old;
+  __device__ char* addr(const image_acc<V>& a, int r, int c) const { return (char*)a.p0 + (ptrdiff_t)r * a.pitch + (ptrdiff_t)c * (int)sizeof(T); }
+  __device__ void load(const image_acc<V>& a, int r, int c) {
+    const char* p = addr(a, r, c);
+    if constexpr (kVec) {
+#pragma unroll
+      for (int i = 0; i < kBytes / 16; i++) now.q[i] = ((const u32x4*)p)[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPX; i++) now.px[i] = ((const T*)p)[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kBytes; i++) old.b[i] = now.b[i];
+  }
+  __device__ void store(const image_acc<V>& a, int r, int c) {
+    if (std::is_const<V>::value) return;
+    // Unchanged chunks are not written.  When the compiler can see that the callable never assigns through this reference the
+    // comparison folds to a constant and the store disappears; when it cannot tell at compile time, the chunk is stored
+    // unconditionally — `old` is then dead, and with it the load of a chunk that the callable only overwrites.
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < kBytes; i++) same = same && (now.b[i] == old.b[i]);
+    if (__builtin_constant_p(same) && same) return;
+    char* p = addr(a, r, c);
+    if constexpr (kVec) {
+#pragma unroll
+      for (int i = 0; i < kBytes / 16; i++) ((u32x4*)p)[i] = now.q[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPX; i++) ((T*)p)[i] = now.px[i];
+    }
+  }
+};
+
+// the argument the callable sees for pixel i of the lane's chunk
+template <class V, int NPX> __device__ V& arg(stage<image_acc<V>, NPX>& s, const image_acc<V>&, int, int, int i) { return (V&)s.now.px[i]; }
+template <int NPX> __device__ vint2 arg(stage<box_acc, NPX>&, const box_acc&, int r, int c, int i) { return vint2(r, c + i); }
+template <class V, int NPX> __device__ nbh_px<V> arg(stage<nbh_acc<V>, NPX>&, const nbh_acc<V>& a, int r, int c, int i) {
+  return nbh_px<V>{(V*)((char*)a.p0 + (ptrdiff_t)r * a.pitch) + c + i, a.pitch};
+}
+template <class V, int R, int C, int NPX> __device__ boxnbh_px<V, R, C> arg(stage<boxnbh_acc<V, R, C>, NPX>&, const boxnbh_acc<V, R, C>& a, int r, int c, int i) {
+  return boxnbh_px<V, R, C>{(V*)((char*)a.p0 + (ptrdiff_t)r * a.pitch) + c + i, a.pitch};
+}
+template <class F, class... X> __device__ __forceinline__ void call_lvalues(F& f, X&&... x) { f(x...); }  // kernels may take `auto&`
+
+// NPX consecutive pixels of row r starting at column c: stage, apply, write back
+template <int NPX, class F, class... A> __device__ __forceinline__ void pixel_step(F& f, int r, int c, const A&... acc) {
+  std::tuple<stage<A, NPX>...> st;
+  std::apply([&](auto&... s) { (void)std::initializer_list<int>{(s.load(acc, r, c), 0)...}; }, st);
+#pragma unroll
+  for (int i = 0; i < NPX; i++) std::apply([&](auto&... s) { call_lvalues(f, arg(s, acc, r, c, i)...); }, st);
+  std::apply([&](auto&... s) { (void)std::initializer_list<int>{(s.store(acc, r, c), 0)...}; }, st);
+}
+
+// One lane = NPX consecutive pixels of one row (the row's ragged tail: pixel by pixel).  grid.x covers the chunks of a row,
+// grid.y the rows.
+template <int NPX, class F, class... A>
+__global__ __launch_bounds__(256) void pixel_wise_kernel(F f, int r0, int c0, int nrows, int ncols, A... acc) {
+  const int chunk = blockIdx.x * 256 + threadIdx.x;
+  const int c = c0 + chunk * NPX;
+  if (chunk * NPX >= ncols) return;
+  const int n = min(NPX, ncols - chunk * NPX);
+  for (int r = r0 + blockIdx.y; r < r0 + nrows; r += gridDim.y) {
+    if (n == NPX) pixel_step<NPX>(f, r, c, acc...);
+    else
+      for (int i = 0; i < n; i++) pixel_step<1>(f, r, c + i, acc...);
+  }
+}
+
+constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
+constexpr int lcm_(int a, int b) { return a / gcd_(a, b) * b; }
+template <class A> struct npx_of { enum { value = 1 }; };
+template <class V> struct npx_of<image_acc<V>> { enum { value = 16 / gcd_(16, (int)sizeof(V)) }; };
+template <class... A> struct npx_all;
+template <> struct npx_all<> { enum { value = 1 }; };
+template <class A0, class... A> struct npx_all<A0, A...> { enum { value = lcm_(npx_of<A0>::value, npx_all<A...>::value) }; };
+
+template <class A> inline bool aligned16(const A&, int) { return true; }
+template <class V> inline bool aligned16(const image_acc<V>& a, int c0) { return ((size_t)((char*)a.p0 + (ptrdiff_t)c0 * (int)sizeof(V)) % 16) == 0 && a.pitch % 16 == 0; }
+
+template <class F, class... A> void launch(F f, int r0, int c0, int nrows, int ncols, A... acc) {
+  if (nrows <= 0 || ncols <= 0) return;
+  constexpr int NPX = npx_all<A...>::value;
+  bool al = true;
+  (void)std::initializer_list<int>{(al = al && aligned16(acc, c0), 0)...};
+  const int gy = nrows < 65535 ? nrows : 65535;
+  if (al && NPX > 1) {
+    const int chunks = (ncols + NPX - 1) / NPX;
+    hipLaunchKernelGGL((pixel_wise_kernel<NPX, F, A...>), dim3((chunks + 255) / 256, gy), dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
+  } else {  // unaligned view (sub-image at an odd column, foreign pitch): one pixel per lane
+    hipLaunchKernelGGL((pixel_wise_kernel<1, F, A...>), dim3((ncols + 255) / 256, gy), dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw std::runtime_error(std::string("pixel_wise (device): launch failed: ") + hipGetErrorString(e));
+  device::check(vpp_sync(device::stream()), "vpp_sync");
+}
+
+}  // namespace pwdev
+}  // namespace vpp
+#endif

@@ -15,5 +15,8 @@ VPP_DEFINE_SYMBOL(block_size)
 VPP_DEFINE_SYMBOL(mem_forward)
 VPP_DEFINE_SYMBOL(mem_backward)
 VPP_DEFINE_SYMBOL(tie_arguments)
+// not in the reference: where an opaque pixel_wise callable runs in a TU compiled by hipcc (vpp/core/pixel_wise_device.hh)
+VPP_DEFINE_SYMBOL(host)
+VPP_DEFINE_SYMBOL(device)
 
 namespace vpp { using namespace s; }

@@ -5,6 +5,15 @@
 #include <cmath>
 #include <type_traits>
 
+// In a translation unit compiled by hipcc the pixel types are also usable inside device code (pixel_wise lambdas evaluated on
+// the GPU, vpp/core/pixel_wise_device.hh): every member below is host + device there.
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define VPP_HD __host__ __device__
+#else
+#define VPP_HD
+#endif
+
 namespace vpp {
 
 template <class T, unsigned N> struct vector {
@@ -13,38 +22,38 @@ template <class T, unsigned N> struct vector {
   T v[N];
 
   vector() = default;
-  template <class A, class B, unsigned M = N, class = typename std::enable_if<M == 2>::type> vector(A a, B b) { v[0] = T(a); v[1] = T(b); }
-  template <class A, class B, class C, unsigned M = N, class = typename std::enable_if<M == 3>::type> vector(A a, B b, C c) { v[0] = T(a); v[1] = T(b); v[2] = T(c); }
-  template <class A, class B, class C, class D, unsigned M = N, class = typename std::enable_if<M == 4>::type> vector(A a, B b, C c, D d) { v[0] = T(a); v[1] = T(b); v[2] = T(c); v[3] = T(d); }
-  explicit vector(const T* p) { for (unsigned i = 0; i < N; i++) v[i] = p[i]; }
+  template <class A, class B, unsigned M = N, class = typename std::enable_if<M == 2>::type> VPP_HD vector(A a, B b) { v[0] = T(a); v[1] = T(b); }
+  template <class A, class B, class C, unsigned M = N, class = typename std::enable_if<M == 3>::type> VPP_HD vector(A a, B b, C c) { v[0] = T(a); v[1] = T(b); v[2] = T(c); }
+  template <class A, class B, class C, class D, unsigned M = N, class = typename std::enable_if<M == 4>::type> VPP_HD vector(A a, B b, C c, D d) { v[0] = T(a); v[1] = T(b); v[2] = T(c); v[3] = T(d); }
+  VPP_HD explicit vector(const T* p) { for (unsigned i = 0; i < N; i++) v[i] = p[i]; }
 
-  static vector Zero() { vector r; for (unsigned i = 0; i < N; i++) r.v[i] = T(0); return r; }
-  static vector Ones() { vector r; for (unsigned i = 0; i < N; i++) r.v[i] = T(1); return r; }
-  static constexpr int size() { return N; }
-  T& operator[](int i) { return v[i]; }
-  const T& operator[](int i) const { return v[i]; }
-  T& operator()(int i) { return v[i]; }
-  const T& operator()(int i) const { return v[i]; }
-  template <class U> vector<U, N> cast() const { vector<U, N> r; for (unsigned i = 0; i < N; i++) r.v[i] = U(v[i]); return r; }
-  template <unsigned K> vector<T, K> segment(int start) const { vector<T, K> r; for (unsigned i = 0; i < K; i++) r.v[i] = v[start + i]; return r; }
+  VPP_HD static vector Zero() { vector r; for (unsigned i = 0; i < N; i++) r.v[i] = T(0); return r; }
+  VPP_HD static vector Ones() { vector r; for (unsigned i = 0; i < N; i++) r.v[i] = T(1); return r; }
+  VPP_HD static constexpr int size() { return N; }
+  VPP_HD T& operator[](int i) { return v[i]; }
+  VPP_HD const T& operator[](int i) const { return v[i]; }
+  VPP_HD T& operator()(int i) { return v[i]; }
+  VPP_HD const T& operator()(int i) const { return v[i]; }
+  template <class U> VPP_HD vector<U, N> cast() const { vector<U, N> r; for (unsigned i = 0; i < N; i++) r.v[i] = U(v[i]); return r; }
+  template <unsigned K> VPP_HD vector<T, K> segment(int start) const { vector<T, K> r; for (unsigned i = 0; i < K; i++) r.v[i] = v[start + i]; return r; }
 
-  vector operator-() const { vector r; for (unsigned i = 0; i < N; i++) r.v[i] = -v[i]; return r; }
-  vector& operator+=(const vector& o) { for (unsigned i = 0; i < N; i++) v[i] += o.v[i]; return *this; }
-  vector& operator-=(const vector& o) { for (unsigned i = 0; i < N; i++) v[i] -= o.v[i]; return *this; }
-  template <class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> vector& operator*=(S s) { for (unsigned i = 0; i < N; i++) v[i] *= T(s); return *this; }
-  template <class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> vector& operator/=(S s) { for (unsigned i = 0; i < N; i++) v[i] /= T(s); return *this; }
-  bool operator==(const vector& o) const { for (unsigned i = 0; i < N; i++) if (!(v[i] == o.v[i])) return false; return true; }
-  bool operator!=(const vector& o) const { return !(*this == o); }
-  T squaredNorm() const { T s = v[0] * v[0]; for (unsigned i = 1; i < N; i++) s += v[i] * v[i]; return s; }
-  T norm() const { return T(std::sqrt(squaredNorm())); }
-  T dot(const vector& o) const { T s = v[0] * o.v[0]; for (unsigned i = 1; i < N; i++) s += v[i] * o.v[i]; return s; }
+  VPP_HD vector operator-() const { vector r; for (unsigned i = 0; i < N; i++) r.v[i] = -v[i]; return r; }
+  VPP_HD vector& operator+=(const vector& o) { for (unsigned i = 0; i < N; i++) v[i] += o.v[i]; return *this; }
+  VPP_HD vector& operator-=(const vector& o) { for (unsigned i = 0; i < N; i++) v[i] -= o.v[i]; return *this; }
+  template <class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> VPP_HD vector& operator*=(S s) { for (unsigned i = 0; i < N; i++) v[i] *= T(s); return *this; }
+  template <class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> VPP_HD vector& operator/=(S s) { for (unsigned i = 0; i < N; i++) v[i] /= T(s); return *this; }
+  VPP_HD bool operator==(const vector& o) const { for (unsigned i = 0; i < N; i++) if (!(v[i] == o.v[i])) return false; return true; }
+  VPP_HD bool operator!=(const vector& o) const { return !(*this == o); }
+  VPP_HD T squaredNorm() const { T s = v[0] * v[0]; for (unsigned i = 1; i < N; i++) s += v[i] * v[i]; return s; }
+  VPP_HD T norm() const { return T(std::sqrt(squaredNorm())); }
+  VPP_HD T dot(const vector& o) const { T s = v[0] * o.v[0]; for (unsigned i = 1; i < N; i++) s += v[i] * o.v[i]; return s; }
 };
 
-template <class T, unsigned N> vector<T, N> operator+(vector<T, N> a, const vector<T, N>& b) { a += b; return a; }
-template <class T, unsigned N> vector<T, N> operator-(vector<T, N> a, const vector<T, N>& b) { a -= b; return a; }
-template <class T, unsigned N, class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> vector<T, N> operator*(vector<T, N> a, S s) { a *= s; return a; }
-template <class T, unsigned N, class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> vector<T, N> operator*(S s, vector<T, N> a) { for (unsigned i = 0; i < N; i++) a.v[i] = T(s) * a.v[i]; return a; }
-template <class T, unsigned N, class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> vector<T, N> operator/(vector<T, N> a, S s) { a /= s; return a; }
+template <class T, unsigned N> VPP_HD vector<T, N> operator+(vector<T, N> a, const vector<T, N>& b) { a += b; return a; }
+template <class T, unsigned N> VPP_HD vector<T, N> operator-(vector<T, N> a, const vector<T, N>& b) { a -= b; return a; }
+template <class T, unsigned N, class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> VPP_HD vector<T, N> operator*(vector<T, N> a, S s) { a *= s; return a; }
+template <class T, unsigned N, class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> VPP_HD vector<T, N> operator*(S s, vector<T, N> a) { for (unsigned i = 0; i < N; i++) a.v[i] = T(s) * a.v[i]; return a; }
+template <class T, unsigned N, class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> VPP_HD vector<T, N> operator/(vector<T, N> a, S s) { a /= s; return a; }
 
 #define VPP_ALIAS_DECL(T1, T2)            \
   template <unsigned N> using v##T2 = vector<T1, N>; \
@@ -63,18 +72,18 @@ template <class V> struct cast_to_float_ { typedef float ret; };
 template <class X, unsigned N> struct cast_to_float_<vector<X, N>> { typedef vector<float, N> ret; };
 template <class V> using cast_to_float = typename cast_to_float_<V>::ret;
 
-template <class V> struct zero { operator V() { return V(0); } };
-template <class X, unsigned N> struct zero<vector<X, N>> { operator vector<X, N>() { return vector<X, N>::Zero(); } };
+template <class V> struct zero { VPP_HD operator V() { return V(0); } };
+template <class X, unsigned N> struct zero<vector<X, N>> { VPP_HD operator vector<X, N>() { return vector<X, N>::Zero(); } };
 
 // cast<U>(v) (vector.hh:55-109): scalar<->scalar, vector<->vector of the same size, size-1 vector <-> scalar
 namespace detail {
 template <class T> struct is_vector : std::false_type {};
 template <class X, unsigned N> struct is_vector<vector<X, N>> : std::true_type {};
 }  // namespace detail
-template <class U, class V> typename std::enable_if<!detail::is_vector<U>::value && !detail::is_vector<V>::value, U>::type cast(const V& v) { return U(v); }
-template <class U, class X, unsigned N> typename std::enable_if<detail::is_vector<U>::value, U>::type cast(const vector<X, N>& v) { return v.template cast<typename U::Scalar>(); }
-template <class U, class X> typename std::enable_if<!detail::is_vector<U>::value, U>::type cast(const vector<X, 1>& v) { return U(v[0]); }
-template <class U, class V> typename std::enable_if<detail::is_vector<U>::value && !detail::is_vector<V>::value, U>::type cast(const V& v) { U r; r[0] = typename U::Scalar(v); return r; }
+template <class U, class V> VPP_HD typename std::enable_if<!detail::is_vector<U>::value && !detail::is_vector<V>::value, U>::type cast(const V& v) { return U(v); }
+template <class U, class X, unsigned N> VPP_HD typename std::enable_if<detail::is_vector<U>::value, U>::type cast(const vector<X, N>& v) { return v.template cast<typename U::Scalar>(); }
+template <class U, class X> VPP_HD typename std::enable_if<!detail::is_vector<U>::value, U>::type cast(const vector<X, 1>& v) { return U(v[0]); }
+template <class U, class V> VPP_HD typename std::enable_if<detail::is_vector<U>::value && !detail::is_vector<V>::value, U>::type cast(const V& v) { U r; r[0] = typename U::Scalar(v); return r; }
 
 // pixel-type traits used by the device glue: component type + channel count
 template <class V> struct pixel_traits { typedef V component; enum { channels = 1 }; };
