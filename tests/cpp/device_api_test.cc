@@ -284,6 +284,13 @@ static void test_dense_fast_and_blockwise_maxima() {
   S(3, 4) = 7; S(5, 5) = 7; S(2, 2) = 3; S(12, 13) = 2; S(15, 3) = -4;
   blockwise_maxima_filter(S, 10);
   CHECK(S(3, 4) == 7 && S(5, 5) == 0 && S(2, 2) == 0 && S(12, 13) == 2 && S(15, 3) == 0);
+  // the same per-block step as a block_wise expression (block_wise.hh:26-56 + the tagged functor), against the oracle
+  image2d<int> T(37, 53), W(37, 53);
+  for (auto p : T.domain()) T(p) = W(p) = (rng() % 5 == 0) ? int(rng() % 50) : 0;
+  block_wise(vint2(7, 7), T) | ops::block_maxima();
+  const vpp_image_desc dw = host_desc(W);
+  CHECK(orc_blockwise_maxima_filter(&dw, 7) == 0);
+  for (auto p : T.domain()) CHECK(T(p) == W(p));
 }
 
 // antialiasing_lowpass_filter / subsample2 / antialias_subsample2 (pyramid.hh:12-123) against the fused pyramid step

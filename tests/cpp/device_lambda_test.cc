@@ -146,6 +146,32 @@ static void test_device_equals_host() {
   }
 }
 
+// block_wise on the device: one lane per block, the callable sees views (tests/block_wise.cc:101-114 restated on views)
+static void test_block_wise_device() {
+  {
+    image2d<int> img(10, 10, _border = 1), ref(10, 10, _border = 1);
+    for (auto* im : {&img, &ref}) { fill_border_with_value(*im, 2); fill(*im, 0); }
+    auto k = [] (auto si) { for (int r = 0; r < si.nrows(); r++) for (int c = 0; c < si.ncols(); c++) si(r, c) = 1 + si.nrows() * 10 + si.ncols(); };
+    block_wise(vint2(3, 3), img) | k;                                   // device: pwdev::block_view<int>
+    block_wise(vint2(3, 3), ref)(_host) | k;                            // host: image2d<int> sub-images
+    for (auto p : img.domain_with_border()) CHECK(img(p) == ref(p));    // blocks cover the image, clip at its edge, never touch the border
+    CHECK(img(0, 0) == 34 && img(9, 9) == 12 && img(-1, -1) == 2);
+  }
+  {  // two ranges + a box range: per-block sum of one image into the block's first pixel of another, block origin from the box
+    image2d<int> A(37, 53), S(37, 53), S2(37, 53);
+    for (auto p : A.domain()) A(p) = int(rng() % 100);
+    fill(S, 0); fill(S2, 0);
+    auto k = [] (auto b, auto a, auto s) {
+      int sum = 0;
+      for (int r = 0; r < a.nrows(); r++) for (int c = 0; c < a.ncols(); c++) sum += a(r, c);
+      s(0, 0) = sum + b.p1()[0] * 7 + b.p1()[1];
+    };
+    block_wise(vint2(8, 16), A.domain(), A, S) | k;
+    block_wise(vint2(8, 16), A.domain(), A, S2)(_host) | k;
+    CHECK(same_pixels(S, S2));
+  }
+}
+
 static double seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static void time_4k() {
@@ -168,6 +194,7 @@ static void time_4k() {
 int main(int argc, char** argv) {
   test_reference_bodies();
   test_device_equals_host();
+  test_block_wise_device();
   if (argc > 1 && !std::strcmp(argv[1], "time")) time_4k();
   std::printf("device_lambda_test ok\n");
   return 0;

@@ -77,6 +77,7 @@ template <int R, int C> struct box_mean {
     out = vpp::cast<V>(sum / (R * C));
   }
 };
+struct block_maxima {};  // block_wise(vint2(b, b), img) | ops::block_maxima(): see block_wise.hh
 }  // namespace ops
 
 namespace pw {

@@ -155,6 +155,47 @@ template <class F, class... A> void launch(F f, int r0, int c0, int nrows, int n
   device::check(vpp_sync(device::stream()), "vpp_sync");
 }
 
+// ---- block_wise on the device (vpp/core/block_wise.hh:26-56): one lane per block, the callable sees one view per range --------
+// A view is what a sub-image is to host code, reduced to what device code can hold: pixel (0, 0) of the block, the pitch and the
+// block's extent (clipped to the domain).  view(r, c), view(vint2), view[r] (row pointer), nrows(), ncols().
+template <class V> struct block_view {
+  V* p0; int pitch, nr, nc;
+  __device__ int nrows() const { return nr; }
+  __device__ int ncols() const { return nc; }
+  __device__ V* operator[](int r) const { return (V*)((char*)p0 + (ptrdiff_t)r * pitch); }
+  __device__ V& operator()(int r, int c) const { return (*this)[r][c]; }
+  __device__ V& operator()(vint2 p) const { return (*this)[p[0]][p[1]]; }
+};
+struct box_view {  // a box2d range: the block's corners in the coordinates of the first range
+  int r0, c0, r1, c1;
+  __device__ vint2 p1() const { return vint2(r0, c0); }
+  __device__ vint2 p2() const { return vint2(r1, c1); }
+  __device__ int nrows() const { return r1 - r0 + 1; }
+  __device__ int ncols() const { return c1 - c0 + 1; }
+};
+template <class V> __device__ block_view<V> block_arg(const image_acc<V>& a, int r0, int c0, int r1, int c1) {
+  return block_view<V>{(V*)((char*)a.p0 + (ptrdiff_t)r0 * a.pitch) + c0, a.pitch, r1 - r0 + 1, c1 - c0 + 1};
+}
+__device__ inline box_view block_arg(const box_acc&, int r0, int c0, int r1, int c1) { return box_view{r0, c0, r1, c1}; }
+
+template <class F, class... A>
+__global__ __launch_bounds__(64) void block_wise_kernel(F f, int rstart, int cstart, int rend, int cend, int bsr, int bsc, int gr, int gc, A... acc) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= gr * gc) return;
+  const int br = b / gc, bc = b - br * gc;
+  const int r0 = rstart + br * bsr, c0 = cstart + bc * bsc;
+  const int r1 = min(r0 + bsr - 1, rend), c1 = min(c0 + bsc - 1, cend);
+  call_lvalues(f, block_arg(acc, r0, c0, r1, c1)...);
+}
+template <class F, class... A> void launch_blocks(F f, int rstart, int cstart, int rend, int cend, int bsr, int bsc, A... acc) {
+  const int gr = (rend - rstart) / bsr + 1, gc = (cend - cstart) / bsc + 1;   // block_wise.hh:37-38
+  if (gr <= 0 || gc <= 0) return;
+  hipLaunchKernelGGL((block_wise_kernel<F, A...>), dim3((gr * gc + 63) / 64), dim3(64), 0, (hipStream_t)device::stream(), f, rstart, cstart, rend, cend, bsr, bsc, gr, gc, acc...);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw std::runtime_error(std::string("block_wise (device): launch failed: ") + hipGetErrorString(e));
+  device::check(vpp_sync(device::stream()), "vpp_sync");
+}
+
 }  // namespace pwdev
 }  // namespace vpp
 #endif
