@@ -209,6 +209,34 @@ int vpp_keypoint_merge(const int32_t* rc_moved, const int32_t* rc_prev, const ui
  * row-major order without the centre; u8 x1 -> u8 x1, in needs border >= 1. */
 int vpp_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in, void* stream);
 
+/* ---- video_extruder with its state resident in HBM (vpp/algorithms/video_extruder/video_extruder.hpp:24-135; SURVEY 8b
+ *      `video_extruder_step`, 8f row 2).  vpp_video_extruder_create = video_extruder_init(domain) (:14-20); one
+ *      vpp_video_extruder_step = one video_extruder_update(ctx, frame1, frame2, options...) with the options of :35-41 in `params`
+ *      (defaults 10, 10, 5, 15, 3, 9, 2).  Keypoints (position, velocity, age: keypoint_container.hh:13-25, dead entries kept in
+ *      place until the next compaction exactly as keypoint_container does) and trajectories (keypoint_trajectory.hh:11-72, as
+ *      rings of trajectory_capacity + 1 slots, newest first from `head`) never leave the device; the step synchronises the
+ *      stream only on re-detection frames (the FAST count).  The accessors copy the state to HOST buffers and synchronise. ---- */
+typedef struct vpp_video_extruder vpp_video_extruder;
+typedef struct vpp_video_extruder_params {
+  int32_t detector_th, keypoint_spacing, detector_period, max_trajectory_length, nscales, winsize, propagation;
+} vpp_video_extruder_params;
+int vpp_video_extruder_create(vpp_video_extruder** ve, int nrows, int ncols, int trajectory_capacity);
+int vpp_video_extruder_destroy(vpp_video_extruder* ve);
+int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2,
+                            const vpp_video_extruder_params* params, void* stream);
+int vpp_video_extruder_count(const vpp_video_extruder* ve, int* n, int* frame_id);   /* container size (dead entries included), frame_id */
+/* n (row, col) int32 pairs for position and velocity, n ages; any output may be NULL */
+int vpp_video_extruder_keypoints(const vpp_video_extruder* ve, int32_t* pos_rc, int32_t* vel_rc, int32_t* age, int capacity, void* stream);
+/* per trajectory: length, start frame, alive flag, ring head; ring_rc = n x slots x (row, col) f32, entry k of trajectory i (0 =
+ * newest) at slot (head[i] + k) % slots; any output may be NULL */
+int vpp_video_extruder_trajectories(const vpp_video_extruder* ve, int32_t* len, int32_t* start_frame, uint8_t* alive, int32_t* head,
+                                    float* ring_rc, int capacity, void* stream);
+int vpp_video_extruder_trajectory_slots(const vpp_video_extruder* ve, int* slots);
+/* replace the state with host data laid out as the two accessors return it (a caller that edited the container between updates) */
+int vpp_video_extruder_upload(vpp_video_extruder* ve, int n, int frame_id, const int32_t* pos_rc, const int32_t* vel_rc, const int32_t* age,
+                              const int32_t* len, const int32_t* start_frame, const uint8_t* alive, const int32_t* head, const float* ring_rc,
+                              void* stream);
+
 /* ---- multi-GPU: the one exchange step of the keypoint-sharded path (no reference counterpart: the reference is a
  *      single OpenMP process; pyrlk_match.hh:24-51 iterates independent keypoints).  One process per GPU: rank 0 obtains
  *      the 128-byte id and ships it to the other ranks out of band (launcher, file, socket), every rank calls

@@ -1,0 +1,355 @@
+// extruder.hip — the video_extruder tracker with its state resident in HBM (SURVEY 8f row 2, 8b `video_extruder_step`).
+// Reference: vpp/algorithms/video_extruder/video_extruder.hpp:24-135 (video_extruder_update), vpp/core/keypoint_container.hpp
+// (move :136-150, remove :118-126, add :96-115, compact :22-55, sync_attributes :67-102), vpp/core/keypoint_trajectory.hh:11-72.
+//
+// One vpp_video_extruder_step = one video_extruder_update, queued on one stream:
+//   flow (K11/K12) -> merge decision (K16) -> FAST score of the moved keypoints -> apply move / remove per keypoint (here)
+//   -> every detector_period-th frame: re-detection mask (K14), FAST-9 blockwise (K7-9), compaction of the container and of
+//      the trajectories + append of the new keypoints (here) -> trajectory update (here).
+// The container keeps the reference's layout semantics: dead entries (age 0) stay in place until the next compaction and take
+// part in every step exactly as they do there (the flow still moves them, which revives them: move() increments the age).
+// Trajectories are fixed-capacity rings in HBM, newest position first from `head`.  The host learns the container size only on
+// re-detection frames (one count read-back, the same synchronisation FAST's count already needs); nothing else waits.
+#include "common.hpp"
+#include <algorithm>
+#include <vector>
+using namespace vpp_amd;
+
+struct vpp_video_extruder {
+  int nrows = 0, ncols = 0, ring = 0;   // ring = slots per trajectory
+  int n = 0, cap = 0, frame_id = -1, device = 0;
+  // container, double buffered for the out-of-place compaction: pos / vel = (row, col) int32 pairs
+  int32_t *pos[2] = {nullptr, nullptr}, *vel[2] = {nullptr, nullptr}, *age[2] = {nullptr, nullptr};
+  // trajectories: ring[cap][ring] float2, head / len / start frame / alive per trajectory
+  float *tring[2] = {nullptr, nullptr};
+  int32_t *thead[2] = {nullptr, nullptr}, *tlen[2] = {nullptr, nullptr}, *tstart[2] = {nullptr, nullptr};
+  uint8_t* talive[2] = {nullptr, nullptr};
+  int cur = 0;
+  // per-step scratch
+  int32_t *fpos = nullptr, *fdist = nullptr, *scores = nullptr, *det = nullptr, *newidx = nullptr, *blocksum = nullptr;
+  uint8_t *fvalid = nullptr, *merged = nullptr, *mask = nullptr;
+  int mask_spacing = -1, mask_pitch = 0, det_cap = 0;
+  size_t mask_bytes = 0;
+  int32_t* host_count = nullptr;  // pinned: alive count of the compaction
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void ve_apply_kernel(int n, int32_t* __restrict__ pos, int32_t* __restrict__ vel, int32_t* __restrict__ age,
+                                                       const int32_t* __restrict__ fpos, const uint8_t* __restrict__ fvalid, const uint8_t* __restrict__ merged,
+                                                       const int32_t* __restrict__ scores, int nr, int nc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int a = age[i];
+  if (fvalid[i]) {  // the match callback (video_extruder.hpp:48-53)
+    const int r = fpos[2 * i], c = fpos[2 * i + 1];
+    if (r >= 0 && c >= 0 && r < nr && c < nc) {  // keypoint_container::move (keypoint_container.hpp:136-150)
+      vel[2 * i] = r - pos[2 * i]; vel[2 * i + 1] = c - pos[2 * i + 1];
+      pos[2 * i] = r; pos[2 * i + 1] = c;
+      a++;
+    } else a = 0;                                 // remove (:118-126)
+  }
+  if (merged[i] || scores[i] < 3) a = 0;          // merge (:60-84) and score cull (:87-91)
+  age[i] = a;
+}
+
+__global__ __launch_bounds__(256) void ve_traj_kernel(int n, const int32_t* __restrict__ pos, const int32_t* __restrict__ age, float* __restrict__ ring,
+                                                      int32_t* __restrict__ head, int32_t* __restrict__ len, uint8_t* __restrict__ alive, int slots, int max_len) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (age[i] > 0) {  // move_to + pop_oldest_position (video_extruder.hpp:125-130)
+    const int h = (head[i] + slots - 1) % slots;
+    float* p = ring + ((size_t)i * slots + h) * 2;
+    p[0] = (float)pos[2 * i]; p[1] = (float)pos[2 * i + 1];
+    head[i] = h;
+    int l = len[i] + 1;
+    if (l > max_len) l--;
+    len[i] = l;
+  } else alive[i] = 0;  // die() (:132)
+}
+
+// ---- compaction: alive entries keep their order (keypoint_container.hpp:22-55) -----------------------------------------
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(256) void ve_count_kernel(int n, const int32_t* __restrict__ age, int32_t* __restrict__ blocksum) {
+  __shared__ int s[4];
+  int c = 0;
+  for (int k = 0; k < kScanBlock / 256; k++) { const int i = blockIdx.x * kScanBlock + k * 256 + threadIdx.x; c += (i < n && age[i] > 0); }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(1024) void ve_scan_kernel(int nblocks, int32_t* __restrict__ blocksum, int32_t* __restrict__ total) {
+  // exclusive scan of the block counts by one workgroup, 1024 entries per pass
+  __shared__ int s[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblocks ? blocksum[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+      __syncthreads();
+      s[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblocks) blocksum[i] = carry + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += s[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(256) void ve_index_kernel(int n, const int32_t* __restrict__ age, const int32_t* __restrict__ blocksum, int32_t* __restrict__ newidx) {
+  // new index of every alive entry: block offset + rank inside the block (waves in order, lanes in order)
+  __shared__ int wsum[4];
+  int run = blocksum[blockIdx.x];
+  for (int k = 0; k < kScanBlock / 256; k++) {
+    const int i = blockIdx.x * kScanBlock + k * 256 + threadIdx.x;
+    const bool a = i < n && age[i] > 0;
+    const unsigned long long b = __ballot(a);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wsum[w] = __popcll(b);
+    __syncthreads();
+    int off = run;
+    for (int j = 0; j < w; j++) off += wsum[j];
+    if (i < n) newidx[i] = a ? off + __popcll(b & ((1ull << lane) - 1)) : -1;
+    run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void ve_compact_kernel(int n, const int32_t* __restrict__ newidx, const int32_t* __restrict__ pos, const int32_t* __restrict__ vel,
+                                                         const int32_t* __restrict__ age, const float* __restrict__ ring, const int32_t* __restrict__ head,
+                                                         const int32_t* __restrict__ len, const int32_t* __restrict__ start, const uint8_t* __restrict__ alive,
+                                                         int32_t* __restrict__ pos2, int32_t* __restrict__ vel2, int32_t* __restrict__ age2, float* __restrict__ ring2,
+                                                         int32_t* __restrict__ head2, int32_t* __restrict__ len2, int32_t* __restrict__ start2, uint8_t* __restrict__ alive2, int slots) {
+  // one wave per entry group: lane j of a 16-lane group copies ring slots j, j + 16, ...
+  const int i = (blockIdx.x * 256 + threadIdx.x) >> 4, j = threadIdx.x & 15;
+  if (i >= n) return;
+  const int d = newidx[i];
+  if (d < 0) return;
+  if (j == 0) {
+    pos2[2 * d] = pos[2 * i]; pos2[2 * d + 1] = pos[2 * i + 1]; vel2[2 * d] = vel[2 * i]; vel2[2 * d + 1] = vel[2 * i + 1]; age2[d] = age[i];
+    head2[d] = head[i]; len2[d] = len[i]; start2[d] = start[i]; alive2[d] = alive[i];
+  }
+  const float2* src = (const float2*)ring + (size_t)i * slots;
+  float2* dst = (float2*)ring2 + (size_t)d * slots;
+  for (int s = j; s < slots; s += 16) dst[s] = src[s];
+}
+__global__ __launch_bounds__(256) void ve_append_kernel(int m, int count, const int32_t* __restrict__ det, int32_t* __restrict__ pos, int32_t* __restrict__ vel,
+                                                        int32_t* __restrict__ age, int32_t* __restrict__ head, int32_t* __restrict__ len, int32_t* __restrict__ start,
+                                                        uint8_t* __restrict__ alive, int frame_id) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= count) return;
+  const int d = m + k;
+  pos[2 * d] = det[2 * k]; pos[2 * d + 1] = det[2 * k + 1]; vel[2 * d] = 0; vel[2 * d + 1] = 0; age[d] = 1;  // keypoint<int>(kp) (keypoint_container.hh:16-18)
+  head[d] = 0; len[d] = 0; start[d] = frame_id; alive[d] = 1;                                                 // keypoint_trajectory(frame_id)
+}
+
+template <class T> int dalloc(T** p, size_t count) { void* v = nullptr; const int rc = vpp_malloc(count * sizeof(T), &v); *p = (T*)v; return rc; }
+template <class T> void dfree(T*& p) { if (p) { vpp_free(p); p = nullptr; } }
+
+int ve_reserve(vpp_video_extruder* ve, int want, hipStream_t st) {
+  if (want <= ve->cap) return VPP_OK;
+  int ncap = std::max(want + want / 4, 4096);
+  vpp_video_extruder old = *ve;
+  int rc = VPP_OK;
+  for (int b = 0; b < 2 && rc == VPP_OK; b++) {
+    rc = dalloc(&ve->pos[b], (size_t)ncap * 2); if (rc) break;
+    rc = dalloc(&ve->vel[b], (size_t)ncap * 2); if (rc) break;
+    rc = dalloc(&ve->age[b], ncap); if (rc) break;
+    rc = dalloc(&ve->tring[b], (size_t)ncap * ve->ring * 2); if (rc) break;
+    rc = dalloc(&ve->thead[b], ncap); if (rc) break;
+    rc = dalloc(&ve->tlen[b], ncap); if (rc) break;
+    rc = dalloc(&ve->tstart[b], ncap); if (rc) break;
+    rc = dalloc(&ve->talive[b], ncap);
+  }
+  if (rc == VPP_OK) rc = dalloc(&ve->fpos, (size_t)ncap * 2);
+  if (rc == VPP_OK) rc = dalloc(&ve->fdist, ncap);
+  if (rc == VPP_OK) rc = dalloc(&ve->scores, ncap);
+  if (rc == VPP_OK) rc = dalloc(&ve->newidx, ncap);
+  if (rc == VPP_OK) rc = dalloc(&ve->blocksum, (size_t)ncap / kScanBlock + 2);
+  if (rc == VPP_OK) rc = dalloc(&ve->fvalid, ncap);
+  if (rc == VPP_OK) rc = dalloc(&ve->merged, ncap);
+  if (rc != VPP_OK) return rc;
+  const int c = old.cur;
+  if (old.n > 0) {  // carry the live state over (the other buffer of each pair is scratch)
+    VPP_HIP_TRY(hipMemcpyAsync(ve->pos[c], old.pos[c], (size_t)old.n * 8, hipMemcpyDeviceToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->vel[c], old.vel[c], (size_t)old.n * 8, hipMemcpyDeviceToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->age[c], old.age[c], (size_t)old.n * 4, hipMemcpyDeviceToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->tring[c], old.tring[c], (size_t)old.n * ve->ring * 8, hipMemcpyDeviceToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->thead[c], old.thead[c], (size_t)old.n * 4, hipMemcpyDeviceToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->tlen[c], old.tlen[c], (size_t)old.n * 4, hipMemcpyDeviceToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->tstart[c], old.tstart[c], (size_t)old.n * 4, hipMemcpyDeviceToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->talive[c], old.talive[c], (size_t)old.n, hipMemcpyDeviceToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->newidx, old.newidx, (size_t)old.n * 4, hipMemcpyDeviceToDevice, st));   // a compaction may be in progress
+    VPP_HIP_TRY(hipStreamSynchronize(st));
+  }
+  for (int b = 0; b < 2; b++) { dfree(old.pos[b]); dfree(old.vel[b]); dfree(old.age[b]); dfree(old.tring[b]); dfree(old.thead[b]); dfree(old.tlen[b]); dfree(old.tstart[b]); dfree(old.talive[b]); }
+  dfree(old.fpos); dfree(old.fdist); dfree(old.scores); dfree(old.newidx); dfree(old.blocksum); dfree(old.fvalid); dfree(old.merged);
+  ve->cap = ncap;
+  return VPP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vpp_video_extruder_create(vpp_video_extruder** out, int nrows, int ncols, int trajectory_capacity) {
+  VPP_REQUIRE(out && nrows > 0 && ncols > 0 && trajectory_capacity > 0, VPP_ERR_INVALID_ARG, "vpp_video_extruder_create: invalid argument");
+  vpp_video_extruder* ve = new vpp_video_extruder();
+  ve->nrows = nrows; ve->ncols = ncols; ve->ring = trajectory_capacity + 1;
+  (void)hipGetDevice(&ve->device);
+  void* h = nullptr;
+  if (vpp_malloc_host(64, &h) != VPP_OK) { delete ve; return VPP_ERR_HIP; }
+  ve->host_count = (int32_t*)h;
+  // a first capacity that a blockwise detection with the default spacing cannot exceed: one keypoint per 10 x 10 block, twice over
+  const int rc = ve_reserve(ve, std::max(4096, (nrows / 10 + 1) * (ncols / 10 + 1) * 2), nullptr);
+  if (rc != VPP_OK) { vpp_free_host(h); delete ve; return rc; }
+  *out = ve;
+  return VPP_OK;
+}
+
+int vpp_video_extruder_destroy(vpp_video_extruder* ve) {
+  if (!ve) return VPP_OK;
+  for (int b = 0; b < 2; b++) { dfree(ve->pos[b]); dfree(ve->vel[b]); dfree(ve->age[b]); dfree(ve->tring[b]); dfree(ve->thead[b]); dfree(ve->tlen[b]); dfree(ve->tstart[b]); dfree(ve->talive[b]); }
+  dfree(ve->fpos); dfree(ve->fdist); dfree(ve->scores); dfree(ve->newidx); dfree(ve->blocksum); dfree(ve->fvalid); dfree(ve->merged); dfree(ve->det); dfree(ve->mask);
+  if (ve->host_count) vpp_free_host(ve->host_count);
+  delete ve;
+  return VPP_OK;
+}
+
+int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2, const vpp_video_extruder_params* p, void* stream) {
+  VPP_REQUIRE(ve && p && valid_desc(frame1) && valid_desc(frame2), VPP_ERR_INVALID_ARG, "vpp_video_extruder_step: invalid argument");
+  VPP_REQUIRE(frame1->nrows == ve->nrows && frame1->ncols == ve->ncols && same_domain(frame1, frame2), VPP_ERR_INVALID_ARG, "vpp_video_extruder_step: frames do not match the tracker's domain");
+  VPP_REQUIRE(p->keypoint_spacing > 0 && p->detector_period > 0 && p->max_trajectory_length > 0 && p->max_trajectory_length < ve->ring, VPP_ERR_INVALID_ARG,
+              "vpp_video_extruder_step: max_trajectory_length %d exceeds the tracker's trajectory capacity %d", p->max_trajectory_length, ve->ring - 1);
+  hipStream_t st = as_stream(stream);
+  ve->frame_id++;
+  const int c = ve->cur, n = ve->n;
+  int rc;
+  if (n > 0) {
+    rc = vpp_semi_dense_optical_flow(frame1, frame2, ve->pos[c], n, p->winsize, p->nscales, 0, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, stream);
+    if (rc != VPP_OK) return rc;
+    rc = vpp_keypoint_merge(ve->fpos, ve->pos[c], ve->fvalid, ve->age[c], n, ve->nrows, ve->ncols, p->keypoint_spacing, ve->merged, stream);
+    if (rc != VPP_OK) return rc;
+    rc = vpp_fast9_scores_moved(frame2, p->detector_th, ve->fpos, ve->pos[c], n, ve->scores, stream);
+    if (rc != VPP_OK) return rc;
+    ve_apply_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, ve->merged, ve->scores, ve->nrows, ve->ncols);
+  }
+  if (ve->frame_id % p->detector_period == 0) {  // re-detection away from every container entry (:94-119)
+    const int s = p->keypoint_spacing;
+    if (ve->mask_spacing != s) {
+      dfree(ve->mask);
+      ve->mask_pitch = (ve->ncols + 2 * s + 31) / 32 * 32;
+      ve->mask_bytes = (size_t)(ve->nrows + 2 * s) * ve->mask_pitch;
+      rc = dalloc(&ve->mask, ve->mask_bytes);
+      if (rc != VPP_OK) return rc;
+      ve->mask_spacing = s;
+    }
+    vpp_image_desc md{ve->mask + (size_t)s * ve->mask_pitch + s, ve->nrows, ve->ncols, ve->mask_pitch, s, VPP_U8, 1};
+    rc = vpp_keypoint_mask(&md, ve->pos[c], n, s, stream);
+    if (rc != VPP_OK) return rc;
+    // the alive count travels to the host behind the detection's own synchronisation
+    const int nblocks = (n + kScanBlock - 1) / kScanBlock;
+    if (n > 0) {
+      ve_count_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum);
+      ve_scan_kernel<<<1, 1024, 0, st>>>(nblocks, ve->blocksum, ve->host_count);
+      ve_index_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum, ve->newidx);
+    } else *ve->host_count = 0;
+    int count = 0;
+    const int det_cap = (ve->nrows / s + 1) * (ve->ncols / s + 1);  // blockwise: at most one keypoint per s x s block
+    if (det_cap > ve->det_cap) {
+      dfree(ve->det);
+      rc = dalloc(&ve->det, (size_t)det_cap * 2);
+      if (rc != VPP_OK) return rc;
+      ve->det_cap = det_cap;
+    }
+    rc = vpp_fast9_detect(frame2, p->detector_th, &md, VPP_FAST9_BLOCKWISE, s, VPP_FAST9_REFERENCE, ve->det, nullptr, det_cap, &count, stream);
+    if (rc != VPP_OK) return rc;
+    const int m = n > 0 ? *ve->host_count : 0;  // vpp_fast9_detect synchronised the stream
+    rc = ve_reserve(ve, m + count, st);
+    if (rc != VPP_OK) return rc;
+    const int d = 1 - ve->cur;
+    if (n > 0)
+      ve_compact_kernel<<<(unsigned)(((size_t)n * 16 + 255) / 256), 256, 0, st>>>(n, ve->newidx, ve->pos[ve->cur], ve->vel[ve->cur], ve->age[ve->cur], ve->tring[ve->cur], ve->thead[ve->cur],
+          ve->tlen[ve->cur], ve->tstart[ve->cur], ve->talive[ve->cur], ve->pos[d], ve->vel[d], ve->age[d], ve->tring[d], ve->thead[d], ve->tlen[d], ve->tstart[d], ve->talive[d], ve->ring);
+    if (count > 0)
+      ve_append_kernel<<<(count + 255) / 256, 256, 0, st>>>(m, count, ve->det, ve->pos[d], ve->vel[d], ve->age[d], ve->thead[d], ve->tlen[d], ve->tstart[d], ve->talive[d], ve->frame_id);
+    ve->cur = d;
+    ve->n = m + count;
+  }
+  if (ve->n > 0) {
+    const int k = ve->cur;
+    ve_traj_kernel<<<(ve->n + 255) / 256, 256, 0, st>>>(ve->n, ve->pos[k], ve->age[k], ve->tring[k], ve->thead[k], ve->tlen[k], ve->talive[k], ve->ring, p->max_trajectory_length);
+  }
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+int vpp_video_extruder_count(const vpp_video_extruder* ve, int* n, int* frame_id) {
+  VPP_REQUIRE(ve, VPP_ERR_INVALID_ARG, "vpp_video_extruder_count: null");
+  if (n) *n = ve->n;
+  if (frame_id) *frame_id = ve->frame_id;
+  return VPP_OK;
+}
+
+int vpp_video_extruder_keypoints(const vpp_video_extruder* ve, int32_t* pos_rc, int32_t* vel_rc, int32_t* age, int capacity, void* stream) {
+  VPP_REQUIRE(ve && capacity >= ve->n, VPP_ERR_INVALID_ARG, "vpp_video_extruder_keypoints: capacity %d < %d entries", capacity, ve ? ve->n : 0);
+  hipStream_t st = as_stream(stream);
+  const int k = ve->cur; const size_t n = ve->n;
+  if (n && pos_rc) VPP_HIP_TRY(hipMemcpyAsync(pos_rc, ve->pos[k], n * 8, hipMemcpyDeviceToHost, st));
+  if (n && vel_rc) VPP_HIP_TRY(hipMemcpyAsync(vel_rc, ve->vel[k], n * 8, hipMemcpyDeviceToHost, st));
+  if (n && age) VPP_HIP_TRY(hipMemcpyAsync(age, ve->age[k], n * 4, hipMemcpyDeviceToHost, st));
+  VPP_HIP_TRY(hipStreamSynchronize(st));
+  return VPP_OK;
+}
+
+int vpp_video_extruder_trajectories(const vpp_video_extruder* ve, int32_t* len, int32_t* start_frame, uint8_t* alive, int32_t* head, float* ring_rc, int capacity, void* stream) {
+  VPP_REQUIRE(ve && capacity >= ve->n, VPP_ERR_INVALID_ARG, "vpp_video_extruder_trajectories: capacity %d < %d entries", capacity, ve ? ve->n : 0);
+  hipStream_t st = as_stream(stream);
+  const int k = ve->cur; const size_t n = ve->n;
+  if (n && len) VPP_HIP_TRY(hipMemcpyAsync(len, ve->tlen[k], n * 4, hipMemcpyDeviceToHost, st));
+  if (n && start_frame) VPP_HIP_TRY(hipMemcpyAsync(start_frame, ve->tstart[k], n * 4, hipMemcpyDeviceToHost, st));
+  if (n && alive) VPP_HIP_TRY(hipMemcpyAsync(alive, ve->talive[k], n, hipMemcpyDeviceToHost, st));
+  if (n && head) VPP_HIP_TRY(hipMemcpyAsync(head, ve->thead[k], n * 4, hipMemcpyDeviceToHost, st));
+  if (n && ring_rc) VPP_HIP_TRY(hipMemcpyAsync(ring_rc, ve->tring[k], n * ve->ring * 8, hipMemcpyDeviceToHost, st));
+  VPP_HIP_TRY(hipStreamSynchronize(st));
+  return VPP_OK;
+}
+
+int vpp_video_extruder_trajectory_slots(const vpp_video_extruder* ve, int* slots) {
+  VPP_REQUIRE(ve && slots, VPP_ERR_INVALID_ARG, "vpp_video_extruder_trajectory_slots: null");
+  *slots = ve->ring;
+  return VPP_OK;
+}
+
+// Replace the tracker's state with host data (a caller that edited the container between two updates): n entries,
+// ring_rc = n x slots x (row, col) floats laid out like vpp_video_extruder_trajectories returns them.
+int vpp_video_extruder_upload(vpp_video_extruder* ve, int n, int frame_id, const int32_t* pos_rc, const int32_t* vel_rc, const int32_t* age, const int32_t* len,
+                              const int32_t* start_frame, const uint8_t* alive, const int32_t* head, const float* ring_rc, void* stream) {
+  VPP_REQUIRE(ve && n >= 0, VPP_ERR_INVALID_ARG, "vpp_video_extruder_upload: invalid argument");
+  hipStream_t st = as_stream(stream);
+  ve->n = 0;  // nothing to carry over
+  int rc = ve_reserve(ve, n, st);
+  if (rc != VPP_OK) return rc;
+  const int k = ve->cur; const size_t m = n;
+  if (m) {
+    VPP_HIP_TRY(hipMemcpyAsync(ve->pos[k], pos_rc, m * 8, hipMemcpyHostToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->vel[k], vel_rc, m * 8, hipMemcpyHostToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->age[k], age, m * 4, hipMemcpyHostToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->tlen[k], len, m * 4, hipMemcpyHostToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->tstart[k], start_frame, m * 4, hipMemcpyHostToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->talive[k], alive, m, hipMemcpyHostToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->thead[k], head, m * 4, hipMemcpyHostToDevice, st));
+    VPP_HIP_TRY(hipMemcpyAsync(ve->tring[k], ring_rc, m * ve->ring * 8, hipMemcpyHostToDevice, st));
+    VPP_HIP_TRY(hipStreamSynchronize(st));
+  }
+  ve->n = n; ve->frame_id = frame_id;
+  return VPP_OK;
+}
+
+}  // extern "C"

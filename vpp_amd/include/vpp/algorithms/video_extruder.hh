@@ -1,29 +1,26 @@
 // video_extruder.hh — semi-dense keypoint tracker (reference: vpp/algorithms/video_extruder.hh:10-44,
-// video_extruder/video_extruder.hpp:24-135).  Flow, FAST scores and FAST re-detection run on the device; the keypoint
-// merge (which particles converged to the same cell) is decided on the device; applying it, the cull and the trajectories stay on
-// the host as in the reference.
+// video_extruder/video_extruder.hpp:24-135).  The whole update runs on the device and the tracker's state — the keypoint
+// container (positions, velocities, ages; dead entries kept in place until the next compaction, exactly as keypoint_container
+// does) and the trajectories — lives in HBM behind the C ABI (vpp_video_extruder_*, include/vpp_amd.h).  `ctx.keypoints` and
+// `ctx.trajectories` are host VIEWS of that state with the reference's types: they are filled from HBM the first time they are
+// looked at after an update, so a loop that only tracks never moves a keypoint across PCIe, and they are uploaded again before
+// the next update if the caller edited them (any non-const access counts as an edit).
+//
+// One documented difference: in the view, `keypoints.index2d()` / `has(p)` index every ALIVE keypoint at its position.  The
+// reference's index image is rebuilt by side effect (prepare_matching clears it, move / add / compact set cells), so between two
+// compactions it misses alive keypoints that the flow did not match in the last update (keypoint_container.hpp:57-63,136-150).
 #pragma once
 #include <chrono>
+#include <memory>
 #include <vector>
 #include <vpp/algorithms/fast_detector/fast.hh>
 #include <vpp/algorithms/optical_flow.hh>
 #include <vpp/core/keypoint_container.hh>
 
 namespace vpp {
-struct video_extruder_ctx {
-  video_extruder_ctx(box2d domain) : keypoints(domain), frame_id(0) {
-    // a std::vector<keypoint_trajectory> that reallocates COPIES every std::deque (libstdc++'s deque move is not noexcept): 24 ms at 75 k keypoints
-    trajectories.reserve(size_t(domain.nrows()) * domain.ncols() / 50);
-  }
-  keypoint_container<keypoint<int>, int> keypoints;
-  std::vector<keypoint_trajectory> trajectories;
-  int frame_id;
-};
-inline video_extruder_ctx video_extruder_init(box2d domain) { video_extruder_ctx res(domain); res.frame_id = -1; return res; }
-
 namespace ve_internals {
 // optional wall-clock breakdown of video_extruder_update (benchmarks/video_extruder_bench.cc defines VPP_AMD_TIMING)
-struct timing_t { double flow = 0, merge = 0, scores = 0, redetect = 0, traj = 0, redetect_mask = 0, redetect_fast9 = 0, redetect_add = 0, redetect_compact = 0, redetect_sync = 0; };
+struct timing_t { double step = 0, upload = 0, view = 0; };
 inline timing_t& timing() { static timing_t t; return t; }
 #ifdef VPP_AMD_TIMING
 struct stopwatch { double& acc; std::chrono::steady_clock::time_point t0; explicit stopwatch(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
@@ -31,70 +28,129 @@ struct stopwatch { double& acc; std::chrono::steady_clock::time_point t0; explic
 #else
 struct stopwatch { explicit stopwatch(double&) {} };
 #endif
-}
-namespace ve_internals { struct position_view { const video_extruder_ctx* c; int size() const { return c->keypoints.size(); } vint2 operator[](int i) const { return c->keypoints[i].position; } }; }
+
+typedef keypoint_container<keypoint<int>, int> container_type;
+typedef std::vector<keypoint_trajectory> trajectories_type;
+
+// the device tracker + the host copies of its state; shared by copies of the ctx (video_extruder_init returns it by value)
+struct state {
+  box2d domain;
+  vpp_video_extruder* h = nullptr;
+  int slots = 0;
+  container_type keypoints;
+  trajectories_type trajectories;
+  bool host_stale = false;    // the device ran an update the host copies have not seen
+  bool host_edited = false;   // the caller may have changed the host copies since the last upload
+  int frame_id = -1;
+  explicit state(box2d d) : domain(d), keypoints(d) {}
+  ~state() { if (h) vpp_video_extruder_destroy(h); }
+  state(const state&) = delete;
+  state& operator=(const state&) = delete;
+
+  void ensure_device(int max_trajectory_length) {
+    if (h && max_trajectory_length < slots) return;
+    if (h) { materialise(); host_edited = true; vpp_video_extruder_destroy(h); h = nullptr; }  // longer trajectories than the rings hold: rebuild around the host copy
+    const int capacity = std::max(max_trajectory_length, 15);
+    device::check(vpp_video_extruder_create(&h, domain.nrows(), domain.ncols(), capacity), "vpp_video_extruder_create");
+    device::check(vpp_video_extruder_trajectory_slots(h, &slots), "vpp_video_extruder_trajectory_slots");
+  }
+  // HBM -> host copies (keypoint_container + std::vector<keypoint_trajectory>)
+  void materialise() {
+    if (!host_stale) return;
+    stopwatch sw(timing().view);
+    host_stale = false;
+    int n = 0;
+    device::check(vpp_video_extruder_count(h, &n, &frame_id), "vpp_video_extruder_count");
+    std::vector<vint2> pos(n), vel(n); std::vector<int> age(n), len(n), start(n), head(n); std::vector<unsigned char> alive(n);
+    std::vector<float> ring(size_t(n) * slots * 2);
+    device::check(vpp_video_extruder_keypoints(h, (int32_t*)pos.data(), (int32_t*)vel.data(), age.data(), n, device::stream()), "vpp_video_extruder_keypoints");
+    device::check(vpp_video_extruder_trajectories(h, len.data(), start.data(), alive.data(), head.data(), ring.data(), n, device::stream()), "vpp_video_extruder_trajectories");
+    keypoints.prepare_matching();
+    auto& kv = keypoints.keypoints();
+    kv.resize(n);
+    for (int i = 0; i < n; i++) { kv[i].position = pos[i]; kv[i].velocity = vel[i]; kv[i].age = age[i]; if (age[i] > 0) keypoints.update_index(i, pos[i]); }
+    keypoints.resize_features(n);
+    trajectories.assign(n, keypoint_trajectory());
+    for (int i = 0; i < n; i++) {
+      keypoint_trajectory t(start[i]);
+      for (int k = len[i] - 1; k >= 0; k--) { const float* p = &ring[(size_t(i) * slots + (head[i] + k) % slots) * 2]; t.move_to(vfloat2(p[0], p[1])); }  // oldest first: move_to pushes to the front
+      if (!alive[i]) t.die();
+      trajectories[i].swap(t);
+    }
+  }
+  // host copies -> HBM (the caller edited them)
+  void upload() {
+    stopwatch sw(timing().upload);
+    const int n = keypoints.size();
+    trajectories.resize(n, keypoint_trajectory(frame_id));
+    std::vector<vint2> pos(n), vel(n); std::vector<int> age(n), len(n), start(n), head(n, 0); std::vector<unsigned char> alive(n);
+    std::vector<float> ring(size_t(n) * slots * 2, 0.f);
+    for (int i = 0; i < n; i++) {
+      pos[i] = keypoints[i].position; vel[i] = keypoints[i].velocity; age[i] = keypoints[i].age;
+      const keypoint_trajectory& t = trajectories[i];
+      len[i] = std::min(t.size(), slots - 1); start[i] = t.start_frame(); alive[i] = t.alive();
+      for (int k = 0; k < len[i]; k++) { ring[(size_t(i) * slots + k) * 2] = t[k][0]; ring[(size_t(i) * slots + k) * 2 + 1] = t[k][1]; }
+    }
+    device::check(vpp_video_extruder_upload(h, n, frame_id, (const int32_t*)pos.data(), (const int32_t*)vel.data(), age.data(), len.data(), start.data(), alive.data(), head.data(),
+                                            ring.data(), device::stream()), "vpp_video_extruder_upload");
+    host_edited = false;
+  }
+};
+
+// a member of the ctx that reads like the reference's member (same type behind it) and keeps it coherent with HBM
+template <class T, T state::*M> class view {
+ public:
+  explicit view(std::shared_ptr<state> s) : s_(std::move(s)) {}
+  const T& get() const { s_->materialise(); return (*s_).*M; }
+  T& edit() { s_->materialise(); s_->host_edited = true; return (*s_).*M; }
+  operator const T&() const { return get(); }
+  operator T&() { return edit(); }
+  T* operator->() { return &edit(); }
+  const T* operator->() const { return &get(); }
+  auto size() const { return get().size(); }
+  decltype(auto) operator[](size_t i) { return edit()[i]; }
+  decltype(auto) operator[](size_t i) const { return get()[i]; }
+  auto begin() { return edit().begin(); }
+  auto end() { return edit().end(); }
+  auto begin() const { return get().begin(); }
+  auto end() const { return get().end(); }
+ private:
+  std::shared_ptr<state> s_;
+};
+}  // namespace ve_internals
+
+struct video_extruder_ctx {
+  video_extruder_ctx(box2d domain) : state_(std::make_shared<ve_internals::state>(domain)), keypoints(state_), trajectories(state_), frame_id(0) {}
+ private:
+  std::shared_ptr<ve_internals::state> state_;   // declared first: the views below share it
+ public:
+  ve_internals::view<ve_internals::container_type, &ve_internals::state::keypoints> keypoints;            // keypoint_container<keypoint<int>, int>  (video_extruder.hh:14-16)
+  ve_internals::view<ve_internals::trajectories_type, &ve_internals::state::trajectories> trajectories;   // std::vector<keypoint_trajectory>        (:18-20)
+  int frame_id;
+  ve_internals::state& internal_state() { return *state_; }
+};
+inline video_extruder_ctx video_extruder_init(box2d domain) { video_extruder_ctx res(domain); res.frame_id = -1; return res; }
 
 template <class... OPTS>
 void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>& frame1, const image2d<unsigned char>& frame2, OPTS... options) {
-  ctx.frame_id++;
   auto opts = opt::make(options...);
-  const int detector_th = opts.get(_detector_th, 10), keypoint_spacing = opts.get(_keypoint_spacing, 10), detector_period = opts.get(_detector_period, 5);
-  const int max_trajectory_length = opts.get(_max_trajectory_length, 15), nscales = opts.get(_nscales, 3), winsize = opts.get(_winsize, 9);
-  const int regularisation_niters = opts.get(_propagation, 2);
-
-  // One device submission per update: the flow, then — on the keypoints as the match callback is about to leave them — the
-  // merge of particles that converged to the same cell (:60-84) and the FAST scores (:87-91); one wait.  The host then
-  // applies move / remove per keypoint in one pass (the three loops of the reference only interact through `age`, which the
-  // merge kernel reconstructs; the index log replays to the same image whether a removal follows its own move or all moves).
-  const int n = ctx.keypoints.size();
-  ctx.keypoints.prepare_matching();
-  if (n) {
-    device::hbuf<int> scores(n), ages(n);
-    device::hbuf<unsigned char> merged(n);
-    of_internals::flow_buffers b(n);
-    {
-      ve_internals::stopwatch sw(ve_internals::timing().flow);
-      for (int i = 0; i < n; i++) ages[i] = ctx.keypoints[i].age;
-      const of_internals::flow_params fp{winsize, nscales, 0, regularisation_niters, 5};
-      of_internals::run(ve_internals::position_view{&ctx}, frame1, frame2, fp, b, [&] {
-        const vpp_image_desc d2 = frame2.device_desc(false);
-        device::check(vpp_keypoint_merge((const int32_t*)b.pos.data(), (const int32_t*)b.dk.p, b.valid.data(), ages.data(), n, frame2.nrows(), frame2.ncols(),
-                                         keypoint_spacing, merged.data(), device::stream()), "vpp_keypoint_merge");
-        device::check(vpp_fast9_scores_moved(&d2, detector_th, (const int32_t*)b.pos.data(), (const int32_t*)b.dk.p, n, scores.data(), device::stream()),
-                      "vpp_fast9_scores_moved");
-      });
-    }
-    ve_internals::stopwatch sw(ve_internals::timing().merge);
-    for (int i = 0; i < n; i++) {
-      if (b.valid[i]) { if (frame1.has(b.pos[i])) ctx.keypoints.move(i, b.pos[i]); else ctx.keypoints.remove(i); }  // :50-53
-      if (merged[i] || scores[i] < 3) ctx.keypoints.remove(i);                                                        // :60-84, :87-91
-    }
+  vpp_video_extruder_params p;
+  p.detector_th = opts.get(_detector_th, 10); p.keypoint_spacing = opts.get(_keypoint_spacing, 10); p.detector_period = opts.get(_detector_period, 5);
+  p.max_trajectory_length = opts.get(_max_trajectory_length, 15); p.nscales = opts.get(_nscales, 3); p.winsize = opts.get(_winsize, 9);
+  p.propagation = opts.get(_propagation, 2);
+  ve_internals::state& s = ctx.internal_state();
+  s.ensure_device(p.max_trajectory_length);
+  if (s.host_edited || s.frame_id != ctx.frame_id) {  // the caller edited the views (or ctx.frame_id): the device continues from the host's copy
+    s.materialise();
+    s.frame_id = ctx.frame_id;
+    s.upload();
   }
-  if (!(ctx.frame_id % detector_period)) {  // re-detect away from the live keypoints (:94-119)
-    ve_internals::stopwatch sw(ve_internals::timing().redetect);
-    image2d<unsigned char> mask(frame2.domain().nrows(), frame2.domain().ncols(), _border = keypoint_spacing);
-    {  ve_internals::stopwatch sw2(ve_internals::timing().redetect_mask);
-       // fill_with_border(mask, 1) + the 2s x 2s zero square of every container entry (:101-110), built in HBM
-      const int n = ctx.keypoints.size();
-      std::vector<vint2> pts(n);
-      for (int i = 0; i < n; i++) pts[i] = ctx.keypoints[i].position;
-      device::dbuf rc(size_t(n) * 8);
-      rc.upload(pts.data(), size_t(n) * 8);
-      const vpp_image_desc dm = mask.device_desc(true, true);
-      device::check(vpp_keypoint_mask(&dm, (const int32_t*)rc.p, n, keypoint_spacing, device::stream()), "vpp_keypoint_mask");
-    }
-    std::vector<vint2> kps;
-    { ve_internals::stopwatch sw2(ve_internals::timing().redetect_fast9); kps = fast9(frame2, detector_th, _blockwise, _block_size = keypoint_spacing, _mask = mask); }
-    { ve_internals::stopwatch sw2(ve_internals::timing().redetect_add); for (auto kp : kps) ctx.keypoints.add(keypoint<int>(kp)); }
-    { ve_internals::stopwatch sw2(ve_internals::timing().redetect_compact); ctx.keypoints.compact(); }
-    { ve_internals::stopwatch sw2(ve_internals::timing().redetect_sync); ctx.keypoints.sync_attributes(ctx.trajectories, keypoint_trajectory(ctx.frame_id)); }
-  }
-  ve_internals::stopwatch sw(ve_internals::timing().traj);
-  for (int i = 0; i < ctx.keypoints.size(); i++) {  // trajectories (:123-133)
-    if (ctx.keypoints[i].alive()) {
-      ctx.trajectories[i].move_to(ctx.keypoints[i].position.template cast<float>());
-      if (ctx.trajectories[i].size() > max_trajectory_length) ctx.trajectories[i].pop_oldest_position();
-    } else ctx.trajectories[i].die();
-  }
+  ve_internals::stopwatch sw(ve_internals::timing().step);
+  const vpp_image_desc d1 = frame1.device_desc(false), d2 = frame2.device_desc(false);
+  device::check(vpp_video_extruder_step(s.h, &d1, &d2, &p, device::stream()), "vpp_video_extruder_step");
+  device::check(vpp_sync(device::stream()), "vpp_sync");   // synchronous like the reference call
+  ctx.frame_id++;
+  s.frame_id = ctx.frame_id;
+  s.host_stale = true;
 }
 }  // namespace vpp

@@ -99,6 +99,7 @@ template <class P, class F> struct keypoint_container {
   }
   void update(unsigned i, const keypoint_type& p, const feature_type& f) { keypoint_vector_[i] = p; feature_vector_[i] = f; set_index(cast<vint2>(p.position), int(i)); }
   void update_index(unsigned i, const vint2& p) { set_index(p, int(i)); }
+  void resize_features(size_t n) { feature_vector_.resize(n); }   // after keypoints() was assigned wholesale (the device tracker's host view)
 
   keypoint_vector_type& keypoints() { return keypoint_vector_; }
   const keypoint_vector_type& keypoints() const { return keypoint_vector_; }
