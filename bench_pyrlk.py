@@ -65,15 +65,11 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
                                "exchange": f"rccl all_gather of {NK * world} 20-byte records"}
 
     # pyramids + gradient of a frame pair (what a caller pays per new frame besides the match)
+    dp2_, dg1_ = vi.desc_array(p2), vi.desc_array(g1)
+
     def step_pyr(i, stream):
-        lib.vpp_copy(P(p2[0].desc), P(d2.desc), 0, stream)
-        lib.vpp_fill_border(P(p2[0].desc), 0, None, stream)
-        for l in range(1, L):
-            lib.vpp_pyr_down(P(p2[l].desc), P(p2[l - 1].desc), stream)
-        lib.vpp_scharr(P(g1[0].desc), P(p1[0].desc), stream)
-        lib.vpp_fill_border(P(g1[0].desc), 0, None, stream)
-        for l in range(1, L):
-            lib.vpp_pyr_down(P(g1[l].desc), P(g1[l - 1].desc), stream)
+        lib.vpp_pyramid_build(dp2_, L, P(d2.desc), stream)            # pyramid2d<uchar>(frame, 3, 2, _border = 3): one launch
+        lib.vpp_scharr_pyramid_build(dg1_, L, P(p1[0].desc), stream)  # scharr + gradient pyramid: one launch
 
     pwall, _ = timed(step_pyr, steps, warmup, graph=True)
     res["pyramids_ms_per_frame"] = pwall / steps * 1e3

@@ -117,6 +117,13 @@ int vpp_fill_border(const vpp_image_desc* img, int mode, const void* value /* VA
  *      prev must have border >= 2 already filled.  next dims must be (1+nr/2, 1+nc/2).
  *      The reference's temporaries are uninitialised heap; the canonical value is 0. ---- */
 int vpp_pyr_down(const vpp_image_desc* next, const vpp_image_desc* prev, void* stream);
+/* A whole pyramid: pyramid2d<V>(src, nlevels, 2, _border = levels[0].border) (pyramid.hh:146-198) = copy src's domain into
+ * level 0, fill_border_mirror, propagate_level0 — for u8 x1 pyramids of 2 or 3 levels ONE launch (a workgroup owns a tile of the
+ * coarsest level and computes everything underneath it in LDS), otherwise the per-level kernels.  Bit-identical either way. */
+int vpp_pyramid_build(const vpp_image_desc* levels, int nlevels, const vpp_image_desc* src, void* stream);
+/* The gradient pyramid of pyrlk_match / lucas_kanade in one launch: scharr(img, grad[0]) (scharr.hh:46-87), fill_border_mirror,
+ * propagate_level0 (pyrlk_opencv_comparison.cc:56-60, lucas_kanade.hpp:151-157).  img: u8 x1, filled border >= 1. */
+int vpp_scharr_pyramid_build(const vpp_image_desc* grad_levels, int nlevels, const vpp_image_desc* img, void* stream);
 /* antialiasing_lowpass_filter alone (pyramid.hh:12-59); out may have any border (left untouched). */
 int vpp_lowpass5(const vpp_image_desc* out, const vpp_image_desc* in, void* stream);
 

@@ -74,6 +74,29 @@ def test_whole_pyramids_match_oracle(lib, orc):
         np.testing.assert_array_equal(d.download().raw, h.raw)
 
 
+@pytest.mark.parametrize("shape", [(40, 56), (41, 57), (35, 33), (18, 300), (271, 481), (1080, 1920), (2160, 3840)])
+@pytest.mark.parametrize("nlevels,border", [(3, 3), (2, 3), (3, 14), (3, 18), (4, 3), (1, 2)])
+def test_fused_pyramid_equals_the_per_level_chain_and_the_oracle(lib, orc, shape, nlevels, border):
+    """vpp_pyramid_build / vpp_scharr_pyramid_build (one launch, LDS tiles) against the oracle's copy + mirror + pyr_down chain: every byte
+    of every level, borders and the SURVEY Q4 cells included; odd / even extents, tiles cut by every edge, borders wider than a tile; 4 levels
+    and 1 level take the per-level kernels; a border wider than the coarsest level falls back too."""
+    if shape == (2160, 3840) and (nlevels, border) not in ((3, 18), (3, 3)):
+        pytest.skip("4K once per pyramid kind")
+    img = rand_image(*shape, vi.U8, 1, border=0, seed=21)
+    hp = pyr.host_pyramid(orc, img, nlevels, border)
+    dp = pyr.device_pyramid(lib, DeviceImage.from_host(img), nlevels, border)
+    _sync(lib)
+    for h, d in zip(hp, dp):
+        np.testing.assert_array_equal(d.download().raw, h.raw)
+    if border >= 1:
+        for gdt in (vi.F32, vi.I32):
+            hg = pyr.host_grad_pyramid(orc, hp[0], nlevels, border, gdt)
+            dg = pyr.device_grad_pyramid(lib, dp[0], nlevels, border, gdt)
+            _sync(lib)
+            for h, d in zip(hg, dg):
+                np.testing.assert_array_equal(d.download().raw, h.raw)
+
+
 # ---- FAST-9 ------------------------------------------------------------------------------------------------
 def gpu_detect(lib, dimg, th, mask=None, mode=0, bs=10, compat=0, cap=400000):
     rc = torch.zeros((cap, 2), dtype=torch.int32, device="cuda")

@@ -1,0 +1,331 @@
+// pyramid_fused.hip — a whole factor-2 pyramid in ONE launch.
+// Reference: pyramid<V,N>::update / propagate_level0 (vpp/core/pyramid.hh:169-198: copy into level 0, fill_border_mirror, then per
+// level antialiasing_lowpass_filter :12-59 + subsample2 :62-81 + fill_border_mirror :182) and, for the gradient pyramid of
+// pyrlk / lucas_kanade, scharr (vpp/algorithms/filters/scharr.hh:46-87) into level 0 first (pyrlk_opencv_comparison.cc:56-60,
+// lucas_kanade.hpp:151-157).
+//
+// The per-level launches of pyramid.hip are 4-10 us kernels of a few hundred workgroups each plus a border launch per level: a
+// frame's pyramids were ~10 launches and launch-latency bound.  Here a workgroup owns a T x T tile of the COARSEST level and
+// produces everything underneath it: it loads the level-0 pixels the tile depends on into LDS (for a 3-level pyramid a
+// (4T+9)^2 patch), runs the reference's two passes per level inside LDS —
+//     H(rr, 2c) = V(tap5 of level l around column 2c, columns past an edge = the level's mirror-filled border),
+//     L(r, c)   = (2r < nr && 2c < nc) ? V(tap5 of H over rows 2r-2 .. 2r+2, rows past an edge mirrored as tmp's border is) : 0
+//   (the zero is the reference's unfilled temp border) —
+// and writes, for every level, the region it owns (level l: 2^(L-1-l) T rows / columns) together with the mirrored copies of
+// the pixels that sit within `border` of an edge (fill_border_mirror).  Every value is computed by the same expression, in
+// the same type and order, from the same truncated intermediate values as the chain of per-level kernels, so the result is
+// bit-identical; the halo recomputation costs (2T+3)^2 / (2T)^2 per level, all of it on chip.
+#include "common.hpp"
+using namespace vpp_amd;
+
+namespace {
+
+template <class T> struct Promo { typedef int type; };
+template <> struct Promo<float> { typedef float type; };
+template <> struct Promo<uint32_t> { typedef uint32_t type; };
+
+template <class T, class S> __device__ __forceinline__ T tap5(S a, S b, S c, S d, S e) { return (T)((1 * a + 4 * b + 6 * c + 4 * d + 1 * e) / 16); }
+__device__ __forceinline__ int mirror_idx(int r, int n) {
+  const int m = r < 0 ? -r - 1 : (r >= n ? 2 * n - r - 1 : r);
+  return min(max(m, 0), n - 1);  // only differs for extents below 2, where the reference reads outside its buffer
+}
+
+struct Rect { int r0, c0, h, w; };  // domain rows [r0, r0 + h), columns [c0, c0 + w) of one level, held in LDS row-major
+
+constexpr int kMaxLevels = 3;
+struct Chain {
+  DImg lv[kMaxLevels];   // the pyramid's levels (lv[0] = finest)
+  DImg src;              // the image level 0 is made from (copied, or differentiated)
+  int nlevels;
+};
+
+// Level-0 producers.  fill(): the workgroup loads / computes the level-0 rect `rt` (columns dword-aligned, possibly a few past
+// the right edge: those cells are never read) into LDS `top` (row pitch rt.w pixels); `aux` is producer-private LDS.
+template <class T, int CH> struct CopySrc {   // level 0 = the source's domain pixels (pyramid.hh:196 copy)
+  static constexpr int kAuxBytes = 16;
+  template <int PITCH> static __device__ __forceinline__ void fill(const DImg& src, const Rect& rt, T* top, uint8_t*) {
+    constexpr int PXB = (int)sizeof(T) * CH;
+    static_assert((PITCH * PXB) % 4 == 0, "LDS rows are dword multiples");
+    const bool vec = ((((uintptr_t)src.p0) | (uintptr_t)src.pitch) & 3) == 0 && (rt.w * PXB) % 4 == 0 && (rt.c0 * PXB) % 4 == 0;
+    if (vec) {  // dword loads (the padded columns stay inside the row pitch: pitch % 4 == 0 and pitch >= ncols * PXB)
+      constexpr int NDW = PITCH * PXB / 4;
+      const int ndw = rt.w * PXB / 4;
+      for (int idx = threadIdx.x; idx < rt.h * NDW; idx += blockDim.x) {
+        const int y = idx / NDW, x = idx - y * NDW;
+        if (x < ndw) ((uint32_t*)top)[idx] = ((const uint32_t*)(src.p0 + (ptrdiff_t)(rt.r0 + y) * src.pitch + (ptrdiff_t)rt.c0 * PXB))[x];
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < rt.h * PITCH; idx += blockDim.x) {
+        const int y = idx / PITCH, x = idx - y * PITCH;
+        if (x >= rt.w) continue;
+        const int c = min(rt.c0 + x, src.nc - 1);
+        const T* p = src.row<T>(rt.r0 + y) + c * CH;
+#pragma unroll
+        for (int k = 0; k < CH; k++) top[(size_t)idx * CH + k] = p[k];
+      }
+    }
+  }
+};
+template <class V> struct ScharrSrc {  // level 0 = scharr(img) (scharr.hh:46-87: arithmetic in V, `/ 32.f`, conversion to V); reads img's border
+  static constexpr int kAuxPitch = 96;   // bytes per staged u8 row: rect width (<= 80) + 1-pixel halo, dword aligned
+  static constexpr int kAuxBytes = kAuxPitch * 84;
+  template <int PITCH> static __device__ __forceinline__ void fill(const DImg& in, const Rect& rt, V* top, uint8_t* aux) {
+    // stage the u8 patch [r0 - 1, r0 + h] x [c0 - 1, c0 + w] (clipped to what img's border holds) with dword loads, then differentiate from LDS
+    const int a0 = (rt.c0 - 1) & ~3, wbytes = ((rt.c0 + rt.w + 1 + 3) & ~3) - a0, ndw = wbytes / 4, rows = rt.h + 2;
+    // a0 can reach column -4 and the far end column nc + 7: inside the border / the row's padding of any vpp-allocated image (border bytes are
+    // rounded up to the alignment, >= 16), checked here for foreign pitches
+    const bool vec = ((((uintptr_t)in.p0) | (uintptr_t)in.pitch) & 3) == 0 && in.border >= 4 && in.pitch >= in.nc + in.border + 8;
+    if (vec) {
+      for (int idx = threadIdx.x; idx < rows * ndw; idx += blockDim.x) {
+        const int y = idx / ndw, x = idx - y * ndw;
+        *(uint32_t*)(aux + y * kAuxPitch + 4 * x) = *(const uint32_t*)(in.p0 + (ptrdiff_t)(rt.r0 - 1 + y) * in.pitch + a0 + 4 * x);
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < rows * wbytes; idx += blockDim.x) {
+        const int y = idx / wbytes, x = idx - y * wbytes;
+        const int c = min(max(a0 + x, -in.border), in.nc + in.border - 1);
+        aux[y * kAuxPitch + x] = in.row<uint8_t>(rt.r0 - 1 + y)[c];
+      }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < rt.h * PITCH; idx += blockDim.x) {
+      const int y = idx / PITCH, x = idx - y * PITCH;
+      if (x >= rt.w) continue;
+      const uint8_t *row1 = aux + y * kAuxPitch + (rt.c0 + x - a0), *row2 = row1 + kAuxPitch, *row3 = row2 + kAuxPitch;
+      const V a1 = (V)row1[-1], b1 = (V)row1[0], c1 = (V)row1[1], a2 = (V)row2[-1], c2 = (V)row2[1];
+      const V a3 = (V)row3[-1], b3 = (V)row3[0], c3 = (V)row3[1];
+      top[(size_t)idx * 2] = (V)((3 * a3 + 10 * b3 + 3 * c3 - 3 * a1 - 10 * b1 - 3 * c1) / 32.f);
+      top[(size_t)idx * 2 + 1] = (V)((3 * c1 + 10 * c2 + 3 * c3 - 3 * a1 - 10 * a2 - 3 * a3) / 32.f);
+    }
+  }
+};
+
+// the mirrored copies of domain pixel (r, c) of `img` in its border (fill.hh:60-83); requires border <= nrows, ncols
+template <class T, int CH> __device__ __forceinline__ void store_border_copies(const DImg& img, int r, int c, const T* v) {
+  const int b = img.border, nr = img.nr, nc = img.nc;
+  if (b == 0 || (r >= b && r < nr - b && c >= b && c < nc - b)) return;
+  auto put = [&](int rr, int cc) { T* p = img.row<T>(rr) + cc * CH;
+#pragma unroll
+    for (int k = 0; k < CH; k++) p[k] = v[k]; };
+  const int mr = r < b ? -r - 1 : (r >= nr - b ? 2 * nr - r - 1 : r);
+  const int mr2 = (r < b && r >= nr - b) ? 2 * nr - r - 1 : mr;   // a row within b of both ends mirrors both ways
+  const int mc = c < b ? -c - 1 : (c >= nc - b ? 2 * nc - c - 1 : c);
+  const int mc2 = (c < b && c >= nc - b) ? 2 * nc - c - 1 : mc;
+  if (mc != c) put(r, mc);
+  if (mc2 != mc) put(r, mc2);
+  if (mr != r) { put(mr, c); if (mc != c) put(mr, mc); if (mc2 != mc) put(mr, mc2); }
+  if (mr2 != mr) { put(mr2, c); if (mc != c) put(mr2, mc); if (mc2 != mc) put(mr2, mc2); }
+}
+template <class T, int CH> __device__ __forceinline__ void store_with_border(const DImg& img, int r, int c, const T* v) {
+  T* p = img.row<T>(r) + c * CH;
+#pragma unroll
+  for (int k = 0; k < CH; k++) p[k] = v[k];
+  store_border_copies<T, CH>(img, r, c, v);
+}
+// the part [r0, r1) x [c0, c1) (at most WMAX wide) of an LDS rect (row pitch PITCH pixels) to `img`, rows as dword stores when
+// everything is dword aligned, plus the border copies
+template <class T, int CH, int PITCH, int WMAX> __device__ __forceinline__ void store_region(const DImg& img, const T* lds, const Rect& rc, int r0, int r1, int c0, int c1) {
+  constexpr int PXB = (int)sizeof(T) * CH;
+  const int w = c1 - c0, h = r1 - r0;
+  if (w <= 0 || h <= 0) return;
+  const bool vec = ((((uintptr_t)img.p0) | (uintptr_t)img.pitch) & 3) == 0 && (c0 * PXB) % 4 == 0 && (w * PXB) % 4 == 0 && ((c0 - rc.c0) * PXB) % 4 == 0 && (PITCH * PXB) % 4 == 0;
+  if (vec) {
+    constexpr int NDW = (WMAX * PXB + 3) / 4;
+    const int ndw = w * PXB / 4;
+    for (int idx = threadIdx.x; idx < h * NDW; idx += blockDim.x) {
+      const int y = idx / NDW, x = idx - y * NDW;
+      if (x < ndw) ((uint32_t*)(img.p0 + (ptrdiff_t)(r0 + y) * img.pitch + (ptrdiff_t)c0 * PXB))[x] = ((const uint32_t*)(lds + ((size_t)(r0 + y - rc.r0) * PITCH + (c0 - rc.c0)) * CH))[x];
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < h * WMAX; idx += blockDim.x) {
+      const int y = idx / WMAX, x = idx - y * WMAX;
+      if (x >= w) continue;
+      const T* v = lds + ((size_t)(r0 + y - rc.r0) * PITCH + (c0 + x - rc.c0)) * CH;
+      T* p = img.row<T>(r0 + y) + (c0 + x) * CH;
+#pragma unroll
+      for (int k = 0; k < CH; k++) p[k] = v[k];
+    }
+  }
+  const int b = img.border;
+  if (b > 0 && (r0 < b || r1 > img.nr - b || c0 < b || c1 > img.nc - b))   // the region touches the band that is mirrored into the border
+    for (int idx = threadIdx.x; idx < h * WMAX; idx += blockDim.x) {
+      const int y = idx / WMAX, x = idx - y * WMAX;
+      if (x < w) store_border_copies<T, CH>(img, r0 + y, c0 + x, lds + ((size_t)(r0 + y - rc.r0) * PITCH + (c0 + x - rc.c0)) * CH);
+    }
+}
+
+// one level down inside LDS: `in` (rect ri of a level with extent nr x nc, row pitch PIN) -> `out` (rect ro of the next level, row
+// pitch POUT), hb = scratch for the horizontal pass (ri.h rows, row pitch POUT).  EDGE = false: the rect is away from every edge
+// of the level, so no tap is mirrored and no output falls into the zero cells — plain offsets.
+template <class T, class S, int CH, int PIN, int POUT, int HIN, bool EDGE>
+__device__ __forceinline__ void down_stage_impl(const T* in, const Rect& ri, int nr, int nc, T* hb, T* out, const Rect& ro) {
+  for (int idx = threadIdx.x; idx < HIN * POUT; idx += blockDim.x) {   // H(rr, 2c) for every held row rr and every wanted column c
+    const int y = idx / POUT, x = idx - y * POUT;
+    if (y >= ri.h || x >= ro.w) continue;
+    const int cc = 2 * (ro.c0 + x);
+    T* o = hb + (size_t)idx * CH;
+    const T* row = in + (size_t)y * PIN * CH;
+    if (!EDGE) {
+      const T* p = row + (cc - 2 - ri.c0) * CH;
+#pragma unroll
+      for (int k = 0; k < CH; k++) o[k] = tap5<T, S>((S)p[k], (S)p[CH + k], (S)p[2 * CH + k], (S)p[3 * CH + k], (S)p[4 * CH + k]);
+    } else if (cc < nc) {
+      const int i0 = mirror_idx(cc - 2, nc) - ri.c0, i1 = mirror_idx(cc - 1, nc) - ri.c0, i2 = cc - ri.c0, i3 = mirror_idx(cc + 1, nc) - ri.c0, i4 = mirror_idx(cc + 2, nc) - ri.c0;
+#pragma unroll
+      for (int k = 0; k < CH; k++) o[k] = tap5<T, S>((S)row[i0 * CH + k], (S)row[i1 * CH + k], (S)row[i2 * CH + k], (S)row[i3 * CH + k], (S)row[i4 * CH + k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < CH; k++) o[k] = 0;
+    }
+  }
+  __syncthreads();
+  constexpr int HOUT = (HIN - 3) / 2 + 1;   // rows of the next level a rect of HIN rows can feed
+  for (int idx = threadIdx.x; idx < HOUT * POUT; idx += blockDim.x) {
+    const int y = idx / POUT, x = idx - y * POUT;
+    if (y >= ro.h || x >= ro.w) continue;
+    const int r = ro.r0 + y, c = ro.c0 + x;
+    T* o = out + (size_t)idx * CH;
+    if (!EDGE) {
+      const T* h = hb + ((size_t)(2 * r - 2 - ri.r0) * POUT + x) * CH;
+#pragma unroll
+      for (int k = 0; k < CH; k++) o[k] = tap5<T, S>((S)h[k], (S)h[POUT * CH + k], (S)h[2 * POUT * CH + k], (S)h[3 * POUT * CH + k], (S)h[4 * POUT * CH + k]);
+    } else if (2 * r < nr && 2 * c < nc) {
+      const T* h0 = hb + ((size_t)(mirror_idx(2 * r - 2, nr) - ri.r0) * POUT + x) * CH;
+      const T* h1 = hb + ((size_t)(mirror_idx(2 * r - 1, nr) - ri.r0) * POUT + x) * CH;
+      const T* h2 = hb + ((size_t)(2 * r - ri.r0) * POUT + x) * CH;
+      const T* h3 = hb + ((size_t)(mirror_idx(2 * r + 1, nr) - ri.r0) * POUT + x) * CH;
+      const T* h4 = hb + ((size_t)(mirror_idx(2 * r + 2, nr) - ri.r0) * POUT + x) * CH;
+#pragma unroll
+      for (int k = 0; k < CH; k++) o[k] = tap5<T, S>((S)h0[k], (S)h1[k], (S)h2[k], (S)h3[k], (S)h4[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < CH; k++) o[k] = 0;
+    }
+  }
+  __syncthreads();
+}
+template <class T, class S, int CH, int PIN, int POUT, int HIN>
+__device__ __forceinline__ void down_stage(const T* in, const Rect& ri, int nr, int nc, T* hb, T* out, const Rect& ro) {
+  // interior: every tap 2c-2 .. 2c+2 / 2r-2 .. 2r+2 of every wanted output lies inside the level
+  const bool interior = 2 * ro.r0 - 2 >= 0 && 2 * (ro.r0 + ro.h - 1) + 2 < nr && 2 * ro.c0 - 2 >= 0 && 2 * (ro.c0 + ro.w - 1) + 2 < nc;
+  if (interior) down_stage_impl<T, S, CH, PIN, POUT, HIN, false>(in, ri, nr, nc, hb, out, ro);
+  else down_stage_impl<T, S, CH, PIN, POUT, HIN, true>(in, ri, nr, nc, hb, out, ro);
+}
+
+// rows / columns of level l that the stage above needs from it: [max(0, 2a - 2), min(n - 1, 2b + 2)] for wanted [a, b] of level l + 1
+__device__ __forceinline__ void needed(int a, int b, int n, int& lo, int& len) { lo = max(0, 2 * a - 2); len = min(n - 1, 2 * b + 2) - lo + 1; }
+
+// T0 x T0 = tile of the coarsest level per workgroup.  LDS: the level rects + one horizontal-pass scratch.
+template <class T, class S, int CH, int T0, class SRC, int NL, bool WRITE0>
+__global__ __launch_bounds__(256) void pyramid_chain_kernel(Chain ch) {
+  static_assert(NL == 2 || NL == 3, "two or three levels per launch");
+  // rect extents (rows) and LDS row pitches (pixels): level NL-2 holds 2 T0 + 3, level 0 of a 3-level chain 2 (2 T0 + 3) + 3; the level-0
+  // pitch leaves room for the dword alignment of its columns and is a dword multiple for every pixel size
+  constexpr int E1 = 2 * T0 + 3, H0 = NL == 3 ? 2 * E1 + 3 : E1, P0 = (H0 + 3 + 3) & ~3, P1 = NL == 3 ? E1 : T0;
+  __shared__ __attribute__((aligned(16))) T s_top[H0 * P0 * CH];                             // level 0 rect
+  __shared__ __attribute__((aligned(16))) T s_mid[(NL == 3 ? E1 * E1 : T0 * T0) * CH];      // level 1 rect (NL == 3) or the level-1 tile (NL == 2)
+  __shared__ __attribute__((aligned(16))) T s_low[(NL == 3 ? T0 * T0 : 1) * CH];            // level 2 tile
+  __shared__ __attribute__((aligned(16))) T s_h[H0 * P1 * CH];                               // horizontal pass of the larger stage
+  __shared__ __attribute__((aligned(16))) uint8_t s_aux[SRC::kAuxBytes];
+
+  const DImg& last = ch.lv[NL - 1];
+  const int tiles_x = (last.nc + T0 - 1) / T0;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  Rect rl;  // the tile of the coarsest level
+  rl.r0 = ty * T0; rl.c0 = tx * T0; rl.h = min(T0, last.nr - rl.r0); rl.w = min(T0, last.nc - rl.c0);
+  Rect rm = rl, rt;  // NL == 3: level-1 rect; rt = level-0 rect
+  if (NL == 3) { needed(rl.r0, rl.r0 + rl.h - 1, ch.lv[1].nr, rm.r0, rm.h); needed(rl.c0, rl.c0 + rl.w - 1, ch.lv[1].nc, rm.c0, rm.w); }
+  needed(rm.r0, rm.r0 + rm.h - 1, ch.lv[0].nr, rt.r0, rt.h); needed(rm.c0, rm.c0 + rm.w - 1, ch.lv[0].nc, rt.c0, rt.w);
+  { const int end = (rt.c0 + rt.w + 3) & ~3; rt.c0 &= ~3; rt.w = end - rt.c0; }   // dword-aligned columns; cells past the right edge are loaded but never read
+
+  // ---- level 0 into LDS; the owned part goes to lv[0]
+  SRC::template fill<P0>(ch.src, rt, s_top, s_aux);
+  __syncthreads();
+  if (WRITE0) {   // (false: level 0 already exists — the source IS level 0, only the coarser levels are produced)
+    const int own_r0 = rl.r0 << (NL - 1), own_c0 = rl.c0 << (NL - 1);
+    store_region<T, CH, P0, (T0 << (NL - 1))>(ch.lv[0], s_top, rt, own_r0, min(own_r0 + (T0 << (NL - 1)), ch.lv[0].nr), own_c0, min(own_c0 + (T0 << (NL - 1)), ch.lv[0].nc));
+  }
+  if (NL == 3) {
+    down_stage<T, S, CH, P0, E1, H0>(s_top, rt, ch.lv[0].nr, ch.lv[0].nc, s_h, s_mid, rm);
+    store_region<T, CH, E1, 2 * T0>(ch.lv[1], s_mid, rm, rl.r0 * 2, min(rl.r0 * 2 + 2 * T0, ch.lv[1].nr), rl.c0 * 2, min(rl.c0 * 2 + 2 * T0, ch.lv[1].nc));
+    down_stage<T, S, CH, E1, T0, E1>(s_mid, rm, ch.lv[1].nr, ch.lv[1].nc, s_h, s_low, rl);
+    store_region<T, CH, T0, T0>(ch.lv[2], s_low, rl, rl.r0, rl.r0 + rl.h, rl.c0, rl.c0 + rl.w);
+  } else {
+    down_stage<T, S, CH, P0, T0, H0>(s_top, rt, ch.lv[0].nr, ch.lv[0].nc, s_h, s_mid, rl);
+    store_region<T, CH, T0, T0>(ch.lv[1], s_mid, rl, rl.r0, rl.r0 + rl.h, rl.c0, rl.c0 + rl.w);
+  }
+}
+
+bool chain_shape_ok(const vpp_image_desc* levels, int nlevels) {
+  for (int l = 0; l < nlevels; l++) {
+    if (levels[l].border > levels[l].nrows || levels[l].border > levels[l].ncols) return false;  // the fused border writes assume the mirror stays inside the level
+    if (l > 0 && (levels[l].nrows != 1 + levels[l - 1].nrows / 2 || levels[l].ncols != 1 + levels[l - 1].ncols / 2)) return false;
+  }
+  return true;
+}
+
+template <class T, class S, int CH, int T0, class SRC, bool WRITE0 = true>
+void launch_chain(const vpp_image_desc* levels, int nlevels, const vpp_image_desc* src, hipStream_t st) {
+  Chain c;
+  for (int l = 0; l < nlevels; l++) c.lv[l] = dimg(&levels[l]);
+  c.src = dimg(src); c.nlevels = nlevels;
+  const vpp_image_desc& last = levels[nlevels - 1];
+  const int tiles = ((last.nrows + T0 - 1) / T0) * ((last.ncols + T0 - 1) / T0);
+  if (nlevels == 3) pyramid_chain_kernel<T, S, CH, T0, SRC, 3, WRITE0><<<tiles, 256, 0, st>>>(c);
+  else pyramid_chain_kernel<T, S, CH, T0, SRC, 2, WRITE0><<<tiles, 256, 0, st>>>(c);
+}
+
+}  // namespace
+
+namespace vpp_amd { int vpp_scharr_bordered(const vpp_image_desc* out, const vpp_image_desc* in, void* stream); }
+
+extern "C" {
+
+// pyramid2d<V>(src, nlevels, 2, _border = levels[0].border) (pyramid.hh:146-198): level 0 = copy of src's domain + mirror
+// border, then propagate_level0.  u8 x1 pyramids of 2 or 3 levels go through the fused kernel, everything else through the
+// per-level kernels (vpp_copy + vpp_fill_border + vpp_pyr_down).
+int vpp_pyramid_build(const vpp_image_desc* levels, int nlevels, const vpp_image_desc* src, void* stream) {
+  VPP_REQUIRE(levels && src && nlevels >= 1, VPP_ERR_INVALID_ARG, "vpp_pyramid_build: invalid argument");
+  for (int l = 0; l < nlevels; l++) VPP_REQUIRE(valid_desc(&levels[l]) && same_type(&levels[l], src), VPP_ERR_INVALID_ARG, "vpp_pyramid_build: level %d: invalid descriptor / element type", l);
+  VPP_REQUIRE(valid_desc(src) && same_domain(&levels[0], src), VPP_ERR_INVALID_ARG, "vpp_pyramid_build: level 0 and the source differ in size");
+  hipStream_t st = as_stream(stream);
+  if (src->dtype == VPP_U8 && src->channels == 1 && (nlevels == 2 || nlevels == 3) && chain_shape_ok(levels, nlevels) && tuning("pyr.fused", 1)) {
+    launch_chain<uint8_t, int, 1, 8, CopySrc<uint8_t, 1>>(levels, nlevels, src, st);
+    VPP_LAUNCH_CHECK();
+    return VPP_OK;
+  }
+  int rc = vpp_copy(&levels[0], src, 0, stream);
+  if (rc != VPP_OK) return rc;
+  rc = vpp_fill_border(&levels[0], VPP_BORDER_MIRROR, nullptr, stream);
+  for (int l = 1; l < nlevels && rc == VPP_OK; l++) rc = vpp_pyr_down(&levels[l], &levels[l - 1], stream);
+  return rc;
+}
+
+// The gradient pyramid of pyrlk_match / lucas_kanade: scharr(img, grad[0]); fill_border_mirror(grad[0]); propagate_level0
+// (pyrlk_opencv_comparison.cc:56-60, lucas_kanade.hpp:151-157).  img: u8 x1 with a filled border >= 1; grad: f32 x2 or i32 x2.
+int vpp_scharr_pyramid_build(const vpp_image_desc* grad, int nlevels, const vpp_image_desc* img, void* stream) {
+  VPP_REQUIRE(grad && img && nlevels >= 1 && valid_desc(img), VPP_ERR_INVALID_ARG, "vpp_scharr_pyramid_build: invalid argument");
+  VPP_REQUIRE(img->dtype == VPP_U8 && img->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_scharr_pyramid_build: the image must be u8 x1");
+  VPP_REQUIRE(img->border >= 1, VPP_ERR_BORDER_TOO_SMALL, "vpp_scharr_pyramid_build: the image needs border >= 1 (scharr.hh:48)");
+  for (int l = 0; l < nlevels; l++)
+    VPP_REQUIRE(valid_desc(&grad[l]) && grad[l].channels == 2 && (grad[l].dtype == VPP_F32 || grad[l].dtype == VPP_I32) && grad[l].dtype == grad[0].dtype, VPP_ERR_UNSUPPORTED,
+                "vpp_scharr_pyramid_build: gradient levels must be f32 x2 or i32 x2");
+  VPP_REQUIRE(same_domain(&grad[0], img), VPP_ERR_INVALID_ARG, "vpp_scharr_pyramid_build: level 0 and the image differ in size");
+
+  if (chain_shape_ok(grad, nlevels) && tuning("pyr.fused", 1)) {
+    // measured (tools/time_pyramids.py, 1080p x 3 levels, f32 x2): scharr inside the tile kernel 34 us, wide scharr + tile kernel for
+    // the coarser levels 33 us, the 4-launch chain 32 us — 8-byte pixels make the LDS tiles slower than the per-level gathers.
+    // What pays is dropping the separate border launch: scharr writes the mirrored copies itself, then the per-level kernels
+    // (which fuse their own borders).
+    int rc = vpp_scharr_bordered(&grad[0], img, stream);
+    for (int l = 1; l < nlevels && rc == VPP_OK; l++) rc = vpp_pyr_down(&grad[l], &grad[l - 1], stream);
+    return rc;
+  }
+  int rc = vpp_scharr(&grad[0], img, stream);
+  if (rc != VPP_OK) return rc;
+  rc = vpp_fill_border(&grad[0], VPP_BORDER_MIRROR, nullptr, stream);
+  for (int l = 1; l < nlevels && rc == VPP_OK; l++) rc = vpp_pyr_down(&grad[l], &grad[l - 1], stream);
+  return rc;
+}
+
+}  // extern "C"

@@ -22,7 +22,22 @@ __global__ __launch_bounds__(256) void scharr_kernel(DImg out, DImg in) {
 }
 // Four pixels per lane: three (possibly unaligned) 8-byte row loads cover columns c-1 .. c+6, the four results leave as two
 // 16-byte stores; the 3x3 sums are the same small exact integers in float or int as in the per-pixel form.
-template <class V>
+// the mirrored copies of domain pixel (r, c) of a 2-component image in its border (fill_border_mirror, fill.hh:60-83; border <= nrows, ncols)
+template <class V> __device__ __forceinline__ void border_copies2(const DImg& img, int r, int c, V v0, V v1) {
+  const int b = img.border, nr = img.nr, nc = img.nc;
+  if (b == 0 || (r >= b && r < nr - b && c >= b && c < nc - b)) return;
+  auto put = [&](int rr, int cc) { V* p = img.row<V>(rr) + 2 * cc; p[0] = v0; p[1] = v1; };
+  const int mr = r < b ? -r - 1 : (r >= nr - b ? 2 * nr - r - 1 : r);
+  const int mr2 = (r < b && r >= nr - b) ? 2 * nr - r - 1 : mr;
+  const int mc = c < b ? -c - 1 : (c >= nc - b ? 2 * nc - c - 1 : c);
+  const int mc2 = (c < b && c >= nc - b) ? 2 * nc - c - 1 : mc;
+  if (mc != c) put(r, mc);
+  if (mc2 != mc) put(r, mc2);
+  if (mr != r) { put(mr, c); if (mc != c) put(mr, mc); if (mc2 != mc) put(mr, mc2); }
+  if (mr2 != mr) { put(mr2, c); if (mc != c) put(mr2, mc); if (mc2 != mc) put(mr2, mc2); }
+}
+
+template <class V, bool BORDER = false>
 __global__ __launch_bounds__(256) void scharr4_kernel(DImg out, DImg in) {
   const int c = (blockIdx.x * 256 + threadIdx.x) * 4, r = blockIdx.y;
   if (c >= out.nc) return;
@@ -34,6 +49,7 @@ __global__ __launch_bounds__(256) void scharr4_kernel(DImg out, DImg in) {
       V* o = out.row<V>(r) + 2 * x;
       o[0] = (V)((3 * a3 + 10 * b3 + 3 * c3 - 3 * a1 - 10 * b1 - 3 * c1) / 32.f);
       o[1] = (V)((3 * c1 + 10 * c2 + 3 * c3 - 3 * a1 - 10 * a2 - 3 * a3) / 32.f);
+      if (BORDER) border_copies2<V>(out, r, x, o[0], o[1]);
     }
     return;
   }
@@ -60,8 +76,31 @@ __global__ __launch_bounds__(256) void scharr4_kernel(DImg out, DImg in) {
 #pragma unroll
     for (int k = 0; k < 8; k++) o[k] = res[k];
   }
+  if (BORDER) {
+    const int b = out.border;
+    if (r < b || r >= out.nr - b || c < b || c + 4 > out.nc - b) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) border_copies2<V>(out, r, c + k, res[2 * k], res[2 * k + 1]);
+    }
+  }
 }
 }  // namespace
+
+// scharr + fill_border_mirror(out) in one launch (the gradient pyramid's level 0); needs the wide kernel's preconditions
+namespace vpp_amd {
+int vpp_scharr_bordered(const vpp_image_desc* out, const vpp_image_desc* in, void* stream) {
+  const bool fusable = in->border >= 3 && out->border <= out->nrows && out->border <= out->ncols && same_domain(out, in);
+  if (!fusable) {
+    const int rc = vpp_scharr(out, in, stream);
+    return rc != VPP_OK ? rc : vpp_fill_border(out, VPP_BORDER_MIRROR, nullptr, stream);
+  }
+  dim3 grid(((out->ncols + 3) / 4 + 255) / 256, out->nrows);
+  if (out->dtype == VPP_F32) scharr4_kernel<float, true><<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in));
+  else scharr4_kernel<int, true><<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in));
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+}  // namespace vpp_amd
 
 extern "C" int vpp_scharr(const vpp_image_desc* out, const vpp_image_desc* in, void* stream) {
   VPP_REQUIRE(valid_desc(out) && valid_desc(in), VPP_ERR_INVALID_ARG, "vpp_scharr: invalid descriptor");

@@ -636,11 +636,8 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
     }
     if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
-  auto build = [&](vpp_image_desc* P, const vpp_image_desc* in) -> int {  // pyramid::update, pyramid.hh:194-198
-    int rc = vpp_copy(&P[0], in, 0, stream); if (rc) return rc;
-    rc = launch_fill_border(&P[0], VPP_BORDER_MIRROR, nullptr, st); if (rc) return rc;
-    for (int s = 1; s < nscales; s++) { rc = vpp_pyr_down(&P[s], &P[s - 1], stream); if (rc) return rc; }
-    return VPP_OK;
+  auto build = [&](vpp_image_desc* P, const vpp_image_desc* in) -> int {  // pyramid::update, pyramid.hh:194-198: one launch for 2-3 scales
+    return vpp_pyramid_build(P, nscales, in, stream);
   };
   int rc = build(P1, i1); if (rc) return rc;
   rc = build(P2, i2); if (rc) return rc;

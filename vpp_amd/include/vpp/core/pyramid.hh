@@ -69,7 +69,21 @@ template <class V, unsigned N> struct pyramid {
     static_assert(sizeof(V) == 0, "pyramid::propagate_level0 runs on the device: build with -DVPP_AMD_DEVICE and link libvpp_amd");
 #endif
   }
-  void update(const image_type& in) { copy(in, levels_[0]); propagate_level0(); }
+  void update(const image_type& in) {  // pyramid.hh:194-198
+#ifdef VPP_AMD_DEVICE
+    bool direct = factor_ == 2.f && in.domain() == levels_[0].domain();
+    for (auto& l : levels_) direct = direct && l.border() >= 2;   // the per-level kernels behind vpp_pyramid_build read 2 border pixels
+    if (direct) {  // copy + mirror border + every level in one submission (one launch for u8 pyramids of 2-3 levels)
+      std::vector<vpp_image_desc> d(levels_.size());
+      for (size_t i = 0; i < levels_.size(); i++) d[i] = levels_[i].device_desc(true, true);
+      const vpp_image_desc s = in.device_desc(false);
+      device::check(vpp_pyramid_build(d.data(), int(d.size()), &s, device::stream()), "vpp_pyramid_build");
+      device::check(vpp_sync(device::stream()), "vpp_sync");
+      return;
+    }
+#endif
+    copy(in, levels_[0]); propagate_level0();
+  }
 
   float factor() const { return factor_; }
   int size() const { return int(levels_.size()); }

@@ -19,22 +19,18 @@ def level_dims(nr, nc, nlevels):
 
 
 def device_pyramid(lib, dimg, nlevels, border, st=None):
+    """pyramid2d<V>(img, nlevels, 2, _border = border) through vpp_pyramid_build (one launch for u8 x1 pyramids of 2-3 levels)."""
     st = st or capi.stream_ptr()
     levels = [DeviceImage(nr, nc, dimg.dtype, dimg.channels, border) for nr, nc in level_dims(dimg.nrows, dimg.ncols, nlevels)]
-    capi.check(lib.vpp_copy(P(levels[0].desc), P(dimg.desc), 0, st))
-    capi.check(lib.vpp_fill_border(P(levels[0].desc), 0, None, st))
-    for l in range(1, nlevels):
-        capi.check(lib.vpp_pyr_down(P(levels[l].desc), P(levels[l - 1].desc), st))
+    capi.check(lib.vpp_pyramid_build(vi.desc_array(levels), nlevels, P(dimg.desc), st))
     return levels
 
 
 def device_grad_pyramid(lib, level0, nlevels, border, dtype=vi.F32, st=None):
+    """scharr(level0) + fill_border_mirror + propagate_level0 through vpp_scharr_pyramid_build (one launch for 2-3 levels)."""
     st = st or capi.stream_ptr()
     levels = [DeviceImage(nr, nc, dtype, 2, border) for nr, nc in level_dims(level0.nrows, level0.ncols, nlevels)]
-    capi.check(lib.vpp_scharr(P(levels[0].desc), P(level0.desc), st))
-    capi.check(lib.vpp_fill_border(P(levels[0].desc), 0, None, st))
-    for l in range(1, nlevels):
-        capi.check(lib.vpp_pyr_down(P(levels[l].desc), P(levels[l - 1].desc), st))
+    capi.check(lib.vpp_scharr_pyramid_build(vi.desc_array(levels), nlevels, P(level0.desc), st))
     return levels
 
 
