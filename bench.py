@@ -261,6 +261,19 @@ def main():
         dt = (time.perf_counter() - t0) / iters
         import bench_pyrlk as _bp
         cpu_extra = _bp.cpu_baseline(orc)
+        # BASELINE configs[0]: pixel_wise A = B + C on 1920x1080 image2d<int> through the CPU / OpenMP plumbing, the protocol of
+        # benchmarks/image_add.cc:77-88 (K = 10 timed calls after one warm-up call)
+        a1 = rand_image(1080, 1920, vi.I32, seed=1, lo=0, hi=2**30 - 1)
+        b1 = rand_image(1080, 1920, vi.I32, seed=2, lo=0, hi=2**30 - 1)
+        c1 = a1.like()
+        add_cpu = (lambda: refomp.ref_pixelwise_add(P(c1.desc), P(a1.desc), P(b1.desc))) if refomp is not None else (lambda: orc.orc_pixelwise_binary(0, P(c1.desc), P(a1.desc), P(b1.desc)))
+        add_cpu()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            add_cpu()
+        dta = (time.perf_counter() - t0) / 10
+        cpu_extra["add_1080p_int_gpixels_per_s"] = 1080 * 1920 / dta / 1e9
+        cpu_extra["add_1080p_sample"] = "BASELINE configs[0]: 10 calls after 1 warm-up (benchmarks/image_add.cc:77-88), " + ("the reference's pixel_wise, OpenMP" if refomp is not None else "oracle port, OpenMP")
         cpu = {"value": npx / dt / 1e9, "unit": "Gpixels/s", "cores": os.cpu_count() if kind == "reference" else int(orc.orc_num_threads()), "kind": kind,
                "sample": f"{iters} passes of the same 3840x2160 vuchar3 box5x5 after 1 warm-up, {what}", **cpu_extra}
 

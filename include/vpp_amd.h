@@ -154,6 +154,11 @@ int vpp_fast9_dense(const vpp_image_desc* dst, const vpp_image_desc* src, int th
 /* blockwise_maxima_filter(A, block_size) (fast.hpp:577-614), in place on a scalar image: per block_size x block_size block
  * (clipped to the domain) only the first strict maximum > 0 in row-major order survives, every other pixel becomes 0. */
 int vpp_blockwise_maxima_filter(const vpp_image_desc* img, int block_size, void* stream);
+/* local_maxima_filter(A, nbh_size) (fast.hpp:555-575; nbh_size is ignored there), in place on a scalar image with border >= 1: a
+ * pixel that is not strictly greater than its 8 neighbours becomes 0, the neighbours above / left of it being compared AFTER their
+ * own filtering — the result of the reference's serial (no-OpenMP) build; its OpenMP build races on exactly those neighbours.
+ * Synchronises the stream (the number of order-dependent pixels is read back). */
+int vpp_local_maxima_filter(const vpp_image_desc* img, void* stream);
 /* The score cull of video_extruder_update (video_extruder/video_extruder.hpp:44-56,87-91) queued behind the flow instead of
  * after a host round trip: keypoint i is scored at rc_moved[i] when that lies inside src's domain (the match callback moved it
  * there), else at rc_prev[i] (the callback removed it, or never ran: its position is unchanged).  All three arrays are

@@ -823,6 +823,42 @@ int orc_fast9_dense(const vpp_image_desc* out, const vpp_image_desc* in, int th)
   return VPP_OK;
 }
 
+// local_maxima_filter (fast.hpp:555-575), in place, the SERIAL form (the reference's test build has no OpenMP, tests/CMakeLists.txt:16):
+// rows top to bottom, columns left to right; the four neighbours above / left of a pixel have already been filtered when it is
+// compared with them, the other four still hold the input.  The border (>= 1) is read, never written.  Pinned to the reference
+// by tests/test_ref_pins_oracle.py.
+extern "C++" {
+template <class V> static void local_maxima_t(Img a) {
+  for (int r = 0; r < a.nr; r++) {
+    V *up = a.row<V>(r - 1), *row = a.row<V>(r), *dn = a.row<V>(r + 1);
+    for (int c = 0; c < a.nc; c++) {
+      const V v = row[c];
+      int is_max = 1;
+      is_max &= v > up[c - 1]; is_max &= v > up[c]; is_max &= v > up[c + 1];
+      is_max &= v > row[c - 1]; is_max &= v > row[c + 1];
+      is_max &= v > dn[c - 1]; is_max &= v > dn[c]; is_max &= v > dn[c + 1];
+      if (!is_max) row[c] = V(0);
+    }
+  }
+}
+}  // extern "C++"
+int orc_local_maxima_filter(const vpp_image_desc* img) {
+  Img a(img);
+  if (a.ch != 1) return VPP_ERR_UNSUPPORTED;
+  if (a.border < 1) return VPP_ERR_BORDER_TOO_SMALL;
+  switch (a.dtype) {
+    case VPP_U8: local_maxima_t<uint8_t>(a); break;
+    case VPP_I8: local_maxima_t<int8_t>(a); break;
+    case VPP_U16: local_maxima_t<uint16_t>(a); break;
+    case VPP_I16: local_maxima_t<int16_t>(a); break;
+    case VPP_I32: local_maxima_t<int32_t>(a); break;
+    case VPP_U32: local_maxima_t<uint32_t>(a); break;
+    case VPP_F32: local_maxima_t<float>(a); break;
+    default: return VPP_ERR_UNSUPPORTED;
+  }
+  return VPP_OK;
+}
+
 // blockwise_maxima_filter (fast.hpp:577-614), in place.  PARITY UNPINNED: the reference template does not compile when
 // instantiated (it stores &A(r + i, 0) of a const image into V* rows[], fast.hpp:590), so no reference output exists for it.
 extern "C++" {

@@ -57,6 +57,7 @@ int orc_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in);
 int orc_fast9_dense(const vpp_image_desc* out, const vpp_image_desc* in, int th);
 /* fast_detector/fast.hpp:577-614 (in place) */
 int orc_blockwise_maxima_filter(const vpp_image_desc* img, int block_size);
+int orc_local_maxima_filter(const vpp_image_desc* img);
 
 #ifdef __cplusplus
 }

@@ -264,5 +264,16 @@ int ref_fast9_dense(const vpp_image_desc* out, const vpp_image_desc* in, int th)
   return VPP_ERR_UNSUPPORTED;
 }
 
+
+// local_maxima_filter(A, nbh_size) (fast.hpp:555-575), in place; the library is the serial build (tests/CMakeLists.txt:16
+// has no OpenMP), where pixel_wise walks the rows top to bottom and each row left to right, so pixels above / left of the current one
+// have already been filtered when they are compared.
+int ref_local_maxima_filter(const vpp_image_desc* img) {
+  if (is(img, VPP_U8, 1)) { auto A = wrap<unsigned char>(img); vpp::local_maxima_filter(A, 3); return 0; }
+  if (is(img, VPP_I32, 1)) { auto A = wrap<int>(img); vpp::local_maxima_filter(A, 3); return 0; }
+  if (is(img, VPP_F32, 1)) { auto A = wrap<float>(img); vpp::local_maxima_filter(A, 3); return 0; }
+  return VPP_ERR_UNSUPPORTED;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

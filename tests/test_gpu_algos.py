@@ -268,3 +268,31 @@ def test_pyrlk_1080p_10k_keypoints(lib, orc):
         np.testing.assert_allclose(got[f][alive], want[f][alive], rtol=1e-4, atol=1e-4)
     vel = np.stack([got["vel_r"], got["vel_c"]], 1)[alive]
     assert np.median(np.linalg.norm(vel - [1.5, -2.25], axis=1)) < 0.15  # size-independent property: recovers the translation
+
+
+@pytest.mark.parametrize("dtype,kind,shape", [(vi.U8, "sparse", (37, 53)), (vi.U8, "dense", (300, 1000)), (vi.I32, "signed", (64, 257)), (vi.F32, "ramp", (40, 3000)),
+                                              (vi.U8, "plateau", (37, 53)), (vi.U8, "scores4k", (2160, 3840)), (vi.I16, "dense", (5, 7)), (vi.U8, "sparse", (1, 1))])
+def test_local_maxima_filter_matches_oracle(lib, orc, dtype, kind, shape):
+    """vpp_local_maxima_filter against the serial oracle (pinned to the reference's serial build): the order-dependent pixels are resolved in
+    rounds, so the cases are chosen for their dependency chains — dense noise, signed values, a 3000-pixel ramp (one chain per row), plateaus,
+    and a 4K FAST-score-like image (the intended use)."""
+    rng = np.random.default_rng(23)
+    im = HostImage(*shape, dtype, 1, 1)
+    v = im.view(with_border=True)[..., 0]
+    if kind == "sparse":
+        v[...] = np.where(rng.random(v.shape) < 0.15, rng.integers(1, 255, v.shape), 0)
+    elif kind == "dense":
+        v[...] = rng.integers(0, 6, v.shape)
+    elif kind == "signed":
+        v[...] = rng.integers(-5, 6, v.shape)
+    elif kind == "ramp":
+        v[...] = (np.arange(v.shape[1])[None, ::-1] * 3.0 + np.arange(v.shape[0])[::-1][:, None] * 0.5 + rng.random(v.shape) * 0.2).astype(np.float32)
+    elif kind == "plateau":
+        v[...] = 7; v[10:20, 10:30] = 9; v[12, 14] = 11
+    else:
+        v[...] = np.where(rng.random(v.shape) < 0.03, rng.integers(1, 16, v.shape), 0)
+    d = DeviceImage.from_host(im)
+    assert orc.orc_local_maxima_filter(P(im.desc)) == 0
+    capi.check(lib.vpp_local_maxima_filter(P(d.desc), capi.stream_ptr()))
+    _sync(lib)
+    np.testing.assert_array_equal(d.download().raw, im.raw)

@@ -180,3 +180,27 @@ def test_semi_dense_optical_flow(orc, ref, shape, ws, nscales, min_scale, prop, 
         outs.append((p, d, v))
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,kind", [(vi.U8, "sparse"), (vi.U8, "dense"), (vi.I32, "signed"), (vi.F32, "ramp"), (vi.U8, "plateau")])
+def test_local_maxima_filter(orc, ref, dtype, kind):
+    """local_maxima_filter in its serial raster-order form (fast.hpp:555-575): score-like sparse images, dense noise (long dependency chains),
+    signed values (zeroing a negative RAISES it), monotone ramps (every pixel waits for its left neighbour), plateaus (ties are not maxima)."""
+    rng = np.random.default_rng(17)
+    shape = (37, 53)
+    im = HostImage(*shape, dtype, 1, 1)
+    v = im.view(with_border=True)[..., 0]
+    if kind == "sparse":
+        v[...] = np.where(rng.random(v.shape) < 0.15, rng.integers(1, 255, v.shape), 0)
+    elif kind == "dense":
+        v[...] = rng.integers(0, 6, v.shape)
+    elif kind == "signed":
+        v[...] = rng.integers(-5, 6, v.shape)
+    elif kind == "ramp":
+        v[...] = (np.arange(v.shape[1])[None, ::-1] * 3.0 + np.arange(v.shape[0])[::-1][:, None] * 0.5 + rng.random(v.shape) * 0.2).astype(np.float32)
+    else:
+        v[...] = 7; v[10:20, 10:30] = 9; v[12, 14] = 11
+    a = im; b = im.like(); b.raw[:] = a.raw
+    assert ref.ref_local_maxima_filter(P(a.desc)) == 0
+    assert orc.orc_local_maxima_filter(P(b.desc)) == 0
+    np.testing.assert_array_equal(a.raw, b.raw)

@@ -82,6 +82,12 @@ template <class V, class U> void fast_detector9(const image2d<V>& A, image2d<U>&
 }  // namespace FAST_internals
 
 // blockwise_maxima_filter (fast.hpp:577-614), in place: per block only the first strict maximum > 0 survives.  (The reference
+// local_maxima_filter(A, nbh_size) (fast.hpp:555-575; nbh_size is ignored there too), in place: the reference's serial raster-order result
+template <class V> void local_maxima_filter(const image2d<V>& A, int /*nbh_size*/) {
+  const vpp_image_desc da = A.device_desc(true);
+  device::check(vpp_local_maxima_filter(&da, device::stream()), "vpp_local_maxima_filter");
+}
+
 // declares it on a const image and does not compile when instantiated; it is callable here.)
 template <class V> void blockwise_maxima_filter(const image2d<V>& A, int block_size) {
   const vpp_image_desc da = A.device_desc(true);
