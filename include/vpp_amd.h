@@ -260,6 +260,14 @@ int vpp_comm_unique_id(void* id128);
 int vpp_comm_init(vpp_comm** comm, int nranks, const void* id128, int rank);
 int vpp_comm_destroy(vpp_comm* comm);
 int vpp_allgather_tracks(vpp_comm* comm, const vpp_keypoint_f32* shard, int n_per_rank, vpp_keypoint_f32* all, void* stream);
+/* Row-strip sharding of the image-space phases (SURVEY 8e bullet 2; no reference counterpart).  A strip is a bordered image holding
+ * rows [r0, r1) of a frame; its border rows are the halo.  At a true frame edge they are an ordinary border (vpp_fill_border); at an
+ * inner edge they must hold the neighbouring strip's rows — full pitch-wide rows, column borders included — so that a stencil kernel
+ * (FAST-9: 3 rows, box R x C: R / 2, low-pass: 2) run on the strip computes what it would on the frame.  vpp_halo_exchange: one strip
+ * per rank, ranks ordered top to bottom, grouped RCCL send / recv with the two neighbours.  vpp_halo_copy: the same transfer between
+ * two strips of one process (two streams of one GPU, peer GPUs). */
+int vpp_halo_exchange(vpp_comm* comm, const vpp_image_desc* strip, int halo_rows, void* stream);
+int vpp_halo_copy(const vpp_image_desc* upper, const vpp_image_desc* lower, int halo_rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,9 +18,11 @@ typedef int (*CommInitRank_t)(void**, int, UniqueId, int);
 typedef int (*CommDestroy_t)(void*);
 typedef int (*AllGather_t)(const void*, void*, size_t, int /*ncclDataType_t*/, void*, hipStream_t);
 typedef const char* (*GetErrorString_t)(int);
+typedef int (*SendRecv_t)(void*, size_t, int /*ncclDataType_t*/, int /*peer*/, void*, hipStream_t);   // ncclSend (const void*) / ncclRecv
+typedef int (*Group_t)(void);
 struct Rccl {
   void* h = nullptr; GetUniqueId_t get_id = nullptr; CommInitRank_t init = nullptr; CommDestroy_t destroy = nullptr; AllGather_t all_gather = nullptr;
-  GetErrorString_t err = nullptr;
+  GetErrorString_t err = nullptr; SendRecv_t send = nullptr, recv = nullptr; Group_t group_start = nullptr, group_end = nullptr;
 };
 Rccl* rccl() {
   static Rccl r;
@@ -34,6 +36,8 @@ Rccl* rccl() {
     r.get_id = (GetUniqueId_t)dlsym(r.h, "ncclGetUniqueId"); r.init = (CommInitRank_t)dlsym(r.h, "ncclCommInitRank");
     r.destroy = (CommDestroy_t)dlsym(r.h, "ncclCommDestroy"); r.all_gather = (AllGather_t)dlsym(r.h, "ncclAllGather");
     r.err = (GetErrorString_t)dlsym(r.h, "ncclGetErrorString");
+    r.send = (SendRecv_t)dlsym(r.h, "ncclSend"); r.recv = (SendRecv_t)dlsym(r.h, "ncclRecv");
+    r.group_start = (Group_t)dlsym(r.h, "ncclGroupStart"); r.group_end = (Group_t)dlsym(r.h, "ncclGroupEnd");
     if (!(r.get_id && r.init && r.destroy && r.all_gather)) r.h = nullptr;
   });
   return r.h ? &r : nullptr;
@@ -83,6 +87,55 @@ int vpp_allgather_tracks(vpp_comm* comm, const vpp_keypoint_f32* shard, int n_pe
   VPP_REQUIRE(R, VPP_ERR_UNSUPPORTED, "vpp_allgather_tracks: no RCCL library");
   static_assert(sizeof(vpp_keypoint_f32) == 20, "keypoint record is 20 bytes");
   VPP_RCCL_TRY(R->all_gather(shard, all, (size_t)n_per_rank * sizeof(vpp_keypoint_f32), 0 /* ncclInt8 / ncclChar */, comm->nccl, as_stream(stream)));
+  return VPP_OK;
+}
+
+// ---- row-strip sharding of the image-space phases (SURVEY 8e bullet 2): halo rows --------------------------------------------
+// A strip is an ordinary bordered image holding rows [r0, r1) of a frame; its border rows are the HALO: at a true frame edge they
+// are filled like any border (fill_border_mirror), at an inner edge they must hold the neighbouring strip's first / last rows —
+// whole rows of the pitch, column borders included, so that a stencil kernel run on the strip reads exactly what it would read
+// on the full frame.  halo <= border rows are exchanged.
+namespace {
+inline uint8_t* strip_row(const vpp_image_desc* d, int r) { return (uint8_t*)d->first_pixel + (ptrdiff_t)r * d->pitch - (ptrdiff_t)d->border * elem_bytes(d); }
+inline size_t strip_row_bytes(const vpp_image_desc* d) { return (size_t)(d->ncols + 2 * d->border) * elem_bytes(d); }
+}  // namespace
+
+// two strips of ONE process (two streams of one GPU, or two GPUs with peer access): upper's last rows -> lower's top halo and
+// lower's first rows -> upper's bottom halo
+int vpp_halo_copy(const vpp_image_desc* upper, const vpp_image_desc* lower, int halo, void* stream) {
+  VPP_REQUIRE(valid_desc(upper) && valid_desc(lower) && same_type(upper, lower) && upper->ncols == lower->ncols && upper->border == lower->border, VPP_ERR_INVALID_ARG,
+              "vpp_halo_copy: the strips must have the same width, border and element type");
+  VPP_REQUIRE(halo >= 0 && halo <= upper->border && halo <= upper->nrows && halo <= lower->nrows, VPP_ERR_INVALID_ARG, "vpp_halo_copy: halo %d exceeds the border / the strips", halo);
+  if (halo == 0) return VPP_OK;
+  const size_t rb = strip_row_bytes(upper);
+  VPP_HIP_TRY(hipMemcpy2DAsync(strip_row(lower, -halo), lower->pitch, strip_row(upper, upper->nrows - halo), upper->pitch, rb, halo, hipMemcpyDeviceToDevice, as_stream(stream)));
+  VPP_HIP_TRY(hipMemcpy2DAsync(strip_row(upper, upper->nrows), upper->pitch, strip_row(lower, 0), lower->pitch, rb, halo, hipMemcpyDeviceToDevice, as_stream(stream)));
+  return VPP_OK;
+}
+
+// one strip per rank, rank order = top to bottom: grouped RCCL send / recv with rank - 1 and rank + 1 over xGMI (rows are packed
+// through staging buffers so that each direction is one message of halo * row_bytes)
+int vpp_halo_exchange(vpp_comm* comm, const vpp_image_desc* strip, int halo, void* stream) {
+  VPP_REQUIRE(comm && valid_desc(strip), VPP_ERR_INVALID_ARG, "vpp_halo_exchange: invalid argument");
+  VPP_REQUIRE(halo >= 0 && halo <= strip->border && halo <= strip->nrows, VPP_ERR_INVALID_ARG, "vpp_halo_exchange: halo %d exceeds the border / the strip", halo);
+  if (halo == 0 || comm->nranks == 1) return VPP_OK;
+  Rccl* R = rccl();
+  VPP_REQUIRE(R && R->send && R->recv && R->group_start && R->group_end, VPP_ERR_UNSUPPORTED, "vpp_halo_exchange: no RCCL send / recv");
+  hipStream_t st = as_stream(stream);
+  const size_t rb = strip_row_bytes(strip), msg = rb * halo;
+  static thread_local Scratch scratch;   // 4 messages: send up, send down, recv from up, recv from down
+  int rc = scratch.ensure(4 * msg, st);
+  if (rc != VPP_OK) return rc;
+  uint8_t* b = (uint8_t*)scratch.p;
+  const bool up = comm->rank > 0, down = comm->rank + 1 < comm->nranks;
+  if (up) VPP_HIP_TRY(hipMemcpy2DAsync(b, rb, strip_row(strip, 0), strip->pitch, rb, halo, hipMemcpyDeviceToDevice, st));
+  if (down) VPP_HIP_TRY(hipMemcpy2DAsync(b + msg, rb, strip_row(strip, strip->nrows - halo), strip->pitch, rb, halo, hipMemcpyDeviceToDevice, st));
+  VPP_RCCL_TRY(R->group_start());
+  if (up) { VPP_RCCL_TRY(R->send(b, msg, 0, comm->rank - 1, comm->nccl, st)); VPP_RCCL_TRY(R->recv(b + 2 * msg, msg, 0, comm->rank - 1, comm->nccl, st)); }
+  if (down) { VPP_RCCL_TRY(R->send(b + msg, msg, 0, comm->rank + 1, comm->nccl, st)); VPP_RCCL_TRY(R->recv(b + 3 * msg, msg, 0, comm->rank + 1, comm->nccl, st)); }
+  VPP_RCCL_TRY(R->group_end());
+  if (up) VPP_HIP_TRY(hipMemcpy2DAsync(strip_row(strip, -halo), strip->pitch, b + 2 * msg, rb, rb, halo, hipMemcpyDeviceToDevice, st));
+  if (down) VPP_HIP_TRY(hipMemcpy2DAsync(strip_row(strip, strip->nrows), strip->pitch, b + 3 * msg, rb, rb, halo, hipMemcpyDeviceToDevice, st));
   return VPP_OK;
 }
 
