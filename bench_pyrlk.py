@@ -50,6 +50,20 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
            "exchange": "rccl all_gather of 20-byte keypoint records" if world > 1 else "none (1 GPU)"}
 
     if world > 1:
+        # the same step without Python on it: one C++ process per GPU (benchmarks/pyrlk_shard_bench.cc), match + RCCL all-gather recorded in a
+        # launch graph per rank.  Guarded by a timeout: a harness that cannot initialise its communicator costs at most that.
+        exe = os.path.join(ROOT, "benchmarks", "pyrlk_shard_bench")
+        if os.path.exists(exe) and os.environ.get("VPP_BENCH_ONE_DEVICE", "0") != "1":
+            import json as _json, subprocess as _sp
+            uid = f"/tmp/vpp_uid_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+            try:
+                out = _sp.run([exe, str(rank), str(world), uid, "200", str(NK)], capture_output=True, text=True, timeout=120)
+                if rank == 0:
+                    res["cpp_harness"] = _json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else {"error": (out.stderr or out.stdout)[-300:], "rc": out.returncode}
+            except Exception as e:  # noqa: BLE001
+                if rank == 0:
+                    res["cpp_harness"] = {"error": f"{type(e).__name__}: {e}"}
+            barrier()
         # weak scaling in keypoints: NK keypoints PER rank (a denser keypoint set on the same frame pair, rank g owning the slice
         # [g*NK, (g+1)*NK) of world*NK), the all-gather carries all world*NK records
         full0 = torch.from_numpy(kps_h.view(np.uint8).reshape(-1).copy()).to(dev)

@@ -61,6 +61,10 @@ int vpp_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int vpp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 int vpp_memset(void* dst, int byte, size_t bytes, void* stream);
 int vpp_sync(void* stream);
+/* A stream of the current device for hosts that have none of their own (every entry point takes `void* stream` = a hipStream_t, NULL =
+ * the null stream): launch graphs are recorded on one, and independent frame pairs overlap on several. */
+int vpp_stream_create(void** stream);
+int vpp_stream_destroy(void* stream);
 /* Launch graphs (no reference counterpart: the reference's frame loops call the algorithms directly, e.g.
  * examples/video_extruder.cc:40-60; on a stream the per-launch host cost is what a graph removes).  Everything queued on
  * `stream` between vpp_graph_begin and vpp_graph_end is recorded instead of run; vpp_graph_launch replays it with one

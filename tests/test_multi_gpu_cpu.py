@@ -47,15 +47,23 @@ def _worker(rank, world, port, n, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [150, 151])  # even and ragged shards
-def test_keypoint_sharding_and_all_gather_gloo(orc, tmp_path, n):
+@pytest.mark.parametrize("n,world", [(150, 2), (151, 2), (151, 3)])  # even and ragged shards, 2 and 3 ranks
+def test_keypoint_sharding_and_all_gather_gloo(orc, tmp_path, n, world):
     import pyr
     from vpp_amd import multi_gpu as mg
-    world = 2
-    port = 29500 + (os.getpid() % 2000) + n
+    port = 29500 + (os.getpid() % 2000) + n + 7 * world
     mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
     want = _track(orc, pyr.make_keypoints(pyr.grid_keypoints(160, 200, n, margin=24))).view(np.uint8).reshape(-1)
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npy"))
         np.testing.assert_array_equal(got, want)
     assert [mg.shard_bounds(10, r, 4) for r in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]
+
+
+def test_cpp_harness_shard_plan(tmp_path):
+    """benchmarks/shard_plan.hh — the slice / pad / unpad arithmetic of benchmarks/pyrlk_shard_bench.cc — for world sizes 1-8, even and ragged."""
+    import subprocess
+    exe = str(tmp_path / "shard_plan_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "cpp", "shard_plan_test.cc"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "shard_plan_test ok" in out.stdout, out.stderr

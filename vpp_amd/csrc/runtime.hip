@@ -201,6 +201,17 @@ int vpp_memset(void* dst, int byte, size_t bytes, void* stream) {
   return VPP_OK;
 }
 int vpp_sync(void* stream) { VPP_HIP_TRY(hipStreamSynchronize(as_stream(stream))); return VPP_OK; }
+int vpp_stream_create(void** stream) {
+  VPP_REQUIRE(stream, VPP_ERR_INVALID_ARG, "vpp_stream_create: null");
+  hipStream_t s;
+  VPP_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void*)s;
+  return VPP_OK;
+}
+int vpp_stream_destroy(void* stream) {
+  if (stream) VPP_HIP_TRY(hipStreamDestroy(as_stream(stream)));
+  return VPP_OK;
+}
 
 // Launch graphs for C / C++ hosts: every entry point of this ABI is stream-ordered and allocation-free on its fast paths, so a
 // frame loop (or K benchmark launches) can be recorded once and replayed with one submission.  With `timed`, the graph gets an
