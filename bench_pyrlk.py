@@ -132,6 +132,30 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     dt = (time.perf_counter() - t0) / it
     res["semi_dense_flow_4k"] = {"ms_per_frame_pair": dt * 1e3, "frame_pairs_per_s": world / dt, "keypoints": m,
                                  "note": "one frame pair per GPU (replicas); serial-order semantics, bit-exact vs the oracle"}
+    # several independent frame pairs in flight on one GPU: each on its own stream (its own scratch: common.hpp Scratch is per stream), so one
+    # pair's single-workgroup ordered sweep overlaps the other pairs' pyramids / claim / descent / Jacobi and their sweeps on other CUs
+    conc = {}
+    for k in (1, 2, 4, 8):
+        streams = [torch.cuda.Stream(device=dev) for _ in range(k)]
+        outs = [(torch.zeros((m, 2), dtype=torch.int32, device=dev), torch.zeros(m, dtype=torch.int32, device=dev), torch.zeros(m, dtype=torch.uint8, device=dev)) for _ in range(k)]
+
+        def run(reps):
+            for _ in range(reps):
+                for j in range(k):
+                    o = outs[j]
+                    lib.vpp_semi_dense_optical_flow(P(e1.desc), P(e2.desc), V(dk.data_ptr()), m, 9, 3, 0, 2, 5, V(o[0].data_ptr()), V(o[1].data_ptr()), V(o[2].data_ptr()),
+                                                    ctypes.c_void_p(streams[j].cuda_stream))
+        torch.cuda.synchronize()
+        run(2)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 4
+        run(reps)
+        barrier()
+        dtk = (time.perf_counter() - t0) / (reps * k)
+        same = all(bool(torch.equal(o[0], gp)) and bool(torch.equal(o[1], gd)) and bool(torch.equal(o[2], gv)) for o in outs)
+        conc[str(k)] = {"frame_pairs_per_s": world / dtk, "identical_to_the_single_stream_result": same}
+    res["semi_dense_flow_4k"]["concurrent_streams"] = conc
 
     # frame ingest: 4K vuchar3 frame -> gray with a mirror-filled border of 3 in one pass; 4 B/px algorithmic
     from vpp_amd.synth import rand_image

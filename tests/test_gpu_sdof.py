@@ -85,3 +85,29 @@ def test_sdof_tall_map_uses_the_1024_thread_instance(lib, orc, ws):
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
     assert int(want[2].sum()) > 1000
+
+
+def test_concurrent_frame_pairs_on_streams_are_each_exact(lib, orc):
+    """Four independent frame pairs in flight on four streams (each call carves its scratch per stream): every result equals the serial oracle."""
+    scenes = [flow_scene(240 + 20 * j, 320 + 10 * j, seed=31 + j, spacing=5) for j in range(4)]
+    streams = [torch.cuda.Stream() for _ in scenes]
+    want, dev, outs = [], [], []
+    for (f1, f2, kps) in scenes:
+        i1, i2 = u8_image(f1, border=3), u8_image(f2, border=3)
+        n = len(kps)
+        wp = np.zeros((n, 2), np.int32); wd = np.zeros(n, np.int32); wv = np.zeros(n, np.uint8)
+        assert orc.orc_semi_dense_optical_flow(P(i1.desc), P(i2.desc), kps.ctypes.data_as(ctypes.c_void_p), n, 9, 3, 0, 2, 5,
+                                               wp.ctypes.data_as(ctypes.c_void_p), wd.ctypes.data_as(ctypes.c_void_p), wv.ctypes.data_as(ctypes.c_void_p)) == 0
+        want.append((wp, wd, wv))
+        dev.append((DeviceImage.from_host(i1), DeviceImage.from_host(i2), torch.from_numpy(kps).cuda()))
+        outs.append((torch.zeros((n, 2), dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda")))
+    torch.cuda.synchronize()
+    for rep in range(3):     # interleaved submissions, several rounds (the scratch slots are reused)
+        for j, ((d1, d2, dk), o) in enumerate(zip(dev, outs)):
+            capi.check(lib.vpp_semi_dense_optical_flow(P(d1.desc), P(d2.desc), ctypes.c_void_p(dk.data_ptr()), len(dk), 9, 3, 0, 2, 5, ctypes.c_void_p(o[0].data_ptr()),
+                                                       ctypes.c_void_p(o[1].data_ptr()), ctypes.c_void_p(o[2].data_ptr()), ctypes.c_void_p(streams[j].cuda_stream)))
+    torch.cuda.synchronize()
+    for (wp, wd, wv), o in zip(want, outs):
+        np.testing.assert_array_equal(o[2].cpu().numpy(), wv)
+        np.testing.assert_array_equal(o[0].cpu().numpy()[wv == 1], wp[wv == 1])
+        np.testing.assert_array_equal(o[1].cpu().numpy()[wv == 1], wd[wv == 1])
