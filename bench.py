@@ -153,17 +153,55 @@ def main():
             regions.append((wall, elapsed_in_graph() if elapsed_in_graph else e0.elapsed_time(e1) * 1e-3))
         # kernel-duration sample for the roofline: the event pair around ONE K-launch region carries ~8 us of fixed marker /
         # command-processor latency (K = 20: 9.0 us per launch inside the bracket where rocprofv3's per-dispatch durations of the
-        # same run average 8.55), so the same graph is replayed back to back until >= 2000 launches sit between one event pair
-        reps = max(1, -(-2000 // max(steps, 1)))
-        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        s0.record(stream)
-        for _ in range(reps):
-            replay()
-        s1.record(stream)
-        torch.cuda.synchronize()
-        sample = {"launches": reps * steps, "us_per_launch": s0.elapsed_time(s1) * 1e3 / (reps * steps),
-                  "how": f"{reps} back-to-back replays of the {steps}-launch graph between one HIP event pair on the launch stream"}
+        # same run average 8.55), and back-to-back replays of a short graph pay a submission gap per replay.  So the roofline's
+        # launch duration comes from ONE replay of a graph of >= 2000 of the same launches (the timed graph itself when K >= 2000).
+        n_sample = max(steps, 2000)
+        sample = None
+        if use_graph and c_graph and mode.startswith("vpp_graph"):
+            sp = ctypes.c_void_p(side.cuda_stream)
+            gh2, timed_nodes = ctypes.c_void_p(), 1
+            if n_sample == steps and elapsed_in_graph:
+                s_replay, s_elapsed = replay, elapsed_in_graph
+            else:
+                capi.check(lib.vpp_graph_begin(sp))
+                for i in range(n_sample):
+                    launch(i, sp)
+                if lib.vpp_graph_end(sp, 1, ctypes.byref(gh2)) != capi.OK:
+                    timed_nodes = 0
+                    capi.check(lib.vpp_graph_begin(sp))
+                    for i in range(n_sample):
+                        launch(i, sp)
+                    capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(gh2)))
+                s_replay = lambda: capi.check(lib.vpp_graph_launch(gh2, sp))
+
+                def s_elapsed():
+                    ms = ctypes.c_float(0)
+                    capi.check(lib.vpp_graph_elapsed_ms(gh2, ctypes.byref(ms)))
+                    return ms.value * 1e-3
+            s_replay(); torch.cuda.synchronize()
+            vals = []
+            for _ in range(3):
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record(side); s_replay(); s1.record(side)
+                torch.cuda.synchronize()
+                vals.append(s_elapsed() if timed_nodes else s0.elapsed_time(s1) * 1e-3)
+            vals.sort()
+            sample = {"launches": n_sample, "us_per_launch": vals[1] / n_sample * 1e6,
+                      "how": f"one replay of a {n_sample}-launch graph of the same launches (same buffer rotation), median of 3, "
+                             + ("event-record nodes inside the graph" if timed_nodes else "stream events around the replay")}
+            if gh2:
+                lib.vpp_graph_destroy(gh2)
+        if sample is None:
+            reps = max(1, -(-2000 // max(steps, 1)))
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            s0.record(stream)
+            for _ in range(reps):
+                replay()
+            s1.record(stream)
+            torch.cuda.synchronize()
+            sample = {"launches": reps * steps, "us_per_launch": s0.elapsed_time(s1) * 1e3 / (reps * steps),
+                      "how": f"{reps} back-to-back replays of the {steps}-launch graph between one HIP event pair on the launch stream"}
         # every region times exactly `steps` launches; the reported one is the median by wall clock (all of them are listed in "timed_regions")
         order = sorted(range(len(regions)), key=lambda k: regions[k][0])
         wall, ev = regions[order[len(order) // 2]]

@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from vpp_amd.synth import P, u8_image, DeviceImage, rects_image
-from test_gpu_sdof import flow_scene
+from vpp_amd.synth import flow_scene, texture, translate
+from vpp_amd import pyr, image as vi
 from vpp_amd import capi
 V = ctypes.c_void_p
 lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
@@ -29,3 +30,17 @@ for i in range(4):
     capi.check(lib.vpp_semi_dense_optical_flow(P(d1.desc), P(d2.desc), V(dk.data_ptr()), m, 9, 3, 0, 2, 5, V(gp.data_ptr()), V(gd.data_ptr()), V(gv.data_ptr()), st))
     torch.cuda.synchronize(); print("sdof 4K", m, "keypoints:", (time.perf_counter() - t0) * 1e3, "ms")
     lib.vpp_debug_sdof_stats(st4, 1); print("  sweep stats: visited %d, jacobi applied %d, slow path %d, slow changed %d" % tuple(st4))
+
+# pyrLK, BASELINE configs[3]: 1080p, 3 levels, 10 000 keypoints, 7x7
+NR, NC, L, B = 1080, 1920, 3, 3
+tex = texture(NR, NC, seed=5)
+g1 = np.clip(np.rint(tex), 0, 255).astype(np.uint8); g2 = np.clip(np.rint(translate(tex, 1.5, -2.25)), 0, 255).astype(np.uint8)
+q1, q2 = DeviceImage.from_host(u8_image(g1)), DeviceImage.from_host(u8_image(g2))
+kps_h = pyr.make_keypoints(pyr.grid_keypoints(NR, NC, 10000, margin=32))
+k0 = torch.from_numpy(kps_h.view(np.uint8).reshape(-1).copy()).cuda()
+for i in range(6):
+    p1 = pyr.device_pyramid(lib, q1, L, B); p2 = pyr.device_pyramid(lib, q2, L, B); gr = pyr.device_grad_pyramid(lib, p1[0], L, B, vi.F32)
+    k = k0.clone()
+    capi.check(lib.vpp_pyrlk_match(vi.desc_array(p1), vi.desc_array(gr), vi.desc_array(p2), L, V(k.data_ptr()), 10000, 7, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30,
+                                   ctypes.c_float(0.01), 0, None, st))
+torch.cuda.synchronize()
