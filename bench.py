@@ -136,14 +136,17 @@ def main():
             preheat["launches"] += n_pre
         regions = []
         for _ in range(max(1, args.regions)):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            outer = elapsed_in_graph is None   # stream events only when the graph does not carry its own event nodes (they cost host time inside the region)
+            if outer:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             barrier()
             t0 = time.perf_counter()
-            e0.record(stream)
+            if outer:
+                e0.record(stream)
             replay()
-            e1.record(stream)
-            torch.cuda.synchronize()
-            barrier()
+            if outer:
+                e1.record(stream)
+            barrier()   # = synchronize (+ dist.barrier for N > 1)
             t1 = time.perf_counter()
             wall = t1 - t0
             if multi:
