@@ -776,6 +776,29 @@ int orc_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int 
   return VPP_OK;
 }
 
+// The merge step of video_extruder_update (video_extruder.hpp:60-84), restated literally: an index image of (nrows / spacing) x
+// (ncols / spacing) cells with border 1 filled with -1, the keypoints visited in container order.  pos / age describe the container AFTER the
+// flow callbacks (:48-53); removed[i] = 1 where the loop called keypoints.remove(i).  Pinned to the reference end to end by the 4K
+// video_extruder run (tests/test_gpu_video_extruder.py), since the reference has no separate entry point for this loop.
+int orc_keypoint_merge(const int32_t* pos_rc, const int32_t* age_in, int n, int nrows, int ncols, int spacing, uint8_t* removed) {
+  if (n < 0 || nrows <= 0 || ncols <= 0 || spacing <= 0) return VPP_ERR_INVALID_ARG;
+  const int gr = nrows / spacing, gc = ncols / spacing;
+  OwnedImg idx(gr > 0 ? gr : 1, gc > 0 ? gc : 1, VPP_I32, 1, 1);
+  for (int r = -1; r <= idx.v.nr; r++) for (int c = -1; c <= idx.v.nc; c++) idx.v.row<int32_t>(r)[c] = -1;   // fill_with_border(idx, -1)
+  std::vector<int> age(age_in, age_in + n);
+  for (int i = 0; i < n; i++) removed[i] = 0;
+  for (int i = 0; i < n; i++) {
+    const int pr = pos_rc[2 * i] / spacing, pc = pos_rc[2 * i + 1] / spacing;   // positions are inside the frame, so the cell is inside the border-1 image
+    int32_t& cell = idx.v.row<int32_t>(pr)[pc];
+    if (cell >= 0) {
+      const int other_age = age[cell];                                            // `auto other = ctx.keypoints[idx(pos)]` is a COPY (:72)
+      if (other_age < age[i]) { removed[cell] = 1; age[cell] = 0; cell = i; }
+      if (other_age > age[i]) { removed[i] = 1; age[i] = 0; }
+    } else cell = i;
+  }
+  return VPP_OK;
+}
+
 // lbp_transform (lbp_transform.hh:6-38): curB[i] = sum of ((neighbour > rows[1][i]) << k), k in row-major neighbour order.
 int orc_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in) {
   Img o(out), a(in);

@@ -50,6 +50,7 @@ int orc_linear_interpolate(const vpp_image_desc* img, float pr, float pc, float*
 int orc_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror);
 /* video_extruder/video_extruder.hpp:95-110 (rc: n host (row, col) pairs) */
 int orc_keypoint_mask(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing);
+int orc_keypoint_merge(const int32_t* pos_rc, const int32_t* age, int n, int nrows, int ncols, int spacing, uint8_t* removed);
 
 /* vpp/algorithms/lbp/lbp_transform.hh:6-38 */
 int orc_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in);

@@ -131,7 +131,7 @@ def _merge_model(pos, age, spacing, nr, nc):
 
 
 @pytest.mark.parametrize("n,nr,nc,spacing,max_age", [(4000, 90, 130, 10, 4), (20000, 211, 317, 7, 30), (3000, 40, 40, 10, 2), (1, 50, 50, 10, 3), (5000, 64, 64, 64, 6)])
-def test_keypoint_merge_matches_the_serial_champion_loop(lib, n, nr, nc, spacing, max_age):
+def test_keypoint_merge_matches_the_serial_champion_loop(lib, orc, n, nr, nc, spacing, max_age):
     rng = np.random.default_rng(n + spacing)
     prev = np.stack([rng.integers(0, nr, n), rng.integers(0, nc, n)], 1).astype(np.int32)
     moved = (prev + rng.integers(-12, 13, size=prev.shape)).astype(np.int32)
@@ -141,7 +141,10 @@ def test_keypoint_merge_matches_the_serial_champion_loop(lib, n, nr, nc, spacing
     inside = (moved[:, 0] >= 0) & (moved[:, 0] < nr) & (moved[:, 1] >= 0) & (moved[:, 1] < nc)
     pos = np.where(((matched == 1) & inside)[:, None], moved, prev)
     age = np.where(matched == 1, np.where(inside, age_prev + 1, 0), age_prev).astype(np.int32)
-    want = _merge_model(pos, age, spacing, nr, nc)
+    want = np.zeros(n, np.uint8)
+    assert orc.orc_keypoint_merge(np.ascontiguousarray(pos, np.int32).ctypes.data_as(ctypes.c_void_p), age.ctypes.data_as(ctypes.c_void_p), n, nr, nc, spacing,
+                                  want.ctypes.data_as(ctypes.c_void_p)) == 0               # the oracle's literal restatement of video_extruder.hpp:60-84
+    np.testing.assert_array_equal(want, _merge_model(pos, age, spacing, nr, nc))           # ... and an independent Python model of the same loop
     assert n < 10 or 0 < want.sum() < n
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     dm, dp, dmt, da = t(moved), t(prev), t(matched), t(age_prev)
