@@ -199,6 +199,13 @@ int vpp_lucas_kanade(const vpp_image_desc* prev, const vpp_image_desc* grad, con
 int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n,
                                 int winsize, int nscales, int min_scale, int propagation, int patchsize,
                                 int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, void* stream);
+/* The same call with its per-keypoint phases (claim, descent) sharded by row strips of the flow maps — the decomposition of SURVEY 8e
+ * bullet 2: every strip has private maps and its own stream, the strips' rows are gathered into the owner's maps, the owner runs the
+ * Jacobi pre-passes and the ordered sweeps, and the swept maps are broadcast back as the next scale's prediction.  One process, one GPU:
+ * the exchanges are device copies; across GPUs they are RCCL gathers / broadcasts of the same rows.  Results identical to nstrips = 1. */
+int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n,
+                                       int winsize, int nscales, int min_scale, int propagation, int patchsize, int nstrips,
+                                       int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, void* stream);
 
 /* ---- the steps either side of the algorithms in the reference's video loop (examples/video_extruder.cc:44-58) ---- */
 /* rgb_to_graylevel (vpp/core/colorspace_conversions.hh:10-33; 4-channel input :36-48 ignores the 4th component):

@@ -111,3 +111,31 @@ def test_concurrent_frame_pairs_on_streams_are_each_exact(lib, orc):
         np.testing.assert_array_equal(o[2].cpu().numpy(), wv)
         np.testing.assert_array_equal(o[0].cpu().numpy()[wv == 1], wp[wv == 1])
         np.testing.assert_array_equal(o[1].cpu().numpy()[wv == 1], wd[wv == 1])
+
+
+@pytest.mark.parametrize("shape,nstrips", [((240, 320), 2), ((240, 320), 3), ((480, 640), 5), ((1080, 1920), 2), ((2160, 3840), 4)])
+def test_strip_sharded_flow_equals_the_single_strip_result(lib, orc, shape, nstrips):
+    """vpp_semi_dense_optical_flow_strips: claim + descent sharded by row strips of the flow maps (private maps per strip, gather to the owner,
+    ordered sweeps on the owner, broadcast of the swept maps): identical to the unsharded call, which is itself exact against the serial oracle."""
+    f1, f2, kps = flow_scene(*shape, spacing=10 if shape[0] > 500 else 5)
+    d1, d2 = DeviceImage.from_host(u8_image(f1, border=3)), DeviceImage.from_host(u8_image(f2, border=3))
+    dk = torch.from_numpy(kps).cuda(); n = len(kps)
+    outs = []
+    for s in (1, nstrips):
+        gp = torch.zeros((n, 2), dtype=torch.int32, device="cuda"); gd = torch.zeros(n, dtype=torch.int32, device="cuda"); gv = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        for _ in range(2):   # twice: the strips' private maps are reused
+            capi.check(lib.vpp_semi_dense_optical_flow_strips(P(d1.desc), P(d2.desc), ctypes.c_void_p(dk.data_ptr()), n, 9, 3, 0, 2, 5, s, ctypes.c_void_p(gp.data_ptr()),
+                                                              ctypes.c_void_p(gd.data_ptr()), ctypes.c_void_p(gv.data_ptr()), capi.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((gp.cpu().numpy(), gd.cpu().numpy(), gv.cpu().numpy()))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+    assert outs[0][2].sum() > n // 2
+    if shape[0] <= 480:   # and against the oracle directly
+        i1, i2 = u8_image(f1, border=3), u8_image(f2, border=3)
+        wp = np.zeros((n, 2), np.int32); wd = np.zeros(n, np.int32); wv = np.zeros(n, np.uint8)
+        assert orc.orc_semi_dense_optical_flow(P(i1.desc), P(i2.desc), kps.ctypes.data_as(ctypes.c_void_p), n, 9, 3, 0, 2, 5,
+                                               wp.ctypes.data_as(ctypes.c_void_p), wd.ctypes.data_as(ctypes.c_void_p), wv.ctypes.data_as(ctypes.c_void_p)) == 0
+        np.testing.assert_array_equal(outs[1][2], wv)
+        np.testing.assert_array_equal(outs[1][0][wv == 1], wp[wv == 1])
+        np.testing.assert_array_equal(outs[1][1][wv == 1], wd[wv == 1])

@@ -20,3 +20,11 @@ for ws in (9, 7):
         capi.check(lib.vpp_semi_dense_optical_flow(P(e1.desc), P(e2.desc), V(dk.data_ptr()), m, ws, 3, 0, 2, 5, V(gp.data_ptr()), V(gd.data_ptr()), V(gv.data_ptr()), st))
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     print(f"winsize {ws}: {min(ts[2:]) * 1e3:.3f} ms per 4K frame pair ({m} keypoints), checksum {int(gp.sum())} {int(gd.sum())}")
+# the strip-sharded form on one GPU (SURVEY 8e bullet 2): claim + descent on `nstrips` streams, gather / broadcast as device copies
+for nstrips in (1, 2, 4, 8):
+    ts = []
+    for it in range(8):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        capi.check(lib.vpp_semi_dense_optical_flow_strips(P(e1.desc), P(e2.desc), V(dk.data_ptr()), m, 9, 3, 0, 2, 5, nstrips, V(gp.data_ptr()), V(gd.data_ptr()), V(gv.data_ptr()), st))
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print(f"winsize 9, {nstrips} strip(s): {min(ts[2:]) * 1e3:.3f} ms per 4K frame pair")

@@ -12,6 +12,8 @@
 //     serial result, deterministic.
 // Integer arithmetic throughout: bit-exact.  SAD windows are L2-resident; the path is integer-VALU / latency bound.
 #include "common.hpp"
+#include <climits>
+#include <vector>
 #include <type_traits>
 #include <climits>
 using namespace vpp_amd;
@@ -110,22 +112,24 @@ __device__ __forceinline__ GdMatch gradient_descent_match(const DImg& i1, const 
   return gradient_descent_impl<WS>([&](int n0, int n1, int th) { return distance_fn<WS>(i1, i2, p0, p1, n0, n1, ws, th); }, p0, p1, pr0, pr1, max_iteration);
 }
 
-__global__ __launch_bounds__(256) void sdof_claim_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, DImg owner) {
+// cell_lo / cell_hi: the flow-map rows this launch owns (row-strip sharding of the per-keypoint phases; [0, INT_MAX) = all)
+__global__ __launch_bounds__(256) void sdof_claim_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, DImg owner, int cell_lo, int cell_hi) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int p0 = kps[2 * i] / scale_div, p1 = kps[2 * i + 1] / scale_div;
   const int pf0 = p0 / patch, pf1 = p1 / patch;
-  if (!owner.has(pf0, pf1)) return;
+  if (!owner.has(pf0, pf1) || pf0 < cell_lo || pf0 >= cell_hi) return;
   atomicMin(owner.row<uint32_t>(pf0) + pf1, (uint32_t)i);
 }
 
 template <int WS>
 __global__ __launch_bounds__(64) void sdof_descent_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
-                                                          DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse) {
+                                                          DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   const int p0 = kps[2 * i] / scale_div, p1 = kps[2 * i + 1] / scale_div;  // :116
   const int pf0 = p0 / patch, pf1 = p1 / patch;
+  if (pf0 < cell_lo || pf0 >= cell_hi) return;
   if (!owner.has(pf0, pf1) || owner.row<uint32_t>(pf0)[pf1] != (uint32_t)i) return;  // :120 — first keypoint in index order claims
   int pr0 = p0, pr1 = p1;
   if (has_coarse) {  // multiscale prediction, :126-128
@@ -599,18 +603,55 @@ struct Carver {
 
 }  // namespace
 
-extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
-                                           int nscales, int min_scale, int propagation, int patchsize, int32_t* out_pos,
-                                           int32_t* out_dist, uint8_t* out_valid, void* stream) {
+// Row-strip sharding of the per-keypoint phases (SURVEY 8e bullet 2), in the shape a multi-GPU run has: strip k > 0 owns the flow-map
+// rows [fr k / S, fr (k + 1) / S) of every scale, has PRIVATE flow / mark / distance / owner maps and its own stream, and runs claim +
+// descent for the keypoints that fall into its rows against the shared (replicated) image pyramids and its own copy of the coarser
+// scale's final maps.  Exchanges, here device copies on the owner's stream (RCCL gather / broadcast of the same rows across GPUs): after
+// the descent the strips' rows are gathered into the owner's (strip 0's) maps, the owner runs the Jacobi pre-passes and the ordered sweeps
+// (their critical path is the wavefront over the whole map whatever the split), and the swept maps are broadcast back as the next finer
+// scale's prediction.  Every cell is written by exactly one strip from the same inputs as the single-strip run, so the result is identical.
+namespace {
+struct StripStreams {
+  std::vector<hipStream_t> st; std::vector<hipEvent_t> done; hipEvent_t start = nullptr;
+  int ensure(int n) {
+    while ((int)st.size() < n) {
+      hipStream_t s; hipEvent_t e;
+      VPP_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+      VPP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      st.push_back(s); done.push_back(e);
+    }
+    if (!start) VPP_HIP_TRY(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+    return VPP_OK;
+  }
+};
+thread_local StripStreams g_strips;
+// rows [lo, hi) of a map image, full pitch-wide rows, from one set of maps to another of the same layout
+int copy_rows(const vpp_image_desc* dst, const vpp_image_desc* src, int lo, int hi, hipStream_t st) {
+  if (hi <= lo) return VPP_OK;
+  const ptrdiff_t off = (ptrdiff_t)lo * src->pitch - (ptrdiff_t)src->border * elem_bytes(src);
+  VPP_HIP_TRY(hipMemcpyAsync((uint8_t*)dst->first_pixel + off, (const uint8_t*)src->first_pixel + off, (size_t)(hi - lo) * src->pitch, hipMemcpyDeviceToDevice, st));
+  return VPP_OK;
+}
+}  // namespace
+
+extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
+                                                  int nscales, int min_scale, int propagation, int patchsize, int nstrips, int32_t* out_pos,
+                                                  int32_t* out_dist, uint8_t* out_valid, void* stream) {
   VPP_REQUIRE(valid_desc(i1) && valid_desc(i2) && same_domain(i1, i2), VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: invalid frames");
   VPP_REQUIRE(i1->dtype == VPP_U8 && i1->channels == 1 && i2->dtype == VPP_U8 && i2->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_semi_dense_optical_flow: u8 x1 frames only");
   VPP_REQUIRE(n >= 0 && (n == 0 || (kps && out_pos && out_dist && out_valid)), VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: null buffer");
   VPP_REQUIRE(winsize > 0 && patchsize > 0 && nscales >= 1 && nscales <= kMaxScales && min_scale >= 0 && min_scale < nscales && propagation >= 0,
               VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: bad parameters");
+  VPP_REQUIRE(nstrips >= 1 && nstrips <= 16, VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow_strips: 1 to 16 strips");
   if (n == 0) return VPP_OK;
   hipStream_t st = as_stream(stream);
-  // carve the scratch: two image pyramids (border 2*winsize, :72-73), flow / mark / distance pyramids (border nscales, :70-74), owners
-  vpp_image_desc P1[kMaxScales], P2[kMaxScales], FL[kMaxScales], MK[kMaxScales], DM[kMaxScales], OW[kMaxScales];
+  // carve the scratch: two image pyramids (border 2*winsize, :72-73), flow / mark / distance pyramids (border nscales, :70-74) and owners per strip
+  vpp_image_desc P1[kMaxScales], P2[kMaxScales];
+  std::vector<vpp_image_desc> FLs((size_t)nstrips * kMaxScales), MKs(FLs.size()), DMs(FLs.size()), OWs(FLs.size());
+  auto FL = [&](int k, int s_) -> vpp_image_desc& { return FLs[(size_t)k * kMaxScales + s_]; };
+  auto MK = [&](int k, int s_) -> vpp_image_desc& { return MKs[(size_t)k * kMaxScales + s_]; };
+  auto DM = [&](int k, int s_) -> vpp_image_desc& { return DMs[(size_t)k * kMaxScales + s_]; };
+  auto OW = [&](int k, int s_) -> vpp_image_desc& { return OWs[(size_t)k * kMaxScales + s_]; };
   Cell* jacobi = nullptr;
   uint8_t* skew = nullptr;
   PairCache* pairs = nullptr;
@@ -618,10 +659,12 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
     Carver cv{pass ? (uint8_t*)g_scratch.p : nullptr};
     int fr = i1->nrows / patchsize, fc = i1->ncols / patchsize, ir = i1->nrows, ic = i1->ncols;
     VPP_REQUIRE(fr > 0 && fc > 0, VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: image smaller than one patch");
-    for (int s = 0; s < nscales; s++) {
-      P1[s] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize); P2[s] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize);
-      FL[s] = cv.image(fr, fc, VPP_I32, 2, nscales); MK[s] = cv.image(fr, fc, VPP_U8, 1, nscales); DM[s] = cv.image(fr, fc, VPP_I32, 1, nscales);
-      OW[s] = cv.image(fr, fc, VPP_U32, 1, 0);
+    for (int s_ = 0; s_ < nscales; s_++) {
+      P1[s_] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize); P2[s_] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize);
+      for (int k = 0; k < nstrips; k++) {
+        FL(k, s_) = cv.image(fr, fc, VPP_I32, 2, nscales); MK(k, s_) = cv.image(fr, fc, VPP_U8, 1, nscales); DM(k, s_) = cv.image(fr, fc, VPP_I32, 1, nscales);
+        OW(k, s_) = cv.image(fr, fc, VPP_U32, 1, 0);
+      }
       fr = 1 + fr / 2; fc = 1 + fc / 2; ir = 1 + ir / 2; ic = 1 + ic / 2;  // pyramid.hh:154
     }
     {  // Jacobi outcomes: one cell per flow-map cell of the finest scale
@@ -636,24 +679,44 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
     }
     if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
-  auto build = [&](vpp_image_desc* P, const vpp_image_desc* in) -> int {  // pyramid::update, pyramid.hh:194-198: one launch for 2-3 scales
-    return vpp_pyramid_build(P, nscales, in, stream);
-  };
-  int rc = build(P1, i1); if (rc) return rc;
-  rc = build(P2, i2); if (rc) return rc;
-  auto maps = [&](int s) { return Maps{dimg(&FL[s]), dimg(&MK[s]), dimg(&DM[s])}; };
+  if (nstrips > 1) { int rc = g_strips.ensure(nstrips - 1); if (rc != VPP_OK) return rc; }
+  // the image pyramids: built once here; across GPUs every rank builds them from the broadcast frames (pyramid::update, pyramid.hh:194-198)
+  int rc = vpp_pyramid_build(P1, nscales, i1, stream); if (rc) return rc;
+  rc = vpp_pyramid_build(P2, nscales, i2, stream); if (rc) return rc;
+  auto maps = [&](int k, int s_) { return Maps{dimg(&FL(k, s_)), dimg(&MK(k, s_)), dimg(&DM(k, s_))}; };
   for (int scale = nscales - 1; scale >= min_scale; scale--) {  // :92
     const int scale_div = 1 << scale;
     const uint8_t zero = 0;
-    rc = vpp_fill(&MK[scale], &zero, 1, stream); if (rc) return rc;  // fill_with_border(flow_map_mark, 0), :111
-    VPP_HIP_TRY(hipMemsetAsync(OW[scale].first_pixel, 0xFF, (size_t)OW[scale].pitch * OW[scale].nrows, st));
-    sdof_claim_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, scale_div, patchsize, dimg(&OW[scale]));
     const bool has_coarse = scale < nscales - 1;
+    const int fr = FL(0, scale).nrows;
     // every kernel that evaluates SAD windows exists once per register-window size (WS = 0: any other size, generic loop)
-    auto launch_scale = [&](auto WSc) {
+    auto launch_scale = [&](auto WSc) -> int {
       constexpr int WS = decltype(WSc)::value;
-      sdof_descent_kernel<WS><<<(n + 63) / 64, 64, 0, st>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW[scale]), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                           maps(scale), maps(has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0);
+      // claim + descent of strip k on stream sk, rows [lo, hi) of the flow map, into strip k's own maps
+      auto strip_phase = [&](int k, hipStream_t sk) -> int {
+        const int lo = nstrips == 1 ? 0 : (int)((long long)fr * k / nstrips), hi = nstrips == 1 ? INT_MAX : (int)((long long)fr * (k + 1) / nstrips);
+        int r2 = vpp_fill(&MK(k, scale), &zero, 1, (void*)sk); if (r2) return r2;  // fill_with_border(flow_map_mark, 0), :111
+        VPP_HIP_TRY(hipMemsetAsync(OW(k, scale).first_pixel, 0xFF, (size_t)OW(k, scale).pitch * OW(k, scale).nrows, sk));
+        sdof_claim_kernel<<<(n + 255) / 256, 256, 0, sk>>>(kps, n, scale_div, patchsize, dimg(&OW(k, scale)), lo, hi);
+        sdof_descent_kernel<WS><<<(n + 63) / 64, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
+                                                             maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi);
+        return VPP_OK;
+      };
+      if (nstrips > 1) VPP_HIP_TRY(hipEventRecord(g_strips.start, st));   // the pyramids / the previous scale's broadcast are behind this point
+      for (int k = 1; k < nstrips; k++) {
+        hipStream_t sk = g_strips.st[k - 1];
+        VPP_HIP_TRY(hipStreamWaitEvent(sk, g_strips.start, 0));
+        int r2 = strip_phase(k, sk); if (r2) return r2;
+        VPP_HIP_TRY(hipEventRecord(g_strips.done[k - 1], sk));
+      }
+      { int r2 = strip_phase(0, st); if (r2) return r2; }
+      for (int k = 1; k < nstrips; k++) {   // gather: strip k's rows of the three maps into the owner's
+        VPP_HIP_TRY(hipStreamWaitEvent(st, g_strips.done[k - 1], 0));
+        const int lo = (int)((long long)fr * k / nstrips), hi = (int)((long long)fr * (k + 1) / nstrips);
+        int r2 = copy_rows(&FL(0, scale), &FL(k, scale), lo, hi, st); if (r2) return r2;
+        r2 = copy_rows(&MK(0, scale), &MK(k, scale), lo, hi, st); if (r2) return r2;
+        r2 = copy_rows(&DM(0, scale), &DM(k, scale), lo, hi, st); if (r2) return r2;
+      }
       if (propagation > 0) {
         const int NI = (P1[scale].nrows - 1) / patchsize + 1;
         const int threads = (NI + 63) / 64 * 64;
@@ -662,29 +725,44 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
         if (mode != 1 && NI <= 1024) {  // mode 1: the generic one-kernel wavefront (also the fallback for maps taller than 1024 cells)
           const size_t lds = (size_t)kRingGroups * threads * kGroupSteps;
           for (int Ki = 0; Ki < propagation; Ki++) {
-            sdof_jacobi_kernel<WS><<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs, skew, threads);
+            sdof_jacobi_kernel<WS><<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs, skew, threads);
             // a workgroup of at most 512 threads may use 256 registers per lane: the out-of-line recomputation then keeps its cells and
             // pair-cache entries in registers instead of scratch memory (4K frames: 448 threads)
-            if (threads <= 512) sdof_propagate_ring_kernel<WS, 512><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
-            else sdof_propagate_ring_kernel<WS, 1024><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
+            if (threads <= 512) sdof_propagate_ring_kernel<WS, 512><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
+            else sdof_propagate_ring_kernel<WS, 1024><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
           }
         } else
-          sdof_propagate_kernel<WS><<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(scale), patchsize, propagation);
+          sdof_propagate_kernel<WS><<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, propagation);
       }
+      if (scale > min_scale)   // broadcast: the swept maps are the next finer scale's prediction in every strip
+        for (int k = 1; k < nstrips; k++) {
+          const int b = FL(0, scale).border;
+          int r2 = copy_rows(&FL(k, scale), &FL(0, scale), -b, fr + b, st); if (r2) return r2;
+          r2 = copy_rows(&MK(k, scale), &MK(0, scale), -b, fr + b, st); if (r2) return r2;
+          r2 = copy_rows(&DM(k, scale), &DM(0, scale), -b, fr + b, st); if (r2) return r2;
+        }
+      return VPP_OK;
     };
     switch (winsize) {
-      case 5: launch_scale(std::integral_constant<int, 5>()); break;
-      case 7: launch_scale(std::integral_constant<int, 7>()); break;
-      case 9: launch_scale(std::integral_constant<int, 9>()); break;
-      case 11: launch_scale(std::integral_constant<int, 11>()); break;
-      default: launch_scale(std::integral_constant<int, 0>()); break;
+      case 5: rc = launch_scale(std::integral_constant<int, 5>()); break;
+      case 7: rc = launch_scale(std::integral_constant<int, 7>()); break;
+      case 9: rc = launch_scale(std::integral_constant<int, 9>()); break;
+      case 11: rc = launch_scale(std::integral_constant<int, 11>()); break;
+      default: rc = launch_scale(std::integral_constant<int, 0>()); break;
     }
+    if (rc) return rc;
     VPP_LAUNCH_CHECK();
   }
   const int ms = 1 << min_scale;
-  sdof_readback_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize * ms, ms, maps(min_scale), out_pos, out_dist, out_valid);
+  sdof_readback_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize * ms, ms, maps(0, min_scale), out_pos, out_dist, out_valid);
   VPP_LAUNCH_CHECK();
   return VPP_OK;
+}
+
+extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
+                                           int nscales, int min_scale, int propagation, int patchsize, int32_t* out_pos,
+                                           int32_t* out_dist, uint8_t* out_valid, void* stream) {
+  return vpp_semi_dense_optical_flow_strips(i1, i2, kps, n, winsize, nscales, min_scale, propagation, patchsize, 1, out_pos, out_dist, out_valid, stream);
 }
 
 // diagnostics (not part of include/vpp_amd.h): counters of the ordered propagation pass, enabled by tuning "sdof.stats"
