@@ -36,3 +36,9 @@ nin = 8
 rgbs = [DeviceImage.from_host(rgb_h) for _ in range(nin)]; grays = [DeviceImage(NR, NC, vi.U8, 1, 3, 32) for _ in range(nin)]
 us = time_graph(lambda i, s: lib.vpp_rgb_to_graylevel(P(grays[i % nin].desc), P(rgbs[i % nin].desc), 1, s))
 print(f"ingest vuchar3 -> gray + border 3: {us:.2f} us  frac {4 * NR * NC / us / 1e6 / 8:.3f}")
+# size scaling of the ingest kernel (fixed launch cost vs stream rate)
+for (nr, nc, nb) in ((1080, 1920, 16), (4320, 7680, 3)):
+    h = rand_image(nr, nc, vi.U8, 3, border=0, seed=6)
+    rg = [DeviceImage.from_host(h) for _ in range(nb)]; gr = [DeviceImage(nr, nc, vi.U8, 1, 3, 32) for _ in range(nb)]
+    us = time_graph(lambda i, s: lib.vpp_rgb_to_graylevel(P(gr[i % nb].desc), P(rg[i % nb].desc), 1, s), steps=100)
+    print(f"ingest {nc}x{nr}: {us:.2f} us  frac {4 * nr * nc / us / 1e6 / 8:.3f}")

@@ -456,13 +456,13 @@ __global__ __launch_bounds__(64 * NW, OCC * 4 / NW) void box_u8_wide_kernel(cons
 // Same shape as the u8 streaming kernel with one pixel per dword: a lane owns 4 consecutive pixels (16 B), keeps their
 // 5-row column sums (integer adds are order-independent, so the running add / subtract is exact, wrap-around included),
 // takes the two halo sums of each side from lane -1 / +1 over DPP, and lanes 1..62 store 4 truncating quotients (`/ 25` in T).
-// All RW + 4 row loads are issued up front.  Elements outside [-border, ncols + border) x [-border, nrows + border) are
-// never read (a straddling chunk takes predicated dword loads), so border == 2 needs no separate guarded body.
+// All RW + 4 row loads are issued up front through a buffer descriptor over the source's addressable bytes: nothing outside the
+// allocation is read (out-of-range dwords come back 0 from the range check), so border == 2 needs no separate guarded body.
 constexpr int kW32StripOut = 62 * 4;
 
 template <class T, int KR, int KC, int RW, bool NT>
 __global__ __launch_bounds__(256) void box_w32_stream_kernel(T* __restrict__ dp, const T* __restrict__ sp, int dpitch, int spitch,
-                                                                int nrows, int ncols, int border, int nstrips, int nblk_y) {
+                                                                int nrows, int ncols, int border, int nstrips, int nblk_y, uint32_t sbytes) {
   // geometry of the round-2 u8 kernel (measured there: 9.4 -> 8.5 us): a workgroup = its waves side by side (adjacent strips of one
   // row block), the block grid walked row-major inside each XCD, so the waves that split a store sector / share a halo line run together
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = (int)(blockDim.x >> 6);
@@ -477,27 +477,20 @@ __global__ __launch_bounds__(256) void box_w32_stream_kernel(T* __restrict__ dp,
   if (r0 >= nrows) return;
   static_assert((KR & 1) && (KC & 1) && KR <= 7 && KC <= 5, "two halo pixels per side come over DPP");
   constexpr int HR = KR / 2, C0 = 2 - KC / 2;  // first window column of output pixel 0 within the 8-pixel register window
-  const int lo = -border, hi = ncols + border;
-  const bool in_reach = x + 4 > lo && x < ncols + 4, inside = x >= lo && x + 4 <= hi;
   const bool writer = lane >= 1 && lane <= 62 && x < ncols;
   typedef uint32_t U;  // raw dwords: integer sums wrap like the hardware's adds (no signed-overflow UB in the source); floats are bit-cast
-  // Every load is unconditional so that the RW + 4 rows are requested back to back: rows past the bottom border are clamped
-  // (they only feed output rows >= nrows, which are not stored), lanes outside the strip's reach read a valid chunk that
-  // nobody consumes, and only the waves that contain a chunk straddling a row end (first / last strip) take the
-  // per-element form (clamped address + select), as a wave-uniform choice.
-  const bool vector_wave = __all(inside || !in_reach);
+  // Buffer descriptor over the source's addressable bytes (16 bytes before row -border .. the last addressable 16-byte granule): the row
+  // term of every address is a scalar offset, the lane term one register, the RW + KR - 1 row loads go out back to back without any
+  // clamping or per-element form — rows past the bottom border and chunks past the last row read 0 (hardware range check, tools/buftest.hip)
+  // and feed only outputs that are not stored; a chunk that straddles a row end reads the row's padding / the next row, which no window uses.
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint8_t*)sp - (ptrdiff_t)border * spitch - 16), 0, sbytes, 0x00020000);
+  const uint32_t vo = (uint32_t)(16 + min(x, (ncols + 3) & ~3) * 4);
+  const int srow = (r0 - HR + border) * spitch;
   U raw[RW + KR - 1][4];
 #pragma unroll
   for (int k = 0; k < RW + KR - 1; k++) {
-    const int r = min(r0 - HR + k, nrows - 1 + border);
-    const U* row = (const U*)((const uint8_t*)sp + (ptrdiff_t)r * spitch);
-    if (vector_wave) {
-      const u32x4 v = *(const u32x4*)(row + (in_reach ? x : 0));
-      raw[k][0] = v.x; raw[k][1] = v.y; raw[k][2] = v.z; raw[k][3] = v.w;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++) { const int c = x + i; const U v = row[min(max(c, lo), hi - 1)]; raw[k][i] = (c >= lo && c < hi) ? v : 0; }
-    }
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, srow + k * spitch, 0);
+    raw[k][0] = v.x; raw[k][1] = v.y; raw[k][2] = v.z; raw[k][3] = v.w;
   }
   const bool full_store = x + 4 <= ncols;
   if constexpr (std::is_floating_point<T>::value) {
@@ -575,15 +568,24 @@ __global__ __launch_bounds__(256) void box_w32_stream_kernel(T* __restrict__ dp,
 }
 
 template <class T, int KR = 5, int KC = 5> int launch_w32(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
-  const int rows = tuning("box.rows32", 4), nt = tuning("box.nt", 1);   // measured 4K int: 1 -> 20.4, 2 -> 17.4, 4 -> 16.6, 8 -> 21.8 us
+  // measured 4K (round 2, descriptor loads): int rows 2 -> 10.6 us, 4 -> 10.9; float (25 adds per pixel) rows 2 -> 13.2, 4 -> 12.4
+  const int rows = tuning("box.rows32", std::is_floating_point<T>::value ? 4 : 2), nt = tuning("box.nt", 1);
   int wpb = tuning("box.waves_per_block", 4);
   if (wpb != 1 && wpb != 2) wpb = 4;
   const int nstrips = (dst->ncols + kW32StripOut - 1) / kW32StripOut;
   auto go = [&](auto RWc, auto NTc) {
     constexpr int RW = decltype(RWc)::value; constexpr bool NT = decltype(NTc)::value;
-    const int nblk_y = (dst->nrows + RW - 1) / RW;
-    box_w32_stream_kernel<T, KR, KC, RW, NT><<<((nstrips + wpb - 1) / wpb) * nblk_y, 64 * wpb, 0, st>>>((T*)dst->first_pixel, (const T*)src->first_pixel, dst->pitch, src->pitch,
-                                                                              dst->nrows, dst->ncols, src->border, nstrips, nblk_y);
+    // one buffer descriptor addresses < 4 GiB: larger sources go out as row bands (a band's upper / lower neighbours are real rows of
+    // the same image, its descriptor simply ends 'border' rows below the band)
+    const size_t row_tail = 16 + (size_t)((((dst->ncols + src->border) * 4) + 15) & ~15);
+    const int band_max = (int)std::min<size_t>((size_t)dst->nrows, std::max<size_t>(RW, (((size_t)1 << 31) / (size_t)src->pitch) / RW * RW));
+    for (int b0 = 0; b0 < dst->nrows; b0 += band_max) {
+      const int band = std::min(band_max, dst->nrows - b0), nblk_y = (band + RW - 1) / RW;
+      const uint32_t sbytes = (uint32_t)((size_t)(band - 1 + 2 * src->border) * src->pitch + row_tail);
+      box_w32_stream_kernel<T, KR, KC, RW, NT><<<((nstrips + wpb - 1) / wpb) * nblk_y, 64 * wpb, 0, st>>>(
+          (T*)((uint8_t*)dst->first_pixel + (ptrdiff_t)b0 * dst->pitch), (const T*)((const uint8_t*)src->first_pixel + (ptrdiff_t)b0 * src->pitch), dst->pitch, src->pitch, band,
+          dst->ncols, src->border, nstrips, nblk_y, sbytes);
+    }
   };
   auto pick = [&](auto NTc) {
     if constexpr (KR == 5 && KC == 5) {

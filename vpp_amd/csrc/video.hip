@@ -23,42 +23,67 @@ constexpr int kGrayChunk = 16;  // output pixels per lane: CH x 16 B loaded, one
 // byte k of a little-endian dword array
 __device__ __forceinline__ uint32_t byte_at(const uint32_t* w, int k) { return (w[k >> 2] >> (8 * (k & 3))) & 255u; }
 
-template <int CH, bool MIRROR>
-__global__ __launch_bounds__(256) void rgb_to_gray_kernel(DImg dst, DImg src, int ext, int c_start, int nchunks, int vec_ok) {
-  const int chunk = blockIdx.x * 256 + threadIdx.x;
-  if (chunk >= nchunks) return;
-  const int r = (int)blockIdx.y - ext, c0 = c_start + kGrayChunk * chunk;
-  const int sr = MIRROR ? mirror_index(r, src.nr) : r;
-  const uint8_t* srow = src.row<uint8_t>(sr);
-  uint8_t* drow = dst.row<uint8_t>(r);
-  const int lo = MIRROR ? 0 : -ext, hi = MIRROR ? src.nc : src.nc + ext;  // source columns that map to themselves
-  if (c0 >= lo && c0 + kGrayChunk <= hi) {
-    uint32_t w[4 * CH];
-    // default cache policy: the CH loads of a lane (and of its neighbours) share cache lines; non-temporal loads measured 25 % slower
-    __builtin_memcpy(w, srow + (ptrdiff_t)c0 * CH, 16 * CH);   // CH (possibly unaligned) 16-B loads
-    uint32_t o[4];
+// 16 gray pixels from their 16 * CH source bytes (little-endian dwords).  The three channel bytes of a pixel are summed by
+// v_dot4_u32_u8 against a 0 / 1 byte mask (two chained dots where a pixel straddles a dword), the quotient (s * 21846) >> 16 is
+// exact for s <= 765 (3 * 21846 = 2^16 + 2: the excess 2 s / (3 * 2^16) < 1/3) and lands in byte 2 of a 24-bit product, so one
+// v_perm_b32 packs two quotients: 13 VALU instructions per 4 pixels against 35 for the extract / add / multiply / shift / or form
+// (the kernel has one resident round of waves whose loads all land together — the arithmetic that follows is not hidden).
+template <int CH> __device__ __forceinline__ void gray_chunk(const uint32_t* w, uint32_t* o) {
+  auto dot = [](uint32_t a, uint32_t mask, uint32_t acc) { return __builtin_amdgcn_udot4(a, mask, acc, false); };
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      uint32_t g[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int px = 4 * q + k;
-        g[k] = div3(byte_at(w, px * CH) + byte_at(w, px * CH + 1) + byte_at(w, px * CH + 2));
-      }
-      o[q] = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+  for (int q = 0; q < 4; q++) {
+    uint32_t s0, s1, s2, s3;
+    if constexpr (CH == 3) {
+      const uint32_t a = w[3 * q], b = w[3 * q + 1], c = w[3 * q + 2];
+      s0 = dot(a, 0x00010101u, 0u);
+      s1 = dot(a, 0x01000000u, dot(b, 0x00000101u, 0u));
+      s2 = dot(b, 0x01010000u, dot(c, 0x00000001u, 0u));
+      s3 = dot(c, 0x01010100u, 0u);
+    } else {
+      s0 = dot(w[4 * q], 0x00010101u, 0u); s1 = dot(w[4 * q + 1], 0x00010101u, 0u); s2 = dot(w[4 * q + 2], 0x00010101u, 0u); s3 = dot(w[4 * q + 3], 0x00010101u, 0u);
     }
-    if (vec_ok & 1) __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, (u32x4*)(drow + c0));
-    else {
-#pragma unroll
-      for (int k = 0; k < kGrayChunk; k++) drow[c0 + k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));
+    const uint32_t p0 = __umul24(s0, 21846u), p1 = __umul24(s1, 21846u), p2 = __umul24(s2, 21846u), p3 = __umul24(s3, 21846u);
+    o[q] = __builtin_amdgcn_perm(p1, p0, 0x0c0c0602u) | __builtin_amdgcn_perm(p3, p2, 0x06020c0cu);
+  }
+}
+
+// One lane = one 16-pixel chunk.  The chunks that lie entirely inside the source columns that map to themselves ("main": CH 16-byte
+// loads, one 16-byte store) are numbered densely over (row, chunk) — no idle lanes at row ends, no divergence in those waves; the
+// chunks that cross the left / right end of a row ("edge", 2 per row: mirrored / clipped columns, per-pixel form) are handled by
+// the FIRST blocks of the same launch, so that their dependent byte loads run under the main stream instead of after it.
+template <int CH, bool MIRROR>
+__global__ __launch_bounds__(256) void rgb_to_gray_kernel(DImg dst, DImg src, int ext, int c_start, int nchunks, int n_left, int n_main, int edge_blocks, int vec_ok) {
+  const int nrows_out = dst.nr + 2 * ext;
+  if ((int)blockIdx.x < edge_blocks) {
+    const int n_edge = nchunks - n_main, t = blockIdx.x * 256 + threadIdx.x;
+    const int row = t / n_edge, e = t - row * n_edge;
+    if (row >= nrows_out) return;
+    const int r = row - ext, c0 = c_start + kGrayChunk * (e < n_left ? e : e + n_main);
+    const uint8_t* srow = src.row<uint8_t>(MIRROR ? mirror_index(r, src.nr) : r);
+    uint8_t* drow = dst.row<uint8_t>(r);
+    for (int k = 0; k < kGrayChunk; k++) {
+      const int c = c0 + k;
+      if (c < -ext || c >= dst.nc + ext) continue;
+      const uint8_t* p = srow + (ptrdiff_t)(MIRROR ? mirror_index(c, src.nc) : c) * CH;
+      drow[c] = (uint8_t)div3((uint32_t)p[0] + p[1] + p[2]);
     }
     return;
   }
-  for (int k = 0; k < kGrayChunk; k++) {
-    const int c = c0 + k;
-    if (c < -ext || c >= dst.nc + ext) continue;
-    const uint8_t* p = srow + (ptrdiff_t)(MIRROR ? mirror_index(c, src.nc) : c) * CH;
-    drow[c] = (uint8_t)div3((uint32_t)p[0] + p[1] + p[2]);
+  const long long t = (long long)(blockIdx.x - edge_blocks) * 256 + threadIdx.x;
+  const int row = (int)(t / n_main), chunk = n_left + (int)(t - (long long)row * n_main);
+  if (row >= nrows_out) return;
+  const int r = row - ext, c0 = c_start + kGrayChunk * chunk;
+  const uint8_t* srow = src.row<uint8_t>(MIRROR ? mirror_index(r, src.nr) : r);
+  uint8_t* drow = dst.row<uint8_t>(r);
+  uint32_t w[4 * CH];
+  // default cache policy: the CH loads of a lane (and of its neighbours) share cache lines; non-temporal loads measured 25 % slower
+  __builtin_memcpy(w, srow + (ptrdiff_t)c0 * CH, 16 * CH);   // CH (possibly unaligned) 16-B loads
+  uint32_t o[4];
+  gray_chunk<CH>(w, o);
+  if (vec_ok & 1) __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, (u32x4*)(drow + c0));
+  else {
+#pragma unroll
+    for (int k = 0; k < kGrayChunk; k++) drow[c0 + k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));
   }
 }
 
@@ -114,15 +139,23 @@ extern "C" int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_d
   const int c_start = -((ext + kGrayChunk - 1) / kGrayChunk) * kGrayChunk;   // chunks are 16-B aligned relative to dst's first pixel
   const int nchunks = (dst->ncols + ext - c_start + kGrayChunk - 1) / kGrayChunk;
   const int dword_ok = aligned16(dst) ? 1 : 0;
-  dim3 grid((nchunks + 255) / 256, dst->nrows + 2 * ext);
+  // main chunks: c0 >= lo && c0 + 16 <= hi with [lo, hi) = the source columns that map to themselves
+  const int lo = mirror ? 0 : -ext, hi = mirror ? src->ncols : src->ncols + ext;
+  const int n_left = (lo - c_start + kGrayChunk - 1) / kGrayChunk;                                 // first chunk with c0 >= lo
+  const int n_main = std::max(0, std::min(nchunks, (hi - c_start) / kGrayChunk) - n_left);            // chunks [n_left, n_left + n_main)
+  const int nrows_out = dst->nrows + 2 * ext;
+  const int edge_blocks = (int)(((long long)nrows_out * (nchunks - n_main) + 255) / 256);
+  const long long main_blocks = ((long long)nrows_out * n_main + 255) / 256;
+  VPP_REQUIRE(edge_blocks + main_blocks < (1ll << 31), VPP_ERR_UNSUPPORTED, "vpp_rgb_to_graylevel: image too large for one launch");
+  const unsigned grid = (unsigned)(edge_blocks + main_blocks);
   hipStream_t st = as_stream(stream);
   DImg d = dimg(dst), s = dimg(src);
   if (src->channels == 3) {
-    if (mirror) rgb_to_gray_kernel<3, true><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, dword_ok);
-    else rgb_to_gray_kernel<3, false><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, dword_ok);
+    if (mirror) rgb_to_gray_kernel<3, true><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
+    else rgb_to_gray_kernel<3, false><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
   } else {
-    if (mirror) rgb_to_gray_kernel<4, true><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, dword_ok);
-    else rgb_to_gray_kernel<4, false><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, dword_ok);
+    if (mirror) rgb_to_gray_kernel<4, true><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
+    else rgb_to_gray_kernel<4, false><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
   }
   VPP_LAUNCH_CHECK();
   return VPP_OK;
