@@ -161,8 +161,13 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
 // every pixel of the wave's 16 rows without divergence, writes F = 0 rows (coalesced) and appends the survivors to a per-wave
 // LDS list (ballot + mbcnt prefix); phase 2 runs the ring test and the score on the list, 64 candidates per pass, so its lanes
 // are all busy; corners overwrite their F entry and set their bit in a per-wave LDS copy of the 16 bitmap words.
-template <bool REF>
-__global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int has_mask, int th, DImg F, uint64_t* __restrict__ bitmap, int ntc) {
+// MODE (what the selection that follows needs): VPP_FAST9_LOCAL_MAXIMA reads F around every corner, so F is written densely (zeros
+// included); RAW reads F at the corners only (no zero fill: 16.6 MB of 2-byte stores less on a 4K frame); BLOCKWISE needs neither F
+// nor the bitmap — a corner raises the key (score / 16) << 32 | ~position of its bs x bs block with one 64-bit atomic max in L2
+// (keys zeroed by a memset node before the launch), which is the reduction fast9_count_blocks_kernel did in a second pass over F.
+template <bool REF, int MODE>
+__global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int has_mask, int th, DImg F, uint64_t* __restrict__ bitmap, int ntc,
+                                                            unsigned long long* __restrict__ blkkey, uint32_t bs_magic, int nbc) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[LROWS * LP];
   __shared__ uint16_t cand[4][TH / 4 * TW];          // per wave: (row in the wave's band) * 64 + column
   __shared__ unsigned long long words[4][TH / 4];    // per wave: corner bitmap words of its 16 rows
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
   const int c = c0 + lane;
   const bool col_ok = c < A.nc;
   const int thc = min(max(th, 0), 255);
-  if (col_ok && ((blockIdx.y == 0 && wv == 0) || (r0 + TH >= A.nr && wv == 1))) {
+  if (MODE == VPP_FAST9_LOCAL_MAXIMA && col_ok && ((blockIdx.y == 0 && wv == 0) || (r0 + TH >= A.nr && wv == 1))) {
     uint16_t* fb = F.row<uint16_t>(wv == 0 ? -1 : A.nr);
     fb[c] = 0;
     if (c == 0) fb[-1] = 0;
@@ -203,10 +208,12 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
 #pragma unroll
       for (int i = 0; i < 16; i += 4) { const int x = p[ring_dr<REF>(i) * LP + ring_dc(i)]; qb = push_sign(qb, vhi - x); qd = push_sign(qd, x - vlo); }
       pass = ((qb & (qb - 1)) | (qd & (qd - 1))) != 0;
-      uint16_t* fr = F.row<uint16_t>(r);
-      fr[c] = 0;
-      if (c == 0) fr[-1] = 0;
-      if (c == A.nc - 1) fr[A.nc] = 0;
+      if (MODE == VPP_FAST9_LOCAL_MAXIMA) {
+        uint16_t* fr = F.row<uint16_t>(r);
+        fr[c] = 0;
+        if (c == 0) fr[-1] = 0;
+        if (c == A.nc - 1) fr[A.nc] = 0;
+      }
     }
     const unsigned long long m = __ballot(pass);
     if (pass) cand[wv][ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(j * TW + lane);
@@ -246,11 +253,20 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
         }
         const int over_sup = (int)(sdn + 16u * dnc - sx) >> 1, over_inf = (int)(sup + sx - 16u * upc) >> 1;
         const uint32_t f = (uint32_t)max(th * __popc(md) + over_sup, th * __popc(mb) + over_inf) + 1u;
-        F.row<uint16_t>(r0 + lr)[c0 + col] = (uint16_t)f;
-        atomicOr(&words[wv][j], 1ull << col);
+        if (MODE == VPP_FAST9_BLOCKWISE) {
+          const uint32_t s16 = (f - 1u) >> 4, r = (uint32_t)(r0 + lr), cc = (uint32_t)(c0 + col);   // stored(): score / 16, 0 never wins (fast.hpp:693,770-789)
+          if (s16) {
+            const uint32_t br = bs_magic ? __umulhi(r, bs_magic) : r, bc = bs_magic ? __umulhi(cc, bs_magic) : cc;
+            atomicMax(&blkkey[(size_t)br * nbc + bc], ((unsigned long long)s16 << 32) | (0xFFFFFFFFu - ((r << 16) | cc)));
+          }
+        } else {
+          F.row<uint16_t>(r0 + lr)[c0 + col] = (uint16_t)f;
+          atomicOr(&words[wv][j], 1ull << col);
+        }
       }
     }
   }
+  if (MODE == VPP_FAST9_BLOCKWISE) return;
   wave_fence_lds();
   if (lane < TH / 4) {
     const int r = r0 + wv * (TH / 4) + lane;
@@ -307,7 +323,13 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* tot) {
 }
 
 // Output offset of workgroup `nb` = sum of the per-workgroup counts before it.  Every write workgroup sums them itself (the
-// array is a few KB and sits in L2), which replaces a separate single-workgroup scan launch between the two passes.
+// array is a few KB and sits in L2), which replaces a separate single-workgroup scan launch between the two passes.  Measured
+// alternatives (round 2, 4K RAW, 2025 workgroups): "last workgroup to finish scans" behind one atomic ticket: +40 us (same-address
+// atomics); per-32-workgroup group sums by atomicAdd: count pass 5.0 -> 12.4 us, write pass unchanged — the re-summation is not
+// what the write pass waits for.
+__device__ __forceinline__ void publish_count(uint32_t* __restrict__ unit_count, uint32_t tot) {
+  if (threadIdx.x == 0) unit_count[blockIdx.x] = tot;
+}
 __device__ __forceinline__ uint32_t group_offset(const uint32_t* __restrict__ unit_count, int nb) {
   __shared__ uint32_t gsum[4];
   uint32_t s = 0;
@@ -356,7 +378,7 @@ __global__ __launch_bounds__(256) void fast9_count_segs_kernel(DImg F, uint16_t*
   }
   uint32_t tot;
   block_exscan((uint32_t)__popc(m), &tot);
-  if (threadIdx.x == 0) unit_count[blockIdx.x] = tot;
+  publish_count(unit_count, tot);
 }
 
 // pass 3, RAW / LOCAL_MAXIMA: ordered write
@@ -372,7 +394,7 @@ __global__ __launch_bounds__(256) void fast9_write_segs_kernel(DImg F, const uin
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = base + tot;
   if (!m) return;
   const int r = u / nsc, cbase = (u - r * nsc) * SEG;
-  const uint16_t* f0 = F.row<uint16_t>(r);
+  const uint16_t* f0 = F.row<uint16_t>(r);   // (both 16-byte halves of the segment loaded ahead of the loop measured slower: 12.5 vs 11.2 us)
   while (m) {
     const int c = cbase + __ffs(m) - 1;
     m &= m - 1;
@@ -427,7 +449,30 @@ __global__ __launch_bounds__(256) void fast9_count_blocks_kernel(DImg F, const u
   }
   uint32_t tot;
   block_exscan(has, &tot);
-  if (threadIdx.x == 0) unit_count[blockIdx.x] = tot;
+  publish_count(unit_count, tot);
+}
+
+// BLOCKWISE after the atomic-key detect: the units are the blocks themselves, 256 per workgroup
+__global__ __launch_bounds__(256) void fast9_count_keys_kernel(const unsigned long long* __restrict__ blkkey, int nblocks, uint32_t* __restrict__ unit_count) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  uint32_t tot;
+  block_exscan((b < nblocks && blkkey[b]) ? 1u : 0u, &tot);
+  publish_count(unit_count, tot);
+}
+__global__ __launch_bounds__(256) void fast9_write_keys_kernel(const unsigned long long* __restrict__ blkkey, int nblocks, const uint32_t* __restrict__ unit_count,
+                                                               uint32_t* __restrict__ total, int32_t* __restrict__ out_rc,
+                                                               int32_t* __restrict__ out_scores, int capacity) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long key = b < nblocks ? blkkey[b] : 0ull;
+  uint32_t tot;
+  const uint32_t base = group_offset(unit_count, blockIdx.x);
+  const uint32_t k = base + block_exscan(key ? 1u : 0u, &tot);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = base + tot;
+  if (key && (int)k < capacity) {
+    const uint32_t pos = 0xFFFFFFFFu - (uint32_t)key;
+    out_rc[2 * (size_t)k] = (int32_t)(pos >> 16); out_rc[2 * (size_t)k + 1] = (int32_t)(pos & 0xFFFFu);
+    if (out_scores) out_scores[k] = (int32_t)(key >> 32);
+  }
 }
 
 __global__ __launch_bounds__(256) void fast9_write_blocks_kernel(const uint2* __restrict__ blkres, int nblocks, int G,
@@ -561,7 +606,7 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   }
   hipStream_t st = as_stream(stream);
   const int nr = src->nrows, nc = src->ncols;
-  // scratch layout: [total][F: u16 map with border 1][bitmap: one u64 per 64-px row segment][blkres][unit_count]
+  // scratch layout: [header][F: u16 map with border 1][bitmap: one u64 per 64-px row segment][blkres / block keys][unit_count]
   int32_t fpitch; size_t fbytes, ffirst;
   vpp_image_layout(nr, nc, 2, 1, 16, &fpitch, &fbytes, &ffirst);
   const int ntc = (nc + TW - 1) / TW, nwords = nr * ntc;
@@ -589,13 +634,26 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   uint32_t* unit_count = (uint32_t*)(base + off_uc);
   DImg A = dimg(src), M = mask ? dimg(mask) : A;
   dim3 grid(ntc, (nr + TH - 1) / TH);
-  if (tuning("fast9.impl", 2) == 2) {  // 2 = two-phase (compacted candidates), 1 = one lane per pixel all the way
-    if (compat == VPP_FAST9_REFERENCE) fast9_detect2_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
-    else fast9_detect2_kernel<false><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
+  const int impl = tuning("fast9.impl", 2);   // 2 = two-phase (compacted candidates), 1 = one lane per pixel all the way
+  const bool keyed = impl == 2 && mode == VPP_FAST9_BLOCKWISE && tuning("fast9.block_keys", 1);
+  unsigned long long* blkkey = (unsigned long long*)blkres;
+  const uint32_t bs_magic = block_size >= 2 ? (uint32_t)((1ull << 32) / (unsigned)block_size) + 1u : 0u;   // x / bs = umulhi(x, magic), exact for x < 2^16
+  if (keyed) VPP_HIP_TRY(hipMemsetAsync(blkkey, 0, (size_t)nblocks * 8, st));
+  if (impl == 2) {
+#define VPP_FAST_DETECT2(R)                                                                                                                             \
+    if (keyed) fast9_detect2_kernel<R, VPP_FAST9_BLOCKWISE><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc);           \
+    else if (mode == VPP_FAST9_RAW) fast9_detect2_kernel<R, VPP_FAST9_RAW><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc); \
+    else fast9_detect2_kernel<R, VPP_FAST9_LOCAL_MAXIMA><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc);
+    if (compat == VPP_FAST9_REFERENCE) { VPP_FAST_DETECT2(true) } else { VPP_FAST_DETECT2(false) }
+#undef VPP_FAST_DETECT2
   } else if (compat == VPP_FAST9_REFERENCE) fast9_detect_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
   else fast9_detect_kernel<false><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
   VPP_LAUNCH_CHECK();
-  if (mode == VPP_FAST9_BLOCKWISE) {
+  if (keyed) {
+    const int ng = (nblocks + 255) / 256;   // <= ngroups (G <= 256): unit_count is large enough
+    fast9_count_keys_kernel<<<ng, 256, 0, st>>>(blkkey, nblocks, unit_count);
+    fast9_write_keys_kernel<<<ng, 256, 0, st>>>(blkkey, nblocks, unit_count, d_total, out_rc, out_scores, capacity);
+  } else if (mode == VPP_FAST9_BLOCKWISE) {
     fast9_count_blocks_kernel<<<ngroups, 256, 0, st>>>(F, bitmap, ntc, block_size, nbc, nblocks, RB, G, blkres, unit_count);
     fast9_write_blocks_kernel<<<ngroups, 256, 0, st>>>(blkres, nblocks, G, unit_count, d_total, out_rc, out_scores, capacity);
   } else if (mode == VPP_FAST9_RAW) {

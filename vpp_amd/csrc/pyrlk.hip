@@ -43,8 +43,11 @@ __device__ __forceinline__ void interp(const DImg& I, float p0, float p1, T* out
   // one 24-bit multiply-add (rows < 2^23, pitch < 2^23).
   const int es = (int)sizeof(T) * CH;
   const uint8_t* base = I.p0 - ((ptrdiff_t)I.border * I.pitch + (ptrdiff_t)I.border * es);
-  const uint32_t o00 = (uint32_t)(__mul24(r0 + I.border, I.pitch) + (c0 + I.border) * es), o10 = (uint32_t)(__mul24(r1 + I.border, I.pitch) + (c0 + I.border) * es);
-  const uint32_t o01 = (uint32_t)(__mul24(r0 + I.border, I.pitch) + (c1 + I.border) * es), o11 = (uint32_t)(__mul24(r1 + I.border, I.pitch) + (c1 + I.border) * es);
+  const uint32_t o00 = (uint32_t)(__mul24(r0 + I.border, I.pitch) + (c0 + I.border) * es);
+  // SAFE: r1 = r0 + 1 and c1 = c0 + 1 exactly — one add each instead of a second multiply-add (which the compiler cannot fold: 24-bit wrap)
+  const uint32_t o10 = SAFE ? o00 + (uint32_t)I.pitch : (uint32_t)(__mul24(r1 + I.border, I.pitch) + (c0 + I.border) * es);
+  const uint32_t o01 = SAFE ? o00 + (uint32_t)es : (uint32_t)(__mul24(r0 + I.border, I.pitch) + (c1 + I.border) * es);
+  const uint32_t o11 = SAFE ? o10 + (uint32_t)es : (uint32_t)(__mul24(r1 + I.border, I.pitch) + (c1 + I.border) * es);
   const float w00 = (1 - a0) * (1 - a1), w10 = a0 * (1 - a1), w01 = (1 - a0) * a1, w11 = a0 * a1;
   if constexpr (SAFE && sizeof(T) == 1 && CH == 1) {
     // the two taps of a row are adjacent bytes: one (unaligned) 16-bit load per row instead of two byte loads — the kernel
@@ -183,6 +186,11 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// lane k (0..3) of every quad, to all four lanes of the quad (v_mov_b32 dpp quad_perm)
+template <int K> __device__ __forceinline__ float quad_bcast(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), K * 0x55, 0xf, 0xf, false));
+}
+
 template <int WS, class GT, bool PYRLK, int LPK>
 __device__ Match lk_match_group(  // WS*WS <= 64
     float p0, float p1, float tr0, float tr1, const DImg& A_, const DImg& B_, const DImg& Ag_, float min_ev_th,
@@ -238,24 +246,25 @@ __device__ Match lk_match_group(  // WS*WS <= 64
   }
   const bool all_valid = mask == ((1ull << N) - 1ull);
   wave_lds_fence();
-  float G00 = 0, G01 = 0, G10 = 0, G11 = 0;
+  // Every sum over the window is the reference's left-to-right float chain, so it cannot be split — but the independent chains can
+  // sit on different lanes of the group (all lanes of a group would otherwise repeat all of them): lane gl & 3 = 0 / 1 / 2 accumulates
+  // G00 / G01 (= G10, the same products in the same order) / G11, and the quad broadcasts them over DPP.
+  float G00, G01, G10, G11;
   int cpt = 0;
-  if (all_valid) {  // the common case, branch-free
+  {
+    const int ia = (gl & 3) == 2 ? 1 : 0, ib = (gl & 3) == 0 ? 0 : 1;   // (gx, gx), (gx, gy), (gy, gy), (gx, gy)
+    float acc = 0.f;
+    if (all_valid) {  // the common case, branch-free
 #pragma unroll
-    for (int i = 0; i < N; i++) {  // lk.hh:56-72 in offset order
-      const float gx = lds[2 * i], gy = lds[2 * i + 1];
-      G00 += gx * gx; G01 += gx * gy; G10 += gx * gy; G11 += gy * gy;
-    }
-    cpt = N;
-  } else {
+      for (int i = 0; i < N; i++) acc += lds[2 * i + ia] * lds[2 * i + ib];   // lk.hh:56-72 in offset order
+      cpt = N;
+    } else {
 #pragma unroll 1
-    for (int i = 0; i < N; i++) {
-      if ((mask >> i) & 1ull) {
-        const float gx = lds[2 * i], gy = lds[2 * i + 1];
-        G00 += gx * gx; G01 += gx * gy; G10 += gx * gy; G11 += gy * gy;
-        cpt++;
+      for (int i = 0; i < N; i++) {
+        if ((mask >> i) & 1ull) { acc += lds[2 * i + ia] * lds[2 * i + ib]; cpt++; }
       }
     }
+    G00 = quad_bcast<0>(acc); G01 = quad_bcast<1>(acc); G11 = quad_bcast<2>(acc); G10 = G01;
   }
   {
     const float fc = (float)cpt;
@@ -306,14 +315,18 @@ __device__ Match lk_match_group(  // WS*WS <= 64
       }
     }
     wave_lds_fence();
-    float bk0 = 0.f, bk1 = 0.f;
-    if (all_valid) {
+    float bk0, bk1;
+    {
+      float acc = 0.f;   // even lanes: bk[0], odd lanes: bk[1]
+      if (all_valid) {
 #pragma unroll
-      for (int i = 0; i < N; i++) { bk0 += lds[2 * i]; bk1 += lds[2 * i + 1]; }
-    } else {
+        for (int i = 0; i < N; i++) acc += lds[2 * i + (gl & 1)];
+      } else {
 #pragma unroll 1
-      for (int i = 0; i < N; i++)
-        if ((mask >> i) & 1ull) { bk0 += lds[2 * i]; bk1 += lds[2 * i + 1]; }
+        for (int i = 0; i < N; i++)
+          if ((mask >> i) & 1ull) acc += lds[2 * i + (gl & 1)];
+      }
+      bk0 = quad_bcast<0>(acc); bk1 = quad_bcast<1>(acc);
     }
     nk0 = I00 * bk0 + I01 * bk1;  // lk.hh:137
     nk1 = I10 * bk0 + I11 * bk1;
@@ -346,19 +359,22 @@ __device__ Match lk_match_group(  // WS*WS <= 64
     }
   }
   wave_lds_fence();
-  float err = 0.f, stddev = 1.f;
-  if (PYRLK) {
-    float avg = 0.f;
-    stddev = 0.f;
+  float err, stddev = 1.f;
+  {
+    float acc = 0.f;   // even lanes: the sum of as[], odd lanes: the sum of |as - b|
 #pragma unroll
-    for (int i = 0; i < N; i++) avg += lds[2 * i];
-    avg /= N;
+    for (int i = 0; i < N; i++) acc += lds[2 * i + (gl & 1)];
+    cpt += N;
+    err = quad_bcast<1>(acc);
+    if (PYRLK) {
+      float avg = quad_bcast<0>(acc);
+      stddev = 0.f;
+      avg /= N;
 #pragma unroll
-    for (int i = 0; i < N; i++) stddev += fabsf(avg - lds[2 * i]);
-    stddev /= N;
+      for (int i = 0; i < N; i++) stddev += fabsf(avg - lds[2 * i]);
+      stddev /= N;
+    }
   }
-#pragma unroll
-  for (int i = 0; i < N; i++) { err += lds[2 * i + 1]; cpt++; }
   if (PYRLK) return Match{v0 - p0, v1 - p1, err / (cpt * stddev)};
   return Match{v0 - p0, v1 - p1, err / (cpt)};
 }
