@@ -87,6 +87,74 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(DImg next, DImg prev) {
   }
 }
 
+// ---- float x 2 pixels (the gradient pyramid of pyrLK: vfloat2 Scharr responses) ------------------------------------------------
+// The generic kernel above spends five 4-byte loads per H value at a 16-byte lane stride.  Here a lane owns one output pixel and the
+// input pair (2c, 2c + 1) under it — ONE 16-byte load per input row through a buffer descriptor over prev's addressable bytes — and
+// takes pixels 2c - 2, 2c - 1 from lane - 1 and pixel 2c + 2 from lane + 1 over DPP (lanes 0 and 63 of a wave are halo lanes: 62
+// outputs per wave), so every input pixel is loaded once per row block.  Arithmetic is tap5<float, float> on the same values in the
+// same order as the generic kernel (bit-identical); the march down TH rows and the fused border copies are the same as there.
+constexpr int kF2Out = 62;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float dpp_left(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true)); }   // lane i <- lane i - 1
+__device__ __forceinline__ float dpp_right(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true)); }  // lane i <- lane i + 1
+
+template <int TH, bool FUSE>
+__global__ __launch_bounds__(256) void pyr_down_f32x2_kernel(DImg next, DImg prev, uint32_t pbytes, int nstrips) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int s = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv);
+  if (s >= nstrips) return;
+  const int c = s * kF2Out - 1 + lane;   // output column of this lane (lanes 0 / 63: halo only)
+  const int r0 = blockIdx.y * TH;
+  const bool writer = lane >= 1 && lane <= kF2Out && c < next.nc;
+  const bool col_ok = 2 * c < prev.nc;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(prev.p0 - (ptrdiff_t)prev.border * prev.pitch - (ptrdiff_t)prev.border * 8), 0, pbytes, 0x00020000);
+  // byte offset of pixel 2c inside a row of the addressable area; out-of-range lanes (past the last addressable pixel) read 0, their
+  // values reach only outputs that are 0 by definition (col_ok false) or not stored
+  const uint32_t vo = (uint32_t)((2 * c + prev.border) * 8);
+  // all 2 TH + 3 input rows of the block are requested before anything is computed or stored (the stores may alias the loads as
+  // far as the compiler knows, so a load-per-iteration march waits one memory round trip per output row: 5.6 us for a 5 MB level)
+  constexpr int NR = 2 * TH + 3;
+  f32x4 raw[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const int rr = mirror_row(2 * r0 - 2 + k, prev.nr);
+    raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (rr + prev.border) * prev.pitch, 0));
+  }
+  float hx[NR], hy[NR];   // H pass of every loaded row at this lane's column, both components
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const f32x4 v = raw[k];
+    const float ax = dpp_left(v.x), ay = dpp_left(v.y), bx = dpp_left(v.z), by = dpp_left(v.w), ex = dpp_right(v.x), ey = dpp_right(v.y);
+    hx[k] = tap5<float, float>(ax, bx, v.x, v.z, ex);
+    hy[k] = tap5<float, float>(ay, by, v.y, v.w, ey);
+  }
+#pragma unroll
+  for (int j = 0; j < TH; j++) {
+    const int r = r0 + j;
+    if (r >= next.nr) break;
+    float vx = 0.f, vy = 0.f;
+    if (col_ok && 2 * r < prev.nr) {
+      vx = tap5<float, float>(hx[2 * j], hx[2 * j + 1], hx[2 * j + 2], hx[2 * j + 3], hx[2 * j + 4]);
+      vy = tap5<float, float>(hy[2 * j], hy[2 * j + 1], hy[2 * j + 2], hy[2 * j + 3], hy[2 * j + 4]);
+    }
+    if (!writer) continue;
+    const float2 v = make_float2(vx, vy);
+    next.row<float2>(r)[c] = v;
+    if (FUSE) {  // the mirrored copies of this pixel in next's border, as in pyr_down_kernel
+      const int b = next.border;
+      const int mr = r < b ? -r - 1 : (r >= next.nr - b ? 2 * next.nr - r - 1 : r);
+      const int mr2 = (r < b && r >= next.nr - b) ? 2 * next.nr - r - 1 : mr;
+      const int mc = c < b ? -c - 1 : (c >= next.nc - b ? 2 * next.nc - c - 1 : c);
+      const int mc2 = (c < b && c >= next.nc - b) ? 2 * next.nc - c - 1 : mc;
+      if (mc != c) next.row<float2>(r)[mc] = v;
+      if (mc2 != mc) next.row<float2>(r)[mc2] = v;
+      if (mr != r) { next.row<float2>(mr)[c] = v; if (mc != c) next.row<float2>(mr)[mc] = v; if (mc2 != mc) next.row<float2>(mr)[mc2] = v; }
+      if (mr2 != mr) { next.row<float2>(mr2)[c] = v; if (mc != c) next.row<float2>(mr2)[mc] = v; if (mc2 != mc) next.row<float2>(mr2)[mc2] = v; }
+    }
+  }
+}
+
 template <class T, class S>
 __global__ __launch_bounds__(256) void lowpass_kernel(DImg out, DImg in) {
   const int ch = in.ch;
@@ -125,6 +193,17 @@ int vpp_pyr_down(const vpp_image_desc* next, const vpp_image_desc* prev, void* s
   const bool fuse = next->border <= next->nrows && next->border <= next->ncols && tuning("pyr.fuse_border", 1);
   const bool tall = tuning("pyr.rows", (long long)next->nrows * next->ncols >= (1 << 20) ? 8 : 4) == 8;  // enough waves either way
   DImg n = dimg(next), p = dimg(prev);
+  const size_t paddr = (size_t)(prev->nrows + 2 * prev->border) * prev->pitch;   // rows -border .. nrows + border - 1 of the pitch
+  if (prev->dtype == VPP_F32 && prev->channels == 2 && paddr < ((size_t)1 << 31) && prev->pitch % 8 == 0 && ((uintptr_t)prev->first_pixel & 7) == 0 &&
+      ((uintptr_t)next->first_pixel & 7) == 0 && next->pitch % 8 == 0 && tuning("pyr.f2", 1)) {
+    const uint32_t pbytes = (uint32_t)((size_t)(prev->nrows + 2 * prev->border - 1) * prev->pitch + (size_t)(prev->ncols + 2 * prev->border) * 8);
+    const int nstrips = (next->ncols + kF2Out - 1) / kF2Out;
+    const dim3 grid((nstrips + 3) / 4, (next->nrows + 3) / 4);   // 4 rows per wave at every size (measured 4K level 1: 8 rows 20.1 us / 88 VGPRs, 4 rows 15 us / 48)
+    if (fuse) pyr_down_f32x2_kernel<4, true><<<grid, 256, 0, st>>>(n, p, pbytes, nstrips);
+    else pyr_down_f32x2_kernel<4, false><<<grid, 256, 0, st>>>(n, p, pbytes, nstrips);
+    VPP_LAUNCH_CHECK();
+    return fuse ? (int)VPP_OK : launch_fill_border(next, VPP_BORDER_MIRROR, nullptr, st);
+  }
   int rc = by_dtype(prev->dtype, [&](auto t) {
     typedef decltype(t) T; typedef typename Promo<T>::type S;
     if (fuse) {
