@@ -35,6 +35,29 @@ def test_pyr_down_matches_oracle(lib, orc, shape, dtype, ch, border):
     np.testing.assert_array_equal(got.view(with_border=True).view(np.uint8), want.view(with_border=True).view(np.uint8))
 
 
+@pytest.mark.parametrize("shape", [(2, 2), (3, 5), (9, 121), (9, 123), (9, 125), (130, 250), (77, 1000)])
+@pytest.mark.parametrize("border", [2, 3, 6])
+def test_pyr_down_float2_kernel_matches_oracle_and_generic(lib, orc, shape, border):
+    """vfloat2 levels (the gradient pyramid) take the 62-outputs-per-wave kernel: widths around the strip boundary (next.nc = 61, 62,
+    63), levels smaller than the border (no fused border copies), one-strip and many-strip rows; bit-identical to the oracle and to
+    the generic kernel, border included."""
+    prev = rand_image(*shape, vi.F32, 2, border=border, seed=17)
+    orc.orc_fill_border(P(prev.desc), 0, None)
+    want = HostImage(1 + shape[0] // 2, 1 + shape[1] // 2, vi.F32, 2, border)
+    assert orc.orc_pyr_down(P(want.desc), P(prev.desc)) == 0
+    dprev = DeviceImage.from_host(prev)
+    try:
+        for f2 in (1, 0):
+            lib.vpp_set_tuning(b"pyr.f2", f2)
+            dnext = DeviceImage.from_host(want.like())
+            capi.check(lib.vpp_pyr_down(P(dnext.desc), P(dprev.desc), capi.stream_ptr()))
+            _sync(lib)
+            got = dnext.download()
+            np.testing.assert_array_equal(got.view(with_border=True).view(np.uint8), want.view(with_border=True).view(np.uint8))
+    finally:
+        lib.vpp_set_tuning(b"pyr.f2", -1)
+
+
 def test_lowpass5_matches_oracle(lib, orc):
     for dtype, ch in [(vi.U8, 3), (vi.F32, 1)]:
         src = rand_image(50, 70, dtype, ch, border=2, seed=8)
@@ -133,6 +156,30 @@ def test_fast9_mask_matches_oracle(lib, orc, mval):
         got_rc, got_sc = gpu_detect(lib, DeviceImage.from_host(im), 10, mask=DeviceImage.from_host(mask), mode=mode, bs=10)
         np.testing.assert_array_equal(got_rc, want_rc)
         np.testing.assert_array_equal(got_sc, want_sc)
+
+
+def test_fast9_blockwise_keys_equal_the_two_pass_selection(lib):
+    """BLOCKWISE: the default path (one 64-bit atomic max per corner into its block's key, inside the detect kernel) and the two-pass
+    selection over the score map return the same list — block sizes that do and do not divide the 64-px tiles, bs = 1, a mask."""
+    im = u8_image(rects_image(333, 517, seed=9), border=3)
+    im.view(with_border=True)[..., 0] = np.pad(im.view()[..., 0], 3, mode="symmetric")
+    d = DeviceImage.from_host(im)
+    mask = HostImage(333, 517, vi.U8, 1, border=10)
+    mask.view()[...] = 255
+    mask.view()[100:200, 50:400] = 0
+    dm = DeviceImage.from_host(mask)
+    try:
+        for bs in (1, 3, 10, 16, 64, 100, 1000):
+            for m in (None, dm):
+                outs = []
+                for keys in (1, 0):
+                    lib.vpp_set_tuning(b"fast9.block_keys", keys)
+                    outs.append(gpu_detect(lib, d, 15, mask=m, mode=2, bs=bs, compat=1))
+                assert len(outs[0][0]) > 0
+                np.testing.assert_array_equal(outs[0][0], outs[1][0])
+                np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    finally:
+        lib.vpp_set_tuning(b"fast9.block_keys", -1)
 
 
 def test_fast9_4k_all_modes(lib, orc):

@@ -136,6 +136,27 @@ def test_box_32bit_streamed_windows_match_oracle(lib, orc, dtype, R, C):
         np.testing.assert_array_equal(ddst.download().raw.view(np.uint8), want.raw.view(np.uint8))
 
 
+@pytest.mark.parametrize("dtype", [vi.I32, vi.F32])
+def test_box_32bit_row_bands_match_oracle(lib, orc, dtype):
+    """Sources of 2 GiB and more leave the 32-bit kernel as row bands (one buffer descriptor addresses < 4 GiB); forced here on a
+    small image: bands of 8 and of 2 rows, ragged last band, every window the streaming kernel serves."""
+    lo, hi = (0, 999) if dtype != vi.F32 else (None, None)
+    src = rand_image(45, 300, dtype, 1, border=3, seed=21, lo=lo, hi=hi, align=16, fill_border=True)
+    dsrc = DeviceImage.from_host(src)
+    try:
+        for band in (8, 2):
+            lib.vpp_set_tuning(b"box.band_rows32", band)
+            for R, C in ((5, 5), (3, 3), (7, 5)):
+                want = src.like(border=0)
+                assert orc.orc_box_filter(P(want.desc), P(src.desc), R, C) == 0
+                ddst = DeviceImage.from_host(src.like(border=0))
+                capi.check(lib.vpp_box_filter(P(ddst.desc), P(dsrc.desc), R, C, capi.stream_ptr()))
+                _sync(lib)
+                np.testing.assert_array_equal(ddst.download().raw.view(np.uint8), want.raw.view(np.uint8))
+    finally:
+        lib.vpp_set_tuning(b"box.band_rows32", -1)
+
+
 def test_box_u8_windows_4k_streamed_equal_generic(lib):
     """BASELINE frame size: the streamed 3x3 / 7x7 / 5x3 results equal the generic kernel's, and one pixel equals the numpy mean."""
     src = rand_image(2160, 3840, vi.U8, 3, border=3, seed=12, fill_border=True)

@@ -578,7 +578,9 @@ template <class T, int KR = 5, int KC = 5> int launch_w32(const vpp_image_desc* 
     // one buffer descriptor addresses < 4 GiB: larger sources go out as row bands (a band's upper / lower neighbours are real rows of
     // the same image, its descriptor simply ends 'border' rows below the band)
     const size_t row_tail = 16 + (size_t)((((dst->ncols + src->border) * 4) + 15) & ~15);
-    const int band_max = (int)std::min<size_t>((size_t)dst->nrows, std::max<size_t>(RW, (((size_t)1 << 31) / (size_t)src->pitch) / RW * RW));
+    const int band_tune = tuning("box.band_rows32", 0);   // tests: force small bands
+    const int band_max = band_tune > 0 ? std::max(RW, band_tune / RW * RW)
+                                       : (int)std::min<size_t>((size_t)dst->nrows, std::max<size_t>(RW, (((size_t)1 << 31) / (size_t)src->pitch) / RW * RW));
     for (int b0 = 0; b0 < dst->nrows; b0 += band_max) {
       const int band = std::min(band_max, dst->nrows - b0), nblk_y = (band + RW - 1) / RW;
       const uint32_t sbytes = (uint32_t)((size_t)(band - 1 + 2 * src->border) * src->pitch + row_tail);
