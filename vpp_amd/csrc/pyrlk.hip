@@ -186,6 +186,15 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+constexpr int kLkRecords = 16 * 3;   // per group, after its NS term pairs: 8 row + 8 column coordinate records of 3 dwords
+// dwords between the LDS blocks of two groups of a wave: the term reads are broadcasts inside a group (every lane sums every term), so
+// the 64 / LPK groups must sit on different banks — stride = LPK (mod 64).  (The unpadded 160-dword blocks of the 8-lane groups put four
+// groups on each of two bank sets: every term read of the 400 k-keypoint case went 4-way serialised, 2.6 -> 5.2 ms.)
+__host__ __device__ constexpr int lk_group_stride(int ns, int lpk) {
+  int g = ns * 2 + kLkRecords;
+  while (lpk < 64 && g % 64 != lpk) g++;
+  return g;
+}
 // lane k (0..3) of every quad, to all four lanes of the quad (v_mov_b32 dpp quad_perm)
 template <int K> __device__ __forceinline__ float quad_bcast(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), K * 0x55, 0xf, 0xf, false));
@@ -195,7 +204,7 @@ template <int WS, class GT, bool PYRLK, int LPK>
 __device__ Match lk_match_group(  // WS*WS <= 64
     float p0, float p1, float tr0, float tr1, const DImg& A_, const DImg& B_, const DImg& Ag_, float min_ev_th,
                                 int max_it, float delta, float* lds, int gl, float norm_T) {
-  constexpr int hws = WS / 2, N = WS * WS, PPL = (N + LPK - 1) / LPK;
+  constexpr int hws = WS / 2, N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
   // the level's descriptors by value: the callers index a kernel-argument array with the (runtime) level, and through the
   // references every use inside the iteration loop was a fresh scalar load + wait
   const DImg A = A_, B = B_, Ag = Ag_;
@@ -203,20 +212,25 @@ __device__ Match lk_match_group(  // WS*WS <= 64
   float gs0[PPL], gs1[PPL];
   int as[PPL];
   unsigned long long mine = 0;  // validity bits of this lane's offsets
-  float off_r[PPL], off_c[PPL];  // this lane's window offsets (a lane past the window repeats the window's last offset)
+  // this lane's window offsets as (row, column) of the window (a lane past the window repeats the window's last offset); kept as the
+  // dword index of the tap's row / column record in the group's coordinate records (see the iteration), the float offsets of the
+  // per-tap form are derived where that form is used (once per level, and on the rare unsafe paths)
+  int rec_r[PPL], rec_c[PPL];
 #pragma unroll
   for (int q = 0; q < PPL; q++) {
     const int i = gl + q * LPK, ii = i < N ? i : N - 1;
-    off_r[q] = (float)(ii / WS - hws); off_c[q] = (float)(ii % WS - hws);
+    rec_r[q] = 3 * (ii / WS); rec_c[q] = 3 * (8 + ii % WS);
   }
+  auto off_r = [&](int q) { return (float)(rec_r[q] / 3 - hws); };
+  auto off_c = [&](int q) { return (float)(rec_c[q] / 3 - 8 - hws); };
   if (a_safe) {  // every tap lies in the bordered area: request all rounds before using any (one round trip, no branch around the loads)
     GT g[PPL][2]; uint8_t a[PPL];
 #pragma unroll
-    for (int k = 0; k < PPL; k++) { interp<GT, 2, true>(Ag, p0 + off_r[k], p1 + off_c[k], g[k]); interp<uint8_t, 1, true>(A, p0 + off_r[k], p1 + off_c[k], &a[k]); }
+    for (int k = 0; k < PPL; k++) { interp<GT, 2, true>(Ag, p0 + off_r(k), p1 + off_c(k), g[k]); interp<uint8_t, 1, true>(A, p0 + off_r(k), p1 + off_c(k), &a[k]); }
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
       const int i = gl + k * LPK;
-      const bool ok = i < N && A.has((int)(p0 + off_r[k]), (int)(p1 + off_c[k]));
+      const bool ok = i < N && A.has((int)(p0 + off_r(k)), (int)(p1 + off_c(k)));
       gs0[k] = ok ? (float)g[k][0] : 0.f; gs1[k] = ok ? (float)g[k][1] : 0.f; as[k] = ok ? (int)a[k] : 0;
       if (ok) mine |= 1ull << i;
       lds[2 * i] = gs0[k]; lds[2 * i + 1] = gs1[k];
@@ -227,7 +241,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
       const int i = gl + k * LPK;
       gs0[k] = 0.f; gs1[k] = 0.f; as[k] = 0;
       if (i < N) {
-        const float n0 = p0 + off_r[k], n1 = p1 + off_c[k];
+        const float n0 = p0 + off_r(k), n1 = p1 + off_c(k);
         if (A.has((int)n0, (int)n1)) {
           GT g[2]; uint8_t a;
           interp<GT, 2, false>(Ag, n0, n1, g); interp<uint8_t, 1, false>(A, n0, n1, &a);
@@ -290,14 +304,58 @@ __device__ Match lk_match_group(  // WS*WS <= 64
       // The common case without a branch around the loads: all PPL rounds of taps are requested back to back and the lane pays
       // ONE memory round trip per iteration instead of PPL dependent ones (a lane past the window samples the window's last
       // offset and stages a term nobody reads).
-      uint8_t b[PPL];
+      if constexpr (LPK >= 16) {
+        // The coordinate part of linear_interpolate (imageNd.hpp:282-290) depends on the tap's row OR its column only: the WS row
+        // records {a0, 1 - a0, byte offset of row x0} and the WS column records {a1, 1 - a1, x1} are evaluated once per group (one
+        // record per lane, the same float operations on the same inputs as the per-tap form) and every tap reads its two records from
+        // LDS: 1 address add per tap instead of 13 VALU operations (adds, conversions, fractions, the row multiply).
+        float* xl = lds + 2 * NS;
 #pragma unroll
-      for (int q = 0; q < PPL; q++) interp<uint8_t, 1, true>(B, v0 + off_r[q], v1 + off_c[q], &b[q]);
+        for (int t = 0; t < (LPK >= 16 ? 1 : 16 / LPK); t++) {
+          const int rec = gl + t * LPK;
+          if (rec < 16) {
+            const bool isrow = rec < 8;
+            const int k = (rec & 7) < WS ? (rec & 7) : WS - 1;
+            const float nn = (isrow ? v0 : v1) + (float)(k - hws);
+            const int x = (int)nn;
+            const float a = nn - x;
+            xl[3 * rec] = a; xl[3 * rec + 1] = 1 - a;
+            ((int*)xl)[3 * rec + 2] = isrow ? __mul24(x + B.border, B.pitch) : x + B.border;
+          }
+        }
+        wave_lds_fence();
+        const uint8_t* bbase = B.p0 - ((ptrdiff_t)B.border * B.pitch + (ptrdiff_t)B.border);
+        uint16_t t0[PPL], t1[PPL];
 #pragma unroll
-      for (int q = 0; q < PPL; q++) {
-        const int i = gl + q * LPK;
-        const float dt = (float)as[q] - (float)b[q];  // lk.hh:130
-        lds[2 * i] = gs0[q] * dt; lds[2 * i + 1] = gs1[q] * dt;
+        for (int q = 0; q < PPL; q++) {   // all taps requested first: one memory round trip per iteration
+          const uint32_t o00 = (uint32_t)(((const int*)xl)[rec_r[q] + 2] + ((const int*)xl)[rec_c[q] + 2]), o10 = o00 + (uint32_t)B.pitch;
+          __builtin_memcpy(&t0[q], bbase + o00, 2);
+          __builtin_memcpy(&t1[q], bbase + o10, 2);
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; q++) {
+          const int i = gl + q * LPK;
+          const float* rr = xl + rec_r[q];   // the fractions are read where they are used: LDS reads cost no VALU issue and keep 4 PPL registers free
+          const float* cc = xl + rec_c[q];
+          const float a0 = rr[0], m0 = rr[1], a1 = cc[0], m1 = cc[1];
+          const float v = (m0 * m1) * (float)(uint8_t)(t0[q] & 255) + (a0 * m1) * (float)(uint8_t)(t1[q] & 255) + (m0 * a1) * (float)(uint8_t)(t0[q] >> 8) +
+                          (a0 * a1) * (float)(uint8_t)(t1[q] >> 8);
+          const uint8_t b = (uint8_t)v;
+          const float dt = (float)as[q] - (float)b;  // lk.hh:130
+          lds[2 * i] = gs0[q] * dt; lds[2 * i + 1] = gs1[q] * dt;
+        }
+      } else {
+        // 7 taps per lane (LPK = 8): the wave's LDS pipe is as busy as its VALU with the 49 broadcast term reads alone, the record reads
+        // on top made the 400 k-keypoint case slower (2.63 -> 2.98 ms): per-tap coordinates here
+        uint8_t b[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; q++) interp<uint8_t, 1, true>(B, v0 + off_r(q), v1 + off_c(q), &b[q]);
+#pragma unroll
+        for (int q = 0; q < PPL; q++) {
+          const int i = gl + q * LPK;
+          const float dt = (float)as[q] - (float)b[q];  // lk.hh:130
+          lds[2 * i] = gs0[q] * dt; lds[2 * i + 1] = gs1[q] * dt;
+        }
       }
     } else {
 #pragma unroll
@@ -306,8 +364,8 @@ __device__ Match lk_match_group(  // WS*WS <= 64
         float t0 = 0.f, t1 = 0.f;
         if (i < N && (all_valid || ((mine >> i) & 1ull))) {
           uint8_t b;
-          if (b_safe) interp<uint8_t, 1, true>(B, v0 + off_r[q], v1 + off_c[q], &b);
-          else interp<uint8_t, 1, false>(B, v0 + off_r[q], v1 + off_c[q], &b);
+          if (b_safe) interp<uint8_t, 1, true>(B, v0 + off_r(q), v1 + off_c(q), &b);
+          else interp<uint8_t, 1, false>(B, v0 + off_r(q), v1 + off_c(q), &b);
           const float dt = (float)as[q] - (float)b;  // lk.hh:130
           t0 = gs0[q] * dt; t1 = gs1[q] * dt;
         }
@@ -339,7 +397,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
   if (b_safe) {
     uint8_t b[PPL];
 #pragma unroll
-    for (int q = 0; q < PPL; q++) interp<uint8_t, 1, true>(B, v0 + off_r[q], v1 + off_c[q], &b[q]);
+    for (int q = 0; q < PPL; q++) interp<uint8_t, 1, true>(B, v0 + off_r(q), v1 + off_c(q), &b[q]);
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
       const int i = gl + q * LPK;
@@ -352,7 +410,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
       float e = 0.f;
       if (i < N) {
         uint8_t b;
-        interp<uint8_t, 1, false>(B, v0 + off_r[q], v1 + off_c[q], &b);
+        interp<uint8_t, 1, false>(B, v0 + off_r(q), v1 + off_c(q), &b);
         e = fabsf((float)(as[q] - (int)b));
       }
       lds[2 * i] = (float)as[q]; lds[2 * i + 1] = e;
@@ -379,16 +437,17 @@ __device__ Match lk_match_group(  // WS*WS <= 64
   return Match{v0 - p0, v1 - p1, err / (cpt)};
 }
 
+// at least 4 waves per SIMD (<= 128 VGPRs): left alone, the 7-taps-per-lane instance took 138-163 registers for no gain in issue rate
 template <int WS, int LPK>
-__global__ __launch_bounds__(64) void pyrlk_match_group_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, vpp_keypoint_f32* __restrict__ kps, int n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pyrlk_match_group_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, vpp_keypoint_f32* __restrict__ kps, int n,
                                                                float min_ev, float max_err, int max_it, float delta, int min_scale,
                                                                float* __restrict__ out_dist) {
   constexpr int N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
-  __shared__ float smem[(64 / LPK) * NS * 2];
+  __shared__ float smem[(64 / LPK) * lk_group_stride(NS, LPK)];
   const int gl = threadIdx.x % LPK, grp = threadIdx.x / LPK;
   const int i = blockIdx.x * (64 / LPK) + grp;
   if (i >= n) return;
-  float* lds = smem + grp * NS * 2;
+  float* lds = smem + grp * lk_group_stride(NS, LPK);
   vpp_keypoint_f32 kp = kps[i];
   if (!(kp.age > 0)) { if (out_dist && gl == 0) out_dist[i] = 0.f; return; }
   float tr0 = 0.f, tr1 = 0.f, dist = 0.f;
@@ -409,15 +468,15 @@ __global__ __launch_bounds__(64) void pyrlk_match_group_kernel(Pyr P, Pyr G, Pyr
 }
 
 template <int WS, int LPK>
-__global__ __launch_bounds__(64) void lucas_kanade_group_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, const float* __restrict__ pts,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lucas_kanade_group_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, const float* __restrict__ pts,
                                                                 const float* __restrict__ pred, int n, float min_ev, int niter, float delta,
                                                                 float* __restrict__ out_flow, float* __restrict__ out_dist) {
   constexpr int N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
-  __shared__ float smem[(64 / LPK) * NS * 2];
+  __shared__ float smem[(64 / LPK) * lk_group_stride(NS, LPK)];
   const int gl = threadIdx.x % LPK, grp = threadIdx.x / LPK;
   const int i = blockIdx.x * (64 / LPK) + grp;
   if (i >= n) return;
-  float* lds = smem + grp * NS * 2;
+  float* lds = smem + grp * lk_group_stride(NS, LPK);
   const float k0 = pts[2 * i], k1 = pts[2 * i + 1];
   const float d = (float)(1 << nlevels);
   float tr0 = (pred ? pred[2 * i] : 0.f) / d, tr1 = (pred ? pred[2 * i + 1] : 0.f) / d;
@@ -510,7 +569,7 @@ int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, cons
   hipStream_t st = as_stream(stream);
   // lanes per keypoint: enough waves to cover the 1024 SIMDs a few times over, no more (total work grows with LPK)
   int lpk = tuning("pyrlk.lpk", 0);
-  if (lpk == 0) lpk = n >= 20000 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));  // measured: tools/tune_pyrlk.py (LPK = 8 also beats 1 lane per keypoint at 400 k keypoints)
+  if (lpk == 0) lpk = n >= 80000 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));  // measured: tools/tune_pyrlk.py (round 2: 16 lanes win up to 40 k keypoints, 8 from 100 k; 8 also beats 1 lane per keypoint at 400 k)
   if (winsize > 7) lpk = 1;  // the group kernels keep a 64-bit validity mask (WS*WS <= 64); larger windows: one lane per keypoint
 #define VPP_LK_LAUNCH(W)                                                                                                                           \
   if (lpk == 64) pyrlk_match_group_kernel<W, 64><<<n, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
@@ -543,7 +602,7 @@ int vpp_lucas_kanade(const vpp_image_desc* prev, const vpp_image_desc* grad, con
   if (n == 0) return VPP_OK;
   hipStream_t st = as_stream(stream);
   int lpk = tuning("pyrlk.lpk", 0);
-  if (lpk == 0) lpk = n >= 20000 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));  // measured: tools/tune_pyrlk.py (LPK = 8 also beats 1 lane per keypoint at 400 k keypoints)
+  if (lpk == 0) lpk = n >= 80000 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));  // measured: tools/tune_pyrlk.py (round 2: 16 lanes win up to 40 k keypoints, 8 from 100 k; 8 also beats 1 lane per keypoint at 400 k)
   if (winsize > 7) lpk = 1;
   const float fev = (float)min_ev, fdelta = (float)delta;
 #define VPP_LK_LAUNCH(W)                                                                                                                           \
