@@ -1,4 +1,4 @@
-"""Launch a few box / add kernels (for rocprofv3 runs).  usage: run_kernels.py [box|add|all] [launches]"""
+"""Launch a few box / add kernels (for rocprofv3 runs).  usage: run_kernels.py [box|add|box32|all] [launches]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -22,4 +22,14 @@ if which in ("add", "all"):
     ns = 4
     A = [DeviceImage(NR, NC, vi.I32) for _ in range(ns)]; B = [DeviceImage.from_host(b_h) for _ in range(ns)]; C = [DeviceImage.from_host(b_h) for _ in range(ns)]
     for i in range(n): capi.check(lib.vpp_pixelwise_binary(0, P(A[i % ns].desc), P(B[i % ns].desc), P(C[i % ns].desc), st))
+    torch.cuda.synchronize()
+if which in ("box32", "all"):   # the reference benchmark's own element type (box_5x5_filter.cc) and the frame ingest
+    src_h = rand_image(NR, NC, vi.I32, 1, border=2, seed=3, align=16, lo=0, hi=999)
+    ns = 5
+    srcs = [DeviceImage.from_host(src_h) for _ in range(ns)]
+    dsts = [DeviceImage(NR, NC, vi.I32, 1, 0, 16) for _ in range(ns)]
+    for i in range(n): capi.check(lib.vpp_box_filter(P(dsts[i % ns].desc), P(srcs[i % ns].desc), 5, 5, st))
+    rgb_h = rand_image(NR, NC, vi.U8, 3, border=0, seed=6)
+    rgbs = [DeviceImage.from_host(rgb_h) for _ in range(8)]; grays = [DeviceImage(NR, NC, vi.U8, 1, 3, 32) for _ in range(8)]
+    for i in range(n): capi.check(lib.vpp_rgb_to_graylevel(P(grays[i % 8].desc), P(rgbs[i % 8].desc), 1, st))
     torch.cuda.synchronize()
