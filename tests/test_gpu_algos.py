@@ -182,6 +182,33 @@ def test_fast9_blockwise_keys_equal_the_two_pass_selection(lib):
         lib.vpp_set_tuning(b"fast9.block_keys", -1)
 
 
+def test_fast9_scratch_notes_state_machine(lib, orc):
+    """The blockwise path keeps a note with its scratch buffer (the block keys were left all-zero by the previous call's write pass, so
+    no memset is queued): a shuffled sequence of calls that changes image size, mode, block size and the keyed / two-pass form between
+    calls must match the oracle every time."""
+    rng = np.random.default_rng(5)
+    shapes = [(60, 90), (130, 257), (480, 640), (64, 64)]
+    ims, want = {}, {}
+    for sh in shapes:
+        im = u8_image(rects_image(*sh, seed=4 + sh[0]), border=3)
+        orc.orc_fill_border(P(im.desc), 0, None)
+        ims[sh] = (im, DeviceImage.from_host(im))
+    cases = [(sh, mode, bs) for sh in shapes for mode in (0, 1, 2) for bs in ((10, 7) if mode == 2 else (10,))]
+    try:
+        for step in range(60):
+            sh, mode, bs = cases[rng.integers(len(cases))]
+            onepass = int(rng.integers(4) != 0)
+            lib.vpp_set_tuning(b"fast9.block_keys", onepass)
+            key = (sh, mode, bs)
+            if key not in want:
+                want[key] = run_detect(orc, ims[sh][0], 20, mode=mode, bs=bs, compat=1, cap=400000)
+            got_rc, got_sc = gpu_detect(lib, ims[sh][1], 20, mode=mode, bs=bs, compat=1)
+            np.testing.assert_array_equal(got_rc, want[key][0], err_msg=f"step {step} {key} keys={onepass}")
+            np.testing.assert_array_equal(got_sc, want[key][1], err_msg=f"step {step} {key} keys={onepass}")
+    finally:
+        lib.vpp_set_tuning(b"fast9.block_keys", -1)
+
+
 def test_fast9_4k_all_modes(lib, orc):
     """BASELINE config 3: 2160x3840, th 20, raw / local-max / blockwise(10), reference and corrected rings."""
     im = u8_image(rects_image(2160, 3840, seed=4), border=3)

@@ -62,7 +62,9 @@ inline bool aligned16(const vpp_image_desc* d) { return ((uintptr_t)d->first_pix
 // also retires the buffers of destroyed streams.
 struct Scratch {
   static constexpr int kSlots = 8;
-  struct Slot { void* p = nullptr; size_t cap = 0; int dev = -1; hipStream_t st = nullptr; unsigned long long used = 0; };
+  // user[]: the owner's notes about what the buffer holds (e.g. "this region is zeroed"); cleared whenever the buffer is (re)allocated
+  struct Slot { void* p = nullptr; size_t cap = 0; int dev = -1; hipStream_t st = nullptr; unsigned long long used = 0; unsigned long long user[4] = {0, 0, 0, 0}; };
+  Slot* cur = nullptr;   // the slot of the last ensure()
   Slot slots[kSlots];
   unsigned long long tick = 0;
   void* p = nullptr;   // the buffer of the last ensure()
@@ -85,8 +87,9 @@ struct Scratch {
       if (s->p) { VPP_HIP_TRY(hipStreamSynchronize(st)); VPP_HIP_TRY(hipFree(s->p)); s->p = nullptr; s->cap = 0; }
       VPP_HIP_TRY(hipMalloc(&s->p, bytes));
       s->cap = bytes;
+      for (unsigned long long& u : s->user) u = 0;
     }
-    p = s->p;
+    p = s->p; cur = s;
     return VPP_OK;
   }
   static int release(Slot& c) {

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
 // MODE (what the selection that follows needs): VPP_FAST9_LOCAL_MAXIMA reads F around every corner, so F is written densely (zeros
 // included); RAW reads F at the corners only (no zero fill: 16.6 MB of 2-byte stores less on a 4K frame); BLOCKWISE needs neither F
 // nor the bitmap — a corner raises the key (score / 16) << 32 | ~position of its bs x bs block with one 64-bit atomic max in L2
-// (keys zeroed by a memset node before the launch), which is the reduction fast9_count_blocks_kernel did in a second pass over F.
+// (keys all-zero before the launch: zeroed by the write pass of the previous call, or by a memset node), which is the reduction fast9_count_blocks_kernel did in a second pass over F.
 template <bool REF, int MODE>
 __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int has_mask, int th, DImg F, uint64_t* __restrict__ bitmap, int ntc,
                                                             unsigned long long* __restrict__ blkkey, uint32_t bs_magic, int nbc) {
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void fast9_count_keys_kernel(const unsigned lo
   block_exscan((b < nblocks && blkkey[b]) ? 1u : 0u, &tot);
   publish_count(unit_count, tot);
 }
-__global__ __launch_bounds__(256) void fast9_write_keys_kernel(const unsigned long long* __restrict__ blkkey, int nblocks, const uint32_t* __restrict__ unit_count,
+__global__ __launch_bounds__(256) void fast9_write_keys_kernel(unsigned long long* __restrict__ blkkey, int nblocks, const uint32_t* __restrict__ unit_count,
                                                                uint32_t* __restrict__ total, int32_t* __restrict__ out_rc,
                                                                int32_t* __restrict__ out_scores, int capacity) {
   const int b = blockIdx.x * 256 + threadIdx.x;
@@ -468,6 +468,7 @@ __global__ __launch_bounds__(256) void fast9_write_keys_kernel(const unsigned lo
   const uint32_t base = group_offset(unit_count, blockIdx.x);
   const uint32_t k = base + block_exscan(key ? 1u : 0u, &tot);
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = base + tot;
+  if (key) blkkey[b] = 0ull;   // consumed: the next call finds the keys zeroed
   if (key && (int)k < capacity) {
     const uint32_t pos = 0xFFFFFFFFu - (uint32_t)key;
     out_rc[2 * (size_t)k] = (int32_t)(pos >> 16); out_rc[2 * (size_t)k + 1] = (int32_t)(pos & 0xFFFFu);
@@ -618,7 +619,10 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   const int RB = block_size < 256 ? (block_size > 0 ? block_size : 1) : 256, G = 256 / RB;   // BLOCKWISE: lanes per block, blocks per workgroup
   const int nsc = ntc * (TW / SEG), nsegs = nr * nsc;                                        // RAW / LOCAL: 16-px segments
   const int ngroups = mode == VPP_FAST9_BLOCKWISE ? (nblocks + G - 1) / G : (nsegs + 255) / 256;
-  const size_t off_f = 256, off_bm = off_f + align_up(fbytes, 256), off_br = off_bm + align_up((size_t)nwords * 8, 256);
+  const int impl = tuning("fast9.impl", 2);   // 2 = two-phase (compacted candidates), 1 = one lane per pixel all the way
+  const bool keyed = impl == 2 && mode == VPP_FAST9_BLOCKWISE && tuning("fast9.block_keys", 1);
+  const size_t off_f = 256;
+  const size_t off_bm = off_f + align_up(fbytes, 256), off_br = off_bm + align_up((size_t)nwords * 8, 256);
   const size_t off_uc = off_br + align_up((size_t)nblocks * 8, 256);
   const size_t total_bytes = off_uc + align_up((size_t)ngroups * 4, 256);
   int rc = g_scratch.ensure(total_bytes, st);
@@ -634,11 +638,16 @@ int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* ma
   uint32_t* unit_count = (uint32_t*)(base + off_uc);
   DImg A = dimg(src), M = mask ? dimg(mask) : A;
   dim3 grid(ntc, (nr + TH - 1) / TH);
-  const int impl = tuning("fast9.impl", 2);   // 2 = two-phase (compacted candidates), 1 = one lane per pixel all the way
-  const bool keyed = impl == 2 && mode == VPP_FAST9_BLOCKWISE && tuning("fast9.block_keys", 1);
   unsigned long long* blkkey = (unsigned long long*)blkres;
+  // a note kept with this scratch buffer (cleared when it is reallocated): user[0] = signature of the key area that the last keyed call
+  // left all-zero (fast9_write_keys_kernel zeroes every key it consumes, so back-to-back blockwise calls need no memset node); any other
+  // call may lay the buffer out differently and clears it
+  Scratch::Slot& sl = *g_scratch.cur;
+  const unsigned long long key_sig = keyed ? (((unsigned long long)off_br << 24) ^ (unsigned long long)nblocks) + 1ull : 0ull;
+  const bool keys_clean = keyed && sl.user[0] == key_sig;
+  sl.user[0] = key_sig;
   const uint32_t bs_magic = block_size >= 2 ? (uint32_t)((1ull << 32) / (unsigned)block_size) + 1u : 0u;   // x / bs = umulhi(x, magic), exact for x < 2^16
-  if (keyed) VPP_HIP_TRY(hipMemsetAsync(blkkey, 0, (size_t)nblocks * 8, st));
+  if (keyed && !keys_clean) VPP_HIP_TRY(hipMemsetAsync(blkkey, 0, (size_t)nblocks * 8, st));
   if (impl == 2) {
 #define VPP_FAST_DETECT2(R)                                                                                                                             \
     if (keyed) fast9_detect2_kernel<R, VPP_FAST9_BLOCKWISE><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc);           \
