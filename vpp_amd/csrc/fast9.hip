@@ -207,7 +207,11 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
       uint32_t qb = 0, qd = 0;
 #pragma unroll
       for (int i = 0; i < 16; i += 4) { const int x = p[ring_dr<REF>(i) * LP + ring_dc(i)]; qb = push_sign(qb, vhi - x); qd = push_sign(qd, x - vlo); }
-      pass = ((qb & (qb - 1)) | (qd & (qd - 1))) != 0;
+      // any 9 consecutive ring positions contain two cardinal samples that are NEIGHBOURS among {0, 4, 8, 12} (8 consecutive positions
+      // already hold exactly two multiples of 4, four apart): both must be on the same side.  Stricter than "any two of the four"
+      // (which lets every line through the centre pass: brighter at 0 and 8 only) and still necessary, so the result is unchanged.
+      const uint32_t ab = qb & ((qb >> 1) | (qb << 3)), ad = qd & ((qd >> 1) | (qd << 3));
+      pass = ((ab | ad) & 0xFu) != 0;
       if (MODE == VPP_FAST9_LOCAL_MAXIMA) {
         uint16_t* fr = F.row<uint16_t>(r);
         fr[c] = 0;
