@@ -1,0 +1,27 @@
+"""Source compatibility of the drop-in headers: the reference's OWN unit tests, compiled UNMODIFIED from where they
+lie under /root/reference against vpp_amd/include (host build, no OpenMP — the reference's tests/CMakeLists.txt builds them serially —
+asserts on) and run.  Nothing is copied; where the reference tree is absent (the GPU box) the test is skipped.
+
+Not in the list, and why: cast.cc (spells Eigen::Matrix types directly), liie.cc (iod's expression templates), pyrlk.cc and
+opencv_bridge.cc (OpenCV bridge; tests/pyrlk.cc's golden is restated in tests/test_gpu_algos.py), descriptor_matcher.cc (not on the
+path), lbp.cc (algorithm headers are device-only: tests/test_gpu_video_steps.py)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/tests"
+OUT = os.path.join(ROOT, "tests", "cpp", "_build", "ref_tests")
+NAMES = ["imageNd", "image2d", "image3d", "imageNd_iterator", "boxNd_iterator", "box_nbh2d", "pixel_wise", "block_wise", "border", "fill", "sum",
+         "colorspace_conversions", "pyramid", "tuple_utils", "window", "sandbox"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not on this machine")
+@pytest.mark.parametrize("name", NAMES)
+def test_reference_unit_test_compiles_and_passes_against_the_drop_in_headers(name):
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, name)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-I" + os.path.join(ROOT, "vpp_amd", "include"), os.path.join(REF, name + ".cc"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -13,13 +13,15 @@ template <unsigned N, class C = int> class boxNd_iterator {
   typedef vector<C, N> coord_type;
   boxNd_iterator(const coord_type& p, const boxNd<N, C>& b) : p_(p), box_(&b) {}
   const coord_type& operator*() const { return p_; }
-  boxNd_iterator& operator++() {
+  operator coord_type() const { return p_; }
+  boxNd_iterator& next() {  // row-major successor; one past the last point is (p2[0] + 1, p1[1], ...) = end() (boxNd_iterator.hh:23-24)
     for (int d = int(N) - 1; d >= 0; d--) {
       if (d == 0 || p_[d] < box_->p2()[d]) { p_[d]++; break; }
       p_[d] = box_->p1()[d];
     }
     return *this;
   }
+  boxNd_iterator& operator++() { return next(); }
   bool operator==(const boxNd_iterator& o) const { return p_ == o.p_; }
   bool operator!=(const boxNd_iterator& o) const { return !(p_ == o.p_); }
  private:

@@ -18,19 +18,13 @@
 #include <utility>
 
 #include <vpp/core/image2d.hh>
+#include <vpp/core/relative_accessor.hh>
 #include <vpp/core/pixel_wise_device.hh>
 
 namespace vpp {
 
 // ---- neighbourhood access ---------------------------------------------------------------------------------
-template <class V> struct relative_access_kernel {  // relative_accessor.hh:26-33
-  V* const* line; int col;
-  V& operator()(int dr, int dc) const { return line[dr][col + dc]; }
-  V& operator()(vint2 p) const { return line[p[0]][col + p[1]]; }
-};
-template <class V> relative_access_kernel<V> relative_accessor(const image2d<V>& img, vint2 p) {
-  return relative_access_kernel<V>{&img[p[0]], p[1]};
-}
+// relative_access_kernel / relative_accessor(img, p): vpp/core/relative_accessor.hh
 template <class I> struct relative_access_ {
   I img;  // the (shallow, shared) handle itself — the reference keeps a dangling reference here
   auto first_point_coordinates() const { return img.domain().p1(); }

@@ -47,6 +47,13 @@ template <class T, unsigned N> struct vector {
   VPP_HD T squaredNorm() const { T s = v[0] * v[0]; for (unsigned i = 1; i < N; i++) s += v[i] * v[i]; return s; }
   VPP_HD T norm() const { return T(std::sqrt(squaredNorm())); }
   VPP_HD T dot(const vector& o) const { T s = v[0] * o.v[0]; for (unsigned i = 1; i < N; i++) s += v[i] * o.v[i]; return s; }
+
+  // `m << a, b, c;` (Eigen's comma initialiser, the spelling the reference's tests use for small vectors): fills the components in order
+  struct comma_filler {
+    vector* self; unsigned next;
+    template <class S> VPP_HD comma_filler& operator,(S s) { if (next < N) self->v[next++] = T(s); return *this; }
+  };
+  template <class S, class = typename std::enable_if<std::is_arithmetic<S>::value>::type> VPP_HD comma_filler operator<<(S s) { v[0] = T(s); return comma_filler{this, 1u}; }
 };
 
 template <class T, unsigned N> VPP_HD vector<T, N> operator+(vector<T, N> a, const vector<T, N>& b) { a += b; return a; }
