@@ -7,8 +7,8 @@
 
 namespace vpp {
 
-template <class T, class U> void rgb_to_graylevel(const vector<U, 3>& i, vector<T, 1>& o) { o[0] = (i[0] + i[1] + i[2]) / 3; }
-template <class T, class U> void rgb_to_graylevel(const vector<U, 3>& i, T& o) { o = (i[0] + i[1] + i[2]) / 3; }
+template <class T, class U> VPP_HD void rgb_to_graylevel(const vector<U, 3>& i, vector<T, 1>& o) { o[0] = (i[0] + i[1] + i[2]) / 3; }
+template <class T, class U> VPP_HD void rgb_to_graylevel(const vector<U, 3>& i, T& o) { o = (i[0] + i[1] + i[2]) / 3; }
 
 namespace colorspace_internals {
 template <class T> struct is_u8_gray : std::integral_constant<bool, sizeof(T) == 1 && (std::is_same<T, unsigned char>::value || std::is_same<T, vector<unsigned char, 1>>::value)> {};

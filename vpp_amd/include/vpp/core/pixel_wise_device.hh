@@ -166,6 +166,10 @@ template <class V> struct block_view {
   __device__ V& operator()(int r, int c) const { return (*this)[r][c]; }
   __device__ V& operator()(vint2 p) const { return (*this)[p[0]][p[1]]; }
 };
+// fill(view, value) inside a block_wise callable (tests/block_wise.cc:104 `[] (auto si) { fill(si, 1); }`)
+template <class V, class U> __device__ void fill(const block_view<V>& v, U value) {
+  for (int r = 0; r < v.nr; r++) for (int c = 0; c < v.nc; c++) v(r, c) = V(value);
+}
 struct box_view {  // a box2d range: the block's corners in the coordinates of the first range
   int r0, c0, r1, c1;
   __device__ vint2 p1() const { return vint2(r0, c0); }

@@ -1,5 +1,6 @@
 // vpp.hh — umbrella header of the vpp-shaped C++ surface (reference: vpp/vpp.hh).
 #pragma once
+#include <iostream>   // the reference's umbrella header brings it in (its tests print without including it)
 #include <vpp/core/vector.hh>
 #include <vpp/core/boxNd.hh>
 #include <vpp/core/imageNd.hh>
