@@ -36,7 +36,11 @@ typedef enum vpp_status {
 
 typedef enum vpp_dtype { VPP_U8 = 0, VPP_I8 = 1, VPP_U16 = 2, VPP_I16 = 3, VPP_I32 = 4, VPP_U32 = 5, VPP_F32 = 6 } vpp_dtype;
 
-/* image2d<V> as seen by the device (vpp/core/imageNd.hh:17-40).  V = vector<dtype, channels>. */
+/* image2d<V> as seen by the device (vpp/core/imageNd.hh:17-40).  V = vector<dtype, channels>.
+ * Memory contract for images in memory the caller allocated itself: the addressable area is rows -border .. nrows + border - 1 of the
+ * pitch, as imageNd::allocate lays it out (imageNd.hpp:151-196), and the 16 bytes before its first byte and after its last byte must be
+ * mapped device memory — the streaming stencil kernels load whole 16-byte chunks, of which the out-of-area bytes are read and never used.
+ * Blocks from vpp_malloc carry that slack themselves. */
 typedef struct vpp_image_desc {
   void*   first_pixel; /* imageNd_data::begin_ */
   int32_t nrows;       /* domain().nrows() */
@@ -51,7 +55,7 @@ typedef struct vpp_image_desc {
  *      vpp/core/imageNd.hpp:177-180, and hangs the device mirror's deleter beside it) ---- */
 int vpp_init(int device);                       /* hipSetDevice + warm the context */
 int vpp_device_count(int* n);
-int vpp_malloc(size_t bytes, void** dptr);        /* freed blocks are cached per device and reused by size (no hipFree sync per frame) */
+int vpp_malloc(size_t bytes, void** dptr);        /* freed blocks are cached per device and reused by size (no hipFree sync per frame); 256 B of slack precede every block */
 int vpp_free(void* dptr);
 int vpp_malloc_host(size_t bytes, void** hptr);   /* pinned host staging memory (hipHostMalloc), cached by size on vpp_free_host */
 int vpp_free_host(void* hptr);

@@ -46,6 +46,13 @@ std::vector<DevicePool*> all_pools() {
 }
 // size classes: 256 B granules, 4 KiB above 64 KiB — per-frame buffers whose element count drifts by a few entries keep hitting the same class
 inline size_t round_block(size_t bytes) { const size_t g = bytes >= (64u << 10) ? 4096 : 256; return ((bytes ? bytes : 1) + g - 1) / g * g; }
+// Every device block starts kGuard bytes after its hipMalloc'd address.  The streaming stencil kernels load whole 16-byte chunks
+// and let a chunk begin up to 16 bytes before an image's first addressable byte (the bytes are never used; the range check of the
+// buffer descriptor covers the far end, not the near one): with the guard that read stays inside this allocation whatever lies before it
+// in the address space.  include/vpp_amd.h states the same requirement for memory the caller allocates itself.
+constexpr size_t kGuard = 256;
+inline void* user_ptr(void* raw) { return (char*)raw + kGuard; }
+inline void* raw_ptr(void* user) { return (char*)user - kGuard; }
 }  // namespace
 
 extern "C" {
@@ -77,7 +84,7 @@ int vpp_init(int device) {
 // that returns recently freed memory.  Cap: tuning "runtime.pool_mb" (default 2048 MiB per device, 0 disables the cache).
 int vpp_malloc(size_t bytes, void** dptr) {
   VPP_REQUIRE(dptr, VPP_ERR_INVALID_ARG, "vpp_malloc: null out pointer");
-  const size_t rb = round_block(bytes);
+  const size_t rb = round_block(bytes + kGuard);
   DevicePool& P = pool_of_current_device();
   {
     std::lock_guard<std::mutex> l(P.mu);
@@ -90,13 +97,15 @@ int vpp_malloc(size_t bytes, void** dptr) {
       return VPP_OK;
     }
   }
-  hipError_t e = hipMalloc(dptr, rb);
+  void* raw = nullptr;
+  hipError_t e = hipMalloc(&raw, rb);
   if (e != hipSuccess) {  // out of memory: give the cached blocks back to the driver and retry once
     (void)hipGetLastError();
     vpp_release_cached_memory();
-    e = hipMalloc(dptr, rb);
+    e = hipMalloc(&raw, rb);
   }
   if (e != hipSuccess) { set_error("vpp_malloc: hipMalloc(%zu) failed: %s", rb, hipGetErrorString(e)); return VPP_ERR_HIP; }
+  *dptr = user_ptr(raw);   // the pool's maps hold user pointers throughout
   std::lock_guard<std::mutex> l(P.mu);
   P.live[*dptr] = rb;
   return VPP_OK;
@@ -118,8 +127,8 @@ int vpp_free(void* dptr) {
     P = cand;
     break;
   }
-  (void)P;
-  VPP_HIP_TRY(hipFree(dptr));   // hipFree takes any device's pointer
+  // a block of the pool that does not fit the cache, or a pointer the pool never handed out (freed as it is); hipFree takes any device's pointer
+  VPP_HIP_TRY(hipFree(P ? raw_ptr(dptr) : dptr));
   return VPP_OK;
 }
 
@@ -179,7 +188,7 @@ int vpp_release_cached_memory(void) {
     blocks.swap(P.free_blocks);
     P.cached_bytes = 0;
   }
-  for (auto& b : blocks) VPP_HIP_TRY(hipFree(b.second));
+  for (auto& b : blocks) VPP_HIP_TRY(hipFree(raw_ptr(b.second)));
   return VPP_OK;
 }
 int vpp_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {

@@ -82,9 +82,10 @@ class DeviceImage(_ImageBase):
     def __init__(self, nrows, ncols, dtype=U8, channels=1, border=0, align=DEFAULT_ALIGN, device="cuda:0"):
         import torch
         self._setup(nrows, ncols, dtype, channels, border, align)
-        # 256-byte slack so the first row can be placed on a 256 B boundary regardless of the caching allocator
-        self.store = torch.zeros(self.alloc_bytes + 256, dtype=torch.uint8, device=device)
-        self.shift = (-self.store.data_ptr()) % 256
+        # the image starts on a 256 B boundary at least 256 bytes into the tensor: the streaming kernels may begin a 16-byte chunk up to
+        # 16 bytes before the first addressable byte (never used; see include/vpp_amd.h), which must not leave the allocation
+        self.store = torch.zeros(self.alloc_bytes + 512, dtype=torch.uint8, device=device)
+        self.shift = 256 + (-self.store.data_ptr()) % 256
         self.device = device
 
     @property
