@@ -146,6 +146,63 @@ __global__ __launch_bounds__(64) void sdof_descent_kernel(const int32_t* __restr
   cur.mark.row<uint8_t>(pf0)[pf1] = 2;           // :141
 }
 
+// The same phase with 8 lanes per keypoint: the candidates of one search step (the 3, 5 or 8 neighbours the reference walks one after
+// the other) are evaluated by the lanes of the group side by side and the winner is the minimum of (distance << 3 | position in the
+// walk) — the sequential rule "replace on strictly smaller" keeps the FIRST of equal minima, and a candidate that the sequential walk
+// would cut short (its early-out threshold is the running best there, the step's starting best here) is one that cannot win in either
+// form: same flow, same distance.  One lane per keypoint left 1180 waves of 28 dependent window SADs each on a 4K frame.
+template <int WS>
+__global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
+                                                                DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi) {
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 3), j = threadIdx.x & 7;
+  if (i >= n) return;
+  const int p0 = kps[2 * i] / scale_div, p1 = kps[2 * i + 1] / scale_div;  // :116
+  const int pf0 = p0 / patch, pf1 = p1 / patch;
+  if (pf0 < cell_lo || pf0 >= cell_hi) return;
+  if (!owner.has(pf0, pf1) || owner.row<uint32_t>(pf0)[pf1] != (uint32_t)i) return;  // :120 — first keypoint in index order claims
+  int pr0 = p0, pr1 = p1;
+  if (has_coarse) {  // multiscale prediction, :126-128
+    const int pfm0 = p0 / (2 * patch), pfm1 = p1 / (2 * patch);
+    if (coarse.mark.has(pfm0, pfm1) && coarse.mark.row<uint8_t>(pfm0)[pfm1]) {
+      const int32_t* f = coarse.flow.row<int32_t>(pfm0) + 2 * pfm1;
+      pr0 = p0 + f[0] * 2; pr1 = p1 + f[1] * 2;
+    }
+  }
+  // gradient_descent_match (gradient_descent.hh:10-89) over the group; tables as in gradient_descent_impl
+  constexpr unsigned kFirst = 0xd22406u, kEnd = 0x27fb5bu, kDr = 0x9224u, kDc = 0x16au;
+  int m0 = pr0, m1 = pr1;
+  int match_distance = distance_fn<WS>(i1, i2, p0, p1, pr0, pr1, ws, INT_MAX);
+  unsigned match_i = 8;
+#pragma nounroll
+  for (int search = 0; search < 5; search++) {
+    const unsigned first = (kFirst >> (3 * match_i)) & 7u, end = (kEnd >> (3 * match_i)) & 7u;
+    const unsigned count = ((end - first - 1u) & 7u) + 1u;   // candidates first, first + 1, ... up to (not including) end, at least one; end == first: all 8
+    const unsigned ci = (first + (unsigned)j) & 7u;
+    const int n0 = pr0 + (int)((kDr >> (2 * ci)) & 3u) - 1, n1 = pr1 + (int)((kDc >> (2 * ci)) & 3u) - 1;
+    const int d = (unsigned)j < count ? distance_fn<WS>(i1, i2, p0, p1, n0, n1, ws, match_distance) : INT_MAX;
+    unsigned long long key = ((unsigned long long)(unsigned)d << 3) | (unsigned)j;
+#pragma unroll
+    for (int x = 1; x < 8; x <<= 1) {
+      const unsigned lo = __shfl_xor((unsigned)key, x), hi = __shfl_xor((unsigned)(key >> 32), x);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      key = o < key ? o : key;
+    }
+    const int best = (int)(unsigned)(key >> 3);
+    if (best < match_distance) {
+      const unsigned wi = (first + (unsigned)(key & 7u)) & 7u;
+      m0 = pr0 + (int)((kDr >> (2 * wi)) & 3u) - 1; m1 = pr1 + (int)((kDc >> (2 * wi)) & 3u) - 1;
+      match_i = wi; match_distance = best;
+    }
+    if (pr0 == m0 && pr1 == m1) break;
+    pr0 = m0; pr1 = m1;
+  }
+  if (j != 0) return;
+  int32_t* f = cur.flow.row<int32_t>(pf0) + 2 * pf1;
+  f[0] = m0 - p0; f[1] = m1 - p1;                  // :137-139
+  cur.dist.row<int32_t>(pf0)[pf1] = match_distance;  // :140
+  cur.mark.row<uint8_t>(pf0)[pf1] = 2;               // :141
+}
+
 __device__ __forceinline__ int inorm(int a, int b) { return (int)sqrt((double)(a * a + b * b)); }  // Eigen norm() on vint2
 
 // loop_body (:149-189) for cell (pf0, pf1) evaluated at image point (r, c)
@@ -698,8 +755,12 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
         int r2 = vpp_fill(&MK(k, scale), &zero, 1, (void*)sk); if (r2) return r2;  // fill_with_border(flow_map_mark, 0), :111
         VPP_HIP_TRY(hipMemsetAsync(OW(k, scale).first_pixel, 0xFF, (size_t)OW(k, scale).pitch * OW(k, scale).nrows, sk));
         sdof_claim_kernel<<<(n + 255) / 256, 256, 0, sk>>>(kps, n, scale_div, patchsize, dimg(&OW(k, scale)), lo, hi);
-        sdof_descent_kernel<WS><<<(n + 63) / 64, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                             maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi);
+        if (tuning("sdof.descent_lanes", 8) == 8)
+          sdof_descent_group_kernel<WS><<<(n + 7) / 8, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
+                                                                    maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi);
+        else
+          sdof_descent_kernel<WS><<<(n + 63) / 64, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
+                                                               maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi);
         return VPP_OK;
       };
       if (nstrips > 1) VPP_HIP_TRY(hipEventRecord(g_strips.start, st));   // the pyramids / the previous scale's broadcast are behind this point
