@@ -59,6 +59,40 @@ __device__ __forceinline__ int sad_rows(const uint8_t* __restrict__ row1, const 
   return err;
 }
 
+// the same with the first window already in registers (callers that compare one fixed window against many candidates)
+template <int WS> struct WindowRegs { uint32_t d[WS ? WS : 1][WS ? (WS + 3) / 4 : 1]; };
+template <int WS>
+__device__ __forceinline__ void load_window(WindowRegs<WS>& w, const uint8_t* __restrict__ row, int pitch) {
+#pragma unroll
+  for (int r = 0; r < WS; r++)
+#pragma unroll
+    for (int d = 0; d < (WS + 3) / 4; d++) __builtin_memcpy(&w.d[r][d], row + (ptrdiff_t)r * pitch + 4 * d, 4);
+}
+template <int WS>
+__device__ __forceinline__ int sad_rows_against(const WindowRegs<WS>& a, const uint8_t* __restrict__ row2, int pitch2, int th) {
+  constexpr int ND = (WS + 3) / 4;
+  constexpr uint32_t tail_mask = (WS % 4) ? ((1u << (8 * (WS % 4))) - 1u) : 0xFFFFFFFFu;
+  uint32_t b[WS][ND];
+#pragma unroll
+  for (int r = 0; r < WS; r++)
+#pragma unroll
+    for (int d = 0; d < ND; d++) __builtin_memcpy(&b[r][d], row2 + (ptrdiff_t)r * pitch2 + 4 * d, 4);
+  int err = 0;
+#pragma unroll
+  for (int r = 0; r < WS; r++) {
+    if (err <= th) {
+      uint32_t err2 = 0;
+#pragma unroll
+      for (int d = 0; d < ND; d++) {
+        const uint32_t m = d == ND - 1 ? tail_mask : 0xFFFFFFFFu;
+        err2 = __builtin_amdgcn_sad_u8(a.d[r][d] & m, b[r][d] & m, err2);
+      }
+      err += (int)err2;
+    }
+  }
+  return err;
+}
+
 // WS: the window size when it is one of the register-window sizes (5, 7, 9, 11), else 0 = the generic loop over the runtime
 // `ws`.  Every kernel of this file is instantiated per WS: with a runtime switch at each of the ~30 inlined call sites the
 // out-of-line recomputation alone was 84 KB of code, more than the instruction cache, on the critical path of the ordered sweep.
@@ -170,8 +204,18 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
   }
   // gradient_descent_match (gradient_descent.hh:10-89) over the group; tables as in gradient_descent_impl
   constexpr unsigned kFirst = 0xd22406u, kEnd = 0x27fb5bu, kDr = 0x9224u, kDc = 0x16au;
+  // the keypoint's own window (image 1 at p) is the same in every comparison of the walk: loaded once, the candidates cost one window each
+  WindowRegs<WS> wa;
+  const bool a_ok = i1.has(p0, p1);
+  if (WS != 0 && a_ok) load_window<WS>(wa, i1.row<uint8_t>(p0 - ws / 2) + (p1 - ws / 2), i1.pitch);
+  auto dist = [&](int b0, int b1, int th) -> int {
+    if constexpr (WS != 0) {
+      if (!(a_ok && i2.has(b0, b1))) return INT_MAX;
+      return sad_rows_against<WS>(wa, i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2), i2.pitch, th);
+    } else return distance_fn<WS>(i1, i2, p0, p1, b0, b1, ws, th);
+  };
   int m0 = pr0, m1 = pr1;
-  int match_distance = distance_fn<WS>(i1, i2, p0, p1, pr0, pr1, ws, INT_MAX);
+  int match_distance = dist(pr0, pr1, INT_MAX);
   unsigned match_i = 8;
 #pragma nounroll
   for (int search = 0; search < 5; search++) {
@@ -179,7 +223,7 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
     const unsigned count = ((end - first - 1u) & 7u) + 1u;   // candidates first, first + 1, ... up to (not including) end, at least one; end == first: all 8
     const unsigned ci = (first + (unsigned)j) & 7u;
     const int n0 = pr0 + (int)((kDr >> (2 * ci)) & 3u) - 1, n1 = pr1 + (int)((kDc >> (2 * ci)) & 3u) - 1;
-    const int d = (unsigned)j < count ? distance_fn<WS>(i1, i2, p0, p1, n0, n1, ws, match_distance) : INT_MAX;
+    const int d = (unsigned)j < count ? dist(n0, n1, match_distance) : INT_MAX;
     unsigned long long key = ((unsigned long long)(unsigned)d << 3) | (unsigned)j;
 #pragma unroll
     for (int x = 1; x < 8; x <<= 1) {
