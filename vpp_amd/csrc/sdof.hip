@@ -697,10 +697,22 @@ struct Carver {
     int32_t pitch; size_t bytes, first;
     vpp_image_layout(nr, nc, dtype_size(dtype) * ch, border, 32, &pitch, &bytes, &first);
     vpp_image_desc d{base ? base + off + first : nullptr, nr, nc, pitch, border, dtype, ch};
-    off += (bytes + 255) / 256 * 256;
+    last_off = off; last_bytes = (bytes + 255) / 256 * 256;
+    off += last_bytes;
     return d;
   }
+  size_t last_off = 0, last_bytes = 0;   // the block of the image carved last (whole allocation, a multiple of 256 bytes)
 };
+
+// One launch resets the maps of every scale that the per-scale phases used to reset one by one (fill_with_border(mark, 0) and the
+// owner map's 0xFF fill: 2 launches per scale, ~5 us each for a few hundred KB): the segments are whole carved blocks, written as 16-byte units.
+struct ResetArgs { uint4* p[16]; uint32_t first_block[17]; uint32_t units[16]; uint32_t value[16]; int nseg; };
+__global__ __launch_bounds__(256) void sdof_reset_kernel(ResetArgs a) {
+  int sgm = 0;
+  while (sgm + 1 < a.nseg && blockIdx.x >= a.first_block[sgm + 1]) sgm++;
+  const uint32_t u = (blockIdx.x - a.first_block[sgm]) * 256 + threadIdx.x;
+  if (u < a.units[sgm]) { const uint32_t v = a.value[sgm]; a.p[sgm][u] = make_uint4(v, v, v, v); }
+}
 
 }  // namespace
 
@@ -756,6 +768,7 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
   Cell* jacobi = nullptr;
   uint8_t* skew = nullptr;
   PairCache* pairs = nullptr;
+  size_t mk_off[kMaxScales] = {}, mk_bytes[kMaxScales] = {}, ow_off[kMaxScales] = {}, ow_bytes[kMaxScales] = {};   // strip 0's mark / owner blocks
   for (int pass = 0; pass < 2; pass++) {
     Carver cv{pass ? (uint8_t*)g_scratch.p : nullptr};
     int fr = i1->nrows / patchsize, fc = i1->ncols / patchsize, ir = i1->nrows, ic = i1->ncols;
@@ -763,8 +776,10 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
     for (int s_ = 0; s_ < nscales; s_++) {
       P1[s_] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize); P2[s_] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize);
       for (int k = 0; k < nstrips; k++) {
-        FL(k, s_) = cv.image(fr, fc, VPP_I32, 2, nscales); MK(k, s_) = cv.image(fr, fc, VPP_U8, 1, nscales); DM(k, s_) = cv.image(fr, fc, VPP_I32, 1, nscales);
-        OW(k, s_) = cv.image(fr, fc, VPP_U32, 1, 0);
+        FL(k, s_) = cv.image(fr, fc, VPP_I32, 2, nscales);
+        MK(k, s_) = cv.image(fr, fc, VPP_U8, 1, nscales); if (k == 0) { mk_off[s_] = cv.last_off; mk_bytes[s_] = cv.last_bytes; }
+        DM(k, s_) = cv.image(fr, fc, VPP_I32, 1, nscales);
+        OW(k, s_) = cv.image(fr, fc, VPP_U32, 1, 0); if (k == 0) { ow_off[s_] = cv.last_off; ow_bytes[s_] = cv.last_bytes; }
       }
       fr = 1 + fr / 2; fc = 1 + fc / 2; ir = 1 + ir / 2; ic = 1 + ic / 2;  // pyramid.hh:154
     }
@@ -785,6 +800,21 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
   int rc = vpp_pyramid_build(P1, nscales, i1, stream); if (rc) return rc;
   rc = vpp_pyramid_build(P2, nscales, i2, stream); if (rc) return rc;
   auto maps = [&](int k, int s_) { return Maps{dimg(&FL(k, s_)), dimg(&MK(k, s_)), dimg(&DM(k, s_))}; };
+  // single strip: the mark and owner maps of all scales are reset here in one launch (nothing writes a scale's maps before its own phase)
+  const bool reset_up_front = nstrips == 1 && 2 * (nscales - min_scale) <= 16 && tuning("sdof.reset_up_front", 1);
+  if (reset_up_front) {
+    ResetArgs ra; ra.nseg = 0; uint32_t blocks = 0;
+    for (int s_ = min_scale; s_ < nscales; s_++)
+      for (int w = 0; w < 2; w++) {
+        const int q = ra.nseg++;
+        ra.p[q] = (uint4*)((uint8_t*)g_scratch.p + (w ? ow_off[s_] : mk_off[s_]));
+        ra.units[q] = (uint32_t)((w ? ow_bytes[s_] : mk_bytes[s_]) / 16); ra.value[q] = w ? 0xFFFFFFFFu : 0u;
+        ra.first_block[q] = blocks; blocks += (ra.units[q] + 255) / 256;
+      }
+    ra.first_block[ra.nseg] = blocks;
+    sdof_reset_kernel<<<blocks, 256, 0, st>>>(ra);
+    VPP_LAUNCH_CHECK();
+  }
   for (int scale = nscales - 1; scale >= min_scale; scale--) {  // :92
     const int scale_div = 1 << scale;
     const uint8_t zero = 0;
@@ -796,8 +826,10 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
       // claim + descent of strip k on stream sk, rows [lo, hi) of the flow map, into strip k's own maps
       auto strip_phase = [&](int k, hipStream_t sk) -> int {
         const int lo = nstrips == 1 ? 0 : (int)((long long)fr * k / nstrips), hi = nstrips == 1 ? INT_MAX : (int)((long long)fr * (k + 1) / nstrips);
-        int r2 = vpp_fill(&MK(k, scale), &zero, 1, (void*)sk); if (r2) return r2;  // fill_with_border(flow_map_mark, 0), :111
-        VPP_HIP_TRY(hipMemsetAsync(OW(k, scale).first_pixel, 0xFF, (size_t)OW(k, scale).pitch * OW(k, scale).nrows, sk));
+        if (!reset_up_front) {
+          int r2 = vpp_fill(&MK(k, scale), &zero, 1, (void*)sk); if (r2) return r2;  // fill_with_border(flow_map_mark, 0), :111
+          VPP_HIP_TRY(hipMemsetAsync(OW(k, scale).first_pixel, 0xFF, (size_t)OW(k, scale).pitch * OW(k, scale).nrows, sk));
+        }
         sdof_claim_kernel<<<(n + 255) / 256, 256, 0, sk>>>(kps, n, scale_div, patchsize, dimg(&OW(k, scale)), lo, hi);
         if (tuning("sdof.descent_lanes", 8) == 8)
           sdof_descent_group_kernel<WS><<<(n + 7) / 8, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
