@@ -313,7 +313,10 @@ constexpr int kJChanged = 0x200;  // Jacobi kernel only: its pass wants to chang
 constexpr int kFlagMarked = 1, kFlagJChanged = 2, kFlagDirty = 4;
 
 // Per (cell, neighbour) results of the costly calls of loop_body, keyed by the neighbour flow they were computed for.
-struct PairCache { int nf0, nf1, d2, gf0, gf1, gdist, flags, pad; };  // flags: 1 = entry valid, 2 = descent result present
+struct PairCache { int nf0, nf1, d2, gf0, gf1, gdist, flags, epoch; };  // flags: 1 = entry valid, 2 = descent result present; epoch: the sweep that recorded it
+// An entry counts only if its epoch is the current sweep's: the Jacobi pass used to clear the flags of all 8 entries of EVERY cell first —
+// 2.6 M scattered 4-byte stores per 4K sweep for entries that are almost never written.  (Epochs come from a counter kept with the
+// scratch buffer; the array is zeroed when the buffer or its layout changes, so no stale bytes can pass for the current epoch.)
 
 // loop_body (semi_dense_optical_flow.hpp:149-189) for the cell at image point (r, c); nbr(dr, dc) returns the neighbour
 // cell at flow-map offset (dr, dc) (mark 0 when outside the map).  distance() and gradient_descent_match() depend only on
@@ -323,7 +326,7 @@ struct PairCache { int nf0, nf1, d2, gf0, gf1, gdist, flags, pad; };  // flags: 
 // DIST(r2, c2) = distance(p, (r2, c2)) with th = INT_MAX, GD(r2, c2) = gradient_descent_match(p, prediction (r2, c2), 5): the
 // Jacobi pass inlines them, the recomputation of the ordered sweep calls its out-of-line copies.
 template <bool RECORD, class NB, class DIST, class GD>
-__device__ __forceinline__ bool loop_body(int r, int c, Cell& cur, NB nbr, PairCache* pc, DIST dist, GD gd) {
+__device__ __forceinline__ bool loop_body(int r, int c, Cell& cur, NB nbr, PairCache* pc, DIST dist, GD gd, int epoch) {
   const int prev0 = cur.f0, prev1 = cur.f1;
   bool changed = false;
   int k = -1;
@@ -333,14 +336,13 @@ __device__ __forceinline__ bool loop_body(int r, int c, Cell& cur, NB nbr, PairC
     for (int dc = -1; dc <= 1; dc++) {
       if (!dr && !dc) continue;
       k++;
-      if (RECORD) pc[k].flags = 0;
       const Cell nb = nbr(dr, dc);
       if (!(nb.mark & 0xFF)) continue;
       const int a0 = cur.f0 - nb.f0, a1 = cur.f1 - nb.f1, b0 = prev0 - nb.f0, b1 = prev1 - nb.f1;
       if (a0 * a0 + a1 * a1 >= 9 && b0 * b0 + b1 * b1 >= 9) {  // Eigen's integer norm(): (int)sqrt(s) > 2  <=>  s >= 9
         const int d1 = cur.dist;
         PairCache e; e.flags = 0;
-        if (!RECORD) { e = pc[k]; if (!((e.flags & 1) && e.nf0 == nb.f0 && e.nf1 == nb.f1)) e.flags = 0; }
+        if (!RECORD) { e = pc[k]; if (!((e.flags & 1) && e.epoch == epoch && e.nf0 == nb.f0 && e.nf1 == nb.f1)) e.flags = 0; }
         const int d2 = (e.flags & 1) ? e.d2 : dist(r + nb.f0, c + nb.f1);
         GdMatch g{0, 0, 0};
         bool have_g = false;
@@ -350,7 +352,7 @@ __device__ __forceinline__ bool loop_body(int r, int c, Cell& cur, NB nbr, PairC
           have_g = true;
           if (g.distance < d1) { cur.mark = 1; cur.f0 = g.f0; cur.f1 = g.f1; cur.dist = g.distance; changed = true; }
         }
-        if (RECORD) pc[k] = PairCache{nb.f0, nb.f1, d2, g.f0, g.f1, g.distance, have_g ? 3 : 1, 0};
+        if (RECORD) pc[k] = PairCache{nb.f0, nb.f1, d2, g.f0, g.f1, g.distance, have_g ? 3 : 1, epoch};
       }
     }
   return changed;
@@ -365,7 +367,7 @@ __device__ __forceinline__ Cell load_map_cell(const Maps& m, int ci, int cj) {
 
 template <int WS>
 __global__ __launch_bounds__(256) void sdof_jacobi_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int NI, int NJ, int forward,
-                                                          Cell* __restrict__ J, PairCache* __restrict__ pairs, uint8_t* __restrict__ skew, int NIp) {
+                                                          Cell* __restrict__ J, PairCache* __restrict__ pairs, uint8_t* __restrict__ skew, int NIp, int epoch) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= NI * NJ) return;
   const int ci = idx / NJ, cj = idx - ci * NJ;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void sdof_jacobi_kernel(DImg i1, DImg i2, int 
     };
     auto dist = [&](int r2, int c2) { return distance_fn<WS>(i1, i2, r, c, r2, c2, ws, INT_MAX); };
     auto gd = [&](int r2, int c2) { return gradient_descent_match<WS>(i1, i2, ws, r, c, r2, c2, 5); };
-    if (loop_body<true>(r, c, cur, nbr, pairs + (size_t)idx * 8, dist, gd)) { cur.mark |= kChanged; pre.mark |= kJChanged; }
+    if (loop_body<true>(r, c, cur, nbr, pairs + (size_t)idx * 8, dist, gd, epoch)) { cur.mark |= kChanged; pre.mark |= kJChanged; }
   }
   J[idx] = cur;
   // the pre-sweep cell (+ "Jacobi wants to change it") in the ordered pass's visiting layout: step-major, wavefront row minor,
@@ -538,7 +540,7 @@ __device__ __forceinline__ Cell load_map_cell_coherent(const MapsG& m, int ci, i
 }
 
 template <int WS, int MAXT>
-__device__ __forceinline__ SlowResult sweep_slow_path_body(const FramePair& f, const MapsG& m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc) {
+__device__ __forceinline__ SlowResult sweep_slow_path_body(const FramePair& f, const MapsG& m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc, int epoch) {
   Cell nb8[8];
   int k = 0;
 #pragma unroll
@@ -561,18 +563,18 @@ __device__ __forceinline__ SlowResult sweep_slow_path_body(const FramePair& f, c
   auto nbr = [&](int dr, int dc) -> Cell { return nb8[(dr + 1) * 3 + (dc + 1) - ((dr > 0 || (dr == 0 && dc > 0)) ? 1 : 0)]; };
   auto dist = [&](int r2, int c2) { return distance_outlined<WS, MAXT>(f, r, c, r2, c2, ws, INT_MAX); };
   auto gd = [&](int r2, int c2) { return gradient_descent_outlined<WS, MAXT>(f, ws, r, c, r2, c2, 5); };
-  const bool changed = loop_body<false>(r, c, cur, nbr, loc, dist, gd);
+  const bool changed = loop_body<false>(r, c, cur, nbr, loc, dist, gd, epoch);
   return SlowResult{cur, changed ? 1 : 0};
 }
 
 template <int WS, int MAXT>
-__device__ __noinline__ SlowResult sweep_slow_path_noinline(FramePair f, MapsG m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc) {
-  return sweep_slow_path_body<WS, MAXT>(f, m, ws, r, c, ci, cj, NI, NJ, pc);
+__device__ __noinline__ SlowResult sweep_slow_path_noinline(FramePair f, MapsG m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc, int epoch) {
+  return sweep_slow_path_body<WS, MAXT>(f, m, ws, r, c, ci, cj, NI, NJ, pc, epoch);
 }
 template <int WS, int MAXT>
-__device__ __forceinline__ SlowResult sweep_slow_path(const FramePair& f, const MapsG& m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc) {
-  if constexpr (MAXT > 512) return sweep_slow_path_noinline<WS, MAXT>(f, m, ws, r, c, ci, cj, NI, NJ, pc);
-  else return sweep_slow_path_body<WS, MAXT>(f, m, ws, r, c, ci, cj, NI, NJ, pc);
+__device__ __forceinline__ SlowResult sweep_slow_path(const FramePair& f, const MapsG& m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc, int epoch) {
+  if constexpr (MAXT > 512) return sweep_slow_path_noinline<WS, MAXT>(f, m, ws, r, c, ci, cj, NI, NJ, pc, epoch);
+  else return sweep_slow_path_body<WS, MAXT>(f, m, ws, r, c, ci, cj, NI, NJ, pc, epoch);
 }
 
 // Ordered pass.  Thread = wavefront row: at step t it visits wavefront column t - 2*row, so data only flows between
@@ -586,7 +588,7 @@ __device__ unsigned g_sweep_stats[4];  // [0] unused, [1] Jacobi outcomes applie
 template <int WS, int MAXT>
 __global__ __launch_bounds__(MAXT) void sdof_propagate_ring_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward,
                                                                    const Cell* __restrict__ J, PairCache* __restrict__ pairs,
-                                                                   const uint8_t* __restrict__ skew, int NIp, int stats) {
+                                                                   const uint8_t* __restrict__ skew, int NIp, int stats, int epoch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [kRingGroups][NIp][16]
   const int NI = (i1.nr - 1) / patch + 1, NJ = (i1.nc - 1) / patch + 1;
   const int iw = threadIdx.x;
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(MAXT) void sdof_propagate_ring_kernel(DImg i1, DImg
             const int pr = forward ? ci * patch : i1.nr - 1 - (NI - 1 - ci) * patch, pcol = forward ? cj * patch : i1.nc - 1 - (NJ - 1 - cj) * patch;
             const SlowResult sr = sweep_slow_path<WS, MAXT>(FramePair{(gcu8)i1.p0, (gcu8)i2.p0, i1.pitch, i2.pitch, i1.nr, i1.nc, i2.nr, i2.nc},
                                                       MapsG{(const VPP_GLOBAL int32_t*)m.flow.p0, (const VPP_GLOBAL uint8_t*)m.mark.p0, (const VPP_GLOBAL int32_t*)m.dist.p0, m.flow.pitch, m.mark.pitch, m.dist.pitch},
-                                                      ws, pr, pcol, ci, cj, NI, NJ, (const VPP_GLOBAL PairCache*)(pairs + ((size_t)ci * NJ + cj) * 8));
+                                                      ws, pr, pcol, ci, cj, NI, NJ, (const VPP_GLOBAL PairCache*)(pairs + ((size_t)ci * NJ + cj) * 8), epoch);
             cur = sr.cell; changed = sr.changed != 0;
             if (stats) { atomicAdd(&g_sweep_stats[2], 1u); if (changed) atomicAdd(&g_sweep_stats[3], 1u); }
           }
@@ -796,6 +798,15 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
     if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
   if (nstrips > 1) { int rc = g_strips.ensure(nstrips - 1); if (rc != VPP_OK) return rc; }
+  {  // pair-cache epochs (see PairCache): the array is zeroed once per (buffer, layout) and when the counter nears its wrap
+    Scratch::Slot& sl = *g_scratch.cur;
+    const size_t cells = (size_t)((i1->nrows - 1) / patchsize + 1) * ((i1->ncols - 1) / patchsize + 1);
+    const unsigned long long sig = ((unsigned long long)((uint8_t*)pairs - (uint8_t*)g_scratch.p) << 20) ^ (unsigned long long)cells ^ 1ull;
+    if (sl.user[0] != sig || sl.user[1] >= 0x7FFF0000ull) {
+      VPP_HIP_TRY(hipMemsetAsync(pairs, 0, cells * 8 * sizeof(PairCache), st));
+      sl.user[0] = sig; sl.user[1] = 0;
+    }
+  }
   // the image pyramids: built once here; across GPUs every rank builds them from the broadcast frames (pyramid::update, pyramid.hh:194-198)
   int rc = vpp_pyramid_build(P1, nscales, i1, stream); if (rc) return rc;
   rc = vpp_pyramid_build(P2, nscales, i2, stream); if (rc) return rc;
@@ -862,11 +873,12 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
         if (mode != 1 && NI <= 1024) {  // mode 1: the generic one-kernel wavefront (also the fallback for maps taller than 1024 cells)
           const size_t lds = (size_t)kRingGroups * threads * kGroupSteps;
           for (int Ki = 0; Ki < propagation; Ki++) {
-            sdof_jacobi_kernel<WS><<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs, skew, threads);
+            const int epoch = (int)++g_scratch.cur->user[1];   // one per sweep; the pair cache was zeroed for this layout (below), so 0 never matches
+            sdof_jacobi_kernel<WS><<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs, skew, threads, epoch);
             // a workgroup of at most 512 threads may use 256 registers per lane: the out-of-line recomputation then keeps its cells and
             // pair-cache entries in registers instead of scratch memory (4K frames: 448 threads)
-            if (threads <= 512) sdof_propagate_ring_kernel<WS, 512><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
-            else sdof_propagate_ring_kernel<WS, 1024><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0));
+            if (threads <= 512) sdof_propagate_ring_kernel<WS, 512><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0), epoch);
+            else sdof_propagate_ring_kernel<WS, 1024><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0), epoch);
           }
         } else
           sdof_propagate_kernel<WS><<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, propagation);
