@@ -4,7 +4,7 @@
 //
 // Pipeline (all on one stream, no host round trip until the final count):
 //   1. fast9_detect2_kernel  (default; fast9_detect_kernel = the single-phase form, tuning fast9.impl = 1)
-//                            LDS tile (64x64 px + 3 px halo, dword loads), one lane per pixel column marching down 16 rows.
+//                            LDS tile (64x32 px + 3 px halo, dword loads), one lane per pixel column marching down 8 rows.
 //                            Segment test per lane: saturated thresholds, 4 cardinal samples first (any 9-arc holds >= 2
 //                            of ring indices {0,4,8,12}), then 16-bit brighter/darker masks and a shift-and "9 circularly
 //                            contiguous" test.  corner = mask_byte & (0x10*B9 | 0x01*D9) != 0 (fast.hpp:120-126,312,333).
@@ -42,9 +42,9 @@ __host__ __device__ constexpr int ring_dc(int i) {
   return dc[i];
 }
 
-constexpr int TW = 64, TH = 64, HALO = 3;
+constexpr int TW = 64, TH = 32, HALO = 3;   // 64 x 32 px per workgroup (8 rows per wave): measured 4K raw / blockwise 64 rows 53.8 / 46.0 us, 48: 53.4 / 43.8, 32: 52.1 / 42.3, 16: 54.5 / 43.4
 constexpr int LP = 72;                       // LDS row pitch: cols [c0-4, c0+68)
-constexpr int LROWS = TH + 2 * HALO;         // 70
+constexpr int LROWS = TH + 2 * HALO;         // 38
 constexpr int LDW = LP / 4;                  // 18 dwords per LDS row
 
 __device__ __forceinline__ uint32_t ld_dword_guarded_px(const uint8_t* __restrict__ p, int off, int lo, int hi, bool aligned) {
