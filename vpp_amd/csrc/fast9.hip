@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
 
 // Two-phase variant of the detect kernel.  In the kernel above a wave pays the full ring test whenever ANY of its 64 lanes
 // passes the four-sample pre-test, and on natural images nearly every wave has such a lane.  Here phase 1 runs the pre-test for
-// every pixel of the wave's 16 rows without divergence, writes F = 0 rows (coalesced) and appends the survivors to a per-wave
+// every pixel of the wave's TH / 4 rows without divergence, writes F = 0 rows (coalesced) and appends the survivors to a per-wave
 // LDS list (ballot + mbcnt prefix); phase 2 runs the ring test and the score on the list, 64 candidates per pass, so its lanes
 // are all busy; corners overwrite their F entry and set their bit in a per-wave LDS copy of the 16 bitmap words.
 // MODE (what the selection that follows needs): VPP_FAST9_LOCAL_MAXIMA reads F around every corner, so F is written densely (zeros
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
                                                             unsigned long long* __restrict__ blkkey, uint32_t bs_magic, int nbc) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[LROWS * LP];
   __shared__ uint16_t cand[4][TH / 4 * TW];          // per wave: (row in the wave's band) * 64 + column
-  __shared__ unsigned long long words[4][TH / 4];    // per wave: corner bitmap words of its 16 rows
+  __shared__ unsigned long long words[4][TH / 4];    // per wave: corner bitmap words of its TH / 4 rows
   const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
   const int lo = -A.border, hi = A.nc + A.border;
   const bool aligned = (((uintptr_t)A.p0 | (uintptr_t)A.pitch) & 3) == 0;
