@@ -55,7 +55,7 @@ template <int CH, bool MIRROR>
 __global__ __launch_bounds__(256) void rgb_to_gray_kernel(DImg dst, DImg src, int ext, int c_start, int nchunks, int n_left, int n_main, int edge_blocks, int vec_ok) {
   const int nrows_out = dst.nr + 2 * ext;
   if ((int)blockIdx.x < edge_blocks) {
-    const int n_edge = nchunks - n_main, t = blockIdx.x * 256 + threadIdx.x;
+    const int n_edge = nchunks - n_main, t = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = t / n_edge, e = t - row * n_edge;
     if (row >= nrows_out) return;
     const int r = row - ext, c0 = c_start + kGrayChunk * (e < n_left ? e : e + n_main);
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void rgb_to_gray_kernel(DImg dst, DImg src, in
     }
     return;
   }
-  const long long t = (long long)(blockIdx.x - edge_blocks) * 256 + threadIdx.x;
+  const long long t = (long long)(blockIdx.x - edge_blocks) * blockDim.x + threadIdx.x;
   const int row = (int)(t / n_main), chunk = n_left + (int)(t - (long long)row * n_main);
   if (row >= nrows_out) return;
   const int r = row - ext, c0 = c_start + kGrayChunk * chunk;
@@ -144,18 +144,20 @@ extern "C" int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_d
   const int n_left = (lo - c_start + kGrayChunk - 1) / kGrayChunk;                                 // first chunk with c0 >= lo
   const int n_main = std::max(0, std::min(nchunks, (hi - c_start) / kGrayChunk) - n_left);            // chunks [n_left, n_left + n_main)
   const int nrows_out = dst->nrows + 2 * ext;
-  const int edge_blocks = (int)(((long long)nrows_out * (nchunks - n_main) + 255) / 256);
-  const long long main_blocks = ((long long)nrows_out * n_main + 255) / 256;
+  int bsz = tuning("ingest.block", 64);   // measured 4K: 256 threads 8.19 us, 128: 7.88, 64: 7.70 (more, shorter workgroups: the single resident round ends more evenly)
+  if (bsz != 128 && bsz != 256) bsz = 64;
+  const int edge_blocks = (int)(((long long)nrows_out * (nchunks - n_main) + bsz - 1) / bsz);
+  const long long main_blocks = ((long long)nrows_out * n_main + bsz - 1) / bsz;
   VPP_REQUIRE(edge_blocks + main_blocks < (1ll << 31), VPP_ERR_UNSUPPORTED, "vpp_rgb_to_graylevel: image too large for one launch");
   const unsigned grid = (unsigned)(edge_blocks + main_blocks);
   hipStream_t st = as_stream(stream);
   DImg d = dimg(dst), s = dimg(src);
   if (src->channels == 3) {
-    if (mirror) rgb_to_gray_kernel<3, true><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
-    else rgb_to_gray_kernel<3, false><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
+    if (mirror) rgb_to_gray_kernel<3, true><<<grid, bsz, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
+    else rgb_to_gray_kernel<3, false><<<grid, bsz, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
   } else {
-    if (mirror) rgb_to_gray_kernel<4, true><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
-    else rgb_to_gray_kernel<4, false><<<grid, 256, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
+    if (mirror) rgb_to_gray_kernel<4, true><<<grid, bsz, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
+    else rgb_to_gray_kernel<4, false><<<grid, bsz, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
   }
   VPP_LAUNCH_CHECK();
   return VPP_OK;
