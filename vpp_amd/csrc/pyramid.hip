@@ -101,7 +101,7 @@ __device__ __forceinline__ float dpp_right(float v) { return __builtin_bit_cast(
 template <int TH, bool FUSE>
 __global__ __launch_bounds__(256) void pyr_down_f32x2_kernel(DImg next, DImg prev, uint32_t pbytes, int nstrips) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int s = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv);
+  const int s = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (int)(blockDim.x >> 6) + wv);
   if (s >= nstrips) return;
   const int c = s * kF2Out - 1 + lane;   // output column of this lane (lanes 0 / 63: halo only)
   const int r0 = blockIdx.y * TH;
@@ -198,9 +198,10 @@ int vpp_pyr_down(const vpp_image_desc* next, const vpp_image_desc* prev, void* s
       ((uintptr_t)next->first_pixel & 7) == 0 && next->pitch % 8 == 0 && tuning("pyr.f2", 1)) {
     const uint32_t pbytes = (uint32_t)((size_t)(prev->nrows + 2 * prev->border - 1) * prev->pitch + (size_t)(prev->ncols + 2 * prev->border) * 8);
     const int nstrips = (next->ncols + kF2Out - 1) / kF2Out;
-    const dim3 grid((nstrips + 3) / 4, (next->nrows + 3) / 4);   // 4 rows per wave at every size (measured 4K level 1: 8 rows 20.1 us / 88 VGPRs, 4 rows 15 us / 48)
-    if (fuse) pyr_down_f32x2_kernel<4, true><<<grid, 256, 0, st>>>(n, p, pbytes, nstrips);
-    else pyr_down_f32x2_kernel<4, false><<<grid, 256, 0, st>>>(n, p, pbytes, nstrips);
+    const int wpb = tuning("pyr.f2_waves", 4) == 1 ? 1 : (tuning("pyr.f2_waves", 4) == 2 ? 2 : 4);
+    const dim3 grid((nstrips + wpb - 1) / wpb, (next->nrows + 3) / 4);   // 4 rows per wave at every size (measured 4K level 1: 8 rows 20.1 us / 88 VGPRs, 4 rows 15 us / 48)
+    if (fuse) pyr_down_f32x2_kernel<4, true><<<grid, 64 * wpb, 0, st>>>(n, p, pbytes, nstrips);
+    else pyr_down_f32x2_kernel<4, false><<<grid, 64 * wpb, 0, st>>>(n, p, pbytes, nstrips);
     VPP_LAUNCH_CHECK();
     return fuse ? (int)VPP_OK : launch_fill_border(next, VPP_BORDER_MIRROR, nullptr, st);
   }

@@ -39,7 +39,7 @@ template <class V> __device__ __forceinline__ void border_copies2(const DImg& im
 
 template <class V, bool BORDER = false>
 __global__ __launch_bounds__(256) void scharr4_kernel(DImg out, DImg in) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 4, r = blockIdx.y;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4, r = blockIdx.y;
   if (c >= out.nc) return;
   if (c + 4 > out.nc) {  // ragged row end: per pixel
     for (int x = c; x < out.nc; x++) {
@@ -94,9 +94,11 @@ int vpp_scharr_bordered(const vpp_image_desc* out, const vpp_image_desc* in, voi
     const int rc = vpp_scharr(out, in, stream);
     return rc != VPP_OK ? rc : vpp_fill_border(out, VPP_BORDER_MIRROR, nullptr, stream);
   }
-  dim3 grid(((out->ncols + 3) / 4 + 255) / 256, out->nrows);
-  if (out->dtype == VPP_F32) scharr4_kernel<float, true><<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in));
-  else scharr4_kernel<int, true><<<grid, 256, 0, as_stream(stream)>>>(dimg(out), dimg(in));
+  // 128 lanes per workgroup (measured scharr + gradient pyramid at 1080p: 256 lanes 23.1 us, 128: 19.4-20.1, 64: 23.7; 4K: 41.4 -> 40.3)
+  const int sbt = tuning("scharr.block", 128), sb = sbt == 64 ? 64 : (sbt == 256 ? 256 : 128);
+  dim3 grid(((out->ncols + 3) / 4 + sb - 1) / sb, out->nrows);
+  if (out->dtype == VPP_F32) scharr4_kernel<float, true><<<grid, sb, 0, as_stream(stream)>>>(dimg(out), dimg(in));
+  else scharr4_kernel<int, true><<<grid, sb, 0, as_stream(stream)>>>(dimg(out), dimg(in));
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }
