@@ -769,6 +769,9 @@ template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_des
         case 42: launch_wide_cfg<CH, 2, 3, kAuxNT, false, 8, 0, 5, 5, 3>(dst, src, st, order, mix, slots); break;   // 192 threads: 3 strips
         case 52: launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0, 5, 5, 16>(dst, src, st, order, mix, slots); break;  // 1024 threads: 4 strips x 4 row blocks
         case 62: launch_wide_cfg<CH, 2, 2, kAuxNT, false, 8, 0, 5, 5, 8>(dst, src, st, order, mix, slots); break;   // 512 threads: 2 strips x 4 row blocks
+        case 72: launch_wide_cfg<CH, 2, 2, kAuxNT, false, 8, 0, 5, 5, 2>(dst, src, st, order, mix, slots); break;   // 128 threads: 2 strips side by side
+        case 82: launch_wide_cfg<CH, 2, 1, kAuxNT, false, 8, 0, 5, 5, 1>(dst, src, st, order, mix, slots); break;   // 64 threads: one strip per workgroup
+        case 92: launch_wide_cfg<CH, 2, 1, kAuxNT, false, 8, 0, 5, 5, 2>(dst, src, st, order, mix, slots); break;   // 128 threads: 1 strip x 2 row blocks
         default: done = false;
       }
     }
