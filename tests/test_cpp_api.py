@@ -86,3 +86,20 @@ def test_single_source_lambdas_on_gpu():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "device_lambda_test ok" in out.stdout
     print(out.stdout)
+
+
+def test_reference_include_paths_resolve():
+    """Every header name of the reference that is on the hot path exists under vpp_amd/include and compiles on its
+    own: an application that includes them one by one, in any order, builds."""
+    core = ["vector", "boxNd", "box2d", "boxNd_iterator", "imageNd", "imageNd_iterator", "image2d", "image3d", "window", "make_array", "tuple_utils", "relative_accessor",
+            "pixel_wise", "block_wise", "copy", "clone", "fill", "sum", "colorspace_conversions", "keypoint_container", "keypoint_trajectory", "pyramid", "symbols",
+            "symbol_definitions", "cast_to_float", "zero", "const"]
+    algos = ["fast_detector/fast", "filters/scharr", "lbp/lbp_transform", "lucas_kanade", "optical_flow", "optical_flow/gradient_descent", "pyrlk/lk", "pyrlk/pyrlk_match",
+             "symbols", "video_extruder"]
+    os.makedirs(OUT, exist_ok=True)
+    for group, names, flags in (("core", core, []), ("algorithms", algos, ["-DVPP_AMD_DEVICE", "-I" + os.path.join(ROOT, "include")])):
+        for n in names:
+            src = os.path.join(OUT, "inc_%s_%s.cc" % (group, n.replace("/", "_")))
+            with open(src, "w") as f:
+                f.write("#include <vpp/%s/%s.hh>\nint main() { return 0; }\n" % (group, n))
+            subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "vpp_amd", "include")] + flags + [src])
