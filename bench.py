@@ -19,6 +19,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): the several-frame-pairs-in-flight leg of the semi-dense flow needs one
+# queue per pair to overlap them (8 pairs: 1 460 -> 2 270 pairs/s).  Read by the runtime at initialisation, so set before torch loads it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 

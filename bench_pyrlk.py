@@ -156,6 +156,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
         same = all(bool(torch.equal(o[0], gp)) and bool(torch.equal(o[1], gd)) and bool(torch.equal(o[2], gv)) for o in outs)
         conc[str(k)] = {"frame_pairs_per_s": world / dtk, "identical_to_the_single_stream_result": same}
     res["semi_dense_flow_4k"]["concurrent_streams"] = conc
+    res["semi_dense_flow_4k"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")
 
     # frame ingest: 4K vuchar3 frame -> gray with a mirror-filled border of 3 in one pass; 4 B/px algorithmic
     from vpp_amd.synth import rand_image
