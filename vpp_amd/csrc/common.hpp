@@ -61,7 +61,7 @@ inline bool aligned16(const vpp_image_desc* d) { return ((uintptr_t)d->first_pix
 // buffers are kept; the least recently used one is released (after a device synchronise) when another stream shows up, which
 // also retires the buffers of destroyed streams.
 struct Scratch {
-  static constexpr int kSlots = 8;
+  static constexpr int kSlots = 16;   // one per (device, stream) that has called in: 8 was the ceiling of the frame-pairs-in-flight case (the 9th stream evicted — and synchronised — every call)
   // user[]: the owner's notes about what the buffer holds (e.g. "this region is zeroed"); cleared whenever the buffer is (re)allocated
   struct Slot { void* p = nullptr; size_t cap = 0; int dev = -1; hipStream_t st = nullptr; unsigned long long used = 0; unsigned long long user[4] = {0, 0, 0, 0}; };
   Slot* cur = nullptr;   // the slot of the last ensure()
