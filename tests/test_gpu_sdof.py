@@ -34,7 +34,7 @@ def run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch):
     ((96, 128), 5, 2, 0, 0, 3),      # no propagation
     ((270, 480), 9, 3, 0, 2, 5),
 ])
-@pytest.mark.parametrize("propagate_impl", [1, 2, 3])  # generic wavefront, LDS ring K=16, LDS ring K=8
+@pytest.mark.parametrize("propagate_impl", [1, 2, 4])  # generic wavefront, LDS ring, Jacobi rounds to the fixed point (default)
 def test_sdof_matches_oracle(lib, orc, shape, ws, nscales, min_scale, prop, patch, propagate_impl):
     lib.vpp_set_tuning(b"sdof.propagate", propagate_impl)
     f1, f2, kps = flow_scene(*shape)

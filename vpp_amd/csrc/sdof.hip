@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include <climits>
 #include <vector>
+#include <algorithm>
 #include <type_traits>
 #include <climits>
 using namespace vpp_amd;
@@ -677,6 +678,234 @@ __global__ __launch_bounds__(MAXT) void sdof_propagate_ring_kernel(DImg i1, DImg
   }
 }
 
+// ---- propagation as Jacobi rounds to the fixed point (round 3) --------------------------------------------------------------
+// A sweep (semi_dense_optical_flow.hpp:146-201) is an in-place raster scan: loop_body(c) reads the 4 neighbours visited earlier at their
+// post-visit values R(n) and the 4 visited later (and c itself) at their pre-sweep values: R(c) = F(c; R|earlier(c)).  The lock-step
+// wavefront of rounds 1-2 walked all 2 NI + NJ anti-diagonals (817 at the middle scale of a 4K pair, each waiting for the slowest cell of
+// the step) on ONE workgroup.  But changes are sparse and their chains are short, so the same R is reached much faster as the fixed
+// point of   S_0(c) = F(c; pre),   S_k(c) = F(c; S_{k-1}|earlier(c)):
+//   by induction over the raster order, S_k(c) = R(c) as soon as every earlier neighbour is final, and a cell whose earlier neighbours
+//   never differ from `pre` is final at k = 0 — the number of rounds is the longest chain of cells that change at all, not the length of
+//   the wavefront (measured with tools/sdof_rounds_sim.cpp, which also checks the identity against the serial sweep: 2 rounds on the
+//   4K bench scene, 5 with a keypoint in every cell, 18 on two unrelated noise frames).
+// Round k only has to visit J_k = D_{k-1} + the later neighbours of D_{k-1} (D_k = cells whose value changed in round k); every other
+// cell keeps its value.  Values are double-buffered by round parity (a round reads B[(k-1)&1] and writes B[k&1]; a cell of D_{k-1} is
+// always in J_k, which carries its value over to the other buffer), so one pass per round needs no ordering between its jobs.
+// All rounds of a sweep run in ONE launch of many workgroups: 8 lanes per job (the 8 neighbour SADs of loop_body side by side, then the
+// 8 candidates of every descent step side by side), jobs pulled from a device queue, a grid barrier between rounds.  The barrier only
+// waits for workgroups that have REGISTERED, and registration closes at the first arrival: a workgroup that was not yet resident when
+// the others finished round 0 simply leaves, so the kernel cannot deadlock whatever else shares the GPU (other streams, other ranks).
+struct SweepCtl { unsigned count[2], head[2], reg, nreg, arrive, pad; unsigned long long gen; };   // zero between sweeps (see the exits)
+constexpr unsigned kRegClosed = 0x80000000u;
+constexpr int kTagShift = 8;            // Cell::mark bits 8..: round + 1 in which the value last changed (0: unchanged this sweep)
+constexpr int kJobsPerGroup = 32;       // 256 threads / 8 lanes
+constexpr unsigned kSpinLimit = 1u << 22;   // polls of a barrier wait (seconds); see the waits
+struct RoundArrays { Cell* pre; Cell* B[2]; uint32_t* Q[2]; uint32_t* qflag[2]; SweepCtl* ctl; };
+__device__ unsigned g_round_stats[4];   // [0] rounds, [1] jobs, [2] jobs evaluated, [3] changes
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Cell load_cell16(const Cell* p) { const v4i v = *(const v4i*)p; return Cell{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void store_cell16(Cell* p, const Cell& c) { *(v4i*)p = v4i{c.f0, c.f1, c.dist, c.mark}; }
+
+// Pass over all cells: copies the pre-sweep maps into the round buffers and lists the cells whose loop_body can do anything at all
+// against the pre-sweep maps (a marked neighbour whose flow differs by more than 2 px, :164-165 with flow_map(pf) == prev_flow).
+__global__ __launch_bounds__(256) void sdof_classify_kernel(Maps m, int NI, int NJ, RoundArrays a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx == 0) { a.ctl->reg = 0; a.ctl->nreg = 0; a.ctl->arrive = 0; a.ctl->gen = 0; }   // nobody touches these during this kernel
+  bool cand = false;
+  if (idx < NI * NJ) {
+    const int ci = idx / NJ, cj = idx - ci * NJ;
+    const Cell cur = load_map_cell(m, ci, cj);
+    if (cur.mark) {
+#pragma unroll
+      for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
+        for (int dc = -1; dc <= 1; dc++) {
+          if (!dr && !dc) continue;
+          const int q0 = ci + dr, q1 = cj + dc;
+          if (q0 < 0 || q1 < 0 || q0 >= NI || q1 >= NJ) continue;
+          if (!m.mark.row<uint8_t>(q0)[q1]) continue;
+          const int32_t* f = m.flow.row<int32_t>(q0) + 2 * q1;
+          const int a0 = cur.f0 - f[0], a1 = cur.f1 - f[1];
+          if (a0 * a0 + a1 * a1 >= 9) cand = true;
+        }
+    }
+    store_cell16(a.pre + idx, cur); store_cell16(a.B[0] + idx, cur); store_cell16(a.B[1] + idx, cur);
+  }
+  const unsigned long long b = __ballot(cand);
+  if (b) {
+    const int lane = __lane_id(), leader = __ffsll((long long)b) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(&a.ctl->count[0], (unsigned)__popcll(b));
+    base = __shfl(base, leader);
+    if (cand) a.Q[0][base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+  }
+}
+
+// gradient_descent_match (gradient_descent.hh:10-89) on a group of 8 lanes (j = lane in group): the candidates of one search step side by
+// side, winner = minimum of (distance, position in the walk) — see sdof_descent_group_kernel.  `start` = distance(p, prediction, INT_MAX).
+template <class DIST>
+__device__ __forceinline__ GdMatch group_descent(DIST dist, int p0, int p1, int pr0, int pr1, int start, int j) {
+  constexpr unsigned kFirst = 0xd22406u, kEnd = 0x27fb5bu, kDr = 0x9224u, kDc = 0x16au;
+  int m0 = pr0, m1 = pr1;
+  int match_distance = start;
+  unsigned match_i = 8;
+#pragma nounroll
+  for (int search = 0; search < 5; search++) {
+    const unsigned first = (kFirst >> (3 * match_i)) & 7u, end = (kEnd >> (3 * match_i)) & 7u;
+    const unsigned count = ((end - first - 1u) & 7u) + 1u;
+    const unsigned ci = (first + (unsigned)j) & 7u;
+    const int n0 = pr0 + (int)((kDr >> (2 * ci)) & 3u) - 1, n1 = pr1 + (int)((kDc >> (2 * ci)) & 3u) - 1;
+    const int d = (unsigned)j < count ? dist(n0, n1, match_distance) : INT_MAX;
+    unsigned long long key = ((unsigned long long)(unsigned)d << 3) | (unsigned)j;
+#pragma unroll
+    for (int x = 1; x < 8; x <<= 1) {
+      const unsigned lo = __shfl_xor((unsigned)key, x), hi = __shfl_xor((unsigned)(key >> 32), x);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      key = o < key ? o : key;
+    }
+    const int best = (int)(unsigned)(key >> 3);
+    if (best < match_distance) {
+      const unsigned wi = (first + (unsigned)(key & 7u)) & 7u;
+      m0 = pr0 + (int)((kDr >> (2 * wi)) & 3u) - 1; m1 = pr1 + (int)((kDc >> (2 * wi)) & 3u) - 1;
+      match_i = wi; match_distance = best;
+    }
+    if (pr0 == m0 && pr1 == m1) break;
+    pr0 = m0; pr1 = m1;
+  }
+  return GdMatch{m0 - p0, m1 - p1, match_distance};
+}
+
+template <int WS>
+__global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats) {
+  __shared__ unsigned s_val;
+  __shared__ unsigned long long s_gen;
+  SweepCtl* const ctl = a.ctl;
+  const int tid = threadIdx.x, j = tid & 7;
+  unsigned n = ctl->count[0];   // complete: written by the classify kernel
+  if (n == 0) return;
+  const unsigned wanted = n <= (unsigned)kJobsPerGroup ? 1u : max(4u, (n + kJobsPerGroup - 1) / kJobsPerGroup);
+  if (blockIdx.x >= wanted) return;
+  if (tid == 0) s_val = __hip_atomic_fetch_add(&ctl->reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_val & kRegClosed) return;   // the others have already finished round 0: every job of it has been handed out
+  __syncthreads();
+  unsigned N = 0;   // registered workgroups (thread 0, known at the first barrier)
+  for (int k = 0;; k++) {
+    const int par = k & 1;
+    const Cell* __restrict__ Bprev = a.B[par ^ 1];
+    Cell* __restrict__ Bcur = a.B[par];
+    const uint32_t* __restrict__ Qcur = a.Q[par];
+    for (;;) {
+      if (tid == 0) s_val = __hip_atomic_fetch_add(&ctl->head[par], (unsigned)kJobsPerGroup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const unsigned base = s_val;
+      __syncthreads();
+      if (base >= n) break;
+      const unsigned job = base + (unsigned)(tid >> 3);
+      if (job < n) {
+        const int cell = (int)Qcur[job];
+        const int ci = cell / NJ, cj = cell - ci * NJ;
+        if (j == 0) a.qflag[par][cell] = 0;   // set by whoever enqueued the cell for this round (nobody enqueues for round k during round k)
+        const Cell pre = load_cell16(a.pre + cell);
+        const Cell old = load_cell16(Bprev + cell);
+        // lane j holds neighbour j in loop_body's order: (-1,-1) (-1,0) (-1,1) (0,-1) (0,1) (1,-1) (1,0) (1,1)
+        const int jj = j + (j >= 4 ? 1 : 0);
+        const int dr = jj / 3 - 1, dc = jj % 3 - 1;
+        const int q0 = ci + dr, q1 = cj + dc;
+        const bool in = q0 >= 0 && q1 >= 0 && q0 < NI && q1 < NJ;
+        const bool earlier = forward ? j < 4 : j >= 4;   // raster / reverse raster visiting order
+        Cell nb{0, 0, 0, 0};
+        if (in) nb = load_cell16((earlier ? Bprev : a.pre) + (size_t)q0 * NJ + q1);
+        const bool nbm = (nb.mark & 0xFF) != 0;
+        // does any earlier neighbour hold a value that changed in round k - 1?  (round 0: everything is evaluated once)
+        const unsigned long long grp = 0xFFull << (__lane_id() & ~7);
+        const bool need = k == 0 || (__ballot(in && earlier && (nb.mark >> kTagShift) == k) & grp) != 0;
+        Cell cur = Cell{old.f0, old.f1, old.dist, old.mark & 0xFF};
+        if (need) {
+          const int r = forward ? ci * patch : i1.nr - 1 - (NI - 1 - ci) * patch, c = forward ? cj * patch : i1.nc - 1 - (NJ - 1 - cj) * patch;
+          WindowRegs<WS> wa;
+          const bool a_ok = i1.has(r, c);
+          if (WS != 0 && a_ok) load_window<WS>(wa, i1.row<uint8_t>(r - ws / 2) + (c - ws / 2), i1.pitch);
+          auto dist = [&](int b0, int b1, int th) -> int {
+            if constexpr (WS != 0) {
+              if (!(a_ok && i2.has(b0, b1))) return INT_MAX;
+              return sad_rows_against<WS>(wa, i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2), i2.pitch, th);
+            } else return distance_fn<WS>(i1, i2, r, c, b0, b1, ws, th);
+          };
+          // static part of the test at :164-165: the neighbour is marked and differs from prev_flow; its d2 (:169) depends on nothing else
+          const int b0 = pre.f0 - nb.f0, b1 = pre.f1 - nb.f1;
+          const bool okb = nbm && b0 * b0 + b1 * b1 >= 9;
+          const int d2 = okb ? dist(r + nb.f0, c + nb.f1, INT_MAX) : INT_MAX;
+          cur = Cell{pre.f0, pre.f1, pre.dist, pre.mark & 0xFF};
+#pragma nounroll
+          for (int kk = 0; kk < 8; kk++) {   // loop_body's walk over the neighbours, uniform over the group
+            if (!__shfl((int)okb, kk, 8)) continue;
+            const int n0 = __shfl(nb.f0, kk, 8), n1 = __shfl(nb.f1, kk, 8);
+            const int a0 = cur.f0 - n0, a1 = cur.f1 - n1;
+            if (a0 * a0 + a1 * a1 < 9) continue;
+            const int d2k = __shfl(d2, kk, 8);
+            if (d2k < cur.dist) {
+              const GdMatch g = group_descent(dist, r, c, r + n0, c + n1, d2k, j);   // :173-175; its first distance is d2 itself
+              if (g.distance < cur.dist) { cur.mark = 1; cur.f0 = g.f0; cur.f1 = g.f1; cur.dist = g.distance; }   // :179-184
+            }
+          }
+        }
+        const bool changed = cur.f0 != old.f0 || cur.f1 != old.f1 || cur.dist != old.dist || cur.mark != (old.mark & 0xFF);
+        if (j == 0) {
+          store_cell16(Bcur + cell, Cell{cur.f0, cur.f1, cur.dist, cur.mark | (changed ? (k + 1) << kTagShift : 0)});
+          int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
+          f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)cur.mark;
+          if (stats) { atomicAdd(&g_round_stats[1], 1u); if (need) atomicAdd(&g_round_stats[2], 1u); if (changed) atomicAdd(&g_round_stats[3], 1u); }
+        }
+        if (changed) {   // next round: this cell (its value must reach the other buffer) and the marked cells that read it as an earlier neighbour
+          int target = -1;
+          if (j == (forward ? 0 : 7)) target = cell;                       // one of the earlier-neighbour lanes speaks for the cell itself
+          else if (!earlier && in && nbm) target = q0 * NJ + q1;
+          if (target >= 0 && __hip_atomic_exchange(&a.qflag[par ^ 1][target], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            const unsigned slot = __hip_atomic_fetch_add(&ctl->count[par ^ 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.Q[par ^ 1][slot] = (uint32_t)target;
+          }
+        }
+      }
+    }
+    // ---- grid barrier over the registered workgroups; the last arriver publishes the size of the next round with the generation
+    __syncthreads();
+    if (tid == 0) {
+      if (N == 0) {
+        const unsigned o = __hip_atomic_fetch_or(&ctl->reg, kRegClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(o & kRegClosed)) { N = o; __hip_atomic_store(&ctl->nreg, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else for (unsigned spin = 0; (N = __hip_atomic_load(&ctl->nreg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && spin < kSpinLimit; spin++) __builtin_amdgcn_s_sleep(1);
+        if (N == 0) { N = 1; ctl->pad = 1; }   // cannot happen (the closer stores nreg right after closing); never hang the GPU on a bug
+      }
+      if (N > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned arrived = __hip_atomic_fetch_add(&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long g;
+      if (arrived == N - 1) {
+        const unsigned nn = __hip_atomic_load(&ctl->count[par ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->count[par], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->head[par], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g = ((unsigned long long)(k + 1) << 32) | nn;
+        __hip_atomic_store(&ctl->gen, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (stats) atomicAdd(&g_round_stats[0], 1u);
+      } else {
+        unsigned spin = 0;
+        while (((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned long long)(k + 1) && ++spin < kSpinLimit) __builtin_amdgcn_s_sleep(1);
+        if (spin >= kSpinLimit) { g = 0; ctl->pad = 1; }   // every registered workgroup is resident and arrives: a timeout is a bug — leave instead of hanging
+      }
+      if (N > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      s_gen = g;
+    }
+    __syncthreads();
+    n = (unsigned)s_gen;
+    __syncthreads();
+    if (n == 0) break;
+  }
+}
+
 __global__ __launch_bounds__(256) void sdof_readback_kernel(const int32_t* __restrict__ kps, int n, int div, int ms, Maps m,
                                                             int32_t* __restrict__ out_pos, int32_t* __restrict__ out_dist, uint8_t* __restrict__ out_valid) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -770,6 +999,8 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
   Cell* jacobi = nullptr;
   uint8_t* skew = nullptr;
   PairCache* pairs = nullptr;
+  RoundArrays ra{};   // the fixed-point rounds' buffers, sized for the finest scale
+  size_t ra_flags_off = 0, ra_flags_bytes = 0;
   size_t mk_off[kMaxScales] = {}, mk_bytes[kMaxScales] = {}, ow_off[kMaxScales] = {}, ow_bytes[kMaxScales] = {};   // strip 0's mark / owner blocks
   for (int pass = 0; pass < 2; pass++) {
     Carver cv{pass ? (uint8_t*)g_scratch.p : nullptr};
@@ -794,6 +1025,12 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
       const size_t ni = (size_t)(i1->nrows - 1) / patchsize + 1, nj = (size_t)(i1->ncols - 1) / patchsize + 1;
       skew = cv.base ? (uint8_t*)(cv.base + cv.off) : nullptr;   // flag bytes, [(2 (NI - 1) + NJ wavefront steps) / 16][NI rows rounded up to whole waves][16]
       cv.off += (((2 * (ni - 1) + nj) / 16 + 1) * ((ni + 63) / 64 * 64) * 16 + 255) / 256 * 256;
+      auto take = [&](size_t bytes) { uint8_t* q = cv.base ? cv.base + cv.off : nullptr; cv.off += (bytes + 255) / 256 * 256; return q; };
+      ra.pre = (Cell*)take(cells * sizeof(Cell)); ra.B[0] = (Cell*)take(cells * sizeof(Cell)); ra.B[1] = (Cell*)take(cells * sizeof(Cell));
+      ra.Q[0] = (uint32_t*)take(cells * 4); ra.Q[1] = (uint32_t*)take(cells * 4);
+      ra_flags_off = cv.off;   // zero between sweeps: queue flags (self-cleaning) and the control block
+      ra.qflag[0] = (uint32_t*)take(cells * 4); ra.qflag[1] = (uint32_t*)take(cells * 4); ra.ctl = (SweepCtl*)take(sizeof(SweepCtl));
+      ra_flags_bytes = cv.off - ra_flags_off;
     }
     if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
@@ -804,6 +1041,7 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
     const unsigned long long sig = ((unsigned long long)((uint8_t*)pairs - (uint8_t*)g_scratch.p) << 20) ^ (unsigned long long)cells ^ 1ull;
     if (sl.user[0] != sig || sl.user[1] >= 0x7FFF0000ull) {
       VPP_HIP_TRY(hipMemsetAsync(pairs, 0, cells * 8 * sizeof(PairCache), st));
+      VPP_HIP_TRY(hipMemsetAsync((uint8_t*)g_scratch.p + ra_flags_off, 0, ra_flags_bytes, st));
       sl.user[0] = sig; sl.user[1] = 0;
     }
   }
@@ -868,9 +1106,16 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
       if (propagation > 0) {
         const int NI = (P1[scale].nrows - 1) / patchsize + 1;
         const int threads = (NI + 63) / 64 * 64;
-        const int mode = tuning("sdof.propagate", 0);  // 0 / 2 / 3: Jacobi + ordered flag pass, 1: generic wavefront kernel
+        const int mode = tuning("sdof.propagate", 4);  // 4: Jacobi rounds to the fixed point; 0 / 2 / 3: Jacobi + ordered flag pass, 1: generic wavefront kernel
         const int NJ = (P1[scale].ncols - 1) / patchsize + 1;
-        if (mode != 1 && NI <= 1024) {  // mode 1: the generic one-kernel wavefront (also the fallback for maps taller than 1024 cells)
+        if (mode == 4) {
+          const int cells = NI * NJ;
+          const int grid = std::min(1024, (cells + kJobsPerGroup - 1) / kJobsPerGroup);
+          for (int Ki = 0; Ki < propagation; Ki++) {
+            sdof_classify_kernel<<<(cells + 255) / 256, 256, 0, st>>>(maps(0, scale), NI, NJ, ra);
+            sdof_rounds_kernel<WS><<<grid, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, ra, tuning("sdof.stats", 0));
+          }
+        } else if (mode != 1 && NI <= 1024) {  // mode 1: the generic one-kernel wavefront (also the fallback for maps taller than 1024 cells)
           const size_t lds = (size_t)kRingGroups * threads * kGroupSteps;
           for (int Ki = 0; Ki < propagation; Ki++) {
             const int epoch = (int)++g_scratch.cur->user[1];   // one per sweep; the pair cache was zeroed for this layout (below), so 0 never matches
@@ -915,6 +1160,12 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
 }
 
 // diagnostics (not part of include/vpp_amd.h): counters of the ordered propagation pass, enabled by tuning "sdof.stats"
+extern "C" int vpp_debug_sdof_round_stats(unsigned* out4, int reset) {
+  VPP_HIP_TRY(hipDeviceSynchronize());
+  VPP_HIP_TRY(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_round_stats), 4 * sizeof(unsigned)));
+  if (reset) { unsigned z[4] = {0, 0, 0, 0}; VPP_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_round_stats), z, sizeof z)); }
+  return VPP_OK;
+}
 extern "C" int vpp_debug_sdof_stats(unsigned* out4, int reset) {
   VPP_HIP_TRY(hipDeviceSynchronize());
   VPP_HIP_TRY(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sweep_stats), 4 * sizeof(unsigned)));
