@@ -38,9 +38,9 @@ typedef enum vpp_dtype { VPP_U8 = 0, VPP_I8 = 1, VPP_U16 = 2, VPP_I16 = 3, VPP_I
 
 /* image2d<V> as seen by the device (vpp/core/imageNd.hh:17-40).  V = vector<dtype, channels>.
  * Memory contract for images in memory the caller allocated itself: the addressable area is rows -border .. nrows + border - 1 of the
- * pitch, as imageNd::allocate lays it out (imageNd.hpp:151-196), and the 16 bytes before its first byte and after its last byte must be
- * mapped device memory — the streaming stencil kernels load whole 16-byte chunks, of which the out-of-area bytes are read and never used.
- * Blocks from vpp_malloc carry that slack themselves. */
+ * pitch, as imageNd::allocate lays it out (imageNd.hpp:151-196).  The streaming stencil kernels load whole ALIGNED 16-byte granules: a
+ * granule that holds an addressable byte may extend up to 15 bytes in front of the area's first byte or past its last one.  Such bytes lie
+ * in the same page as an addressable byte, so the load cannot fault, and they are never used; nothing else outside the area is touched. */
 typedef struct vpp_image_desc {
   void*   first_pixel; /* imageNd_data::begin_ */
   int32_t nrows;       /* domain().nrows() */

@@ -284,3 +284,28 @@ def test_error_statuses(lib):
     assert b"border" in lib.vpp_last_error()
     c = DeviceImage(8, 9, vi.U8, 3)
     assert lib.vpp_pixelwise_binary(0, P(b.desc), P(b.desc), P(c.desc), None) == capi.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("dtype,ch,R,C", [(vi.U8, 3, 5, 5), (vi.U8, 1, 3, 3), (vi.U8, 4, 7, 5), (vi.I32, 1, 5, 5), (vi.F32, 1, 5, 5), (vi.I32, 1, 3, 3)])
+def test_box_source_at_the_very_start_of_an_allocation(lib, orc, dtype, ch, R, C):
+    """A source whose buffer begins exactly where its device allocation begins (a fresh torch segment, border exactly the window reach):
+    the descriptor kernels start their first chunk in the aligned 16-byte granule that holds the first row's left border (see box.hip,
+    fits_descriptor) — inside the allocation's first page, never in front of it.  Same result as the oracle, no fault."""
+    import torch
+    border = max(R, C) // 2
+    lo, hi = (0, 999) if dtype == vi.I32 else (None, None)
+    src = rand_image(301, 1777, dtype, ch, border=border, seed=9, lo=lo, hi=hi, align=32, fill_border=True)
+    want = src.like(border=0)
+    assert orc.orc_box_filter(P(want.desc), P(src.desc), R, C) == 0
+    dsrc = DeviceImage(301, 1777, dtype, ch, border=border, align=32)
+    dsrc.store = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")   # its own segment: data_ptr() is the allocation's first byte
+    dsrc.shift = 0
+    dsrc.upload(src)
+    ddst = DeviceImage.from_host(src.like(border=0))
+    capi.check(lib.vpp_box_filter(P(ddst.desc), P(dsrc.desc), R, C, capi.stream_ptr()))
+    _sync(lib)
+    got = ddst.download()
+    if dtype == vi.F32:
+        np.testing.assert_array_equal(got.view().view(np.uint32), want.view().view(np.uint32))
+    else:
+        np.testing.assert_array_equal(got.view(), want.view())

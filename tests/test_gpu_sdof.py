@@ -34,7 +34,7 @@ def run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch):
     ((96, 128), 5, 2, 0, 0, 3),      # no propagation
     ((270, 480), 9, 3, 0, 2, 5),
 ])
-@pytest.mark.parametrize("propagate_impl", [1, 2, 4])  # generic wavefront, LDS ring, Jacobi rounds to the fixed point (default)
+@pytest.mark.parametrize("propagate_impl", [0, 1])  # Jacobi rounds to the fixed point (default); lock-step wavefront on one workgroup
 def test_sdof_matches_oracle(lib, orc, shape, ws, nscales, min_scale, prop, patch, propagate_impl):
     lib.vpp_set_tuning(b"sdof.propagate", propagate_impl)
     f1, f2, kps = flow_scene(*shape)
@@ -65,8 +65,7 @@ def test_sdof_1080p_frame(lib, orc):
 
 def test_sdof_4k_bench_scene_matches_oracle(lib, orc):
     """The exact frame pair and keypoint set bench_pyrlk.py times (BASELINE configs[4] shapes): 81 748 keypoints, winsize 9, 3 scales,
-    2 sweeps.  Its middle scale holds a chain of ~900 dependent recomputations along the motion boundaries — the hard case of the
-    ordered pass."""
+    2 sweeps.  Its middle scale's first sweep changes ~350 cells along the motion boundaries (6 propagation rounds over ~4 000 jobs)."""
     lib.vpp_set_tuning(b"sdof.propagate", -1)
     f1, f2, kps = flow_scene(2160, 3840, spacing=10)
     got, want = run_both(lib, orc, f1, f2, kps, 9, 3, 0, 2, 5)
@@ -76,10 +75,8 @@ def test_sdof_4k_bench_scene_matches_oracle(lib, orc):
 
 
 @pytest.mark.parametrize("ws", [7, 9])
-def test_sdof_tall_map_uses_the_1024_thread_instance(lib, orc, ws):
-    """A flow map taller than 512 cells (1700 rows at patchsize 3: 567 cells) runs the ordered sweep in its 1024-thread instance
-    (out-of-line recomputation, 128 registers per lane) instead of the 512-thread one every smaller frame uses; taller than 1024
-    cells (patchsize 1 would be) falls to the generic wavefront kernel, covered by sdof.propagate = 1 elsewhere."""
+def test_sdof_tall_narrow_map(lib, orc, ws):
+    """A tall, narrow flow map (1700 rows at patchsize 3: 567 x 30 cells): the raster order's dependencies run mostly down the rows."""
     f1, f2, kps = flow_scene(1700, 90, seed=11 + ws, spacing=3)
     got, want = run_both(lib, orc, f1, f2, kps, ws, 2, 0, 2, 3)
     for g, w in zip(got, want):
@@ -139,3 +136,53 @@ def test_strip_sharded_flow_equals_the_single_strip_result(lib, orc, shape, nstr
         np.testing.assert_array_equal(outs[1][2], wv)
         np.testing.assert_array_equal(outs[1][0][wv == 1], wp[wv == 1])
         np.testing.assert_array_equal(outs[1][1][wv == 1], wd[wv == 1])
+
+
+def test_sdof_unrelated_noise_frames_many_rounds(lib, orc):
+    """Two unrelated noise frames with a keypoint in every cell: nearly every cell has a neighbour of a different flow, the propagation
+    needs many rounds (18 at 1080p in tools/sdof_rounds_sim.cpp) over tens of thousands of jobs — still identical to the serial sweep."""
+    rng = np.random.default_rng(1)
+    nr, nc = 540, 960
+    f1 = rng.integers(0, 256, (nr, nc)).astype(np.uint8); f2 = rng.integers(0, 256, (nr, nc)).astype(np.uint8)
+    rr, cc = np.meshgrid(np.arange(5, nr - 5, 5), np.arange(5, nc - 5, 5), indexing="ij")
+    kps = np.stack([rr.ravel(), cc.ravel()], 1).astype(np.int32)
+    for ws, nscales, prop in ((9, 3, 2), (7, 4, 4)):
+        got, want = run_both(lib, orc, f1, f2, kps, ws, nscales, 0, prop, 5)
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
+    assert hasattr(lib, "vpp_debug_sdof_round_stats")
+    lib.vpp_set_tuning(b"sdof.stats", 1)
+    st4 = (ctypes.c_uint * 4)(); lib.vpp_debug_sdof_round_stats(st4, 1)
+    run_both(lib, orc, f1, f2, kps, 9, 3, 0, 2, 5)
+    lib.vpp_debug_sdof_round_stats(st4, 1); lib.vpp_set_tuning(b"sdof.stats", 0)
+    rounds, jobs, evaluated, changes = list(st4)
+    assert rounds > 20 and jobs > 20000 and changes > 2000, list(st4)   # the hard regime really was exercised
+
+
+def test_sdof_recorded_graph_replays_on_new_frames(lib, orc):
+    """A flow call recorded into a launch graph and replayed after the frame CONTENTS changed gives the new pair's result (nothing
+    of the propagation state — queue flags, round tags, the control block — survives a call; round 2's pair-cache epochs did)."""
+    scenes = [flow_scene(240, 320, seed=41 + j, spacing=5) for j in range(3)]
+    f1, f2, kps = scenes[0]
+    d1, d2 = DeviceImage.from_host(u8_image(f1, border=3)), DeviceImage.from_host(u8_image(f2, border=3))
+    n = len(kps); dk = torch.from_numpy(kps).cuda()
+    gp = torch.zeros((n, 2), dtype=torch.int32, device="cuda"); gd = torch.zeros(n, dtype=torch.int32, device="cuda"); gv = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.Stream()
+    sp = ctypes.c_void_p(st.cuda_stream)
+    call = lambda: capi.check(lib.vpp_semi_dense_optical_flow(P(d1.desc), P(d2.desc), ctypes.c_void_p(dk.data_ptr()), n, 9, 3, 0, 2, 5,
+                                                              ctypes.c_void_p(gp.data_ptr()), ctypes.c_void_p(gd.data_ptr()), ctypes.c_void_p(gv.data_ptr()), sp))
+    call(); capi.check(lib.vpp_sync(sp))      # eager once: sizes the scratch (a capture must not allocate)
+    graph = ctypes.c_void_p()
+    capi.check(lib.vpp_graph_begin(sp)); call(); capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(graph)))
+    for (a1, a2, k2) in scenes:               # same keypoint grid, new pixels
+        assert np.array_equal(k2, kps)
+        i1, i2 = u8_image(a1, border=3), u8_image(a2, border=3)
+        d1.upload(i1); d2.upload(i2); torch.cuda.synchronize()
+        capi.check(lib.vpp_graph_launch(graph, sp)); capi.check(lib.vpp_sync(sp))
+        wp = np.zeros((n, 2), np.int32); wd = np.zeros(n, np.int32); wv = np.zeros(n, np.uint8)
+        assert orc.orc_semi_dense_optical_flow(P(i1.desc), P(i2.desc), kps.ctypes.data_as(ctypes.c_void_p), n, 9, 3, 0, 2, 5,
+                                               wp.ctypes.data_as(ctypes.c_void_p), wd.ctypes.data_as(ctypes.c_void_p), wv.ctypes.data_as(ctypes.c_void_p)) == 0
+        np.testing.assert_array_equal(gv.cpu().numpy(), wv)
+        np.testing.assert_array_equal(gp.cpu().numpy(), wp)
+        np.testing.assert_array_equal(gd.cpu().numpy(), wd)
+    capi.check(lib.vpp_graph_destroy(graph))

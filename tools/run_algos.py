@@ -24,12 +24,12 @@ gp = torch.zeros((m, 2), dtype=torch.int32, device="cuda"); gd = torch.zeros(m, 
 import time
 lib.vpp_set_tuning(b"sdof.stats", 1)
 st4 = (ctypes.c_uint * 4)()
-lib.vpp_debug_sdof_stats(st4, 1)
+lib.vpp_debug_sdof_round_stats(st4, 1)
 for i in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     capi.check(lib.vpp_semi_dense_optical_flow(P(d1.desc), P(d2.desc), V(dk.data_ptr()), m, 9, 3, 0, 2, 5, V(gp.data_ptr()), V(gd.data_ptr()), V(gv.data_ptr()), st))
     torch.cuda.synchronize(); print("sdof 4K", m, "keypoints:", (time.perf_counter() - t0) * 1e3, "ms")
-    lib.vpp_debug_sdof_stats(st4, 1); print("  sweep stats: visited %d, jacobi applied %d, slow path %d, slow changed %d" % tuple(st4))
+    lib.vpp_debug_sdof_round_stats(st4, 1); print("  propagation: %d rounds, %d jobs, %d evaluated, %d changes" % tuple(st4))
 
 # pyrLK, BASELINE configs[3]: 1080p, 3 levels, 10 000 keypoints, 7x7
 NR, NC, L, B = 1080, 1920, 3, 3

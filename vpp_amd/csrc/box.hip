@@ -687,6 +687,11 @@ int launch_generic(const vpp_image_desc* dst, const vpp_image_desc* src, int R, 
 // -DVPP_BOX_LAB) instantiates the sweep for CH == 3, the product only the configuration the sweep picked.
 // rows: RW rows per wave; mix = 1: row blocks of RW and RW - 1 rows mixed so that nstrips * nblocks <= `slots` waves (the whole
 // grid resident in one round: slots = CUs x 32 wave slots at 8 waves / SIMD).
+// Why starting a row's first chunk 16 bytes before pixel (row, 0) can never fault, whatever memory the caller handed in: these kernels
+// only run on images with first_pixel and pitch 16-byte aligned (aligned16) and border >= 1, so pixel (-border, 0) is 16-byte aligned and
+// the byte just before it is the image's own left border, i.e. addressable.  The chunk [pixel - 16, pixel) is the aligned 16-byte granule
+// that holds that byte: same page, same mapping — at worst its first 16 - border * elem_bytes bytes belong to whatever precedes the image
+// in memory; they are loaded and never used (no window reaches them).  The far end is covered by the descriptor's range check.
 inline bool fits_descriptor(const vpp_image_desc* dst, const vpp_image_desc* src) {
   const size_t lim = 0xFFFFFF00u;
   return (size_t)(src->nrows + 2 * src->border) * (size_t)src->pitch + 64 < lim && (size_t)dst->nrows * (size_t)dst->pitch < lim;

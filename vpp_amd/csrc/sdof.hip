@@ -7,9 +7,10 @@
 //   * cell claims (:114-143): the serial loop lets the LOWEST keypoint index that maps to a flow-map cell compute it.
 //     Kernel 1 takes atomicMin(index) per cell, kernel 2 runs the descent for the winners only: same result, any order.
 //   * propagation sweeps (:146-201) are in-place Gauss-Seidel scans in raster (Ki odd) / reverse raster (Ki even) order.
-//     Cell (i,j) depends on the already-updated (i-1,j-1),(i-1,j),(i-1,j+1),(i,j-1), so all cells with 2i+j = t are
-//     independent: one workgroup walks the skewed wavefront t = 0..2(NI-1)+(NJ-1) with a barrier per step — exactly the
-//     serial result, deterministic.
+//     Cell (i,j) depends on the already-updated (i-1,j-1),(i-1,j),(i-1,j+1),(i,j-1).  The result of the serial scan is computed as
+//     the fixed point of parallel Jacobi rounds over the cells whose inputs changed (sdof_classify_kernel + sdof_rounds_kernel, many
+//     workgroups, a handful of rounds); the lock-step wavefront on one workgroup (sdof_propagate_kernel: all cells with 2i+j = t are
+//     independent, one barrier per step) is kept as an independent on-device cross-check (tuning sdof.propagate = 1).
 // Integer arithmetic throughout: bit-exact.  SAD windows are L2-resident; the path is integer-VALU / latency bound.
 #include "common.hpp"
 #include <climits>
@@ -181,6 +182,40 @@ __global__ __launch_bounds__(64) void sdof_descent_kernel(const int32_t* __restr
   cur.mark.row<uint8_t>(pf0)[pf1] = 2;           // :141
 }
 
+// gradient_descent_match (gradient_descent.hh:10-89) on a group of 8 lanes (j = lane in group): the candidates of one search step side by
+// side, winner = minimum of (distance << 3 | position in the walk): the FIRST of equal minima, as the sequential strict-less rule keeps.  `start` = distance(p, prediction, INT_MAX).
+template <class DIST>
+__device__ __forceinline__ GdMatch group_descent(DIST dist, int p0, int p1, int pr0, int pr1, int start, int j) {
+  constexpr unsigned kFirst = 0xd22406u, kEnd = 0x27fb5bu, kDr = 0x9224u, kDc = 0x16au;
+  int m0 = pr0, m1 = pr1;
+  int match_distance = start;
+  unsigned match_i = 8;
+#pragma nounroll
+  for (int search = 0; search < 5; search++) {
+    const unsigned first = (kFirst >> (3 * match_i)) & 7u, end = (kEnd >> (3 * match_i)) & 7u;
+    const unsigned count = ((end - first - 1u) & 7u) + 1u;
+    const unsigned ci = (first + (unsigned)j) & 7u;
+    const int n0 = pr0 + (int)((kDr >> (2 * ci)) & 3u) - 1, n1 = pr1 + (int)((kDc >> (2 * ci)) & 3u) - 1;
+    const int d = (unsigned)j < count ? dist(n0, n1, match_distance) : INT_MAX;
+    unsigned long long key = ((unsigned long long)(unsigned)d << 3) | (unsigned)j;
+#pragma unroll
+    for (int x = 1; x < 8; x <<= 1) {
+      const unsigned lo = __shfl_xor((unsigned)key, x), hi = __shfl_xor((unsigned)(key >> 32), x);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      key = o < key ? o : key;
+    }
+    const int best = (int)(unsigned)(key >> 3);
+    if (best < match_distance) {
+      const unsigned wi = (first + (unsigned)(key & 7u)) & 7u;
+      m0 = pr0 + (int)((kDr >> (2 * wi)) & 3u) - 1; m1 = pr1 + (int)((kDc >> (2 * wi)) & 3u) - 1;
+      match_i = wi; match_distance = best;
+    }
+    if (pr0 == m0 && pr1 == m1) break;
+    pr0 = m0; pr1 = m1;
+  }
+  return GdMatch{m0 - p0, m1 - p1, match_distance};
+}
+
 // The same phase with 8 lanes per keypoint: the candidates of one search step (the 3, 5 or 8 neighbours the reference walks one after
 // the other) are evaluated by the lanes of the group side by side and the winner is the minimum of (distance << 3 | position in the
 // walk) — the sequential rule "replace on strictly smaller" keeps the FIRST of equal minima, and a candidate that the sequential walk
@@ -203,8 +238,6 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
       pr0 = p0 + f[0] * 2; pr1 = p1 + f[1] * 2;
     }
   }
-  // gradient_descent_match (gradient_descent.hh:10-89) over the group; tables as in gradient_descent_impl
-  constexpr unsigned kFirst = 0xd22406u, kEnd = 0x27fb5bu, kDr = 0x9224u, kDc = 0x16au;
   // the keypoint's own window (image 1 at p) is the same in every comparison of the walk: loaded once, the candidates cost one window each
   WindowRegs<WS> wa;
   const bool a_ok = i1.has(p0, p1);
@@ -215,36 +248,11 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
       return sad_rows_against<WS>(wa, i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2), i2.pitch, th);
     } else return distance_fn<WS>(i1, i2, p0, p1, b0, b1, ws, th);
   };
-  int m0 = pr0, m1 = pr1;
-  int match_distance = dist(pr0, pr1, INT_MAX);
-  unsigned match_i = 8;
-#pragma nounroll
-  for (int search = 0; search < 5; search++) {
-    const unsigned first = (kFirst >> (3 * match_i)) & 7u, end = (kEnd >> (3 * match_i)) & 7u;
-    const unsigned count = ((end - first - 1u) & 7u) + 1u;   // candidates first, first + 1, ... up to (not including) end, at least one; end == first: all 8
-    const unsigned ci = (first + (unsigned)j) & 7u;
-    const int n0 = pr0 + (int)((kDr >> (2 * ci)) & 3u) - 1, n1 = pr1 + (int)((kDc >> (2 * ci)) & 3u) - 1;
-    const int d = (unsigned)j < count ? dist(n0, n1, match_distance) : INT_MAX;
-    unsigned long long key = ((unsigned long long)(unsigned)d << 3) | (unsigned)j;
-#pragma unroll
-    for (int x = 1; x < 8; x <<= 1) {
-      const unsigned lo = __shfl_xor((unsigned)key, x), hi = __shfl_xor((unsigned)(key >> 32), x);
-      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-      key = o < key ? o : key;
-    }
-    const int best = (int)(unsigned)(key >> 3);
-    if (best < match_distance) {
-      const unsigned wi = (first + (unsigned)(key & 7u)) & 7u;
-      m0 = pr0 + (int)((kDr >> (2 * wi)) & 3u) - 1; m1 = pr1 + (int)((kDc >> (2 * wi)) & 3u) - 1;
-      match_i = wi; match_distance = best;
-    }
-    if (pr0 == m0 && pr1 == m1) break;
-    pr0 = m0; pr1 = m1;
-  }
+  const GdMatch g = group_descent(dist, p0, p1, pr0, pr1, dist(pr0, pr1, INT_MAX), j);
   if (j != 0) return;
   int32_t* f = cur.flow.row<int32_t>(pf0) + 2 * pf1;
-  f[0] = m0 - p0; f[1] = m1 - p1;                  // :137-139
-  cur.dist.row<int32_t>(pf0)[pf1] = match_distance;  // :140
+  f[0] = g.f0; f[1] = g.f1;                        // :137-139
+  cur.dist.row<int32_t>(pf0)[pf1] = g.distance;    // :140
   cur.mark.row<uint8_t>(pf0)[pf1] = 2;               // :141
 }
 
@@ -299,383 +307,13 @@ __global__ __launch_bounds__(1024) void sdof_propagate_kernel(DImg i1, DImg i2, 
   }
 }
 
-// ---- propagation: speculative (Jacobi) evaluation + ordered validation -------------------------------------------------
-// A sweep visits the cells in raster (or reverse raster) order and loop_body(cell) reads its 8 neighbours: the 4 visited
-// earlier hold their post-visit values, the 4 visited later their pre-sweep values.  Hence loop_body(cell) evaluated
-// against the PRE-sweep maps (all cells in parallel: sdof_jacobi_kernel) is exactly the sequential result unless one of
-// the 4 earlier neighbours was changed during this sweep.  The ordered pass (sdof_propagate_ring_kernel, skewed wavefront,
-// one barrier per step) therefore only checks four "changed" flags per cell and applies the precomputed outcome; it
-// re-runs loop_body in place (SADs and all) only for cells behind a neighbour that really changed.  Same result as the
-// serial reference, but the 81-pixel SADs no longer sit on the critical path of the wavefront.
-struct Cell { int f0, f1, dist, mark; };  // mark: low byte = flow_map_mark value, bit 8 = changed during this sweep
-constexpr int kChanged = 0x100;  // Jacobi result array only: the Jacobi pass changed this cell
-constexpr int kJChanged = 0x200;  // Jacobi kernel only: its pass wants to change this cell
-// flag byte of a cell in the skewed array / the LDS ring of the ordered pass
-constexpr int kFlagMarked = 1, kFlagJChanged = 2, kFlagDirty = 4;
-
-// Per (cell, neighbour) results of the costly calls of loop_body, keyed by the neighbour flow they were computed for.
-struct PairCache { int nf0, nf1, d2, gf0, gf1, gdist, flags, epoch; };  // flags: 1 = entry valid, 2 = descent result present; epoch: the sweep that recorded it
-// An entry counts only if its epoch is the current sweep's: the Jacobi pass used to clear the flags of all 8 entries of EVERY cell first —
-// 2.6 M scattered 4-byte stores per 4K sweep for entries that are almost never written.  (Epochs come from a counter kept with the
-// scratch buffer; the array is zeroed when the buffer or its layout changes, so no stale bytes can pass for the current epoch.)
-
-// loop_body (semi_dense_optical_flow.hpp:149-189) for the cell at image point (r, c); nbr(dr, dc) returns the neighbour
-// cell at flow-map offset (dr, dc) (mark 0 when outside the map).  distance() and gradient_descent_match() depend only on
-// (r, c) and on the neighbour's flow: RECORD stores them in pc[8] (Jacobi pass), otherwise pc[8] is consulted and a
-// result is recomputed only when the neighbour's flow is no longer the one it was computed for.  Returns true when the
-// cell was updated.
-// DIST(r2, c2) = distance(p, (r2, c2)) with th = INT_MAX, GD(r2, c2) = gradient_descent_match(p, prediction (r2, c2), 5): the
-// Jacobi pass inlines them, the recomputation of the ordered sweep calls its out-of-line copies.
-template <bool RECORD, class NB, class DIST, class GD>
-__device__ __forceinline__ bool loop_body(int r, int c, Cell& cur, NB nbr, PairCache* pc, DIST dist, GD gd, int epoch) {
-  const int prev0 = cur.f0, prev1 = cur.f1;
-  bool changed = false;
-  int k = -1;
-#pragma unroll
-  for (int dr = -1; dr <= 1; dr++)
-#pragma unroll
-    for (int dc = -1; dc <= 1; dc++) {
-      if (!dr && !dc) continue;
-      k++;
-      const Cell nb = nbr(dr, dc);
-      if (!(nb.mark & 0xFF)) continue;
-      const int a0 = cur.f0 - nb.f0, a1 = cur.f1 - nb.f1, b0 = prev0 - nb.f0, b1 = prev1 - nb.f1;
-      if (a0 * a0 + a1 * a1 >= 9 && b0 * b0 + b1 * b1 >= 9) {  // Eigen's integer norm(): (int)sqrt(s) > 2  <=>  s >= 9
-        const int d1 = cur.dist;
-        PairCache e; e.flags = 0;
-        if (!RECORD) { e = pc[k]; if (!((e.flags & 1) && e.epoch == epoch && e.nf0 == nb.f0 && e.nf1 == nb.f1)) e.flags = 0; }
-        const int d2 = (e.flags & 1) ? e.d2 : dist(r + nb.f0, c + nb.f1);
-        GdMatch g{0, 0, 0};
-        bool have_g = false;
-        if (d2 < d1) {
-          if (e.flags & 2) g = GdMatch{e.gf0, e.gf1, e.gdist};
-          else g = gd(r + nb.f0, c + nb.f1);
-          have_g = true;
-          if (g.distance < d1) { cur.mark = 1; cur.f0 = g.f0; cur.f1 = g.f1; cur.dist = g.distance; changed = true; }
-        }
-        if (RECORD) pc[k] = PairCache{nb.f0, nb.f1, d2, g.f0, g.f1, g.distance, have_g ? 3 : 1, epoch};
-      }
-    }
-  return changed;
-}
+struct Cell { int f0, f1, dist, mark; };  // mark: low byte = flow_map_mark value; bits 8.. see kTagShift
 
 __device__ __forceinline__ Cell load_map_cell(const Maps& m, int ci, int cj) {
   Cell c;
   const int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
   c.f0 = f[0]; c.f1 = f[1]; c.dist = m.dist.row<int32_t>(ci)[cj]; c.mark = m.mark.row<uint8_t>(ci)[cj];
   return c;
-}
-
-template <int WS>
-__global__ __launch_bounds__(256) void sdof_jacobi_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int NI, int NJ, int forward,
-                                                          Cell* __restrict__ J, PairCache* __restrict__ pairs, uint8_t* __restrict__ skew, int NIp, int epoch) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= NI * NJ) return;
-  const int ci = idx / NJ, cj = idx - ci * NJ;
-  Cell cur = load_map_cell(m, ci, cj);
-  Cell pre = cur;
-  if (cur.mark) {
-    int r, c;
-    if (forward) { r = ci * patch; c = cj * patch; } else { r = i1.nr - 1 - (NI - 1 - ci) * patch; c = i1.nc - 1 - (NJ - 1 - cj) * patch; }
-    auto nbr = [&](int dr, int dc) -> Cell {
-      const int q0 = ci + dr, q1 = cj + dc;
-      if (q0 < 0 || q1 < 0 || q0 >= NI || q1 >= NJ) return Cell{0, 0, 0, 0};
-      return load_map_cell(m, q0, q1);
-    };
-    auto dist = [&](int r2, int c2) { return distance_fn<WS>(i1, i2, r, c, r2, c2, ws, INT_MAX); };
-    auto gd = [&](int r2, int c2) { return gradient_descent_match<WS>(i1, i2, ws, r, c, r2, c2, 5); };
-    if (loop_body<true>(r, c, cur, nbr, pairs + (size_t)idx * 8, dist, gd, epoch)) { cur.mark |= kChanged; pre.mark |= kJChanged; }
-  }
-  J[idx] = cur;
-  // the pre-sweep cell (+ "Jacobi wants to change it") in the ordered pass's visiting layout: step-major, wavefront row minor,
-  // so that at every step the rows of the wavefront read one contiguous run of 16-byte records
-  const int iw = forward ? ci : NI - 1 - ci, jw = forward ? cj : NJ - 1 - cj;
-  const int t = 2 * iw + jw;
-  skew[((size_t)(t >> 4) * NIp + iw) * 16 + (t & 15)] = (uint8_t)(((pre.mark & 0xFF) ? kFlagMarked : 0) | ((pre.mark & kJChanged) ? kFlagJChanged : 0));
-}
-
-// The ordered pass keeps ONE flag byte per cell in LDS (marked? Jacobi wants to change it? dirty?) — all the common path needs.
-// Sixteen consecutive wavefront steps of a row share a 16-byte record, [step / 16][row][step % 16], so that one LDS-direct
-// dwordx4 load per wave brings the flags of its 64 rows for 16 steps: the cost of a step used to be the LDS-DMA instruction
-// itself (~100 cycles each, one per wave and step, serialised on the CU), and before that the 7 KB of whole cells per step
-// that the one CU running the pass had to pull (a single CU draws only ~10 B/cycle from beyond its L2).
-constexpr int kGroupSteps = 16, kRingGroups = 4;
-__device__ __forceinline__ int flag_byte_index(int NIp, int row, int t) { return (((t >> 4) & (kRingGroups - 1)) * NIp + row) * kGroupSteps + (t & 15); }
-
-// A cell of the flow maps as the other waves of this workgroup left it: changed cells are written to the global maps at their
-// step and their stores have completed before the step's barrier, so an L1-bypassing (agent-scope) load after the barrier sees
-// them; cells not yet visited in this sweep hold their pre-sweep values — exactly what loop_body must read.
-__device__ __forceinline__ Cell load_map_cell_coherent(const Maps& m, int ci, int cj) {
-  Cell c;
-  const int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
-  c.f0 = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  c.f1 = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  c.dist = __hip_atomic_load(m.dist.row<int32_t>(ci) + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  c.mark = __hip_atomic_load(m.mark.row<uint8_t>(ci) + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return c;
-}
-
-// Slow path of the ordered pass (a neighbour visited earlier was changed): loop_body against the current maps.  Kept out of
-// line so that the per-step code stays small.  The cell, its eight neighbours and its eight pair-cache entries are fetched
-// up front, back to back: one memory round trip instead of dependent ones on the critical path of the wavefront.
-struct SlowResult { Cell cell; int changed; };
-// Arguments of the out-of-line functions are small structs BY VALUE (registers) holding global-address-space pointers: through
-// `const DImg&` every call began with a round trip to the caller's stack for the descriptor fields and every pixel load was a
-// flat_load; the recomputation chain is latency, not throughput.
-#define VPP_GLOBAL __attribute__((address_space(1)))
-typedef const VPP_GLOBAL uint8_t* gcu8;
-struct FramePair { gcu8 p1, p2; int pitch1, pitch2, nr1, nc1, nr2, nc2; };
-struct MapsG { const VPP_GLOBAL int32_t* flow; const VPP_GLOBAL uint8_t* mark; const VPP_GLOBAL int32_t* dist; int fpitch, mpitch, dpitch; };
-struct __attribute__((packed)) PackedU32 { uint32_t v; };
-
-// sad_rows / distance_fn on a FramePair (same arithmetic, global loads)
-template <int WS>
-__device__ __forceinline__ int distance_g(const FramePair& f, int a0, int a1, int b0, int b1, int ws, int th) {
-  if (!(a0 >= 0 && a1 >= 0 && a0 < f.nr1 && a1 < f.nc1 && b0 >= 0 && b1 >= 0 && b0 < f.nr2 && b1 < f.nc2)) return INT_MAX;
-  gcu8 row1 = f.p1 + (ptrdiff_t)(a0 - ws / 2) * f.pitch1 + (a1 - ws / 2);
-  gcu8 row2 = f.p2 + (ptrdiff_t)(b0 - ws / 2) * f.pitch2 + (b1 - ws / 2);
-  if constexpr (WS != 0) {
-    constexpr int ND = (WS + 3) / 4;
-    constexpr uint32_t tail_mask = (WS % 4) ? ((1u << (8 * (WS % 4))) - 1u) : 0xFFFFFFFFu;
-    uint32_t a[WS][ND], b[WS][ND];
-#pragma unroll
-    for (int r = 0; r < WS; r++)
-#pragma unroll
-      for (int d = 0; d < ND; d++) {
-        a[r][d] = ((const VPP_GLOBAL PackedU32*)(row1 + (ptrdiff_t)r * f.pitch1 + 4 * d))->v;
-        b[r][d] = ((const VPP_GLOBAL PackedU32*)(row2 + (ptrdiff_t)r * f.pitch2 + 4 * d))->v;
-      }
-    int err = 0;
-#pragma unroll
-    for (int r = 0; r < WS; r++) {
-      if (err <= th) {
-        uint32_t err2 = 0;
-#pragma unroll
-        for (int d = 0; d < ND; d++) {
-          const uint32_t m = d == ND - 1 ? tail_mask : 0xFFFFFFFFu;
-          err2 = __builtin_amdgcn_sad_u8(a[r][d] & m, b[r][d] & m, err2);
-        }
-        err += (int)err2;
-      }
-    }
-    return err;
-  } else {
-    int err = 0;
-    for (int r = 0; r < ws && err <= th; r++) {
-      int err2 = 0;
-      for (int c = 0; c < ws; c++) err2 += abs((int)row1[c] - (int)row2[c]);
-      err += err2;
-      row1 += f.pitch1; row2 += f.pitch2;
-    }
-    return err;
-  }
-}
-// Out of line only in the 1024-thread instance (128 registers per lane: inlining there would spill); the <= 512-thread instance has
-// 256 registers and runs the whole recomputation inline — measured same-box on the 4K scene: all out of line 2.64 ms, descent + SAD
-// inline 2.44 ms, everything inline 2.38 ms.
-template <int WS, int MAXT>
-__device__ __noinline__ int distance_noinline(FramePair f, int a0, int a1, int b0, int b1, int ws, int th) { return distance_g<WS>(f, a0, a1, b0, b1, ws, th); }
-template <int WS, int MAXT>
-__device__ __forceinline__ int distance_outlined(const FramePair& f, int a0, int a1, int b0, int b1, int ws, int th) {
-  if constexpr (MAXT > 512) return distance_noinline<WS, MAXT>(f, a0, a1, b0, b1, ws, th);
-  else return distance_g<WS>(f, a0, a1, b0, b1, ws, th);
-}
-template <int WS, int MAXT>
-__device__ __forceinline__ GdMatch gradient_descent_window(const FramePair& f, int ws, int p0, int p1, int pr0, int pr1, int max_iteration) {
-  if constexpr (WS != 0) {
-    // every candidate of the descent is compared with the same window of frame 1: it is loaded once, a candidate costs the
-    // loads of its frame-2 window only (the loads, not the arithmetic, are what a single-lane SAD waits for)
-    constexpr int ND = (WS + 3) / 4;
-    constexpr uint32_t tail_mask = (WS % 4) ? ((1u << (8 * (WS % 4))) - 1u) : 0xFFFFFFFFu;
-    const bool a_ok = p0 >= 0 && p1 >= 0 && p0 < f.nr1 && p1 < f.nc1;
-    uint32_t a[WS][ND];
-    gcu8 row1 = f.p1 + (ptrdiff_t)(p0 - WS / 2) * f.pitch1 + (p1 - WS / 2);
-#pragma unroll
-    for (int r = 0; r < WS; r++)
-#pragma unroll
-      for (int d = 0; d < ND; d++) a[r][d] = a_ok ? ((const VPP_GLOBAL PackedU32*)(row1 + (ptrdiff_t)r * f.pitch1 + 4 * d))->v & (d == ND - 1 ? tail_mask : 0xFFFFFFFFu) : 0u;
-    auto distance_of = [&](int n0, int n1, int th) -> int {
-      if (!(a_ok && n0 >= 0 && n1 >= 0 && n0 < f.nr2 && n1 < f.nc2)) return INT_MAX;
-      gcu8 row2 = f.p2 + (ptrdiff_t)(n0 - WS / 2) * f.pitch2 + (n1 - WS / 2);
-      uint32_t b[WS][ND];
-#pragma unroll
-      for (int r = 0; r < WS; r++)
-#pragma unroll
-        for (int d = 0; d < ND; d++) b[r][d] = ((const VPP_GLOBAL PackedU32*)(row2 + (ptrdiff_t)r * f.pitch2 + 4 * d))->v;
-      int err = 0;
-#pragma unroll
-      for (int r = 0; r < WS; r++) {
-        if (err <= th) {
-          uint32_t err2 = 0;
-#pragma unroll
-          for (int d = 0; d < ND; d++) err2 = __builtin_amdgcn_sad_u8(a[r][d], b[r][d] & (d == ND - 1 ? tail_mask : 0xFFFFFFFFu), err2);
-          err += (int)err2;
-        }
-      }
-      return err;
-    };
-    return gradient_descent_impl<WS>(distance_of, p0, p1, pr0, pr1, max_iteration);
-  } else {
-    return gradient_descent_impl<WS>([&](int n0, int n1, int th) { return distance_g<WS>(f, p0, p1, n0, n1, ws, th); }, p0, p1, pr0, pr1, max_iteration);
-  }
-}
-
-template <int WS, int MAXT>
-__device__ __noinline__ GdMatch gradient_descent_noinline(FramePair f, int ws, int p0, int p1, int pr0, int pr1, int max_iteration) {
-  return gradient_descent_window<WS, MAXT>(f, ws, p0, p1, pr0, pr1, max_iteration);
-}
-template <int WS, int MAXT>
-__device__ __forceinline__ GdMatch gradient_descent_outlined(const FramePair& f, int ws, int p0, int p1, int pr0, int pr1, int max_iteration) {
-  if constexpr (MAXT > 512) return gradient_descent_noinline<WS, MAXT>(f, ws, p0, p1, pr0, pr1, max_iteration);
-  else return gradient_descent_window<WS, MAXT>(f, ws, p0, p1, pr0, pr1, max_iteration);
-}
-
-__device__ __forceinline__ Cell load_map_cell_coherent(const MapsG& m, int ci, int cj) {
-  Cell c;
-  const VPP_GLOBAL int32_t* f = (const VPP_GLOBAL int32_t*)((gcu8)m.flow + (ptrdiff_t)ci * m.fpitch) + 2 * cj;
-  c.f0 = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  c.f1 = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  c.dist = __hip_atomic_load((const VPP_GLOBAL int32_t*)((gcu8)m.dist + (ptrdiff_t)ci * m.dpitch) + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  c.mark = __hip_atomic_load(m.mark + (ptrdiff_t)ci * m.mpitch + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return c;
-}
-
-template <int WS, int MAXT>
-__device__ __forceinline__ SlowResult sweep_slow_path_body(const FramePair& f, const MapsG& m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc, int epoch) {
-  Cell nb8[8];
-  int k = 0;
-#pragma unroll
-  for (int dr = -1; dr <= 1; dr++)
-#pragma unroll
-    for (int dc = -1; dc <= 1; dc++) {
-      if (!dr && !dc) continue;
-      const int q0 = ci + dr, q1 = cj + dc;
-      nb8[k] = Cell{0, 0, 0, 0};
-      if (q0 >= 0 && q1 >= 0 && q0 < NI && q1 < NJ) nb8[k] = load_map_cell_coherent(m, q0, q1);
-      k++;
-    }
-  Cell cur = load_map_cell_coherent(m, ci, cj);
-  PairCache loc[8];
-#pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const VPP_GLOBAL int* e = (const VPP_GLOBAL int*)pc + 8 * q;
-    loc[q] = PairCache{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]};
-  }
-  auto nbr = [&](int dr, int dc) -> Cell { return nb8[(dr + 1) * 3 + (dc + 1) - ((dr > 0 || (dr == 0 && dc > 0)) ? 1 : 0)]; };
-  auto dist = [&](int r2, int c2) { return distance_outlined<WS, MAXT>(f, r, c, r2, c2, ws, INT_MAX); };
-  auto gd = [&](int r2, int c2) { return gradient_descent_outlined<WS, MAXT>(f, ws, r, c, r2, c2, 5); };
-  const bool changed = loop_body<false>(r, c, cur, nbr, loc, dist, gd, epoch);
-  return SlowResult{cur, changed ? 1 : 0};
-}
-
-template <int WS, int MAXT>
-__device__ __noinline__ SlowResult sweep_slow_path_noinline(FramePair f, MapsG m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc, int epoch) {
-  return sweep_slow_path_body<WS, MAXT>(f, m, ws, r, c, ci, cj, NI, NJ, pc, epoch);
-}
-template <int WS, int MAXT>
-__device__ __forceinline__ SlowResult sweep_slow_path(const FramePair& f, const MapsG& m, int ws, int r, int c, int ci, int cj, int NI, int NJ, const VPP_GLOBAL PairCache* pc, int epoch) {
-  if constexpr (MAXT > 512) return sweep_slow_path_noinline<WS, MAXT>(f, m, ws, r, c, ci, cj, NI, NJ, pc, epoch);
-  else return sweep_slow_path_body<WS, MAXT>(f, m, ws, r, c, ci, cj, NI, NJ, pc, epoch);
-}
-
-// Ordered pass.  Thread = wavefront row: at step t it visits wavefront column t - 2*row, so data only flows between
-// adjacent threads.  The flag bytes of steps 16g .. 16g+15 are group g of the skewed array written by sdof_jacobi_kernel; a
-// group is copied into ring slot g & 3 by one LDS-direct load per wave (global_load_lds_dwordx4: no VGPR destination), two
-// groups ahead.  A cell that changes writes the global maps and flags its four later neighbours dirty (steps t+1 .. t+3: at
-// most one group ahead, already resident).  A 16-step group in which no row has a cell to apply or recompute is skipped
-// whole (one 16-byte LDS read, one barrier); only the other groups are walked step by step with a barrier per step.
-__device__ unsigned g_sweep_stats[4];  // [0] unused, [1] Jacobi outcomes applied, [2] slow-path recomputations, [3] slow-path changes
-
-template <int WS, int MAXT>
-__global__ __launch_bounds__(MAXT) void sdof_propagate_ring_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward,
-                                                                   const Cell* __restrict__ J, PairCache* __restrict__ pairs,
-                                                                   const uint8_t* __restrict__ skew, int NIp, int stats, int epoch) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // [kRingGroups][NIp][16]
-  const int NI = (i1.nr - 1) / patch + 1, NJ = (i1.nc - 1) / patch + 1;
-  const int iw = threadIdx.x;
-  const bool row_ok = iw < NI;
-  const int ci = forward ? iw : NI - 1 - iw;  // flow-map row of this thread
-  const int tmax = 2 * (NI - 1) + (NJ - 1), gmax = tmax >> 4;
-  const int wave_base = (int)threadIdx.x & ~63;
-  __shared__ int noisy_word[3];  // per group: bit u = step 16 g + u has a cell to apply or recompute (rotating, zeroed one group ahead of their first use)
-  auto issue = [&](int g) {  // g is uniform; each wave copies the 16-byte records of its 64 rows (lane L lands at dst + 16 L)
-    if (g > gmax) return;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(skew + ((size_t)g * NIp + threadIdx.x) * kGroupSteps),
-                                     (__attribute__((address_space(3))) void*)(ring + ((size_t)(g & (kRingGroups - 1)) * NIp + wave_base) * kGroupSteps), 16, 0, 0);
-  };
-  auto flag_dirty = [&](int drow, int col) {  // two rows can flag the same cell in one step, and a word holds four cells: LDS atomic
-    const int r = iw + drow;
-    if (r < NI && col >= 0 && col < NJ) {
-      const int tt = 2 * r + col, b = flag_byte_index(NIp, r, tt);
-      atomicOr((uint32_t*)(ring + (b & ~3)), (uint32_t)kFlagDirty << (8 * (b & 3)));
-      atomicOr(&noisy_word[(tt >> 4) % 3], 1 << (tt & 15));  // that step (this group or the next) now has work
-    }
-  };
-  if (threadIdx.x < 3) noisy_word[threadIdx.x] = 0;
-  issue(0); issue(1);
-  for (int g = 0; g <= gmax; g++) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): group g + 1 (requested one group ago) and the warm-up are in LDS
-    __syncthreads();
-    issue(g + 2);                         // replaces group g - 2, last read at step 16 (g - 2) + 15
-    // Step mask of the group: a marked cell does something only if the Jacobi pass wants to change it or an earlier neighbour
-    // made it dirty; a step at which no row has such a cell changes nothing and flags nothing and is not executed at all — a quiet
-    // group costs one 16-byte LDS read and one barrier.  (Dirty flags set during earlier groups are already in the ring and in
-    // the mask word.)
-    {
-      int mine = 0;
-      if (row_ok) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 rec = *(const u32x4*)(ring + ((size_t)(g & (kRingGroups - 1)) * NIp + iw) * kGroupSteps);
-        const uint32_t d[4] = {rec.x, rec.y, rec.z, rec.w};
-#pragma unroll
-        for (int u = 0; u < kGroupSteps; u++) {
-          const int jw = g * kGroupSteps + u - 2 * iw;
-          const uint32_t b = (d[u >> 2] >> (8 * (u & 3))) & 0xFFu;
-          if (jw >= 0 && jw < NJ && (b & kFlagMarked) && (b & (kFlagJChanged | kFlagDirty))) mine |= 1 << u;
-        }
-      }
-      if (threadIdx.x == 0) noisy_word[(g + 2) % 3] = 0;   // group g + 2's word: last read during group g - 1, first flagged during g + 1
-      if (mine) atomicOr(&noisy_word[g % 3], mine);
-      __syncthreads();
-    }
-    // Walk only the steps that have work.  A step's changes can add steps u+1 .. u+3 (or the first steps of the next group) to the
-    // mask, never the step being executed or an earlier one, so every thread derives the same sequence from its own reads.
-    int u = 0;
-    while (true) {
-      const int rem = (noisy_word[g % 3] >> u) << u;
-      if (!rem) break;
-      u = __ffs(rem) - 1;
-      const int t = g * kGroupSteps + u;
-      const int jw = t - 2 * iw;
-      if (row_ok && t <= tmax && jw >= 0 && jw < NJ) {
-        const int w = ring[flag_byte_index(NIp, iw, t)];
-        if ((w & kFlagMarked) && (w & (kFlagJChanged | kFlagDirty))) {
-          const int cj = forward ? jw : NJ - 1 - jw;
-          Cell cur = Cell{0, 0, 0, 0};
-          bool changed = false;
-          if (!(w & kFlagDirty)) {  // none of the four neighbours visited earlier changed: the Jacobi outcome is the sequential one
-            cur = J[(size_t)ci * NJ + cj]; changed = true;
-            if (stats) atomicAdd(&g_sweep_stats[1], 1u);
-          } else {
-            const int pr = forward ? ci * patch : i1.nr - 1 - (NI - 1 - ci) * patch, pcol = forward ? cj * patch : i1.nc - 1 - (NJ - 1 - cj) * patch;
-            const SlowResult sr = sweep_slow_path<WS, MAXT>(FramePair{(gcu8)i1.p0, (gcu8)i2.p0, i1.pitch, i2.pitch, i1.nr, i1.nc, i2.nr, i2.nc},
-                                                      MapsG{(const VPP_GLOBAL int32_t*)m.flow.p0, (const VPP_GLOBAL uint8_t*)m.mark.p0, (const VPP_GLOBAL int32_t*)m.dist.p0, m.flow.pitch, m.mark.pitch, m.dist.pitch},
-                                                      ws, pr, pcol, ci, cj, NI, NJ, (const VPP_GLOBAL PairCache*)(pairs + ((size_t)ci * NJ + cj) * 8), epoch);
-            cur = sr.cell; changed = sr.changed != 0;
-            if (stats) { atomicAdd(&g_sweep_stats[2], 1u); if (changed) atomicAdd(&g_sweep_stats[3], 1u); }
-          }
-          if (changed) {
-            int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
-            f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)(cur.mark & 0xFF);
-            // tell the four cells that are visited later and read this one
-            flag_dirty(0, jw + 1); flag_dirty(1, jw - 1); flag_dirty(1, jw); flag_dirty(1, jw + 1);
-          }
-        }
-      }
-      __syncthreads();  // includes s_waitcnt vmcnt(0): the stores of a changed cell have completed before anyone reads them
-      u++;
-    }
-  }
 }
 
 // ---- propagation as Jacobi rounds to the fixed point (round 3) --------------------------------------------------------------
@@ -740,40 +378,6 @@ __global__ __launch_bounds__(256) void sdof_classify_kernel(Maps m, int NI, int 
     base = __shfl(base, leader);
     if (cand) a.Q[0][base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)idx;
   }
-}
-
-// gradient_descent_match (gradient_descent.hh:10-89) on a group of 8 lanes (j = lane in group): the candidates of one search step side by
-// side, winner = minimum of (distance, position in the walk) — see sdof_descent_group_kernel.  `start` = distance(p, prediction, INT_MAX).
-template <class DIST>
-__device__ __forceinline__ GdMatch group_descent(DIST dist, int p0, int p1, int pr0, int pr1, int start, int j) {
-  constexpr unsigned kFirst = 0xd22406u, kEnd = 0x27fb5bu, kDr = 0x9224u, kDc = 0x16au;
-  int m0 = pr0, m1 = pr1;
-  int match_distance = start;
-  unsigned match_i = 8;
-#pragma nounroll
-  for (int search = 0; search < 5; search++) {
-    const unsigned first = (kFirst >> (3 * match_i)) & 7u, end = (kEnd >> (3 * match_i)) & 7u;
-    const unsigned count = ((end - first - 1u) & 7u) + 1u;
-    const unsigned ci = (first + (unsigned)j) & 7u;
-    const int n0 = pr0 + (int)((kDr >> (2 * ci)) & 3u) - 1, n1 = pr1 + (int)((kDc >> (2 * ci)) & 3u) - 1;
-    const int d = (unsigned)j < count ? dist(n0, n1, match_distance) : INT_MAX;
-    unsigned long long key = ((unsigned long long)(unsigned)d << 3) | (unsigned)j;
-#pragma unroll
-    for (int x = 1; x < 8; x <<= 1) {
-      const unsigned lo = __shfl_xor((unsigned)key, x), hi = __shfl_xor((unsigned)(key >> 32), x);
-      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-      key = o < key ? o : key;
-    }
-    const int best = (int)(unsigned)(key >> 3);
-    if (best < match_distance) {
-      const unsigned wi = (first + (unsigned)(key & 7u)) & 7u;
-      m0 = pr0 + (int)((kDr >> (2 * wi)) & 3u) - 1; m1 = pr1 + (int)((kDc >> (2 * wi)) & 3u) - 1;
-      match_i = wi; match_distance = best;
-    }
-    if (pr0 == m0 && pr1 == m1) break;
-    pr0 = m0; pr1 = m1;
-  }
-  return GdMatch{m0 - p0, m1 - p1, match_distance};
 }
 
 template <int WS>
@@ -996,9 +600,6 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
   auto MK = [&](int k, int s_) -> vpp_image_desc& { return MKs[(size_t)k * kMaxScales + s_]; };
   auto DM = [&](int k, int s_) -> vpp_image_desc& { return DMs[(size_t)k * kMaxScales + s_]; };
   auto OW = [&](int k, int s_) -> vpp_image_desc& { return OWs[(size_t)k * kMaxScales + s_]; };
-  Cell* jacobi = nullptr;
-  uint8_t* skew = nullptr;
-  PairCache* pairs = nullptr;
   RoundArrays ra{};   // the fixed-point rounds' buffers, sized for the finest scale
   size_t ra_flags_off = 0, ra_flags_bytes = 0;
   size_t mk_off[kMaxScales] = {}, mk_bytes[kMaxScales] = {}, ow_off[kMaxScales] = {}, ow_bytes[kMaxScales] = {};   // strip 0's mark / owner blocks
@@ -1016,15 +617,8 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
       }
       fr = 1 + fr / 2; fc = 1 + fc / 2; ir = 1 + ir / 2; ic = 1 + ic / 2;  // pyramid.hh:154
     }
-    {  // Jacobi outcomes: one cell per flow-map cell of the finest scale
+    {  // the rounds' buffers: one entry per cell of the finest scale's sweep domain
       const size_t cells = (size_t)((i1->nrows - 1) / patchsize + 1) * ((i1->ncols - 1) / patchsize + 1);
-      jacobi = cv.base ? (Cell*)(cv.base + cv.off) : nullptr;
-      cv.off += (cells * sizeof(Cell) + 255) / 256 * 256;
-      pairs = cv.base ? (PairCache*)(cv.base + cv.off) : nullptr;
-      cv.off += (cells * 8 * sizeof(PairCache) + 255) / 256 * 256;
-      const size_t ni = (size_t)(i1->nrows - 1) / patchsize + 1, nj = (size_t)(i1->ncols - 1) / patchsize + 1;
-      skew = cv.base ? (uint8_t*)(cv.base + cv.off) : nullptr;   // flag bytes, [(2 (NI - 1) + NJ wavefront steps) / 16][NI rows rounded up to whole waves][16]
-      cv.off += (((2 * (ni - 1) + nj) / 16 + 1) * ((ni + 63) / 64 * 64) * 16 + 255) / 256 * 256;
       auto take = [&](size_t bytes) { uint8_t* q = cv.base ? cv.base + cv.off : nullptr; cv.off += (bytes + 255) / 256 * 256; return q; };
       ra.pre = (Cell*)take(cells * sizeof(Cell)); ra.B[0] = (Cell*)take(cells * sizeof(Cell)); ra.B[1] = (Cell*)take(cells * sizeof(Cell));
       ra.Q[0] = (uint32_t*)take(cells * 4); ra.Q[1] = (uint32_t*)take(cells * 4);
@@ -1035,14 +629,12 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
     if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
   if (nstrips > 1) { int rc = g_strips.ensure(nstrips - 1); if (rc != VPP_OK) return rc; }
-  {  // pair-cache epochs (see PairCache): the array is zeroed once per (buffer, layout) and when the counter nears its wrap
+  {  // the queue flags clean themselves up and the control block is left zeroed by every sweep: zeroed here once per (buffer, layout)
     Scratch::Slot& sl = *g_scratch.cur;
-    const size_t cells = (size_t)((i1->nrows - 1) / patchsize + 1) * ((i1->ncols - 1) / patchsize + 1);
-    const unsigned long long sig = ((unsigned long long)((uint8_t*)pairs - (uint8_t*)g_scratch.p) << 20) ^ (unsigned long long)cells ^ 1ull;
-    if (sl.user[0] != sig || sl.user[1] >= 0x7FFF0000ull) {
-      VPP_HIP_TRY(hipMemsetAsync(pairs, 0, cells * 8 * sizeof(PairCache), st));
+    const unsigned long long sig = ((unsigned long long)ra_flags_off << 24) ^ (unsigned long long)ra_flags_bytes ^ 1ull;
+    if (sl.user[0] != sig) {
       VPP_HIP_TRY(hipMemsetAsync((uint8_t*)g_scratch.p + ra_flags_off, 0, ra_flags_bytes, st));
-      sl.user[0] = sig; sl.user[1] = 0;
+      sl.user[0] = sig;
     }
   }
   // the image pyramids: built once here; across GPUs every rank builds them from the broadcast frames (pyramid::update, pyramid.hh:194-198)
@@ -1105,25 +697,15 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
       }
       if (propagation > 0) {
         const int NI = (P1[scale].nrows - 1) / patchsize + 1;
-        const int threads = (NI + 63) / 64 * 64;
-        const int mode = tuning("sdof.propagate", 4);  // 4: Jacobi rounds to the fixed point; 0 / 2 / 3: Jacobi + ordered flag pass, 1: generic wavefront kernel
+        const int mode = tuning("sdof.propagate", 0);  // 0: Jacobi rounds to the fixed point; 1: the lock-step wavefront on one workgroup (cross-check)
         const int NJ = (P1[scale].ncols - 1) / patchsize + 1;
-        if (mode == 4) {
+        if (mode != 1) {
           const int cells = NI * NJ;
-          const int grid = std::min(1024, (cells + kJobsPerGroup - 1) / kJobsPerGroup);
+          // most sweeps have nothing or a few hundred cells to do: a small grid keeps the empty launch cheap; long lists are walked in passes
+          const int grid = std::min(tuning("sdof.rounds_grid", 256), (cells + kJobsPerGroup - 1) / kJobsPerGroup);
           for (int Ki = 0; Ki < propagation; Ki++) {
             sdof_classify_kernel<<<(cells + 255) / 256, 256, 0, st>>>(maps(0, scale), NI, NJ, ra);
             sdof_rounds_kernel<WS><<<grid, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, ra, tuning("sdof.stats", 0));
-          }
-        } else if (mode != 1 && NI <= 1024) {  // mode 1: the generic one-kernel wavefront (also the fallback for maps taller than 1024 cells)
-          const size_t lds = (size_t)kRingGroups * threads * kGroupSteps;
-          for (int Ki = 0; Ki < propagation; Ki++) {
-            const int epoch = (int)++g_scratch.cur->user[1];   // one per sweep; the pair cache was zeroed for this layout (below), so 0 never matches
-            sdof_jacobi_kernel<WS><<<(NI * NJ + 255) / 256, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, NI, NJ, Ki % 2, jacobi, pairs, skew, threads, epoch);
-            // a workgroup of at most 512 threads may use 256 registers per lane: the out-of-line recomputation then keeps its cells and
-            // pair-cache entries in registers instead of scratch memory (4K frames: 448 threads)
-            if (threads <= 512) sdof_propagate_ring_kernel<WS, 512><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0), epoch);
-            else sdof_propagate_ring_kernel<WS, 1024><<<1, threads, lds, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, jacobi, pairs, skew, threads, tuning("sdof.stats", 0), epoch);
           }
         } else
           sdof_propagate_kernel<WS><<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, propagation);
@@ -1159,16 +741,10 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
   return vpp_semi_dense_optical_flow_strips(i1, i2, kps, n, winsize, nscales, min_scale, propagation, patchsize, 1, out_pos, out_dist, out_valid, stream);
 }
 
-// diagnostics (not part of include/vpp_amd.h): counters of the ordered propagation pass, enabled by tuning "sdof.stats"
+// diagnostics (not part of include/vpp_amd.h): counters of the propagation rounds, enabled by tuning "sdof.stats"
 extern "C" int vpp_debug_sdof_round_stats(unsigned* out4, int reset) {
   VPP_HIP_TRY(hipDeviceSynchronize());
   VPP_HIP_TRY(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_round_stats), 4 * sizeof(unsigned)));
   if (reset) { unsigned z[4] = {0, 0, 0, 0}; VPP_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_round_stats), z, sizeof z)); }
-  return VPP_OK;
-}
-extern "C" int vpp_debug_sdof_stats(unsigned* out4, int reset) {
-  VPP_HIP_TRY(hipDeviceSynchronize());
-  VPP_HIP_TRY(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sweep_stats), 4 * sizeof(unsigned)));
-  if (reset) { unsigned z[4] = {0, 0, 0, 0}; VPP_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_stats), z, sizeof z)); }
   return VPP_OK;
 }
