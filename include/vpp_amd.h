@@ -283,6 +283,19 @@ int vpp_allgather_tracks(vpp_comm* comm, const vpp_keypoint_f32* shard, int n_pe
  * two strips of one process (two streams of one GPU, peer GPUs). */
 int vpp_halo_exchange(vpp_comm* comm, const vpp_image_desc* strip, int halo_rows, void* stream);
 int vpp_halo_copy(const vpp_image_desc* upper, const vpp_image_desc* lower, int halo_rows, void* stream);
+/* The semi-dense flow (semi_dense_optical_flow.hpp:48-214) with its per-keypoint phase (:114-143) sharded over the ranks of `comm`, one
+ * process per GPU (BASELINE configs[4]; no reference counterpart).  A match may land anywhere in the frame (prediction from the coarser
+ * scale + descent + adopted neighbour flows), so a fixed image halo would not be exact: both frames are complete on every rank and the
+ * pyramids replicated.  vpp_allgather_rows completes a frame of which rank g holds rows [g nrows / G, (g + 1) nrows / G) (what a sharded
+ * capture / decode front-end leaves on each GPU) with one in-place RCCL all-gather of pitch-wide rows; nrows must divide by G.
+ * vpp_semi_dense_optical_flow_sharded: rank g claims and descends only the keypoints whose flow-map cell lies in its row strip of each
+ * scale, one grouped in-place all-gather per scale completes the three maps on every rank, the (deterministic, cheap) propagation sweeps
+ * (:146-201) run on every rank, and every rank returns the full result — identical to vpp_semi_dense_optical_flow.  All ranks pass the
+ * same frames, keypoints and parameters. */
+int vpp_allgather_rows(vpp_comm* comm, const vpp_image_desc* frame, void* stream);
+int vpp_semi_dense_optical_flow_sharded(vpp_comm* comm, const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps_rc, int n, int winsize,
+                                        int nscales, int min_scale, int propagation, int patchsize, int32_t* out_pos_rc,
+                                        int32_t* out_distance, uint8_t* out_valid, void* stream);
 
 #ifdef __cplusplus
 }

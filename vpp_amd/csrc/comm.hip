@@ -51,6 +51,24 @@ Rccl* rccl() {
 
 struct vpp_comm { void* nccl; int nranks, rank; };
 
+namespace vpp_amd {
+int comm_info(const vpp_comm* comm, int* rank, int* nranks) {
+  VPP_REQUIRE(comm, VPP_ERR_INVALID_ARG, "null communicator");
+  *rank = comm->rank; *nranks = comm->nranks;
+  return VPP_OK;
+}
+int comm_allgather_inplace(vpp_comm* comm, void* base, size_t bytes_per_rank, hipStream_t st) {
+  VPP_REQUIRE(comm && base, VPP_ERR_INVALID_ARG, "comm_allgather_inplace: invalid argument");
+  if (comm->nranks == 1 || bytes_per_rank == 0) return VPP_OK;
+  Rccl* R = rccl();
+  VPP_REQUIRE(R, VPP_ERR_UNSUPPORTED, "no RCCL library");
+  VPP_RCCL_TRY(R->all_gather((const char*)base + (size_t)comm->rank * bytes_per_rank, base, bytes_per_rank, 0 /* ncclInt8 */, comm->nccl, st));
+  return VPP_OK;
+}
+int comm_group_begin() { Rccl* R = rccl(); VPP_REQUIRE(R && R->group_start, VPP_ERR_UNSUPPORTED, "no RCCL library"); VPP_RCCL_TRY(R->group_start()); return VPP_OK; }
+int comm_group_end() { Rccl* R = rccl(); VPP_REQUIRE(R && R->group_end, VPP_ERR_UNSUPPORTED, "no RCCL library"); VPP_RCCL_TRY(R->group_end()); return VPP_OK; }
+}  // namespace vpp_amd
+
 extern "C" {
 
 int vpp_comm_unique_id(void* id128) {
@@ -137,6 +155,16 @@ int vpp_halo_exchange(vpp_comm* comm, const vpp_image_desc* strip, int halo, voi
   if (up) VPP_HIP_TRY(hipMemcpy2DAsync(strip_row(strip, -halo), strip->pitch, b + 2 * msg, rb, rb, halo, hipMemcpyDeviceToDevice, st));
   if (down) VPP_HIP_TRY(hipMemcpy2DAsync(strip_row(strip, strip->nrows), strip->pitch, b + 3 * msg, rb, rb, halo, hipMemcpyDeviceToDevice, st));
   return VPP_OK;
+}
+
+// Row-sharded frames: rank g holds rows [g * nrows / G, (g + 1) * nrows / G) of a frame (what a sharded decoder / capture front-end
+// leaves on each GPU); one in-place RCCL all-gather of whole pitch rows completes the frame on every rank — the image-row exchange of
+// the sharded semi-dense flow, whose matches may land anywhere in the frame (a fixed halo would not be exact).  nrows must divide evenly.
+int vpp_allgather_rows(vpp_comm* comm, const vpp_image_desc* img, void* stream) {
+  VPP_REQUIRE(comm && valid_desc(img), VPP_ERR_INVALID_ARG, "vpp_allgather_rows: invalid argument");
+  VPP_REQUIRE(img->nrows % comm->nranks == 0, VPP_ERR_UNSUPPORTED, "vpp_allgather_rows: %d rows do not split evenly over %d ranks", img->nrows, comm->nranks);
+  const int per = img->nrows / comm->nranks;
+  return comm_allgather_inplace(comm, strip_row(img, 0), (size_t)per * img->pitch, as_stream(stream));
 }
 
 }  // extern "C"

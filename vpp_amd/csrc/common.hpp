@@ -30,6 +30,13 @@ int tuning(const char* name, int dflt);  // runtime tuning knobs (vpp_set_tuning
 
 #define VPP_LAUNCH_CHECK() VPP_HIP_TRY(hipGetLastError())
 
+// RCCL plumbing shared by the sharded entry points (comm.hip): every rank holds `bytes_per_rank` bytes at base + rank * bytes_per_rank
+// and ends up with all of them (in-place all-gather); several gathers between comm_group_begin / _end go out as one RCCL launch.
+int comm_info(const vpp_comm* comm, int* rank, int* nranks);
+int comm_allgather_inplace(vpp_comm* comm, void* base, size_t bytes_per_rank, hipStream_t st);
+int comm_group_begin();
+int comm_group_end();
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 __host__ __device__ inline int dtype_size(int dt) {

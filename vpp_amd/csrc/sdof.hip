@@ -582,9 +582,15 @@ int copy_rows(const vpp_image_desc* dst, const vpp_image_desc* src, int lo, int 
 }
 }  // namespace
 
-extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
-                                                  int nscales, int min_scale, int propagation, int patchsize, int nstrips, int32_t* out_pos,
-                                                  int32_t* out_dist, uint8_t* out_valid, void* stream) {
+namespace {
+// comm != nullptr: one process per GPU (vpp_semi_dense_optical_flow_sharded).  Rank g owns the flow-map rows [g per, (g + 1) per) of every
+// scale (per = ceil(rows / ranks)): it claims and descends only the keypoints of its rows, the ranks' rows of the three maps are then
+// completed on every rank by ONE grouped in-place RCCL all-gather per scale (the maps are carved with per * ranks rows of memory, so that a
+// rank's rows are one contiguous chunk at rank * chunk), and every rank runs the propagation rounds on the complete maps — they are
+// deterministic and cost a few tens of microseconds, less than broadcasting their result.  Frames and pyramids are replicated.
+int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
+              int nscales, int min_scale, int propagation, int patchsize, int nstrips, vpp_comm* comm, int32_t* out_pos,
+              int32_t* out_dist, uint8_t* out_valid, void* stream) {
   VPP_REQUIRE(valid_desc(i1) && valid_desc(i2) && same_domain(i1, i2), VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: invalid frames");
   VPP_REQUIRE(i1->dtype == VPP_U8 && i1->channels == 1 && i2->dtype == VPP_U8 && i2->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_semi_dense_optical_flow: u8 x1 frames only");
   VPP_REQUIRE(n >= 0 && (n == 0 || (kps && out_pos && out_dist && out_valid)), VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: null buffer");
@@ -593,6 +599,8 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
   VPP_REQUIRE(nstrips >= 1 && nstrips <= 16, VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow_strips: 1 to 16 strips");
   if (n == 0) return VPP_OK;
   hipStream_t st = as_stream(stream);
+  int rank = 0, world = 1;
+  if (comm) { int rc = comm_info(comm, &rank, &world); if (rc) return rc; }
   // carve the scratch: two image pyramids (border 2*winsize, :72-73), flow / mark / distance pyramids (border nscales, :70-74) and owners per strip
   vpp_image_desc P1[kMaxScales], P2[kMaxScales];
   std::vector<vpp_image_desc> FLs((size_t)nstrips * kMaxScales), MKs(FLs.size()), DMs(FLs.size()), OWs(FLs.size());
@@ -609,10 +617,11 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
     VPP_REQUIRE(fr > 0 && fc > 0, VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: image smaller than one patch");
     for (int s_ = 0; s_ < nscales; s_++) {
       P1[s_] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize); P2[s_] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize);
+      const int fr_mem = (fr + world - 1) / world * world;   // rows of memory: whole chunks per rank (the descriptors keep fr rows)
       for (int k = 0; k < nstrips; k++) {
-        FL(k, s_) = cv.image(fr, fc, VPP_I32, 2, nscales);
-        MK(k, s_) = cv.image(fr, fc, VPP_U8, 1, nscales); if (k == 0) { mk_off[s_] = cv.last_off; mk_bytes[s_] = cv.last_bytes; }
-        DM(k, s_) = cv.image(fr, fc, VPP_I32, 1, nscales);
+        FL(k, s_) = cv.image(fr_mem, fc, VPP_I32, 2, nscales); FL(k, s_).nrows = fr;
+        MK(k, s_) = cv.image(fr_mem, fc, VPP_U8, 1, nscales); MK(k, s_).nrows = fr; if (k == 0) { mk_off[s_] = cv.last_off; mk_bytes[s_] = cv.last_bytes; }
+        DM(k, s_) = cv.image(fr_mem, fc, VPP_I32, 1, nscales); DM(k, s_).nrows = fr;
         OW(k, s_) = cv.image(fr, fc, VPP_U32, 1, 0); if (k == 0) { ow_off[s_] = cv.last_off; ow_bytes[s_] = cv.last_bytes; }
       }
       fr = 1 + fr / 2; fc = 1 + fc / 2; ir = 1 + ir / 2; ic = 1 + ic / 2;  // pyramid.hh:154
@@ -666,7 +675,8 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
       constexpr int WS = decltype(WSc)::value;
       // claim + descent of strip k on stream sk, rows [lo, hi) of the flow map, into strip k's own maps
       auto strip_phase = [&](int k, hipStream_t sk) -> int {
-        const int lo = nstrips == 1 ? 0 : (int)((long long)fr * k / nstrips), hi = nstrips == 1 ? INT_MAX : (int)((long long)fr * (k + 1) / nstrips);
+        int lo = nstrips == 1 ? 0 : (int)((long long)fr * k / nstrips), hi = nstrips == 1 ? INT_MAX : (int)((long long)fr * (k + 1) / nstrips);
+        if (world > 1) { const int per = (fr + world - 1) / world; lo = rank * per; hi = rank + 1 == world ? INT_MAX : (rank + 1) * per; }
         if (!reset_up_front) {
           int r2 = vpp_fill(&MK(k, scale), &zero, 1, (void*)sk); if (r2) return r2;  // fill_with_border(flow_map_mark, 0), :111
           VPP_HIP_TRY(hipMemsetAsync(OW(k, scale).first_pixel, 0xFF, (size_t)OW(k, scale).pitch * OW(k, scale).nrows, sk));
@@ -694,6 +704,15 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
         int r2 = copy_rows(&FL(0, scale), &FL(k, scale), lo, hi, st); if (r2) return r2;
         r2 = copy_rows(&MK(0, scale), &MK(k, scale), lo, hi, st); if (r2) return r2;
         r2 = copy_rows(&DM(0, scale), &DM(k, scale), lo, hi, st); if (r2) return r2;
+      }
+      if (world > 1) {   // the ranks' rows of the three maps -> every rank, in place, one RCCL launch
+        const int per = (fr + world - 1) / world;
+        auto rows0 = [](const vpp_image_desc& d) { return (uint8_t*)d.first_pixel - (ptrdiff_t)d.border * elem_bytes(&d); };   // byte 0 of row 0 incl. its left border
+        int r2 = comm_group_begin(); if (r2) return r2;
+        r2 = comm_allgather_inplace(comm, rows0(FL(0, scale)), (size_t)per * FL(0, scale).pitch, st); if (r2) return r2;
+        r2 = comm_allgather_inplace(comm, rows0(MK(0, scale)), (size_t)per * MK(0, scale).pitch, st); if (r2) return r2;
+        r2 = comm_allgather_inplace(comm, rows0(DM(0, scale)), (size_t)per * DM(0, scale).pitch, st); if (r2) return r2;
+        r2 = comm_group_end(); if (r2) return r2;
       }
       if (propagation > 0) {
         const int NI = (P1[scale].nrows - 1) / patchsize + 1;
@@ -735,10 +754,25 @@ extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, cons
   return VPP_OK;
 }
 
+}  // namespace
+
+extern "C" int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
+                                                  int nscales, int min_scale, int propagation, int patchsize, int nstrips, int32_t* out_pos,
+                                                  int32_t* out_dist, uint8_t* out_valid, void* stream) {
+  return flow_impl(i1, i2, kps, n, winsize, nscales, min_scale, propagation, patchsize, nstrips, nullptr, out_pos, out_dist, out_valid, stream);
+}
+
 extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
                                            int nscales, int min_scale, int propagation, int patchsize, int32_t* out_pos,
                                            int32_t* out_dist, uint8_t* out_valid, void* stream) {
-  return vpp_semi_dense_optical_flow_strips(i1, i2, kps, n, winsize, nscales, min_scale, propagation, patchsize, 1, out_pos, out_dist, out_valid, stream);
+  return flow_impl(i1, i2, kps, n, winsize, nscales, min_scale, propagation, patchsize, 1, nullptr, out_pos, out_dist, out_valid, stream);
+}
+
+extern "C" int vpp_semi_dense_optical_flow_sharded(vpp_comm* comm, const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
+                                                   int nscales, int min_scale, int propagation, int patchsize, int32_t* out_pos,
+                                                   int32_t* out_dist, uint8_t* out_valid, void* stream) {
+  VPP_REQUIRE(comm, VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow_sharded: null communicator");
+  return flow_impl(i1, i2, kps, n, winsize, nscales, min_scale, propagation, patchsize, 1, comm, out_pos, out_dist, out_valid, stream);
 }
 
 // diagnostics (not part of include/vpp_amd.h): counters of the propagation rounds, enabled by tuning "sdof.stats"
