@@ -4,8 +4,8 @@
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
-one 5x5 box_nbh2d launch over a 3840x2160 vuchar3 frame (BASELINE.json configs[1]), rotating over
-enough distinct frame buffers (> 256 MiB) that the Infinity Cache cannot serve the stream.
+the 5x5 box_nbh2d filter of a batch of 16 distinct 3840x2160 vuchar3 frames (BASELINE.json configs[1]) in ONE launch
+(vpp_box_filter_batch), rotating over 32 frame sets = 800 MB of sources, so that the 256 MiB Infinity Cache cannot serve the reads.  The per-frame call form is timed beside it.
 value = Gpixels/s over all ranks (box / add / FAST "shard" as independent replicas: "replicas only").
 Extra objects on the same JSON line: roofline (dominant kernel vs HBM), cpu_baseline (the oracle timed on the host
 cores, bounded sample), add4k (4K int32 pixel_wise add) and — when built — pyrlk (tracks/s, keypoint-sharded + all-gather).
@@ -29,12 +29,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--regions", type=int, default=5, help="timed regions of exactly --steps launches each; the median one (by wall clock) is reported, all are listed")
     ap.add_argument("--preheat", type=float, default=0.3, help="seconds of untimed, reported replays before each headline timed region (clock ramp)")
     ap.add_argument("--workload", default="box5x5", choices=["box5x5"])
+    ap.add_argument("--sets", type=int, default=32, help="distinct 4K frame sets the steps rotate over (16 per step): 32 sets = 800 MB of sources + 800 MB of results")
     args = ap.parse_args()
 
     import numpy as np
@@ -160,8 +161,9 @@ def main():
         # kernel-duration sample for the roofline: the event pair around ONE K-launch region carries ~8 us of fixed marker /
         # command-processor latency (K = 20: 9.0 us per launch inside the bracket where rocprofv3's per-dispatch durations of the
         # same run average 8.55), and back-to-back replays of a short graph pay a submission gap per replay.  So the roofline's
-        # launch duration comes from ONE replay of a graph of >= 2000 of the same launches (the timed graph itself when K >= 2000).
-        n_sample = max(steps, 2000)
+        # SUSTAINED launch duration (frac_sustained) comes from ONE replay of a graph of >= 500 of the same launches (the timed graph itself when K >= 500);
+        # roofline.frac itself is taken from the K timed launches (event nodes inside the timed graph).
+        n_sample = max(steps, 500)
         sample = None
         if use_graph and c_graph and mode.startswith("vpp_graph"):
             sp = ctypes.c_void_p(side.cuda_stream)
@@ -218,7 +220,8 @@ def main():
     NR, NC = 2160, 3840
     npx = NR * NC
     src_h = rand_image(NR, NC, vi.U8, 3, border=2, seed=3, align=16)
-    nsets = 8  # 8 x (25.0 + 24.9 MB) = 399 MB > 256 MiB Infinity Cache
+    FPS = 16                              # frames per step: one step = a batch of 16 frames filtered by ONE launch (vpp_box_filter_batch)
+    nsets = max(FPS, args.sets // FPS * FPS)  # 32 x 25.0 MB of sources alone = 800 MB: even a cache that kept only the reads (the stores are non-temporal) could not hold them in 256 MiB
     srcs = [DeviceImage.from_host(src_h, dev) for _ in range(nsets)]
     dsts = [DeviceImage(NR, NC, vi.U8, 3, 0, 16, dev) for _ in range(nsets)]
     for s in srcs:
@@ -226,8 +229,15 @@ def main():
     sdesc = [s.desc for s in srcs]
     ddesc = [d.desc for d in dsts]
     box = lib.vpp_box_filter
+    box_batch = lib.vpp_box_filter_batch
+    nb = nsets // FPS
+    sarr = [vi.desc_array(srcs[j * FPS:(j + 1) * FPS]) for j in range(nb)]
+    darr = [vi.desc_array(dsts[j * FPS:(j + 1) * FPS]) for j in range(nb)]
 
     def launch_box(i, stream):
+        box_batch(darr[i % nb], sarr[i % nb], FPS, 5, 5, stream)
+
+    def launch_box_single(i, stream):
         k = i % nsets
         box(P(ddesc[k]), P(sdesc[k]), 5, 5, stream)
 
@@ -235,43 +245,88 @@ def main():
     box_mode = dict(launch_mode)
     box_regions = region_log[-1]
     ms_per_step = wall / args.steps * 1e3
-    value = npx * world / (wall / args.steps) / 1e9
-    box_kernel_s = box_regions["sample"]["us_per_launch"] * 1e-6
-    roof = {"bound": "hbm", "kernel": "box_u8_wide_kernel<3, 5, 5, 2, 4, ...>", "achieved": 6.0 * npx / box_kernel_s / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": 6 * npx, "avg_launch_us": box_kernel_s * 1e6,
-            "avg_launch_us_in_region": ev / args.steps * 1e6, "sample": box_regions["sample"]}
+    value = npx * FPS * world / (wall / args.steps) / 1e9
+    alg_bytes = 6 * npx * FPS                              # 6 B/px (3 read + 3 written), x the frames one launch processes
+    launch_s = ev / args.steps                             # HIP event-record nodes around exactly the K timed launches, on the launch stream
+    sustained_s = box_regions["sample"]["us_per_launch"] * 1e-6
+    roof = {"bound": "hbm", "kernel": "box_u8_wide_kernel<3, 5, 5, 6, 4, ...> (16 frames per launch)", "achieved": alg_bytes / launch_s / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": FPS, "avg_launch_us": launch_s * 1e6,
+            "how": "achieved = algorithmic bytes / average launch duration over the K timed launches themselves (event-record nodes in front of the first and behind the last of them)",
+            "frac_sustained": alg_bytes / sustained_s / 1e9 / HBM_PEAK_GBS, "avg_launch_us_sustained": sustained_s * 1e6, "sample": box_regions["sample"]}
     roof["frac"] = roof["achieved"] / roof["peak"]
 
     def pmc_traffic(prefix):
         """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json, tools/make_traffic_json.py:
-        FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate --pmc runs); None when no profile is present."""
+        FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate --pmc runs), keyed by kernel symbol: None when no committed profile
+        was taken on a kernel of this name (the number would be another kernel's)."""
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
             for k, v in json.load(open(path)).items():
                 if k.startswith(prefix):
-                    return v["hbm_bytes_per_launch"]
-        return None
-    roof["traffic"] = pmc_traffic("box_u8_wide_kernel<3, 5, 5")
-    roof["traffic_source"] = "profiles/*_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled)"
+                    return v["hbm_bytes_per_launch"], os.path.basename(path)
+        return None, None
+    roof["traffic"], roof["traffic_source"] = pmc_traffic("box_u8_wide_kernel<3, 5, 5, 6")
+    if roof["traffic_source"]:
+        roof["traffic_source"] += " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this kernel symbol, FETCH doubled per the gfx950 note)"
+    # the same frames one launch per frame (the reference's call form, benchmarks/box_5x5_filter2.cc:43-69): K x 8 launches in the region
+    swall, sev = timed(launch_box_single, args.steps * FPS, args.warmup, preheat_s=0.0, c_graph=True)
+    single_s = region_log[-1]["sample"]["us_per_launch"] * 1e-6
+    per_frame = {"gpixels_per_s": npx * world / (swall / (args.steps * FPS)) / 1e9, "avg_launch_us_in_region": sev / (args.steps * FPS) * 1e6,
+                 "avg_launch_us_sustained": single_s * 1e6, "kernel": "box_u8_wide_kernel<3, 5, 5, 2, 4, ...>",
+                 "frac_in_region": 6.0 * npx / (sev / (args.steps * FPS)) / 1e9 / HBM_PEAK_GBS, "frac_sustained": 6.0 * npx / single_s / 1e9 / HBM_PEAK_GBS,
+                 "traffic": pmc_traffic("box_u8_wide_kernel<3, 5, 5, 2")[0]}
+    # frames per launch against the roofline fraction (a launch pays ~5 us of ramp and drain whatever its size): event-timed graphs of >= 64 frames
+    sweep = {}
+    for fpl in (1, 2, 4, 8, 16, 32):
+        if fpl > nsets:
+            continue
+        groups = nsets // fpl
+        sa = [vi.desc_array(srcs[j * fpl:(j + 1) * fpl]) for j in range(groups)]
+        da = [vi.desc_array(dsts[j * fpl:(j + 1) * fpl]) for j in range(groups)]
+        nl = max(4, 128 // fpl)
+        sp = ctypes.c_void_p(side.cuda_stream)
+        gh = ctypes.c_void_p()
+        capi.check(lib.vpp_graph_begin(sp))
+        for i in range(nl):
+            box_batch(da[i % groups], sa[i % groups], fpl, 5, 5, sp)
+        if lib.vpp_graph_end(sp, 1, ctypes.byref(gh)) != capi.OK:
+            continue
+        ts = []
+        for _ in range(4):
+            capi.check(lib.vpp_graph_launch(gh, sp)); torch.cuda.synchronize()
+            ms = ctypes.c_float(0); capi.check(lib.vpp_graph_elapsed_ms(gh, ctypes.byref(ms))); ts.append(ms.value)
+        lib.vpp_graph_destroy(gh)
+        us = sorted(ts[1:])[1] * 1e3 / (nl * fpl)
+        sweep[str(fpl)] = {"us_per_frame": round(us, 3), "frac": round(6.0 * npx / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    per_frame["frames_per_launch_sweep"] = sweep
 
     # ---------------- 4K int32 pixel_wise add ----------------
-    nadd = 4  # 4 x 99.5 MB
-    A = [DeviceImage(NR, NC, vi.I32, 1, 0, 32, dev) for _ in range(nadd)]
+    nadd = 4  # triples per step (4 x 99.5 MB)
+    nadd_sets = 12  # 12 x 66 MB of operands = 796 MB
+    A = [DeviceImage(NR, NC, vi.I32, 1, 0, 32, dev) for _ in range(nadd_sets)]
     b_h = rand_image(NR, NC, vi.I32, seed=2, lo=0, hi=2**30 - 1)
-    B = [DeviceImage.from_host(b_h, dev) for _ in range(nadd)]
-    C = [DeviceImage.from_host(b_h, dev) for _ in range(nadd)]
+    B = [DeviceImage.from_host(b_h, dev) for _ in range(nadd_sets)]
+    C = [DeviceImage.from_host(b_h, dev) for _ in range(nadd_sets)]
     ad, bd, cd = [x.desc for x in A], [x.desc for x in B], [x.desc for x in C]
     add = lib.vpp_pixelwise_binary
 
+    add_batch = lib.vpp_pixelwise_binary_batch
+    nab = nadd_sets // nadd
+    aarr = [vi.desc_array(A[j * nadd:(j + 1) * nadd]) for j in range(nab)]
+    barr = [vi.desc_array(B[j * nadd:(j + 1) * nadd]) for j in range(nab)]
+    carr = [vi.desc_array(C[j * nadd:(j + 1) * nadd]) for j in range(nab)]
+
     def launch_add(i, stream):
-        k = i % nadd
-        add(0, P(ad[k]), P(bd[k]), P(cd[k]), stream)
+        j = i % nab
+        add_batch(0, aarr[j], barr[j], carr[j], nadd, stream)   # one step = 4 triples, one launch
 
     awall, aev = timed(launch_add, args.steps, args.warmup, preheat_s=args.preheat, c_graph=True)
-    add_s = region_log[-1]["sample"]["us_per_launch"] * 1e-6
-    add4k = {"gpixels_per_s": npx * world / (awall / args.steps) / 1e9, "avg_launch_us": add_s * 1e6, "avg_launch_us_in_region": aev / args.steps * 1e6,
-             "roofline": {"bound": "hbm", "kernel": "binary_flat_kernel<add,int>", "achieved": 12.0 * npx / add_s / 1e9,
-                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 12.0 * npx / add_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("binary_flat_kernel<0, int")}}
+    add_s = aev / args.steps
+    add_sus = region_log[-1]["sample"]["us_per_launch"] * 1e-6
+    add4k = {"gpixels_per_s": npx * nadd * world / (awall / args.steps) / 1e9, "frames_per_step": nadd, "avg_launch_us": add_s * 1e6,
+             "roofline": {"bound": "hbm", "kernel": "binary_flat_batch_kernel<add,int>", "achieved": 12.0 * npx * nadd / add_s / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 12.0 * npx * nadd / add_s / 1e9 / HBM_PEAK_GBS,
+                          "frac_sustained": 12.0 * npx * nadd / add_sus / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("binary_flat_batch_kernel<0, int")[0]}}
 
     extras = {}
     try:
@@ -326,10 +381,10 @@ def main():
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
                "config": {"workload": "box_nbh2d 5x5 mean on 3840x2160 vuchar3 (BASELINE configs[1]), border 2 mirror-filled, "
-                                      f"{nsets} rotating frame sets (>256 MiB)", "parallelism": f"replicas x{world}", "launch": box_mode["mode"], "events": box_mode["events"], "timed_regions": {"count": max(1, args.regions), "reported": "median by wall clock", "wall_ms": box_regions["wall_ms"], "event_ms": box_regions["event_ms"]},
+                                      f"one step = a batch of {FPS} frames in one launch, rotating over {nsets} distinct frame sets ({nsets * 25} MB of sources + {nsets * 25} MB of results)", "frames_per_step": FPS, "parallelism": f"replicas x{world}", "launch": box_mode["mode"], "events": box_mode["events"], "timed_regions": {"count": max(1, args.regions), "reported": "median by wall clock", "wall_ms": box_regions["wall_ms"], "event_ms": box_regions["event_ms"]},
                           "preheat": {"untimed_ms": round(preheat["ms"], 1), "untimed_launches": preheat["launches"],
                                       "note": "replays of the same graphs before the timed regions (clock ramp); not part of steps / value"}},
-               "roofline": roof, "cpu_baseline": cpu, "add4k": add4k}
+               "roofline": roof, "cpu_baseline": cpu, "add4k": add4k, "box5x5_one_launch_per_frame": per_frame}
         out.update(extras)
         print(json.dumps(out))
     if multi:

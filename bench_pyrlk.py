@@ -64,6 +64,21 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
                 if rank == 0:
                     res["cpp_harness"] = {"error": f"{type(e).__name__}: {e}"}
             barrier()
+        # BASELINE configs[4] as a tile-sharded step (benchmarks/flow_strip_bench.cc, one C++ process per GPU): RCCL all-gather of the frames'
+        # row strips, claim + descent sharded by flow-map row strips with one grouped all-gather of the maps per scale, halo exchange + FAST-9
+        # on strips; every rank checks its results against its own single-rank calls.  Reported beside the replicas leg below.
+        exe = os.path.join(ROOT, "benchmarks", "flow_strip_bench")
+        if os.path.exists(exe) and os.environ.get("VPP_BENCH_ONE_DEVICE", "0") != "1" and 2160 % world == 0:
+            import json as _json, subprocess as _sp
+            uid = f"/tmp/vpp_uid_flow_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+            try:
+                out = _sp.run([exe, str(rank), str(world), uid, "50"], capture_output=True, text=True, timeout=180)
+                if rank == 0:
+                    res["flow_strips_4k"] = _json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else {"error": (out.stderr or out.stdout)[-300:], "rc": out.returncode}
+            except Exception as e:  # noqa: BLE001
+                if rank == 0:
+                    res["flow_strips_4k"] = {"error": f"{type(e).__name__}: {e}"}
+            barrier()
         # weak scaling in keypoints: NK keypoints PER rank (a denser keypoint set on the same frame pair, rank g owning the slice
         # [g*NK, (g+1)*NK) of world*NK), the all-gather carries all world*NK records
         full0 = torch.from_numpy(kps_h.view(np.uint8).reshape(-1).copy()).to(dev)
@@ -132,8 +147,8 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     dt = (time.perf_counter() - t0) / it
     res["semi_dense_flow_4k"] = {"ms_per_frame_pair": dt * 1e3, "frame_pairs_per_s": world / dt, "keypoints": m,
                                  "note": "one frame pair per GPU (replicas); serial-order semantics, bit-exact vs the oracle"}
-    # several independent frame pairs in flight on one GPU: each on its own stream (its own scratch: common.hpp Scratch is per stream), so one
-    # pair's single-workgroup ordered sweep overlaps the other pairs' pyramids / claim / descent / Jacobi and their sweeps on other CUs
+    # several independent frame pairs in flight on one GPU: each on its own stream (its own scratch: common.hpp Scratch is per stream); a pair is a
+    # chain of ~25 short launches (pyramids, claim, descent, classify, propagation rounds), so independent pairs fill each other's launch gaps
     conc = {}
     for k in (1, 2, 4, 8):
         streams = [torch.cuda.Stream(device=dev) for _ in range(k)]

@@ -105,6 +105,8 @@ typedef enum vpp_binary_op { VPP_OP_ADD = 0, VPP_OP_SUB = 1, VPP_OP_MUL = 2, VPP
 /* dst(p) = V(a(p) op b(p)) over dst's domain; arithmetic in the C++ promoted type of V's component then
  * converted back (so u8 wraps modulo 256 and i32 wraps modulo 2^32, as the compiled reference does). */
 int vpp_pixelwise_binary(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, void* stream);
+/* dst[k] = a[k] op b[k] for n image triples of one size in ONE launch (see vpp_box_filter_batch); same results as n single calls. */
+int vpp_pixelwise_binary_batch(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, int n, void* stream);
 /* copy(src,dst) (vpp/core/copy.hh:10-20); with_border=1 is copy_with_border (copy.hh:22-27): copies src's border too. */
 int vpp_copy(const vpp_image_desc* dst, const vpp_image_desc* src, int with_border, void* stream);
 /* fill (vpp/core/fill.hh:12-16) / fill_with_border (fill.hh:24-29): `value` points to one pixel (host memory). */
@@ -115,6 +117,11 @@ int vpp_fill(const vpp_image_desc* img, const void* value, int with_border, void
  *      and examples/box_filter.cc:23-32: per component, sum over the window in the promoted type (taps in
  *      row-major order), C++ `/ (R*C)`, cast back.  Reads src's border (needs border >= max(R,C)/2). ---- */
 int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream);
+/* The same filter over n frame pairs dst[k] <- src[k] of one geometry (a decoded group of frames, the levels of a frame ring) in ONE launch:
+ * the chip does not drain between frames and the host submits once (no reference counterpart: the reference's frame loops call the
+ * filter per frame, benchmarks/box_5x5_filter2.cc:43-69).  Results are those of n vpp_box_filter calls; shapes the batched kernel does not
+ * serve go out as exactly those calls. */
+int vpp_box_filter_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int R, int C, void* stream);
 
 /* ---- borders (vpp/core/fill.hh:31-122) ---- */
 typedef enum vpp_border_mode { VPP_BORDER_MIRROR = 0, VPP_BORDER_CLOSEST = 1, VPP_BORDER_VALUE = 2 } vpp_border_mode;

@@ -309,3 +309,43 @@ def test_box_source_at_the_very_start_of_an_allocation(lib, orc, dtype, ch, R, C
         np.testing.assert_array_equal(got.view().view(np.uint32), want.view().view(np.uint32))
     else:
         np.testing.assert_array_equal(got.view(), want.view())
+
+
+@pytest.mark.parametrize("shape,ch,border,n", [((67, 131), 3, 2, 5), ((270, 480), 3, 2, 8), ((64, 1024), 1, 3, 17), ((40, 5000), 4, 2, 3), ((31, 45), 3, 2, 2)])
+def test_box_filter_batch_equals_the_oracle_per_frame(lib, orc, shape, ch, border, n):
+    """vpp_box_filter_batch: n frames of one geometry in ONE launch (17 > the 16 frames one launch carries: two launches) — every frame
+    bit-identical to the oracle's box filter of that frame; and with mixed geometries (falls back to single calls)."""
+    srcs = [rand_image(*shape, vi.U8, ch, border=border, seed=20 + k, align=16, fill_border=True) for k in range(n)]
+    wants = []
+    for s in srcs:
+        w = s.like(border=0); assert orc.orc_box_filter(P(w.desc), P(s.desc), 5, 5) == 0; wants.append(w)
+    dsrc = [DeviceImage.from_host(s) for s in srcs]
+    ddst = [DeviceImage.from_host(s.like(border=0)) for s in srcs]
+    capi.check(lib.vpp_box_filter_batch(vi.desc_array(ddst), vi.desc_array(dsrc), n, 5, 5, capi.stream_ptr()))
+    _sync(lib)
+    for d, w in zip(ddst, wants):
+        np.testing.assert_array_equal(d.download().view(), w.view())
+    # mixed geometries: one frame of another size in the batch
+    odd = rand_image(shape[0] + 3, shape[1] + 5, vi.U8, ch, border=border, seed=99, align=16, fill_border=True)
+    wodd = odd.like(border=0); assert orc.orc_box_filter(P(wodd.desc), P(odd.desc), 5, 5) == 0
+    dsrc2 = dsrc[:2] + [DeviceImage.from_host(odd)]
+    ddst2 = [DeviceImage.from_host(srcs[0].like(border=0)), DeviceImage.from_host(srcs[1].like(border=0)), DeviceImage.from_host(wodd.like())]
+    capi.check(lib.vpp_box_filter_batch(vi.desc_array(ddst2), vi.desc_array(dsrc2), 3, 5, 5, capi.stream_ptr()))
+    _sync(lib)
+    for d, w in zip(ddst2, [wants[0], wants[1], wodd]):
+        np.testing.assert_array_equal(d.download().view(), w.view())
+
+
+@pytest.mark.parametrize("shape,n", [((135, 240), 4), ((1080, 1920), 3), ((33, 52), 18)])
+def test_pixelwise_binary_batch_equals_the_oracle_per_triple(lib, orc, shape, n):
+    for op in (0, 1, 4):   # add, sub (batched kernel), max (single calls)
+        bs = [rand_image(*shape, vi.I32, seed=30 + k, lo=0, hi=2**30) for k in range(n)]
+        cs = [rand_image(*shape, vi.I32, seed=60 + k, lo=0, hi=2**30) for k in range(n)]
+        wants = []
+        for b, c in zip(bs, cs):
+            a = b.like(); assert orc.orc_pixelwise_binary(op, P(a.desc), P(b.desc), P(c.desc)) == 0; wants.append(a)
+        db, dc, da = [DeviceImage.from_host(x) for x in bs], [DeviceImage.from_host(x) for x in cs], [DeviceImage.from_host(x.like()) for x in bs]
+        capi.check(lib.vpp_pixelwise_binary_batch(op, vi.desc_array(da), vi.desc_array(db), vi.desc_array(dc), n, capi.stream_ptr()))
+        _sync(lib)
+        for d, w in zip(da, wants):
+            np.testing.assert_array_equal(d.download().view(), w.view())

@@ -21,7 +21,9 @@ int tuning(const char* name, int dflt) { auto it = g_tune.find(name); return it 
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-static const int NR = 2160, NC = 3840, CH = 3, BORDER = 2, NSETS = 8;
+// 32 frame sets: 800 MB of sources + 800 MB of results.  (Rounds 1-2 rotated over 8 sets = 200 MB of sources, which the 256 MiB Infinity Cache
+// kept resident — the stores are non-temporal and do not allocate — so those timings were of an L3-fed kernel, not an HBM-fed one.)
+static const int NR = 2160, NC = 3840, CH = 3, BORDER = 2, NSETS = 32;
 
 __global__ void copy16_kernel(u32x4* __restrict__ d, const u32x4* __restrict__ s, size_t n, int nt) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,7 +90,12 @@ int main(int argc, char** argv) {
     ddsc[k] = vpp_image_desc{dd[k] + dfirst, NR, NC, dpitch, 0, VPP_U8, CH};
   }
   printf("# src pitch %d first %zu (base %% 256 = %zu), dst pitch %d\n", spitch, sfirst, (size_t)((uintptr_t)ds[0] % 256), dpitch);
-  auto box = [&](int i, hipStream_t s) { int k = i % NSETS; if (vpp_box_filter(&ddsc[k], &sd[k], 5, 5, s) != VPP_OK) { fprintf(stderr, "box: %s\n", vpp_amd::g_err); exit(1); } };
+  auto box = [&](int i, hipStream_t s) {
+    const int batch = vpp_amd::tuning("box.batch", 1);   // frames per launch (vpp_box_filter_batch); NSETS % batch == 0
+    const int k = (i * batch) % NSETS;
+    const int rc = batch > 1 ? vpp_box_filter_batch(&ddsc[k], &sd[k], batch, 5, 5, s) : vpp_box_filter(&ddsc[k], &sd[k], 5, 5, s);
+    if (rc != VPP_OK) { fprintf(stderr, "box: %s\n", vpp_amd::g_err); exit(1); }
+  };
   // clock preheat: ~0.3 s of the default kernel
   { for (int rep = 0; rep < 60; rep++) { for (int i = 0; i < 500; i++) box(i, st); CK(hipStreamSynchronize(st)); } }
 
@@ -107,7 +114,9 @@ int main(int argc, char** argv) {
     size_t bad = 0;
     const int probe = vpp_amd::tuning("box.probe", 0);
     if (!probe) for (int r = 0; r < NR; r++) bad += memcmp(&got[dfirst + (size_t)r * dpitch], &want[(size_t)r * row_bytes], row_bytes) != 0;
-    Timing t = time_graph(st, box);
+    const int batch = vpp_amd::tuning("box.batch", 1);
+    Timing t = time_graph(st, box, std::max(32, 200 / batch));
+    t.best /= batch; t.med /= batch;   // per frame
     printf("%-58s best %6.2f us  med %6.2f us  %5.2f TB/s  frac %.3f  %s\n", cfg.c_str(), t.best, t.med, 6.0 * NR * NC / t.med / 1e6, 6.0 * NR * NC / t.med / 1e6 / 8.0,
            probe ? "(probe)" : bad ? "MISMATCH" : "exact");
     if (bad) printf("   !! %zu rows differ\n", bad);
@@ -162,6 +171,36 @@ int main(int argc, char** argv) {
     for (int laux : {0, 1, 2, 16})
       for (int sp : {0, 1, 2, 3, 16, 17, 18, 19}) { if (laux == 0 && sp == 2) continue; char b[160]; snprintf(b, sizeof b, "impl=2,sp=%d,laux=%d", sp, laux); cfgs.push_back(b); }
     cfgs.push_back("impl=2");
+  } else if (mode == "sweep6") {   // round 3: everything again with the sources really coming from HBM
+    for (int batch : {1, 8}) {
+      char b[160];
+      snprintf(b, sizeof b, "impl=2,batch=%d", batch); cfgs.push_back(b);
+      for (int rows : {2, 3, 4}) for (int wx : {4, 1}) { snprintf(b, sizeof b, "impl=2,halo=0,wx=%d,order=%d,rows=%d,mix=0,occ=8,batch=%d", wx, wx == 1 ? 1 : 0, rows, batch); cfgs.push_back(b); }
+      for (int order : {1, 2, 3}) { snprintf(b, sizeof b, "impl=2,halo=0,wx=4,order=%d,rows=2,mix=0,occ=8,batch=%d", order, batch); cfgs.push_back(b); }
+      for (int occ : {6, 4}) { snprintf(b, sizeof b, "impl=2,halo=0,wx=4,order=0,rows=2,mix=0,occ=%d,batch=%d", occ, batch); cfgs.push_back(b); }
+      for (int probe : {1, 3}) { snprintf(b, sizeof b, "impl=2,halo=0,wx=4,order=0,rows=2,mix=0,occ=8,probe=%d,batch=%d", probe, batch); cfgs.push_back(b); }
+      for (int laux : {1, 2, 16}) { snprintf(b, sizeof b, "impl=2,sp=2,laux=%d,batch=%d", laux, batch); cfgs.push_back(b); }
+      for (int sp : {0, 1, 3, 16, 18}) { snprintf(b, sizeof b, "impl=2,sp=%d,laux=0,batch=%d", sp, batch); cfgs.push_back(b); }
+      for (int shape : {1, 5, 6}) { snprintf(b, sizeof b, "impl=2,shape=%d,rows=2,batch=%d", shape, batch); cfgs.push_back(b); }
+      snprintf(b, sizeof b, "impl=2,halo=1,wx=4,order=0,rows=2,mix=0,occ=8,batch=%d", batch); cfgs.push_back(b);
+    }
+    cfgs.push_back("impl=1,rows=2");
+    cfgs.push_back("impl=0,rows=8");
+  } else if (mode == "sweep7") {   // batch of 8, honest HBM: more rows per wave (more unique bytes in flight per wave) against occupancy
+    cfgs.push_back("impl=2,batch=8");
+    for (int rows : {3, 4, 5, 6})
+      for (int occ : {8, 6, 4})
+        for (int mix : {0, 1}) { char b[160]; snprintf(b, sizeof b, "impl=2,halo=0,wx=4,order=0,rows=%d,mix=%d,occ=%d,batch=8", rows, mix, occ); cfgs.push_back(b); }
+    for (int rows : {3, 4, 6}) { char b[160]; snprintf(b, sizeof b, "impl=2,halo=0,wx=2,order=0,rows=%d,mix=0,occ=%d,batch=8", rows, rows == 3 ? 8 : 4); cfgs.push_back(b); }
+    for (int batch : {2, 4, 16}) { char b[160]; snprintf(b, sizeof b, "impl=2,halo=0,wx=4,order=0,rows=3,mix=0,occ=8,batch=%d", batch); cfgs.push_back(b); }
+  } else if (mode == "sweep9") {   // which kernel at which batch size
+    for (int batch : {1, 2, 4, 8, 16, 32}) {
+      char b[160];
+      snprintf(b, sizeof b, "impl=2,halo=0,wx=4,order=0,rows=2,mix=0,occ=8,batch=%d", batch); cfgs.push_back(b);
+      snprintf(b, sizeof b, "impl=2,halo=0,wx=4,order=0,rows=3,mix=0,occ=8,batch=%d", batch); cfgs.push_back(b);
+      snprintf(b, sizeof b, "impl=2,halo=0,wx=4,order=0,rows=6,mix=0,occ=4,batch=%d", batch); cfgs.push_back(b);
+      snprintf(b, sizeof b, "impl=2,halo=0,wx=4,order=0,rows=2,mix=0,occ=8,probe=1,batch=%d", batch); cfgs.push_back(b);
+    }
   } else if (mode == "sweep2") {
     for (int wx : {1, 4})
       for (int probe : {0, 1, 2, 3})
@@ -175,7 +214,7 @@ int main(int argc, char** argv) {
   {
     const size_t n16 = 24883200 / 16;
     for (int nt : {0, 1})
-      for (int blocks : {2048, 4096, 8192, 16384}) {
+      for (int blocks : {2048, 8192, 16384, 97200}) {
         Timing t = time_graph(st, [&](int i, hipStream_t s) { int k = i % NSETS; copy16_kernel<<<blocks, 256, 0, s>>>((u32x4*)dd[k], (const u32x4*)ds[k], n16, nt); });
         printf("copy 24.9 MB -> 24.9 MB, 16 B/lane grid-stride, %5d blocks, nt=%d: best %6.2f med %6.2f us (%.2f TB/s)\n", blocks, nt, t.best, t.med, 2.0 * 24883200 / t.med / 1e6);
       }

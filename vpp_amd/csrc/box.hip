@@ -431,13 +431,22 @@ __device__ __forceinline__ void box_u8_wide_body(const BoxGeom& g, int x0, int r
   }
 }
 
-// nby row blocks per strip: the first nhi have RW rows, the others RW - 1 (nhi == nby: all RW)
+// nby row blocks per strip: the first nhi have RW rows, the others RW - 1 (nhi == nby: all RW).
+// One launch serves a BATCH of nframes frames of one geometry (vpp_box_filter_batch; vpp_box_filter = a batch of one): the block grid is the
+// frames' grids back to back, walked XCD-major as a whole, so the chip never drains between frames — consecutive single-frame launches each
+// pay their own ramp and tail (a 50 MB frame is only ~6 rounds of resident waves) and, from a host that submits few launches per
+// synchronisation, the submission latency once per frame.
+constexpr int kBoxBatchMax = 32;
+struct BoxBatch { const uint8_t* sbase[kBoxBatchMax]; uint8_t* dbase[kBoxBatchMax]; };
 template <int CH, int KR, int KC, int RW, int WX, int SAUX, int LAUX, bool HALO, int OCC, int PROBE, int NW = 4>
-__global__ __launch_bounds__(64 * NW, OCC * 4 / NW) void box_u8_wide_kernel(const BoxGeom g) {
+__global__ __launch_bounds__(64 * NW, OCC * 4 / NW) void box_u8_wide_kernel(const BoxGeom g0, const BoxBatch frames, int nframes) {
   static_assert(CH >= 1 && CH <= 4 && NW % WX == 0, "window holds 2*CH <= 8 halo bytes; NW waves per workgroup, WX of them side by side");
   constexpr int WY = NW / WX;
-  const unsigned nb = (unsigned)g.nbx * (unsigned)g.nby;
-  const unsigned lb = (g.order & 2) ? blockIdx.x : xcd_remap(blockIdx.x, nb);
+  const unsigned nb = (unsigned)g0.nbx * (unsigned)g0.nby;
+  const unsigned L = (g0.order & 2) ? blockIdx.x : xcd_remap(blockIdx.x, nb * (unsigned)nframes);
+  const unsigned f = L / nb, lb = L - f * nb;
+  BoxGeom g = g0;
+  g.sbase = frames.sbase[f]; g.dbase = frames.dbase[f];
   int bx, by;
   if ((g.order & 1) == 0) { by = lb / g.nbx; bx = lb - by * g.nbx; } else { bx = lb / g.nby; by = lb - bx * g.nby; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -696,8 +705,23 @@ inline bool fits_descriptor(const vpp_image_desc* dst, const vpp_image_desc* src
   const size_t lim = 0xFFFFFF00u;
   return (size_t)(src->nrows + 2 * src->border) * (size_t)src->pitch + 64 < lim && (size_t)dst->nrows * (size_t)dst->pitch < lim;
 }
+template <int CH, int RW, int WX, bool HALO, int NW>
+BoxGeom wide_geometry(const vpp_image_desc* dst, const vpp_image_desc* src, int order, int mix, int slots);
 template <int CH, int RW, int WX, int SAUX, bool HALO, int OCC, int PROBE, int KR = 5, int KC = 5, int NW = 4, int LAUX = kAuxDefault>
-void launch_wide_cfg(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st, int order, int mix, int slots) {
+void launch_wide_cfg(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st, int order, int mix, int slots, int n = 1) {
+  const BoxGeom g = wide_geometry<CH, RW, WX, HALO, NW>(&dst[0], &src[0], order, mix, slots);   // n frames of one geometry: dst[k] <- src[k]
+  for (int b0 = 0; b0 < n; b0 += kBoxBatchMax) {
+    const int nb = std::min(kBoxBatchMax, n - b0);
+    BoxBatch fr{};
+    for (int k = 0; k < nb; k++) {
+      fr.sbase[k] = (const uint8_t*)src[b0 + k].first_pixel - (ptrdiff_t)src[b0 + k].border * src[b0 + k].pitch - 16;
+      fr.dbase[k] = (uint8_t*)dst[b0 + k].first_pixel;
+    }
+    box_u8_wide_kernel<CH, KR, KC, RW, WX, SAUX, LAUX, HALO, OCC, PROBE, NW><<<g.nbx * g.nby * nb, 64 * NW, 0, st>>>(g, fr, nb);
+  }
+}
+template <int CH, int RW, int WX, bool HALO, int NW>
+BoxGeom wide_geometry(const vpp_image_desc* dst, const vpp_image_desc* src, int order, int mix, int slots) {
   const int row_bytes = dst->ncols * CH, strip = HALO ? 1024 : kStripOut, WY = NW / WX, bb = src->border * CH;
   const int nstrips = (row_bytes + strip - 1) / strip;
   BoxGeom g;
@@ -718,9 +742,9 @@ void launch_wide_cfg(const vpp_image_desc* dst, const vpp_image_desc* src, hipSt
   g.sbytes = (uint32_t)((size_t)(dst->nrows - 1 + 2 * src->border) * src->pitch + 16 + (size_t)((row_bytes + bb + 15) & ~15));
   g.dbytes = (uint32_t)((size_t)(dst->nrows - 1) * dst->pitch + row_bytes);
   g.spitch = src->pitch; g.dpitch = dst->pitch; g.nrows = dst->nrows; g.row_bytes = row_bytes; g.srow0 = src->border;
-  box_u8_wide_kernel<CH, KR, KC, RW, WX, SAUX, LAUX, HALO, OCC, PROBE, NW><<<g.nbx * g.nby, 64 * NW, 0, st>>>(g);
+  return g;
 }
-template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st) {
+template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st, int n = 1) {
   // measured on MI355X (tools/boxlab, 4K vuchar3): 992-B strips, 2 rows per wave, workgroup = 4 strips side by side, block grid
   // walked row-major per XCD, non-temporal stores: 8.6 us; strip-major order 8.9, one strip per workgroup 9.4, no XCD remap 15.5
   const int rows = tuning("box.rows", 2), wx = tuning("box.wx", 4), sp = tuning("box.sp", kAuxNT), order = tuning("box.order", 0);
@@ -730,7 +754,7 @@ template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_des
   bool done = false;
   auto try_cfg = [&](auto RWc, auto WXc, auto SPc, auto HALOc, auto OCCc, auto PRc) {
     if (!done && rows == decltype(RWc)::value && wx == decltype(WXc)::value && sp == decltype(SPc)::value && halo == (int)decltype(HALOc)::value && occ == decltype(OCCc)::value && probe == decltype(PRc)::value) {
-      launch_wide_cfg<CH, decltype(RWc)::value, decltype(WXc)::value, decltype(SPc)::value, decltype(HALOc)::value, decltype(OCCc)::value, decltype(PRc)::value>(dst, src, st, order, mix, slots);
+      launch_wide_cfg<CH, decltype(RWc)::value, decltype(WXc)::value, decltype(SPc)::value, decltype(HALOc)::value, decltype(OCCc)::value, decltype(PRc)::value>(dst, src, st, order, mix, slots, n);
       done = true;
     }
   };
@@ -757,7 +781,7 @@ template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_des
   if (CH == 3 && !done && (shape || laux || (sp != kAuxNT && sp != (kAuxNT | kAuxSC1)))) {
     // policy / workgroup-shape sweep around the chosen geometry (992-B strips, 2 rows per wave)
     auto pol = [&](auto SPc, auto LAc) {
-      if (!done && shape == 0 && sp == decltype(SPc)::value && laux == decltype(LAc)::value) { launch_wide_cfg<CH, 2, 4, decltype(SPc)::value, false, 8, 0, 5, 5, 4, decltype(LAc)::value>(dst, src, st, order, mix, slots); done = true; }
+      if (!done && shape == 0 && sp == decltype(SPc)::value && laux == decltype(LAc)::value) { launch_wide_cfg<CH, 2, 4, decltype(SPc)::value, false, 8, 0, 5, 5, 4, decltype(LAc)::value>(dst, src, st, order, mix, slots, n); done = true; }
     };
     auto pols = [&](auto LAc) {
       pol(std::integral_constant<int, 0>(), LAc); pol(std::integral_constant<int, 1>(), LAc); pol(std::integral_constant<int, 2>(), LAc); pol(std::integral_constant<int, 3>(), LAc);
@@ -767,16 +791,16 @@ template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_des
     if (!done && sp == kAuxNT && laux == 0) {
       done = true;
       switch (shape * 10 + rows) {
-        case 12: launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0, 5, 5, 8>(dst, src, st, order, mix, slots); break;   // 512 threads: 4 strips x 2 row blocks
-        case 13: launch_wide_cfg<CH, 3, 4, kAuxNT, false, 8, 0, 5, 5, 8>(dst, src, st, order, mix, slots); break;
-        case 22: launch_wide_cfg<CH, 2, 6, kAuxNT, false, 8, 0, 5, 5, 6>(dst, src, st, order, mix, slots); break;   // 384 threads: 6 strips side by side
-        case 32: launch_wide_cfg<CH, 2, 12, kAuxNT, false, 8, 0, 5, 5, 12>(dst, src, st, order, mix, slots); break; // 768 threads: a whole 4K row
-        case 42: launch_wide_cfg<CH, 2, 3, kAuxNT, false, 8, 0, 5, 5, 3>(dst, src, st, order, mix, slots); break;   // 192 threads: 3 strips
-        case 52: launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0, 5, 5, 16>(dst, src, st, order, mix, slots); break;  // 1024 threads: 4 strips x 4 row blocks
-        case 62: launch_wide_cfg<CH, 2, 2, kAuxNT, false, 8, 0, 5, 5, 8>(dst, src, st, order, mix, slots); break;   // 512 threads: 2 strips x 4 row blocks
-        case 72: launch_wide_cfg<CH, 2, 2, kAuxNT, false, 8, 0, 5, 5, 2>(dst, src, st, order, mix, slots); break;   // 128 threads: 2 strips side by side
-        case 82: launch_wide_cfg<CH, 2, 1, kAuxNT, false, 8, 0, 5, 5, 1>(dst, src, st, order, mix, slots); break;   // 64 threads: one strip per workgroup
-        case 92: launch_wide_cfg<CH, 2, 1, kAuxNT, false, 8, 0, 5, 5, 2>(dst, src, st, order, mix, slots); break;   // 128 threads: 1 strip x 2 row blocks
+        case 12: launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0, 5, 5, 8>(dst, src, st, order, mix, slots, n); break;   // 512 threads: 4 strips x 2 row blocks
+        case 13: launch_wide_cfg<CH, 3, 4, kAuxNT, false, 8, 0, 5, 5, 8>(dst, src, st, order, mix, slots, n); break;
+        case 22: launch_wide_cfg<CH, 2, 6, kAuxNT, false, 8, 0, 5, 5, 6>(dst, src, st, order, mix, slots, n); break;   // 384 threads: 6 strips side by side
+        case 32: launch_wide_cfg<CH, 2, 12, kAuxNT, false, 8, 0, 5, 5, 12>(dst, src, st, order, mix, slots, n); break; // 768 threads: a whole 4K row
+        case 42: launch_wide_cfg<CH, 2, 3, kAuxNT, false, 8, 0, 5, 5, 3>(dst, src, st, order, mix, slots, n); break;   // 192 threads: 3 strips
+        case 52: launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0, 5, 5, 16>(dst, src, st, order, mix, slots, n); break;  // 1024 threads: 4 strips x 4 row blocks
+        case 62: launch_wide_cfg<CH, 2, 2, kAuxNT, false, 8, 0, 5, 5, 8>(dst, src, st, order, mix, slots, n); break;   // 512 threads: 2 strips x 4 row blocks
+        case 72: launch_wide_cfg<CH, 2, 2, kAuxNT, false, 8, 0, 5, 5, 2>(dst, src, st, order, mix, slots, n); break;   // 128 threads: 2 strips side by side
+        case 82: launch_wide_cfg<CH, 2, 1, kAuxNT, false, 8, 0, 5, 5, 1>(dst, src, st, order, mix, slots, n); break;   // 64 threads: one strip per workgroup
+        case 92: launch_wide_cfg<CH, 2, 1, kAuxNT, false, 8, 0, 5, 5, 2>(dst, src, st, order, mix, slots, n); break;   // 128 threads: 1 strip x 2 row blocks
         default: done = false;
       }
     }
@@ -784,7 +808,13 @@ template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_des
   if (!done) { set_error("boxlab: configuration rows=%d wx=%d sp=%d halo=%d occ=%d probe=%d not instantiated", rows, wx, sp, halo, occ, probe); return VPP_ERR_UNSUPPORTED; }
 #else
   (void)rows; (void)wx; (void)sp; (void)halo;
-  launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0>(dst, src, st, order, mix, slots);
+  // Round 3, sources really from HBM (tools/boxlab sweep6-9, 32 rotating frame sets; us per 4K vuchar3 frame at 1 / 2 / 4 / 8 / 16 / 32 frames per
+  // launch): 2 rows per wave 13.4 / 11.5 / 10.6 / 10.1 / 9.4 / 9.2, 3 rows 13.3 / 11.3 / 10.4 / 9.8 / 9.0 / 8.8, 6 rows at 4 waves per SIMD
+  // 13.7 / 11.3 / 10.2 / 9.4 / 8.6 / 8.4 — more new bytes in flight per wave (10 row loads for 6 rows instead of 6 for 2) once there are
+  // enough waves; a plain copy of the same geometry: 11.8 / 10.2 / 9.1 / 8.6 / 8.1 / 8.0.
+  if (n >= 4) launch_wide_cfg<CH, 6, 4, kAuxNT, false, 4, 0>(dst, src, st, order, mix, slots, n);
+  else if (n >= 2) launch_wide_cfg<CH, 3, 4, kAuxNT, false, 8, 0>(dst, src, st, order, mix, slots, n);
+  else launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0>(dst, src, st, order, mix, slots, n);
 #endif
   VPP_LAUNCH_CHECK();
   return VPP_OK;
@@ -881,6 +911,34 @@ template <int CH> int launch_stream_windows(const vpp_image_desc* dst, const vpp
     }
   }
   return -1;  // not a streaming window: the caller falls back to the LDS-tiled generic kernel
+}
+
+// n frames of one geometry, one launch (u8 5x5 images the streaming kernel serves; anything else goes out as n calls of vpp_box_filter)
+extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream);
+extern "C" int vpp_box_filter_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int R, int C, void* stream) {
+  VPP_REQUIRE(n >= 0 && (n == 0 || (dst && src)), VPP_ERR_INVALID_ARG, "vpp_box_filter_batch: invalid argument");
+  if (n == 0) return VPP_OK;
+  bool same = true;
+  for (int k = 0; k < n; k++) {
+    VPP_REQUIRE(valid_desc(&dst[k]) && valid_desc(&src[k]), VPP_ERR_INVALID_ARG, "vpp_box_filter_batch: invalid descriptor %d", k);
+    same = same && same_domain(&dst[k], &dst[0]) && same_type(&dst[k], &dst[0]) && dst[k].pitch == dst[0].pitch && same_domain(&src[k], &dst[0]) && same_type(&src[k], &dst[0]) &&
+           src[k].pitch == src[0].pitch && src[k].border == src[0].border && dst[k].first_pixel != src[k].first_pixel;
+  }
+  const bool wide = same && n > 1 && R == 5 && C == 5 && dst[0].dtype == VPP_U8 && dst[0].channels <= 4 && src[0].border >= 2 && !tuning("box.force_generic", 0) &&
+                    tuning("box.impl", 2) == 2 && tuning("box.batch", 1);
+  bool ok16 = wide;
+  for (int k = 0; ok16 && k < n; k++) ok16 = aligned16(&dst[k]) && aligned16(&src[k]) && fits_descriptor(&dst[k], &src[k]);
+  if (ok16) {
+    hipStream_t st = as_stream(stream);
+    switch (dst[0].channels) {
+      case 1: return launch_wide<1>(dst, src, st, n);
+      case 2: return launch_wide<2>(dst, src, st, n);
+      case 3: return launch_wide<3>(dst, src, st, n);
+      case 4: return launch_wide<4>(dst, src, st, n);
+    }
+  }
+  for (int k = 0; k < n; k++) { const int rc = vpp_box_filter(&dst[k], &src[k], R, C, stream); if (rc) return rc; }
+  return VPP_OK;
 }
 
 extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream) {

@@ -5,6 +5,7 @@
 // accesses in flight per lane.  Row-pitch aware: images whose rows are contiguous are walked as one flat byte range,
 // otherwise one grid row per image row.  Algorithmic bytes: (2 reads + 1 write) * sizeof(V) per pixel (12 B/px for int).
 #include "common.hpp"
+#include <algorithm>
 #include <cstring>
 #include <type_traits>
 using namespace vpp_amd;
@@ -104,9 +105,8 @@ template <int OP, class T> __device__ __forceinline__ u32x4 op_vec(u32x4 a, u32x
 
 // Flat range of nvec 16-byte vectors (+ tail bytes handled by the scalar kernel).
 template <int OP, class T, int UNROLL, bool NT>
-__global__ __launch_bounds__(256) void binary_flat_kernel(u32x4* __restrict__ d, const u32x4* __restrict__ a,
-                                                          const u32x4* __restrict__ b, size_t nvec) {
-  const size_t base = (size_t)blockIdx.x * (256 * UNROLL) + threadIdx.x;
+__device__ __forceinline__ void binary_flat_body(u32x4* __restrict__ d, const u32x4* __restrict__ a, const u32x4* __restrict__ b, size_t nvec, unsigned blk) {
+  const size_t base = (size_t)blk * (256 * UNROLL) + threadIdx.x;
   if constexpr (std::is_integral<T>::value && sizeof(T) == 4) {
     // 32-bit integers (the 4K add of the benchmark): per-access guards.  This form compiles to 40 VGPRs and measures 15.7 us on the
     // 99.5 MB add; the unguarded form below makes the scheduler hold more loads back (56-66 VGPRs) and measures 16.6 us.
@@ -151,6 +151,20 @@ __global__ __launch_bounds__(256) void binary_flat_kernel(u32x4* __restrict__ d,
     const size_t i = base + (size_t)u * 256;
     if (i < nvec) d[i] = op_vec<OP, T>(a[i], b[i]);
   }
+}
+
+template <int OP, class T, int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void binary_flat_kernel(u32x4* __restrict__ d, const u32x4* __restrict__ a,
+                                                          const u32x4* __restrict__ b, size_t nvec) {
+  binary_flat_body<OP, T, UNROLL, NT>(d, a, b, nvec, blockIdx.x);
+}
+// n image triples of one size in ONE launch (vpp_pixelwise_binary_batch): the frames' block ranges back to back, no drain between frames
+constexpr int kPwBatchMax = 16;
+struct PwBatch { u32x4* d[kPwBatchMax]; const u32x4* a[kPwBatchMax]; const u32x4* b[kPwBatchMax]; };
+template <int OP, class T, int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void binary_flat_batch_kernel(const PwBatch fr, size_t nvec, unsigned blocks_per_frame) {
+  const unsigned f = blockIdx.x / blocks_per_frame, blk = blockIdx.x - f * blocks_per_frame;
+  binary_flat_body<OP, T, UNROLL, NT>(fr.d[f], fr.a[f], fr.b[f], nvec, blk);
 }
 
 // Pitched rows: blockIdx.y = row, x covers the row's 16-byte vectors; row tail (< 16 B) done scalar by one lane.
@@ -271,6 +285,24 @@ __global__ __launch_bounds__(256) void fill_kernel_v(DImg d, int r0, int c0, int
 
 }  // namespace
 
+namespace {
+// n triples of one size in one launch: the batched form of the flat 32-bit integer / float case (contiguous 16-byte aligned images — what
+// imageNd::allocate gives a border-less image whose row is a multiple of the alignment); anything else goes out as n single calls.
+template <int OP, class T> int launch_flat_batch(const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, int n, hipStream_t st) {
+  const size_t total = (size_t)dst[0].ncols * elem_bytes(&dst[0]) * dst[0].nrows, nvec = total >> 4;
+  constexpr int UN = 8;
+  const unsigned bpf = (unsigned)((nvec + 256 * UN - 1) / (256 * UN));
+  for (int b0 = 0; b0 < n; b0 += kPwBatchMax) {
+    const int nb = std::min(kPwBatchMax, n - b0);
+    PwBatch fr{};
+    for (int k = 0; k < nb; k++) { fr.d[k] = (u32x4*)dst[b0 + k].first_pixel; fr.a[k] = (const u32x4*)a[b0 + k].first_pixel; fr.b[k] = (const u32x4*)b[b0 + k].first_pixel; }
+    binary_flat_batch_kernel<OP, T, UN, true><<<bpf * nb, 256, 0, st>>>(fr, nvec, bpf);
+  }
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int vpp_pixelwise_binary(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, void* stream) {
@@ -288,6 +320,29 @@ int vpp_pixelwise_binary(int op, const vpp_image_desc* dst, const vpp_image_desc
     case VPP_F32: return dispatch_op<float>(op, dst, a, b, st);
   }
   return VPP_ERR_UNSUPPORTED;
+}
+
+int vpp_pixelwise_binary_batch(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, int n, void* stream) {
+  VPP_REQUIRE(n >= 0 && (n == 0 || (dst && a && b)), VPP_ERR_INVALID_ARG, "vpp_pixelwise_binary_batch: invalid argument");
+  if (n == 0) return VPP_OK;
+  bool flat = n > 1 && tuning("add.batch", 1) && op >= VPP_OP_ADD && op <= VPP_OP_ABSDIFF;
+  for (int k = 0; k < n && flat; k++) {
+    const vpp_image_desc* t[3] = {&dst[k], &a[k], &b[k]};
+    for (const vpp_image_desc* d : t) {
+      const int row_bytes = d->ncols * elem_bytes(d);
+      flat = flat && valid_desc(d) && same_domain(d, &dst[0]) && same_type(d, &dst[0]) && aligned16(d) && d->pitch == row_bytes && ((size_t)row_bytes * d->nrows) % 16 == 0;
+    }
+  }
+  flat = flat && (dst[0].dtype == VPP_I32 || dst[0].dtype == VPP_U32);
+  if (flat) {
+    hipStream_t st = as_stream(stream);
+    switch (op) {
+      case VPP_OP_ADD: return launch_flat_batch<VPP_OP_ADD, int32_t>(dst, a, b, n, st);
+      case VPP_OP_SUB: return launch_flat_batch<VPP_OP_SUB, int32_t>(dst, a, b, n, st);
+    }
+  }
+  for (int k = 0; k < n; k++) { const int rc = vpp_pixelwise_binary(op, &dst[k], &a[k], &b[k], stream); if (rc) return rc; }
+  return VPP_OK;
 }
 
 int vpp_copy(const vpp_image_desc* dst, const vpp_image_desc* src, int with_border, void* stream) {
