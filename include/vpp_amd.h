@@ -160,6 +160,11 @@ typedef enum vpp_fast9_compat {
  * synchronises the stream.  count > capacity => VPP_ERR_CAPACITY (first `capacity` entries valid). */
 int vpp_fast9_detect(const vpp_image_desc* src, int th, const vpp_image_desc* mask, int mode, int block_size,
                      int compat, int32_t* out_rc, int32_t* out_scores, int capacity, int* count, void* stream);
+/* The same detection without the host round trip: everything is queued on `stream` and the number of keypoints found (not clamped to
+ * `capacity`; entries beyond it are not written) lands in *count_dev, a device-visible 32-bit word (HBM or vpp_malloc_host memory), for a
+ * consumer on the same stream — or for the host after its own synchronisation.  Can be recorded into a launch graph. */
+int vpp_fast9_detect_async(const vpp_image_desc* src, int th, const vpp_image_desc* mask, int mode, int block_size,
+                           int compat, int32_t* out_rc, int32_t* out_scores, int capacity, uint32_t* count_dev, void* stream);
 /* fast9_scores (fast.hpp:643-652): n (row,col) pairs in device memory -> n int32 full scores. */
 int vpp_fast9_scores(const vpp_image_desc* src, int th, const int32_t* rc, int n, int32_t* out_scores, void* stream);
 /* FAST_internals::fast_detector9(A, B, th) (fast.hpp:511-551): dst(r,c) = 1 where 9 contiguous pixels of the TRUE 16-pixel

@@ -125,7 +125,8 @@ def test_gpu_matches_reference_golden(lib):
     got = dk.cpu().numpy().view(pyr.KP_DTYPE); want = g["kps"].view(pyr.KP_DTYPE)
     np.testing.assert_array_equal(got["age"], want["age"])
     for f in ("pos_r", "pos_c", "vel_r", "vel_c"):
-        np.testing.assert_allclose(got[f], want[f], rtol=1e-4, atol=1e-4)  # north-star tolerance; observed bit-identical
+        np.testing.assert_allclose(got[f], want[f], rtol=1e-4, atol=1e-4 if f.startswith("pos") else 0.0)  # north-star tolerance: relative on the displacements
+        assert (got[f].view(np.uint32) == want[f].view(np.uint32)).mean() > 0.999, f                             # observed: bit-identical
     j1, j2, pts = gc.lk_golden_case(); g = load("lucas_kanade")
     dp1 = pyr.device_pyramid(lib, DeviceImage.from_host(j1), 2, 2); dp2 = pyr.device_pyramid(lib, DeviceImage.from_host(j2), 2, 2)
     dg = pyr.device_grad_pyramid(lib, dp1[0], 2, 2, vi.I32)

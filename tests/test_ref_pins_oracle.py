@@ -204,3 +204,50 @@ def test_local_maxima_filter(orc, ref, dtype, kind):
     assert ref.ref_local_maxima_filter(P(a.desc)) == 0
     assert orc.orc_local_maxima_filter(P(b.desc)) == 0
     np.testing.assert_array_equal(a.raw, b.raw)
+
+
+def _min_ev_boundary(track_alive, lo=1e-4, hi=1e9):
+    """Smallest float32 threshold at which `track_alive(th)` turns False (the keypoint is kept at lo and removed at hi): bisection over the
+    float's bit pattern, so the answer is exact to the ulp."""
+    lo_b, hi_b = int(np.float32(lo).view(np.uint32)), int(np.float32(hi).view(np.uint32))
+    assert track_alive(np.float32(lo)) and not track_alive(np.float32(hi))
+    while hi_b - lo_b > 1:
+        mid = (lo_b + hi_b) // 2
+        if track_alive(np.array([mid], np.uint32).view(np.float32)[0]):
+            lo_b = mid
+        else:
+            hi_b = mid
+    return np.array([hi_b], np.uint32).view(np.float32)[0]
+
+
+def test_min_ev_gate_at_the_threshold(orc, ref):
+    """lk.hh:75-81 removes a keypoint when min |eigenvalue| of its structure tensor is below `_min_ev`.  The reference takes the eigenvalues
+    from Eigen's general solver (third-party, absent here); the shim and the oracle use the closed form of the symmetric 2x2 case.  For a
+    handful of keypoints the exact float threshold at which the ORACLE starts to remove the keypoint is found by bisection, and the
+    reference's own code over the shim is shown to flip at the same ulp (kept one ulp below, removed at and above)."""
+    f1, f2, kps = lk_scene(120, 160, 40)
+    i1, i2 = u8_image(f1), u8_image(f2)
+    hp1, hp2 = pyr.host_pyramid(orc, i1, 3, 5), pyr.host_pyramid(orc, i2, 3, 5)
+    hg = pyr.host_grad_pyramid(orc, hp1[0], 3, 5, vi.F32)
+
+    def orc_alive(k, th):
+        one = kps[k:k + 1].copy()
+        orc.orc_pyrlk_match(vi.desc_array(hp1), vi.desc_array(hg), vi.desc_array(hp2), 3, one.ctypes.data_as(ctypes.c_void_p), 1, 7,
+                            ctypes.c_float(float(th)), ctypes.c_float(1e9), 30, ctypes.c_float(0.01), 0, None)
+        return bool(one["age"][0] > 0)
+
+    def ref_alive(k, th):
+        one = kps[k:k + 1].copy()
+        assert ref.ref_pyrlk_match(P(i1.desc), P(i2.desc), 3, 5, one.ctypes.data_as(ctypes.c_void_p), 1, 7, ctypes.c_float(float(th)), ctypes.c_float(1e9), 30, ctypes.c_float(0.01), 0) == 0
+        return bool(one["age"][0] > 0)
+
+    found = 0
+    for k in range(0, 40, 7):
+        if not orc_alive(k, 1e-4):
+            continue
+        t = _min_ev_boundary(lambda th: orc_alive(k, th))
+        below, above = np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(np.inf))
+        assert orc_alive(k, below) and not orc_alive(k, t) and not orc_alive(k, above)
+        assert ref_alive(k, below) and not ref_alive(k, t) and not ref_alive(k, above), (k, t)
+        found += 1
+    assert found >= 4
