@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DIR = os.path.join(ROOT, "oracle", "_ref", "unit_tests_gpu")
 NAMES = ["imageNd", "image2d", "image3d", "imageNd_iterator", "boxNd_iterator", "box_nbh2d", "pixel_wise", "block_wise", "border", "fill", "sum",
-         "colorspace_conversions", "pyramid", "tuple_utils", "window", "sandbox", "lbp"]
+         "colorspace_conversions", "pyramid", "tuple_utils", "window", "sandbox", "lbp", "cast"]
 
 
 @pytest.mark.parametrize("name", NAMES)

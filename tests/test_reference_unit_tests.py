@@ -2,7 +2,7 @@
 lie under /root/reference against vpp_amd/include (host build, no OpenMP — the reference's tests/CMakeLists.txt builds them serially —
 asserts on) and run.  Nothing is copied; where the reference tree is absent (the GPU box) the test is skipped.
 
-Not in the list, and why: cast.cc (spells Eigen::Matrix types directly), liie.cc (iod's expression templates), pyrlk.cc and
+Not in the list, and why: liie.cc (iod's expression templates), pyrlk.cc and
 opencv_bridge.cc (OpenCV bridge; tests/pyrlk.cc's golden is restated in tests/test_gpu_algos.py), descriptor_matcher.cc (not on the
 path), lbp.cc (algorithm headers are device-only: tests/test_gpu_video_steps.py)."""
 import os
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/tests"
 OUT = os.path.join(ROOT, "tests", "cpp", "_build", "ref_tests")
 NAMES = ["imageNd", "image2d", "image3d", "imageNd_iterator", "boxNd_iterator", "box_nbh2d", "pixel_wise", "block_wise", "border", "fill", "sum",
-         "colorspace_conversions", "pyramid", "tuple_utils", "window", "sandbox"]
+         "colorspace_conversions", "pyramid", "tuple_utils", "window", "sandbox", "cast"]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not on this machine")

@@ -14,14 +14,32 @@
 #define VPP_HD
 #endif
 
+// The reference's pixel vectors ARE Eigen::Matrix<T,N,1> (vpp/core/vector.hh:10-20), and user code may name their Eigen bases
+// (tests/cast.cc:9-13 binds a vuchar3 to `const Eigen::MatrixBase<vuchar3>&` and asks is_base_of<Eigen::EigenBase<V>, V>).  The two CRTP
+// tags below are empty (the vector keeps its exact N * sizeof(T) layout through the empty-base optimisation) and give back the
+// vector through derived(); Eigen::Matrix<T,N,1> names the same type as vpp::vector<T,N>.
+namespace Eigen {
+template <class D> struct EigenBase {
+  VPP_HD const D& derived() const { return *static_cast<const D*>(this); }
+  VPP_HD D& derived() { return *static_cast<D*>(this); }
+};
+template <class D> struct MatrixBase : EigenBase<D> {
+  friend VPP_HD bool operator==(const D& a, const MatrixBase& b) { return a == b.derived(); }
+  friend VPP_HD bool operator==(const MatrixBase& a, const D& b) { return a.derived() == b; }
+  friend VPP_HD bool operator!=(const D& a, const MatrixBase& b) { return !(a == b.derived()); }
+  friend VPP_HD bool operator!=(const MatrixBase& a, const D& b) { return !(a.derived() == b); }
+};
+}  // namespace Eigen
+
 namespace vpp {
 
-template <class T, unsigned N> struct vector {
+template <class T, unsigned N> struct vector : Eigen::MatrixBase<vector<T, N>> {
   typedef T Scalar;
   enum { SizeAtCompileTime = N };
   T v[N];
 
   vector() = default;
+  template <class A, unsigned M = N, class = typename std::enable_if<M == 1 && std::is_arithmetic<A>::value>::type> VPP_HD explicit vector(A a) { v[0] = T(a); }   // vfloat1(1): Eigen's 1x1 scalar constructor
   template <class A, class B, unsigned M = N, class = typename std::enable_if<M == 2>::type> VPP_HD vector(A a, B b) { v[0] = T(a); v[1] = T(b); }
   template <class A, class B, class C, unsigned M = N, class = typename std::enable_if<M == 3>::type> VPP_HD vector(A a, B b, C c) { v[0] = T(a); v[1] = T(b); v[2] = T(c); }
   template <class A, class B, class C, class D, unsigned M = N, class = typename std::enable_if<M == 4>::type> VPP_HD vector(A a, B b, C c, D d) { v[0] = T(a); v[1] = T(b); v[2] = T(c); v[3] = T(d); }
@@ -92,8 +110,19 @@ template <class U, class X, unsigned N> VPP_HD typename std::enable_if<detail::i
 template <class U, class X> VPP_HD typename std::enable_if<!detail::is_vector<U>::value, U>::type cast(const vector<X, 1>& v) { return U(v[0]); }
 template <class U, class V> VPP_HD typename std::enable_if<detail::is_vector<U>::value && !detail::is_vector<V>::value, U>::type cast(const V& v) { U r; r[0] = typename U::Scalar(v); return r; }
 
+static_assert(sizeof(vuchar3) == 3 && sizeof(vfloat2) == 8 && sizeof(vint1) == 4, "pixel vectors are exactly their components: the pitches depend on it");
+static_assert(std::is_trivially_copyable<vuchar3>::value && std::is_standard_layout<vuchar3>::value, "pixel vectors travel by memcpy / as kernel arguments");
+
 // pixel-type traits used by the device glue: component type + channel count
 template <class V> struct pixel_traits { typedef V component; enum { channels = 1 }; };
 template <class X, unsigned N> struct pixel_traits<vector<X, N>> { typedef X component; enum { channels = N }; };
 
 }  // namespace vpp
+
+namespace Eigen {
+namespace vpp_detail {
+template <class T, int R, int C> struct column_vector;   // only column vectors exist on this path (vector.hh:10: Matrix<T, N, 1>)
+template <class T, int R> struct column_vector<T, R, 1> { typedef vpp::vector<T, unsigned(R)> type; };
+}  // namespace vpp_detail
+template <class T, int R, int C = 1> using Matrix = typename vpp_detail::column_vector<T, R, C>::type;
+}  // namespace Eigen
