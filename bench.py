@@ -4,8 +4,8 @@
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
-the 5x5 box_nbh2d filter of a batch of 16 distinct 3840x2160 vuchar3 frames (BASELINE.json configs[1]) in ONE launch
-(vpp_box_filter_batch), rotating over 32 frame sets = 800 MB of sources, so that the 256 MiB Infinity Cache cannot serve the reads.  The per-frame call form is timed beside it.
+the 5x5 box_nbh2d filter of a batch of 32 distinct 3840x2160 vuchar3 frames (BASELINE.json configs[1]) in ONE launch
+(vpp_box_filter_batch), rotating over 64 frame sets = 1.6 GB of sources, so that the 256 MiB Infinity Cache cannot serve the reads.  The per-frame call form is timed beside it.
 value = Gpixels/s over all ranks (box / add / FAST "shard" as independent replicas: "replicas only").
 Extra objects on the same JSON line: roofline (dominant kernel vs HBM), cpu_baseline (the oracle timed on the host
 cores, bounded sample), add4k (4K int32 pixel_wise add) and — when built — pyrlk (tracks/s, keypoint-sharded + all-gather).
@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--regions", type=int, default=5, help="timed regions of exactly --steps launches each; the median one (by wall clock) is reported, all are listed")
     ap.add_argument("--preheat", type=float, default=0.3, help="seconds of untimed, reported replays before each headline timed region (clock ramp)")
     ap.add_argument("--workload", default="box5x5", choices=["box5x5"])
-    ap.add_argument("--sets", type=int, default=32, help="distinct 4K frame sets the steps rotate over (16 per step): 32 sets = 800 MB of sources + 800 MB of results")
+    ap.add_argument("--sets", type=int, default=64, help="distinct 4K frame sets the steps rotate over (32 per step): 64 sets = 1.6 GB of sources + 1.6 GB of results")
     args = ap.parse_args()
 
     import numpy as np
@@ -220,8 +220,8 @@ def main():
     NR, NC = 2160, 3840
     npx = NR * NC
     src_h = rand_image(NR, NC, vi.U8, 3, border=2, seed=3, align=16)
-    FPS = 16                              # frames per step: one step = a batch of 16 frames filtered by ONE launch (vpp_box_filter_batch)
-    nsets = max(FPS, args.sets // FPS * FPS)  # 32 x 25.0 MB of sources alone = 800 MB: even a cache that kept only the reads (the stores are non-temporal) could not hold them in 256 MiB
+    FPS = 32                              # frames per step: one step = a batch of 32 frames filtered by ONE launch (vpp_box_filter_batch; kBoxBatchMax)
+    nsets = max(FPS, args.sets // FPS * FPS)  # one step alone reads 32 x 25.0 MB = 800 MB and writes as much: no part of it survives in the 256 MiB Infinity Cache until the next step
     srcs = [DeviceImage.from_host(src_h, dev) for _ in range(nsets)]
     dsts = [DeviceImage(NR, NC, vi.U8, 3, 0, 16, dev) for _ in range(nsets)]
     for s in srcs:
@@ -249,7 +249,7 @@ def main():
     alg_bytes = 6 * npx * FPS                              # 6 B/px (3 read + 3 written), x the frames one launch processes
     launch_s = ev / args.steps                             # HIP event-record nodes around exactly the K timed launches, on the launch stream
     sustained_s = box_regions["sample"]["us_per_launch"] * 1e-6
-    roof = {"bound": "hbm", "kernel": "box_u8_wide_kernel<3, 5, 5, 6, 4, ...> (16 frames per launch)", "achieved": alg_bytes / launch_s / 1e9, "peak": HBM_PEAK_GBS,
+    roof = {"bound": "hbm", "kernel": f"box_u8_wide_kernel<3, 5, 5, 6, 4, ...> ({FPS} frames per launch)", "achieved": alg_bytes / launch_s / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": FPS, "avg_launch_us": launch_s * 1e6,
             "how": "achieved = algorithmic bytes / average launch duration over the K timed launches themselves (event-record nodes in front of the first and behind the last of them)",
             "frac_sustained": alg_bytes / sustained_s / 1e9 / HBM_PEAK_GBS, "avg_launch_us_sustained": sustained_s * 1e6, "sample": box_regions["sample"]}
@@ -268,7 +268,7 @@ def main():
     roof["traffic"], roof["traffic_source"] = pmc_traffic("box_u8_wide_kernel<3, 5, 5, 6")
     if roof["traffic_source"]:
         roof["traffic_source"] += " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this kernel symbol, FETCH doubled per the gfx950 note)"
-    # the same frames one launch per frame (the reference's call form, benchmarks/box_5x5_filter2.cc:43-69): K x 8 launches in the region
+    # the same frames one launch per frame (the reference's call form, benchmarks/box_5x5_filter2.cc:43-69): K x FPS launches in the region
     swall, sev = timed(launch_box_single, args.steps * FPS, args.warmup, preheat_s=0.0, c_graph=True)
     single_s = region_log[-1]["sample"]["us_per_launch"] * 1e-6
     per_frame = {"gpixels_per_s": npx * world / (swall / (args.steps * FPS)) / 1e9, "avg_launch_us_in_region": sev / (args.steps * FPS) * 1e6,

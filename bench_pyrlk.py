@@ -12,6 +12,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
+def issue_roofline(prefix):
+    """Per-leg roofline of a kernel that is bound by the SIMDs' instruction issue, not by HBM: the fraction of the chip's
+    VALU issue cycles the kernel uses while it runs, from the committed rocprofv3 PMC passes of the round (profiles/*_issue.json, written by
+    tools/make_issue_json.py from the passes of tools/profile_round.sh; the same numbers are readable in profiles/*_pmc.md):
+      frac = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs  /  (SQ_BUSY_CYCLES / 32 counter instances)      [both per dispatch]
+    Keyed by kernel symbol: None when no committed pass was taken on a kernel of this name."""
+    import glob
+    import json
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue.json")), reverse=True):
+        for k, v in json.load(open(path)).items():
+            if k.startswith(prefix):
+                return {"bound": "valu_issue", "kernel": k, "frac": v["valu_issue_frac"], "lds_issue_frac": v.get("lds_issue_frac"),
+                        "valu_wave_instructions": v.get("insts_valu"), "kernel_cycles": v.get("kernel_cycles"), "unit": "fraction of the SIMD issue cycles",
+                        "source": os.path.basename(path) + " (rocprofv3 --pmc SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / SQ_ACTIVE_INST_LDS / SQ_INSTS_VALU, separate passes; recompute from the *_pmc.md of the same round)"}
+    return None
+
+
 def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     import torch
     import torch.distributed as dist
@@ -48,6 +65,24 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     res = {"workload": "pyrlk_match 1920x1080, 3 levels, 10k keypoints, 7x7, min_ev 1e-4, max_err 500, 30 it, delta 0.01",
            "tracks_per_s": NK / (wall / steps), "ms_per_frame": wall / steps * 1e3, "keypoints_per_rank": n_local,
            "exchange": "rccl all_gather of 20-byte keypoint records" if world > 1 else "none (1 GPU)"}
+
+    res["roofline"] = issue_roofline("pyrlk_match_group_kernel<7, 16>")
+
+    # keypoint-count sweep on one GPU (where tracks/s saturates; 1 250 = what one of 8 ranks sees of the 10 k keypoints of configs[3])
+    if world == 1:
+        sweep = {}
+        for nk in (1250, 2500, 5000, 10000, 20000, 40000, 160000):
+            kh = pyr.make_keypoints(pyr.grid_keypoints(NR, NC, nk, margin=32))
+            k0 = torch.from_numpy(kh.view(np.uint8).reshape(-1).copy()).to(dev)
+            k1 = k0.clone()
+            nn = len(kh)
+
+            def step_n(i, stream, k0=k0, k1=k1, nn=nn):
+                k1.copy_(k0, non_blocking=True)
+                match(dp1, dg1, dp2, L, V(k1.data_ptr()), nn, WS, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None, stream)
+            w, _ = timed(step_n, 20, 3, graph=True)
+            sweep[str(nn)] = {"ms": round(w / 20 * 1e3, 4), "tracks_per_s": round(nn / (w / 20))}
+        res["sweep"] = sweep
 
     if world > 1:
         # the same step without Python on it: one C++ process per GPU (benchmarks/pyrlk_shard_bench.cc), match + RCCL all-gather recorded in a
@@ -124,6 +159,8 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
         barrier()
         dt = (time.perf_counter() - t0) / it
         fast[name] = {"ms": dt * 1e3, "gpixels_per_s": 2160 * 3840 * world / dt / 1e9, "keypoints": n.value}
+    fast["raw"]["roofline"] = issue_roofline("fast9_detect2_kernel<true, 0>")
+    fast["blockwise10"]["roofline"] = issue_roofline("fast9_detect2_kernel<true, 2>")
     res["fast9_4k"] = fast
 
     # semi-dense optical flow on one 4K frame pair (BASELINE configs[4] on a single GPU): a keypoint every 10 px
@@ -146,7 +183,8 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     barrier()
     dt = (time.perf_counter() - t0) / it
     res["semi_dense_flow_4k"] = {"ms_per_frame_pair": dt * 1e3, "frame_pairs_per_s": world / dt, "keypoints": m,
-                                 "note": "one frame pair per GPU (replicas); serial-order semantics, bit-exact vs the oracle"}
+                                 "note": "one frame pair per GPU (replicas); serial-order semantics, bit-exact vs the oracle",
+                                 "roofline": issue_roofline("sdof_descent_group_kernel<9>"), "roofline_rounds": issue_roofline("sdof_rounds_kernel<9>")}
     # several independent frame pairs in flight on one GPU: each on its own stream (its own scratch: common.hpp Scratch is per stream); a pair is a
     # chain of ~25 short launches (pyramids, claim, descent, classify, propagation rounds), so independent pairs fill each other's launch gaps
     conc = {}

@@ -2,10 +2,10 @@
 # Summarise gpurun_out/prof_<tag> (written by tools/profile_round.sh, same call, on the GPU box) into <dest> (default profiles/);
 # the summaries are then copied into the tracked profiles/ directory.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 D=${2:-profiles}
 P=gpurun_out/prof_$TAG
-{ echo "# Round ${TAG#r} — rocprofv3 --kernel-trace --stats of \`python bench.py --no-cpu\` (defaults: 2000 steps, 200 warm-up), of the driver's"
+{ echo "# Round ${TAG#r} — rocprofv3 --kernel-trace --stats of \`python bench.py --no-cpu\` (defaults: 500 steps, 50 warm-up), of the driver's"
   echo "\`python bench.py --gpus 1 --steps 20 --warmup 5\` and of tools/run_algos.py"; echo
   echo "Produced by tools/profile_round.sh on one MI355X; summarised from the rocpd sqlite outputs by tools/prof_summary.py."
   echo "bench.py's own JSON lines from the same (profiled) runs: ${TAG}_bench_under_rocprof.json, ${TAG}_bench_s20_under_rocprof.json — roofline.avg_launch_us"
@@ -21,3 +21,4 @@ P=gpurun_out/prof_$TAG
 tail -1 $P/bench_under_rocprof.json > $D/${TAG}_bench_under_rocprof.json
 tail -1 $P/bench_s20_under_rocprof.json > $D/${TAG}_bench_s20_under_rocprof.json
 python tools/make_traffic_json.py $P/pmc_fetch/p_results.db $P/pmc_write/p_results.db $D/${TAG}_traffic.json > /dev/null
+python tools/make_issue_json.py $D/${TAG}_issue.json $P/pmc_busy/p_results.db $P/pmc_wait/p_results.db $P/pmc_sq/p_results.db $P/pmc_busy_algos/p_results.db $P/pmc_wait_algos/p_results.db $P/pmc_sq_algos/p_results.db > /dev/null

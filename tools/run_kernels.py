@@ -11,12 +11,12 @@ lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
 NR, NC = 2160, 3840
 if which in ("box", "all"):
     src_h = rand_image(NR, NC, vi.U8, 3, border=2, seed=3, align=16)
-    ns = 8
+    ns = 32
     srcs = [DeviceImage.from_host(src_h) for _ in range(ns)]
     dsts = [DeviceImage(NR, NC, vi.U8, 3, 0, 16) for _ in range(ns)]
     for s in srcs: capi.check(lib.vpp_fill_border(P(s.desc), 0, None, st))
     for i in range(n): capi.check(lib.vpp_box_filter(P(dsts[i % ns].desc), P(srcs[i % ns].desc), 5, 5, st))
-    for i in range(max(2, n // ns)): capi.check(lib.vpp_box_filter_batch(vi.desc_array(dsts), vi.desc_array(srcs), ns, 5, 5, st))   # bench.py's headline launch: 8 frames
+    for i in range(max(2, n // ns)): capi.check(lib.vpp_box_filter_batch(vi.desc_array(dsts), vi.desc_array(srcs), ns, 5, 5, st))   # bench.py's headline launch: 32 frames
     torch.cuda.synchronize()
 if which in ("add", "all"):
     b_h = rand_image(NR, NC, vi.I32, seed=2, lo=0, hi=2**30 - 1)
