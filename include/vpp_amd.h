@@ -231,6 +231,10 @@ int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, const vpp_image
  * `clone(frame, _border = b); fill_border_mirror(frame); rgb_to_graylevel<uchar>(frame)` in one pass; src's border
  * is not read (it may be 0). */
 int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream);
+/* The ingest fused with the image pyramid it feeds (examples/video_extruder.cc:46-48 followed by pyramid<uchar>::update, vpp/core/pyramid.hh:
+ * 169-198): levels[0] (u8 x1, any border <= its extents) = rgb_to_graylevel<uchar>(rgb) with a mirror-filled border, levels[1..] = propagate_level0.
+ * Bit-identical to vpp_rgb_to_graylevel(gray, rgb, 1) + vpp_pyramid_build(levels, nlevels, gray); one launch for 2 or 3 levels. */
+int vpp_rgb_pyramid_build(const vpp_image_desc* levels, int nlevels, const vpp_image_desc* rgb, void* stream);
 /* Re-detection mask of video_extruder (video_extruder/video_extruder.hpp:95-110): mask (u8 x1) = 1 over its domain
  * with border, then 0 over [r - spacing, r + spacing) x [c - spacing, c + spacing) for each of the n (row, col) int32
  * pairs in DEVICE memory (clipped to the mask's border). */

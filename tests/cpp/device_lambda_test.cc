@@ -189,6 +189,56 @@ static void time_4k() {
   const double tag = (seconds() - t0) / K;
   std::printf("4K int add, synchronous calls: lambda %.2f us, ops::add %.2f us (ratio %.2f)\n", lam * 1e6, tag * 1e6, lam / tag);
   for (int r = 0; r < 2160; r += 97) for (int c = 0; c < 3840; c += 89) CHECK(A(r, c) == B(r, c) + C(r, c));
+  // the 5x5 box of benchmarks/box_5x5_filter2.cc:71-81 as the opaque lambda against ops::box_mean<5, 5> (the hand-written K2i kernel), 4K int
+  {
+    image2d<int> S(2160, 3840, _border = 2), D(S.domain()), T(S.domain());
+    for (auto p : S.domain_with_border()) S(p) = int(rng() % 1000);
+    vpp_pixel_wise(D, S);
+    pixel_wise(T, relative_access(S)) | ops::box_mean<5, 5>();
+    CHECK(same_pixels(D, T));
+    t0 = seconds();
+    for (int k = 0; k < K; k++) vpp_pixel_wise(D, S);
+    const double blam = (seconds() - t0) / K;
+    t0 = seconds();
+    for (int k = 0; k < K; k++) pixel_wise(T, relative_access(S)) | ops::box_mean<5, 5>();
+    const double btag = (seconds() - t0) / K;
+    std::printf("4K int box 5x5, synchronous calls: lambda %.2f us, ops::box_mean<5,5> %.2f us (ratio %.2f)\n", blam * 1e6, btag * 1e6, blam / btag);
+  }
+  // the same on vuchar3 (examples/box_filter.cc:23-32 body; BASELINE configs[1]'s pixel type)
+  {
+    image2d<vuchar3> S(2160, 3840, _border = 2), D(S.domain()), T(S.domain());
+    for (auto p : S.domain_with_border()) S(p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
+    auto k3 = [] (vuchar3& out, auto nbh) {
+      vint3 sum = vint3::Zero();
+      for (int i = -2; i <= 2; i++) for (int j = -2; j <= 2; j++) sum += nbh(i, j).template cast<int>();
+      out = (sum / 25).template cast<unsigned char>();
+    };
+    pixel_wise(D, relative_access(S)) | k3;
+    pixel_wise(T, relative_access(S)) | ops::box_mean<5, 5>();
+    CHECK(same_pixels(D, T));
+    t0 = seconds();
+    for (int k = 0; k < K; k++) pixel_wise(D, relative_access(S)) | k3;
+    const double blam = (seconds() - t0) / K;
+    t0 = seconds();
+    for (int k = 0; k < K; k++) pixel_wise(T, relative_access(S)) | ops::box_mean<5, 5>();
+    const double btag = (seconds() - t0) / K;
+    std::printf("4K vuchar3 box 5x5, synchronous calls: lambda %.2f us, ops::box_mean<5,5> %.2f us (ratio %.2f)\n", blam * 1e6, btag * 1e6, blam / btag);
+  }
+  // block_wise on the device: 16 x 16 block sums (one wave per block) and 4 x 4 (one lane per block)
+  for (int bs : {16, 4}) {
+    image2d<int> A2(2160, 3840), S2(2160, 3840);
+    for (auto p : A2.domain()) A2(p) = int(rng() % 100);
+    fill(S2, 0);
+    auto kb = [] (auto a, auto s) {
+      int sum = 0;
+      for (int r = 0; r < a.nrows(); r++) for (int c = 0; c < a.ncols(); c++) sum += a(r, c);
+      s(0, 0) = sum;
+    };
+    block_wise(vint2(bs, bs), A2, S2) | kb;
+    t0 = seconds();
+    for (int k = 0; k < 50; k++) block_wise(vint2(bs, bs), A2, S2) | kb;
+    std::printf("4K int block_wise %d x %d sums, synchronous calls: %.2f us\n", bs, bs, (seconds() - t0) / 50 * 1e6);
+  }
 }
 
 int main(int argc, char** argv) {

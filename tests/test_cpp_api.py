@@ -5,29 +5,22 @@ import subprocess
 
 import pytest
 
+import cppbuild
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
 OUT = os.path.join(ROOT, "tests", "cpp", "_build")
 
 
-def _compile(src, exe, device):
-    os.makedirs(OUT, exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused", "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "vpp_amd", "include"), os.path.join(CPP, src), "-o", exe]
-    if device:
+def _product_library():
+    """The CPU tests that link the device library make sure it is built (hipcc cross-compiles here); the -m gpu tests run what was shipped."""
+    if not os.path.exists(os.path.join(ROOT, "vpp_amd", "csrc", "libvpp_amd.so")) or not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         import __graft_entry__ as g
         g.build()
-        cmd += ["-DVPP_AMD_DEVICE", "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "vpp_amd", "csrc"), "-lvpp_amd",
-                "-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "vpp_amd", "csrc"),
-                "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,--allow-shlib-undefined"]
-        refdir = os.path.join(ROOT, "oracle", "_ref")
-        if os.path.exists(os.path.join(refdir, "libvpp_ref_ve.so")):  # the real reference, where it was built: video_extruder parity
-            cmd += ["-DHAVE_VPP_REF", "-L" + refdir, "-lvpp_ref_ve", "-Wl,-rpath," + refdir]
-    subprocess.check_call(cmd)
-    return exe
 
 
 def test_host_api_contract():
-    exe = _compile("host_api_test.cc", os.path.join(OUT, "host_api_test"), device=False)
+    exe = cppbuild.host_program("host_api_test.cc", "host_api_test")
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "host_api_test ok" in out.stdout
@@ -52,36 +45,27 @@ def test_algorithm_headers_refuse_a_host_only_build():
 
 
 def test_device_api_links():
-    _compile("device_api_test.cc", os.path.join(OUT, "device_api_test"), device=True)
+    _product_library()
+    cppbuild.device_program("device_api_test.cc", "device_api_test")
 
 
 @pytest.mark.gpu
 def test_device_api_on_gpu():
-    exe = _compile("device_api_test.cc", os.path.join(OUT, "device_api_test_gpu"), device=True)
+    exe = cppbuild.device_program("device_api_test.cc", "device_api_test")   # prebuilt by the CPU test / build(); recompiled only if stale and g++ exists
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "device_api_test ok" in out.stdout
 
 
-def _compile_single_source(exe):
-    """The user's translation unit compiled by hipcc: -DVPP_AMD_DEVICE -DVPP_AMD_HIPCC turns opaque pixel_wise lambdas into gfx950 kernels."""
-    import __graft_entry__ as g
-    g.build()
-    os.makedirs(OUT, exist_ok=True)
-    subprocess.check_call(["hipcc", "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-result", "-Wno-unused-command-line-argument", "-DVPP_AMD_DEVICE", "-DVPP_AMD_HIPCC",
-                           "-I" + os.path.join(ROOT, "vpp_amd", "include"), "-I" + os.path.join(ROOT, "include"), os.path.join(CPP, "device_lambda_test.cc"), "-o", exe,
-                           "-L" + os.path.join(ROOT, "vpp_amd", "csrc"), "-lvpp_amd", "-Wl,-rpath," + os.path.join(ROOT, "vpp_amd", "csrc")])
-    return exe
-
-
 def test_single_source_lambdas_compile():
     """benchmarks/image_add.cc:51-57 and benchmarks/box_5x5_filter2.cc:71-81, pasted unmodified, compile for gfx950 against the drop-in headers."""
-    _compile_single_source(os.path.join(OUT, "device_lambda_test"))
+    _product_library()
+    cppbuild.single_source_program("device_lambda_test.cc", "device_lambda_test")
 
 
 @pytest.mark.gpu
 def test_single_source_lambdas_on_gpu():
-    exe = _compile_single_source(os.path.join(OUT, "device_lambda_test_gpu"))
+    exe = cppbuild.single_source_program("device_lambda_test.cc", "device_lambda_test")   # prebuilt by the CPU test / build()
     out = subprocess.run([exe, "time"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "device_lambda_test ok" in out.stdout

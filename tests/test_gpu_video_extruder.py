@@ -7,23 +7,16 @@ import subprocess
 
 import pytest
 
+import cppbuild
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REFLIB = os.path.join(ROOT, "oracle", "_ref", "libvpp_ref_ve.so")
-OUT = os.path.join(ROOT, "tests", "cpp", "_build")
 
 
 def _build():
-    import __graft_entry__ as g
-    g.build()   # also builds oracle/_ref where /root/reference exists
-    assert os.path.exists(REFLIB), ("oracle/_ref/libvpp_ref_ve.so is missing: build it where /root/reference exists (make -C oracle ref); "
-                                    "the video_extruder parity check has no other checker and does not skip")
-    os.makedirs(OUT, exist_ok=True)
-    exe = os.path.join(OUT, "video_extruder_parity")
-    refdir = os.path.dirname(REFLIB)
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-w", "-DVPP_AMD_DEVICE", "-I" + os.path.join(ROOT, "vpp_amd", "include"), "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "video_extruder_parity.cc"), "-o", exe, "-L" + os.path.join(ROOT, "vpp_amd", "csrc"), "-lvpp_amd",
-                           "-L" + refdir, "-lvpp_ref_ve", "-Wl,-rpath," + os.path.join(ROOT, "vpp_amd", "csrc"), "-Wl,-rpath," + refdir, "-Wl,--allow-shlib-undefined"])
-    return exe
+    if not os.path.exists(cppbuild.REFLIB_VE) and os.path.isdir("/root/reference/vpp"):
+        import __graft_entry__ as g
+        g.build()   # builds oracle/_ref where /root/reference exists
+    return cppbuild.video_extruder_parity()   # prebuilt by the CPU test / build(); recompiled only if stale and g++ exists
 
 
 def test_video_extruder_parity_program_builds():

@@ -40,6 +40,26 @@ def test_ingest_4k_properties(lib):
     np.testing.assert_array_equal(g, np.pad(inner, 3, mode="symmetric"))
 
 
+@pytest.mark.parametrize("ch", [3, 4])
+@pytest.mark.parametrize("shape,nlevels,border,align", [((40, 56), 3, 3, 32), ((41, 57), 3, 3, 32), ((35, 33), 2, 3, 16), ((18, 300), 3, 3, 32), ((271, 481), 3, 14, 32),
+                                                          ((64, 130), 3, 3, 1), ((1080, 1920), 3, 3, 32), ((2160, 3840), 3, 18, 32), ((96, 96), 4, 3, 32), ((50, 70), 1, 2, 32)])
+def test_rgb_pyramid_build_equals_the_ingest_followed_by_the_pyramid(lib, orc, ch, shape, nlevels, border, align):
+    """vpp_rgb_pyramid_build (frame ingest fused with the image pyramid, one launch) leaves in every level, borders included, exactly what the
+    oracle's rgb_to_graylevel(mirror) + pyramid chain leaves; frames cut by every tile edge, unaligned pitches, 4 levels / 1 level (chain fallback)."""
+    import pyr
+    if shape == (2160, 3840) and ch == 4:
+        pytest.skip("4K once")
+    rgb = rand_image(*shape, vi.U8, ch, border=0, seed=35, align=align)
+    gray = HostImage(*shape, vi.U8, 1, border, 32)
+    assert orc.orc_rgb_to_graylevel(P(gray.desc), P(rgb.desc), 1) == 0
+    want = pyr.host_pyramid(orc, gray, nlevels, border)
+    levels = [DeviceImage(nr, nc, vi.U8, 1, border) for nr, nc in pyr.level_dims(shape[0], shape[1], nlevels)]
+    capi.check(lib.vpp_rgb_pyramid_build(vi.desc_array(levels), nlevels, P(DeviceImage.from_host(rgb).desc), capi.stream_ptr()))
+    for h, d in zip(want, levels):
+        np.testing.assert_array_equal(d.download().raw, h.raw)
+    assert lib.vpp_rgb_pyramid_build(vi.desc_array(levels), nlevels, P(levels[0].desc), None) != 0   # the frame must be x3 / x4
+
+
 def test_rgb_to_graylevel_rejects_bad_arguments(lib):
     a, b = DeviceImage(8, 8, vi.U8, 3), DeviceImage(8, 8, vi.U8, 1)
     assert lib.vpp_rgb_to_graylevel(P(a.desc), P(a.desc), 0, None) != 0            # dst must be x1

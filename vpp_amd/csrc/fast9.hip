@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
 // (keys all-zero before the launch: zeroed by the write pass of the previous call, or by a memset node), which is the reduction fast9_count_blocks_kernel did in a second pass over F.
 template <bool REF, int MODE>
 __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int has_mask, int th, DImg F, uint64_t* __restrict__ bitmap, int ntc,
-                                                            unsigned long long* __restrict__ blkkey, uint32_t bs_magic, int nbc) {
+                                                            unsigned long long* __restrict__ blkkey, uint32_t bs_magic, int nbc,
+                                                            uint8_t* __restrict__ rowcnt, uint16_t* __restrict__ tiletot) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[LROWS * LP];
   __shared__ uint16_t cand[4][TH / 4 * TW];          // per wave: (row in the wave's band) * 64 + column
   __shared__ unsigned long long words[4][TH / 4];    // per wave: corner bitmap words of its TH / 4 rows
@@ -298,9 +299,23 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
   }
   if (MODE == VPP_FAST9_BLOCKWISE) return;
   wave_fence_lds();
+  uint32_t nrow = 0;
   if (lane < TH / 4) {
     const int r = r0 + wv * (TH / 4) + lane;
-    if (r < A.nr) bitmap[(size_t)r * ntc + blockIdx.x] = words[wv][lane];
+    if (r < A.nr) {
+      const unsigned long long w = words[wv][lane];
+      bitmap[(size_t)r * ntc + blockIdx.x] = w;
+      if (MODE == VPP_FAST9_RAW) { nrow = (uint32_t)__popcll(w); rowcnt[(size_t)r * ntc + blockIdx.x] = (uint8_t)nrow; }   // <= 64
+    }
+  }
+  if (MODE == VPP_FAST9_RAW) {
+    // RAW keeps every corner, so the ordered write needs no count pass of its own: this tile's corner total (and the per-row counts above) are
+    // all the offsets are made of — fast9_write_rows_kernel sums the tiles of the bands above its row and the rows above it in its band
+    __shared__ uint32_t wtot[4];
+    nrow += __shfl_xor(nrow, 1); nrow += __shfl_xor(nrow, 2); nrow += __shfl_xor(nrow, 4);
+    if (lane == 0) wtot[wv] = nrow;
+    __syncthreads();
+    if (threadIdx.x == 0) tiletot[(size_t)blockIdx.y * ntc + blockIdx.x] = (uint16_t)(wtot[0] + wtot[1] + wtot[2] + wtot[3]);   // <= 2048
   }
 }
 
@@ -434,6 +449,57 @@ __global__ __launch_bounds__(256) void fast9_write_segs_kernel(DImg F, const uin
     }
     k++;
   }
+}
+
+// RAW after the two-phase detect kernel, which left the corner count of every (row, 64-px tile) in rowcnt and of every TH-row tile in
+// tiletot: one workgroup per image row computes its output offset from those (the tiles of the bands above: <= 8 KB of u16 at 4K; the rows
+// above it inside its band: <= 31 x ntc bytes) and writes the row's corners in column order — raw detection is two launches.
+__global__ __launch_bounds__(256) void fast9_write_rows_kernel(DImg F, const uint16_t* __restrict__ segs, int nsc, int ntc, const uint8_t* __restrict__ rowcnt,
+                                                               const uint16_t* __restrict__ tiletot, uint32_t* __restrict__ total,
+                                                               int32_t* __restrict__ out_rc, int32_t* __restrict__ out_scores, int capacity) {
+  __shared__ uint32_t gsum[4];
+  const int r = blockIdx.x, band = r / TH;
+  uint32_t s = 0;
+  {  // both ranges start 16-byte aligned (the arrays are 256-byte aligned, TH * ntc is a multiple of 16): 16-byte loads, SWAR sums
+    const int n16 = band * ntc;   // u16 tile totals of the bands above
+    const uint4* t4 = (const uint4*)tiletot;
+    for (int i = threadIdx.x; i < n16 / 8; i += 256) {
+      const uint4 v = t4[i];
+      s += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16) + (v.z & 0xFFFFu) + (v.z >> 16) + (v.w & 0xFFFFu) + (v.w >> 16);
+    }
+    for (int i = (n16 & ~7) + threadIdx.x; i < n16; i += 256) s += tiletot[i];
+    const int b0 = band * TH * ntc, n8 = r * ntc - b0;   // u8 counts of the rows above this one inside its band
+    const uint4* c4 = (const uint4*)(rowcnt + b0);
+    for (int i = threadIdx.x; i < n8 / 16; i += 256) {
+      const uint4 v = c4[i];
+      s = __builtin_amdgcn_sad_u8(v.x, 0u, s); s = __builtin_amdgcn_sad_u8(v.y, 0u, s); s = __builtin_amdgcn_sad_u8(v.z, 0u, s); s = __builtin_amdgcn_sad_u8(v.w, 0u, s);
+    }
+    for (int i = (n8 & ~15) + threadIdx.x; i < n8; i += 256) s += rowcnt[b0 + i];
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if ((threadIdx.x & 63) == 0) gsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  uint32_t base = gsum[0] + gsum[1] + gsum[2] + gsum[3];
+  const uint16_t* f0 = F.row<uint16_t>(r);
+  for (int u0 = 0; u0 < nsc; u0 += 256) {   // 256 segments = 4096 px per step (one step up to 4K frames)
+    const int u = u0 + threadIdx.x;
+    uint32_t m = u < nsc ? segs[(size_t)r * nsc + u] : 0;
+    uint32_t tot;
+    uint32_t k = base + block_exscan((uint32_t)__popc(m), &tot);
+    base += tot;
+    const int cbase = u * SEG;
+    while (m) {
+      const int c = cbase + __ffs(m) - 1;
+      m &= m - 1;
+      if ((int)k < capacity) {
+        out_rc[2 * (size_t)k] = r; out_rc[2 * (size_t)k + 1] = c;
+        if (out_scores) out_scores[k] = (int32_t)f0[c] - 1;
+      }
+      k++;
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = base;
 }
 
 // pass 1, BLOCKWISE: first strict maximum of each bs x bs block in scan order (fast.hpp:770-789).  Only corner pixels (bits of
@@ -656,7 +722,11 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
   const size_t off_f = 256;
   const size_t off_bm = off_f + align_up(fbytes, 256), off_br = off_bm + align_up((size_t)nwords * 8, 256);
   const size_t off_uc = off_br + align_up((size_t)nblocks * 8, 256);
-  const size_t total_bytes = off_uc + align_up((size_t)ngroups * 4, 256);
+  const bool fused_raw = impl == 2 && mode == VPP_FAST9_RAW && tuning("fast9.raw_rows", 1);   // RAW: the detect kernel leaves the counts, no count pass
+  const int nby = (nr + TH - 1) / TH;
+  const bool raw2 = impl == 2 && mode == VPP_FAST9_RAW;   // the RAW instance of the two-phase kernel always writes its counts
+  const size_t off_rc = off_uc + align_up((size_t)ngroups * 4, 256), off_tt = off_rc + align_up(raw2 ? (size_t)nwords : 0, 256);
+  const size_t total_bytes = off_tt + align_up(raw2 ? (size_t)nby * ntc * 2 : 0, 256);
   int rc = g_scratch.ensure(total_bytes, st);
   if (rc != VPP_OK) return rc;
   uint8_t* base = (uint8_t*)g_scratch.p;
@@ -665,6 +735,8 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
   uint64_t* bitmap = (uint64_t*)(base + off_bm);
   uint2* blkres = (uint2*)(base + off_br);
   uint32_t* unit_count = (uint32_t*)(base + off_uc);
+  uint8_t* rowcnt = base + off_rc;
+  uint16_t* tiletot = (uint16_t*)(base + off_tt);
   DImg A = dimg(src), M = mask ? dimg(mask) : A;
   dim3 grid(ntc, (nr + TH - 1) / TH);
   unsigned long long* blkkey = (unsigned long long*)blkres;
@@ -684,9 +756,9 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
   if (keyed && !keys_clean) VPP_HIP_TRY(hipMemsetAsync(blkkey, 0, (size_t)nblocks * 8, st));
   if (impl == 2) {
 #define VPP_FAST_DETECT2(R)                                                                                                                             \
-    if (keyed) fast9_detect2_kernel<R, VPP_FAST9_BLOCKWISE><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc);           \
-    else if (mode == VPP_FAST9_RAW) fast9_detect2_kernel<R, VPP_FAST9_RAW><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc); \
-    else fast9_detect2_kernel<R, VPP_FAST9_LOCAL_MAXIMA><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc);
+    if (keyed) fast9_detect2_kernel<R, VPP_FAST9_BLOCKWISE><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot);           \
+    else if (mode == VPP_FAST9_RAW) fast9_detect2_kernel<R, VPP_FAST9_RAW><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot); \
+    else fast9_detect2_kernel<R, VPP_FAST9_LOCAL_MAXIMA><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot);
     if (compat == VPP_FAST9_REFERENCE) { VPP_FAST_DETECT2(true) } else { VPP_FAST_DETECT2(false) }
 #undef VPP_FAST_DETECT2
   } else if (compat == VPP_FAST9_REFERENCE) fast9_detect_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);
@@ -700,6 +772,8 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
   } else if (mode == VPP_FAST9_BLOCKWISE) {
     fast9_count_blocks_kernel<<<ngroups, 256, 0, st>>>(F, bitmap, ntc, block_size, nbc, nblocks, RB, G, blkres, unit_count);
     fast9_write_blocks_kernel<<<ngroups, 256, 0, st>>>(blkres, nblocks, G, unit_count, d_total, out_rc, out_scores, capacity);
+  } else if (fused_raw) {
+    fast9_write_rows_kernel<<<nr, 256, 0, st>>>(F, (const uint16_t*)bitmap, nsc, ntc, rowcnt, tiletot, d_total, out_rc, out_scores, capacity);
   } else if (mode == VPP_FAST9_RAW) {
     fast9_count_segs_kernel<0><<<ngroups, 256, 0, st>>>(F, (uint16_t*)bitmap, nsc, nsegs, unit_count);
     fast9_write_segs_kernel<0><<<ngroups, 256, 0, st>>>(F, (const uint16_t*)bitmap, nsc, nsegs, unit_count, d_total, out_rc, out_scores, capacity);
