@@ -21,7 +21,8 @@ def time_graph(launch, steps=200):
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / steps * 1e3)
     return best
-for (nr, nc, border, nset) in ((2160, 3840, 3, 12), (2160, 3840, 18, 12), (1080, 1920, 3, 40)):
+for (nr, nc, border, nset, sw) in ((2160, 3840, 3, 12, 1), (2160, 3840, 18, 12, 1), (1080, 1920, 3, 40, 1), (2160, 3840, 18, 12, 0), (1080, 1920, 3, 40, 0)):
+    lib.vpp_set_tuning(b"pyr.swar", sw)
     rgb_h = rand_image(nr, nc, vi.U8, 3, border=0, seed=6)
     rgbs = [DeviceImage.from_host(rgb_h) for _ in range(nset)]
     grays = [DeviceImage(nr, nc, vi.U8, 1, border, 32) for _ in range(nset)]
@@ -40,4 +41,4 @@ for (nr, nc, border, nset) in ((2160, 3840, 3, 12), (2160, 3840, 18, 12), (1080,
     def pyronly(i, s):
         k = i % nset
         lib.vpp_pyramid_build(dls[k], 3, P(grays[k].desc), s)
-    print(f"{nr}x{nc} border {border}: ingest {time_graph(ingest):.2f} us, pyramid {time_graph(pyronly):.2f} us, ingest + pyramid {time_graph(chain):.2f} us, fused vpp_rgb_pyramid_build {time_graph(fused):.2f} us", flush=True)
+    print(f"{nr}x{nc} border {border} packed={sw}: ingest {time_graph(ingest):.2f} us, pyramid {time_graph(pyronly):.2f} us, ingest + pyramid {time_graph(chain):.2f} us, fused vpp_rgb_pyramid_build {time_graph(fused):.2f} us", flush=True)

@@ -255,7 +255,7 @@ __device__ __forceinline__ void needed(int a, int b, int n, int& lo, int& len) {
 
 // T0 x T0 = tile of the coarsest level per workgroup.  LDS: the level rects + one horizontal-pass scratch.
 template <class T, class S, int CH, int T0, class SRC, int NL, bool WRITE0>
-__global__ __launch_bounds__(256) void pyramid_chain_kernel(Chain ch) {
+__device__ __forceinline__ void chain_tile(const Chain& ch, int ty, int tx) {
   static_assert(NL == 2 || NL == 3, "two or three levels per launch");
   // rect extents (rows) and LDS row pitches (pixels): level NL-2 holds 2 T0 + 3, level 0 of a 3-level chain 2 (2 T0 + 3) + 3; the level-0
   // pitch leaves room for the dword alignment of its columns and is a dword multiple for every pixel size
@@ -267,8 +267,6 @@ __global__ __launch_bounds__(256) void pyramid_chain_kernel(Chain ch) {
   __shared__ __attribute__((aligned(16))) uint8_t s_aux[SRC::kAuxBytes];
 
   const DImg& last = ch.lv[NL - 1];
-  const int tiles_x = (last.nc + T0 - 1) / T0;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   Rect rl;  // the tile of the coarsest level
   rl.r0 = ty * T0; rl.c0 = tx * T0; rl.h = min(T0, last.nr - rl.r0); rl.w = min(T0, last.nc - rl.c0);
   Rect rm = rl, rt;  // NL == 3: level-1 rect; rt = level-0 rect
@@ -293,6 +291,153 @@ __global__ __launch_bounds__(256) void pyramid_chain_kernel(Chain ch) {
     store_region<T, CH, T0, T0>(ch.lv[1], s_mid, rl, rl.r0, rl.r0 + rl.h, rl.c0, rl.c0 + rl.w);
   }
 }
+template <class T, class S, int CH, int T0, class SRC, int NL, bool WRITE0>
+__global__ __launch_bounds__(256) void pyramid_chain_kernel(Chain ch) {
+  const int tiles_x = (ch.lv[NL - 1].nc + T0 - 1) / T0;
+  const int ty = blockIdx.x / tiles_x;
+  chain_tile<T, S, CH, T0, SRC, NL, WRITE0>(ch, ty, blockIdx.x - ty * tiles_x);
+}
+
+// ---- three u8 x1 levels with packed arithmetic (round 3) ----------------------------------------------------------------------------
+// The tile kernel above spends ~64 lane-operations per level-0 pixel (a byte per lane and tap, index arithmetic and edge tests per item) and
+// is issue / latency bound: 25 us for a 4K pyramid whose bytes take 4 us.  Away from the frame's edges none of the edge handling is needed,
+// and the 5-tap passes vectorise over bytes: a lane produces FOUR outputs per item from dwords — the horizontal pass of a decimating level
+// takes 16 consecutive bytes, splits them into their even and odd bytes as packed 16-bit pairs (v_perm), lines the taps up with v_alignbit
+// and evaluates a + 4 b + 6 c + 4 d + e on two pixels per 32-bit operation (sums < 4096: no carry between the halves); the vertical pass
+// does the same on the five rows' dwords.  `>> 4` and the byte pack are one shift and one v_perm.  Same integer arithmetic, same truncated
+// intermediate (the horizontal pass' u8), so the levels are bit-identical to the tile kernel's.
+// A workgroup owns an 8 x 16 tile of level 2 (16 x 32 of level 1, 32 x 64 of level 0) and holds a 41 x 88 byte patch of level 0.  Tiles whose
+// patch, or whose owned pixels' mirror copies, touch a frame edge (of any level) take the tile kernel's code path, as two workgroups of one 8 x 8
+// tile each; they are numbered first so that the slower workgroups start first.
+__device__ __forceinline__ uint32_t even_u16(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c020c00u); }   // bytes 0, 2 as two u16 fields
+__device__ __forceinline__ uint32_t odd_u16(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c01u); }    // bytes 1, 3
+// bytes x[0 .. 15] = w0 .. w3: four outputs k = 0 .. 3, output k centred on x[2 k + 4]
+__device__ __forceinline__ uint32_t hpass4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  const uint32_t e0 = even_u16(w0), e1 = even_u16(w1), e2 = even_u16(w2), e3 = even_u16(w3);   // e_i = (x[4i], x[4i + 2])
+  const uint32_t o0 = odd_u16(w0), o1 = odd_u16(w1), o2 = odd_u16(w2);                           // o_i = (x[4i + 1], x[4i + 3])
+  const uint32_t a01 = __builtin_amdgcn_alignbit(e1, e0, 16), b01 = __builtin_amdgcn_alignbit(o1, o0, 16);   // (x2, x4), (x3, x5)
+  const uint32_t f01 = __builtin_amdgcn_alignbit(e2, e1, 16), b23 = __builtin_amdgcn_alignbit(o2, o1, 16);   // (x6, x8), (x7, x9)
+  const uint32_t f23 = __builtin_amdgcn_alignbit(e3, e2, 16);                                                // (x10, x12)
+  const uint32_t s01 = __umul24(e1, 6u) + (a01 + f01) + ((b01 + o1) << 2);   // outputs 0, 1: x2 + 4 x3 + 6 x4 + 4 x5 + x6 | x4 + ... + x8
+  const uint32_t s23 = __umul24(e2, 6u) + (f01 + f23) + ((b23 + o2) << 2);   // outputs 2, 3
+  return __builtin_amdgcn_perm(s23 >> 4, s01 >> 4, 0x06040200u);
+}
+// the same tap over five rows, four columns packed in each dword
+__device__ __forceinline__ uint32_t vpass4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t r4) {
+  const uint32_t se = __umul24(even_u16(r2), 6u) + (even_u16(r0) + even_u16(r4)) + ((even_u16(r1) + even_u16(r3)) << 2);
+  const uint32_t so = __umul24(odd_u16(r2), 6u) + (odd_u16(r0) + odd_u16(r4)) + ((odd_u16(r1) + odd_u16(r3)) << 2);
+  return __builtin_amdgcn_perm(so >> 4, se >> 4, 0x06020400u);
+}
+// level-0 producers of the packed path: the dword of four level-0 pixels at (r, c), c a multiple of 4
+struct CopyFast {
+  static __device__ __forceinline__ uint32_t load4(const DImg& src, int r, int c) { return *(const uint32_t*)(src.p0 + (ptrdiff_t)r * src.pitch + c); }
+};
+template <int CH> struct GrayFast {   // rgb_to_graylevel of four pixels (GraySrc's arithmetic)
+  static __device__ __forceinline__ uint32_t load4(const DImg& src, int r, int c) {
+    const uint32_t* q = (const uint32_t*)(src.p0 + (ptrdiff_t)r * src.pitch + (ptrdiff_t)c * CH);
+    auto gray = [](uint32_t a, uint32_t b, uint32_t cc) { return ((a + b + cc) * 43691u) >> 17; };
+    if constexpr (CH == 3) {
+      const uint32_t a = q[0], b = q[1], cc = q[2];
+      return gray(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u) | gray(a >> 24, b & 255u, (b >> 8) & 255u) << 8 |
+             gray((b >> 16) & 255u, b >> 24, cc & 255u) << 16 | gray((cc >> 8) & 255u, (cc >> 16) & 255u, cc >> 24) << 24;
+    } else {
+      uint32_t o = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const uint32_t a = q[k]; o |= gray(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u) << (8 * k); }
+      return o;
+    }
+  }
+};
+struct Swar3 { Chain ch; int TX, TY, tx_lo, tx_hi, ty_lo, ty_hi, tiles_x8; };
+
+template <class FAST, class SRC>
+__global__ __launch_bounds__(256) void pyramid_swar3_kernel(Swar3 a) {
+  constexpr int R0 = 41, W0 = 22, G1 = 10, R1 = 19, G2 = 4;   // level-0 patch rows / dwords per row, level-1 groups per row / patch rows, level-2 groups
+  int ty, tx;
+  {
+    // blocks [0, 2 n_edge): the edge tiles, one 8 x 8 tile of the tile kernel each (two per 8 x 16 tile, so that no workgroup runs two in a row —
+    // that chain was the whole kernel's critical path at 1080p); then the interior tiles
+    const int wi = a.tx_hi - a.tx_lo, n_top = a.ty_lo * a.TX, n_mid = (a.ty_hi - a.ty_lo) * (a.TX - wi), n_bot = (a.TY - a.ty_hi) * a.TX;
+    const int n_edge = n_top + n_mid + n_bot;
+    const bool interior = (int)blockIdx.x >= 2 * n_edge;
+    int q = interior ? (int)blockIdx.x - 2 * n_edge : (int)blockIdx.x >> 1;
+    if (interior) { const int row = q / wi; ty = a.ty_lo + row; tx = a.tx_lo + (q - row * wi); }
+    else if (q < n_top) { ty = q / a.TX; tx = q - ty * a.TX; }
+    else if (q < n_top + n_mid) { q -= n_top; const int row = q / (a.TX - wi), k = q - row * (a.TX - wi); ty = a.ty_lo + row; tx = k < a.tx_lo ? k : k + wi; }
+    else { q -= n_top + n_mid; const int row = q / a.TX; ty = a.ty_hi + row; tx = q - row * a.TX; }
+    if (!interior) {   // a tile that touches an edge: the tile kernel's path
+      const int tx8 = 2 * tx + ((int)blockIdx.x & 1);
+      if (tx8 < a.tiles_x8) chain_tile<uint8_t, int, 1, 8, SRC, 3, true>(a.ch, ty, tx8);
+      return;
+    }
+  }
+  __shared__ __attribute__((aligned(16))) uint32_t s0[R0 * W0], sh0[R0 * G1], s1[R1 * G1], sh1[R1 * G2];
+  const DImg L0 = a.ch.lv[0], L1 = a.ch.lv[1], L2 = a.ch.lv[2], src = a.ch.src;
+  const int r2 = 8 * ty, c2 = 16 * tx;
+  const int pr0 = 4 * r2 - 6, pc0 = 4 * c2 - 12;   // origin of the level-0 patch; level-1 patch: rows from 2 r2 - 2, columns from 2 c2 - 4
+  for (int idx = threadIdx.x; idx < R0 * W0; idx += 256) {
+    const int y = idx / W0, x = idx - y * W0;
+    const uint32_t v = FAST::load4(src, pr0 + y, pc0 + 4 * x);
+    s0[idx] = v;
+    if (y >= 6 && y < 38 && x >= 3 && x < 19) *(uint32_t*)(L0.p0 + (ptrdiff_t)(pr0 + y) * L0.pitch + (pc0 + 4 * x)) = v;   // the owned 32 x 64 pixels
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < R0 * G1; idx += 256) {   // horizontal pass of level 0: level-1 columns 2 c2 - 4 + 4 g + k from patch bytes 8 g .. 8 g + 15
+    const int y = idx / G1, g = idx - y * G1;
+    const uint2 lo = *(const uint2*)&s0[y * W0 + 2 * g], hi = *(const uint2*)&s0[y * W0 + 2 * g + 2];
+    sh0[idx] = hpass4(lo.x, lo.y, hi.x, hi.y);
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < R1 * G1; idx += 256) {   // vertical pass: level-1 row 2 r2 - 2 + i from patch rows 2 i .. 2 i + 4
+    const int i = idx / G1, g = idx - i * G1;
+    const uint32_t* p = &sh0[2 * i * G1 + g];
+    const uint32_t v = vpass4(p[0], p[G1], p[2 * G1], p[3 * G1], p[4 * G1]);
+    s1[idx] = v;
+    if (i >= 2 && i < 18 && g >= 1 && g < 9) *(uint32_t*)(L1.p0 + (ptrdiff_t)(2 * r2 - 2 + i) * L1.pitch + (2 * c2 - 4 + 4 * g)) = v;   // the owned 16 x 32
+  }
+  __syncthreads();
+  if (threadIdx.x < R1 * G2) {   // horizontal pass of level 1: level-2 columns c2 + 4 g + k
+    const int i = threadIdx.x >> 2, g = threadIdx.x & 3;
+    const uint2 lo = *(const uint2*)&s1[i * G1 + 2 * g], hi = *(const uint2*)&s1[i * G1 + 2 * g + 2];
+    sh1[threadIdx.x] = hpass4(lo.x, lo.y, hi.x, hi.y);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 * G2) {    // vertical pass: the 8 x 16 tile of level 2
+    const int i = threadIdx.x >> 2, g = threadIdx.x & 3;
+    const uint32_t* p = &sh1[2 * i * G2 + g];
+    *(uint32_t*)(L2.p0 + (ptrdiff_t)(r2 + i) * L2.pitch + (c2 + 4 * g)) = vpass4(p[0], p[G2], p[2 * G2], p[3 * G2], p[4 * G2]);
+  }
+}
+
+// interior tile ranges of the packed path along one axis: tiles [lo, hi) of `step2` level-2 pixels whose level-0 patch (from 4 t0 - lead0, `span0`
+// pixels) lies inside the level and whose owned pixels are at least a border away from both ends on every level
+void swar3_axis(int n0, int n1, int n2, int b0, int b1, int b2, int step2, int lead0, int span0, int ntiles, int* lo, int* hi) {
+  auto ok = [&](int t) {
+    const int p2 = t * step2, p1 = 2 * p2, p0 = 4 * p2;
+    return p0 - lead0 >= 0 && p0 - lead0 + span0 <= n0 && p0 >= b0 && p0 + 4 * step2 <= n0 - b0 && p1 >= b1 && p1 + 2 * step2 <= n1 - b1 && p2 >= b2 &&
+           p2 + step2 <= n2 - b2;
+  };
+  int l = 0;
+  while (l < ntiles && !ok(l)) l++;
+  int h = l;
+  while (h < ntiles && ok(h)) h++;
+  *lo = l; *hi = h;
+}
+template <class FAST, class SRC>
+bool launch_swar3(const vpp_image_desc* levels, const vpp_image_desc* src, hipStream_t st) {
+  auto al4 = [](const vpp_image_desc& d) { return ((uintptr_t)d.first_pixel & 3) == 0 && (d.pitch & 3) == 0; };
+  if (!(al4(levels[0]) && al4(levels[1]) && al4(levels[2]) && al4(*src))) return false;
+  Swar3 a;
+  for (int l = 0; l < 3; l++) a.ch.lv[l] = dimg(&levels[l]);
+  a.ch.src = dimg(src); a.ch.nlevels = 3;
+  a.TY = (levels[2].nrows + 7) / 8; a.TX = (levels[2].ncols + 15) / 16; a.tiles_x8 = (levels[2].ncols + 7) / 8;
+  swar3_axis(levels[0].nrows, levels[1].nrows, levels[2].nrows, levels[0].border, levels[1].border, levels[2].border, 8, 6, 41, a.TY, &a.ty_lo, &a.ty_hi);
+  swar3_axis(levels[0].ncols, levels[1].ncols, levels[2].ncols, levels[0].border, levels[1].border, levels[2].border, 16, 12, 88, a.TX, &a.tx_lo, &a.tx_hi);
+  if (a.ty_hi <= a.ty_lo || a.tx_hi <= a.tx_lo) return false;   // no interior tile: the tile kernel
+  const int n_int = (a.ty_hi - a.ty_lo) * (a.tx_hi - a.tx_lo), n_edge = a.TY * a.TX - n_int;
+  pyramid_swar3_kernel<FAST, SRC><<<2 * n_edge + n_int, 256, 0, st>>>(a);
+  return true;
+}
 
 bool chain_shape_ok(const vpp_image_desc* levels, int nlevels) {
   for (int l = 0; l < nlevels; l++) {
@@ -309,6 +454,7 @@ void launch_chain(const vpp_image_desc* levels, int nlevels, const vpp_image_des
   c.src = dimg(src); c.nlevels = nlevels;
   const vpp_image_desc& last = levels[nlevels - 1];
   const int tiles = ((last.nrows + T0 - 1) / T0) * ((last.ncols + T0 - 1) / T0);
+  // (128- and 64-thread workgroups measured: 4K 25.9 / 28.9 us against 26.1, 1080p 13.8 / 18.8 against 12.5)
   if (nlevels == 3) pyramid_chain_kernel<T, S, CH, T0, SRC, 3, WRITE0><<<tiles, 256, 0, st>>>(c);
   else pyramid_chain_kernel<T, S, CH, T0, SRC, 2, WRITE0><<<tiles, 256, 0, st>>>(c);
 }
@@ -328,8 +474,10 @@ int vpp_pyramid_build(const vpp_image_desc* levels, int nlevels, const vpp_image
   VPP_REQUIRE(valid_desc(src) && same_domain(&levels[0], src), VPP_ERR_INVALID_ARG, "vpp_pyramid_build: level 0 and the source differ in size");
   hipStream_t st = as_stream(stream);
   if (src->dtype == VPP_U8 && src->channels == 1 && (nlevels == 2 || nlevels == 3) && chain_shape_ok(levels, nlevels) && tuning("pyr.fused", 1)) {
+    // three levels: the packed kernel (its edge tiles run the tile kernel's code); two levels, unaligned images, frames without interior tiles: the tile kernel
     // (8 x 8 coarse tiles: 16 x 16 — a 64 x 64 level-0 tile per workgroup, 1.3x instead of 1.6x halo — measured 24.7 vs 26.1 us at 4K and 17.5 vs 12.8 us at 1080p)
-    launch_chain<uint8_t, int, 1, 8, CopySrc<uint8_t, 1>>(levels, nlevels, src, st);
+    if (!(nlevels == 3 && tuning("pyr.swar", 1) && launch_swar3<CopyFast, CopySrc<uint8_t, 1>>(levels, src, st)))
+      launch_chain<uint8_t, int, 1, 8, CopySrc<uint8_t, 1>>(levels, nlevels, src, st);
     VPP_LAUNCH_CHECK();
     return VPP_OK;
   }
@@ -352,8 +500,9 @@ int vpp_rgb_pyramid_build(const vpp_image_desc* levels, int nlevels, const vpp_i
   VPP_REQUIRE(same_domain(&levels[0], rgb), VPP_ERR_INVALID_ARG, "vpp_rgb_pyramid_build: level 0 and the frame differ in size");
   hipStream_t st = as_stream(stream);
   if ((nlevels == 2 || nlevels == 3) && chain_shape_ok(levels, nlevels) && tuning("pyr.fused", 1)) {
-    if (rgb->channels == 3) launch_chain<uint8_t, int, 1, 8, GraySrc<3>>(levels, nlevels, rgb, st);
-    else launch_chain<uint8_t, int, 1, 8, GraySrc<4>>(levels, nlevels, rgb, st);
+    const bool swar = nlevels == 3 && tuning("pyr.swar", 1);
+    if (rgb->channels == 3) { if (!(swar && launch_swar3<GrayFast<3>, GraySrc<3>>(levels, rgb, st))) launch_chain<uint8_t, int, 1, 8, GraySrc<3>>(levels, nlevels, rgb, st); }
+    else if (!(swar && launch_swar3<GrayFast<4>, GraySrc<4>>(levels, rgb, st))) launch_chain<uint8_t, int, 1, 8, GraySrc<4>>(levels, nlevels, rgb, st);
     VPP_LAUNCH_CHECK();
     return VPP_OK;
   }

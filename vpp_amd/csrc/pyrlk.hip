@@ -186,14 +186,38 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kLkRecords = 16 * 3;   // per group, after its NS term pairs: 8 row + 8 column coordinate records of 3 dwords
-// dwords between the LDS blocks of two groups of a wave: the term reads are broadcasts inside a group (every lane sums every term), so
-// the 64 / LPK groups must sit on different banks — stride = LPK (mod 64).  (The unpadded 160-dword blocks of the 8-lane groups put four
-// groups on each of two bank sets: every term read of the 400 k-keypoint case went 4-way serialised, 2.6 -> 5.2 ms.)
+constexpr int kLkRecords = 16 * 3;   // per group, after its two term arrays: 8 row + 8 column coordinate records of 3 dwords
+// LDS block of a group (round 3): the two term arrays of an offset sit in two planes — T0[i] at dword i, T1[i] at lk_plane(ns) + i — so that
+// the ordered sums fetch FOUR consecutive terms of their chain with one ds_read_b128 (13 LDS instructions per 49-term sum instead of 25
+// ds_read2_b32 on the interleaved layout; the kernel is issue bound and LDS instructions were 19 % of its issue cycles).  The reads are
+// broadcasts inside a group, so the 64 / LPK groups x 2 planes must start on different banks: planes 4 dwords apart (mod 32), groups 8 apart
+// (LPK >= 16: 4 groups x 2 planes = the eight 16-byte slots of the 32 banks) or 4 apart (LPK = 8: 16 chunks, two per slot at best).
+__host__ __device__ constexpr int lk_plane(int ns) { return ns + 4; }
 __host__ __device__ constexpr int lk_group_stride(int ns, int lpk) {
-  int g = ns * 2 + kLkRecords;
-  while (lpk < 64 && g % 64 != lpk) g++;
+  int g = lk_plane(ns) + ns + kLkRecords;
+  const int want = lpk >= 16 ? 8 : 4;
+  while (lpk < 64 && g % 32 != want) g++;
   return g;
+}
+// sum of t[0 .. N) in index order (the reference's left-to-right float chain), four terms per LDS read; t is 16-byte aligned
+template <int N> __device__ __forceinline__ float ordered_sum(const float* t, float acc) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int j = 0; j < N / 4; j++) { const f4 q = *(const f4*)(t + 4 * j); acc += q.x; acc += q.y; acc += q.z; acc += q.w; }
+#pragma unroll
+  for (int i = N / 4 * 4; i < N; i++) acc += t[i];
+  return acc;
+}
+template <int N> __device__ __forceinline__ float ordered_dot(const float* a, const float* b, float acc) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int j = 0; j < N / 4; j++) {
+    const f4 x = *(const f4*)(a + 4 * j), y = *(const f4*)(b + 4 * j);
+    acc += x.x * y.x; acc += x.y * y.y; acc += x.z * y.z; acc += x.w * y.w;
+  }
+#pragma unroll
+  for (int i = N / 4 * 4; i < N; i++) acc += a[i] * b[i];
+  return acc;
 }
 // lane k (0..3) of every quad, to all four lanes of the quad (v_mov_b32 dpp quad_perm)
 template <int K> __device__ __forceinline__ float quad_bcast(float x) {
@@ -204,7 +228,8 @@ template <int WS, class GT, bool PYRLK, int LPK>
 __device__ Match lk_match_group(  // WS*WS <= 64
     float p0, float p1, float tr0, float tr1, const DImg& A_, const DImg& B_, const DImg& Ag_, float min_ev_th,
                                 int max_it, float delta, float* lds, int gl, float norm_T) {
-  constexpr int hws = WS / 2, N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
+  constexpr int hws = WS / 2, N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK, TP = lk_plane(NS);
+  float* const lds1 = lds + TP;   // the second term plane (see lk_group_stride)
   // the level's descriptors by value: the callers index a kernel-argument array with the (runtime) level, and through the
   // references every use inside the iteration loop was a fresh scalar load + wait
   const DImg A = A_, B = B_, Ag = Ag_;
@@ -233,7 +258,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
       const bool ok = i < N && A.has((int)(p0 + off_r(k)), (int)(p1 + off_c(k)));
       gs0[k] = ok ? (float)g[k][0] : 0.f; gs1[k] = ok ? (float)g[k][1] : 0.f; as[k] = ok ? (int)a[k] : 0;
       if (ok) mine |= 1ull << i;
-      lds[2 * i] = gs0[k]; lds[2 * i + 1] = gs1[k];
+      lds[i] = gs0[k]; lds1[i] = gs1[k];
     }
   } else {
 #pragma unroll
@@ -249,7 +274,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
           mine |= 1ull << i;
         }
       }
-      lds[2 * i] = gs0[k]; lds[2 * i + 1] = gs1[k];
+      lds[i] = gs0[k]; lds1[i] = gs1[k];
     }
   }
   unsigned long long mask = mine;  // OR over the group's lanes (xor-butterfly stays inside aligned groups of LPK lanes)
@@ -269,13 +294,12 @@ __device__ Match lk_match_group(  // WS*WS <= 64
     const int ia = (gl & 3) == 2 ? 1 : 0, ib = (gl & 3) == 0 ? 0 : 1;   // (gx, gx), (gx, gy), (gy, gy), (gx, gy)
     float acc = 0.f;
     if (all_valid) {  // the common case, branch-free
-#pragma unroll
-      for (int i = 0; i < N; i++) acc += lds[2 * i + ia] * lds[2 * i + ib];   // lk.hh:56-72 in offset order
+      acc = ordered_dot<N>(lds + ia * TP, lds + ib * TP, acc);   // lk.hh:56-72 in offset order
       cpt = N;
     } else {
 #pragma unroll 1
       for (int i = 0; i < N; i++) {
-        if ((mask >> i) & 1ull) { acc += lds[2 * i + ia] * lds[2 * i + ib]; cpt++; }
+        if ((mask >> i) & 1ull) { acc += lds[ia * TP + i] * lds[ib * TP + i]; cpt++; }
       }
     }
     G00 = quad_bcast<0>(acc); G01 = quad_bcast<1>(acc); G11 = quad_bcast<2>(acc); G10 = G01;
@@ -309,7 +333,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
         // records {a0, 1 - a0, byte offset of row x0} and the WS column records {a1, 1 - a1, x1} are evaluated once per group (one
         // record per lane, the same float operations on the same inputs as the per-tap form) and every tap reads its two records from
         // LDS: 1 address add per tap instead of 13 VALU operations (adds, conversions, fractions, the row multiply).
-        float* xl = lds + 2 * NS;
+        float* xl = lds1 + NS;
 #pragma unroll
         for (int t = 0; t < (LPK >= 16 ? 1 : 16 / LPK); t++) {
           const int rec = gl + t * LPK;
@@ -342,7 +366,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
                           (a0 * a1) * (float)(uint8_t)(t1[q] >> 8);
           const uint8_t b = (uint8_t)v;
           const float dt = (float)as[q] - (float)b;  // lk.hh:130
-          lds[2 * i] = gs0[q] * dt; lds[2 * i + 1] = gs1[q] * dt;
+          lds[i] = gs0[q] * dt; lds1[i] = gs1[q] * dt;
         }
       } else {
         // 7 taps per lane (LPK = 8): the wave's LDS pipe is as busy as its VALU with the 49 broadcast term reads alone, the record reads
@@ -354,7 +378,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
         for (int q = 0; q < PPL; q++) {
           const int i = gl + q * LPK;
           const float dt = (float)as[q] - (float)b[q];  // lk.hh:130
-          lds[2 * i] = gs0[q] * dt; lds[2 * i + 1] = gs1[q] * dt;
+          lds[i] = gs0[q] * dt; lds1[i] = gs1[q] * dt;
         }
       }
     } else {
@@ -369,7 +393,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
           const float dt = (float)as[q] - (float)b;  // lk.hh:130
           t0 = gs0[q] * dt; t1 = gs1[q] * dt;
         }
-        lds[2 * i] = t0; lds[2 * i + 1] = t1;
+        lds[i] = t0; lds1[i] = t1;
       }
     }
     wave_lds_fence();
@@ -377,12 +401,11 @@ __device__ Match lk_match_group(  // WS*WS <= 64
     {
       float acc = 0.f;   // even lanes: bk[0], odd lanes: bk[1]
       if (all_valid) {
-#pragma unroll
-        for (int i = 0; i < N; i++) acc += lds[2 * i + (gl & 1)];
+        acc = ordered_sum<N>(lds + (gl & 1) * TP, acc);
       } else {
 #pragma unroll 1
         for (int i = 0; i < N; i++)
-          if ((mask >> i) & 1ull) acc += lds[2 * i + (gl & 1)];
+          if ((mask >> i) & 1ull) acc += lds[(gl & 1) * TP + i];
       }
       bk0 = quad_bcast<0>(acc); bk1 = quad_bcast<1>(acc);
     }
@@ -401,7 +424,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
       const int i = gl + q * LPK;
-      lds[2 * i] = (float)as[q]; lds[2 * i + 1] = fabsf((float)(as[q] - (int)b[q]));
+      lds[i] = (float)as[q]; lds1[i] = fabsf((float)(as[q] - (int)b[q]));
     }
   } else {
 #pragma unroll
@@ -413,15 +436,14 @@ __device__ Match lk_match_group(  // WS*WS <= 64
         interp<uint8_t, 1, false>(B, v0 + off_r(q), v1 + off_c(q), &b);
         e = fabsf((float)(as[q] - (int)b));
       }
-      lds[2 * i] = (float)as[q]; lds[2 * i + 1] = e;
+      lds[i] = (float)as[q]; lds1[i] = e;
     }
   }
   wave_lds_fence();
   float err, stddev = 1.f;
   {
     float acc = 0.f;   // even lanes: the sum of as[], odd lanes: the sum of |as - b|
-#pragma unroll
-    for (int i = 0; i < N; i++) acc += lds[2 * i + (gl & 1)];
+    acc = ordered_sum<N>(lds + (gl & 1) * TP, acc);
     cpt += N;
     err = quad_bcast<1>(acc);
     if (PYRLK) {
@@ -429,7 +451,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
       stddev = 0.f;
       avg /= N;
 #pragma unroll
-      for (int i = 0; i < N; i++) stddev += fabsf(avg - lds[2 * i]);
+      for (int i = 0; i < N; i++) stddev += fabsf(avg - lds[i]);
       stddev /= N;
     }
   }
@@ -443,7 +465,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void py
                                                                float min_ev, float max_err, int max_it, float delta, int min_scale,
                                                                float* __restrict__ out_dist) {
   constexpr int N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
-  __shared__ float smem[(64 / LPK) * lk_group_stride(NS, LPK)];
+  __shared__ __attribute__((aligned(16))) float smem[(64 / LPK) * lk_group_stride(NS, LPK)];
   const int gl = threadIdx.x % LPK, grp = threadIdx.x / LPK;
   const int i = blockIdx.x * (64 / LPK) + grp;
   if (i >= n) return;
@@ -472,7 +494,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lu
                                                                 const float* __restrict__ pred, int n, float min_ev, int niter, float delta,
                                                                 float* __restrict__ out_flow, float* __restrict__ out_dist) {
   constexpr int N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
-  __shared__ float smem[(64 / LPK) * lk_group_stride(NS, LPK)];
+  __shared__ __attribute__((aligned(16))) float smem[(64 / LPK) * lk_group_stride(NS, LPK)];
   const int gl = threadIdx.x % LPK, grp = threadIdx.x / LPK;
   const int i = blockIdx.x * (64 / LPK) + grp;
   if (i >= n) return;

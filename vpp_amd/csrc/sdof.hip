@@ -158,6 +158,19 @@ __global__ __launch_bounds__(256) void sdof_claim_kernel(const int32_t* __restri
   atomicMin(owner.row<uint32_t>(pf0) + pf1, (uint32_t)i);
 }
 
+// the claims of every scale in one launch (single strip, single rank): a claim depends on the keypoint list and the scale only, not on any flow
+struct ClaimAll { DImg owner[kMaxScales]; int first, last; };
+__global__ __launch_bounds__(256) void sdof_claim_all_kernel(const int32_t* __restrict__ kps, int n, int patch, ClaimAll c) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k0 = kps[2 * i], k1 = kps[2 * i + 1];
+  for (int s = c.first; s <= c.last; s++) {
+    const int div = 1 << s;
+    const int pf0 = (k0 / div) / patch, pf1 = (k1 / div) / patch;
+    if (c.owner[s].has(pf0, pf1)) atomicMin(c.owner[s].row<uint32_t>(pf0) + pf1, (uint32_t)i);
+  }
+}
+
 template <int WS>
 __global__ __launch_bounds__(64) void sdof_descent_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
                                                           DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi) {
@@ -216,6 +229,98 @@ __device__ __forceinline__ GdMatch group_descent(DIST dist, int p0, int p1, int 
   return GdMatch{m0 - p0, m1 - p1, match_distance};
 }
 
+// LDS hand-off inside one wave (the 8 lanes of a group sit in one wave): LDS operations of a wave execute in program order, the fences keep
+// the compiler from moving them across the hand-off.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+constexpr int kUnionRows = 13;   // (WS + 2) rows of 16 bytes for WS <= 11; 13 x 16 B = 52 dwords per group: the 8 groups of a wave start 20 banks apart
+
+// group_descent with the candidates' windows staged through LDS.  The 3 / 5 / 8 candidates of a search step are the 8-neighbours of the
+// step's centre: their WS x WS windows all lie inside one (WS + 2) x (WS + 2) patch of image 2.  With a window per lane (WS 12-byte row loads
+// each) a step cost a group 8 x WS scattered row loads, and the phase was bound by the address rate of those gathers (~1 lane per clock
+// and CU: 37-40 us per scale for 75 k keypoints at 4K, VALU issue at 26 %).  Here the group loads the patch ONCE per step — lane j takes
+// rows j and j + 8, 16 bytes each — into its LDS slot, and every lane cuts its candidate's rows out of the staged rows (one 16-byte LDS
+// read and three v_alignbyte per row).  Same windows, same row-wise early-out rule, same first-of-minima selection: bit-identical.
+// A patch that is not entirely inside the bordered area (a walk along the frame's edge) takes the per-lane form `dist` for that step.
+// have_start: `start` = distance(p, pr) is known (the sweeps pass d2); otherwise it is taken from the first staged patch's centre.
+template <int WS, class DIST>
+__device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa, bool a_ok, const DImg& i2, int p0, int p1, int pr0, int pr1,
+                                                        bool have_start, int start, int j, uint4* __restrict__ slot, DIST dist) {
+  static_assert(WS >= 3 && WS + 2 <= kUnionRows, "the patch of a step is (WS + 2) rows of at most 16 bytes");
+  constexpr int H = WS / 2, UR = WS + 2, ND = (WS + 3) / 4;
+  constexpr uint32_t tail_mask = (WS % 4) ? ((1u << (8 * (WS % 4))) - 1u) : 0xFFFFFFFFu;
+  constexpr unsigned kFirst = 0xd22406u, kEnd = 0x27fb5bu, kDr = 0x9224u, kDc = 0x16au;
+  int m0 = pr0, m1 = pr1;
+  int match_distance = start;
+  unsigned match_i = 8;
+#pragma nounroll
+  for (int search = 0; search < 5; search++) {
+    const int ur0 = pr0 - H - 1, uc0 = pr1 - H - 1;   // the patch: rows [ur0, ur0 + UR), 16 bytes from column uc0
+    const bool staged = a_ok && ur0 >= -i2.border && ur0 + UR <= i2.nr + i2.border && uc0 >= -i2.border && uc0 + 16 <= i2.nc + i2.border;
+    if (staged) {
+      wave_lds_fence();   // the previous step's reads are done
+      const uint8_t* src = i2.row<uint8_t>(ur0 + j) + uc0;
+      uint4 v0, v1;
+      __builtin_memcpy(&v0, src, 16);
+      if (j + 8 < UR) __builtin_memcpy(&v1, src + (ptrdiff_t)8 * i2.pitch, 16);
+      slot[j] = v0;
+      if (j + 8 < UR) slot[j + 8] = v1;
+      wave_lds_fence();
+    }
+    // sad_distance of the keypoint's window against the window centred (dr, dc) from the step's centre, cut out of the staged patch
+    auto sad_at = [&](int dr, int dc, int th) -> int {
+      const uint32_t o = (uint32_t)(1 + dc);
+      int err = 0;
+#pragma unroll
+      for (int r = 0; r < WS; r++) {
+        const uint4 q = slot[1 + dr + r];
+        if (err <= th) {
+          const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+          uint32_t err2 = 0;
+#pragma unroll
+          for (int d = 0; d < ND; d++) {
+            const uint32_t m = d == ND - 1 ? tail_mask : 0xFFFFFFFFu;
+            const uint32_t b = __builtin_amdgcn_alignbyte(w[d + 1], w[d], o);
+            err2 = __builtin_amdgcn_sad_u8(wa.d[r][d] & m, b & m, err2);
+          }
+          err += (int)err2;
+        }
+      }
+      return err;
+    };
+    if (!have_start) {
+      match_distance = staged ? (i2.has(pr0, pr1) ? sad_at(0, 0, INT_MAX) : INT_MAX) : dist(pr0, pr1, INT_MAX);
+      have_start = true;
+    }
+    const unsigned first = (kFirst >> (3 * match_i)) & 7u, end = (kEnd >> (3 * match_i)) & 7u;
+    const unsigned count = ((end - first - 1u) & 7u) + 1u;
+    const unsigned ci = (first + (unsigned)j) & 7u;
+    const int cdr = (int)((kDr >> (2 * ci)) & 3u) - 1, cdc = (int)((kDc >> (2 * ci)) & 3u) - 1;
+    const int n0 = pr0 + cdr, n1 = pr1 + cdc;
+    int d = INT_MAX;
+    if ((unsigned)j < count) d = staged ? (i2.has(n0, n1) ? sad_at(cdr, cdc, match_distance) : INT_MAX) : dist(n0, n1, match_distance);
+    unsigned long long key = ((unsigned long long)(unsigned)d << 3) | (unsigned)j;
+#pragma unroll
+    for (int x = 1; x < 8; x <<= 1) {
+      const unsigned lo = __shfl_xor((unsigned)key, x), hi = __shfl_xor((unsigned)(key >> 32), x);
+      const unsigned long long ok = ((unsigned long long)hi << 32) | lo;
+      key = ok < key ? ok : key;
+    }
+    const int best = (int)(unsigned)(key >> 3);
+    if (best < match_distance) {
+      const unsigned wi = (first + (unsigned)(key & 7u)) & 7u;
+      m0 = pr0 + (int)((kDr >> (2 * wi)) & 3u) - 1; m1 = pr1 + (int)((kDc >> (2 * wi)) & 3u) - 1;
+      match_i = wi; match_distance = best;
+    }
+    if (pr0 == m0 && pr1 == m1) break;
+    pr0 = m0; pr1 = m1;
+  }
+  return GdMatch{m0 - p0, m1 - p1, match_distance};
+}
+
 // The same phase with 8 lanes per keypoint: the candidates of one search step (the 3, 5 or 8 neighbours the reference walks one after
 // the other) are evaluated by the lanes of the group side by side and the winner is the minimum of (distance << 3 | position in the
 // walk) — the sequential rule "replace on strictly smaller" keeps the FIRST of equal minima, and a candidate that the sequential walk
@@ -224,6 +329,7 @@ __device__ __forceinline__ GdMatch group_descent(DIST dist, int p0, int p1, int 
 template <int WS>
 __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
                                                                 DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi) {
+  __shared__ uint4 s_union[8][kUnionRows];   // per group: the (WS + 2)-row patch of the current search step
   const int i = blockIdx.x * 8 + (threadIdx.x >> 3), j = threadIdx.x & 7;
   if (i >= n) return;
   const int p0 = kps[2 * i] / scale_div, p1 = kps[2 * i + 1] / scale_div;  // :116
@@ -248,7 +354,9 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
       return sad_rows_against<WS>(wa, i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2), i2.pitch, th);
     } else return distance_fn<WS>(i1, i2, p0, p1, b0, b1, ws, th);
   };
-  const GdMatch g = group_descent(dist, p0, p1, pr0, pr1, dist(pr0, pr1, INT_MAX), j);
+  GdMatch g;
+  if constexpr (WS != 0) g = group_descent_staged<WS>(wa, a_ok, i2, p0, p1, pr0, pr1, false, INT_MAX, j, s_union[threadIdx.x >> 3], dist);
+  else g = group_descent(dist, p0, p1, pr0, pr1, dist(pr0, pr1, INT_MAX), j);
   if (j != 0) return;
   int32_t* f = cur.flow.row<int32_t>(pf0) + 2 * pf1;
   f[0] = g.f0; f[1] = g.f1;                        // :137-139
@@ -380,10 +488,27 @@ __global__ __launch_bounds__(256) void sdof_classify_kernel(Maps m, int NI, int 
   }
 }
 
+// Append the lanes' targets (-1: none) to the queue of round parity `q`: the flag exchange keeps a cell from being listed twice, and the
+// slots are taken with ONE atomic per wave (the counter is a single word: returning atomics on one address retire at ~11 ns each, and a
+// changed cell lists up to five cells).  Called at a point every lane of the wave reaches.
+__device__ __forceinline__ void enqueue_targets(const RoundArrays& a, SweepCtl* ctl, int q, int target) {
+  bool push = false;
+  if (target >= 0) push = __hip_atomic_exchange(&a.qflag[q][target], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+  const unsigned long long b = __ballot(push);
+  if (b) {
+    const int lane = __lane_id(), leader = __ffsll((long long)b) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = __hip_atomic_fetch_add(&ctl->count[q], (unsigned)__popcll(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    base = __shfl(base, leader);
+    if (push) a.Q[q][base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)target;
+  }
+}
+
 template <int WS>
 __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats) {
   __shared__ unsigned s_val;
   __shared__ unsigned long long s_gen;
+  __shared__ uint4 s_union[kJobsPerGroup][kUnionRows];   // per 8-lane group: the candidate patch of a descent step (group_descent_staged)
   SweepCtl* const ctl = a.ctl;
   const int tid = threadIdx.x, j = tid & 7;
   unsigned n = ctl->count[0];   // complete: written by the classify kernel
@@ -407,6 +532,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
       __syncthreads();
       if (base >= n) break;
       const unsigned job = base + (unsigned)(tid >> 3);
+      int target = -1;   // the cell this lane wants in the next round's queue
       if (job < n) {
         const int cell = (int)Qcur[job];
         const int ci = cell / NJ, cj = cell - ci * NJ;
@@ -426,33 +552,48 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
         const unsigned long long grp = 0xFFull << (__lane_id() & ~7);
         const bool need = k == 0 || (__ballot(in && earlier && (nb.mark >> kTagShift) == k) & grp) != 0;
         Cell cur = Cell{old.f0, old.f1, old.dist, old.mark & 0xFF};
+        const int r = forward ? ci * patch : i1.nr - 1 - (NI - 1 - ci) * patch, c = forward ? cj * patch : i1.nc - 1 - (NJ - 1 - cj) * patch;
+        WindowRegs<WS> wa;
+        bool a_ok = false, okb = false, need_walk = false;
+        int d2 = INT_MAX;
+        auto dist = [&](int b0, int b1, int th) -> int {
+          if constexpr (WS != 0) {
+            if (!(a_ok && i2.has(b0, b1))) return INT_MAX;
+            return sad_rows_against<WS>(wa, i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2), i2.pitch, th);
+          } else return distance_fn<WS>(i1, i2, r, c, b0, b1, ws, th);
+        };
         if (need) {
-          const int r = forward ? ci * patch : i1.nr - 1 - (NI - 1 - ci) * patch, c = forward ? cj * patch : i1.nc - 1 - (NJ - 1 - cj) * patch;
-          WindowRegs<WS> wa;
-          const bool a_ok = i1.has(r, c);
+          a_ok = i1.has(r, c);
           if (WS != 0 && a_ok) load_window<WS>(wa, i1.row<uint8_t>(r - ws / 2) + (c - ws / 2), i1.pitch);
-          auto dist = [&](int b0, int b1, int th) -> int {
-            if constexpr (WS != 0) {
-              if (!(a_ok && i2.has(b0, b1))) return INT_MAX;
-              return sad_rows_against<WS>(wa, i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2), i2.pitch, th);
-            } else return distance_fn<WS>(i1, i2, r, c, b0, b1, ws, th);
-          };
           // static part of the test at :164-165: the neighbour is marked and differs from prev_flow; its d2 (:169) depends on nothing else
           const int b0 = pre.f0 - nb.f0, b1 = pre.f1 - nb.f1;
-          const bool okb = nbm && b0 * b0 + b1 * b1 >= 9;
-          const int d2 = okb ? dist(r + nb.f0, c + nb.f1, INT_MAX) : INT_MAX;
+          okb = nbm && b0 * b0 + b1 * b1 >= 9;
+          d2 = okb ? dist(r + nb.f0, c + nb.f1, INT_MAX) : INT_MAX;
           cur = Cell{pre.f0, pre.f1, pre.dist, pre.mark & 0xFF};
-#pragma nounroll
-          for (int kk = 0; kk < 8; kk++) {   // loop_body's walk over the neighbours, uniform over the group
-            if (!__shfl((int)okb, kk, 8)) continue;
-            const int n0 = __shfl(nb.f0, kk, 8), n1 = __shfl(nb.f1, kk, 8);
+          need_walk = true;
+        }
+        // loop_body's walk over the neighbours (:160-187).  Each group keeps its OWN cursor: it skips ahead to its next neighbour that passes the
+        // tests at :164-170 against its running best, and the groups of the wave then run their descents TOGETHER, whatever neighbour each of them
+        // is at.  (With one loop over kk for the whole wave, a descent was executed once per kk at which ANY of the 8 groups needed one — up to 8
+        // descents of up to 5 dependent search steps per wave, most lanes idle: a round lasted as long as that chain, ~17 us on the 4K bench scene.)
+        // Per group the sequence of tests, descents and updates is exactly the sequential one.
+        int kk = 0;
+        for (;;) {
+          bool found = false;
+          int n0 = 0, n1 = 0, d2k = 0;
+          while (need_walk && kk < 8) {
+            const int ok = __shfl((int)okb, kk, 8);
+            n0 = __shfl(nb.f0, kk, 8); n1 = __shfl(nb.f1, kk, 8); d2k = __shfl(d2, kk, 8);
+            kk++;
             const int a0 = cur.f0 - n0, a1 = cur.f1 - n1;
-            if (a0 * a0 + a1 * a1 < 9) continue;
-            const int d2k = __shfl(d2, kk, 8);
-            if (d2k < cur.dist) {
-              const GdMatch g = group_descent(dist, r, c, r + n0, c + n1, d2k, j);   // :173-175; its first distance is d2 itself
-              if (g.distance < cur.dist) { cur.mark = 1; cur.f0 = g.f0; cur.f1 = g.f1; cur.dist = g.distance; }   // :179-184
-            }
+            if (ok && a0 * a0 + a1 * a1 >= 9 && d2k < cur.dist) { found = true; break; }
+          }
+          if (!__ballot(found)) break;   // no group of this wave has a descent left
+          if (found) {
+            GdMatch g;   // :173-175; its first distance is d2 itself
+            if constexpr (WS != 0) g = group_descent_staged<WS>(wa, a_ok, i2, r, c, r + n0, c + n1, true, d2k, j, s_union[tid >> 3], dist);
+            else g = group_descent(dist, r, c, r + n0, c + n1, d2k, j);
+            if (g.distance < cur.dist) { cur.mark = 1; cur.f0 = g.f0; cur.f1 = g.f1; cur.dist = g.distance; }   // :179-184
           }
         }
         const bool changed = cur.f0 != old.f0 || cur.f1 != old.f1 || cur.dist != old.dist || cur.mark != (old.mark & 0xFF);
@@ -463,15 +604,11 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
           if (stats) { atomicAdd(&g_round_stats[1], 1u); if (need) atomicAdd(&g_round_stats[2], 1u); if (changed) atomicAdd(&g_round_stats[3], 1u); }
         }
         if (changed) {   // next round: this cell (its value must reach the other buffer) and the marked cells that read it as an earlier neighbour
-          int target = -1;
           if (j == (forward ? 0 : 7)) target = cell;                       // one of the earlier-neighbour lanes speaks for the cell itself
           else if (!earlier && in && nbm) target = q0 * NJ + q1;
-          if (target >= 0 && __hip_atomic_exchange(&a.qflag[par ^ 1][target], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            const unsigned slot = __hip_atomic_fetch_add(&ctl->count[par ^ 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.Q[par ^ 1][slot] = (uint32_t)target;
-          }
         }
       }
+      enqueue_targets(a, ctl, par ^ 1, target);
     }
     // ---- grid barrier over the registered workgroups; the last arriver publishes the size of the next round with the generation
     __syncthreads();
@@ -665,6 +802,13 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
     sdof_reset_kernel<<<blocks, 256, 0, st>>>(ra);
     VPP_LAUNCH_CHECK();
   }
+  const bool claim_up_front = reset_up_front && world == 1 && tuning("sdof.claim_up_front", 1);
+  if (claim_up_front) {
+    ClaimAll ca; ca.first = min_scale; ca.last = nscales - 1;
+    for (int s_ = min_scale; s_ < nscales; s_++) ca.owner[s_] = dimg(&OW(0, s_));
+    sdof_claim_all_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize, ca);
+    VPP_LAUNCH_CHECK();
+  }
   for (int scale = nscales - 1; scale >= min_scale; scale--) {  // :92
     const int scale_div = 1 << scale;
     const uint8_t zero = 0;
@@ -681,7 +825,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
           int r2 = vpp_fill(&MK(k, scale), &zero, 1, (void*)sk); if (r2) return r2;  // fill_with_border(flow_map_mark, 0), :111
           VPP_HIP_TRY(hipMemsetAsync(OW(k, scale).first_pixel, 0xFF, (size_t)OW(k, scale).pitch * OW(k, scale).nrows, sk));
         }
-        sdof_claim_kernel<<<(n + 255) / 256, 256, 0, sk>>>(kps, n, scale_div, patchsize, dimg(&OW(k, scale)), lo, hi);
+        if (!claim_up_front) sdof_claim_kernel<<<(n + 255) / 256, 256, 0, sk>>>(kps, n, scale_div, patchsize, dimg(&OW(k, scale)), lo, hi);
         if (tuning("sdof.descent_lanes", 8) == 8)
           sdof_descent_group_kernel<WS><<<(n + 7) / 8, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
                                                                     maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi);

@@ -58,17 +58,13 @@ template <class V, int NPX> struct stage<image_acc<V>, NPX> {
   typedef typename std::remove_const<V>::type T;
   static constexpr int kBytes = NPX * (int)sizeof(T);
   static constexpr bool kVec = kBytes % 16 == 0;   // NPX > 1 chunks are 16-byte multiples and 16-byte aligned (the launcher checks)
-  static constexpr bool kVec4 = !kVec && NPX > 1 && kBytes % 4 == 0;   // 4 px of a 3-byte type: 12 B at a dword-aligned address
-  union buf { T px[NPX]; u32x4 q[(kBytes + 15) / 16]; unsigned int d[(kBytes + 3) / 4]; unsigned char b[kBytes]; __device__ buf() {} } now, old;
+  union buf { T px[NPX]; u32x4 q[(kBytes + 15) / 16]; unsigned char b[kBytes]; __device__ buf() {} } now, old;
   __device__ char* addr(const image_acc<V>& a, int r, int c) const { return (char*)a.p0 + (ptrdiff_t)r * a.pitch + (ptrdiff_t)c * (int)sizeof(T); }
   __device__ void load(const image_acc<V>& a, int r, int c) {
     const char* p = addr(a, r, c);
     if constexpr (kVec) {
 #pragma unroll
       for (int i = 0; i < kBytes / 16; i++) now.q[i] = ((const u32x4*)p)[i];
-    } else if constexpr (kVec4) {
-#pragma unroll
-      for (int i = 0; i < kBytes / 4; i++) now.d[i] = ((const unsigned int*)p)[i];
     } else {
 #pragma unroll
       for (int i = 0; i < NPX; i++) now.px[i] = ((const T*)p)[i];
@@ -89,9 +85,6 @@ template <class V, int NPX> struct stage<image_acc<V>, NPX> {
     if constexpr (kVec) {
 #pragma unroll
       for (int i = 0; i < kBytes / 16; i++) ((u32x4*)p)[i] = now.q[i];
-    } else if constexpr (kVec4) {
-#pragma unroll
-      for (int i = 0; i < kBytes / 4; i++) ((unsigned int*)p)[i] = now.d[i];
     } else {
 #pragma unroll
       for (int i = 0; i < NPX; i++) ((T*)p)[i] = now.px[i];
@@ -158,7 +151,8 @@ template <class F, class... A> void launch(F f, int r0, int c0, int nrows, int n
   const int gy = nrows < 65535 ? nrows : 65535;
   // A callable that reads a neighbourhood issues its taps per pixel, so with NPX pixels per lane the lanes of a wave sit NPX pixels apart and every
   // tap of the wave is spread over NPX times as many cache lines.  For pixel types whose 16-byte chunk is many pixels (vuchar3: 16 px = 48 B per lane,
-  // a byte load per component and tap) four pixels per lane (12 B, moved as dwords) are the measured optimum — 4K vuchar3 5 x 5 mean through the
+  // a byte load per component and tap) four pixels per lane (12 B, moved pixel by pixel: packing them into dwords made the compiler keep the
+  // chunk in LDS, 175 us) are the measured optimum — 4K vuchar3 5 x 5 mean through the
   // opaque lambda, synchronous calls: 16 px per lane 369 us, 1 px 107 us, 4 px 63 us (ops::box_mean<5, 5>: 19 us; `int` pixels are 4 px per lane anyway)
   if (kNbh && al && NPX > 4 && NPX % 4 == 0) {
     const int chunks = (ncols + 3) / 4;
