@@ -348,7 +348,8 @@ def main():
         refomp = binding.load_ref_omp()  # the reference's own pixel_wise + relative_access code, OpenMP build, where it was built
         if refomp is not None:
             run_cpu = lambda: refomp.ref_box_filter5x5(P(dst_h.desc), P(src_h.desc))
-            kind, what = "reference", "oracle/_ref/libvpp_ref_omp.so = matt-42/vpp headers, -O3 -fopenmp -DNDEBUG (benchmarks/CMakeLists.txt:10,18)"
+            kind, what = "reference", ("oracle/_ref/libvpp_ref_omp.so = matt-42/vpp headers, -O3 -fopenmp -DNDEBUG (benchmarks/CMakeLists.txt:10,18); a LOWER BOUND on the reference: "
+                                       "the vuchar3 -> vint3 arithmetic of the window runs through the scalar loops of oracle/ref/shims/Eigen/Core (Eigen itself is absent), not Eigen's vectorised packets")
         else:
             run_cpu = lambda: orc.orc_box_filter(P(dst_h.desc), P(src_h.desc), 5, 5)
             kind, what = "port", "oracle/liboracle_omp.so (-O3 -fopenmp)"

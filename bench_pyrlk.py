@@ -224,6 +224,25 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
                         "us_per_frame": iev / isteps * 1e6, "gpixels_per_s": 2160 * 3840 * world / (iwall / isteps) / 1e9,
                         "roofline": {"bound": "hbm", "achieved": ibytes / (iev / isteps) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": ibytes / (iev / isteps) / 1e9 / 8000.0}}
 
+    # ingest fused with the image pyramid it feeds (vpp_rgb_pyramid_build: one launch) against the two-call chain, 4K, border 3, 3 levels
+    try:
+        npy = 12
+        lvs = [[DeviceImage(a, b, vi.U8, 1, 3, 32, dev) for a, b in pyr.level_dims(2160, 3840, 3)] for _ in range(npy)]
+        dls = [vi.desc_array(l) for l in lvs]
+        psteps = 200
+        fw, fev = timed(lambda i, s: lib.vpp_rgb_pyramid_build(dls[i % npy], 3, P(rd[i % nin]), s), psteps, 20, graph=True)
+
+        def chain2(i, s):
+            lib.vpp_rgb_to_graylevel(P(gdsc[i % nin]), P(rd[i % nin]), 1, s)
+            lib.vpp_pyramid_build(dls[i % npy], 3, P(gdsc[i % nin]), s)
+        cw, cev = timed(chain2, psteps, 20, graph=True)
+        pw, pev = timed(lambda i, s: lib.vpp_pyramid_build(dls[i % npy], 3, P(gdsc[i % nin]), s), psteps, 20, graph=True)
+        res["ingest_pyramid_4k"] = {"workload": "vuchar3 3840x2160 -> 3-level uchar pyramid with mirror border 3",
+                                    "fused_us": fev / psteps * 1e6, "ingest_then_pyramid_us": cev / psteps * 1e6, "pyramid_only_us": pev / psteps * 1e6,
+                                    "note": "vpp_rgb_pyramid_build (one launch, the gray frame written once) vs vpp_rgb_to_graylevel + vpp_pyramid_build; bit-identical levels"}
+    except Exception as e:  # noqa: BLE001
+        res["ingest_pyramid_4k"] = {"error": f"{type(e).__name__}: {e}"}
+
     # video_extruder_update on 4K frames through the C++ drop-in surface (benchmarks/video_extruder_bench.cc), rank 0 only
     exe = os.path.join(ROOT, "benchmarks", "video_extruder_bench")
     if rank == 0 and os.path.exists(exe):

@@ -198,6 +198,39 @@ static void test_sdof_and_video_extruder() {
     good += ctx.keypoints[i].velocity == vint2(1, 2);
   }
   CHECK(alive > 30 && good > alive * 0.8);
+
+  // the same sequence with the views handed out NON-CONST between the updates (what `draw::draw_trajectories(display, ctx.trajectories, 200)` does
+  // in examples/video_extruder.cc:57) but not changed: the update compares the host copies with what it downloaded and leaves the device state
+  // alone — the run ends in exactly the same state; then a real edit (a keypoint removed on the host) does reach the device
+  video_extruder_ctx ctx2 = video_extruder_init(make_box2d(nr, nc));
+  prev = texture(nr, nc, 0, 0);
+  fill_border_mirror(prev);
+  for (int t = 1; t <= 6; t++) {
+    image2d<unsigned char> next = texture(nr, nc, 1.f * t, 2.f * t);
+    fill_border_mirror(next);
+    video_extruder_update(ctx2, prev, next, _detector_th = 10, _keypoint_spacing = 10, _detector_period = 5, _nscales = 3, _winsize = 9);
+    std::vector<keypoint_trajectory>& tr = ctx2.trajectories;   // non-const view, nothing written
+    CHECK(tr.size() == size_t(ctx2.keypoints.size()));
+    prev = next;
+  }
+  CHECK(ctx2.frame_id == ctx.frame_id && ctx2.keypoints.size() == ctx.keypoints.size());
+  for (int i = 0; i < ctx.keypoints.size(); i++) {
+    CHECK(ctx2.keypoints[i].position == ctx.keypoints[i].position && ctx2.keypoints[i].velocity == ctx.keypoints[i].velocity && ctx2.keypoints[i].age == ctx.keypoints[i].age);
+    CHECK(ctx2.trajectories[i].size() == ctx.trajectories[i].size() && ctx2.trajectories[i].alive() == ctx.trajectories[i].alive());
+    for (int k = 0; k < ctx.trajectories[i].size(); k++) CHECK(ctx2.trajectories[i][k] == ctx.trajectories[i][k]);
+  }
+  int victim = -1;
+  for (int i = 0; i < ctx2.keypoints.size() && victim < 0; i++) if (ctx2.keypoints[i].age >= 3 && ctx2.keypoints[i].velocity == vint2(1, 2)) victim = i;
+  CHECK(victim >= 0);
+  ctx2.keypoints->remove(victim);   // keypoint_container::remove (keypoint_container.hpp:133-140): age = 0
+  {
+    image2d<unsigned char> next = texture(nr, nc, 7.f, 14.f);
+    fill_border_mirror(next);
+    video_extruder_update(ctx2, prev, next, _detector_th = 10, _keypoint_spacing = 10, _detector_period = 50, _nscales = 3, _winsize = 9);
+  }
+  // the flow runs over every container entry and its callback moves the matched ones, dead or not (video_extruder.hpp:44-53, keypoint_container.hpp:
+  // 143-156: age++): the removed keypoint is matched again and comes back with age 0 + 1 — had the edit not reached the device it would be >= 4
+  CHECK(ctx2.keypoints[victim].age == 1);
 }
 
 #ifdef HAVE_VPP_REF

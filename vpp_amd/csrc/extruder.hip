@@ -152,45 +152,61 @@ __global__ __launch_bounds__(256) void ve_append_kernel(int m, int count, const 
 template <class T> int dalloc(T** p, size_t count) { void* v = nullptr; const int rc = vpp_malloc(count * sizeof(T), &v); *p = (T*)v; return rc; }
 template <class T> void dfree(T*& p) { if (p) { vpp_free(p); p = nullptr; } }
 
+// Grows the state's buffers.  Everything is allocated into a copy of the state first and *ve is only replaced once every allocation (and the
+// carry-over of the live entries) has succeeded: on failure the new blocks are released and *ve still describes the old, intact buffers.
 int ve_reserve(vpp_video_extruder* ve, int want, hipStream_t st) {
   if (want <= ve->cap) return VPP_OK;
-  int ncap = std::max(want + want / 4, 4096);
-  vpp_video_extruder old = *ve;
+  const int ncap = std::max(want + want / 4, 4096);
+  vpp_video_extruder nw = *ve;
+  for (int b = 0; b < 2; b++) { nw.pos[b] = nullptr; nw.vel[b] = nullptr; nw.age[b] = nullptr; nw.tring[b] = nullptr; nw.thead[b] = nullptr; nw.tlen[b] = nullptr; nw.tstart[b] = nullptr; nw.talive[b] = nullptr; }
+  nw.fpos = nullptr; nw.fdist = nullptr; nw.scores = nullptr; nw.newidx = nullptr; nw.blocksum = nullptr; nw.fvalid = nullptr; nw.merged = nullptr;
+  auto release = [](vpp_video_extruder& x) {
+    for (int b = 0; b < 2; b++) { dfree(x.pos[b]); dfree(x.vel[b]); dfree(x.age[b]); dfree(x.tring[b]); dfree(x.thead[b]); dfree(x.tlen[b]); dfree(x.tstart[b]); dfree(x.talive[b]); }
+    dfree(x.fpos); dfree(x.fdist); dfree(x.scores); dfree(x.newidx); dfree(x.blocksum); dfree(x.fvalid); dfree(x.merged);
+  };
   int rc = VPP_OK;
   for (int b = 0; b < 2 && rc == VPP_OK; b++) {
-    rc = dalloc(&ve->pos[b], (size_t)ncap * 2); if (rc) break;
-    rc = dalloc(&ve->vel[b], (size_t)ncap * 2); if (rc) break;
-    rc = dalloc(&ve->age[b], ncap); if (rc) break;
-    rc = dalloc(&ve->tring[b], (size_t)ncap * ve->ring * 2); if (rc) break;
-    rc = dalloc(&ve->thead[b], ncap); if (rc) break;
-    rc = dalloc(&ve->tlen[b], ncap); if (rc) break;
-    rc = dalloc(&ve->tstart[b], ncap); if (rc) break;
-    rc = dalloc(&ve->talive[b], ncap);
+    rc = dalloc(&nw.pos[b], (size_t)ncap * 2); if (rc) break;
+    rc = dalloc(&nw.vel[b], (size_t)ncap * 2); if (rc) break;
+    rc = dalloc(&nw.age[b], ncap); if (rc) break;
+    rc = dalloc(&nw.tring[b], (size_t)ncap * ve->ring * 2); if (rc) break;
+    rc = dalloc(&nw.thead[b], ncap); if (rc) break;
+    rc = dalloc(&nw.tlen[b], ncap); if (rc) break;
+    rc = dalloc(&nw.tstart[b], ncap); if (rc) break;
+    rc = dalloc(&nw.talive[b], ncap);
   }
-  if (rc == VPP_OK) rc = dalloc(&ve->fpos, (size_t)ncap * 2);
-  if (rc == VPP_OK) rc = dalloc(&ve->fdist, ncap);
-  if (rc == VPP_OK) rc = dalloc(&ve->scores, ncap);
-  if (rc == VPP_OK) rc = dalloc(&ve->newidx, ncap);
-  if (rc == VPP_OK) rc = dalloc(&ve->blocksum, (size_t)ncap / kScanBlock + 2);
-  if (rc == VPP_OK) rc = dalloc(&ve->fvalid, ncap);
-  if (rc == VPP_OK) rc = dalloc(&ve->merged, ncap);
-  if (rc != VPP_OK) return rc;
-  const int c = old.cur;
-  if (old.n > 0) {  // carry the live state over (the other buffer of each pair is scratch)
-    VPP_HIP_TRY(hipMemcpyAsync(ve->pos[c], old.pos[c], (size_t)old.n * 8, hipMemcpyDeviceToDevice, st));
-    VPP_HIP_TRY(hipMemcpyAsync(ve->vel[c], old.vel[c], (size_t)old.n * 8, hipMemcpyDeviceToDevice, st));
-    VPP_HIP_TRY(hipMemcpyAsync(ve->age[c], old.age[c], (size_t)old.n * 4, hipMemcpyDeviceToDevice, st));
-    VPP_HIP_TRY(hipMemcpyAsync(ve->tring[c], old.tring[c], (size_t)old.n * ve->ring * 8, hipMemcpyDeviceToDevice, st));
-    VPP_HIP_TRY(hipMemcpyAsync(ve->thead[c], old.thead[c], (size_t)old.n * 4, hipMemcpyDeviceToDevice, st));
-    VPP_HIP_TRY(hipMemcpyAsync(ve->tlen[c], old.tlen[c], (size_t)old.n * 4, hipMemcpyDeviceToDevice, st));
-    VPP_HIP_TRY(hipMemcpyAsync(ve->tstart[c], old.tstart[c], (size_t)old.n * 4, hipMemcpyDeviceToDevice, st));
-    VPP_HIP_TRY(hipMemcpyAsync(ve->talive[c], old.talive[c], (size_t)old.n, hipMemcpyDeviceToDevice, st));
-    VPP_HIP_TRY(hipMemcpyAsync(ve->newidx, old.newidx, (size_t)old.n * 4, hipMemcpyDeviceToDevice, st));   // a compaction may be in progress
-    VPP_HIP_TRY(hipStreamSynchronize(st));
+  if (rc == VPP_OK) rc = dalloc(&nw.fpos, (size_t)ncap * 2);
+  if (rc == VPP_OK) rc = dalloc(&nw.fdist, ncap);
+  if (rc == VPP_OK) rc = dalloc(&nw.scores, ncap);
+  if (rc == VPP_OK) rc = dalloc(&nw.newidx, ncap);
+  if (rc == VPP_OK) rc = dalloc(&nw.blocksum, (size_t)ncap / kScanBlock + 2);
+  if (rc == VPP_OK) rc = dalloc(&nw.fvalid, ncap);
+  if (rc == VPP_OK) rc = dalloc(&nw.merged, ncap);
+  if (rc != VPP_OK) { release(nw); return rc; }
+  const int c = ve->cur;
+  if (ve->n > 0) {  // carry the live state over (the other buffer of each pair is scratch)
+    const size_t n = (size_t)ve->n;
+    hipError_t e = hipMemcpyAsync(nw.pos[c], ve->pos[c], n * 8, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nw.vel[c], ve->vel[c], n * 8, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nw.age[c], ve->age[c], n * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nw.tring[c], ve->tring[c], n * ve->ring * 8, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nw.thead[c], ve->thead[c], n * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nw.tlen[c], ve->tlen[c], n * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nw.tstart[c], ve->tstart[c], n * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nw.talive[c], ve->talive[c], n, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nw.newidx, ve->newidx, n * 4, hipMemcpyDeviceToDevice, st);   // a compaction may be in progress
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(st);   // nothing may still be writing into the blocks that are about to be released
+      release(nw);
+      set_error("video_extruder: carrying the state over to larger buffers failed: %s", hipGetErrorString(e));
+      return VPP_ERR_HIP;
+    }
   }
-  for (int b = 0; b < 2; b++) { dfree(old.pos[b]); dfree(old.vel[b]); dfree(old.age[b]); dfree(old.tring[b]); dfree(old.thead[b]); dfree(old.tlen[b]); dfree(old.tstart[b]); dfree(old.talive[b]); }
-  dfree(old.fpos); dfree(old.fdist); dfree(old.scores); dfree(old.newidx); dfree(old.blocksum); dfree(old.fvalid); dfree(old.merged);
+  vpp_video_extruder old = *ve;
+  *ve = nw;
   ve->cap = ncap;
+  release(old);
   return VPP_OK;
 }
 

@@ -4,13 +4,16 @@
 // does) and the trajectories — lives in HBM behind the C ABI (vpp_video_extruder_*, include/vpp_amd.h).  `ctx.keypoints` and
 // `ctx.trajectories` are host VIEWS of that state with the reference's types: they are filled from HBM the first time they are
 // looked at after an update, so a loop that only tracks never moves a keypoint across PCIe, and they are uploaded again before
-// the next update if the caller edited them (any non-const access counts as an edit).
+// the next update only if the caller really changed them: a non-const access (which includes the implicit conversion to T& of
+// `draw::draw_trajectories(display, ctx.trajectories, 200)`, examples/video_extruder.cc:57) marks them as possibly edited, and the next
+// update compares the host copies with what was downloaded — equal copies leave the device state untouched (rings, heads and all).
 //
 // One documented difference: in the view, `keypoints.index2d()` / `has(p)` index every ALIVE keypoint at its position.  The
 // reference's index image is rebuilt by side effect (prepare_matching clears it, move / add / compact set cells), so between two
 // compactions it misses alive keypoints that the flow did not match in the last update (keypoint_container.hpp:57-63,136-150).
 #pragma once
 #include <chrono>
+#include <cstring>
 #include <memory>
 #include <vector>
 #include <vpp/algorithms/fast_detector/fast.hh>
@@ -40,8 +43,19 @@ struct state {
   container_type keypoints;
   trajectories_type trajectories;
   bool host_stale = false;    // the device ran an update the host copies have not seen
-  bool host_edited = false;   // the caller may have changed the host copies since the last upload
+  bool host_edited = false;   // the caller may have changed the host copies since the last upload (a non-const access was handed out)
   int frame_id = -1;
+  // the state in the flat form the C ABI moves (positions, velocities, ages, trajectory lengths / start frames / alive flags, ring points newest
+  // first from slot 0); `seen` = what the last download produced, compared against the host copies before an upload
+  struct flat {
+    std::vector<vint2> pos, vel; std::vector<int> age, len, start; std::vector<unsigned char> alive; std::vector<float> ring;
+    bool operator==(const flat& o) const {
+      auto same2 = [](const std::vector<vint2>& a, const std::vector<vint2>& b) { return a.size() == b.size() && (a.empty() || !std::memcmp(a.data(), b.data(), a.size() * sizeof(vint2))); };
+      return same2(pos, o.pos) && same2(vel, o.vel) && age == o.age && len == o.len && start == o.start && alive == o.alive && ring == o.ring;
+    }
+  };
+  flat seen;
+  bool seen_valid = false;
   explicit state(box2d d) : domain(d), keypoints(d) {}
   ~state() { if (h) vpp_video_extruder_destroy(h); }
   state(const state&) = delete;
@@ -77,23 +91,39 @@ struct state {
       if (!alive[i]) t.die();
       trajectories[i].swap(t);
     }
+    seen = pack();   // what an unedited host copy packs to
+    seen_valid = true;
+  }
+  // the host copies in the flat form of the C ABI
+  flat pack() const {
+    flat f;
+    const int n = keypoints.size();
+    f.pos.resize(n); f.vel.resize(n); f.age.resize(n); f.len.resize(n); f.start.resize(n); f.alive.resize(n); f.ring.assign(size_t(n) * slots * 2, 0.f);
+    for (int i = 0; i < n; i++) {
+      f.pos[i] = keypoints[i].position; f.vel[i] = keypoints[i].velocity; f.age[i] = keypoints[i].age;
+      const keypoint_trajectory& t = trajectories[i];
+      f.len[i] = std::min(t.size(), slots - 1); f.start[i] = t.start_frame(); f.alive[i] = t.alive();
+      for (int k = 0; k < f.len[i]; k++) { f.ring[(size_t(i) * slots + k) * 2] = t[k][0]; f.ring[(size_t(i) * slots + k) * 2 + 1] = t[k][1]; }
+    }
+    return f;
+  }
+  // a non-const access was handed out since the download: did anything actually change?  (an unchanged copy needs no upload — the device state,
+  // ring heads included, stays as it is)
+  bool host_differs() {
+    if (!seen_valid || (int)trajectories.size() != keypoints.size()) return true;
+    return !(pack() == seen);
   }
   // host copies -> HBM (the caller edited them)
   void upload() {
     stopwatch sw(timing().upload);
     const int n = keypoints.size();
     trajectories.resize(n, keypoint_trajectory(frame_id));
-    std::vector<vint2> pos(n), vel(n); std::vector<int> age(n), len(n), start(n), head(n, 0); std::vector<unsigned char> alive(n);
-    std::vector<float> ring(size_t(n) * slots * 2, 0.f);
-    for (int i = 0; i < n; i++) {
-      pos[i] = keypoints[i].position; vel[i] = keypoints[i].velocity; age[i] = keypoints[i].age;
-      const keypoint_trajectory& t = trajectories[i];
-      len[i] = std::min(t.size(), slots - 1); start[i] = t.start_frame(); alive[i] = t.alive();
-      for (int k = 0; k < len[i]; k++) { ring[(size_t(i) * slots + k) * 2] = t[k][0]; ring[(size_t(i) * slots + k) * 2 + 1] = t[k][1]; }
-    }
-    device::check(vpp_video_extruder_upload(h, n, frame_id, (const int32_t*)pos.data(), (const int32_t*)vel.data(), age.data(), len.data(), start.data(), alive.data(), head.data(),
-                                            ring.data(), device::stream()), "vpp_video_extruder_upload");
+    const flat f = pack();
+    const std::vector<int> head(n, 0);
+    device::check(vpp_video_extruder_upload(h, n, frame_id, (const int32_t*)f.pos.data(), (const int32_t*)f.vel.data(), f.age.data(), f.len.data(), f.start.data(), f.alive.data(), head.data(),
+                                            f.ring.data(), device::stream()), "vpp_video_extruder_upload");
     host_edited = false;
+    seen_valid = false;
   }
 };
 
@@ -140,6 +170,10 @@ void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>
   p.propagation = opts.get(_propagation, 2);
   ve_internals::state& s = ctx.internal_state();
   s.ensure_device(p.max_trajectory_length);
+  if (s.host_edited && s.frame_id == ctx.frame_id) {   // a non-const view was handed out: upload only if the copies really changed
+    s.materialise();
+    if (!s.host_differs()) s.host_edited = false;
+  }
   if (s.host_edited || s.frame_id != ctx.frame_id) {  // the caller edited the views (or ctx.frame_id): the device continues from the host's copy
     s.materialise();
     s.frame_id = ctx.frame_id;
