@@ -33,6 +33,8 @@ struct vpp_video_extruder {
   int32_t* host_count = nullptr;  // pinned: alive count of the compaction
 };
 
+namespace vpp_amd { int keypoint_mask_squares(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, hipStream_t st); }
+
 namespace {
 
 __global__ __launch_bounds__(256) void ve_apply_kernel(int n, int32_t* __restrict__ pos, int32_t* __restrict__ vel, int32_t* __restrict__ age,
@@ -267,7 +269,9 @@ int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1
       ve->mask_spacing = s;
     }
     vpp_image_desc md{ve->mask + (size_t)s * ve->mask_pitch + s, ve->nrows, ve->ncols, ve->mask_pitch, s, VPP_U8, 1};
-    rc = vpp_keypoint_mask(&md, ve->pos[c], n, s, stream);
+    // fill_with_border(mask, 1) (:101): the mask block is the tracker's own, rows and padding: one memset instead of a pass over bordered rows
+    VPP_HIP_TRY(hipMemsetAsync(ve->mask, 1, ve->mask_bytes, st));
+    rc = keypoint_mask_squares(&md, ve->pos[c], n, s, st);
     if (rc != VPP_OK) return rc;
     // the alive count travels to the host behind the detection's own synchronisation
     const int nblocks = (n + kScanBlock - 1) / kScanBlock;
