@@ -299,6 +299,35 @@ def main():
         us = sorted(ts[1:])[1] * 1e3 / (nl * fpl)
         sweep[str(fpl)] = {"us_per_frame": round(us, 3), "frac": round(6.0 * npx / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
     per_frame["frames_per_launch_sweep"] = sweep
+    # independent frames launched one per call on SEVERAL streams (a fork / join launch graph): the ramp of one launch overlaps the drain of another
+    on_streams = {}
+    for ns in (2, 4):
+        try:
+            extra = [torch.cuda.Stream() for _ in range(ns - 1)]
+            streams = [side] + extra
+            sp = ctypes.c_void_p(side.cuda_stream)
+            nl = 256
+            capi.check(lib.vpp_graph_begin(sp))
+            ev = torch.cuda.Event(); ev.record(side)
+            for x in extra:
+                x.wait_event(ev)
+            for i in range(nl):
+                launch_box_single(i, ctypes.c_void_p(streams[i % ns].cuda_stream))
+            for x in extra:
+                e = torch.cuda.Event(); e.record(x); side.wait_event(e)
+            gh = ctypes.c_void_p()
+            if lib.vpp_graph_end(sp, 1, ctypes.byref(gh)) != capi.OK:
+                continue
+            ts = []
+            for _ in range(4):
+                capi.check(lib.vpp_graph_launch(gh, sp)); torch.cuda.synchronize()
+                ms = ctypes.c_float(0); capi.check(lib.vpp_graph_elapsed_ms(gh, ctypes.byref(ms))); ts.append(ms.value)
+            lib.vpp_graph_destroy(gh)
+            us = sorted(ts[1:])[1] * 1e3 / nl
+            on_streams[str(ns)] = {"us_per_frame": round(us, 3), "frac": round(6.0 * npx / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        except Exception as e:  # noqa: BLE001
+            on_streams[str(ns)] = {"error": f"{type(e).__name__}: {e}"}
+    per_frame["one_launch_per_frame_on_n_streams"] = on_streams
 
     # ---------------- 4K int32 pixel_wise add ----------------
     nadd = 4  # triples per step (4 x 99.5 MB)
