@@ -308,9 +308,9 @@ def main():
             sp = ctypes.c_void_p(side.cuda_stream)
             nl = 256
             capi.check(lib.vpp_graph_begin(sp))
-            ev = torch.cuda.Event(); ev.record(side)
+            fork = torch.cuda.Event(); fork.record(side)
             for x in extra:
-                x.wait_event(ev)
+                x.wait_event(fork)
             for i in range(nl):
                 launch_box_single(i, ctypes.c_void_p(streams[i % ns].cuda_stream))
             for x in extra:
