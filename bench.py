@@ -4,8 +4,8 @@
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
-the 5x5 box_nbh2d filter of a batch of 32 distinct 3840x2160 vuchar3 frames (BASELINE.json configs[1]) in ONE launch
-(vpp_box_filter_batch), rotating over 64 frame sets = 1.6 GB of sources, so that the 256 MiB Infinity Cache cannot serve the reads.  The per-frame call form is timed beside it.
+the 5x5 box_nbh2d filter of a batch of 64 distinct 3840x2160 vuchar3 frames (BASELINE.json configs[1]) in ONE launch
+(vpp_box_filter_batch), rotating over 128 frame sets = 3.2 GB of sources, so that the 256 MiB Infinity Cache cannot serve the reads.  The per-frame call form is timed beside it.
 value = Gpixels/s over all ranks (box / add / FAST "shard" as independent replicas: "replicas only").
 Extra objects on the same JSON line: roofline (dominant kernel vs HBM), cpu_baseline (the oracle timed on the host
 cores, bounded sample), add4k (4K int32 pixel_wise add) and — when built — pyrlk (tracks/s, keypoint-sharded + all-gather).
@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--regions", type=int, default=5, help="timed regions of exactly --steps launches each; the median one (by wall clock) is reported, all are listed")
     ap.add_argument("--preheat", type=float, default=0.3, help="seconds of untimed, reported replays before each headline timed region (clock ramp)")
     ap.add_argument("--workload", default="box5x5", choices=["box5x5"])
-    ap.add_argument("--sets", type=int, default=64, help="distinct 4K frame sets the steps rotate over (32 per step): 64 sets = 1.6 GB of sources + 1.6 GB of results")
+    ap.add_argument("--sets", type=int, default=128, help="distinct 4K frame sets the steps rotate over (64 per step): 128 sets = 3.2 GB of sources + 3.2 GB of results")
     args = ap.parse_args()
 
     import numpy as np
@@ -220,8 +220,8 @@ def main():
     NR, NC = 2160, 3840
     npx = NR * NC
     src_h = rand_image(NR, NC, vi.U8, 3, border=2, seed=3, align=16)
-    FPS = 32                              # frames per step: one step = a batch of 32 frames filtered by ONE launch (vpp_box_filter_batch; kBoxBatchMax)
-    nsets = max(FPS, args.sets // FPS * FPS)  # one step alone reads 32 x 25.0 MB = 800 MB and writes as much: no part of it survives in the 256 MiB Infinity Cache until the next step
+    FPS = 64                              # frames per step: one step = a batch of 64 frames filtered by ONE launch (vpp_box_filter_batch; kBoxBatchMax)
+    nsets = max(FPS, args.sets // FPS * FPS)  # one step alone reads 64 x 25.0 MB = 1.6 GB and writes as much: no part of it survives in the 256 MiB Infinity Cache until the next step
     srcs = [DeviceImage.from_host(src_h, dev) for _ in range(nsets)]
     dsts = [DeviceImage(NR, NC, vi.U8, 3, 0, 16, dev) for _ in range(nsets)]
     for s in srcs:
@@ -277,7 +277,7 @@ def main():
                  "traffic": pmc_traffic("box_u8_wide_kernel<3, 5, 5, 2")[0]}
     # frames per launch against the roofline fraction (a launch pays ~5 us of ramp and drain whatever its size): event-timed graphs of >= 64 frames
     sweep = {}
-    for fpl in (1, 2, 4, 8, 16, 32):
+    for fpl in (1, 2, 4, 8, 16, 32, 64):
         if fpl > nsets:
             continue
         groups = nsets // fpl
@@ -330,8 +330,8 @@ def main():
     per_frame["one_launch_per_frame_on_n_streams"] = on_streams
 
     # ---------------- 4K int32 pixel_wise add ----------------
-    nadd = 4  # triples per step (4 x 99.5 MB)
-    nadd_sets = 12  # 12 x 66 MB of operands = 796 MB
+    nadd = 16  # triples per step (16 x 99.5 MB = 1.6 GB per launch, like the box step; kPwBatchMax)
+    nadd_sets = 32  # 32 x 66 MB of operands = 2.1 GB
     A = [DeviceImage(NR, NC, vi.I32, 1, 0, 32, dev) for _ in range(nadd_sets)]
     b_h = rand_image(NR, NC, vi.I32, seed=2, lo=0, hi=2**30 - 1)
     B = [DeviceImage.from_host(b_h, dev) for _ in range(nadd_sets)]
@@ -347,7 +347,7 @@ def main():
 
     def launch_add(i, stream):
         j = i % nab
-        add_batch(0, aarr[j], barr[j], carr[j], nadd, stream)   # one step = 4 triples, one launch
+        add_batch(0, aarr[j], barr[j], carr[j], nadd, stream)   # one step = 16 triples, one launch
 
     awall, aev = timed(launch_add, args.steps, args.warmup, preheat_s=args.preheat, c_graph=True)
     add_s = aev / args.steps

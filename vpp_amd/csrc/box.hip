@@ -436,7 +436,7 @@ __device__ __forceinline__ void box_u8_wide_body(const BoxGeom& g, int x0, int r
 // frames' grids back to back, walked XCD-major as a whole, so the chip never drains between frames — consecutive single-frame launches each
 // pay their own ramp and tail (a 50 MB frame is only ~6 rounds of resident waves) and, from a host that submits few launches per
 // synchronisation, the submission latency once per frame.
-constexpr int kBoxBatchMax = 32;
+constexpr int kBoxBatchMax = 64;
 struct BoxBatch { const uint8_t* sbase[kBoxBatchMax]; uint8_t* dbase[kBoxBatchMax]; };
 template <int CH, int KR, int KC, int RW, int WX, int SAUX, int LAUX, bool HALO, int OCC, int PROBE, int NW = 4>
 __global__ __launch_bounds__(64 * NW, OCC * 4 / NW) void box_u8_wide_kernel(const BoxGeom g0, const BoxBatch frames, int nframes) {
@@ -812,6 +812,8 @@ template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_des
   // launch): 2 rows per wave 13.4 / 11.5 / 10.6 / 10.1 / 9.4 / 9.2, 3 rows 13.3 / 11.3 / 10.4 / 9.8 / 9.0 / 8.8, 6 rows at 4 waves per SIMD
   // 13.7 / 11.3 / 10.2 / 9.4 / 8.6 / 8.4 — more new bytes in flight per wave (10 row loads for 6 rows instead of 6 for 2) once there are
   // enough waves; a plain copy of the same geometry: 11.8 / 10.2 / 9.1 / 8.6 / 8.1 / 8.0.
+  // (8 rows per wave measured: 8.90 / 8.72 us per frame at 32 / 64 frames per launch against 8.93 / 8.73 for 6 — not worth an instance; 64 frames per launch, kBoxBatchMax,
+  // are worth 2.3 % over 32: 0.697 -> 0.713 of the HBM peak on the box of that run)
   if (n >= 4) launch_wide_cfg<CH, 6, 4, kAuxNT, false, 4, 0>(dst, src, st, order, mix, slots, n);
   else if (n >= 2) launch_wide_cfg<CH, 3, 4, kAuxNT, false, 8, 0>(dst, src, st, order, mix, slots, n);
   else launch_wide_cfg<CH, 2, 4, kAuxNT, false, 8, 0>(dst, src, st, order, mix, slots, n);
