@@ -11,6 +11,7 @@
 // Trajectories are fixed-capacity rings in HBM, newest position first from `head`.  The host learns the container size only on
 // re-detection frames (one count read-back, the same synchronisation FAST's count already needs); nothing else waits.
 #include "common.hpp"
+#include "tracker_device.hpp"
 #include <algorithm>
 #include <vector>
 using namespace vpp_amd;
@@ -37,24 +38,6 @@ namespace vpp_amd { int keypoint_mask_squares(const vpp_image_desc* mask, const 
 
 namespace {
 
-__global__ __launch_bounds__(256) void ve_apply_kernel(int n, int32_t* __restrict__ pos, int32_t* __restrict__ vel, int32_t* __restrict__ age,
-                                                       const int32_t* __restrict__ fpos, const uint8_t* __restrict__ fvalid, const uint8_t* __restrict__ merged,
-                                                       const int32_t* __restrict__ scores, int nr, int nc) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int a = age[i];
-  if (fvalid[i]) {  // the match callback (video_extruder.hpp:48-53)
-    const int r = fpos[2 * i], c = fpos[2 * i + 1];
-    if (r >= 0 && c >= 0 && r < nr && c < nc) {  // keypoint_container::move (keypoint_container.hpp:136-150)
-      vel[2 * i] = r - pos[2 * i]; vel[2 * i + 1] = c - pos[2 * i + 1];
-      pos[2 * i] = r; pos[2 * i + 1] = c;
-      a++;
-    } else a = 0;                                 // remove (:118-126)
-  }
-  if (merged[i] || scores[i] < 3) a = 0;          // merge (:60-84) and score cull (:87-91)
-  age[i] = a;
-}
-
 __global__ __launch_bounds__(256) void ve_traj_kernel(int n, const int32_t* __restrict__ pos, const int32_t* __restrict__ age, float* __restrict__ ring,
                                                       int32_t* __restrict__ head, int32_t* __restrict__ len, uint8_t* __restrict__ alive, int slots, int max_len) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -68,6 +51,46 @@ __global__ __launch_bounds__(256) void ve_traj_kernel(int n, const int32_t* __re
     if (l > max_len) l--;
     len[i] = l;
   } else alive[i] = 0;  // die() (:132)
+}
+
+// The rest of an update after the flow and the merge lists, per keypoint and in ONE launch (round 3): the merge's verdict (video_extruder.hpp:60-84),
+// fast9_score at the keypoint's new position (:87-91), the match callback + merge + score cull applied to the container (:48-53), and — on the
+// frames without re-detection, where nothing moves entries afterwards — the trajectory update (:122-133).  They were four launches (+ a fifth for the
+// trajectories) of ~5 us each for a few instructions per keypoint.
+template <bool TRAJ>
+__global__ __launch_bounds__(256) void ve_finish_kernel(int n, int32_t* __restrict__ pos, int32_t* __restrict__ vel, int32_t* __restrict__ age, const int32_t* __restrict__ fpos,
+                                                        const uint8_t* __restrict__ fvalid, MergeLists lists, DImg frame2, int th, float* __restrict__ ring,
+                                                        int32_t* __restrict__ head, int32_t* __restrict__ len, uint8_t* __restrict__ alive, int slots, int max_len) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int nr = frame2.nr, nc = frame2.nc;
+  const bool merged = merge_removes(lists, i);
+  const int p0 = pos[2 * i], p1 = pos[2 * i + 1];
+  const int r = fpos[2 * i], c = fpos[2 * i + 1];
+  const bool inside = r >= 0 && c >= 0 && r < nr && c < nc;
+  const int score = inside ? fast9_score_at(frame2, r, c, th) : fast9_score_at(frame2, p0, p1, th);   // an out-of-frame match removes the keypoint where it was (:50-53)
+  int a = age[i], q0 = p0, q1 = p1;
+  if (fvalid[i]) {  // the match callback (video_extruder.hpp:48-53)
+    if (inside) {   // keypoint_container::move (keypoint_container.hpp:136-150)
+      vel[2 * i] = r - p0; vel[2 * i + 1] = c - p1;
+      pos[2 * i] = r; pos[2 * i + 1] = c;
+      q0 = r; q1 = c;
+      a++;
+    } else a = 0;   // remove (:118-126)
+  }
+  if (merged || score < 3) a = 0;   // merge (:60-84) and score cull (:87-91)
+  age[i] = a;
+  if (TRAJ) {
+    if (a > 0) {  // move_to + pop_oldest_position (video_extruder.hpp:125-130)
+      const int h = (head[i] + slots - 1) % slots;
+      float* p = ring + ((size_t)i * slots + h) * 2;
+      p[0] = (float)q0; p[1] = (float)q1;
+      head[i] = h;
+      int l = len[i] + 1;
+      if (l > max_len) l--;
+      len[i] = l;
+    } else alive[i] = 0;  // die() (:132)
+  }
 }
 
 // ---- compaction: alive entries keep their order (keypoint_container.hpp:22-55) -----------------------------------------
@@ -248,17 +271,22 @@ int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1
   hipStream_t st = as_stream(stream);
   ve->frame_id++;
   const int c = ve->cur, n = ve->n;
+  const bool detect = ve->frame_id % p->detector_period == 0;   // re-detection frame: the compaction moves entries, the trajectories are updated after it
   int rc;
   if (n > 0) {
     rc = vpp_semi_dense_optical_flow(frame1, frame2, ve->pos[c], n, p->winsize, p->nscales, 0, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, stream);
     if (rc != VPP_OK) return rc;
-    rc = vpp_keypoint_merge(ve->fpos, ve->pos[c], ve->fvalid, ve->age[c], n, ve->nrows, ve->ncols, p->keypoint_spacing, ve->merged, stream);
+    VPP_REQUIRE(frame2->dtype == VPP_U8 && frame2->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_video_extruder_step: u8 x1 frames only");
+    VPP_REQUIRE(frame2->border >= 3, VPP_ERR_BORDER_TOO_SMALL, "Image need a border of 3px at least for the FAST detector");
+    MergeLists lists;
+    rc = keypoint_merge_link(ve->fpos, ve->pos[c], ve->fvalid, ve->age[c], n, ve->nrows, ve->ncols, p->keypoint_spacing, &lists, st);
     if (rc != VPP_OK) return rc;
-    rc = vpp_fast9_scores_moved(frame2, p->detector_th, ve->fpos, ve->pos[c], n, ve->scores, stream);
-    if (rc != VPP_OK) return rc;
-    ve_apply_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, ve->merged, ve->scores, ve->nrows, ve->ncols);
+    if (detect) ve_finish_kernel<false><<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, lists, dimg(frame2), p->detector_th, ve->tring[c],
+                                                                           ve->thead[c], ve->tlen[c], ve->talive[c], ve->ring, p->max_trajectory_length);
+    else ve_finish_kernel<true><<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, lists, dimg(frame2), p->detector_th, ve->tring[c],
+                                                                  ve->thead[c], ve->tlen[c], ve->talive[c], ve->ring, p->max_trajectory_length);
   }
-  if (ve->frame_id % p->detector_period == 0) {  // re-detection away from every container entry (:94-119)
+  if (detect) {  // re-detection away from every container entry (:94-119)
     const int s = p->keypoint_spacing;
     if (ve->mask_spacing != s) {
       dfree(ve->mask);
@@ -302,7 +330,7 @@ int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1
     ve->cur = d;
     ve->n = m + count;
   }
-  if (ve->n > 0) {
+  if (ve->n > 0 && (detect || n == 0)) {   // (otherwise done by ve_finish_kernel)
     const int k = ve->cur;
     ve_traj_kernel<<<(ve->n + 255) / 256, 256, 0, st>>>(ve->n, ve->pos[k], ve->age[k], ve->tring[k], ve->thead[k], ve->tlen[k], ve->talive[k], ve->ring, p->max_trajectory_length);
   }

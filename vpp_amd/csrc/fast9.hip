@@ -25,6 +25,7 @@
 //                            5 + 5 + 12 us, LOCAL 18 + 5 + 6 us, BLOCKWISE 13 + 5 + 6 us after the 30 us detect kernel.
 // VALU-bound (the ring test is ~100 lane-ops per pixel against 1 B/px of HBM traffic); see DESIGN.md.
 #include "common.hpp"
+#include "tracker_device.hpp"
 #include <mutex>
 using namespace vpp_amd;
 
@@ -319,18 +320,7 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
   }
 }
 
-__device__ __forceinline__ int fast9_score_px(const DImg& A, int r, int c, int th) {  // fast.hpp:38-77
-  const int v = A.row<uint8_t>(r)[c];
-  int sum_inf = 0, sum_sup = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int a = A.row<uint8_t>(r + ring_dr<false>(i))[c + ring_dc(i)];
-    const int diff = v - a;
-    if (diff < -th) sum_inf -= diff;
-    else if (diff > th) sum_sup += diff;
-  }
-  return max(sum_sup, sum_inf);
-}
+__device__ __forceinline__ int fast9_score_px(const DImg& A, int r, int c, int th) { return fast9_score_at(A, r, c, th); }  // fast.hpp:38-77 (tracker_device.hpp)
 
 __global__ __launch_bounds__(256) void fast9_scores_list_kernel(DImg A, int th, const int32_t* __restrict__ rc, int n, int32_t* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;

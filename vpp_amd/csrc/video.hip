@@ -9,6 +9,7 @@
 //  * keypoint mask of video_extruder's re-detection (video_extruder/video_extruder.hpp:95-110): mask = 1 over the domain with
 //    border, then the [r - s, r + s) x [c - s, c + s) square of every keypoint is zeroed.
 #include "common.hpp"
+#include "tracker_device.hpp"
 #include <cstring>
 using namespace vpp_amd;
 
@@ -211,29 +212,17 @@ __global__ __launch_bounds__(256) void merge_link_kernel(const int32_t* __restri
   age_now[i] = age; cell_of[i] = cell;
   next[i] = atomicExch(&head[cell], i);
 }
-__global__ __launch_bounds__(256) void merge_fate_kernel(int n, const int32_t* __restrict__ head, const int32_t* __restrict__ next, const int32_t* __restrict__ age_now,
-                                                         const int32_t* __restrict__ cell_of, uint8_t* __restrict__ removed) {
+__global__ __launch_bounds__(256) void merge_fate_kernel(int n, MergeLists m, uint8_t* __restrict__ removed) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int a = age_now[i];
-  int E = -1, L = -1;  // ages are >= 0
-  bool earlier = false;
-  for (int j = head[cell_of[i]]; j >= 0; j = next[j]) {
-    if (j < i) { earlier = true; E = max(E, age_now[j]); }
-    else if (j > i) L = max(L, age_now[j]);
-  }
-  removed[i] = (earlier && a <= E) ? (a < E) : (L > a);
+  if (i < n) removed[i] = merge_removes(m, i) ? 1 : 0;
 }
 
-extern "C" int vpp_keypoint_merge(const int32_t* rc_moved, const int32_t* rc_prev, const uint8_t* matched, const int32_t* age_prev, int n,
-                                  int nrows, int ncols, int spacing, uint8_t* removed, void* stream) {
-  VPP_REQUIRE(n >= 0 && nrows > 0 && ncols > 0 && spacing > 0 && (n == 0 || (rc_moved && rc_prev && matched && age_prev && removed)), VPP_ERR_INVALID_ARG,
-              "vpp_keypoint_merge: invalid argument");
-  if (n == 0) return VPP_OK;
+namespace vpp_amd {
+int keypoint_merge_link(const int32_t* rc_moved, const int32_t* rc_prev, const uint8_t* matched, const int32_t* age_prev, int n, int nrows, int ncols, int spacing,
+                        MergeLists* lists, hipStream_t st) {
   const int gr = nrows / spacing + 1, gc = ncols / spacing + 1;  // the reference's idx image is (nrows/s) x (ncols/s) with border 1 (:63-64)
   const size_t cells = (size_t)gr * gc;
   static thread_local Scratch scratch;  // per host thread, like the FAST / flow scratch
-  hipStream_t st = as_stream(stream);
   size_t want = 1 << 20;  // grown in powers of two: the keypoint count creeps up at every re-detection
   while (want < (cells + 3 * (size_t)n) * sizeof(int32_t)) want <<= 1;
   const int rc = scratch.ensure(want, st);
@@ -241,7 +230,22 @@ extern "C" int vpp_keypoint_merge(const int32_t* rc_moved, const int32_t* rc_pre
   int32_t *head = (int32_t*)scratch.p, *next = head + cells, *age_now = next + n, *cell_of = age_now + n;
   VPP_HIP_TRY(hipMemsetAsync(head, 0xFF, cells * sizeof(int32_t), st));
   merge_link_kernel<<<(n + 255) / 256, 256, 0, st>>>(rc_moved, rc_prev, matched, age_prev, n, nrows, ncols, spacing, gr, gc, head, next, age_now, cell_of);
-  merge_fate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, head, next, age_now, cell_of, removed);
+  VPP_LAUNCH_CHECK();
+  *lists = MergeLists{head, next, age_now, cell_of};
+  return VPP_OK;
+}
+}  // namespace vpp_amd
+
+extern "C" int vpp_keypoint_merge(const int32_t* rc_moved, const int32_t* rc_prev, const uint8_t* matched, const int32_t* age_prev, int n,
+                                  int nrows, int ncols, int spacing, uint8_t* removed, void* stream) {
+  VPP_REQUIRE(n >= 0 && nrows > 0 && ncols > 0 && spacing > 0 && (n == 0 || (rc_moved && rc_prev && matched && age_prev && removed)), VPP_ERR_INVALID_ARG,
+              "vpp_keypoint_merge: invalid argument");
+  if (n == 0) return VPP_OK;
+  hipStream_t st = as_stream(stream);
+  MergeLists m;
+  const int rc = keypoint_merge_link(rc_moved, rc_prev, matched, age_prev, n, nrows, ncols, spacing, &m, st);
+  if (rc != VPP_OK) return rc;
+  merge_fate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, m, removed);
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }
