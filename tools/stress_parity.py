@@ -1,5 +1,5 @@
 """One-off randomized parity sweep (GPU vs the CPU oracle) over shapes / parameters the fixed tests do not enumerate:
-FAST-9 (all modes, masks, thresholds), semi-dense flow (window sizes, scales, sweeps, patch sizes), box filters, rgb->gray.
+FAST-9 (all modes, masks, thresholds), semi-dense flow (window sizes, scales, sweeps, patch sizes), box filters, rgb->gray, u8 pyramids (gray and fused rgb ingest).
 usage: python tools/stress_parity.py [n_cases] [seed]      (needs a GPU; exits non-zero on the first mismatch)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -99,5 +99,21 @@ for case in range(N):
     capi.check(lib.vpp_keypoint_merge(V(dm.data_ptr()), V(dp.data_ptr()), V(dmt.data_ptr()), V(da.data_ptr()), n, mr, mc, sp, V(out.data_ptr()), capi.stream_ptr()))
     ok = np.array_equal(out.cpu().numpy(), want)
     print(f"merge n={n} {mr}x{mc} spacing={sp}: removed={int(want.sum())} {'ok' if ok else 'MISMATCH'}"); bad += not ok
+    # u8 pyramids of 3 levels (the packed kernel away from the edges, the tile kernel on them) from a gray frame and from an rgb frame (fused ingest)
+    import pyr as tpyr
+    nr, nc, pb = int(rng.integers(100, 700)), int(rng.integers(100, 1100)), int(rng.integers(2, 21))   # the low-pass reads 2 px beyond a level
+    g = rand_image(nr, nc, vi.U8, 1, border=0, seed=int(rng.integers(1 << 30)), align=int(rng.choice([1, 16, 32])))
+    want = tpyr.host_pyramid(orc, g, 3, pb)
+    got = tpyr.device_pyramid(lib, DeviceImage.from_host(g), 3, pb); capi.check(lib.vpp_sync(capi.stream_ptr()))
+    ok = all(np.array_equal(d.download().raw, h.raw) for d, h in zip(got, want))
+    print(f"pyramid {nr}x{nc} border={pb}: {'ok' if ok else 'MISMATCH'}"); bad += not ok
+    chn = int(rng.choice([3, 4]))
+    rgbp = rand_image(nr, nc, vi.U8, chn, border=0, seed=int(rng.integers(1 << 30)), align=int(rng.choice([1, 16, 32])))
+    gray = HostImage(nr, nc, vi.U8, 1, pb, 32); orc.orc_rgb_to_graylevel(P(gray.desc), P(rgbp.desc), 1)
+    want = tpyr.host_pyramid(orc, gray, 3, pb)
+    lv = [DeviceImage(a, b, vi.U8, 1, pb) for a, b in tpyr.level_dims(nr, nc, 3)]
+    capi.check(lib.vpp_rgb_pyramid_build(vi.desc_array(lv), 3, P(DeviceImage.from_host(rgbp).desc), capi.stream_ptr())); capi.check(lib.vpp_sync(capi.stream_ptr()))
+    ok = all(np.array_equal(d.download().raw, h.raw) for d, h in zip(lv, want))
+    print(f"rgb pyramid x{chn} {nr}x{nc} border={pb}: {'ok' if ok else 'MISMATCH'}"); bad += not ok
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
