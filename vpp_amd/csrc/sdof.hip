@@ -518,6 +518,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
   if (tid == 0) s_val = __hip_atomic_fetch_add(&ctl->reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (s_val & kRegClosed) return;   // the others have already finished round 0: every job of it has been handed out
+  const unsigned ticket = s_val;   // this workgroup's registration number
   __syncthreads();
   unsigned N = 0;   // registered workgroups (thread 0, known at the first barrier)
   for (int k = 0;; k++) {
@@ -644,6 +645,13 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
     n = (unsigned)s_gen;
     __syncthreads();
     if (n == 0) break;
+    // A round that fits one batch (the tail of a sweep: a handful of cells whose neighbours changed) is left to ONE workgroup, the first that
+    // registered; what the others wrote was released and acquired at the barrier above.  Alone, its barriers are workgroup-scoped: no L2 write-back,
+    // no L2 invalidation in front of the next round's loads (which made a round of 5 jobs cost as much as one of 1 500).
+    if (n <= (unsigned)kJobsPerGroup && N != 1) {
+      if (ticket != 0) return;
+      N = 1;
+    }
   }
 }
 
