@@ -443,9 +443,8 @@ __global__ __launch_bounds__(64 * NW, OCC * 4 / NW) void box_u8_wide_kernel(cons
   static_assert(CH >= 1 && CH <= 4 && NW % WX == 0, "window holds 2*CH <= 8 halo bytes; NW waves per workgroup, WX of them side by side");
   constexpr int WY = NW / WX;
   const unsigned nb = (unsigned)g0.nbx * (unsigned)g0.nby;
-  unsigned f, lb;
-  if (g0.order & 4) { f = blockIdx.x / nb; lb = xcd_remap(blockIdx.x - f * nb, nb); }   // batches: every frame split over the 8 XCDs, frame after frame (see launch_wide)
-  else { const unsigned L = (g0.order & 2) ? blockIdx.x : xcd_remap(blockIdx.x, nb * (unsigned)nframes); f = L / nb; lb = L - f * nb; }
+  const unsigned L = (g0.order & 2) ? blockIdx.x : xcd_remap(blockIdx.x, nb * (unsigned)nframes);
+  const unsigned f = L / nb, lb = L - f * nb;
   BoxGeom g = g0;
   g.sbase = frames.sbase[f]; g.dbase = frames.dbase[f];
   int bx, by;
@@ -748,9 +747,9 @@ BoxGeom wide_geometry(const vpp_image_desc* dst, const vpp_image_desc* src, int 
 template <int CH> int launch_wide(const vpp_image_desc* dst, const vpp_image_desc* src, hipStream_t st, int n = 1) {
   // measured on MI355X (tools/boxlab, 4K vuchar3): 992-B strips, 2 rows per wave, workgroup = 4 strips side by side, block grid
   // walked row-major per XCD, non-temporal stores: 8.6 us; strip-major order 8.9, one strip per workgroup 9.4, no XCD remap 15.5
-  // Batches walk the frames one after the other and split EVERY frame over the 8 XCDs (order bit 2): with one remap over the whole batch an XCD owned whole
-  // frames, the XCDs drifted apart and drained one by one — 8 frames per launch 9.98 -> 9.35 us per frame, 64 frames 9.09 -> 8.94 (same box, same call)
-  const int rows = tuning("box.rows", 2), wx = tuning("box.wx", 4), sp = tuning("box.sp", kAuxNT), order = tuning("box.order", n > 1 ? 4 : 0);
+  // (A batch is one XCD remap over all its frames: an XCD owns whole frames.  Splitting EVERY frame over the 8 XCDs instead, frame after frame, measured faster on one
+  // box — 8 frames per launch 9.98 -> 9.35 us per frame — and 1-1.5 % slower on four others: not kept.)
+  const int rows = tuning("box.rows", 2), wx = tuning("box.wx", 4), sp = tuning("box.sp", kAuxNT), order = tuning("box.order", 0);
   const int halo = tuning("box.halo", 0), mix = tuning("box.mix", 0), slots = tuning("box.slots", 8192);
 #ifdef VPP_BOX_LAB
   const int probe = tuning("box.probe", 0), occ = tuning("box.occ", 8);
