@@ -215,6 +215,12 @@ int vpp_lucas_kanade(const vpp_image_desc* prev, const vpp_image_desc* grad, con
 int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n,
                                 int winsize, int nscales, int min_scale, int propagation, int patchsize,
                                 int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, void* stream);
+/* The same call over pyramids the caller already holds (a video loop builds each frame's pyramid once and uses it twice): pyr1 / pyr2 = nscales
+ * u8 x1 levels each, level l of (1 + n / 2)-halved size (pyramid.hh:154), with a mirror-filled border of winsize / 2 pixels at least — what
+ * vpp_pyramid_build / vpp_rgb_pyramid_build leave.  Results identical to vpp_semi_dense_optical_flow on the levels 0. */
+int vpp_semi_dense_optical_flow_pyramids(const vpp_image_desc* pyr1, const vpp_image_desc* pyr2, int nscales, const int32_t* kps, int n,
+                                         int winsize, int min_scale, int propagation, int patchsize,
+                                         int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, void* stream);
 /* The same call with its per-keypoint phases (claim, descent) sharded by row strips of the flow maps — the decomposition of SURVEY 8e
  * bullet 2: every strip has private maps and its own stream, the strips' rows are gathered into the owner's maps, the owner runs the
  * Jacobi pre-passes and the ordered sweeps, and the swept maps are broadcast back as the next scale's prediction.  One process, one GPU:
@@ -267,6 +273,13 @@ int vpp_video_extruder_create(vpp_video_extruder** ve, int nrows, int ncols, int
 int vpp_video_extruder_destroy(vpp_video_extruder* ve);
 int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2,
                             const vpp_video_extruder_params* params, void* stream);
+/* The video loop's own shape (examples/video_extruder.cc:44-58: `prev` is kept, one video_extruder_update(ctx, prev, frame) per frame): one frame in,
+ * one update out.  frame: u8 x1 (gray), or u8 x3 / x4 — then the rgb_to_graylevel of the loop (:48) happens inside, fused with the pyramid's
+ * level 0.  The tracker keeps the previous frame's pyramid, so a frame's pyramid is built once (vpp_video_extruder_step builds both per
+ * update); the frame's own border is not read (the levels are mirror-filled, as fill_border_mirror on the gray frame does).  The first frame
+ * after create — or after a change of nscales / winsize — only becomes `prev`: no update, frame_id unchanged.  Results are those of
+ * vpp_video_extruder_step on the mirror-bordered gray frames.  Do not interleave with vpp_video_extruder_step on one tracker. */
+int vpp_video_extruder_push_frame(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* params, void* stream);
 int vpp_video_extruder_count(const vpp_video_extruder* ve, int* n, int* frame_id);   /* container size (dead entries included), frame_id */
 /* n (row, col) int32 pairs for position and velocity, n ages; any output may be NULL */
 int vpp_video_extruder_keypoints(const vpp_video_extruder* ve, int32_t* pos_rc, int32_t* vel_rc, int32_t* age, int capacity, void* stream);

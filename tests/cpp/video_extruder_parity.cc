@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -58,6 +59,27 @@ static std::vector<image2d<unsigned char>> make_frames(int nr, int nc, int T) {
   return frames;
 }
 
+static bool same_as_reference(const char* what, video_extruder_ctx& ctx, const std::vector<int32_t>& want, const std::vector<int32_t>& wlen, int wn, int wfid, int nr, int nc,
+                              int* alive_out, int* moved_out) {
+  CHECK(ctx.frame_id == wfid);
+  CHECK(ctx.keypoints.size() == wn);
+  CHECK(wn > nr * nc / 400);
+  int alive = 0, moved = 0;
+  for (int i = 0; i < wn; i++) {
+    const auto& k = ctx.keypoints[i];
+    if (!(k.position[0] == want[5 * i] && k.position[1] == want[5 * i + 1] && k.velocity[0] == want[5 * i + 2] && k.velocity[1] == want[5 * i + 3] && k.age == want[5 * i + 4])) {
+      std::fprintf(stderr, "%s: keypoint %d: got pos (%d,%d) vel (%d,%d) age %d, reference pos (%d,%d) vel (%d,%d) age %d\n", what, i, k.position[0], k.position[1], k.velocity[0], k.velocity[1], k.age,
+                   want[5 * i], want[5 * i + 1], want[5 * i + 2], want[5 * i + 3], want[5 * i + 4]);
+      return false;
+    }
+    if (ctx.trajectories[i].size() != wlen[i]) { std::fprintf(stderr, "%s: trajectory %d: length %d, reference %d\n", what, i, ctx.trajectories[i].size(), wlen[i]); return false; }
+    alive += k.age > 0;
+    moved += k.velocity[0] != 0 || k.velocity[1] != 0;
+  }
+  *alive_out = alive; *moved_out = moved;
+  return true;
+}
+
 int main(int argc, char** argv) {
   const int nr = argc > 1 ? atoi(argv[1]) : 240, nc = argc > 2 ? atoi(argv[2]) : 320, T = argc > 3 ? atoi(argv[3]) : 9;
   CHECK(vpp_init(0) == 0);
@@ -76,22 +98,41 @@ int main(int argc, char** argv) {
     video_extruder_update(ctx, frames[t - 1], frames[t], _detector_th = 10, _keypoint_spacing = 10, _detector_period = 5, _max_trajectory_length = 15,
                           _nscales = 3, _winsize = 9, _propagation = 2);
   std::printf("  drop-in:   %d container entries after frame %d, %.2f ms per update (incl. first-touch uploads)\n", ctx.keypoints.size(), ctx.frame_id, (now() - t0) * 1e3 / (T - 1));
-  CHECK(ctx.frame_id == wfid);
-  CHECK(ctx.keypoints.size() == wn);
-  CHECK(wn > nr * nc / 400);
   int alive = 0, moved = 0;
-  for (int i = 0; i < wn; i++) {
-    const auto& k = ctx.keypoints[i];
-    if (!(k.position[0] == want[5 * i] && k.position[1] == want[5 * i + 1] && k.velocity[0] == want[5 * i + 2] && k.velocity[1] == want[5 * i + 3] && k.age == want[5 * i + 4])) {
-      std::fprintf(stderr, "keypoint %d: got pos (%d,%d) vel (%d,%d) age %d, reference pos (%d,%d) vel (%d,%d) age %d\n", i, k.position[0], k.position[1], k.velocity[0], k.velocity[1], k.age,
-                   want[5 * i], want[5 * i + 1], want[5 * i + 2], want[5 * i + 3], want[5 * i + 4]);
-      return 1;
-    }
-    if (ctx.trajectories[i].size() != wlen[i]) { std::fprintf(stderr, "trajectory %d: length %d, reference %d\n", i, ctx.trajectories[i].size(), wlen[i]); return 1; }
-    alive += k.age > 0;
-    moved += k.velocity[0] != 0 || k.velocity[1] != 0;
-  }
+  if (!same_as_reference("drop-in", ctx, want, wlen, wn, wfid, nr, nc, &alive, &moved)) return 1;
   CHECK(alive > wn / 2 && moved > alive / 4);
-  std::printf("  identical: %d entries (%d alive, %d moving), positions / velocities / ages / trajectory lengths\nvideo_extruder_parity ok\n", wn, alive, moved);
+  std::printf("  identical: %d entries (%d alive, %d moving), positions / velocities / ages / trajectory lengths\n", wn, alive, moved);
+
+  // the one-frame-per-call loop (video_extruder_push_frame, the tracker keeps `prev` and its pyramid): gray frames WITHOUT a border, then colour
+  // frames whose rgb_to_graylevel is the gray sequence — both must land on the reference's state too
+  {
+    video_extruder_ctx c2 = video_extruder_init(make_box2d(nr, nc));
+    t0 = now();
+    for (int t = 0; t < T; t++) {
+      image2d<unsigned char> bare(nr, nc, _border = 0);
+      for (int r = 0; r < nr; r++) std::memcpy(&bare(r, 0), &frames[t](r, 0), nc);
+      const bool ran = video_extruder_push_frame(c2, bare, _detector_th = 10, _keypoint_spacing = 10, _detector_period = 5, _max_trajectory_length = 15, _nscales = 3, _winsize = 9, _propagation = 2);
+      CHECK(ran == (t > 0));
+    }
+    std::printf("  push_frame (gray):  %d entries, %.2f ms per frame (incl. the frame's upload)\n", c2.keypoints.size(), (now() - t0) * 1e3 / T);
+    if (!same_as_reference("push_frame(gray)", c2, want, wlen, wn, wfid, nr, nc, &alive, &moved)) return 1;
+  }
+  {
+    video_extruder_ctx c3 = video_extruder_init(make_box2d(nr, nc));
+    std::mt19937 rng(17);
+    t0 = now();
+    for (int t = 0; t < T; t++) {
+      image2d<vuchar3> rgb(nr, nc, _border = 0);
+      for (int r = 0; r < nr; r++) for (int c = 0; c < nc; c++) {   // (g + d, g, g - d + k), k in {0, 1, 2}: the integer mean is g
+        const int g = frames[t](r, c), d = std::min(std::min(g, 255 - g), int(rng() & 31)), k = g - d + 2 <= 255 ? int(rng() % 3) : 0;
+        rgb(r, c) = vuchar3(g + d, g, g - d + k);
+      }
+      const bool ran = video_extruder_push_frame(c3, rgb, _detector_th = 10, _keypoint_spacing = 10, _detector_period = 5, _max_trajectory_length = 15, _nscales = 3, _winsize = 9, _propagation = 2);
+      CHECK(ran == (t > 0));
+    }
+    std::printf("  push_frame (rgb):   %d entries\n", c3.keypoints.size());
+    if (!same_as_reference("push_frame(rgb)", c3, want, wlen, wn, wfid, nr, nc, &alive, &moved)) return 1;
+  }
+  std::printf("  push_frame: gray and colour sequences identical to the reference as well\nvideo_extruder_parity ok\n");
   return 0;
 }

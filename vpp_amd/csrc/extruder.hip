@@ -32,6 +32,11 @@ struct vpp_video_extruder {
   int mask_spacing = -1, mask_pitch = 0, det_cap = 0;
   size_t mask_bytes = 0;
   int32_t* host_count = nullptr;  // pinned: alive count of the compaction
+  // vpp_video_extruder_push_frame: the pyramids of the previous and of the incoming frame, kept here so that every frame's pyramid is built once
+  uint8_t* pyr_mem[2] = {nullptr, nullptr};
+  vpp_image_desc pyr[2][8];        // levels with the flow's layout (border 2 * winsize of memory)
+  int pyr_scales = 0, pyr_winsize = 0, pyr_fill = 0, pyr_prev = 0;
+  bool have_prev = false;
 };
 
 namespace vpp_amd { int keypoint_mask_squares(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, hipStream_t st); }
@@ -257,13 +262,15 @@ int vpp_video_extruder_create(vpp_video_extruder** out, int nrows, int ncols, in
 int vpp_video_extruder_destroy(vpp_video_extruder* ve) {
   if (!ve) return VPP_OK;
   for (int b = 0; b < 2; b++) { dfree(ve->pos[b]); dfree(ve->vel[b]); dfree(ve->age[b]); dfree(ve->tring[b]); dfree(ve->thead[b]); dfree(ve->tlen[b]); dfree(ve->tstart[b]); dfree(ve->talive[b]); }
-  dfree(ve->fpos); dfree(ve->fdist); dfree(ve->scores); dfree(ve->newidx); dfree(ve->blocksum); dfree(ve->fvalid); dfree(ve->merged); dfree(ve->det); dfree(ve->mask);
+  dfree(ve->fpos); dfree(ve->fdist); dfree(ve->scores); dfree(ve->newidx); dfree(ve->blocksum); dfree(ve->fvalid); dfree(ve->merged); dfree(ve->det); dfree(ve->mask); dfree(ve->pyr_mem[0]); dfree(ve->pyr_mem[1]);
   if (ve->host_count) vpp_free_host(ve->host_count);
   delete ve;
   return VPP_OK;
 }
 
-int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2, const vpp_video_extruder_params* p, void* stream) {
+// pyr1 / pyr2 != nullptr: the frames' pyramids are the tracker's own (vpp_video_extruder_push_frame) and the flow takes them as they are
+static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2, const vpp_video_extruder_params* p, void* stream,
+                     const vpp_image_desc* pyr1, const vpp_image_desc* pyr2) {
   VPP_REQUIRE(ve && p && valid_desc(frame1) && valid_desc(frame2), VPP_ERR_INVALID_ARG, "vpp_video_extruder_step: invalid argument");
   VPP_REQUIRE(frame1->nrows == ve->nrows && frame1->ncols == ve->ncols && same_domain(frame1, frame2), VPP_ERR_INVALID_ARG, "vpp_video_extruder_step: frames do not match the tracker's domain");
   VPP_REQUIRE(p->keypoint_spacing > 0 && p->detector_period > 0 && p->max_trajectory_length > 0 && p->max_trajectory_length < ve->ring, VPP_ERR_INVALID_ARG,
@@ -274,7 +281,8 @@ int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1
   const bool detect = ve->frame_id % p->detector_period == 0;   // re-detection frame: the compaction moves entries, the trajectories are updated after it
   int rc;
   if (n > 0) {
-    rc = vpp_semi_dense_optical_flow(frame1, frame2, ve->pos[c], n, p->winsize, p->nscales, 0, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, stream);
+    if (pyr1) rc = vpp_semi_dense_optical_flow_pyramids(pyr1, pyr2, p->nscales, ve->pos[c], n, p->winsize, 0, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, stream);
+    else rc = vpp_semi_dense_optical_flow(frame1, frame2, ve->pos[c], n, p->winsize, p->nscales, 0, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, stream);
     if (rc != VPP_OK) return rc;
     VPP_REQUIRE(frame2->dtype == VPP_U8 && frame2->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_video_extruder_step: u8 x1 frames only");
     VPP_REQUIRE(frame2->border >= 3, VPP_ERR_BORDER_TOO_SMALL, "Image need a border of 3px at least for the FAST detector");
@@ -335,6 +343,67 @@ int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1
     ve_traj_kernel<<<(ve->n + 255) / 256, 256, 0, st>>>(ve->n, ve->pos[k], ve->age[k], ve->tring[k], ve->thead[k], ve->tlen[k], ve->talive[k], ve->ring, p->max_trajectory_length);
   }
   VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2, const vpp_video_extruder_params* p, void* stream) {
+  return step_impl(ve, frame1, frame2, p, stream, nullptr, nullptr);
+}
+
+// (Re)carves the two pyramid sets for (nscales, winsize): levels of pyramid.hh:154's sizes, laid out like the flow's own (border 2 * winsize of memory, :72-73).
+static int ve_pyramids(vpp_video_extruder* ve, int nscales, int winsize) {
+  if (ve->pyr_mem[0] && ve->pyr_scales == nscales && ve->pyr_winsize == winsize) return VPP_OK;
+  const int border = std::max(2 * winsize, 3);
+  uint8_t* mem[2] = {nullptr, nullptr};
+  vpp_image_desc lv[2][8];
+  for (int pass = 0; pass < 2; pass++) {
+    size_t off = 0;
+    int nr = ve->nrows, nc = ve->ncols;
+    for (int l = 0; l < nscales; l++) {
+      int32_t pitch; size_t bytes, first;
+      vpp_image_layout(nr, nc, 1, border, 32, &pitch, &bytes, &first);
+      if (pass) for (int b = 0; b < 2; b++) lv[b][l] = vpp_image_desc{mem[b] + off + first, nr, nc, pitch, border, VPP_U8, 1};
+      off += (bytes + 255) / 256 * 256;
+      nr = 1 + nr / 2; nc = 1 + nc / 2;
+    }
+    if (!pass) {
+      int rc = dalloc(&mem[0], off);
+      if (rc == VPP_OK) rc = dalloc(&mem[1], off);
+      if (rc != VPP_OK) { dfree(mem[0]); dfree(mem[1]); return rc; }
+    }
+  }
+  dfree(ve->pyr_mem[0]); dfree(ve->pyr_mem[1]);
+  for (int b = 0; b < 2; b++) { ve->pyr_mem[b] = mem[b]; for (int l = 0; l < nscales; l++) ve->pyr[b][l] = lv[b][l]; }
+  ve->pyr_scales = nscales; ve->pyr_winsize = winsize;
+  // only the pixels a SAD (winsize / 2) or the FAST ring (3) can reach beyond a level are mirror-filled (see flow_impl, sdof.hip)
+  ve->pyr_fill = std::min(border, std::max(winsize / 2, 3));
+  ve->have_prev = false;
+  return VPP_OK;
+}
+
+// One frame in, one update out (examples/video_extruder.cc:44-58 keeps `prev` and calls video_extruder_update(ctx, prev, frame) per frame): the tracker
+// keeps the previous frame's pyramid, so each frame's pyramid is built once (the two-frame entry builds both every update), and an RGB frame goes
+// through the fused ingest + pyramid launch without a gray frame in between.  The first frame after create (or after nscales / winsize change)
+// only becomes `prev` — no update, frame_id unchanged — exactly as the example's first iteration.
+int vpp_video_extruder_push_frame(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* p, void* stream) {
+  VPP_REQUIRE(ve && p && valid_desc(frame), VPP_ERR_INVALID_ARG, "vpp_video_extruder_push_frame: invalid argument");
+  VPP_REQUIRE(frame->nrows == ve->nrows && frame->ncols == ve->ncols, VPP_ERR_INVALID_ARG, "vpp_video_extruder_push_frame: the frame does not match the tracker's domain");
+  VPP_REQUIRE(frame->dtype == VPP_U8 && (frame->channels == 1 || frame->channels == 3 || frame->channels == 4), VPP_ERR_UNSUPPORTED,
+              "vpp_video_extruder_push_frame: u8 x1 (gray), x3 or x4 (rgb / rgba) frames only");
+  VPP_REQUIRE(p->nscales >= 1 && p->nscales <= 8 && p->winsize > 0, VPP_ERR_INVALID_ARG, "vpp_video_extruder_push_frame: bad parameters");
+  int rc = ve_pyramids(ve, p->nscales, p->winsize);
+  if (rc != VPP_OK) return rc;
+  const int in = ve->have_prev ? 1 - ve->pyr_prev : ve->pyr_prev;
+  vpp_image_desc fill[8];
+  for (int l = 0; l < p->nscales; l++) { fill[l] = ve->pyr[in][l]; fill[l].border = ve->pyr_fill; }
+  rc = frame->channels == 1 ? vpp_pyramid_build(fill, p->nscales, frame, stream) : vpp_rgb_pyramid_build(fill, p->nscales, frame, stream);
+  if (rc != VPP_OK) return rc;
+  if (!ve->have_prev) { ve->have_prev = true; return VPP_OK; }
+  vpp_image_desc f1 = ve->pyr[ve->pyr_prev][0], f2 = fill[0];
+  f1.border = ve->pyr_fill;
+  rc = step_impl(ve, &f1, &f2, p, stream, ve->pyr[ve->pyr_prev], ve->pyr[in]);
+  if (rc != VPP_OK) { ve->have_prev = false; return rc; }   // the state of a failed update is the caller's to re-upload; the next frame starts over as `prev`
+  ve->pyr_prev = in;
   return VPP_OK;
 }
 

@@ -735,7 +735,8 @@ namespace {
 // deterministic and cost a few tens of microseconds, less than broadcasting their result.  Frames and pyramids are replicated.
 int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
               int nscales, int min_scale, int propagation, int patchsize, int nstrips, vpp_comm* comm, int32_t* out_pos,
-              int32_t* out_dist, uint8_t* out_valid, void* stream) {
+              int32_t* out_dist, uint8_t* out_valid, void* stream, const vpp_image_desc* pre1 = nullptr, const vpp_image_desc* pre2 = nullptr) {
+  // pre1 / pre2 != nullptr (vpp_semi_dense_optical_flow_pyramids): the caller's pyramids of the two frames are used as they are, i1 / i2 are their levels 0
   VPP_REQUIRE(valid_desc(i1) && valid_desc(i2) && same_domain(i1, i2), VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: invalid frames");
   VPP_REQUIRE(i1->dtype == VPP_U8 && i1->channels == 1 && i2->dtype == VPP_U8 && i2->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_semi_dense_optical_flow: u8 x1 frames only");
   VPP_REQUIRE(n >= 0 && (n == 0 || (kps && out_pos && out_dist && out_valid)), VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: null buffer");
@@ -761,7 +762,8 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
     int fr = i1->nrows / patchsize, fc = i1->ncols / patchsize, ir = i1->nrows, ic = i1->ncols;
     VPP_REQUIRE(fr > 0 && fc > 0, VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: image smaller than one patch");
     for (int s_ = 0; s_ < nscales; s_++) {
-      P1[s_] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize); P2[s_] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize);
+      if (!pre1) { P1[s_] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize); P2[s_] = cv.image(ir, ic, VPP_U8, 1, 2 * winsize); }
+      else P1[s_] = P2[s_] = vpp_image_desc{nullptr, ir, ic, 0, 0, VPP_U8, 1};   // the level's size, checked against the caller's below
       const int fr_mem = (fr + world - 1) / world * world;   // rows of memory: whole chunks per rank (the descriptors keep fr rows)
       for (int k = 0; k < nstrips; k++) {
         FL(k, s_) = cv.image(fr_mem, fc, VPP_I32, 2, nscales); FL(k, s_).nrows = fr;
@@ -795,13 +797,24 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   // The levels are laid out with the reference's border of 2 * winsize (:72-73), but only winsize / 2 pixels beyond a level's domain are ever read into a SAD
   // (window centres must lie inside the domain, :102-108): the mirror fill is limited to that (>= 2: the per-level low-pass of other pyramid depths reads 2) —
   // with the full 18 pixels three rings of the one-launch pyramid kernel's tiles took its slow edge path (16.4 vs 13.5 us per 4K pyramid).
-  vpp_image_desc B1[kMaxScales], B2[kMaxScales];
-  for (int s_ = 0; s_ < nscales; s_++) {
-    B1[s_] = P1[s_]; B2[s_] = P2[s_];
-    B1[s_].border = B2[s_].border = std::min(P1[s_].border, std::max(winsize / 2, 2));
+  int rc = VPP_OK;
+  if (pre1) {
+    for (int s_ = 0; s_ < nscales; s_++) {   // the levels must be the ones pyramid.hh:154 halves to, with the pixels a SAD can reach (see above) in their border
+      for (const vpp_image_desc* L : {&pre1[s_], &pre2[s_]})
+        VPP_REQUIRE(valid_desc(L) && L->dtype == VPP_U8 && L->channels == 1 && L->nrows == P1[s_].nrows && L->ncols == P1[s_].ncols && L->border >= winsize / 2,
+                    VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow_pyramids: level %d: u8 x1, %d x %d with a filled border of %d at least expected", s_,
+                    P1[s_].nrows, P1[s_].ncols, winsize / 2);
+      P1[s_] = pre1[s_]; P2[s_] = pre2[s_];
+    }
+  } else {
+    vpp_image_desc B1[kMaxScales], B2[kMaxScales];
+    for (int s_ = 0; s_ < nscales; s_++) {
+      B1[s_] = P1[s_]; B2[s_] = P2[s_];
+      B1[s_].border = B2[s_].border = std::min(P1[s_].border, std::max(winsize / 2, 2));
+    }
+    rc = vpp_pyramid_build(B1, nscales, i1, stream); if (rc) return rc;
+    rc = vpp_pyramid_build(B2, nscales, i2, stream); if (rc) return rc;
   }
-  int rc = vpp_pyramid_build(B1, nscales, i1, stream); if (rc) return rc;
-  rc = vpp_pyramid_build(B2, nscales, i2, stream); if (rc) return rc;
   auto maps = [&](int k, int s_) { return Maps{dimg(&FL(k, s_)), dimg(&MK(k, s_)), dimg(&DM(k, s_))}; };
   // single strip: the mark and owner maps of all scales are reset here in one launch (nothing writes a scale's maps before its own phase)
   const bool reset_up_front = nstrips == 1 && 2 * (nscales - min_scale) <= 16 && tuning("sdof.reset_up_front", 1);
@@ -926,6 +939,13 @@ extern "C" int vpp_semi_dense_optical_flow(const vpp_image_desc* i1, const vpp_i
                                            int nscales, int min_scale, int propagation, int patchsize, int32_t* out_pos,
                                            int32_t* out_dist, uint8_t* out_valid, void* stream) {
   return flow_impl(i1, i2, kps, n, winsize, nscales, min_scale, propagation, patchsize, 1, nullptr, out_pos, out_dist, out_valid, stream);
+}
+
+extern "C" int vpp_semi_dense_optical_flow_pyramids(const vpp_image_desc* pyr1, const vpp_image_desc* pyr2, int nscales, const int32_t* kps, int n, int winsize,
+                                                     int min_scale, int propagation, int patchsize, int32_t* out_pos, int32_t* out_dist,
+                                                     uint8_t* out_valid, void* stream) {
+  VPP_REQUIRE(pyr1 && pyr2 && nscales >= 1, VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow_pyramids: null pyramid");
+  return flow_impl(&pyr1[0], &pyr2[0], kps, n, winsize, nscales, min_scale, propagation, patchsize, 1, nullptr, out_pos, out_dist, out_valid, stream, pyr1, pyr2);
 }
 
 extern "C" int vpp_semi_dense_optical_flow_sharded(vpp_comm* comm, const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,

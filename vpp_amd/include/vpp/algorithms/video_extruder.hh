@@ -161,14 +161,15 @@ struct video_extruder_ctx {
 };
 inline video_extruder_ctx video_extruder_init(box2d domain) { video_extruder_ctx res(domain); res.frame_id = -1; return res; }
 
-template <class... OPTS>
-void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>& frame1, const image2d<unsigned char>& frame2, OPTS... options) {
+namespace ve_internals {
+// the options of video_extruder.hpp:35-41 and the host-view bookkeeping every update starts with
+template <class... OPTS> vpp_video_extruder_params begin_update(video_extruder_ctx& ctx, OPTS... options) {
   auto opts = opt::make(options...);
   vpp_video_extruder_params p;
   p.detector_th = opts.get(_detector_th, 10); p.keypoint_spacing = opts.get(_keypoint_spacing, 10); p.detector_period = opts.get(_detector_period, 5);
   p.max_trajectory_length = opts.get(_max_trajectory_length, 15); p.nscales = opts.get(_nscales, 3); p.winsize = opts.get(_winsize, 9);
   p.propagation = opts.get(_propagation, 2);
-  ve_internals::state& s = ctx.internal_state();
+  state& s = ctx.internal_state();
   s.ensure_device(p.max_trajectory_length);
   if (s.host_edited && s.frame_id == ctx.frame_id) {   // a non-const view was handed out: upload only if the copies really changed
     s.materialise();
@@ -179,12 +180,45 @@ void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>
     s.frame_id = ctx.frame_id;
     s.upload();
   }
-  ve_internals::stopwatch sw(ve_internals::timing().step);
-  const vpp_image_desc d1 = frame1.device_desc(false), d2 = frame2.device_desc(false);
-  device::check(vpp_video_extruder_step(s.h, &d1, &d2, &p, device::stream()), "vpp_video_extruder_step");
+  return p;
+}
+inline void end_update(video_extruder_ctx& ctx) {
+  state& s = ctx.internal_state();
   device::check(vpp_sync(device::stream()), "vpp_sync");   // synchronous like the reference call
   ctx.frame_id++;
   s.frame_id = ctx.frame_id;
   s.host_stale = true;
+}
+}  // namespace ve_internals
+
+template <class... OPTS>
+void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>& frame1, const image2d<unsigned char>& frame2, OPTS... options) {
+  const vpp_video_extruder_params p = ve_internals::begin_update(ctx, options...);
+  ve_internals::state& s = ctx.internal_state();
+  ve_internals::stopwatch sw(ve_internals::timing().step);
+  const vpp_image_desc d1 = frame1.device_desc(false), d2 = frame2.device_desc(false);
+  device::check(vpp_video_extruder_step(s.h, &d1, &d2, &p, device::stream()), "vpp_video_extruder_step");
+  ve_internals::end_update(ctx);
+}
+
+// Extension (no reference counterpart): the video loop of examples/video_extruder.cc:43-58 with `prev` kept by the tracker.  One call per frame —
+// gray (unsigned char) or colour (vuchar3 / vuchar4: the loop's rgb_to_graylevel happens on the device, fused with the pyramid) — replaces
+// clone(_border = 3) + fill_border_mirror + rgb_to_graylevel + video_extruder_update + copy(frame_gl, prev_frame).  The first frame only becomes
+// `prev` (returns false, like the example's `first`); later calls run one update (return true) whose results are those of video_extruder_update on
+// the mirror-bordered gray frames.  The frame's own border is not read.
+template <class V, class... OPTS>
+bool video_extruder_push_frame(video_extruder_ctx& ctx, const image2d<V>& frame, OPTS... options) {
+  static_assert(std::is_same<V, unsigned char>::value || std::is_same<V, vuchar3>::value || std::is_same<V, vuchar4>::value, "gray, rgb or rgba 8-bit frames");
+  const vpp_video_extruder_params p = ve_internals::begin_update(ctx, options...);
+  ve_internals::state& s = ctx.internal_state();
+  ve_internals::stopwatch sw(ve_internals::timing().step);
+  const vpp_image_desc d = frame.device_desc(false);
+  int n = 0, before = 0, after = 0;
+  device::check(vpp_video_extruder_count(s.h, &n, &before), "vpp_video_extruder_count");
+  device::check(vpp_video_extruder_push_frame(s.h, &d, &p, device::stream()), "vpp_video_extruder_push_frame");
+  device::check(vpp_video_extruder_count(s.h, &n, &after), "vpp_video_extruder_count");
+  if (after == before) { device::check(vpp_sync(device::stream()), "vpp_sync"); return false; }
+  ve_internals::end_update(ctx);
+  return true;
 }
 }  // namespace vpp
