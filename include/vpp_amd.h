@@ -280,6 +280,10 @@ int vpp_video_extruder_step(vpp_video_extruder* ve, const vpp_image_desc* frame1
  * after create — or after a change of nscales / winsize — only becomes `prev`: no update, frame_id unchanged.  Results are those of
  * vpp_video_extruder_step on the mirror-bordered gray frames.  Do not interleave with vpp_video_extruder_step on one tracker. */
 int vpp_video_extruder_push_frame(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* params, void* stream);
+/* The same for a frame in HOST memory (a decoder's output; pinned — vpp_malloc_host — for the copy engine's full rate): the frame is copied into one
+ * of two staging frames on a stream of the tracker's own, so the upload of frame t + 1 overlaps the update of frame t.  Returns once the host buffer
+ * has been read (it may be refilled at once), with the update queued on `stream`.  frame->border is ignored.  Not recordable into a launch graph. */
+int vpp_video_extruder_push_host_frame(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* params, void* stream);
 int vpp_video_extruder_count(const vpp_video_extruder* ve, int* n, int* frame_id);   /* container size (dead entries included), frame_id */
 /* n (row, col) int32 pairs for position and velocity, n ages; any output may be NULL */
 int vpp_video_extruder_keypoints(const vpp_video_extruder* ve, int32_t* pos_rc, int32_t* vel_rc, int32_t* age, int capacity, void* stream);

@@ -37,6 +37,13 @@ struct vpp_video_extruder {
   vpp_image_desc pyr[2][8];        // levels with the flow's layout (border 2 * winsize of memory)
   int pyr_scales = 0, pyr_winsize = 0, pyr_fill = 0, pyr_prev = 0;
   bool have_prev = false;
+  // vpp_video_extruder_push_host_frame: two staging frames filled by the copy engine on a stream of their own, while the previous update computes
+  uint8_t* stage[2] = {nullptr, nullptr};
+  size_t stage_bytes = 0;
+  int stage_k = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t staged = nullptr, consumed[2] = {nullptr, nullptr};   // staged: the upload is in HBM; consumed[k]: the pyramid built from stage[k] is done
+  bool consumed_set[2] = {false, false};
 };
 
 namespace vpp_amd { int keypoint_mask_squares(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, hipStream_t st); }
@@ -263,6 +270,9 @@ int vpp_video_extruder_destroy(vpp_video_extruder* ve) {
   if (!ve) return VPP_OK;
   for (int b = 0; b < 2; b++) { dfree(ve->pos[b]); dfree(ve->vel[b]); dfree(ve->age[b]); dfree(ve->tring[b]); dfree(ve->thead[b]); dfree(ve->tlen[b]); dfree(ve->tstart[b]); dfree(ve->talive[b]); }
   dfree(ve->fpos); dfree(ve->fdist); dfree(ve->scores); dfree(ve->newidx); dfree(ve->blocksum); dfree(ve->fvalid); dfree(ve->merged); dfree(ve->det); dfree(ve->mask); dfree(ve->pyr_mem[0]); dfree(ve->pyr_mem[1]);
+  if (ve->copy_stream) { (void)hipStreamSynchronize(ve->copy_stream); (void)hipStreamDestroy(ve->copy_stream); }
+  if (ve->staged) (void)hipEventDestroy(ve->staged);
+  for (int k = 0; k < 2; k++) { if (ve->consumed[k]) (void)hipEventDestroy(ve->consumed[k]); dfree(ve->stage[k]); }
   if (ve->host_count) vpp_free_host(ve->host_count);
   delete ve;
   return VPP_OK;
@@ -385,7 +395,8 @@ static int ve_pyramids(vpp_video_extruder* ve, int nscales, int winsize) {
 // keeps the previous frame's pyramid, so each frame's pyramid is built once (the two-frame entry builds both every update), and an RGB frame goes
 // through the fused ingest + pyramid launch without a gray frame in between.  The first frame after create (or after nscales / winsize change)
 // only becomes `prev` — no update, frame_id unchanged — exactly as the example's first iteration.
-int vpp_video_extruder_push_frame(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* p, void* stream) {
+// ingested != nullptr: recorded on the stream right behind the pyramid launch, the last reader of `frame`
+static int push_impl(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* p, void* stream, hipEvent_t ingested, bool* recorded) {
   VPP_REQUIRE(ve && p && valid_desc(frame), VPP_ERR_INVALID_ARG, "vpp_video_extruder_push_frame: invalid argument");
   VPP_REQUIRE(frame->nrows == ve->nrows && frame->ncols == ve->ncols, VPP_ERR_INVALID_ARG, "vpp_video_extruder_push_frame: the frame does not match the tracker's domain");
   VPP_REQUIRE(frame->dtype == VPP_U8 && (frame->channels == 1 || frame->channels == 3 || frame->channels == 4), VPP_ERR_UNSUPPORTED,
@@ -398,6 +409,7 @@ int vpp_video_extruder_push_frame(vpp_video_extruder* ve, const vpp_image_desc* 
   for (int l = 0; l < p->nscales; l++) { fill[l] = ve->pyr[in][l]; fill[l].border = ve->pyr_fill; }
   rc = frame->channels == 1 ? vpp_pyramid_build(fill, p->nscales, frame, stream) : vpp_rgb_pyramid_build(fill, p->nscales, frame, stream);
   if (rc != VPP_OK) return rc;
+  if (ingested) { VPP_HIP_TRY(hipEventRecord(ingested, as_stream(stream))); *recorded = true; }
   if (!ve->have_prev) { ve->have_prev = true; return VPP_OK; }
   vpp_image_desc f1 = ve->pyr[ve->pyr_prev][0], f2 = fill[0];
   f1.border = ve->pyr_fill;
@@ -405,6 +417,55 @@ int vpp_video_extruder_push_frame(vpp_video_extruder* ve, const vpp_image_desc* 
   if (rc != VPP_OK) { ve->have_prev = false; return rc; }   // the state of a failed update is the caller's to re-upload; the next frame starts over as `prev`
   ve->pyr_prev = in;
   return VPP_OK;
+}
+
+int vpp_video_extruder_push_frame(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* p, void* stream) {
+  return push_impl(ve, frame, p, stream, nullptr, nullptr);
+}
+
+// The same call for a frame in HOST memory (a decoder's output; pinned memory — vpp_malloc_host — for the copy engine's full rate): the frame is
+// copied into one of two staging frames on a stream of the tracker's own, so the upload of frame t + 1 runs while the update of frame t computes
+// (a 4K rgb frame is 0.45 ms of PCIe, an update 0.2 ms of GPU: back to back they would add up).  Returns when the host buffer has been read —
+// the caller may decode the next frame into it — with the update queued on `stream`.  Not recordable into a launch graph (it waits for the copy).
+int vpp_video_extruder_push_host_frame(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* p, void* stream) {
+  VPP_REQUIRE(ve && p && frame && frame->first_pixel && frame->nrows == ve->nrows && frame->ncols == ve->ncols, VPP_ERR_INVALID_ARG,
+              "vpp_video_extruder_push_host_frame: the frame does not match the tracker's domain");
+  VPP_REQUIRE(frame->dtype == VPP_U8 && (frame->channels == 1 || frame->channels == 3 || frame->channels == 4), VPP_ERR_UNSUPPORTED,
+              "vpp_video_extruder_push_host_frame: u8 x1 (gray), x3 or x4 (rgb / rgba) frames only");
+  const size_t row_bytes = (size_t)frame->ncols * frame->channels;
+  VPP_REQUIRE(frame->pitch >= (int64_t)row_bytes, VPP_ERR_INVALID_ARG, "vpp_video_extruder_push_host_frame: pitch smaller than a row");
+  const size_t dpitch = (row_bytes + 255) / 256 * 256, bytes = dpitch * frame->nrows;
+  hipStream_t st = as_stream(stream);
+  if (!ve->copy_stream) {
+    VPP_HIP_TRY(hipStreamCreateWithFlags(&ve->copy_stream, hipStreamNonBlocking));
+    VPP_HIP_TRY(hipEventCreateWithFlags(&ve->staged, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) VPP_HIP_TRY(hipEventCreateWithFlags(&ve->consumed[k], hipEventDisableTiming));
+  }
+  if (ve->stage_bytes < bytes) {   // first frame, or wider pixels than before: nothing may still read the old staging frames
+    VPP_HIP_TRY(hipStreamSynchronize(ve->copy_stream));
+    VPP_HIP_TRY(hipStreamSynchronize(st));
+    uint8_t* nw[2] = {nullptr, nullptr};
+    int rc = dalloc(&nw[0], bytes);
+    if (rc == VPP_OK) rc = dalloc(&nw[1], bytes);
+    if (rc != VPP_OK) { dfree(nw[0]); dfree(nw[1]); return rc; }
+    for (int k = 0; k < 2; k++) { dfree(ve->stage[k]); ve->stage[k] = nw[k]; ve->consumed_set[k] = false; }
+    ve->stage_bytes = bytes;
+  }
+  const int k = ve->stage_k;
+  ve->stage_k ^= 1;
+  if (ve->consumed_set[k]) VPP_HIP_TRY(hipStreamWaitEvent(ve->copy_stream, ve->consumed[k], 0));   // the pyramid built from this staging frame two frames ago
+  if ((size_t)frame->pitch == row_bytes && dpitch == row_bytes)   // tight rows on both sides (3840-wide frames are): one linear copy for the copy engine
+    VPP_HIP_TRY(hipMemcpyAsync(ve->stage[k], frame->first_pixel, bytes, hipMemcpyHostToDevice, ve->copy_stream));
+  else
+    VPP_HIP_TRY(hipMemcpy2DAsync(ve->stage[k], dpitch, frame->first_pixel, (size_t)frame->pitch, row_bytes, (size_t)frame->nrows, hipMemcpyHostToDevice, ve->copy_stream));
+  VPP_HIP_TRY(hipEventRecord(ve->staged, ve->copy_stream));
+  VPP_HIP_TRY(hipStreamWaitEvent(st, ve->staged, 0));
+  const vpp_image_desc d{ve->stage[k], frame->nrows, frame->ncols, (int32_t)dpitch, 0, VPP_U8, frame->channels};
+  bool recorded = false;
+  const int rc = push_impl(ve, &d, p, stream, ve->consumed[k], &recorded);   // queued while the copy is still in flight
+  ve->consumed_set[k] = recorded;
+  VPP_HIP_TRY(hipEventSynchronize(ve->staged));   // the host buffer is the caller's again
+  return rc;
 }
 
 int vpp_video_extruder_count(const vpp_video_extruder* ve, int* n, int* frame_id) {

@@ -182,9 +182,9 @@ template <class... OPTS> vpp_video_extruder_params begin_update(video_extruder_c
   }
   return p;
 }
-inline void end_update(video_extruder_ctx& ctx) {
+inline void end_update(video_extruder_ctx& ctx, bool wait = true) {
   state& s = ctx.internal_state();
-  device::check(vpp_sync(device::stream()), "vpp_sync");   // synchronous like the reference call
+  if (wait) device::check(vpp_sync(device::stream()), "vpp_sync");   // synchronous like the reference call
   ctx.frame_id++;
   s.frame_id = ctx.frame_id;
   s.host_stale = true;
@@ -206,19 +206,27 @@ void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>
 // clone(_border = 3) + fill_border_mirror + rgb_to_graylevel + video_extruder_update + copy(frame_gl, prev_frame).  The first frame only becomes
 // `prev` (returns false, like the example's `first`); later calls run one update (return true) whose results are those of video_extruder_update on
 // the mirror-bordered gray frames.  The frame's own border is not read.
+// A frame whose newest pixels are on the host (a decoder wrote them) is handed over as a host frame: the tracker stages it on a copy stream while the
+// previous update still computes (vpp_video_extruder_push_host_frame).  The call returns when the frame has been consumed — the image may be written
+// again — and the update itself completes asynchronously: looking at ctx.keypoints / ctx.trajectories (or any synchronous call) waits for it.
 template <class V, class... OPTS>
 bool video_extruder_push_frame(video_extruder_ctx& ctx, const image2d<V>& frame, OPTS... options) {
   static_assert(std::is_same<V, unsigned char>::value || std::is_same<V, vuchar3>::value || std::is_same<V, vuchar4>::value, "gray, rgb or rgba 8-bit frames");
   const vpp_video_extruder_params p = ve_internals::begin_update(ctx, options...);
   ve_internals::state& s = ctx.internal_state();
   ve_internals::stopwatch sw(ve_internals::timing().step);
-  const vpp_image_desc d = frame.device_desc(false);
   int n = 0, before = 0, after = 0;
   device::check(vpp_video_extruder_count(s.h, &n, &before), "vpp_video_extruder_count");
-  device::check(vpp_video_extruder_push_frame(s.h, &d, &p, device::stream()), "vpp_video_extruder_push_frame");
+  if (frame.device_current()) {
+    const vpp_image_desc d = frame.device_desc(false);
+    device::check(vpp_video_extruder_push_frame(s.h, &d, &p, device::stream()), "vpp_video_extruder_push_frame");
+  } else {
+    const vpp_image_desc d = frame.host_desc();
+    device::check(vpp_video_extruder_push_host_frame(s.h, &d, &p, device::stream()), "vpp_video_extruder_push_host_frame");
+  }
   device::check(vpp_video_extruder_count(s.h, &n, &after), "vpp_video_extruder_count");
-  if (after == before) { device::check(vpp_sync(device::stream()), "vpp_sync"); return false; }
-  ve_internals::end_update(ctx);
+  if (after == before) return false;
+  ve_internals::end_update(ctx, false);
   return true;
 }
 }  // namespace vpp

@@ -149,6 +149,19 @@ template <class V, unsigned N> class imageNd {
 #endif
   }
 #ifdef VPP_AMD_DEVICE
+  // true when the HBM mirror exists and is as new as the host pixels (device_desc would not upload)
+  bool device_current() const { return ptr_ && ptr_->store_->dev && ptr_->store_->state != 0; }
+  // C-ABI descriptor of the HOST pixels (for entry points that take host frames and stage them themselves); a newer mirror is downloaded first
+  vpp_image_desc host_desc() const {
+    static_assert(N == 2, "device evaluation handles image2d");
+    typedef pixel_traits<V> PT;
+    host_read();
+    vpp_image_desc d;
+    d.first_pixel = (void*)ptr_->begin_;
+    d.nrows = nrows(); d.ncols = ncols(); d.pitch = pitch(); d.border = border();
+    d.dtype = device::dtype_of<typename PT::component>::value; d.channels = PT::channels;
+    return d;
+  }
   // C-ABI descriptor of this image in HBM (vpp_image_desc); the mirror is uploaded if stale.  will_write marks the
   // mirror as the newer copy: the next host access downloads it; discard (with will_write) skips the upload of a stale
   // mirror when the callee overwrites the whole image, border included.
