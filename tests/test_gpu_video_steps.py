@@ -232,3 +232,121 @@ def test_blockwise_maxima_filter_4k_properties(lib):
     np.testing.assert_array_equal(blocks.max(axis=(1, 3)), a.reshape(216, 10, 384, 10).max(axis=(1, 3)))  # and it is the block maximum
     capi.check(lib.vpp_blockwise_maxima_filter(P(d.desc), 10, capi.stream_ptr()))
     np.testing.assert_array_equal(d.download().view()[..., 0], once)                            # idempotent
+
+
+class _VeParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("detector_th", "keypoint_spacing", "detector_period", "max_trajectory_length", "nscales", "winsize", "propagation")]
+
+
+def _tracker_state(lib, ve):
+    n, fid = ctypes.c_int(), ctypes.c_int()
+    capi.check(lib.vpp_video_extruder_count(ve, ctypes.byref(n), ctypes.byref(fid)))
+    pos = np.zeros((n.value, 2), np.int32); vel = np.zeros((n.value, 2), np.int32); age = np.zeros(n.value, np.int32); ln = np.zeros(n.value, np.int32)
+    capi.check(lib.vpp_video_extruder_keypoints(ve, pos.ctypes.data_as(V), vel.ctypes.data_as(V), age.ctypes.data_as(V), n.value, capi.stream_ptr()))
+    capi.check(lib.vpp_video_extruder_trajectories(ve, ln.ctypes.data_as(V), None, None, None, None, n.value, capi.stream_ptr()))
+    return fid.value, pos, vel, age, ln
+
+
+@pytest.mark.parametrize("shape,winsize,nscales", [((120, 200), 9, 3), ((97, 131), 7, 2), ((64, 96), 5, 4)])
+def test_one_frame_per_call_equals_the_two_frame_update(lib, shape, winsize, nscales):
+    """vpp_video_extruder_push_frame (gray and colour frames in HBM) and vpp_video_extruder_push_host_frame (tight and pitched frames in host memory)
+    leave the tracker in the state of vpp_video_extruder_step on the mirror-bordered gray frames: every position, velocity, age and trajectory
+    length after 7 frames, re-detection every 3rd.  (The two-frame call is pinned against the reference by tests/cpp/video_extruder_parity.cc.)"""
+    from vpp_amd.synth import texture, translate, rects_image
+    nr, nc = shape
+    T = 7
+    base = texture(nr + 40, nc + 40, seed=9, sigma=1.5)
+    rect = rects_image(nr + 40, nc + 40, seed=4).astype(np.float64)
+    frames = []
+    for t in range(T):
+        f = 0.6 * translate(base, 0.9 * t, -1.3 * t) + 0.4 * translate(rect, 0.9 * t, -1.3 * t)
+        frames.append(np.clip(np.rint(f[20:20 + nr, 20:20 + nc]), 0, 255).astype(np.uint8))
+    par = _VeParams(10, 10, 3, 15, nscales, winsize, 2)
+    lib.vpp_video_extruder_create.argtypes = [ctypes.POINTER(V), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+
+    def run(feed):
+        ve = V()
+        capi.check(lib.vpp_video_extruder_create(ctypes.byref(ve), nr, nc, 15))
+        try:
+            feed(ve)
+            return _tracker_state(lib, ve)
+        finally:
+            lib.vpp_video_extruder_destroy(ve)
+
+    def bordered(f):   # gray frame with a mirror-filled border of 3, in HBM
+        h = HostImage(nr, nc, vi.U8, 1, 3)
+        h.view()[..., 0] = f
+        d = DeviceImage.from_host(h)
+        capi.check(lib.vpp_fill_border(P(d.desc), 0, None, capi.stream_ptr()))   # VPP_BORDER_MIRROR
+        return d
+
+    def two_frame(ve):
+        d = [bordered(f) for f in frames]
+        for t in range(1, T):
+            capi.check(lib.vpp_video_extruder_step(ve, P(d[t - 1].desc), P(d[t].desc), ctypes.byref(par), capi.stream_ptr()))
+
+    def colour(f, ch):   # (g + d, g, g - d): the integer mean is g
+        g = f.astype(np.int32); d = np.minimum(np.minimum(g, 255 - g), 11)
+        h = HostImage(nr, nc, vi.U8, ch, 0)
+        v = h.view(); v[..., 0] = g + d; v[..., 1] = g; v[..., 2] = g - d
+        if ch == 4:
+            v[..., 3] = 200
+        return h
+
+    def push_device(ch):
+        def feed(ve):
+            for f in frames:
+                if ch == 1:
+                    h = HostImage(nr, nc, vi.U8, 1, 0); h.view()[..., 0] = f
+                else:
+                    h = colour(f, ch)
+                capi.check(lib.vpp_video_extruder_push_frame(ve, P(DeviceImage.from_host(h).desc), ctypes.byref(par), capi.stream_ptr()))
+        return feed
+
+    def push_host(ch, pad):
+        def feed(ve):
+            keep = []
+            for f in frames:
+                if ch == 1:
+                    rows = f[..., None]
+                else:
+                    rows = colour(f, ch).view()
+                buf = np.full((nr, nc * ch + pad), 0x5A, np.uint8)   # rows `pad` bytes apart from tight
+                buf[:, :nc * ch] = rows.reshape(nr, nc * ch)
+                keep.append(buf)
+                desc = vi.ImageDesc(buf.ctypes.data, nr, nc, buf.shape[1], 0, vi.U8, ch)
+                capi.check(lib.vpp_video_extruder_push_host_frame(ve, ctypes.byref(desc), ctypes.byref(par), capi.stream_ptr()))
+                buf[:] = 0   # the call has read the buffer: overwriting it must not change anything
+        return feed
+
+    want = run(two_frame)
+    assert want[0] == T - 2 and len(want[1]) > 20 and (want[3] > 0).sum() > 10 and (want[2] != 0).any()
+    for name, feed in (("gray hbm", push_device(1)), ("rgb hbm", push_device(3)), ("rgba hbm", push_device(4)), ("gray host tight", push_host(1, 0)),
+                       ("gray host pitched", push_host(1, 13)), ("rgb host pitched", push_host(3, 7)), ("rgba host tight", push_host(4, 0))):
+        got = run(feed)
+        assert got[0] == want[0], name
+        for g, w in zip(got[1:], want[1:]):
+            np.testing.assert_array_equal(g, w, err_msg=name)
+
+
+def test_push_frame_rejects_bad_frames(lib):
+    ve = V()
+    lib.vpp_video_extruder_create.argtypes = [ctypes.POINTER(V), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    capi.check(lib.vpp_video_extruder_create(ctypes.byref(ve), 64, 96, 15))
+    par = _VeParams(10, 10, 5, 15, 3, 9, 2)
+    try:
+        assert lib.vpp_video_extruder_push_frame(ve, P(DeviceImage(64, 97, vi.U8, 1).desc), ctypes.byref(par), None) != 0      # another domain
+        assert lib.vpp_video_extruder_push_frame(ve, P(DeviceImage(64, 96, vi.U8, 2).desc), ctypes.byref(par), None) != 0      # 2 channels
+        assert lib.vpp_video_extruder_push_frame(ve, P(DeviceImage(64, 96, vi.F32, 1).desc), ctypes.byref(par), None) != 0     # not 8-bit
+        buf = np.zeros((64, 96), np.uint8)
+        short = vi.ImageDesc(buf.ctypes.data, 64, 96, 95, 0, vi.U8, 1)
+        assert lib.vpp_video_extruder_push_host_frame(ve, ctypes.byref(short), ctypes.byref(par), None) != 0                   # pitch below a row
+        null = vi.ImageDesc(None, 64, 96, 96, 0, vi.U8, 1)
+        assert lib.vpp_video_extruder_push_host_frame(ve, ctypes.byref(null), ctypes.byref(par), None) != 0
+        bad = _VeParams(10, 10, 5, 15, 9, 9, 2)                                                                                   # 9 scales
+        assert lib.vpp_video_extruder_push_frame(ve, P(DeviceImage(64, 96, vi.U8, 1).desc), ctypes.byref(bad), None) != 0
+        n, fid = ctypes.c_int(), ctypes.c_int()
+        capi.check(lib.vpp_video_extruder_count(ve, ctypes.byref(n), ctypes.byref(fid)))
+        assert (n.value, fid.value) == (0, -1)   # nothing ran
+    finally:
+        lib.vpp_video_extruder_destroy(ve)
