@@ -107,6 +107,19 @@ int main(int argc, char** argv) {
   }();
   const double push_rgb_host = push_leg(colour_host, &push_entries[2]);     // host legs first: they leave the images' mirrors untouched ...
   const double push_gray_host = push_leg(gray_host, &push_entries[3]);
+  auto nowait_leg = [&](auto& seq) {   // the C ABI's two-buffer protocol: wait for the frame before last, push without waiting
+    vpp_video_extruder* h = nullptr;
+    device::check(vpp_video_extruder_create(&h, nr, nc, 15), "vpp_video_extruder_create");
+    const vpp_video_extruder_params p{10, 10, 5, 15, 3, 9, 2};
+    const double v = per_frame([&](int t) {
+      const vpp_image_desc d = seq[t].host_desc();
+      device::check(vpp_video_extruder_wait_host_frame(h, 1), "vpp_video_extruder_wait_host_frame");
+      device::check(vpp_video_extruder_push_host_frame_nowait(h, &d, &p, device::stream()), "vpp_video_extruder_push_host_frame_nowait");
+    });
+    vpp_video_extruder_destroy(h);
+    return v;
+  };
+  const double nowait_gray_host = nowait_leg(gray_host), nowait_rgb_host = nowait_leg(colour_host);
   const double chain_rgb_host = chain_leg(colour_host);                      // ... this one uploads them (as a caller of the plain API would, frame by frame)
   const double push_gray = push_leg(frames, &push_entries[0]);
   const double push_rgb = push_leg(colour, &push_entries[1]);
@@ -121,8 +134,8 @@ int main(int argc, char** argv) {
   std::printf("{\"workload\": \"video_extruder_update %dx%d uchar, defaults (th 10, spacing 10, period 5, 3 scales, winsize 9, 2 sweeps), %d updates after the detecting one\", "
               "\"ms_per_update\": %.3f, \"ms_per_update_median_steady\": %.3f, \"frames_per_s\": %.2f, \"keypoints\": %d, \"alive\": %d, \"velocity_ok\": %d, \"trajectory_points\": %zu, "
               "\"breakdown_ms\": {\"device_step_incl_wait\": %.3f, \"host_upload\": %.3f, \"host_view_during_updates\": %.3f}, "
-              "\"host_view_once_after_the_run_ms\": %.3f, \"ms_per_frame_frames_3_to_end_incl_detection_frames\": {\"frames_in_hbm\": {\"video_extruder_update_gray\": %.3f, \"push_frame_gray\": %.3f, \"push_frame_rgb\": %.3f, \"rgb_to_graylevel_mirror_then_update\": %.3f}, \"frames_in_pinned_host_memory\": {\"push_frame_gray\": %.3f, \"push_frame_rgb\": %.3f, \"rgb_to_graylevel_mirror_then_update\": %.3f}, \"entries\": [%d, %d, %d, %d]}, \"state\": \"keypoints and trajectories resident in HBM (vpp_video_extruder_*)\", \"per_update_ms\": [",
-              nr, nc, int(per.size() - 1), mean, median, 1000.0 / mean, nk.back(), alive, good, traj_points, tm.step / n, tm.upload / n, tm.view / n, view_ms, update_gray, push_gray, push_rgb, chain_rgb, push_gray_host, push_rgb_host, chain_rgb_host, push_entries[0], push_entries[1], push_entries[2], push_entries[3]);
+              "\"host_view_once_after_the_run_ms\": %.3f, \"ms_per_frame_frames_3_to_end_incl_detection_frames\": {\"frames_in_hbm\": {\"video_extruder_update_gray\": %.3f, \"push_frame_gray\": %.3f, \"push_frame_rgb\": %.3f, \"rgb_to_graylevel_mirror_then_update\": %.3f}, \"frames_in_pinned_host_memory\": {\"push_frame_gray\": %.3f, \"push_frame_rgb\": %.3f, \"two_host_buffers_nowait_gray\": %.3f, \"two_host_buffers_nowait_rgb\": %.3f, \"rgb_to_graylevel_mirror_then_update\": %.3f}, \"entries\": [%d, %d, %d, %d]}, \"state\": \"keypoints and trajectories resident in HBM (vpp_video_extruder_*)\", \"per_update_ms\": [",
+              nr, nc, int(per.size() - 1), mean, median, 1000.0 / mean, nk.back(), alive, good, traj_points, tm.step / n, tm.upload / n, tm.view / n, view_ms, update_gray, push_gray, push_rgb, chain_rgb, push_gray_host, push_rgb_host, nowait_gray_host, nowait_rgb_host, chain_rgb_host, push_entries[0], push_entries[1], push_entries[2], push_entries[3]);
   for (size_t i = 0; i < per.size(); i++) std::printf("%s%.2f", i ? ", " : "", per[i]);
   std::printf("]}\n");
   colour_host.clear(); gray_host.clear();

@@ -263,8 +263,8 @@ int vpp_lbp_transform(const vpp_image_desc* out, const vpp_image_desc* in, void*
  *      vpp_video_extruder_step = one video_extruder_update(ctx, frame1, frame2, options...) with the options of :35-41 in `params`
  *      (defaults 10, 10, 5, 15, 3, 9, 2).  Keypoints (position, velocity, age: keypoint_container.hh:13-25, dead entries kept in
  *      place until the next compaction exactly as keypoint_container does) and trajectories (keypoint_trajectory.hh:11-72, as
- *      rings of trajectory_capacity + 1 slots, newest first from `head`) never leave the device; the step synchronises the
- *      stream only on re-detection frames (the FAST count).  The accessors copy the state to HOST buffers and synchronise. ---- */
+ *      rings of trajectory_capacity + 1 slots, newest first from `head`) never leave the device; the step never waits for the
+ *      device (a re-detection's counts are read back when the next call needs them).  The accessors copy the state to HOST buffers and synchronise. ---- */
 typedef struct vpp_video_extruder vpp_video_extruder;
 typedef struct vpp_video_extruder_params {
   int32_t detector_th, keypoint_spacing, detector_period, max_trajectory_length, nscales, winsize, propagation;
@@ -284,7 +284,13 @@ int vpp_video_extruder_push_frame(vpp_video_extruder* ve, const vpp_image_desc* 
  * of two staging frames on a stream of the tracker's own, so the upload of frame t + 1 overlaps the update of frame t.  Returns once the host buffer
  * has been read (it may be refilled at once), with the update queued on `stream`.  frame->border is ignored.  Not recordable into a launch graph. */
 int vpp_video_extruder_push_host_frame(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* params, void* stream);
-int vpp_video_extruder_count(const vpp_video_extruder* ve, int* n, int* frame_id);   /* container size (dead entries included), frame_id */
+/* For callers that rotate two host buffers (decoding frame t + 1 into one while frame t uploads from the other): the same without the wait.
+ * vpp_video_extruder_wait_host_frame(ve, back) returns once the frame pushed last (back = 0) or the one before it (back = 1) has been read. */
+int vpp_video_extruder_push_host_frame_nowait(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* params, void* stream);
+int vpp_video_extruder_wait_host_frame(vpp_video_extruder* ve, int back);
+/* container size (dead entries included), frame_id; either may be NULL.  Asking for the size after a re-detection frame waits for that frame's FAST count
+ * (the update itself does not: everything behind the re-detection is queued against the two counts in HBM). */
+int vpp_video_extruder_count(const vpp_video_extruder* ve, int* n, int* frame_id);
 /* n (row, col) int32 pairs for position and velocity, n ages; any output may be NULL */
 int vpp_video_extruder_keypoints(const vpp_video_extruder* ve, int32_t* pos_rc, int32_t* vel_rc, int32_t* age, int capacity, void* stream);
 /* per trajectory: length, start frame, alive flag, ring head; ring_rc = n x slots x (row, col) f32, entry k of trajectory i (0 =

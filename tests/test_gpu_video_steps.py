@@ -319,10 +319,19 @@ def test_one_frame_per_call_equals_the_two_frame_update(lib, shape, winsize, nsc
                 buf[:] = 0   # the call has read the buffer: overwriting it must not change anything
         return feed
 
+    def push_host_two_buffers(ve):   # the two-buffer protocol: refill a buffer only after wait(back = 1) has vouched for it
+        bufs = [np.zeros((nr, nc), np.uint8), np.zeros((nr, nc), np.uint8)]
+        for t, f in enumerate(frames):
+            capi.check(lib.vpp_video_extruder_wait_host_frame(ve, 1))
+            bufs[t & 1][:] = f
+            desc = vi.ImageDesc(bufs[t & 1].ctypes.data, nr, nc, nc, 0, vi.U8, 1)
+            capi.check(lib.vpp_video_extruder_push_host_frame_nowait(ve, ctypes.byref(desc), ctypes.byref(par), capi.stream_ptr()))
+        capi.check(lib.vpp_video_extruder_wait_host_frame(ve, 0))
+
     want = run(two_frame)
     assert want[0] == T - 2 and len(want[1]) > 20 and (want[3] > 0).sum() > 10 and (want[2] != 0).any()
     for name, feed in (("gray hbm", push_device(1)), ("rgb hbm", push_device(3)), ("rgba hbm", push_device(4)), ("gray host tight", push_host(1, 0)),
-                       ("gray host pitched", push_host(1, 13)), ("rgb host pitched", push_host(3, 7)), ("rgba host tight", push_host(4, 0))):
+                       ("gray host pitched", push_host(1, 13)), ("rgb host pitched", push_host(3, 7)), ("rgba host tight", push_host(4, 0)), ("gray host, two buffers", push_host_two_buffers)):
         got = run(feed)
         assert got[0] == want[0], name
         for g, w in zip(got[1:], want[1:]):

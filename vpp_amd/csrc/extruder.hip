@@ -31,7 +31,11 @@ struct vpp_video_extruder {
   uint8_t *fvalid = nullptr, *merged = nullptr, *mask = nullptr;
   int mask_spacing = -1, mask_pitch = 0, det_cap = 0;
   size_t mask_bytes = 0;
-  int32_t* host_count = nullptr;  // pinned: alive count of the compaction
+  int32_t* host_count = nullptr;  // pinned: [0] alive count of the compaction, [1] keypoints found by the re-detection (copies of dcount)
+  int32_t* dcount = nullptr;      // the same two words in HBM, read by the kernels queued behind the re-detection
+  hipEvent_t count_ready = nullptr;
+  bool pending = false;           // a re-detection left the container size on the device: n is an upper bound until ve_resolve
+  int pending_cap = 0;
   // vpp_video_extruder_push_frame: the pyramids of the previous and of the incoming frame, kept here so that every frame's pyramid is built once
   uint8_t* pyr_mem[2] = {nullptr, nullptr};
   vpp_image_desc pyr[2][8];        // levels with the flow's layout (border 2 * winsize of memory)
@@ -42,7 +46,8 @@ struct vpp_video_extruder {
   size_t stage_bytes = 0;
   int stage_k = 0;
   hipStream_t copy_stream = nullptr;
-  hipEvent_t staged = nullptr, consumed[2] = {nullptr, nullptr};   // staged: the upload is in HBM; consumed[k]: the pyramid built from stage[k] is done
+  hipEvent_t staged[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};   // staged[k]: the upload into stage[k] is in HBM; consumed[k]: the pyramid built from it is done
+  int last_k = 0;                 // the staging frame of the push made last
   bool consumed_set[2] = {false, false};
 };
 
@@ -50,9 +55,11 @@ namespace vpp_amd { int keypoint_mask_squares(const vpp_image_desc* mask, const 
 
 namespace {
 
-__global__ __launch_bounds__(256) void ve_traj_kernel(int n, const int32_t* __restrict__ pos, const int32_t* __restrict__ age, float* __restrict__ ring,
+// dn != nullptr (re-detection frames): the container size is dn[0] + min(dn[1], dcap), n is only the launch's upper bound
+__global__ __launch_bounds__(256) void ve_traj_kernel(int n, const int32_t* __restrict__ dn, int dcap, const int32_t* __restrict__ pos, const int32_t* __restrict__ age, float* __restrict__ ring,
                                                       int32_t* __restrict__ head, int32_t* __restrict__ len, uint8_t* __restrict__ alive, int slots, int max_len) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (dn) n = dn[0] + min(dn[1], dcap);
   if (i >= n) return;
   if (age[i] > 0) {  // move_to + pop_oldest_position (video_extruder.hpp:125-130)
     const int h = (head[i] + slots - 1) % slots;
@@ -176,10 +183,12 @@ __global__ __launch_bounds__(256) void ve_compact_kernel(int n, const int32_t* _
   float2* dst = (float2*)ring2 + (size_t)d * slots;
   for (int s = j; s < slots; s += 16) dst[s] = src[s];
 }
-__global__ __launch_bounds__(256) void ve_append_kernel(int m, int count, const int32_t* __restrict__ det, int32_t* __restrict__ pos, int32_t* __restrict__ vel,
+// m = dn[0] compacted entries, count = min(dn[1], dcap) new keypoints (the launch covers dcap)
+__global__ __launch_bounds__(256) void ve_append_kernel(const int32_t* __restrict__ dn, int dcap, const int32_t* __restrict__ det, int32_t* __restrict__ pos, int32_t* __restrict__ vel,
                                                         int32_t* __restrict__ age, int32_t* __restrict__ head, int32_t* __restrict__ len, int32_t* __restrict__ start,
                                                         uint8_t* __restrict__ alive, int frame_id) {
   const int k = blockIdx.x * 256 + threadIdx.x;
+  const int m = dn[0], count = min(dn[1], dcap);
   if (k >= count) return;
   const int d = m + k;
   pos[2 * d] = det[2 * k]; pos[2 * d + 1] = det[2 * k + 1]; vel[2 * d] = 0; vel[2 * d + 1] = 0; age[d] = 1;  // keypoint<int>(kp) (keypoint_container.hh:16-18)
@@ -259,9 +268,13 @@ int vpp_video_extruder_create(vpp_video_extruder** out, int nrows, int ncols, in
   void* h = nullptr;
   if (vpp_malloc_host(64, &h) != VPP_OK) { delete ve; return VPP_ERR_HIP; }
   ve->host_count = (int32_t*)h;
+  ve->host_count[0] = ve->host_count[1] = 0;
+  if (dalloc(&ve->dcount, 2) != VPP_OK || hipEventCreateWithFlags(&ve->count_ready, hipEventDisableTiming) != hipSuccess) {
+    dfree(ve->dcount); vpp_free_host(h); delete ve; return VPP_ERR_HIP;
+  }
   // a first capacity that a blockwise detection with the default spacing cannot exceed: one keypoint per 10 x 10 block, twice over
   const int rc = ve_reserve(ve, std::max(4096, (nrows / 10 + 1) * (ncols / 10 + 1) * 2), nullptr);
-  if (rc != VPP_OK) { vpp_free_host(h); delete ve; return rc; }
+  if (rc != VPP_OK) { (void)hipEventDestroy(ve->count_ready); dfree(ve->dcount); vpp_free_host(h); delete ve; return rc; }
   *out = ve;
   return VPP_OK;
 }
@@ -271,10 +284,22 @@ int vpp_video_extruder_destroy(vpp_video_extruder* ve) {
   for (int b = 0; b < 2; b++) { dfree(ve->pos[b]); dfree(ve->vel[b]); dfree(ve->age[b]); dfree(ve->tring[b]); dfree(ve->thead[b]); dfree(ve->tlen[b]); dfree(ve->tstart[b]); dfree(ve->talive[b]); }
   dfree(ve->fpos); dfree(ve->fdist); dfree(ve->scores); dfree(ve->newidx); dfree(ve->blocksum); dfree(ve->fvalid); dfree(ve->merged); dfree(ve->det); dfree(ve->mask); dfree(ve->pyr_mem[0]); dfree(ve->pyr_mem[1]);
   if (ve->copy_stream) { (void)hipStreamSynchronize(ve->copy_stream); (void)hipStreamDestroy(ve->copy_stream); }
-  if (ve->staged) (void)hipEventDestroy(ve->staged);
-  for (int k = 0; k < 2; k++) { if (ve->consumed[k]) (void)hipEventDestroy(ve->consumed[k]); dfree(ve->stage[k]); }
+  for (int k = 0; k < 2; k++) { if (ve->staged[k]) (void)hipEventDestroy(ve->staged[k]); if (ve->consumed[k]) (void)hipEventDestroy(ve->consumed[k]); dfree(ve->stage[k]); }
+  if (ve->count_ready) { (void)hipEventSynchronize(ve->count_ready); (void)hipEventDestroy(ve->count_ready); }
+  dfree(ve->dcount);
   if (ve->host_count) vpp_free_host(ve->host_count);
   delete ve;
+  return VPP_OK;
+}
+
+// A re-detection leaves the container's new size on the device (alive entries + keypoints found) and queues everything behind it against an upper bound;
+// the host learns the size here, the next time it needs it — by then the two words have usually landed — instead of waiting inside the update.
+static int ve_resolve(const vpp_video_extruder* cve) {
+  vpp_video_extruder* ve = const_cast<vpp_video_extruder*>(cve);
+  if (!ve->pending) return VPP_OK;
+  VPP_HIP_TRY(hipEventSynchronize(ve->count_ready));
+  ve->n = ve->host_count[0] + std::min(ve->host_count[1], ve->pending_cap);
+  ve->pending = false;
   return VPP_OK;
 }
 
@@ -286,10 +311,17 @@ static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
   VPP_REQUIRE(p->keypoint_spacing > 0 && p->detector_period > 0 && p->max_trajectory_length > 0 && p->max_trajectory_length < ve->ring, VPP_ERR_INVALID_ARG,
               "vpp_video_extruder_step: max_trajectory_length %d exceeds the tracker's trajectory capacity %d", p->max_trajectory_length, ve->ring - 1);
   hipStream_t st = as_stream(stream);
+  int rc = ve_resolve(ve);
+  if (rc != VPP_OK) return rc;
   ve->frame_id++;
-  const int c = ve->cur, n = ve->n;
   const bool detect = ve->frame_id % p->detector_period == 0;   // re-detection frame: the compaction moves entries, the trajectories are updated after it
-  int rc;
+  const int s_ = p->keypoint_spacing;
+  const int det_cap = (ve->nrows / s_ + 1) * (ve->ncols / s_ + 1);  // blockwise: at most one keypoint per s x s block
+  if (detect) {   // room for every entry + every block's keypoint, before anything of this update is queued on the buffers
+    rc = ve_reserve(ve, ve->n + det_cap, st);
+    if (rc != VPP_OK) return rc;
+  }
+  const int c = ve->cur, n = ve->n;
   if (n > 0) {
     if (pyr1) rc = vpp_semi_dense_optical_flow_pyramids(pyr1, pyr2, p->nscales, ve->pos[c], n, p->winsize, 0, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, stream);
     else rc = vpp_semi_dense_optical_flow(frame1, frame2, ve->pos[c], n, p->winsize, p->nscales, 0, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, stream);
@@ -319,38 +351,34 @@ static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
     VPP_HIP_TRY(hipMemsetAsync(ve->mask, 1, ve->mask_bytes, st));
     rc = keypoint_mask_squares(&md, ve->pos[c], n, s, st);
     if (rc != VPP_OK) return rc;
-    // the alive count travels to the host behind the detection's own synchronisation
+    // the alive count and the number of keypoints found stay on the device: the kernels behind them read the two words, the host reads its copy
+    // when it next needs the container's size (ve_resolve)
     const int nblocks = (n + kScanBlock - 1) / kScanBlock;
     if (n > 0) {
       ve_count_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum);
-      ve_scan_kernel<<<1, 1024, 0, st>>>(nblocks, ve->blocksum, ve->host_count);
+      ve_scan_kernel<<<1, 1024, 0, st>>>(nblocks, ve->blocksum, ve->dcount);
       ve_index_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum, ve->newidx);
-    } else *ve->host_count = 0;
-    int count = 0;
-    const int det_cap = (ve->nrows / s + 1) * (ve->ncols / s + 1);  // blockwise: at most one keypoint per s x s block
+    } else VPP_HIP_TRY(hipMemsetAsync(ve->dcount, 0, 4, st));
     if (det_cap > ve->det_cap) {
       dfree(ve->det);
       rc = dalloc(&ve->det, (size_t)det_cap * 2);
       if (rc != VPP_OK) return rc;
       ve->det_cap = det_cap;
     }
-    rc = vpp_fast9_detect(frame2, p->detector_th, &md, VPP_FAST9_BLOCKWISE, s, VPP_FAST9_REFERENCE, ve->det, nullptr, det_cap, &count, stream);
+    rc = vpp_fast9_detect_async(frame2, p->detector_th, &md, VPP_FAST9_BLOCKWISE, s, VPP_FAST9_REFERENCE, ve->det, nullptr, det_cap, (uint32_t*)(ve->dcount + 1), stream);
     if (rc != VPP_OK) return rc;
-    const int m = n > 0 ? *ve->host_count : 0;  // vpp_fast9_detect synchronised the stream
-    rc = ve_reserve(ve, m + count, st);
-    if (rc != VPP_OK) return rc;
-    const int d = 1 - ve->cur;
+    VPP_HIP_TRY(hipMemcpyAsync(ve->host_count, ve->dcount, 8, hipMemcpyDeviceToHost, st));
+    VPP_HIP_TRY(hipEventRecord(ve->count_ready, st));
+    const int d = 1 - c;
     if (n > 0)
-      ve_compact_kernel<<<(unsigned)(((size_t)n * 16 + 255) / 256), 256, 0, st>>>(n, ve->newidx, ve->pos[ve->cur], ve->vel[ve->cur], ve->age[ve->cur], ve->tring[ve->cur], ve->thead[ve->cur],
-          ve->tlen[ve->cur], ve->tstart[ve->cur], ve->talive[ve->cur], ve->pos[d], ve->vel[d], ve->age[d], ve->tring[d], ve->thead[d], ve->tlen[d], ve->tstart[d], ve->talive[d], ve->ring);
-    if (count > 0)
-      ve_append_kernel<<<(count + 255) / 256, 256, 0, st>>>(m, count, ve->det, ve->pos[d], ve->vel[d], ve->age[d], ve->thead[d], ve->tlen[d], ve->tstart[d], ve->talive[d], ve->frame_id);
+      ve_compact_kernel<<<(unsigned)(((size_t)n * 16 + 255) / 256), 256, 0, st>>>(n, ve->newidx, ve->pos[c], ve->vel[c], ve->age[c], ve->tring[c], ve->thead[c],
+          ve->tlen[c], ve->tstart[c], ve->talive[c], ve->pos[d], ve->vel[d], ve->age[d], ve->tring[d], ve->thead[d], ve->tlen[d], ve->tstart[d], ve->talive[d], ve->ring);
+    ve_append_kernel<<<(det_cap + 255) / 256, 256, 0, st>>>(ve->dcount, det_cap, ve->det, ve->pos[d], ve->vel[d], ve->age[d], ve->thead[d], ve->tlen[d], ve->tstart[d], ve->talive[d], ve->frame_id);
+    ve_traj_kernel<<<(n + det_cap + 255) / 256, 256, 0, st>>>(n + det_cap, ve->dcount, det_cap, ve->pos[d], ve->age[d], ve->tring[d], ve->thead[d], ve->tlen[d], ve->talive[d], ve->ring,
+                                                              p->max_trajectory_length);
     ve->cur = d;
-    ve->n = m + count;
-  }
-  if (ve->n > 0 && (detect || n == 0)) {   // (otherwise done by ve_finish_kernel)
-    const int k = ve->cur;
-    ve_traj_kernel<<<(ve->n + 255) / 256, 256, 0, st>>>(ve->n, ve->pos[k], ve->age[k], ve->tring[k], ve->thead[k], ve->tlen[k], ve->talive[k], ve->ring, p->max_trajectory_length);
+    ve->n = n + det_cap;   // upper bound until ve_resolve
+    ve->pending = true; ve->pending_cap = det_cap;
   }
   VPP_LAUNCH_CHECK();
   return VPP_OK;
@@ -427,7 +455,7 @@ int vpp_video_extruder_push_frame(vpp_video_extruder* ve, const vpp_image_desc* 
 // copied into one of two staging frames on a stream of the tracker's own, so the upload of frame t + 1 runs while the update of frame t computes
 // (a 4K rgb frame is 0.45 ms of PCIe, an update 0.2 ms of GPU: back to back they would add up).  Returns when the host buffer has been read —
 // the caller may decode the next frame into it — with the update queued on `stream`.  Not recordable into a launch graph (it waits for the copy).
-int vpp_video_extruder_push_host_frame(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* p, void* stream) {
+static int push_host_impl(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* p, void* stream, bool wait) {
   VPP_REQUIRE(ve && p && frame && frame->first_pixel && frame->nrows == ve->nrows && frame->ncols == ve->ncols, VPP_ERR_INVALID_ARG,
               "vpp_video_extruder_push_host_frame: the frame does not match the tracker's domain");
   VPP_REQUIRE(frame->dtype == VPP_U8 && (frame->channels == 1 || frame->channels == 3 || frame->channels == 4), VPP_ERR_UNSUPPORTED,
@@ -438,8 +466,7 @@ int vpp_video_extruder_push_host_frame(vpp_video_extruder* ve, const vpp_image_d
   hipStream_t st = as_stream(stream);
   if (!ve->copy_stream) {
     VPP_HIP_TRY(hipStreamCreateWithFlags(&ve->copy_stream, hipStreamNonBlocking));
-    VPP_HIP_TRY(hipEventCreateWithFlags(&ve->staged, hipEventDisableTiming));
-    for (int k = 0; k < 2; k++) VPP_HIP_TRY(hipEventCreateWithFlags(&ve->consumed[k], hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) { VPP_HIP_TRY(hipEventCreateWithFlags(&ve->staged[k], hipEventDisableTiming)); VPP_HIP_TRY(hipEventCreateWithFlags(&ve->consumed[k], hipEventDisableTiming)); }
   }
   if (ve->stage_bytes < bytes) {   // first frame, or wider pixels than before: nothing may still read the old staging frames
     VPP_HIP_TRY(hipStreamSynchronize(ve->copy_stream));
@@ -452,30 +479,46 @@ int vpp_video_extruder_push_host_frame(vpp_video_extruder* ve, const vpp_image_d
     ve->stage_bytes = bytes;
   }
   const int k = ve->stage_k;
-  ve->stage_k ^= 1;
+  ve->stage_k ^= 1; ve->last_k = k;
   if (ve->consumed_set[k]) VPP_HIP_TRY(hipStreamWaitEvent(ve->copy_stream, ve->consumed[k], 0));   // the pyramid built from this staging frame two frames ago
   if ((size_t)frame->pitch == row_bytes && dpitch == row_bytes)   // tight rows on both sides (3840-wide frames are): one linear copy for the copy engine
     VPP_HIP_TRY(hipMemcpyAsync(ve->stage[k], frame->first_pixel, bytes, hipMemcpyHostToDevice, ve->copy_stream));
   else
     VPP_HIP_TRY(hipMemcpy2DAsync(ve->stage[k], dpitch, frame->first_pixel, (size_t)frame->pitch, row_bytes, (size_t)frame->nrows, hipMemcpyHostToDevice, ve->copy_stream));
-  VPP_HIP_TRY(hipEventRecord(ve->staged, ve->copy_stream));
-  VPP_HIP_TRY(hipStreamWaitEvent(st, ve->staged, 0));
+  VPP_HIP_TRY(hipEventRecord(ve->staged[k], ve->copy_stream));
+  VPP_HIP_TRY(hipStreamWaitEvent(st, ve->staged[k], 0));
   const vpp_image_desc d{ve->stage[k], frame->nrows, frame->ncols, (int32_t)dpitch, 0, VPP_U8, frame->channels};
   bool recorded = false;
   const int rc = push_impl(ve, &d, p, stream, ve->consumed[k], &recorded);   // queued while the copy is still in flight
   ve->consumed_set[k] = recorded;
-  VPP_HIP_TRY(hipEventSynchronize(ve->staged));   // the host buffer is the caller's again
+  if (wait) VPP_HIP_TRY(hipEventSynchronize(ve->staged[k]));   // the host buffer is the caller's again
   return rc;
+}
+
+int vpp_video_extruder_push_host_frame(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* p, void* stream) {
+  return push_host_impl(ve, frame, p, stream, true);
+}
+// For a caller that rotates two host buffers (decode frame t + 1 into one while frame t uploads from the other): returns with the copy still in flight.
+// vpp_video_extruder_wait_host_frame(ve, back) returns once the frame pushed last (back = 0) or the one before it (back = 1) has been read.
+int vpp_video_extruder_push_host_frame_nowait(vpp_video_extruder* ve, const vpp_image_desc* frame, const vpp_video_extruder_params* p, void* stream) {
+  return push_host_impl(ve, frame, p, stream, false);
+}
+int vpp_video_extruder_wait_host_frame(vpp_video_extruder* ve, int back) {
+  VPP_REQUIRE(ve && (back == 0 || back == 1), VPP_ERR_INVALID_ARG, "vpp_video_extruder_wait_host_frame: back must be 0 or 1");
+  const int k = back ? 1 - ve->last_k : ve->last_k;
+  if (ve->staged[k]) VPP_HIP_TRY(hipEventSynchronize(ve->staged[k]));   // (never recorded: returns at once)
+  return VPP_OK;
 }
 
 int vpp_video_extruder_count(const vpp_video_extruder* ve, int* n, int* frame_id) {
   VPP_REQUIRE(ve, VPP_ERR_INVALID_ARG, "vpp_video_extruder_count: null");
-  if (n) *n = ve->n;
+  if (n) { const int rc = ve_resolve(ve); if (rc != VPP_OK) return rc; *n = ve->n; }   // (frame_id alone never waits)
   if (frame_id) *frame_id = ve->frame_id;
   return VPP_OK;
 }
 
 int vpp_video_extruder_keypoints(const vpp_video_extruder* ve, int32_t* pos_rc, int32_t* vel_rc, int32_t* age, int capacity, void* stream) {
+  if (ve) { const int rc = ve_resolve(ve); if (rc != VPP_OK) return rc; }
   VPP_REQUIRE(ve && capacity >= ve->n, VPP_ERR_INVALID_ARG, "vpp_video_extruder_keypoints: capacity %d < %d entries", capacity, ve ? ve->n : 0);
   hipStream_t st = as_stream(stream);
   const int k = ve->cur; const size_t n = ve->n;
@@ -487,6 +530,7 @@ int vpp_video_extruder_keypoints(const vpp_video_extruder* ve, int32_t* pos_rc, 
 }
 
 int vpp_video_extruder_trajectories(const vpp_video_extruder* ve, int32_t* len, int32_t* start_frame, uint8_t* alive, int32_t* head, float* ring_rc, int capacity, void* stream) {
+  if (ve) { const int rc = ve_resolve(ve); if (rc != VPP_OK) return rc; }
   VPP_REQUIRE(ve && capacity >= ve->n, VPP_ERR_INVALID_ARG, "vpp_video_extruder_trajectories: capacity %d < %d entries", capacity, ve ? ve->n : 0);
   hipStream_t st = as_stream(stream);
   const int k = ve->cur; const size_t n = ve->n;
@@ -511,6 +555,7 @@ int vpp_video_extruder_upload(vpp_video_extruder* ve, int n, int frame_id, const
                               const int32_t* start_frame, const uint8_t* alive, const int32_t* head, const float* ring_rc, void* stream) {
   VPP_REQUIRE(ve && n >= 0, VPP_ERR_INVALID_ARG, "vpp_video_extruder_upload: invalid argument");
   hipStream_t st = as_stream(stream);
+  { const int rc0 = ve_resolve(ve); if (rc0 != VPP_OK) return rc0; }
   ve->n = 0;  // nothing to carry over
   int rc = ve_reserve(ve, n, st);
   if (rc != VPP_OK) return rc;

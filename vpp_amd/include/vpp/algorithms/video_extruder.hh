@@ -215,8 +215,8 @@ bool video_extruder_push_frame(video_extruder_ctx& ctx, const image2d<V>& frame,
   const vpp_video_extruder_params p = ve_internals::begin_update(ctx, options...);
   ve_internals::state& s = ctx.internal_state();
   ve_internals::stopwatch sw(ve_internals::timing().step);
-  int n = 0, before = 0, after = 0;
-  device::check(vpp_video_extruder_count(s.h, &n, &before), "vpp_video_extruder_count");
+  int before = 0, after = 0;
+  device::check(vpp_video_extruder_count(s.h, nullptr, &before), "vpp_video_extruder_count");   // (the frame id alone: asking for the size could wait for a re-detection)
   if (frame.device_current()) {
     const vpp_image_desc d = frame.device_desc(false);
     device::check(vpp_video_extruder_push_frame(s.h, &d, &p, device::stream()), "vpp_video_extruder_push_frame");
@@ -224,7 +224,7 @@ bool video_extruder_push_frame(video_extruder_ctx& ctx, const image2d<V>& frame,
     const vpp_image_desc d = frame.host_desc();
     device::check(vpp_video_extruder_push_host_frame(s.h, &d, &p, device::stream()), "vpp_video_extruder_push_host_frame");
   }
-  device::check(vpp_video_extruder_count(s.h, &n, &after), "vpp_video_extruder_count");
+  device::check(vpp_video_extruder_count(s.h, nullptr, &after), "vpp_video_extruder_count");
   if (after == before) return false;
   ve_internals::end_update(ctx, false);
   return true;
