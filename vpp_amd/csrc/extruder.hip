@@ -8,8 +8,9 @@
 //      the trajectories + append of the new keypoints (here) -> trajectory update (here).
 // The container keeps the reference's layout semantics: dead entries (age 0) stay in place until the next compaction and take
 // part in every step exactly as they do there (the flow still moves them, which revives them: move() increments the age).
-// Trajectories are fixed-capacity rings in HBM, newest position first from `head`.  The host learns the container size only on
-// re-detection frames (one count read-back, the same synchronisation FAST's count already needs); nothing else waits.
+// Trajectories are fixed-capacity rings in HBM, newest position first from `head`.  Nothing in an update waits for the device: a
+// re-detection leaves the container's new size in HBM for the kernels behind it and the host reads its copy when it next needs it
+// (ve_resolve).  vpp_video_extruder_push_frame / _push_host_frame are the video loop's shape: one frame per call, `prev` and its pyramid kept here.
 #include "common.hpp"
 #include "tracker_device.hpp"
 #include <algorithm>
