@@ -359,3 +359,42 @@ def test_push_frame_rejects_bad_frames(lib):
         assert (n.value, fid.value) == (0, -1)   # nothing ran
     finally:
         lib.vpp_video_extruder_destroy(ve)
+
+
+def test_push_frame_restarts_when_the_pyramids_change_shape(lib):
+    """A change of nscales / winsize between two pushes re-carves the tracker's pyramids: the frame after the change only becomes `prev` (documented in
+    include/vpp_amd.h) — the state equals the two-frame updates with that one update left out."""
+    from vpp_amd.synth import texture, translate, rects_image
+    nr, nc, T = 96, 160, 7
+    base = texture(nr + 40, nc + 40, seed=3, sigma=1.5); rect = rects_image(nr + 40, nc + 40, seed=8).astype(np.float64)
+    frames = [np.clip(np.rint((0.6 * translate(base, 1.1 * t, 0.7 * t) + 0.4 * translate(rect, 1.1 * t, 0.7 * t))[20:20 + nr, 20:20 + nc]), 0, 255).astype(np.uint8) for t in range(T)]
+    par_a, par_b = _VeParams(10, 10, 2, 15, 3, 9, 2), _VeParams(10, 10, 2, 15, 2, 7, 2)
+    lib.vpp_video_extruder_create.argtypes = [ctypes.POINTER(V), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    switch = 4   # frames 0..3 with par_a, frames 4.. with par_b: the update (3 -> 4) does not run
+
+    def bordered(f):
+        h = HostImage(nr, nc, vi.U8, 1, 3); h.view()[..., 0] = f
+        d = DeviceImage.from_host(h)
+        capi.check(lib.vpp_fill_border(P(d.desc), 0, None, capi.stream_ptr()))
+        return d
+    states = []
+    for mode in ("two_frame", "push"):
+        ve = V(); capi.check(lib.vpp_video_extruder_create(ctypes.byref(ve), nr, nc, 15))
+        try:
+            if mode == "two_frame":
+                d = [bordered(f) for f in frames]
+                for t in range(1, T):
+                    if t == switch:
+                        continue
+                    capi.check(lib.vpp_video_extruder_step(ve, P(d[t - 1].desc), P(d[t].desc), ctypes.byref(par_a if t < switch else par_b), capi.stream_ptr()))
+            else:
+                for t, f in enumerate(frames):
+                    h = HostImage(nr, nc, vi.U8, 1, 0); h.view()[..., 0] = f
+                    capi.check(lib.vpp_video_extruder_push_frame(ve, P(DeviceImage.from_host(h).desc), ctypes.byref(par_a if t < switch else par_b), capi.stream_ptr()))
+            states.append(_tracker_state(lib, ve))
+        finally:
+            lib.vpp_video_extruder_destroy(ve)
+    assert states[0][0] == T - 3 and len(states[0][1]) > 20
+    assert states[1][0] == states[0][0]
+    for g, w in zip(states[1][1:], states[0][1:]):
+        np.testing.assert_array_equal(g, w)
