@@ -506,7 +506,7 @@ __device__ __forceinline__ void enqueue_targets(const RoundArrays& a, SweepCtl* 
 
 template <int WS>
 __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats) {
-  __shared__ unsigned s_val;
+  __shared__ unsigned s_val, s_nreg;
   __shared__ unsigned long long s_gen;
   __shared__ uint4 s_union[kJobsPerGroup][kUnionRows];   // per 8-lane group: the candidate patch of a descent step (group_descent_staged)
   SweepCtl* const ctl = a.ctl;
@@ -521,16 +521,25 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
   const unsigned ticket = s_val;   // this workgroup's registration number
   __syncthreads();
   unsigned N = 0;   // registered workgroups (thread 0, known at the first barrier)
+  unsigned nall = 0;   // the same for every thread, from the first barrier on
+  const bool static_batches = stats != 2;   // (stats == 2: every round pops its batches from the counter, as round 0 does — kept for A/B)
   for (int k = 0;; k++) {
     const int par = k & 1;
     const Cell* __restrict__ Bprev = a.B[par ^ 1];
     Cell* __restrict__ Bcur = a.B[par];
     const uint32_t* __restrict__ Qcur = a.Q[par];
+    unsigned batch = ticket;
     for (;;) {
-      if (tid == 0) s_val = __hip_atomic_fetch_add(&ctl->head[par], (unsigned)kJobsPerGroup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      const unsigned base = s_val;
-      __syncthreads();
+      // Round 0 hands its batches out from a counter (a workgroup that is not resident yet must not own jobs: it may never register).  From round 1 on
+      // the registered workgroups are known and all resident: workgroup `ticket` takes the batches ticket, ticket + N, ... — no atomic round trip in front
+      // of a round's first loads and none behind its last batch.
+      unsigned base;
+      if (k == 0 || !static_batches) {
+        if (tid == 0) s_val = __hip_atomic_fetch_add(&ctl->head[par], (unsigned)kJobsPerGroup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        base = s_val;
+        __syncthreads();
+      } else { base = batch * (unsigned)kJobsPerGroup; batch += nall; }
       if (base >= n) break;
       const unsigned job = base + (unsigned)(tid >> 3);
       int target = -1;   // the cell this lane wants in the next round's queue
@@ -602,7 +611,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
           store_cell16(Bcur + cell, Cell{cur.f0, cur.f1, cur.dist, cur.mark | (changed ? (k + 1) << kTagShift : 0)});
           int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
           f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)cur.mark;
-          if (stats) { atomicAdd(&g_round_stats[1], 1u); if (need) atomicAdd(&g_round_stats[2], 1u); if (changed) atomicAdd(&g_round_stats[3], 1u); }
+          if (stats == 1) { atomicAdd(&g_round_stats[1], 1u); if (need) atomicAdd(&g_round_stats[2], 1u); if (changed) atomicAdd(&g_round_stats[3], 1u); }
         }
         if (changed) {   // next round: this cell (its value must reach the other buffer) and the marked cells that read it as an earlier neighbour
           if (j == (forward ? 0 : 7)) target = cell;                       // one of the earlier-neighbour lanes speaks for the cell itself
@@ -619,6 +628,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
         if (!(o & kRegClosed)) { N = o; __hip_atomic_store(&ctl->nreg, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         else for (unsigned spin = 0; (N = __hip_atomic_load(&ctl->nreg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && spin < kSpinLimit; spin++) __builtin_amdgcn_s_sleep(1);
         if (N == 0) { N = 1; ctl->pad = 1; }   // cannot happen (the closer stores nreg right after closing); never hang the GPU on a bug
+        s_nreg = N;
       }
       if (N > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -632,7 +642,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         g = ((unsigned long long)(k + 1) << 32) | nn;
         __hip_atomic_store(&ctl->gen, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (stats) atomicAdd(&g_round_stats[0], 1u);
+        if (stats == 1) atomicAdd(&g_round_stats[0], 1u);
       } else {
         unsigned spin = 0;
         while (((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned long long)(k + 1) && ++spin < kSpinLimit) __builtin_amdgcn_s_sleep(1);
@@ -643,6 +653,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
     }
     __syncthreads();
     n = (unsigned)s_gen;
+    if (k == 0) nall = s_nreg;
     __syncthreads();
     if (n == 0) break;
     // A round that fits one batch (the tail of a sweep: a handful of cells whose neighbours changed) is left to ONE workgroup, the first that
@@ -650,7 +661,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
     // no L2 invalidation in front of the next round's loads (which made a round of 5 jobs cost as much as one of 1 500).
     if (n <= (unsigned)kJobsPerGroup && N != 1) {
       if (ticket != 0) return;
-      N = 1;
+      N = 1; nall = 1;
     }
   }
 }
