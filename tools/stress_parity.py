@@ -1,5 +1,5 @@
 """One-off randomized parity sweep (GPU vs the CPU oracle) over shapes / parameters the fixed tests do not enumerate:
-FAST-9 (all modes, masks, thresholds), semi-dense flow (window sizes, scales, sweeps, patch sizes), box filters, rgb->gray, u8 pyramids (gray and fused rgb ingest).
+FAST-9 (all modes, masks, thresholds), semi-dense flow (window sizes, scales, sweeps, patch sizes), box filters, rgb->gray, u8 pyramids (gray and fused rgb ingest), tracker sequences (two-frame update vs one frame per call).
 usage: python tools/stress_parity.py [n_cases] [seed]      (needs a GPU; exits non-zero on the first mismatch)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -115,5 +115,49 @@ for case in range(N):
     capi.check(lib.vpp_rgb_pyramid_build(vi.desc_array(lv), 3, P(DeviceImage.from_host(rgbp).desc), capi.stream_ptr())); capi.check(lib.vpp_sync(capi.stream_ptr()))
     ok = all(np.array_equal(d.download().raw, h.raw) for d, h in zip(lv, want))
     print(f"rgb pyramid x{chn} {nr}x{nc} border={pb}: {'ok' if ok else 'MISMATCH'}"); bad += not ok
+    # the tracker: the two-frame update on mirror-bordered gray frames against one frame per call (frames in HBM / pitched host frames, gray or colour),
+    # random geometry and options; every position, velocity, age and trajectory length after 6 frames
+    from vpp_amd.synth import texture, translate
+    class VeParams(ctypes.Structure):
+        _fields_ = [(n_, ctypes.c_int32) for n_ in ("detector_th", "keypoint_spacing", "detector_period", "max_trajectory_length", "nscales", "winsize", "propagation")]
+    nr, nc = int(rng.integers(40, 260)), int(rng.integers(48, 360))
+    par = VeParams(int(rng.integers(5, 25)), int(rng.integers(4, 14)), int(rng.integers(1, 5)), int(rng.integers(2, 12)), int(rng.integers(1, 4)), int(rng.choice([5, 7, 9, 11])), int(rng.integers(0, 3)))
+    while min(nr, nc) >> (par.nscales - 1) < 5 * 2:   # every flow-map level needs one patch at least
+        par.nscales -= 1
+    tex = texture(nr + 40, nc + 40, seed=int(rng.integers(1 << 30)), sigma=1.5); rc = rects_image(nr + 40, nc + 40, seed=int(rng.integers(1 << 30))).astype(np.float64)
+    dr, dc = float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2))
+    fr = [np.clip(np.rint((0.6 * translate(tex, dr * t, dc * t) + 0.4 * translate(rc, dr * t, dc * t))[20:20 + nr, 20:20 + nc]), 0, 255).astype(np.uint8) for t in range(6)]
+    lib.vpp_video_extruder_create.argtypes = [ctypes.POINTER(V), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    def ve_state(ve):
+        n_, fid = ctypes.c_int(), ctypes.c_int()
+        capi.check(lib.vpp_video_extruder_count(ve, ctypes.byref(n_), ctypes.byref(fid)))
+        pos = np.zeros((n_.value, 2), np.int32); vel = np.zeros((n_.value, 2), np.int32); age = np.zeros(n_.value, np.int32); ln = np.zeros(n_.value, np.int32)
+        capi.check(lib.vpp_video_extruder_keypoints(ve, pos.ctypes.data_as(V), vel.ctypes.data_as(V), age.ctypes.data_as(V), n_.value, capi.stream_ptr()))
+        capi.check(lib.vpp_video_extruder_trajectories(ve, ln.ctypes.data_as(V), None, None, None, None, n_.value, capi.stream_ptr()))
+        return fid.value, pos, vel, age, ln
+    chn = int(rng.choice([1, 3, 4])); host = bool(rng.integers(0, 2)); pad = int(rng.integers(0, 20))
+    states = []
+    for mode in (0, 1):
+        ve = V(); capi.check(lib.vpp_video_extruder_create(ctypes.byref(ve), nr, nc, 15))
+        keep = []
+        for t, f in enumerate(fr):
+            if mode == 0:
+                h = HostImage(nr, nc, vi.U8, 1, 3); h.view()[..., 0] = f
+                d = DeviceImage.from_host(h); capi.check(lib.vpp_fill_border(P(d.desc), 0, None, capi.stream_ptr())); keep.append(d)
+                if t: capi.check(lib.vpp_video_extruder_step(ve, P(keep[t - 1].desc), P(d.desc), ctypes.byref(par), capi.stream_ptr()))
+                continue
+            g = f.astype(np.int32); dd = np.minimum(np.minimum(g, 255 - g), 9)
+            px = f[..., None] if chn == 1 else np.stack([g + dd, g, g - dd] + ([np.full_like(g, 9)] if chn == 4 else []), -1).astype(np.uint8)
+            if host:
+                buf = np.zeros((nr, nc * chn + pad), np.uint8); buf[:, :nc * chn] = px.reshape(nr, nc * chn); keep.append(buf)
+                desc = vi.ImageDesc(buf.ctypes.data, nr, nc, buf.shape[1], 0, vi.U8, chn)
+                capi.check(lib.vpp_video_extruder_push_host_frame(ve, ctypes.byref(desc), ctypes.byref(par), capi.stream_ptr()))
+            else:
+                h = HostImage(nr, nc, vi.U8, chn, 0); h.view()[...] = px; d = DeviceImage.from_host(h); keep.append(d)
+                capi.check(lib.vpp_video_extruder_push_frame(ve, P(d.desc), ctypes.byref(par), capi.stream_ptr()))
+        states.append(ve_state(ve)); lib.vpp_video_extruder_destroy(ve)
+    ok = states[0][0] == states[1][0] and all(np.array_equal(a_, b_) for a_, b_ in zip(states[0][1:], states[1][1:]))
+    print(f"tracker {nr}x{nc} x{chn} {'host' if host else 'hbm'} th={par.detector_th} spacing={par.keypoint_spacing} period={par.detector_period} scales={par.nscales} ws={par.winsize} "
+          f"prop={par.propagation}: {len(states[0][1])} entries, {int((states[0][3] > 0).sum())} alive {'ok' if ok else 'MISMATCH'}"); bad += not ok
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
