@@ -1,6 +1,7 @@
 // vpp.hh — umbrella header of the vpp-shaped C++ surface (reference: vpp/vpp.hh).
 #pragma once
 #include <iostream>   // the reference's umbrella header brings it in (its tests print without including it)
+#include <unistd.h>   // likewise (through Eigen / OpenMP there): benchmarks/image_iterations.cc:90 calls ::getpid() with no include of its own
 #include <vpp/core/vector.hh>
 #include <vpp/core/boxNd.hh>
 #include <vpp/core/imageNd.hh>
