@@ -326,16 +326,30 @@ __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa
 // walk) — the sequential rule "replace on strictly smaller" keeps the FIRST of equal minima, and a candidate that the sequential walk
 // would cut short (its early-out threshold is the running best there, the step's starting best here) is one that cannot win in either
 // form: same flow, same distance.  One lane per keypoint left 1180 waves of 28 dependent window SADs each on a 4K frame.
-template <int WS>
+// BYCELL: a group per flow-map cell instead of per keypoint — the same set of descents (a cell's owner is the keypoint that descends for it), launched
+// where the cells are fewer than the keypoints (coarse scales: several keypoints share a cell and all but the owner would leave at once, yet their
+// groups occupied 3/4 of every wave of the coarsest scale).
+template <int WS, bool BYCELL = false>
 __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
                                                                 DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi) {
   __shared__ uint4 s_union[8][kUnionRows];   // per group: the (WS + 2)-row patch of the current search step
-  const int i = blockIdx.x * 8 + (threadIdx.x >> 3), j = threadIdx.x & 7;
+  const int grp = blockIdx.x * 8 + (threadIdx.x >> 3), j = threadIdx.x & 7;
+  int i = grp;
+  if constexpr (BYCELL) {
+    if (grp >= owner.nr * owner.nc) return;
+    const int c0 = grp / owner.nc, c1 = grp - c0 * owner.nc;
+    if (c0 < cell_lo || c0 >= cell_hi) return;
+    const uint32_t o = owner.row<uint32_t>(c0)[c1];
+    if (o == 0xFFFFFFFFu) return;   // nobody claimed the cell
+    i = (int)o;
+  }
   if (i >= n) return;
   const int p0 = kps[2 * i] / scale_div, p1 = kps[2 * i + 1] / scale_div;  // :116
   const int pf0 = p0 / patch, pf1 = p1 / patch;
-  if (pf0 < cell_lo || pf0 >= cell_hi) return;
-  if (!owner.has(pf0, pf1) || owner.row<uint32_t>(pf0)[pf1] != (uint32_t)i) return;  // :120 — first keypoint in index order claims
+  if constexpr (!BYCELL) {
+    if (pf0 < cell_lo || pf0 >= cell_hi) return;
+    if (!owner.has(pf0, pf1) || owner.row<uint32_t>(pf0)[pf1] != (uint32_t)i) return;  // :120 — first keypoint in index order claims
+  }
   int pr0 = p0, pr1 = p1;
   if (has_coarse) {  // multiscale prediction, :126-128
     const int pfm0 = p0 / (2 * patch), pfm1 = p1 / (2 * patch);
@@ -866,7 +880,11 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
           VPP_HIP_TRY(hipMemsetAsync(OW(k, scale).first_pixel, 0xFF, (size_t)OW(k, scale).pitch * OW(k, scale).nrows, sk));
         }
         if (!claim_up_front) sdof_claim_kernel<<<(n + 255) / 256, 256, 0, sk>>>(kps, n, scale_div, patchsize, dimg(&OW(k, scale)), lo, hi);
-        if (tuning("sdof.descent_lanes", 8) == 8)
+        const long long cells = (long long)OW(k, scale).nrows * OW(k, scale).ncols;
+        if (tuning("sdof.descent_lanes", 8) == 8 && cells * 2 <= n && tuning("sdof.descent_bycell", 1))
+          sdof_descent_group_kernel<WS, true><<<(unsigned)((cells + 7) / 8), 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
+                                                                                         maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi);
+        else if (tuning("sdof.descent_lanes", 8) == 8)
           sdof_descent_group_kernel<WS><<<(n + 7) / 8, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
                                                                     maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi);
         else
