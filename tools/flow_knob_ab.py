@@ -7,6 +7,7 @@ import numpy as np, torch
 from vpp_amd.synth import P, u8_image, DeviceImage, flow_scene
 from vpp_amd import capi
 V = ctypes.c_void_p
+if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]  # A/B of two builds in one call
 knob = sys.argv[1].encode(); values = [int(x) for x in sys.argv[2:]]
 lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
 for shape, spacing in (((2160, 3840), 10), ((2160, 3840), 5), ((1080, 1920), 10)):

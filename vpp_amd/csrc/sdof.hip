@@ -271,25 +271,30 @@ __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa
       wave_lds_fence();
     }
     // sad_distance of the keypoint's window against the window centred (dr, dc) from the step's centre, cut out of the staged patch
-    auto sad_at = [&](int dr, int dc, int th) -> int {
+    // The full sum, without sad_distance's row-wise early-out (:30-38): a candidate that the early-out would cut short has a partial sum above the
+    // running best already, its full sum is larger still, and either way it is only ever compared `< best` — same decisions, and every distance that is
+    // stored belongs to an accepted candidate, whose sum was never cut.  (The test per row was a compare, an exec-mask update and a branch that a wave of
+    // 64 candidates practically never takes.)  A window of 4k + 1 bytes ends with a single byte that lies inside one dword of the row for every shift:
+    // one bit-field extract instead of a byte-align and a mask.
+    auto sad_at = [&](int dr, int dc, int) -> int {
       const uint32_t o = (uint32_t)(1 + dc);
-      int err = 0;
+      uint32_t err = 0;
 #pragma unroll
       for (int r = 0; r < WS; r++) {
         const uint4 q = slot[1 + dr + r];
-        if (err <= th) {
-          const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-          uint32_t err2 = 0;
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-          for (int d = 0; d < ND; d++) {
+        for (int d = 0; d < ND; d++) {
+          if (d == ND - 1 && WS % 4 == 1) {
+            err = __builtin_amdgcn_sad_u8(wa.d[r][d] & tail_mask, __builtin_amdgcn_ubfe(w[d], 8u * o, 8u), err);
+          } else {
             const uint32_t m = d == ND - 1 ? tail_mask : 0xFFFFFFFFu;
             const uint32_t b = __builtin_amdgcn_alignbyte(w[d + 1], w[d], o);
-            err2 = __builtin_amdgcn_sad_u8(wa.d[r][d] & m, b & m, err2);
+            err = __builtin_amdgcn_sad_u8(wa.d[r][d] & m, b & m, err);
           }
-          err += (int)err2;
         }
       }
-      return err;
+      return (int)err;
     };
     if (!have_start) {
       match_distance = staged ? (i2.has(pr0, pr1) ? sad_at(0, 0, INT_MAX) : INT_MAX) : dist(pr0, pr1, INT_MAX);
