@@ -173,13 +173,14 @@ __global__ __launch_bounds__(256) void sdof_claim_all_kernel(const int32_t* __re
 
 template <int WS>
 __global__ __launch_bounds__(64) void sdof_descent_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
-                                                          DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi) {
+                                                          DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi, int clean_owner) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   const int p0 = kps[2 * i] / scale_div, p1 = kps[2 * i + 1] / scale_div;  // :116
   const int pf0 = p0 / patch, pf1 = p1 / patch;
   if (pf0 < cell_lo || pf0 >= cell_hi) return;
   if (!owner.has(pf0, pf1) || owner.row<uint32_t>(pf0)[pf1] != (uint32_t)i) return;  // :120 — first keypoint in index order claims
+  if (clean_owner) owner.row<uint32_t>(pf0)[pf1] = 0xFFFFFFFFu;   // (see sdof_descent_group_kernel)
   int pr0 = p0, pr1 = p1;
   if (has_coarse) {  // multiscale prediction, :126-128
     const int pfm0 = p0 / (2 * patch), pfm1 = p1 / (2 * patch);
@@ -336,7 +337,7 @@ __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa
 // groups occupied 3/4 of every wave of the coarsest scale).
 template <int WS, bool BYCELL = false>
 __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
-                                                                DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi) {
+                                                                DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi, int clean_owner) {
   __shared__ uint4 s_union[8][kUnionRows];   // per group: the (WS + 2)-row patch of the current search step
   const int grp = blockIdx.x * 8 + (threadIdx.x >> 3), j = threadIdx.x & 7;
   int i = grp;
@@ -355,6 +356,9 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
     if (pf0 < cell_lo || pf0 >= cell_hi) return;
     if (!owner.has(pf0, pf1) || owner.row<uint32_t>(pf0)[pf1] != (uint32_t)i) return;  // :120 — first keypoint in index order claims
   }
+  // clean_owner: the cell's one owner hands the owner map back empty (every lane of the group has read the entry: one wave, program order; the cell's other
+  // keypoints compare against their own index and leave on either value) — the next call finds the maps as a reset would leave them
+  if (clean_owner && j == 0) owner.row<uint32_t>(pf0)[pf1] = 0xFFFFFFFFu;
   int pr0 = p0, pr1 = p1;
   if (has_coarse) {  // multiscale prediction, :126-128
     const int pfm0 = p0 / (2 * patch), pfm1 = p1 / (2 * patch);
@@ -723,6 +727,26 @@ __global__ __launch_bounds__(256) void sdof_reset_kernel(ResetArgs a) {
   const uint32_t u = (blockIdx.x - a.first_block[sgm]) * 256 + threadIdx.x;
   if (u < a.units[sgm]) { const uint32_t v = a.value[sgm]; a.p[sgm][u] = make_uint4(v, v, v, v); }
 }
+// The mark maps' reset and the claims of every scale in ONE launch: the first blocks fill the mark blocks, the others claim — the two touch different maps.
+// The owner maps need no reset here: every descent hands its cell back empty (clean_owner), so a call finds them as the previous one left them.
+__global__ __launch_bounds__(256) void sdof_reset_claim_kernel(ResetArgs a, const int32_t* __restrict__ kps, int n, int patch, ClaimAll c) {
+  const uint32_t reset_blocks = a.first_block[a.nseg];
+  if (blockIdx.x < reset_blocks) {
+    int sgm = 0;
+    while (sgm + 1 < a.nseg && blockIdx.x >= a.first_block[sgm + 1]) sgm++;
+    const uint32_t u = (blockIdx.x - a.first_block[sgm]) * 256 + threadIdx.x;
+    if (u < a.units[sgm]) { const uint32_t v = a.value[sgm]; a.p[sgm][u] = make_uint4(v, v, v, v); }
+    return;
+  }
+  const int i = (int)(blockIdx.x - reset_blocks) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k0 = kps[2 * i], k1 = kps[2 * i + 1];
+  for (int s = c.first; s <= c.last; s++) {
+    const int div = 1 << s;
+    const int pf0 = (k0 / div) / patch, pf1 = (k1 / div) / patch;
+    if (c.owner[s].has(pf0, pf1)) atomicMin(c.owner[s].row<uint32_t>(pf0) + pf1, (uint32_t)i);
+  }
+}
 
 }  // namespace
 
@@ -848,21 +872,36 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   auto maps = [&](int k, int s_) { return Maps{dimg(&FL(k, s_)), dimg(&MK(k, s_)), dimg(&DM(k, s_))}; };
   // single strip: the mark and owner maps of all scales are reset here in one launch (nothing writes a scale's maps before its own phase)
   const bool reset_up_front = nstrips == 1 && 2 * (nscales - min_scale) <= 16 && tuning("sdof.reset_up_front", 1);
+  const bool claim_up_front = reset_up_front && world == 1 && tuning("sdof.claim_up_front", 1);
+  // Self-cleaning owner maps (single strip, single rank): every descent hands its cell back empty, so the owner maps are not part of the reset and the
+  // mark reset shares ONE launch with the claims.  The slot's note says whether the maps of this layout were left clean by a call that ran to its end;
+  // anything else (first use, another layout, another code path, a call that returned early) gets a plain 0xFF fill first.
+  const bool self_cleaning = claim_up_front && tuning("sdof.self_cleaning_owner", 1);
+  Scratch::Slot& slot = *g_scratch.cur;
+  unsigned long long owner_sig = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(nscales * 16 + min_scale);
+  for (int s_ = min_scale; s_ < nscales; s_++) owner_sig = (owner_sig * 1099511628211ull) ^ ((unsigned long long)ow_off[s_] << 20) ^ (unsigned long long)ow_bytes[s_];
+  const bool owner_known_clean = self_cleaning && slot.user[1] == owner_sig;
+  slot.user[1] = 0;   // until this call has queued every descent
   if (reset_up_front) {
     ResetArgs ra; ra.nseg = 0; uint32_t blocks = 0;
     for (int s_ = min_scale; s_ < nscales; s_++)
-      for (int w = 0; w < 2; w++) {
+      for (int w = 0; w < (self_cleaning ? 1 : 2); w++) {
         const int q = ra.nseg++;
         ra.p[q] = (uint4*)((uint8_t*)g_scratch.p + (w ? ow_off[s_] : mk_off[s_]));
         ra.units[q] = (uint32_t)((w ? ow_bytes[s_] : mk_bytes[s_]) / 16); ra.value[q] = w ? 0xFFFFFFFFu : 0u;
         ra.first_block[q] = blocks; blocks += (ra.units[q] + 255) / 256;
       }
     ra.first_block[ra.nseg] = blocks;
-    sdof_reset_kernel<<<blocks, 256, 0, st>>>(ra);
+    if (self_cleaning) {
+      if (!owner_known_clean)
+        for (int s_ = min_scale; s_ < nscales; s_++) VPP_HIP_TRY(hipMemsetAsync((uint8_t*)g_scratch.p + ow_off[s_], 0xFF, ow_bytes[s_], st));
+      ClaimAll ca; ca.first = min_scale; ca.last = nscales - 1;
+      for (int s_ = min_scale; s_ < nscales; s_++) ca.owner[s_] = dimg(&OW(0, s_));
+      sdof_reset_claim_kernel<<<blocks + (unsigned)((n + 255) / 256), 256, 0, st>>>(ra, kps, n, patchsize, ca);
+    } else sdof_reset_kernel<<<blocks, 256, 0, st>>>(ra);
     VPP_LAUNCH_CHECK();
   }
-  const bool claim_up_front = reset_up_front && world == 1 && tuning("sdof.claim_up_front", 1);
-  if (claim_up_front) {
+  if (claim_up_front && !self_cleaning) {
     ClaimAll ca; ca.first = min_scale; ca.last = nscales - 1;
     for (int s_ = min_scale; s_ < nscales; s_++) ca.owner[s_] = dimg(&OW(0, s_));
     sdof_claim_all_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize, ca);
@@ -888,13 +927,13 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
         const long long cells = (long long)OW(k, scale).nrows * OW(k, scale).ncols;
         if (tuning("sdof.descent_lanes", 8) == 8 && cells * 2 <= n && tuning("sdof.descent_bycell", 1))
           sdof_descent_group_kernel<WS, true><<<(unsigned)((cells + 7) / 8), 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                                                         maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi);
+                                                                                         maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0);
         else if (tuning("sdof.descent_lanes", 8) == 8)
           sdof_descent_group_kernel<WS><<<(n + 7) / 8, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                                    maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi);
+                                                                    maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0);
         else
           sdof_descent_kernel<WS><<<(n + 63) / 64, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                               maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi);
+                                                               maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0);
         return VPP_OK;
       };
       if (nstrips > 1) VPP_HIP_TRY(hipEventRecord(g_strips.start, st));   // the pyramids / the previous scale's broadcast are behind this point
@@ -958,6 +997,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   const int ms = 1 << min_scale;
   sdof_readback_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize * ms, ms, maps(0, min_scale), out_pos, out_dist, out_valid);
   VPP_LAUNCH_CHECK();
+  if (self_cleaning) slot.user[1] = owner_sig;   // every descent of this call is queued: the owner maps of this layout end up empty
   return VPP_OK;
 }
 
