@@ -351,7 +351,7 @@ template <int CH> struct GrayFast {   // rgb_to_graylevel of four pixels (GraySr
 struct Swar3 { Chain ch; int TX, TY, tx_lo, tx_hi, ty_lo, ty_hi, tiles_x8; };
 
 template <class FAST, class SRC>
-__global__ __launch_bounds__(256) void pyramid_swar3_kernel(Swar3 a) {
+__device__ __forceinline__ void pyramid_swar3_body(const Swar3& a, const int bid) {
   constexpr int R0 = 41, W0 = 22, G1 = 10, R1 = 19, G2 = 4;   // level-0 patch rows / dwords per row, level-1 groups per row / patch rows, level-2 groups
   int ty, tx;
   {
@@ -359,14 +359,14 @@ __global__ __launch_bounds__(256) void pyramid_swar3_kernel(Swar3 a) {
     // that chain was the whole kernel's critical path at 1080p); then the interior tiles
     const int wi = a.tx_hi - a.tx_lo, n_top = a.ty_lo * a.TX, n_mid = (a.ty_hi - a.ty_lo) * (a.TX - wi), n_bot = (a.TY - a.ty_hi) * a.TX;
     const int n_edge = n_top + n_mid + n_bot;
-    const bool interior = (int)blockIdx.x >= 2 * n_edge;
-    int q = interior ? (int)blockIdx.x - 2 * n_edge : (int)blockIdx.x >> 1;
+    const bool interior = bid >= 2 * n_edge;
+    int q = interior ? bid - 2 * n_edge : bid >> 1;
     if (interior) { const int row = q / wi; ty = a.ty_lo + row; tx = a.tx_lo + (q - row * wi); }
     else if (q < n_top) { ty = q / a.TX; tx = q - ty * a.TX; }
     else if (q < n_top + n_mid) { q -= n_top; const int row = q / (a.TX - wi), k = q - row * (a.TX - wi); ty = a.ty_lo + row; tx = k < a.tx_lo ? k : k + wi; }
     else { q -= n_top + n_mid; const int row = q / a.TX; ty = a.ty_hi + row; tx = q - row * a.TX; }
     if (!interior) {   // a tile that touches an edge: the tile kernel's path
-      const int tx8 = 2 * tx + ((int)blockIdx.x & 1);
+      const int tx8 = 2 * tx + (bid & 1);
       if (tx8 < a.tiles_x8) chain_tile<uint8_t, int, 1, 8, SRC, 3, true>(a.ch, ty, tx8);
       return;
     }
@@ -424,10 +424,19 @@ void swar3_axis(int n0, int n1, int n2, int b0, int b1, int b2, int step2, int l
   *lo = l; *hi = h;
 }
 template <class FAST, class SRC>
-bool launch_swar3(const vpp_image_desc* levels, const vpp_image_desc* src, hipStream_t st) {
+__global__ __launch_bounds__(256) void pyramid_swar3_kernel(Swar3 a) { pyramid_swar3_body<FAST, SRC>(a, (int)blockIdx.x); }
+// two pyramids of one geometry in one launch (the two frames of a flow call): the second pyramid's tiles follow the first's
+template <class FAST, class SRC>
+__global__ __launch_bounds__(256) void pyramid_swar3_pair_kernel(Swar3 a, Swar3 b, int blocks_a) {
+  if ((int)blockIdx.x < blocks_a) pyramid_swar3_body<FAST, SRC>(a, (int)blockIdx.x);
+  else pyramid_swar3_body<FAST, SRC>(b, (int)blockIdx.x - blocks_a);
+}
+
+// the packed kernel's arguments for one pyramid; false: unaligned levels or no interior tile (the tile kernel takes the pyramid); *blocks = its grid
+inline bool swar3_args(const vpp_image_desc* levels, const vpp_image_desc* src, Swar3* out, int* blocks) {
   auto al4 = [](const vpp_image_desc& d) { return ((uintptr_t)d.first_pixel & 3) == 0 && (d.pitch & 3) == 0; };
   if (!(al4(levels[0]) && al4(levels[1]) && al4(levels[2]) && al4(*src))) return false;
-  Swar3 a;
+  Swar3& a = *out;
   for (int l = 0; l < 3; l++) a.ch.lv[l] = dimg(&levels[l]);
   a.ch.src = dimg(src); a.ch.nlevels = 3;
   a.TY = (levels[2].nrows + 7) / 8; a.TX = (levels[2].ncols + 15) / 16; a.tiles_x8 = (levels[2].ncols + 7) / 8;
@@ -435,7 +444,14 @@ bool launch_swar3(const vpp_image_desc* levels, const vpp_image_desc* src, hipSt
   swar3_axis(levels[0].ncols, levels[1].ncols, levels[2].ncols, levels[0].border, levels[1].border, levels[2].border, 16, 12, 88, a.TX, &a.tx_lo, &a.tx_hi);
   if (a.ty_hi <= a.ty_lo || a.tx_hi <= a.tx_lo) return false;   // no interior tile: the tile kernel
   const int n_int = (a.ty_hi - a.ty_lo) * (a.tx_hi - a.tx_lo), n_edge = a.TY * a.TX - n_int;
-  pyramid_swar3_kernel<FAST, SRC><<<2 * n_edge + n_int, 256, 0, st>>>(a);
+  *blocks = 2 * n_edge + n_int;
+  return true;
+}
+template <class FAST, class SRC>
+bool launch_swar3(const vpp_image_desc* levels, const vpp_image_desc* src, hipStream_t st) {
+  Swar3 a; int blocks = 0;
+  if (!swar3_args(levels, src, &a, &blocks)) return false;
+  pyramid_swar3_kernel<FAST, SRC><<<blocks, 256, 0, st>>>(a);
   return true;
 }
 
@@ -485,6 +501,27 @@ int vpp_pyramid_build(const vpp_image_desc* levels, int nlevels, const vpp_image
   if (rc != VPP_OK) return rc;
   rc = vpp_fill_border(&levels[0], VPP_BORDER_MIRROR, nullptr, stream);
   for (int l = 1; l < nlevels && rc == VPP_OK; l++) rc = vpp_pyr_down(&levels[l], &levels[l - 1], stream);
+  return rc;
+}
+
+// Two pyramids of one geometry (the two frames of a flow call) in ONE launch when both take the packed kernel; otherwise two vpp_pyramid_build calls.
+// Internal (sdof.hip): not part of include/vpp_amd.h.
+int vpp_pyramid_build_pair(const vpp_image_desc* levels_a, const vpp_image_desc* src_a, const vpp_image_desc* levels_b, const vpp_image_desc* src_b, int nlevels, void* stream) {
+  hipStream_t st = as_stream(stream);
+  if (nlevels == 3 && levels_a && levels_b && src_a && src_b && tuning("pyr.fused", 1) && tuning("pyr.swar", 1) && tuning("pyr.pair", 1)) {
+    bool ok = true;
+    for (int l = 0; l < 3 && ok; l++) ok = valid_desc(&levels_a[l]) && valid_desc(&levels_b[l]) && same_type(&levels_a[l], src_a) && same_type(&levels_b[l], src_b);
+    ok = ok && valid_desc(src_a) && valid_desc(src_b) && src_a->dtype == VPP_U8 && src_a->channels == 1 && src_b->dtype == VPP_U8 && src_b->channels == 1 &&
+         same_domain(&levels_a[0], src_a) && same_domain(&levels_b[0], src_b) && chain_shape_ok(levels_a, 3) && chain_shape_ok(levels_b, 3);
+    Swar3 a, b; int na = 0, nb = 0;
+    if (ok && swar3_args(levels_a, src_a, &a, &na) && swar3_args(levels_b, src_b, &b, &nb)) {
+      pyramid_swar3_pair_kernel<CopyFast, CopySrc<uint8_t, 1>><<<na + nb, 256, 0, st>>>(a, b, na);
+      VPP_LAUNCH_CHECK();
+      return VPP_OK;
+    }
+  }
+  int rc = vpp_pyramid_build(levels_a, nlevels, src_a, stream);
+  if (rc == VPP_OK) rc = vpp_pyramid_build(levels_b, nlevels, src_b, stream);
   return rc;
 }
 

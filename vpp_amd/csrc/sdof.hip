@@ -781,6 +781,8 @@ int copy_rows(const vpp_image_desc* dst, const vpp_image_desc* src, int lo, int 
 }
 }  // namespace
 
+extern "C" int vpp_pyramid_build_pair(const vpp_image_desc* levels_a, const vpp_image_desc* src_a, const vpp_image_desc* levels_b, const vpp_image_desc* src_b, int nlevels, void* stream);   // pyramid_fused.hip
+
 namespace {
 // comm != nullptr: one process per GPU (vpp_semi_dense_optical_flow_sharded).  Rank g owns the flow-map rows [g per, (g + 1) per) of every
 // scale (per = ceil(rows / ranks)): it claims and descends only the keypoints of its rows, the ranks' rows of the three maps are then
@@ -866,8 +868,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
       B1[s_] = P1[s_]; B2[s_] = P2[s_];
       B1[s_].border = B2[s_].border = std::min(P1[s_].border, std::max(winsize / 2, 2));
     }
-    rc = vpp_pyramid_build(B1, nscales, i1, stream); if (rc) return rc;
-    rc = vpp_pyramid_build(B2, nscales, i2, stream); if (rc) return rc;
+    rc = vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream); if (rc) return rc;   // one launch for both when the packed kernel takes them
   }
   auto maps = [&](int k, int s_) { return Maps{dimg(&FL(k, s_)), dimg(&MK(k, s_)), dimg(&DM(k, s_))}; };
   // single strip: the mark and owner maps of all scales are reset here in one launch (nothing writes a scale's maps before its own phase)
