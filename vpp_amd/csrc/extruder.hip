@@ -52,7 +52,11 @@ struct vpp_video_extruder {
   bool consumed_set[2] = {false, false};
 };
 
-namespace vpp_amd { int keypoint_mask_squares(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, hipStream_t st); }
+namespace vpp_amd {
+int keypoint_mask_squares(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, hipStream_t st);
+int sdof_flow_linked(const vpp_image_desc* i1, const vpp_image_desc* i2, const vpp_image_desc* pyr1, const vpp_image_desc* pyr2, const int32_t* kps, int n, int winsize, int nscales,
+                     int propagation, int patchsize, int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, const MergeLinkArgs* link, size_t link_head_units, void* stream);   // sdof.hip
+}
 
 namespace {
 
@@ -324,14 +328,16 @@ static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
   }
   const int c = ve->cur, n = ve->n;
   if (n > 0) {
-    if (pyr1) rc = vpp_semi_dense_optical_flow_pyramids(pyr1, pyr2, p->nscales, ve->pos[c], n, p->winsize, 0, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, stream);
-    else rc = vpp_semi_dense_optical_flow(frame1, frame2, ve->pos[c], n, p->winsize, p->nscales, 0, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, stream);
+    // the flow, with the merge's first pass (video_extruder.hpp:60-84: every keypoint threaded onto its cell's list) folded into its read-back launch
+    // and the lists' heads reset beside the flow maps: two launches fewer per update than flow + heads reset + link
+    MergeLinkArgs link; size_t head_units = 0;
+    rc = keypoint_merge_prepare(ve->age[c], n, ve->nrows, ve->ncols, p->keypoint_spacing, &link, &head_units, st);
+    if (rc != VPP_OK) return rc;
+    rc = sdof_flow_linked(frame1, frame2, pyr1, pyr2, ve->pos[c], n, p->winsize, p->nscales, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, &link, head_units, stream);
     if (rc != VPP_OK) return rc;
     VPP_REQUIRE(frame2->dtype == VPP_U8 && frame2->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_video_extruder_step: u8 x1 frames only");
     VPP_REQUIRE(frame2->border >= 3, VPP_ERR_BORDER_TOO_SMALL, "Image need a border of 3px at least for the FAST detector");
-    MergeLists lists;
-    rc = keypoint_merge_link(ve->fpos, ve->pos[c], ve->fvalid, ve->age[c], n, ve->nrows, ve->ncols, p->keypoint_spacing, &lists, st);
-    if (rc != VPP_OK) return rc;
+    const MergeLists lists{link.head, link.next, link.age_now, link.cell_of};
     if (detect) ve_finish_kernel<false><<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, lists, dimg(frame2), p->detector_th, ve->tring[c],
                                                                            ve->thead[c], ve->tlen[c], ve->talive[c], ve->ring, p->max_trajectory_length);
     else ve_finish_kernel<true><<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, lists, dimg(frame2), p->detector_th, ve->tring[c],

@@ -13,6 +13,7 @@
 //     independent, one barrier per step) is kept as an independent on-device cross-check (tuning sdof.propagate = 1).
 // Integer arithmetic throughout: bit-exact.  SAD windows are L2-resident; the path is integer-VALU / latency bound.
 #include "common.hpp"
+#include "tracker_device.hpp"
 #include <climits>
 #include <vector>
 #include <algorithm>
@@ -689,8 +690,11 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
   }
 }
 
+// LINK (the tracker's step): the keypoint's match is also threaded onto the merge step's per-cell list (merge_link_one: the first pass of
+// video_extruder.hpp:60-84 needs exactly what this thread holds — the keypoint's old and new position and whether it matched)
+template <bool LINK>
 __global__ __launch_bounds__(256) void sdof_readback_kernel(const int32_t* __restrict__ kps, int n, int div, int ms, Maps m,
-                                                            int32_t* __restrict__ out_pos, int32_t* __restrict__ out_dist, uint8_t* __restrict__ out_valid) {
+                                                            int32_t* __restrict__ out_pos, int32_t* __restrict__ out_dist, uint8_t* __restrict__ out_valid, MergeLinkArgs link) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int k0 = kps[2 * i], k1 = kps[2 * i + 1];
@@ -701,6 +705,7 @@ __global__ __launch_bounds__(256) void sdof_readback_kernel(const int32_t* __res
     o0 = k0 + f[0] * ms; o1 = k1 + f[1] * ms; d = m.dist.row<int32_t>(q0)[q1]; v = 1;  // :210-211
   }
   out_pos[2 * i] = o0; out_pos[2 * i + 1] = o1; out_dist[i] = d; out_valid[i] = v;
+  if constexpr (LINK) merge_link_one(link, i, o0, o1, k0, k1, v != 0);
 }
 
 thread_local Scratch g_scratch;
@@ -791,7 +796,9 @@ namespace {
 // deterministic and cost a few tens of microseconds, less than broadcasting their result.  Frames and pyramids are replicated.
 int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
               int nscales, int min_scale, int propagation, int patchsize, int nstrips, vpp_comm* comm, int32_t* out_pos,
-              int32_t* out_dist, uint8_t* out_valid, void* stream, const vpp_image_desc* pre1 = nullptr, const vpp_image_desc* pre2 = nullptr) {
+              int32_t* out_dist, uint8_t* out_valid, void* stream, const vpp_image_desc* pre1 = nullptr, const vpp_image_desc* pre2 = nullptr,
+              const MergeLinkArgs* link = nullptr, size_t link_head_units = 0) {
+  // link != nullptr (the tracker): the merge lists' heads are reset with the maps and the read-back threads every match onto its cell's list
   // pre1 / pre2 != nullptr (vpp_semi_dense_optical_flow_pyramids): the caller's pyramids of the two frames are used as they are, i1 / i2 are their levels 0
   VPP_REQUIRE(valid_desc(i1) && valid_desc(i2) && same_domain(i1, i2), VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: invalid frames");
   VPP_REQUIRE(i1->dtype == VPP_U8 && i1->channels == 1 && i2->dtype == VPP_U8 && i2->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_semi_dense_optical_flow: u8 x1 frames only");
@@ -872,7 +879,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   }
   auto maps = [&](int k, int s_) { return Maps{dimg(&FL(k, s_)), dimg(&MK(k, s_)), dimg(&DM(k, s_))}; };
   // single strip: the mark and owner maps of all scales are reset here in one launch (nothing writes a scale's maps before its own phase)
-  const bool reset_up_front = nstrips == 1 && 2 * (nscales - min_scale) <= 16 && tuning("sdof.reset_up_front", 1);
+  const bool reset_up_front = nstrips == 1 && 2 * (nscales - min_scale) + 1 <= 16 && tuning("sdof.reset_up_front", 1);
   const bool claim_up_front = reset_up_front && world == 1 && tuning("sdof.claim_up_front", 1);
   // Self-cleaning owner maps (single strip, single rank): every descent hands its cell back empty, so the owner maps are not part of the reset and the
   // mark reset shares ONE launch with the claims.  The slot's note says whether the maps of this layout were left clean by a call that ran to its end;
@@ -892,6 +899,11 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
         ra.units[q] = (uint32_t)((w ? ow_bytes[s_] : mk_bytes[s_]) / 16); ra.value[q] = w ? 0xFFFFFFFFu : 0u;
         ra.first_block[q] = blocks; blocks += (ra.units[q] + 255) / 256;
       }
+    if (link) {   // the merge lists' heads (-1), beside the mark maps
+      const int q = ra.nseg++;
+      ra.p[q] = (uint4*)link->head; ra.units[q] = (uint32_t)link_head_units; ra.value[q] = 0xFFFFFFFFu;
+      ra.first_block[q] = blocks; blocks += (ra.units[q] + 255) / 256;
+    }
     ra.first_block[ra.nseg] = blocks;
     if (self_cleaning) {
       if (!owner_known_clean)
@@ -996,7 +1008,14 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
     VPP_LAUNCH_CHECK();
   }
   const int ms = 1 << min_scale;
-  sdof_readback_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize * ms, ms, maps(0, min_scale), out_pos, out_dist, out_valid);
+  if (link) {
+    if (!reset_up_front) {   // no up-front reset launch on this path: the heads get their own
+      ResetArgs rh; rh.nseg = 1; rh.p[0] = (uint4*)link->head; rh.units[0] = (uint32_t)link_head_units; rh.value[0] = 0xFFFFFFFFu; rh.first_block[0] = 0;
+      rh.first_block[1] = (rh.units[0] + 255) / 256;
+      sdof_reset_kernel<<<rh.first_block[1], 256, 0, st>>>(rh);
+    }
+    sdof_readback_kernel<true><<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize * ms, ms, maps(0, min_scale), out_pos, out_dist, out_valid, *link);
+  } else sdof_readback_kernel<false><<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize * ms, ms, maps(0, min_scale), out_pos, out_dist, out_valid, MergeLinkArgs{});
   VPP_LAUNCH_CHECK();
   if (self_cleaning) slot.user[1] = owner_sig;   // every descent of this call is queued: the owner maps of this layout end up empty
   return VPP_OK;
@@ -1022,6 +1041,15 @@ extern "C" int vpp_semi_dense_optical_flow_pyramids(const vpp_image_desc* pyr1, 
   VPP_REQUIRE(pyr1 && pyr2 && nscales >= 1, VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow_pyramids: null pyramid");
   return flow_impl(&pyr1[0], &pyr2[0], kps, n, winsize, nscales, min_scale, propagation, patchsize, 1, nullptr, out_pos, out_dist, out_valid, stream, pyr1, pyr2);
 }
+
+// The tracker's flow (extruder.hip): over the frames (pyr1 == nullptr) or over its own pyramids, with the merge step's first pass folded in.
+namespace vpp_amd {
+int sdof_flow_linked(const vpp_image_desc* i1, const vpp_image_desc* i2, const vpp_image_desc* pyr1, const vpp_image_desc* pyr2, const int32_t* kps, int n, int winsize, int nscales,
+                     int propagation, int patchsize, int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, const MergeLinkArgs* link, size_t link_head_units, void* stream) {
+  return flow_impl(pyr1 ? &pyr1[0] : i1, pyr1 ? &pyr2[0] : i2, kps, n, winsize, nscales, 0, propagation, patchsize, 1, nullptr, out_pos, out_dist, out_valid, stream, pyr1, pyr2, link,
+                   link_head_units);
+}
+}  // namespace vpp_amd
 
 extern "C" int vpp_semi_dense_optical_flow_sharded(vpp_comm* comm, const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
                                                    int nscales, int min_scale, int propagation, int patchsize, int32_t* out_pos,

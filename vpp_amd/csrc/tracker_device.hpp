@@ -39,6 +39,22 @@ __device__ __forceinline__ bool merge_removes(const MergeLists& m, int i) {
   return (earlier && a <= E) ? (a < E) : (L > a);
 }
 
+// Pass 1 of the merge for ONE keypoint (merge_link_kernel, video.hip; also run by the flow's read-back kernel for the tracker, sdof.hip): the keypoint's age
+// after the match callback (keypoint_container::move :51 / remove :52) and its cell, then threaded onto the cell's list by an atomic exchange of the head.
+struct MergeLinkArgs { const int32_t* age_prev; int nr, nc, spacing, gr, gc; int32_t *head, *next, *age_now, *cell_of; };
+__device__ __forceinline__ void merge_link_one(const MergeLinkArgs& a, int i, int moved_r, int moved_c, int prev_r, int prev_c, bool matched) {
+  int r = moved_r, c = moved_c, age = a.age_prev[i];
+  if (matched) {
+    if (r >= 0 && c >= 0 && r < a.nr && c < a.nc) age++;   // keypoint_container::move (:51)
+    else { age = 0; r = prev_r; c = prev_c; }               // remove (:52): dies where it was
+  } else { r = prev_r; c = prev_c; }
+  const int cell = min(max(r / a.spacing, 0), a.gr - 1) * a.gc + min(max(c / a.spacing, 0), a.gc - 1);
+  a.age_now[i] = age; a.cell_of[i] = cell;
+  a.next[i] = atomicExch(&a.head[cell], i);
+}
+// the lists' storage for n keypoints (no launch): head[] must be reset to -1 (head_units16 16-byte units from head) before the first merge_link_one
+int keypoint_merge_prepare(const int32_t* age_prev, int n, int nrows, int ncols, int spacing, MergeLinkArgs* args, size_t* head_units16, hipStream_t st);
+
 // memset of the heads + merge_link_kernel on `st`; the lists stay valid until the next call on the same host thread
 int keypoint_merge_link(const int32_t* rc_moved, const int32_t* rc_prev, const uint8_t* matched, const int32_t* age_prev, int n, int nrows, int ncols, int spacing,
                         MergeLists* lists, hipStream_t st);

@@ -203,14 +203,7 @@ __global__ __launch_bounds__(256) void merge_link_kernel(const int32_t* __restri
                                                          int32_t* __restrict__ head, int32_t* __restrict__ next, int32_t* __restrict__ age_now, int32_t* __restrict__ cell_of) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  int r = moved[2 * i], c = moved[2 * i + 1], age = age_prev[i];
-  if (matched[i]) {
-    if (r >= 0 && c >= 0 && r < nr && c < nc) age++;        // keypoint_container::move (:51)
-    else { age = 0; r = prev[2 * i]; c = prev[2 * i + 1]; } // remove (:52): dies where it was
-  } else { r = prev[2 * i]; c = prev[2 * i + 1]; }
-  const int cell = min(max(r / spacing, 0), gr - 1) * gc + min(max(c / spacing, 0), gc - 1);
-  age_now[i] = age; cell_of[i] = cell;
-  next[i] = atomicExch(&head[cell], i);
+  merge_link_one(MergeLinkArgs{age_prev, nr, nc, spacing, gr, gc, head, next, age_now, cell_of}, i, moved[2 * i], moved[2 * i + 1], prev[2 * i], prev[2 * i + 1], matched[i] != 0);
 }
 __global__ __launch_bounds__(256) void merge_fate_kernel(int n, MergeLists m, uint8_t* __restrict__ removed) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -218,27 +211,34 @@ __global__ __launch_bounds__(256) void merge_fate_kernel(int n, MergeLists m, ui
 }
 
 // head[] = -1 in one launch (hipMemsetAsync of this size is two dispatches of the runtime's fill kernel: head + aligned body, ~4.5 us each in a chain)
-__global__ __launch_bounds__(256) void merge_heads_reset_kernel(int4* __restrict__ head4, int32_t* __restrict__ head, int n4, int n) {
+__global__ __launch_bounds__(256) void merge_heads_reset_kernel(int4* __restrict__ head4, int n4) {
   const int u = blockIdx.x * 256 + threadIdx.x;
   if (u < n4) head4[u] = make_int4(-1, -1, -1, -1);
-  else if (u == n4) for (int k = 4 * n4; k < n; k++) head[k] = -1;
 }
 
 namespace vpp_amd {
-int keypoint_merge_link(const int32_t* rc_moved, const int32_t* rc_prev, const uint8_t* matched, const int32_t* age_prev, int n, int nrows, int ncols, int spacing,
-                        MergeLists* lists, hipStream_t st) {
+int keypoint_merge_prepare(const int32_t* age_prev, int n, int nrows, int ncols, int spacing, MergeLinkArgs* args, size_t* head_units16, hipStream_t st) {
   const int gr = nrows / spacing + 1, gc = ncols / spacing + 1;  // the reference's idx image is (nrows/s) x (ncols/s) with border 1 (:63-64)
-  const size_t cells = (size_t)gr * gc;
+  const size_t cells = ((size_t)gr * gc + 3) / 4 * 4;   // head[] padded to whole 16-byte units
   static thread_local Scratch scratch;  // per host thread, like the FAST / flow scratch
   size_t want = 1 << 20;  // grown in powers of two: the keypoint count creeps up at every re-detection
   while (want < (cells + 3 * (size_t)n) * sizeof(int32_t)) want <<= 1;
   const int rc = scratch.ensure(want, st);
   if (rc != VPP_OK) return rc;
   int32_t *head = (int32_t*)scratch.p, *next = head + cells, *age_now = next + n, *cell_of = age_now + n;
-  { const int n4 = (int)(cells / 4); merge_heads_reset_kernel<<<(n4 + 1 + 255) / 256, 256, 0, st>>>((int4*)head, head, n4, (int)cells); }   // (the scratch block is 256-byte aligned)
-  merge_link_kernel<<<(n + 255) / 256, 256, 0, st>>>(rc_moved, rc_prev, matched, age_prev, n, nrows, ncols, spacing, gr, gc, head, next, age_now, cell_of);
+  *args = MergeLinkArgs{age_prev, nrows, ncols, spacing, gr, gc, head, next, age_now, cell_of};
+  *head_units16 = cells / 4;
+  return VPP_OK;
+}
+int keypoint_merge_link(const int32_t* rc_moved, const int32_t* rc_prev, const uint8_t* matched, const int32_t* age_prev, int n, int nrows, int ncols, int spacing,
+                        MergeLists* lists, hipStream_t st) {
+  MergeLinkArgs a; size_t units = 0;
+  const int rc = keypoint_merge_prepare(age_prev, n, nrows, ncols, spacing, &a, &units, st);
+  if (rc != VPP_OK) return rc;
+  merge_heads_reset_kernel<<<(unsigned)((units + 255) / 256), 256, 0, st>>>((int4*)a.head, (int)units);   // (the scratch block is 256-byte aligned)
+  merge_link_kernel<<<(n + 255) / 256, 256, 0, st>>>(rc_moved, rc_prev, matched, age_prev, n, nrows, ncols, spacing, a.gr, a.gc, a.head, a.next, a.age_now, a.cell_of);
   VPP_LAUNCH_CHECK();
-  *lists = MergeLists{head, next, age_now, cell_of};
+  *lists = MergeLists{a.head, a.next, a.age_now, a.cell_of};
   return VPP_OK;
 }
 }  // namespace vpp_amd
