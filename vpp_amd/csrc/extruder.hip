@@ -200,6 +200,11 @@ __global__ __launch_bounds__(256) void ve_append_kernel(const int32_t* __restric
   head[d] = 0; len[d] = 0; start[d] = frame_id; alive[d] = 1;                                                 // keypoint_trajectory(frame_id)
 }
 
+__global__ __launch_bounds__(256) void ve_fill16_kernel(uint4* __restrict__ p, size_t units, uint32_t v) {
+  const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (u < units) p[u] = make_uint4(v, v, v, v);
+}
+
 template <class T> int dalloc(T** p, size_t count) { void* v = nullptr; const int rc = vpp_malloc(count * sizeof(T), &v); *p = (T*)v; return rc; }
 template <class T> void dfree(T*& p) { if (p) { vpp_free(p); p = nullptr; } }
 
@@ -355,7 +360,7 @@ static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
     }
     vpp_image_desc md{ve->mask + (size_t)s * ve->mask_pitch + s, ve->nrows, ve->ncols, ve->mask_pitch, s, VPP_U8, 1};
     // fill_with_border(mask, 1) (:101): the mask block is the tracker's own, rows and padding: one memset instead of a pass over bordered rows
-    VPP_HIP_TRY(hipMemsetAsync(ve->mask, 1, ve->mask_bytes, st));
+    ve_fill16_kernel<<<(unsigned)((ve->mask_bytes / 16 + 255) / 256), 256, 0, st>>>((uint4*)ve->mask, ve->mask_bytes / 16, 0x01010101u);   // (the runtime's memset is two dispatches)
     rc = keypoint_mask_squares(&md, ve->pos[c], n, s, st);
     if (rc != VPP_OK) return rc;
     // the alive count and the number of keypoints found stay on the device: the kernels behind them read the two words, the host reads its copy
