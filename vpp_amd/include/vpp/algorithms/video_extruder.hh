@@ -206,6 +206,7 @@ void video_extruder_update(video_extruder_ctx& ctx, const image2d<unsigned char>
 // clone(_border = 3) + fill_border_mirror + rgb_to_graylevel + video_extruder_update + copy(frame_gl, prev_frame).  The first frame only becomes
 // `prev` (returns false, like the example's `first`); later calls run one update (return true) whose results are those of video_extruder_update on
 // the mirror-bordered gray frames.  The frame's own border is not read.
+// (A call that changes _nscales / _winsize, or asks for longer trajectories than the tracker's rings hold, starts over: that frame only becomes `prev`.)
 // A frame whose newest pixels are on the host (a decoder wrote them) is handed over as a host frame: the tracker stages it on a copy stream while the
 // previous update still computes (vpp_video_extruder_push_host_frame).  The call returns when the frame has been consumed — the image may be written
 // again — and the update itself completes asynchronously: looking at ctx.keypoints / ctx.trajectories (or any synchronous call) waits for it.
