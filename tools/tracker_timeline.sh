@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/ve_tl
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- $R/benchmarks/video_extruder_bench 2160 3840 9 > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- $R/benchmarks/video_extruder_bench 2160 3840 14 > $OUT/run.log 2>&1
 cd $R
 F=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python - "$F" <<'PY'
@@ -12,7 +12,12 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 fin = [i for i, r in enumerate(rows) if 've_finish_kernel<true>' in r['Kernel_Name'] or 've_finish_kernel<(bool)1>' in r['Kernel_Name']]
-a, b = fin[1] + 1, fin[2]   # the dispatches of the third steady update
+import os
+if os.environ.get("DETECT"):
+    ff = [i for i, r in enumerate(rows) if "ve_finish_kernel<false>" in r["Kernel_Name"]]
+    a = ff[1]; b = [i for i in fin if i > a][0] - 1   # from a re-detection frame's finish kernel to the end of the next steady update's flow
+else:
+    a, b = fin[1] + 1, fin[2]   # the dispatches of the third steady update
 t0 = int(rows[a]['Start_Timestamp']); prev = None
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')

@@ -60,22 +60,6 @@ int sdof_flow_linked(const vpp_image_desc* i1, const vpp_image_desc* i2, const v
 
 namespace {
 
-// dn != nullptr (re-detection frames): the container size is dn[0] + min(dn[1], dcap), n is only the launch's upper bound
-__global__ __launch_bounds__(256) void ve_traj_kernel(int n, const int32_t* __restrict__ dn, int dcap, const int32_t* __restrict__ pos, const int32_t* __restrict__ age, float* __restrict__ ring,
-                                                      int32_t* __restrict__ head, int32_t* __restrict__ len, uint8_t* __restrict__ alive, int slots, int max_len) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (dn) n = dn[0] + min(dn[1], dcap);
-  if (i >= n) return;
-  if (age[i] > 0) {  // move_to + pop_oldest_position (video_extruder.hpp:125-130)
-    const int h = (head[i] + slots - 1) % slots;
-    float* p = ring + ((size_t)i * slots + h) * 2;
-    p[0] = (float)pos[2 * i]; p[1] = (float)pos[2 * i + 1];
-    head[i] = h;
-    int l = len[i] + 1;
-    if (l > max_len) l--;
-    len[i] = l;
-  } else alive[i] = 0;  // die() (:132)
-}
 
 // The rest of an update after the flow and the merge lists, per keypoint and in ONE launch (round 3): the merge's verdict (video_extruder.hpp:60-84),
 // fast9_score at the keypoint's new position (:87-91), the match callback + merge + score cull applied to the container (:48-53), and — on the
@@ -170,39 +154,52 @@ __global__ __launch_bounds__(256) void ve_index_kernel(int n, const int32_t* __r
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void ve_compact_kernel(int n, const int32_t* __restrict__ newidx, const int32_t* __restrict__ pos, const int32_t* __restrict__ vel,
-                                                         const int32_t* __restrict__ age, const float* __restrict__ ring, const int32_t* __restrict__ head,
-                                                         const int32_t* __restrict__ len, const int32_t* __restrict__ start, const uint8_t* __restrict__ alive,
-                                                         int32_t* __restrict__ pos2, int32_t* __restrict__ vel2, int32_t* __restrict__ age2, float* __restrict__ ring2,
-                                                         int32_t* __restrict__ head2, int32_t* __restrict__ len2, int32_t* __restrict__ start2, uint8_t* __restrict__ alive2, int slots) {
-  // one wave per entry group: lane j of a 16-lane group copies ring slots j, j + 16, ...
-  const int i = (blockIdx.x * 256 + threadIdx.x) >> 4, j = threadIdx.x & 15;
-  if (i >= n) return;
-  const int d = newidx[i];
-  if (d < 0) return;
-  if (j == 0) {
-    pos2[2 * d] = pos[2 * i]; pos2[2 * d + 1] = pos[2 * i + 1]; vel2[2 * d] = vel[2 * i]; vel2[2 * d + 1] = vel[2 * i + 1]; age2[d] = age[i];
-    head2[d] = head[i]; len2[d] = len[i]; start2[d] = start[i]; alive2[d] = alive[i];
-  }
-  const float2* src = (const float2*)ring + (size_t)i * slots;
-  float2* dst = (float2*)ring2 + (size_t)d * slots;
-  for (int s = j; s < slots; s += 16) dst[s] = src[s];
-}
-// m = dn[0] compacted entries, count = min(dn[1], dcap) new keypoints (the launch covers dcap)
-__global__ __launch_bounds__(256) void ve_append_kernel(const int32_t* __restrict__ dn, int dcap, const int32_t* __restrict__ det, int32_t* __restrict__ pos, int32_t* __restrict__ vel,
-                                                        int32_t* __restrict__ age, int32_t* __restrict__ head, int32_t* __restrict__ len, int32_t* __restrict__ start,
-                                                        uint8_t* __restrict__ alive, int frame_id) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  const int m = dn[0], count = min(dn[1], dcap);
-  if (k >= count) return;
-  const int d = m + k;
-  pos[2 * d] = det[2 * k]; pos[2 * d + 1] = det[2 * k + 1]; vel[2 * d] = 0; vel[2 * d + 1] = 0; age[d] = 1;  // keypoint<int>(kp) (keypoint_container.hh:16-18)
-  head[d] = 0; len[d] = 0; start[d] = frame_id; alive[d] = 1;                                                 // keypoint_trajectory(frame_id)
-}
 
 __global__ __launch_bounds__(256) void ve_fill16_kernel(uint4* __restrict__ p, size_t units, uint32_t v) {
   const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (u < units) p[u] = make_uint4(v, v, v, v);
+}
+
+// A re-detection frame's rebuild of the container in ONE launch: compaction of the surviving entries with their trajectory rings (keypoint_container::compact
+// :22-55, sync_attributes :67-102), append of the new keypoints (:96-115) and the frame's trajectory update of both (video_extruder.hpp:122-133) — they were three
+// launches (+ a device-to-host copy of the two counts, now written to the pinned words by this kernel).  The first `compact_blocks` blocks take the old
+// entries, 16 lanes each (lane j copies ring slots j, j + 16, ...; the lane that owns the slot of the new head writes the new position there instead of
+// the copied one), the others the new keypoints.
+struct RebuildArgs {
+  const int32_t *newidx, *pos, *vel, *age, *head, *len, *start; const float* ring; const uint8_t* alive;   // the old container
+  int32_t *pos2, *vel2, *age2, *head2, *len2, *start2; float* ring2; uint8_t* alive2;                        // the new one
+  const int32_t *dn, *det; int32_t* host_counts;
+  int n, dcap, slots, max_len, frame_id, compact_blocks;
+};
+__global__ __launch_bounds__(256) void ve_rebuild_kernel(RebuildArgs a) {
+  if ((int)blockIdx.x < a.compact_blocks) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 4, j = threadIdx.x & 15;
+    if (i >= a.n) return;
+    const int d = a.newidx[i];
+    if (d < 0) return;   // (dead entries are dropped: age 0)
+    const int h = (a.head[i] + a.slots - 1) % a.slots;   // compacted entries are alive: move_to + pop_oldest_position (:125-130)
+    const int p0 = a.pos[2 * i], p1 = a.pos[2 * i + 1];
+    if (j == 0) {
+      a.pos2[2 * d] = p0; a.pos2[2 * d + 1] = p1; a.vel2[2 * d] = a.vel[2 * i]; a.vel2[2 * d + 1] = a.vel[2 * i + 1]; a.age2[d] = a.age[i];
+      int l = a.len[i] + 1;
+      if (l > a.max_len) l--;
+      a.head2[d] = h; a.len2[d] = l; a.start2[d] = a.start[i]; a.alive2[d] = a.alive[i];
+    }
+    const float2* src = (const float2*)a.ring + (size_t)i * a.slots;
+    float2* dst = (float2*)a.ring2 + (size_t)d * a.slots;
+    for (int s = j; s < a.slots; s += 16) dst[s] = s == h ? make_float2((float)p0, (float)p1) : src[s];
+    return;
+  }
+  const int k = ((int)blockIdx.x - a.compact_blocks) * 256 + threadIdx.x;
+  const int m = a.dn[0], count = min(a.dn[1], a.dcap);
+  if (k == 0) { a.host_counts[0] = m; a.host_counts[1] = a.dn[1]; }   // pinned words: the host reads them behind the event that follows this launch
+  if (k >= count) return;
+  const int d = m + k, h = a.slots - 1;   // keypoint<int>(kp) (keypoint_container.hh:16-18), keypoint_trajectory(frame_id), then its first move_to
+  const int p0 = a.det[2 * k], p1 = a.det[2 * k + 1];
+  a.pos2[2 * d] = p0; a.pos2[2 * d + 1] = p1; a.vel2[2 * d] = 0; a.vel2[2 * d + 1] = 0; a.age2[d] = 1;
+  float* q = a.ring2 + ((size_t)d * a.slots + h) * 2;
+  q[0] = (float)p0; q[1] = (float)p1;
+  a.head2[d] = h; a.len2[d] = 1 > a.max_len ? 0 : 1; a.start2[d] = a.frame_id; a.alive2[d] = 1;
 }
 
 template <class T> int dalloc(T** p, size_t count) { void* v = nullptr; const int rc = vpp_malloc(count * sizeof(T), &v); *p = (T*)v; return rc; }
@@ -379,15 +376,17 @@ static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
     }
     rc = vpp_fast9_detect_async(frame2, p->detector_th, &md, VPP_FAST9_BLOCKWISE, s, VPP_FAST9_REFERENCE, ve->det, nullptr, det_cap, (uint32_t*)(ve->dcount + 1), stream);
     if (rc != VPP_OK) return rc;
-    VPP_HIP_TRY(hipMemcpyAsync(ve->host_count, ve->dcount, 8, hipMemcpyDeviceToHost, st));
-    VPP_HIP_TRY(hipEventRecord(ve->count_ready, st));
     const int d = 1 - c;
-    if (n > 0)
-      ve_compact_kernel<<<(unsigned)(((size_t)n * 16 + 255) / 256), 256, 0, st>>>(n, ve->newidx, ve->pos[c], ve->vel[c], ve->age[c], ve->tring[c], ve->thead[c],
-          ve->tlen[c], ve->tstart[c], ve->talive[c], ve->pos[d], ve->vel[d], ve->age[d], ve->tring[d], ve->thead[d], ve->tlen[d], ve->tstart[d], ve->talive[d], ve->ring);
-    ve_append_kernel<<<(det_cap + 255) / 256, 256, 0, st>>>(ve->dcount, det_cap, ve->det, ve->pos[d], ve->vel[d], ve->age[d], ve->thead[d], ve->tlen[d], ve->tstart[d], ve->talive[d], ve->frame_id);
-    ve_traj_kernel<<<(n + det_cap + 255) / 256, 256, 0, st>>>(n + det_cap, ve->dcount, det_cap, ve->pos[d], ve->age[d], ve->tring[d], ve->thead[d], ve->tlen[d], ve->talive[d], ve->ring,
-                                                              p->max_trajectory_length);
+    RebuildArgs ra;
+    ra.newidx = ve->newidx; ra.pos = ve->pos[c]; ra.vel = ve->vel[c]; ra.age = ve->age[c]; ra.head = ve->thead[c]; ra.len = ve->tlen[c]; ra.start = ve->tstart[c];
+    ra.ring = ve->tring[c]; ra.alive = ve->talive[c];
+    ra.pos2 = ve->pos[d]; ra.vel2 = ve->vel[d]; ra.age2 = ve->age[d]; ra.head2 = ve->thead[d]; ra.len2 = ve->tlen[d]; ra.start2 = ve->tstart[d]; ra.ring2 = ve->tring[d];
+    ra.alive2 = ve->talive[d];
+    ra.dn = ve->dcount; ra.det = ve->det; ra.host_counts = ve->host_count;
+    ra.n = n; ra.dcap = det_cap; ra.slots = ve->ring; ra.max_len = p->max_trajectory_length; ra.frame_id = ve->frame_id;
+    ra.compact_blocks = (int)(((size_t)n * 16 + 255) / 256);
+    ve_rebuild_kernel<<<(unsigned)(ra.compact_blocks + (det_cap + 255) / 256), 256, 0, st>>>(ra);
+    VPP_HIP_TRY(hipEventRecord(ve->count_ready, st));
     ve->cur = d;
     ve->n = n + det_cap;   // upper bound until ve_resolve
     ve->pending = true; ve->pending_cap = det_cap;
