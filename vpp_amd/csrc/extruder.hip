@@ -3,9 +3,10 @@
 // (move :136-150, remove :118-126, add :96-115, compact :22-55, sync_attributes :67-102), vpp/core/keypoint_trajectory.hh:11-72.
 //
 // One vpp_video_extruder_step = one video_extruder_update, queued on one stream:
-//   flow (K11/K12) -> merge decision (K16) -> FAST score of the moved keypoints -> apply move / remove per keypoint (here)
-//   -> every detector_period-th frame: re-detection mask (K14), FAST-9 blockwise (K7-9), compaction of the container and of
-//      the trajectories + append of the new keypoints (here) -> trajectory update (here).
+//   flow (K11/K12; its read-back launch also threads every match onto the merge lists, K16) -> ve_finish_kernel: merge verdict, FAST score of the
+//   moved keypoints, apply move / remove per keypoint, and on ordinary frames the trajectory update
+//   -> every detector_period-th frame: re-detection mask (K14), FAST-9 blockwise (K7-9), ve_rebuild_kernel: compaction of the container and of
+//      the trajectories + append of the new keypoints + trajectory update.
 // The container keeps the reference's layout semantics: dead entries (age 0) stay in place until the next compaction and take
 // part in every step exactly as they do there (the flow still moves them, which revives them: move() increments the age).
 // Trajectories are fixed-capacity rings in HBM, newest position first from `head`.  Nothing in an update waits for the device: a
