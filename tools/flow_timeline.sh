@@ -18,7 +18,7 @@ t0 = int(rows[start]['Start_Timestamp']); prev = None
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     return (n[:n.index('(')] if '(' in n else n)[:48]
-print('| # | kernel | start us | dur us | gap us | grid |')
+print('| # | kernel | start us | dur us | gap us | grid |\n|---|---|---|---|---|---|')
 for k, r in enumerate(rows[start:end + 1]):
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     gap = '' if prev is None else f'{(s - prev) / 1e3:.1f}'

@@ -22,7 +22,7 @@ t0 = int(rows[a]['Start_Timestamp']); prev = None
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     return (n[:n.index('(')] if '(' in n else n)[:56]
-print('| # | kernel | start us | dur us | gap us | grid |')
+print('| # | kernel | start us | dur us | gap us | grid |\n|---|---|---|---|---|---|')
 for k, r in enumerate(rows[a:b + 1]):
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     gap = '' if prev is None else f'{(s - prev) / 1e3:.1f}'
