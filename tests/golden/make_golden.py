@@ -78,6 +78,19 @@ for th in ths:
     dense["th_%d" % th] = np.packbits(o8.view()[..., 0].astype(bool), axis=1)
 out["fast_dense"] = dict(in_crc=crc(fim.raw), **dense)
 
+# video_extruder_update over a short sequence: the reference's own tracker (oracle/_ref/libvpp_ref_ve.so)
+ve_lib = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "libvpp_ref_ve.so")
+assert os.path.exists(ve_lib), "build oracle/_ref first (make -C oracle ref)"
+ve = ctypes.CDLL(ve_lib)
+frames, par = gc.video_extruder_case()
+cap = 4096
+state = np.zeros((cap, 5), np.int32); tlen = np.zeros(cap, np.int32); cnt, fid = ctypes.c_int(0), ctypes.c_int(0)
+assert ve.ref_video_extruder_run(vi.desc_array(frames), len(frames), *par, state.ctypes.data_as(V), tlen.ctypes.data_as(V), cap, ctypes.byref(cnt), ctypes.byref(fid)) == 0
+out["video_extruder"] = dict(in_crc=crc(*[f.raw for f in frames]), state=state[:cnt.value].copy(), traj_len=tlen[:cnt.value].copy(), frame_id=np.int32(fid.value))
+
+only = set(sys.argv[1:])   # python make_golden.py [names...]: rewrite only these fixtures
 for name, d in out.items():
+    if only and name not in only:
+        continue
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
     print(name, {k: getattr(v, "shape", v) for k, v in d.items()})

@@ -65,3 +65,18 @@ def ingest_case():
 def fast_dense_case():
     """FAST_internals::fast_detector9(A, B, th) on the FAST fixture; thresholds incl. 0 and a negative one (plain int compares)."""
     return fast_case(), (20, 7, 0, -3)
+
+
+def video_extruder_case():
+    """A 7-frame sequence (texture + rectangles drifting by (0.9, -1.3) px per frame), gray frames with a mirror border of 3, and video_extruder_update's options
+    (th, spacing, period, max trajectory length, scales, winsize, sweeps): re-detection every 3rd frame."""
+    nr, nc, T = 96, 136, 7
+    base = texture(nr + 40, nc + 40, seed=9, sigma=1.5)
+    rect = rects_image(nr + 40, nc + 40, seed=4).astype(np.float64)
+    frames = []
+    for t in range(T):
+        f = 0.6 * translate(base, 0.9 * t, -1.3 * t) + 0.4 * translate(rect, 0.9 * t, -1.3 * t)
+        im = u8_image(np.clip(np.rint(f[20:20 + nr, 20:20 + nc]), 0, 255).astype(np.uint8), border=3)
+        im.view(with_border=True)[..., 0] = np.pad(im.view()[..., 0], 3, mode="symmetric")
+        frames.append(im)
+    return frames, (10, 10, 3, 15, 3, 9, 2)

@@ -153,3 +153,55 @@ def test_gpu_matches_reference_golden(lib):
     capi.check(lib.vpp_rgb_to_graylevel(P(dg1.desc), P(drgb.desc), 1, st)); capi.check(lib.vpp_rgb_to_graylevel(P(dg2.desc), P(drgba.desc), 0, st))
     np.testing.assert_array_equal(dg1.download().view(with_border=True), g["gray_mirror"])
     np.testing.assert_array_equal(dg2.download().view(with_border=True), g["gray_rgba"])
+
+
+# ---------------- the tracker: video_extruder_update over a 7-frame sequence, fixture from the reference's own headers ----------------
+def test_video_extruder_fixture_belongs_to_the_seeded_sequence():
+    frames, par = gc.video_extruder_case(); g = load("video_extruder")
+    assert gc.crc(*[f.raw for f in frames]) == g["in_crc"]
+    assert int(g["frame_id"]) == len(frames) - 2 and len(g["state"]) == len(g["traj_len"]) > 50
+    assert (g["state"][:, 4] > 0).sum() > 30 and (g["state"][:, 2:4] != 0).any()   # alive keypoints, moving ones
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", ["two_frame", "push_frame", "push_host_rgb"])
+def test_gpu_video_extruder_matches_reference_golden(lib, entry):
+    """vpp_video_extruder_step on the bordered gray frames, vpp_video_extruder_push_frame on the bare gray frames in HBM and vpp_video_extruder_push_host_frame
+    on colour frames in host memory whose integer mean is the gray sequence: every position, velocity, age and trajectory length of the reference."""
+    from vpp_amd import capi
+
+    class VeParams(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int32) for n in ("detector_th", "keypoint_spacing", "detector_period", "max_trajectory_length", "nscales", "winsize", "propagation")]
+    frames, par = gc.video_extruder_case(); g = load("video_extruder")
+    nr, nc = frames[0].nrows, frames[0].ncols
+    p = VeParams(*par)
+    lib.vpp_video_extruder_create.argtypes = [ctypes.POINTER(V), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    ve = V(); capi.check(lib.vpp_video_extruder_create(ctypes.byref(ve), nr, nc, 15))
+    keep = []
+    try:
+        for t, f in enumerate(frames):
+            if entry == "two_frame":
+                keep.append(DeviceImage.from_host(f))
+                if t:
+                    capi.check(lib.vpp_video_extruder_step(ve, P(keep[t - 1].desc), P(keep[t].desc), ctypes.byref(p), capi.stream_ptr()))
+            elif entry == "push_frame":
+                h = HostImage(nr, nc, vi.U8, 1, 0); h.view()[...] = f.view()
+                keep.append(DeviceImage.from_host(h))
+                capi.check(lib.vpp_video_extruder_push_frame(ve, P(keep[-1].desc), ctypes.byref(p), capi.stream_ptr()))
+            else:
+                gray = f.view()[..., 0].astype(np.int32); d = np.minimum(np.minimum(gray, 255 - gray), 13)
+                buf = np.zeros((nr, nc * 3 + 5), np.uint8)   # rows 5 bytes apart from tight
+                buf[:, :nc * 3] = np.stack([gray + d, gray, gray - d], -1).astype(np.uint8).reshape(nr, nc * 3)
+                keep.append(buf)
+                desc = vi.ImageDesc(buf.ctypes.data, nr, nc, buf.shape[1], 0, vi.U8, 3)
+                capi.check(lib.vpp_video_extruder_push_host_frame(ve, ctypes.byref(desc), ctypes.byref(p), capi.stream_ptr()))
+        n, fid = ctypes.c_int(), ctypes.c_int()
+        capi.check(lib.vpp_video_extruder_count(ve, ctypes.byref(n), ctypes.byref(fid)))
+        assert (n.value, fid.value) == (len(g["state"]), int(g["frame_id"]))
+        pos = np.zeros((n.value, 2), np.int32); vel = np.zeros((n.value, 2), np.int32); age = np.zeros(n.value, np.int32); ln = np.zeros(n.value, np.int32)
+        capi.check(lib.vpp_video_extruder_keypoints(ve, pos.ctypes.data_as(V), vel.ctypes.data_as(V), age.ctypes.data_as(V), n.value, capi.stream_ptr()))
+        capi.check(lib.vpp_video_extruder_trajectories(ve, ln.ctypes.data_as(V), None, None, None, None, n.value, capi.stream_ptr()))
+        np.testing.assert_array_equal(np.concatenate([pos, vel, age[:, None]], 1), g["state"])
+        np.testing.assert_array_equal(ln, g["traj_len"])
+    finally:
+        lib.vpp_video_extruder_destroy(ve)
