@@ -19,6 +19,10 @@ extern "C" int ref_video_extruder_run(const vpp_image_desc* frames, int nframes,
                                       int max_trajectory_length, int nscales, int winsize, int propagation, int32_t* out, int32_t* traj_len,
                                       int capacity, int* count, int* frame_id);
 
+extern "C" int ref_video_extruder_run_schedule(const vpp_image_desc* frames, int nframes, int detector_th, int keypoint_spacing, int detector_period,
+                                               const int* max_len, int nscales, int winsize, int propagation, int32_t* out, int32_t* traj_len,
+                                               int capacity, int* count, int* frame_id);
+
 static vpp_image_desc host_desc(const image2d<unsigned char>& i) { return vpp_image_desc{(void*)&i(0, 0), i.nrows(), i.ncols(), i.pitch(), i.border(), VPP_U8, 1}; }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -134,6 +138,23 @@ int main(int argc, char** argv) {
     std::printf("  push_frame (rgb, %s):   %d entries\n", resident ? "frames in HBM" : "host frames", c3.keypoints.size());
     if (!same_as_reference(resident ? "push_frame(rgb, device)" : "push_frame(rgb, host)", c3, want, wlen, wn, wfid, nr, nc, &alive, &moved)) return 1;
   }
-  std::printf("  push_frame: gray and colour sequences identical to the reference as well\nvideo_extruder_parity ok\n");
+  std::printf("  push_frame: gray and colour sequences identical to the reference as well\n");
+  // _max_trajectory_length changed mid-sequence (an argument of every call, video_extruder.hpp:40): raised beyond what the tracker's rings hold (the
+  // device tracker is rebuilt around the host copy and must continue from it), then lowered (one pop per update: lengths stay above the new bound)
+  if (T >= 7) {
+    std::vector<int> sched(T - 1);
+    for (int t = 0; t < T - 1; t++) sched[t] = t < 3 ? 4 : t < T - 3 ? 40 : 6;
+    CHECK(ref_video_extruder_run_schedule(descs.data(), T, 10, 10, 5, sched.data(), 3, 9, 2, want.data(), wlen.data(), cap, &wn, &wfid) == 0);
+    video_extruder_ctx c4 = video_extruder_init(make_box2d(nr, nc));
+    for (int t = 1; t < T; t++)
+      video_extruder_update(c4, frames[t - 1], frames[t], _detector_th = 10, _keypoint_spacing = 10, _detector_period = 5, _max_trajectory_length = sched[t - 1],
+                            _nscales = 3, _winsize = 9, _propagation = 2);
+    if (!same_as_reference("changing max_trajectory_length", c4, want, wlen, wn, wfid, nr, nc, &alive, &moved)) return 1;
+    int longest = 0;
+    for (int i = 0; i < wn; i++) longest = std::max(longest, wlen[i]);
+    CHECK(longest > 6);   // the schedule really left trajectories above the final bound
+    std::printf("  _max_trajectory_length 4 -> 40 -> 6 mid-sequence: identical (%d entries, longest trajectory %d)\n", wn, longest);
+  }
+  std::printf("video_extruder_parity ok\n");
   return 0;
 }

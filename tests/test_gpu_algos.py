@@ -307,15 +307,22 @@ def _run_pyrlk_both(lib, orc, f1, f2, kps, L=3, B=5, ws=7, min_ev=1e-4, max_err=
 
 
 @pytest.mark.parametrize("lpk", [1, 8, 16, 32, 64])
-@pytest.mark.parametrize("ws", [5, 7, 9])
+@pytest.mark.parametrize("ws", [3, 5, 7, 9, 11, 15, 21])
 def test_pyrlk_match_matches_oracle(lib, orc, ws, lpk):
+    """Every window size the entry point dispatches (3 ... 21; 11 with 4 scales is the reference's own benchmark configuration,
+    benchmarks/pyrlk_opencv_comparison.cc:47,64-65) x every lanes-per-keypoint grouping the window has an instance for (the others run the
+    default grouping: the knob is advisory)."""
+    if ws > 11 and lpk not in (1, 16):
+        pytest.skip("windows > 11 have one instance (a lane per keypoint): covered by lpk = 1 and the default dispatch")
     f1, f2, kps = lk_scene(240, 320, 500)
     kps["age"][::17] = 0  # dead keypoints are skipped (pyrlk_match.hh:27)
     kps["pos_r"][5], kps["pos_c"][5] = 1.5, 2.25      # windows that leave the image: partially valid offsets (lk.hh:62)
     kps["pos_r"][6], kps["pos_c"][6] = 238.2, 317.9
     lib.vpp_set_tuning(b"pyrlk.lpk", lpk)
     try:
-        got, want, gd, wd = _run_pyrlk_both(lib, orc, f1, f2, kps, ws=ws)
+        # border: the error pass (lk.hh:161-171) samples image 2 at EVERY window offset around the match, without a domain test — the
+        # reference relies on the border being wide enough; half the window + the displacement + the interpolation's second tap
+        got, want, gd, wd = _run_pyrlk_both(lib, orc, f1, f2, kps, ws=ws, B=max(5, ws // 2 + 6))
     finally:
         lib.vpp_set_tuning(b"pyrlk.lpk", -1)
     np.testing.assert_array_equal(got["age"], want["age"])

@@ -313,8 +313,9 @@ def test_box_source_at_the_very_start_of_an_allocation(lib, orc, dtype, ch, R, C
 
 @pytest.mark.parametrize("shape,ch,border,n", [((67, 131), 3, 2, 5), ((270, 480), 3, 2, 8), ((64, 1024), 1, 3, 17), ((40, 5000), 4, 2, 3), ((31, 45), 3, 2, 2)])
 def test_box_filter_batch_equals_the_oracle_per_frame(lib, orc, shape, ch, border, n):
-    """vpp_box_filter_batch: n frames of one geometry in ONE launch (17 > the 16 frames one launch carries: two launches) — every frame
-    bit-identical to the oracle's box filter of that frame; and with mixed geometries (falls back to single calls)."""
+    """vpp_box_filter_batch: n frames of one geometry in ONE launch (up to kBoxBatchMax = 64 frames per launch; the split of larger batches is
+    exercised at 4K by test_box_filter_batch_4k_at_the_benchmarked_geometry) — every frame bit-identical to the oracle's box filter of that
+    frame; and with mixed geometries (falls back to single calls)."""
     srcs = [rand_image(*shape, vi.U8, ch, border=border, seed=20 + k, align=16, fill_border=True) for k in range(n)]
     wants = []
     for s in srcs:
@@ -349,3 +350,109 @@ def test_pixelwise_binary_batch_equals_the_oracle_per_triple(lib, orc, shape, n)
         _sync(lib)
         for d, w in zip(da, wants):
             np.testing.assert_array_equal(d.download().view(), w.view())
+
+
+def _device_equal(dimg, want_dev):
+    """Whole allocation (pixels, padding, everything) of a DeviceImage against an uploaded expectation, compared in HBM."""
+    import torch
+    return bool(torch.equal(dimg.store[dimg.shift:dimg.shift + dimg.alloc_bytes], want_dev.store[want_dev.shift:want_dev.shift + want_dev.alloc_bytes]))
+
+
+def test_box_filter_batch_4k_at_the_benchmarked_geometry(lib, orc):
+    """The instance bench.py times: vpp_box_filter_batch on 64 distinct 3840x2160 vuchar3 frames in ONE launch
+    (box_u8_wide_kernel<3,5,5,6,4,...>, 6 rows per wave, one XCD remap over the whole 64-frame block grid), then 65 frames (64 + 1: the
+    second launch carries a single frame through the same instance) and 130 frames (64 + 64 + 2: the n > kBoxBatchMax split) — every byte
+    of every frame against the oracle (the per-frame expectation is computed by the oracle and compared in HBM); and the per-frame call
+    form on the same frames.  The inline checker of benchmarks/box_5x5_filter2.cc:26-41 restated on sampled pixels of one frame."""
+    from oracle import binding
+    omp = binding.load(omp=True)     # the same restatement built with OpenMP (integer arithmetic: identical results, checked on frame 0 below)
+    nr, nc, N = 2160, 3840, 130
+    base = rand_image(nr, nc, vi.U8, 3, border=2, seed=3, align=16)
+    srcs, wants = [], []
+    for k in range(N):
+        h = base.like()
+        h.view()[...] = base.view() ^ np.uint8((k * 37 + 1) & 255)     # 130 distinct frames
+        orc.orc_fill_border(P(h.desc), 0, None)
+        w = h.like(border=0)
+        assert omp.orc_box_filter(P(w.desc), P(h.desc), 5, 5) == 0
+        if k == 0:
+            w1 = h.like(border=0)
+            assert orc.orc_box_filter(P(w1.desc), P(h.desc), 5, 5) == 0
+            np.testing.assert_array_equal(w.raw, w1.raw)
+            full = h.view(with_border=True).astype(np.int64)
+            rng = np.random.default_rng(0)
+            for r, c in zip(rng.integers(0, nr, 500), rng.integers(0, nc, 500)):
+                assert (w.view()[r, c] == full[r:r + 5, c:c + 5].sum(axis=(0, 1)) // 25).all()
+        srcs.append(DeviceImage.from_host(h)); wants.append(DeviceImage.from_host(w))
+    dsts = [DeviceImage(nr, nc, vi.U8, 3, 0, 16) for _ in range(N)]
+    for n in (64, 65, 130):
+        for d in dsts:
+            d.store.zero_()
+        capi.check(lib.vpp_box_filter_batch(vi.desc_array(dsts[:n]), vi.desc_array(srcs[:n]), n, 5, 5, capi.stream_ptr()))
+        _sync(lib)
+        bad = [k for k in range(n) if not _device_equal(dsts[k], wants[k])]
+        assert not bad, (n, bad[:8])
+        assert all(int(d.store.count_nonzero()) == 0 for d in dsts[n:]), n     # nothing beyond the batch was written
+    # the reference's call form on the same frames: one call per frame
+    for d in dsts[:8]:
+        d.store.zero_()
+    for k in range(8):
+        capi.check(lib.vpp_box_filter(P(dsts[k].desc), P(srcs[k].desc), 5, 5, capi.stream_ptr()))
+    _sync(lib)
+    assert all(_device_equal(dsts[k], wants[k]) for k in range(8))
+
+
+def test_pixelwise_binary_batch_4k_at_the_benchmarked_geometry(lib, orc):
+    """The instance bench.py times: vpp_pixelwise_binary_batch(add) on 16 triples of 3840x2160 int images in ONE launch
+    (binary_flat_batch_kernel), and 17 triples (16 + 1: the split) — every element of every triple against the oracle."""
+    nr, nc, N = 2160, 3840, 17
+    bs = [rand_image(nr, nc, vi.I32, seed=100 + k, lo=0, hi=2**30 - 1) for k in range(N)]
+    cs = [rand_image(nr, nc, vi.I32, seed=200 + k, lo=0, hi=2**30 - 1) for k in range(N)]
+    wants = []
+    for b, c in zip(bs, cs):
+        a = b.like(); assert orc.orc_pixelwise_binary(0, P(a.desc), P(b.desc), P(c.desc)) == 0
+        wants.append(DeviceImage.from_host(a))
+    np.testing.assert_array_equal(wants[3].download().view(), bs[3].view() + cs[3].view())   # benchmarks/image_add.cc:21-28
+    db, dc = [DeviceImage.from_host(x) for x in bs], [DeviceImage.from_host(x) for x in cs]
+    da = [DeviceImage(nr, nc, vi.I32) for _ in range(N)]
+    for n in (16, 17):
+        for d in da:
+            d.store.zero_()
+        capi.check(lib.vpp_pixelwise_binary_batch(0, vi.desc_array(da[:n]), vi.desc_array(db[:n]), vi.desc_array(dc[:n]), n, capi.stream_ptr()))
+        _sync(lib)
+        bad = [k for k in range(n) if not _device_equal(da[k], wants[k])]
+        assert not bad, (n, bad)
+        assert all(int(d.store.count_nonzero()) == 0 for d in da[n:])
+
+
+def test_batches_whose_frames_feed_each_other_run_in_sequence(lib, orc):
+    """The batch entry points promise the results of n calls made one after the other.  A chain — frame k's result is frame k + 1's source (the
+    frames of a ring) — only has those results in sequence: such a batch must not go out as one launch (box.hip / pixelwise.hip fall back to the
+    n calls); same for two results that overlap."""
+    # box: I[k + 1] = box5x5(I[k]), all images bordered (the border of a result keeps its old bytes, as with n single calls)
+    n = 5
+    ims = [rand_image(96, 256, vi.U8, 3, border=2, seed=70 + k, align=16, fill_border=True) for k in range(n + 1)]
+    dev = [DeviceImage.from_host(x) for x in ims]
+    for k in range(n):
+        assert orc.orc_box_filter(P(ims[k + 1].desc), P(ims[k].desc), 5, 5) == 0
+    capi.check(lib.vpp_box_filter_batch(vi.desc_array(dev[1:]), vi.desc_array(dev[:n]), n, 5, 5, capi.stream_ptr()))
+    _sync(lib)
+    for k in range(n + 1):
+        np.testing.assert_array_equal(dev[k].download().raw, ims[k].raw, err_msg=f"box chain, image {k}")
+    # add: A[k + 1] = A[k] + C[k]
+    A = [rand_image(64, 128, vi.I32, seed=80 + k, lo=0, hi=2**20) for k in range(n + 1)]
+    C = [rand_image(64, 128, vi.I32, seed=90 + k, lo=0, hi=2**20) for k in range(n)]
+    dA, dC = [DeviceImage.from_host(x) for x in A], [DeviceImage.from_host(x) for x in C]
+    for k in range(n):
+        assert orc.orc_pixelwise_binary(0, P(A[k + 1].desc), P(A[k].desc), P(C[k].desc)) == 0
+    capi.check(lib.vpp_pixelwise_binary_batch(0, vi.desc_array(dA[1:]), vi.desc_array(dA[:n]), vi.desc_array(dC), n, capi.stream_ptr()))
+    _sync(lib)
+    for k in range(n + 1):
+        np.testing.assert_array_equal(dA[k].download().raw, A[k].raw, err_msg=f"add chain, image {k}")
+    # in place per triple (A[k] += C[k]) is each call's own business and stays one launch: results as the single calls
+    B = [rand_image(64, 128, vi.I32, seed=95 + k, lo=0, hi=2**20) for k in range(n)]
+    dB = [DeviceImage.from_host(x) for x in B]
+    capi.check(lib.vpp_pixelwise_binary_batch(0, vi.desc_array(dB), vi.desc_array(dB), vi.desc_array(dC), n, capi.stream_ptr()))
+    _sync(lib)
+    for k in range(n):
+        np.testing.assert_array_equal(dB[k].download().view(), B[k].view() + C[k].view())

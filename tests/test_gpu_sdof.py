@@ -231,3 +231,62 @@ def test_sdof_recorded_graph_replays_on_new_frames(lib, orc):
         np.testing.assert_array_equal(gp.cpu().numpy(), wp)
         np.testing.assert_array_equal(gd.cpu().numpy(), wd)
     capi.check(lib.vpp_graph_destroy(graph))
+
+
+def test_sdof_graph_replays_between_eager_calls_of_another_layout(lib, orc):
+    """The scratch notes ("queue flags / control block are zero", "owner maps were left clean") describe the buffer as the last QUEUED call leaves it.
+    A recorded call runs later, between arbitrary other calls: it must carry its own resets and neither trust nor leave a note.  Sequence on ONE
+    stream (= one scratch buffer): eager A, record A, eager B (another geometry: its maps overlay A's flag and owner regions), replay A, eager A,
+    replay A, eager B — every result equals the oracle's."""
+    fa1, fa2, ka = flow_scene(240, 320, seed=51, spacing=5)
+    fb1, fb2, kb = flow_scene(150, 200, seed=52, spacing=4)     # smaller: the scratch never grows after the first call (a growing buffer would orphan the graph)
+    st = torch.cuda.Stream(); sp = ctypes.c_void_p(st.cuda_stream)
+
+    def setup(f1, f2, kps):
+        i1, i2 = u8_image(f1, border=3), u8_image(f2, border=3)
+        n = len(kps)
+        want = (np.zeros((n, 2), np.int32), np.zeros(n, np.int32), np.zeros(n, np.uint8))
+        assert orc.orc_semi_dense_optical_flow(P(i1.desc), P(i2.desc), kps.ctypes.data_as(ctypes.c_void_p), n, 9, 3, 0, 2, 5,
+                                               want[0].ctypes.data_as(ctypes.c_void_p), want[1].ctypes.data_as(ctypes.c_void_p), want[2].ctypes.data_as(ctypes.c_void_p)) == 0
+        d1, d2, dk = DeviceImage.from_host(i1), DeviceImage.from_host(i2), torch.from_numpy(kps).cuda()
+        out = (torch.zeros((n, 2), dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda"))
+
+        def call():
+            capi.check(lib.vpp_semi_dense_optical_flow(P(d1.desc), P(d2.desc), ctypes.c_void_p(dk.data_ptr()), n, 9, 3, 0, 2, 5,
+                                                       ctypes.c_void_p(out[0].data_ptr()), ctypes.c_void_p(out[1].data_ptr()), ctypes.c_void_p(out[2].data_ptr()), sp))
+
+        def check(what):
+            capi.check(lib.vpp_sync(sp))
+            for g, w, name in zip(out, want, ("pos", "dist", "valid")):
+                np.testing.assert_array_equal(g.cpu().numpy(), w, err_msg=f"{what}: {name}")
+                g.zero_()
+            torch.cuda.synchronize()   # the zeroing ran on torch's stream, the next call runs on `st`
+        return call, check, (d1, d2, i1, i2)
+
+    call_a, check_a, _ = setup(fa1, fa2, ka)
+    call_b, check_b, _ = setup(fb1, fb2, kb)
+    torch.cuda.synchronize()
+    call_a(); check_a("eager A")
+    graph = ctypes.c_void_p()
+    capi.check(lib.vpp_graph_begin(sp)); call_a(); capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(graph)))
+    replay = lambda: capi.check(lib.vpp_graph_launch(graph, sp))
+    call_b(); check_b("eager B after the recording")
+    replay(); check_a("replay A after eager B")
+    call_a(); check_a("eager A after a replay")
+    replay(); check_a("replay A after eager A")
+    call_b(); check_b("eager B after a replay")
+    replay(); replay(); check_a("two replays back to back")
+    capi.check(lib.vpp_graph_destroy(graph))
+    # a recording that would have to grow the scratch is refused readably (it cannot allocate), not failed inside the runtime
+    fc1, fc2, kc = flow_scene(480, 640, seed=53, spacing=5)
+    call_c, check_c, _ = setup(fc1, fc2, kc)
+    torch.cuda.synchronize()
+    capi.check(lib.vpp_graph_begin(sp))
+    with pytest.raises(capi.VppError) as e:
+        call_c()
+    assert "run the same call once" in str(e.value)
+    g2 = ctypes.c_void_p()
+    lib.vpp_graph_end(sp, 0, ctypes.byref(g2))
+    if g2:
+        lib.vpp_graph_destroy(g2)
+    call_c(); check_c("eager C after the refused recording")

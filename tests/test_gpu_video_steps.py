@@ -398,3 +398,43 @@ def test_push_frame_restarts_when_the_pyramids_change_shape(lib):
     assert states[1][0] == states[0][0]
     for g, w in zip(states[1][1:], states[0][1:]):
         np.testing.assert_array_equal(g, w)
+
+
+def test_a_refused_update_does_not_advance_the_tracker(lib):
+    """An update that is refused (frame2 without the 3-pixel border FAST needs, fast.hpp:937-938; a frame of another type) leaves frame_id and the
+    container untouched — frame_id % detector_period decides which frames re-detect, so a clock that ran ahead would shift every later detection —
+    and the sequence continued after the refusal ends in the state of the sequence without it."""
+    from vpp_amd.synth import texture, translate, rects_image
+    nr, nc, T = 96, 160, 6
+    base = texture(nr + 40, nc + 40, seed=5, sigma=1.5); rect = rects_image(nr + 40, nc + 40, seed=6).astype(np.float64)
+    frames = [np.clip(np.rint((0.6 * translate(base, 0.8 * t, -0.9 * t) + 0.4 * translate(rect, 0.8 * t, -0.9 * t))[20:20 + nr, 20:20 + nc]), 0, 255).astype(np.uint8) for t in range(T)]
+    par = _VeParams(10, 10, 2, 15, 3, 9, 2)
+    lib.vpp_video_extruder_create.argtypes = [ctypes.POINTER(V), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+
+    def bordered(f, border=3):
+        h = HostImage(nr, nc, vi.U8, 1, border); h.view()[..., 0] = f
+        d = DeviceImage.from_host(h)
+        capi.check(lib.vpp_fill_border(P(d.desc), 0, None, capi.stream_ptr()))
+        return d
+    states = []
+    for refuse in (False, True):
+        ve = V(); capi.check(lib.vpp_video_extruder_create(ctypes.byref(ve), nr, nc, 15))
+        try:
+            d = [bordered(f) for f in frames]
+            for t in range(1, T):
+                if refuse and t in (1, 3):   # before the first update (empty container) and in the middle of the sequence
+                    n0, f0 = ctypes.c_int(), ctypes.c_int()
+                    capi.check(lib.vpp_video_extruder_count(ve, ctypes.byref(n0), ctypes.byref(f0)))
+                    assert lib.vpp_video_extruder_step(ve, P(d[t - 1].desc), P(bordered(frames[t], 2).desc), ctypes.byref(par), capi.stream_ptr()) == capi.ERR_BORDER_TOO_SMALL
+                    assert lib.vpp_video_extruder_step(ve, P(d[t - 1].desc), P(DeviceImage(nr, nc, vi.U8, 3, 3).desc), ctypes.byref(par), capi.stream_ptr()) == capi.ERR_UNSUPPORTED
+                    n1, f1 = ctypes.c_int(), ctypes.c_int()
+                    capi.check(lib.vpp_video_extruder_count(ve, ctypes.byref(n1), ctypes.byref(f1)))
+                    assert (n1.value, f1.value) == (n0.value, f0.value)
+                capi.check(lib.vpp_video_extruder_step(ve, P(d[t - 1].desc), P(d[t].desc), ctypes.byref(par), capi.stream_ptr()))
+            states.append(_tracker_state(lib, ve))
+        finally:
+            lib.vpp_video_extruder_destroy(ve)
+    assert states[0][0] == T - 2 and len(states[0][1]) > 20
+    assert states[1][0] == states[0][0]
+    for g, w in zip(states[1][1:], states[0][1:]):
+        np.testing.assert_array_equal(g, w)

@@ -932,6 +932,9 @@ extern "C" int vpp_box_filter_batch(const vpp_image_desc* dst, const vpp_image_d
                     tuning("box.impl", 2) == 2 && tuning("box.batch", 1);
   bool ok16 = wide;
   for (int k = 0; ok16 && k < n; k++) ok16 = aligned16(&dst[k]) && aligned16(&src[k]) && fits_descriptor(&dst[k], &src[k]);
+  // "the results of n calls one after the other": a frame whose result is another frame's source (frames of a ring, a chain) or overlaps another
+  // result is only that in sequence — such a batch goes out as the n calls
+  if (ok16) { const vpp_image_desc* srcs[1] = {src}; ok16 = !batch_frames_interfere(n, dst, srcs, 1); }
   if (ok16) {
     hipStream_t st = as_stream(stream);
     switch (dst[0].channels) {

@@ -4,6 +4,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
+#include <vector>
 #include "../../include/vpp_amd.h"
 
 namespace vpp_amd {
@@ -67,10 +69,61 @@ inline bool aligned16(const vpp_image_desc* d) { return ((uintptr_t)d->first_pix
 // stream capture (a capture must not be the FIRST call on its stream at a given size: growing allocates).  At most kSlots
 // buffers are kept; the least recently used one is released (after a device synchronise) when another stream shows up, which
 // also retires the buffers of destroyed streams.
+// A batch entry point promises the results of n calls made one after the other.  In ONE launch that only holds when no frame's result is another frame's
+// input or result: true when dst[j] overlaps dst[k] or any source of frame k, k != j (a frame's own in-place / aliasing rules are the single call's).
+// Byte extents are the whole bordered areas.  O(n log n): the extents sorted by start, and for each kind the two furthest-reaching open extents of
+// different frames.
+inline bool batch_frames_interfere(int n, const vpp_image_desc* dst, const vpp_image_desc* const* srcs, int nsrc) {
+  struct Ext { uintptr_t lo, hi; int frame; bool is_dst; };
+  std::vector<Ext> v;
+  v.reserve((size_t)n * (1 + nsrc));
+  auto ext = [](const vpp_image_desc& d, int frame, bool is_dst) {
+    const uintptr_t p = (uintptr_t)d.first_pixel;
+    const size_t es = (size_t)elem_bytes(&d);
+    return Ext{p - (size_t)d.border * d.pitch - (size_t)d.border * es, p + (size_t)(d.nrows - 1 + d.border) * d.pitch + (size_t)(d.ncols + d.border) * es, frame, is_dst};
+  };
+  for (int k = 0; k < n; k++) {
+    v.push_back(ext(dst[k], k, true));
+    for (int q = 0; q < nsrc; q++) v.push_back(ext(srcs[q][k], k, false));
+  }
+  std::sort(v.begin(), v.end(), [](const Ext& a, const Ext& b) { return a.lo < b.lo; });
+  struct Top { uintptr_t hi[2] = {0, 0}; int frame[2] = {-1, -1}; };   // the furthest end seen, and the furthest end of another frame than that one
+  auto reaches = [](const Top& t, uintptr_t lo, int frame) { return (t.frame[0] >= 0 && t.frame[0] != frame && t.hi[0] > lo) || (t.frame[1] >= 0 && t.frame[1] != frame && t.hi[1] > lo); };
+  auto add = [](Top& t, uintptr_t hi, int frame) {
+    if (t.frame[0] == frame) { t.hi[0] = std::max(t.hi[0], hi); return; }
+    if (t.frame[0] < 0 || hi > t.hi[0]) { t.hi[1] = t.hi[0]; t.frame[1] = t.frame[0]; t.hi[0] = hi; t.frame[0] = frame; return; }
+    if (t.frame[1] < 0 || t.frame[1] == frame || hi > t.hi[1]) { if (t.frame[1] != frame || hi > t.hi[1]) { t.hi[1] = hi; t.frame[1] = frame; } }
+  };
+  Top dsts, srcx;
+  for (const Ext& e : v) {
+    if (e.is_dst ? (reaches(dsts, e.lo, e.frame) || reaches(srcx, e.lo, e.frame)) : reaches(dsts, e.lo, e.frame)) return true;
+    add(e.is_dst ? dsts : srcx, e.hi, e.frame);
+  }
+  return false;
+}
+
+// Bumped whenever something may have left ANY scratch buffer in an unknown state (a device-side protocol that gave up, check_device_error): every note
+// taken before the bump stops being believed.
+unsigned notes_epoch();
+void invalidate_scratch_notes();
+
 struct Scratch {
   static constexpr int kSlots = 16;   // one per (device, stream) that has called in: 8 was the ceiling of the frame-pairs-in-flight case (the 9th stream evicted — and synchronised — every call)
-  // user[]: the owner's notes about what the buffer holds (e.g. "this region is zeroed"); cleared whenever the buffer is (re)allocated
-  struct Slot { void* p = nullptr; size_t cap = 0; int dev = -1; hipStream_t st = nullptr; unsigned long long used = 0; unsigned long long user[4] = {0, 0, 0, 0}; };
+  // user[]: the owner's notes about what the buffer holds (e.g. "this region is zeroed"); cleared whenever the buffer is (re)allocated.
+  // Notes describe the buffer as the LAST QUEUED call leaves it.  A call recorded into a launch graph runs later, any number of times, between any
+  // other calls — so once a capture has recorded work on a buffer (`recorded`, sticky until the buffer is reallocated) no note about it can be
+  // trusted any more and none is taken: note() then always reports "unknown", and every call (recorded or eager) carries its own resets.
+  struct Slot {
+    void* p = nullptr; size_t cap = 0; int dev = -1; hipStream_t st = nullptr; unsigned long long used = 0; unsigned long long user[4] = {0, 0, 0, 0};
+    bool recorded = false;     // a stream capture has recorded work that uses this buffer
+    bool capturing = false;    // the call that is being queued right now is being captured
+    unsigned epoch = 0;        // notes_epoch() when the notes were last written
+    bool note(int i, unsigned long long sig) const { return !recorded && epoch == notes_epoch() && user[i] == sig; }
+    void set_note(int i, unsigned long long sig) {
+      if (epoch != notes_epoch()) { for (unsigned long long& u : user) u = 0; epoch = notes_epoch(); }
+      user[i] = recorded ? 0 : sig;
+    }
+  };
   Slot* cur = nullptr;   // the slot of the last ensure()
   Slot slots[kSlots];
   unsigned long long tick = 0;
@@ -78,8 +131,15 @@ struct Scratch {
   int ensure(size_t bytes, hipStream_t st) {
     int dev = 0;
     VPP_HIP_TRY(hipGetDevice(&dev));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
     Slot* s = nullptr;
     for (Slot& c : slots) if (c.p && c.dev == dev && c.st == st) { s = &c; break; }
+    // growing the buffer synchronises the stream and allocates — both illegal while the stream is captured, and the graph would keep the address of a
+    // buffer that a later, larger call frees: refuse readably instead of failing inside the runtime
+    VPP_REQUIRE(!capturing || (s && bytes <= s->cap), VPP_ERR_UNSUPPORTED,
+                "the call needs %zu bytes of scratch on this stream and a stream capture cannot allocate them: run the same call once on this stream before recording it", bytes);
     if (!s) {
       for (Slot& c : slots) if (!c.p) { s = &c; break; }
       if (!s) {  // evict the least recently used buffer; it may still be in use by queued work, or belong to another device
@@ -95,7 +155,10 @@ struct Scratch {
       VPP_HIP_TRY(hipMalloc(&s->p, bytes));
       s->cap = bytes;
       for (unsigned long long& u : s->user) u = 0;
+      s->recorded = false;   // graphs recorded on the old buffer are invalid from here on (they hold its address): documented in include/vpp_amd.h
     }
+    s->capturing = capturing;
+    if (capturing) { s->recorded = true; for (unsigned long long& u : s->user) u = 0; }
     p = s->p; cur = s;
     return VPP_OK;
   }
@@ -113,6 +176,13 @@ struct Scratch {
   }
   ~Scratch() { for (Slot& c : slots) if (c.p) (void)hipFree(c.p); }
 };
+
+// Sticky device-side error word (runtime.hip): one 32-bit word in pinned, device-visible host memory that kernels raise bits of when a device-side
+// protocol gives up (a grid barrier's poll limit); vpp_sync and the tracker's count read-back check it after the stream has drained and return
+// VPP_ERR_HIP once (the word is cleared by the report).  nullptr when the allocation failed (the kernels then skip the store).
+unsigned* device_error_word();
+int check_device_error(const char* where);   // VPP_OK, or VPP_ERR_HIP + vpp_last_error() when a bit is up
+enum { kDevErrSweepBarrier = 1u };
 
 // blockIdx remap so that consecutive logical blocks share an XCD (hardware places block b on XCD b % 8;
 // MI355X_MICROARCH.md "Workgroup dispatch").  Speed only, never correctness.

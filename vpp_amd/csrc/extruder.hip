@@ -51,7 +51,16 @@ struct vpp_video_extruder {
   hipEvent_t staged[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};   // staged[k]: the upload into stage[k] is in HBM; consumed[k]: the pyramid built from it is done
   int last_k = 0;                 // the staging frame of the push made last
   bool consumed_set[2] = {false, false};
+  // Updates are queued, never waited for: `queued` is recorded on the caller's stream behind the last kernel of every update, and whatever hands one of the
+  // tracker's blocks back to the pool (destroy, larger buffers, other pyramid / mask / detection sizes) waits for it first — vpp_free does not synchronise,
+  // and another stream or thread could be handed memory the queued kernels still use.  (An event outlives the stream it was recorded on.)
+  hipEvent_t queued = nullptr;
+  bool queued_set = false;
 };
+// nothing of the tracker's queued work may still touch its blocks
+static void ve_quiesce(vpp_video_extruder* ve) {
+  if (ve->queued && ve->queued_set) { if (hipEventSynchronize(ve->queued) != hipSuccess) (void)hipGetLastError(); }   // (an event recorded into a launch graph cannot be waited for: the graph's owner orders that)
+}
 
 namespace vpp_amd {
 int keypoint_mask_squares(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, hipStream_t st);
@@ -257,6 +266,7 @@ int ve_reserve(vpp_video_extruder* ve, int want, hipStream_t st) {
       return VPP_ERR_HIP;
     }
   }
+  ve_quiesce(ve);   // n == 0 skipped the synchronising copy above: kernels of the last update may still be queued on the old blocks
   vpp_video_extruder old = *ve;
   *ve = nw;
   ve->cap = ncap;
@@ -277,18 +287,22 @@ int vpp_video_extruder_create(vpp_video_extruder** out, int nrows, int ncols, in
   if (vpp_malloc_host(64, &h) != VPP_OK) { delete ve; return VPP_ERR_HIP; }
   ve->host_count = (int32_t*)h;
   ve->host_count[0] = ve->host_count[1] = 0;
-  if (dalloc(&ve->dcount, 2) != VPP_OK || hipEventCreateWithFlags(&ve->count_ready, hipEventDisableTiming) != hipSuccess) {
+  if (dalloc(&ve->dcount, 2) != VPP_OK || hipEventCreateWithFlags(&ve->count_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ve->queued, hipEventDisableTiming) != hipSuccess) {
+    if (ve->count_ready) (void)hipEventDestroy(ve->count_ready);
     dfree(ve->dcount); vpp_free_host(h); delete ve; return VPP_ERR_HIP;
   }
   // a first capacity that a blockwise detection with the default spacing cannot exceed: one keypoint per 10 x 10 block, twice over
   const int rc = ve_reserve(ve, std::max(4096, (nrows / 10 + 1) * (ncols / 10 + 1) * 2), nullptr);
-  if (rc != VPP_OK) { (void)hipEventDestroy(ve->count_ready); dfree(ve->dcount); vpp_free_host(h); delete ve; return rc; }
+  if (rc != VPP_OK) { (void)hipEventDestroy(ve->count_ready); (void)hipEventDestroy(ve->queued); dfree(ve->dcount); vpp_free_host(h); delete ve; return rc; }
   *out = ve;
   return VPP_OK;
 }
 
 int vpp_video_extruder_destroy(vpp_video_extruder* ve) {
   if (!ve) return VPP_OK;
+  ve_quiesce(ve);   // the last update may still be queued on the caller's stream
+  if (ve->queued) (void)hipEventDestroy(ve->queued);
   for (int b = 0; b < 2; b++) { dfree(ve->pos[b]); dfree(ve->vel[b]); dfree(ve->age[b]); dfree(ve->tring[b]); dfree(ve->thead[b]); dfree(ve->tlen[b]); dfree(ve->tstart[b]); dfree(ve->talive[b]); }
   dfree(ve->fpos); dfree(ve->fdist); dfree(ve->scores); dfree(ve->newidx); dfree(ve->blocksum); dfree(ve->fvalid); dfree(ve->merged); dfree(ve->det); dfree(ve->mask); dfree(ve->pyr_mem[0]); dfree(ve->pyr_mem[1]);
   if (ve->copy_stream) { (void)hipStreamSynchronize(ve->copy_stream); (void)hipStreamDestroy(ve->copy_stream); }
@@ -312,9 +326,24 @@ static int ve_resolve(const vpp_video_extruder* cve) {
 }
 
 // pyr1 / pyr2 != nullptr: the frames' pyramids are the tracker's own (vpp_video_extruder_push_frame) and the flow takes them as they are
+static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2, const vpp_video_extruder_params* p, void* stream,
+                     const vpp_image_desc* pyr1, const vpp_image_desc* pyr2);
 static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2, const vpp_video_extruder_params* p, void* stream,
                      const vpp_image_desc* pyr1, const vpp_image_desc* pyr2) {
+  const int frame_id = ve ? ve->frame_id : 0;
+  const int rc = step_body(ve, frame1, frame2, p, stream, pyr1, pyr2);
+  // A failed update must not advance the tracker's clock: the caller's frame counter has not advanced either, and frame_id % detector_period decides which
+  // frames re-detect for the rest of the sequence.  (What the failed call had already queued is the caller's to discard: re-upload the state.)
+  if (rc != VPP_OK && ve) ve->frame_id = frame_id;
+  if (ve && ve->queued && hipEventRecord(ve->queued, as_stream(stream)) == hipSuccess) ve->queued_set = true; else (void)hipGetLastError();
+  return rc;
+}
+static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2, const vpp_video_extruder_params* p, void* stream,
+                     const vpp_image_desc* pyr1, const vpp_image_desc* pyr2) {
   VPP_REQUIRE(ve && p && valid_desc(frame1) && valid_desc(frame2), VPP_ERR_INVALID_ARG, "vpp_video_extruder_step: invalid argument");
+  // everything that can be refused is refused before anything is queued or counted (the reference throws here too: fast.hpp:937-938)
+  VPP_REQUIRE(frame2->dtype == VPP_U8 && frame2->channels == 1 && frame1->dtype == VPP_U8 && frame1->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_video_extruder_step: u8 x1 frames only");
+  VPP_REQUIRE(frame2->border >= 3, VPP_ERR_BORDER_TOO_SMALL, "Image need a border of 3px at least for the FAST detector");
   VPP_REQUIRE(frame1->nrows == ve->nrows && frame1->ncols == ve->ncols && same_domain(frame1, frame2), VPP_ERR_INVALID_ARG, "vpp_video_extruder_step: frames do not match the tracker's domain");
   VPP_REQUIRE(p->keypoint_spacing > 0 && p->detector_period > 0 && p->max_trajectory_length > 0 && p->max_trajectory_length < ve->ring, VPP_ERR_INVALID_ARG,
               "vpp_video_extruder_step: max_trajectory_length %d exceeds the tracker's trajectory capacity %d", p->max_trajectory_length, ve->ring - 1);
@@ -338,8 +367,6 @@ static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
     if (rc != VPP_OK) return rc;
     rc = sdof_flow_linked(frame1, frame2, pyr1, pyr2, ve->pos[c], n, p->winsize, p->nscales, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, &link, head_units, stream);
     if (rc != VPP_OK) return rc;
-    VPP_REQUIRE(frame2->dtype == VPP_U8 && frame2->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_video_extruder_step: u8 x1 frames only");
-    VPP_REQUIRE(frame2->border >= 3, VPP_ERR_BORDER_TOO_SMALL, "Image need a border of 3px at least for the FAST detector");
     const MergeLists lists{link.head, link.next, link.age_now, link.cell_of};
     if (detect) ve_finish_kernel<false><<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, lists, dimg(frame2), p->detector_th, ve->tring[c],
                                                                            ve->thead[c], ve->tlen[c], ve->talive[c], ve->ring, p->max_trajectory_length);
@@ -349,6 +376,7 @@ static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
   if (detect) {  // re-detection away from every container entry (:94-119)
     const int s = p->keypoint_spacing;
     if (ve->mask_spacing != s) {
+      ve_quiesce(ve);
       dfree(ve->mask);
       ve->mask_pitch = (ve->ncols + 2 * s + 31) / 32 * 32;
       ve->mask_bytes = (size_t)(ve->nrows + 2 * s) * ve->mask_pitch;
@@ -370,6 +398,7 @@ static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
       ve_index_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum, ve->newidx);
     } else VPP_HIP_TRY(hipMemsetAsync(ve->dcount, 0, 4, st));
     if (det_cap > ve->det_cap) {
+      ve_quiesce(ve);
       dfree(ve->det);
       rc = dalloc(&ve->det, (size_t)det_cap * 2);
       if (rc != VPP_OK) return rc;
@@ -422,6 +451,7 @@ static int ve_pyramids(vpp_video_extruder* ve, int nscales, int winsize) {
       if (rc != VPP_OK) { dfree(mem[0]); dfree(mem[1]); return rc; }
     }
   }
+  ve_quiesce(ve);   // the last update's flow may still be reading the old pyramids
   dfree(ve->pyr_mem[0]); dfree(ve->pyr_mem[1]);
   for (int b = 0; b < 2; b++) { ve->pyr_mem[b] = mem[b]; for (int l = 0; l < nscales; l++) ve->pyr[b][l] = lv[b][l]; }
   ve->pyr_scales = nscales; ve->pyr_winsize = winsize;

@@ -737,11 +737,9 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
   const unsigned long long key_sig = keyed ? (((unsigned long long)off_br << 24) ^ (unsigned long long)nblocks) + 1ull : 0ull;
   // under stream capture nothing runs now: a graph must carry its own memset (it may be replayed after any other call has used the key
   // area) and must not leave a note about a state it did not produce
-  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cap_status);
-  const bool capturing = cap_status != hipStreamCaptureStatusNone;
-  const bool keys_clean = keyed && !capturing && sl.user[0] == key_sig;
-  sl.user[0] = 0;   // until this call's write pass is queued (an error return in between must not leave a wrong note)
+  // (Scratch::ensure has looked: a buffer that a capture recorded work on — now or ever — takes and believes no notes)
+  const bool keys_clean = keyed && sl.note(0, key_sig);
+  sl.set_note(0, 0);   // until this call's write pass is queued (an error return in between must not leave a wrong note)
   const uint32_t bs_magic = block_size >= 2 ? (uint32_t)((1ull << 32) / (unsigned)block_size) + 1u : 0u;   // x / bs = umulhi(x, magic), exact for x < 2^16
   if (keyed && !keys_clean) VPP_HIP_TRY(hipMemsetAsync(blkkey, 0, (size_t)nblocks * 8, st));
   if (impl == 2) {
@@ -758,7 +756,7 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
     const int ng = (nblocks + 255) / 256;   // <= ngroups (G <= 256): unit_count is large enough
     fast9_count_keys_kernel<<<ng, 256, 0, st>>>(blkkey, nblocks, unit_count);
     fast9_write_keys_kernel<<<ng, 256, 0, st>>>(blkkey, nblocks, unit_count, d_total, out_rc, out_scores, capacity);
-    if (!capturing && hipPeekAtLastError() == hipSuccess) sl.user[0] = key_sig;   // every key that was raised is zero again once this kernel has run
+    if (hipPeekAtLastError() == hipSuccess) sl.set_note(0, key_sig);   // every key that was raised is zero again once this kernel has run
   } else if (mode == VPP_FAST9_BLOCKWISE) {
     fast9_count_blocks_kernel<<<ngroups, 256, 0, st>>>(F, bitmap, ntc, block_size, nbc, nblocks, RB, G, blkres, unit_count);
     fast9_write_blocks_kernel<<<ngroups, 256, 0, st>>>(blkres, nblocks, G, unit_count, d_total, out_rc, out_scores, capacity);

@@ -334,6 +334,8 @@ int vpp_pixelwise_binary_batch(int op, const vpp_image_desc* dst, const vpp_imag
     }
   }
   flat = flat && (dst[0].dtype == VPP_I32 || dst[0].dtype == VPP_U32);
+  // one launch only when no triple's result is another triple's operand or result (else: the n calls in sequence, whose results are the contract)
+  if (flat) { const vpp_image_desc* srcs[2] = {a, b}; flat = !batch_frames_interfere(n, dst, srcs, 2); }
   if (flat) {
     hipStream_t st = as_stream(stream);
     switch (op) {

@@ -1,5 +1,6 @@
 // runtime.hip — device/runtime entry points of the C ABI (include/vpp_amd.h "runtime" block).
 #include "common.hpp"
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -18,6 +19,31 @@ int tuning(const char* name, int dflt) {
   auto it = g_tune.find(name);
   return it == g_tune.end() ? dflt : it->second;
 }
+// The sticky device-side error word (common.hpp): pinned host memory mapped into every device, written by kernels with plain stores (a PCIe write,
+// only ever on a failure path), read by the host after a synchronisation at the cost of one load.
+static std::once_flag g_deverr_once;
+static unsigned* g_deverr = nullptr;
+unsigned* device_error_word() {
+  std::call_once(g_deverr_once, [] {
+    void* q = nullptr;
+    if (hipHostMalloc(&q, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) { memset(q, 0, 64); g_deverr = (unsigned*)q; }
+    else (void)hipGetLastError();
+  });
+  return g_deverr;
+}
+int check_device_error(const char* where) {
+  unsigned* w = g_deverr;   // never allocated: no kernel could have raised it
+  if (!w) return VPP_OK;
+  const unsigned bits = __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL);
+  if (!bits) return VPP_OK;
+  invalidate_scratch_notes();   // whatever that kernel left in its scratch region is unknown: the next call resets it
+  set_error("%s: a device-side protocol gave up waiting (bits 0x%x:%s) - the results of the calls queued before this point are not valid", where, bits,
+            (bits & kDevErrSweepBarrier) ? " grid barrier of the semi-dense flow's propagation rounds" : "");
+  return VPP_ERR_HIP;
+}
+static std::atomic<unsigned> g_notes_epoch{1};
+unsigned notes_epoch() { return g_notes_epoch.load(std::memory_order_relaxed); }
+void invalidate_scratch_notes() { g_notes_epoch.fetch_add(1, std::memory_order_relaxed); }
 }  // namespace vpp_amd
 using namespace vpp_amd;
 
@@ -209,7 +235,7 @@ int vpp_memset(void* dst, int byte, size_t bytes, void* stream) {
   VPP_HIP_TRY(hipMemsetAsync(dst, byte, bytes, as_stream(stream)));
   return VPP_OK;
 }
-int vpp_sync(void* stream) { VPP_HIP_TRY(hipStreamSynchronize(as_stream(stream))); return VPP_OK; }
+int vpp_sync(void* stream) { VPP_HIP_TRY(hipStreamSynchronize(as_stream(stream))); return check_device_error("vpp_sync"); }
 int vpp_stream_create(void** stream) {
   VPP_REQUIRE(stream, VPP_ERR_INVALID_ARG, "vpp_stream_create: null");
   hipStream_t s;

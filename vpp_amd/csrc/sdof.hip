@@ -469,8 +469,13 @@ struct SweepCtl { unsigned count[2], head[2], reg, nreg, arrive, pad; unsigned l
 constexpr unsigned kRegClosed = 0x80000000u;
 constexpr int kTagShift = 8;            // Cell::mark bits 8..: round + 1 in which the value last changed (0: unchanged this sweep)
 constexpr int kJobsPerGroup = 32;       // 256 threads / 8 lanes
-constexpr unsigned kSpinLimit = 1u << 22;   // polls of a barrier wait (seconds); see the waits
-struct RoundArrays { Cell* pre; Cell* B[2]; uint32_t* Q[2]; uint32_t* qflag[2]; SweepCtl* ctl; };
+constexpr unsigned kSpinLimit = 1u << 22;   // polls of a barrier wait: a poll is s_sleep(1) + an L2 load, ~1 us under load, so ~4 s — far beyond any legitimate wait; on a timeout the
+                                            // workgroup raises kDevErrSweepBarrier in the sticky device error word (common.hpp) and leaves: the host's next vpp_sync reports VPP_ERR_HIP
+struct RoundArrays { Cell* pre; Cell* B[2]; uint32_t* Q[2]; uint32_t* qflag[2]; SweepCtl* ctl; unsigned* err; };   // err: the sticky device error word (pinned host memory) or nullptr
+__device__ __forceinline__ void raise_barrier_timeout(const RoundArrays& a) {
+  a.ctl->pad = 1;
+  if (a.err) __hip_atomic_fetch_or(a.err, (unsigned)kDevErrSweepBarrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ unsigned g_round_stats[4];   // [0] rounds, [1] jobs, [2] jobs evaluated, [3] changes
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
         const unsigned o = __hip_atomic_fetch_or(&ctl->reg, kRegClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!(o & kRegClosed)) { N = o; __hip_atomic_store(&ctl->nreg, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         else for (unsigned spin = 0; (N = __hip_atomic_load(&ctl->nreg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && spin < kSpinLimit; spin++) __builtin_amdgcn_s_sleep(1);
-        if (N == 0) { N = 1; ctl->pad = 1; }   // cannot happen (the closer stores nreg right after closing); never hang the GPU on a bug
+        if (N == 0) { N = 1; raise_barrier_timeout(a); }   // cannot happen (the closer stores nreg right after closing); never hang the GPU on a bug
         s_nreg = N;
       }
       if (N > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -670,7 +675,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
       } else {
         unsigned spin = 0;
         while (((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned long long)(k + 1) && ++spin < kSpinLimit) __builtin_amdgcn_s_sleep(1);
-        if (spin >= kSpinLimit) { g = 0; ctl->pad = 1; }   // every registered workgroup is resident and arrives: a timeout is a bug — leave instead of hanging
+        if (spin >= kSpinLimit) { g = 0; raise_barrier_timeout(a); }   // every registered workgroup is resident and arrives: a timeout is a bug — leave instead of hanging
       }
       if (N > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       s_gen = g;
@@ -844,16 +849,19 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
       ra_flags_off = cv.off;   // zero between sweeps: queue flags (self-cleaning) and the control block
       ra.qflag[0] = (uint32_t*)take(cells * 4); ra.qflag[1] = (uint32_t*)take(cells * 4); ra.ctl = (SweepCtl*)take(sizeof(SweepCtl));
       ra_flags_bytes = cv.off - ra_flags_off;
+      ra.err = device_error_word();
     }
     if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
   if (nstrips > 1) { int rc = g_strips.ensure(nstrips - 1); if (rc != VPP_OK) return rc; }
-  {  // the queue flags clean themselves up and the control block is left zeroed by every sweep: zeroed here once per (buffer, layout)
+  {  // the queue flags clean themselves up and the control block is left zeroed by every sweep: zeroed here once per (buffer, layout).  A call that is
+     // being recorded into a launch graph, and every call on a buffer that a graph has been recorded on, carries the reset itself (Scratch::Slot::note):
+     // a replay runs between arbitrary other calls, whose layouts may have left anything in this region.
     Scratch::Slot& sl = *g_scratch.cur;
     const unsigned long long sig = ((unsigned long long)ra_flags_off << 24) ^ (unsigned long long)ra_flags_bytes ^ 1ull;
-    if (sl.user[0] != sig) {
+    if (!sl.note(0, sig)) {
       VPP_HIP_TRY(hipMemsetAsync((uint8_t*)g_scratch.p + ra_flags_off, 0, ra_flags_bytes, st));
-      sl.user[0] = sig;
+      sl.set_note(0, sig);
     }
   }
   // the image pyramids: built once here; across GPUs every rank builds them from the broadcast frames (pyramid::update, pyramid.hh:194-198)
@@ -888,8 +896,8 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   Scratch::Slot& slot = *g_scratch.cur;
   unsigned long long owner_sig = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(nscales * 16 + min_scale);
   for (int s_ = min_scale; s_ < nscales; s_++) owner_sig = (owner_sig * 1099511628211ull) ^ ((unsigned long long)ow_off[s_] << 20) ^ (unsigned long long)ow_bytes[s_];
-  const bool owner_known_clean = self_cleaning && slot.user[1] == owner_sig;
-  slot.user[1] = 0;   // until this call has queued every descent
+  const bool owner_known_clean = self_cleaning && slot.note(1, owner_sig);   // never while recording / on a buffer a graph was recorded on
+  slot.set_note(1, 0);   // until this call has queued every descent
   if (reset_up_front) {
     ResetArgs ra; ra.nseg = 0; uint32_t blocks = 0;
     for (int s_ = min_scale; s_ < nscales; s_++)
@@ -1017,7 +1025,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
     sdof_readback_kernel<true><<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize * ms, ms, maps(0, min_scale), out_pos, out_dist, out_valid, *link);
   } else sdof_readback_kernel<false><<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize * ms, ms, maps(0, min_scale), out_pos, out_dist, out_valid, MergeLinkArgs{});
   VPP_LAUNCH_CHECK();
-  if (self_cleaning) slot.user[1] = owner_sig;   // every descent of this call is queued: the owner maps of this layout end up empty
+  if (self_cleaning) slot.set_note(1, owner_sig);   // every descent of this call is queued: the owner maps of this layout end up empty
   return VPP_OK;
 }
 

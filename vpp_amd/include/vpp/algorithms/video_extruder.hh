@@ -44,6 +44,7 @@ struct state {
   trajectories_type trajectories;
   bool host_stale = false;    // the device ran an update the host copies have not seen
   bool host_edited = false;   // the caller may have changed the host copies since the last upload (a non-const access was handed out)
+  bool force_upload = false;  // the device tracker was rebuilt (longer rings): it is EMPTY, whatever the host copies compare equal to
   int frame_id = -1;
   // the state in the flat form the C ABI moves (positions, velocities, ages, trajectory lengths / start frames / alive flags, ring points newest
   // first from slot 0); `seen` = what the last download produced, compared against the host copies before an upload
@@ -63,7 +64,9 @@ struct state {
 
   void ensure_device(int max_trajectory_length) {
     if (h && max_trajectory_length < slots) return;
-    if (h) { materialise(); host_edited = true; vpp_video_extruder_destroy(h); h = nullptr; }  // longer trajectories than the rings hold: rebuild around the host copy
+    // longer trajectories than the rings hold: rebuild around the host copy.  The new tracker starts empty, so the upload must happen even though the
+    // host copies equal what was last downloaded (the host_differs() shortcut of begin_update is about an UNCHANGED device state).
+    if (h) { materialise(); host_edited = true; force_upload = true; vpp_video_extruder_destroy(h); h = nullptr; }
     const int capacity = std::max(max_trajectory_length, 15);
     device::check(vpp_video_extruder_create(&h, domain.nrows(), domain.ncols(), capacity), "vpp_video_extruder_create");
     device::check(vpp_video_extruder_trajectory_slots(h, &slots), "vpp_video_extruder_trajectory_slots");
@@ -123,6 +126,7 @@ struct state {
     device::check(vpp_video_extruder_upload(h, n, frame_id, (const int32_t*)f.pos.data(), (const int32_t*)f.vel.data(), f.age.data(), f.len.data(), f.start.data(), f.alive.data(), head.data(),
                                             f.ring.data(), device::stream()), "vpp_video_extruder_upload");
     host_edited = false;
+    force_upload = false;
     seen_valid = false;
   }
 };
@@ -171,11 +175,11 @@ template <class... OPTS> vpp_video_extruder_params begin_update(video_extruder_c
   p.propagation = opts.get(_propagation, 2);
   state& s = ctx.internal_state();
   s.ensure_device(p.max_trajectory_length);
-  if (s.host_edited && s.frame_id == ctx.frame_id) {   // a non-const view was handed out: upload only if the copies really changed
+  if (s.host_edited && !s.force_upload && s.frame_id == ctx.frame_id) {   // a non-const view was handed out: upload only if the copies really changed
     s.materialise();
     if (!s.host_differs()) s.host_edited = false;
   }
-  if (s.host_edited || s.frame_id != ctx.frame_id) {  // the caller edited the views (or ctx.frame_id): the device continues from the host's copy
+  if (s.host_edited || s.force_upload || s.frame_id != ctx.frame_id) {  // the caller edited the views (or ctx.frame_id): the device continues from the host's copy
     s.materialise();
     s.frame_id = ctx.frame_id;
     s.upload();
