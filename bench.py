@@ -238,11 +238,34 @@ def main():
     def launch_box(i, stream):
         box_batch(darr[i % nb], sarr[i % nb], FPS, 5, 5, stream)
 
+    # ---- self-check (benchmarks/box_5x5_filter2.cc:26-41 checks its result inline): what the TIMED launches left in HBM is compared, frame by frame and
+    # byte by byte, with the oracle's result for the same source (the oracle is the checker here, never the thing measured)
+    from oracle import binding as _orc_binding
+    _chk = _orc_binding.load(omp=True)
+    _chk.orc_fill_border(P(src_h.desc), 0, None)
+    want_h = src_h.like(border=0)
+    assert _chk.orc_box_filter(P(want_h.desc), P(src_h.desc), 5, 5) == 0
+    want_d = DeviceImage.from_host(want_h, dev)
+    checked = {"how": "after the timed regions every result frame in HBM is compared byte for byte with the oracle's box5x5 of the same source (torch.equal on the device), "
+                      "the results are zeroed between the batch leg and the per-frame leg; add: every timed triple against the oracle's A = B + C"}
+
+    def check_box(tag):
+        w = want_d.store[want_d.shift:want_d.shift + want_d.alloc_bytes]
+        bad = [k for k, d in enumerate(dsts) if not torch.equal(d.store[d.shift:d.shift + d.alloc_bytes], w)]
+        checked[tag] = not bad
+        if bad:
+            sys.stderr.write(f"[bench] SELF-CHECK FAILED ({tag}): frames {bad[:8]} differ from the oracle\n")
+        for d in dsts:
+            d.store.zero_()
+        torch.cuda.synchronize()
+
     def launch_box_single(i, stream):
         k = i % nsets
         box(P(ddesc[k]), P(sdesc[k]), 5, 5, stream)
 
     wall, ev = timed(launch_box, args.steps, args.warmup, preheat_s=args.preheat, c_graph=True)
+    if args.steps + args.warmup >= nb:   # every frame set was written by a timed or warm-up launch
+        check_box("box5x5_batch")
     box_mode = dict(launch_mode)
     box_regions = region_log[-1]
     ms_per_step = wall / args.steps * 1e3
@@ -255,6 +278,31 @@ def main():
             "how": "achieved = algorithmic bytes / average launch duration over the K timed launches themselves (event-record nodes in front of the first and behind the last of them)",
             "frac_sustained": alg_bytes / sustained_s / 1e9 / HBM_PEAK_GBS, "avg_launch_us_sustained": sustained_s * 1e6, "sample": box_regions["sample"]}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    # what a plain copy of the same geometry reaches on THIS box in THIS run: the same kernel instance with the arithmetic compiled out (vpp_debug_box_copy_batch),
+    # the same K launches over the same frame sets in one event-timed graph — a roofline fraction of 0.69 reads as "0.96 of copy on a box whose copy runs at 0.72"
+    try:
+        sp = ctypes.c_void_p(side.cuda_stream)
+        gh = ctypes.c_void_p()
+        capi.check(lib.vpp_graph_begin(sp))
+        for i in range(args.steps):
+            capi.check(lib.vpp_debug_box_copy_batch(darr[i % nb], sarr[i % nb], FPS, sp))
+        capi.check(lib.vpp_graph_end(sp, 1, ctypes.byref(gh)))
+        ts = []
+        for _ in range(4):
+            capi.check(lib.vpp_graph_launch(gh, sp)); torch.cuda.synchronize()
+            ms = ctypes.c_float(0); capi.check(lib.vpp_graph_elapsed_ms(gh, ctypes.byref(ms))); ts.append(ms.value)
+        lib.vpp_graph_destroy(gh)
+        copy_s = sorted(ts[1:])[1] * 1e-3 / args.steps
+        roof["copy_frac"] = alg_bytes / copy_s / 1e9 / HBM_PEAK_GBS
+        roof["frac_of_copy"] = roof["frac"] / roof["copy_frac"]
+        roof["copy_launch_us"] = copy_s * 1e6
+        roof["copy_how"] = "the timed kernel instance with its arithmetic compiled out (same loads, same stores, same grid), same K launches over the same frame sets, event-timed graph, median of 3"
+        for d in dsts:
+            d.store.zero_()
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        roof["copy_frac"] = None
+        roof["copy_error"] = f"{type(e).__name__}: {e}"
 
     def pmc_traffic(prefix):
         """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json, tools/make_traffic_json.py:
@@ -271,11 +319,47 @@ def main():
         roof["traffic_source"] += " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this kernel symbol, FETCH doubled per the gfx950 note)"
     # the same frames one launch per frame (the reference's call form, benchmarks/box_5x5_filter2.cc:43-69): K x FPS launches in the region
     swall, sev = timed(launch_box_single, args.steps * FPS, args.warmup, preheat_s=0.0, c_graph=True)
+    check_box("box5x5_one_launch_per_frame")
+    per_frame_mode = dict(launch_mode)
     single_s = region_log[-1]["sample"]["us_per_launch"] * 1e-6
     per_frame = {"gpixels_per_s": npx * world / (swall / (args.steps * FPS)) / 1e9, "avg_launch_us_in_region": sev / (args.steps * FPS) * 1e6,
-                 "avg_launch_us_sustained": single_s * 1e6, "kernel": "box_u8_wide_kernel<3, 5, 5, 2, 4, ...>",
+                 "avg_launch_us_sustained": single_s * 1e6, "kernel": "box_u8_wide_kernel<3, 5, 5, 6, 4, ...> carrying the frames of up to 64 recorded calls (box_u8_wide_kernel<3, 5, 5, 2, 4, ...> per call without the batching)",
                  "frac_in_region": 6.0 * npx / (sev / (args.steps * FPS)) / 1e9 / HBM_PEAK_GBS, "frac_sustained": 6.0 * npx / single_s / 1e9 / HBM_PEAK_GBS,
-                 "traffic": pmc_traffic("box_u8_wide_kernel<3, 5, 5, 2")[0]}
+                 "launch": per_frame_mode["mode"],
+                 "how": "K x 64 calls of vpp_box_filter on ONE stream, one 4K frame per call (the reference's call form), recorded into a launch graph through the C ABI with the "
+                        "library's defaults: while a stream is recorded, a call whose frame is unrelated to what was recorded since the previous call's node is folded into that node "
+                        "(record-time batching, box.hip: the node is re-parameterised to carry one frame more, up to 64), so the replay makes one launch per 64 calls; data flow is kept "
+                        "exactly (tests/test_gpu_core.py::test_recorded_per_frame_calls_are_batched_and_keep_their_data_flow).  'without_record_time_batching' = the same calls as one "
+                        "launch each; eager callers get 'one_stream_serial' (tools/overlap_lab.hip: the AQL barrier bit cannot be dropped on gfx950, hipExtAnyOrderLaunch does not overlap)"}
+    def graph_us_per_call(ncalls, launch):
+        """(us per call, kernel nodes in the graph) of `ncalls` calls recorded into one event-timed launch graph; median of 3 replays after one."""
+        sp = ctypes.c_void_p(side.cuda_stream)
+        gh = ctypes.c_void_p()
+        capi.check(lib.vpp_graph_begin(sp))
+        for i in range(ncalls):
+            launch(i, sp)
+        capi.check(lib.vpp_graph_end(sp, 1, ctypes.byref(gh)))
+        nodes = ctypes.c_int(0)
+        lib.vpp_debug_graph_kernel_nodes(gh, ctypes.byref(nodes))
+        ts = []
+        for _ in range(4):
+            capi.check(lib.vpp_graph_launch(gh, sp)); torch.cuda.synchronize()
+            ms = ctypes.c_float(0); capi.check(lib.vpp_graph_elapsed_ms(gh, ctypes.byref(ms))); ts.append(ms.value)
+        lib.vpp_graph_destroy(gh)
+        return sorted(ts[1:])[1] * 1e3 / ncalls, nodes.value
+
+    us_rec, nodes_rec = graph_us_per_call(256, launch_box_single)
+    per_frame["kernel_nodes_per_256_calls"] = nodes_rec
+    # the same calls with the record-time batching switched off: REALLY one launch per call, every launch behind the previous one (what an eager caller gets from one
+    # stream), and as two lanes of sibling nodes (IndependentCall without the batching)
+    lib.vpp_set_tuning(b"box.coalesce", 0)
+    forms = {}
+    for name, width in (("one_stream_serial", 1), ("two_lanes_of_sibling_nodes", 2)):
+        lib.vpp_set_tuning(b"launch.capture_width", width)
+        us, nodes = graph_us_per_call(256, launch_box_single)
+        forms[name] = {"us_per_frame": round(us, 3), "frac": round(6.0 * npx / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernel_nodes_per_256_calls": nodes}
+    lib.vpp_set_tuning(b"launch.capture_width", 1)   # the explicit multi-stream legs below fork and join themselves
+    per_frame["without_record_time_batching"] = forms
     # frames per launch against the roofline fraction (a launch pays ~5 us of ramp and drain whatever its size): event-timed graphs of >= 64 frames
     sweep = {}
     for fpl in (1, 2, 4, 8, 16, 32, 64):
@@ -329,6 +413,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             on_streams[str(ns)] = {"error": f"{type(e).__name__}: {e}"}
     per_frame["one_launch_per_frame_on_n_streams"] = on_streams
+    lib.vpp_set_tuning(b"box.coalesce", -1); lib.vpp_set_tuning(b"launch.capture_width", -1)
 
     # ---------------- 4K int32 pixel_wise add ----------------
     nadd = 16  # triples per step (16 x 99.5 MB = 1.6 GB per launch, like the box step; kPwBatchMax)
@@ -351,6 +436,11 @@ def main():
         add_batch(0, aarr[j], barr[j], carr[j], nadd, stream)   # one step = 16 triples, one launch
 
     awall, aev = timed(launch_add, args.steps, args.warmup, preheat_s=args.preheat, c_graph=True)
+    a_want = b_h.like()
+    assert _chk.orc_pixelwise_binary(0, P(a_want.desc), P(b_h.desc), P(b_h.desc)) == 0
+    a_want_d = DeviceImage.from_host(a_want, dev)
+    w = a_want_d.store[a_want_d.shift:a_want_d.shift + a_want_d.alloc_bytes]
+    checked["add4k"] = all(torch.equal(x.store[x.shift:x.shift + x.alloc_bytes], w) for x in A)
     add_s = aev / args.steps
     add_sus = region_log[-1]["sample"]["us_per_launch"] * 1e-6
     add4k = {"gpixels_per_s": npx * nadd * world / (awall / args.steps) / 1e9, "frames_per_step": nadd, "avg_launch_us": add_s * 1e6,
@@ -415,11 +505,14 @@ def main():
                                       f"one step = a batch of {FPS} frames in one launch, over {nsets} distinct frame sets ({nsets * 25} MB of sources + {nsets * 25} MB of results)", "frames_per_step": FPS, "parallelism": f"replicas x{world}", "launch": box_mode["mode"], "events": box_mode["events"], "timed_regions": {"count": max(1, args.regions), "reported": "median by wall clock", "wall_ms": box_regions["wall_ms"], "event_ms": box_regions["event_ms"]},
                           "preheat": {"untimed_ms": round(preheat["ms"], 1), "untimed_launches": preheat["launches"],
                                       "note": "replays of the same graphs before the timed regions (clock ramp); not part of steps / value"}},
-               "roofline": roof, "cpu_baseline": cpu, "add4k": add4k, "box5x5_one_launch_per_frame": per_frame}
+               "roofline": roof, "cpu_baseline": cpu, "add4k": add4k, "box5x5_one_launch_per_frame": per_frame,
+               "checked": all(v for k, v in checked.items() if k != "how"), "checks": checked}
         out.update(extras)
         print(json.dumps(out))
     if multi:
         dist.destroy_process_group()
+    if not all(v for k, v in checked.items() if k != "how"):
+        sys.exit(3)   # a timed kernel left a wrong result: the line above says which leg
 
 
 if __name__ == "__main__":

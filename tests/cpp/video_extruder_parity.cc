@@ -143,7 +143,7 @@ int main(int argc, char** argv) {
   // device tracker is rebuilt around the host copy and must continue from it), then lowered (one pop per update: lengths stay above the new bound)
   if (T >= 7) {
     std::vector<int> sched(T - 1);
-    for (int t = 0; t < T - 1; t++) sched[t] = t < 3 ? 4 : t < T - 3 ? 40 : 6;
+    for (int t = 0; t < T - 1; t++) sched[t] = t < 2 ? 3 : t < T - 3 ? 40 : 5;
     CHECK(ref_video_extruder_run_schedule(descs.data(), T, 10, 10, 5, sched.data(), 3, 9, 2, want.data(), wlen.data(), cap, &wn, &wfid) == 0);
     video_extruder_ctx c4 = video_extruder_init(make_box2d(nr, nc));
     for (int t = 1; t < T; t++)
@@ -152,8 +152,8 @@ int main(int argc, char** argv) {
     if (!same_as_reference("changing max_trajectory_length", c4, want, wlen, wn, wfid, nr, nc, &alive, &moved)) return 1;
     int longest = 0;
     for (int i = 0; i < wn; i++) longest = std::max(longest, wlen[i]);
-    CHECK(longest > 6);   // the schedule really left trajectories above the final bound
-    std::printf("  _max_trajectory_length 4 -> 40 -> 6 mid-sequence: identical (%d entries, longest trajectory %d)\n", wn, longest);
+    CHECK(longest > 5);   // the schedule really left trajectories above the final bound (one pop per update: a trajectory of 6 or 7 points stays that long)
+    std::printf("  _max_trajectory_length 3 -> 40 -> 5 mid-sequence: identical (%d entries, longest trajectory %d)\n", wn, longest);
   }
   std::printf("video_extruder_parity ok\n");
   return 0;

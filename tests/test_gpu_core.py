@@ -456,3 +456,75 @@ def test_batches_whose_frames_feed_each_other_run_in_sequence(lib, orc):
     _sync(lib)
     for k in range(n):
         np.testing.assert_array_equal(dB[k].download().view(), B[k].view() + C[k].view())
+
+
+def _kernel_nodes(lib, graph):
+    n = ctypes.c_int()
+    capi.check(lib.vpp_debug_graph_kernel_nodes(graph, ctypes.byref(n)))
+    return n.value
+
+
+def test_recorded_per_frame_calls_are_batched_and_keep_their_data_flow(lib, orc):
+    """Record-time batching (box.hip): per-frame vpp_box_filter calls recorded into a launch graph fold into the previous call's node while their
+    frames are unrelated to everything recorded in between — and only then.  A sequence with 70 independent frames, a frame that reads an earlier
+    result (RAW on the batch), frames related only to what the current node already waits for (they join it), a frame that overwrites a source the
+    first batch read (WAR) and a frame that reads what the current node writes (a node of its own): results equal the calls made one after the other
+    (the oracle applies them in sequence), and the graph has the 4 kernel nodes the data flow needs instead of 75.  With the knobs off: 75 nodes,
+    same results."""
+    shape, ch = (48, 200), 3
+    rng_ims = lambda: [rand_image(*shape, vi.U8, ch, border=2, seed=300 + k, align=16, fill_border=True) for k in range(210)]
+    seq = [(100 + k, k) for k in range(70)] + [(200, 103), (201, 104), (5, 150), (202, 5), (203, 202)]
+    host = rng_ims()
+    for d, s_ in seq:
+        assert orc.orc_box_filter(P(host[d].desc), P(host[s_].desc), 5, 5) == 0
+    st = torch_stream()
+    sp = ctypes.c_void_p(st.cuda_stream)
+    for knobs, want_nodes in (({}, 5), ({b"box.coalesce": 0, b"launch.capture_width": 1}, 75)):
+        for k, v in knobs.items():
+            lib.vpp_set_tuning(k, v)
+        try:
+            dev = [DeviceImage.from_host(x) for x in rng_ims()]
+            import torch
+            torch.cuda.synchronize()
+            graph = ctypes.c_void_p()
+            capi.check(lib.vpp_graph_begin(sp))
+            for d, s_ in seq:
+                capi.check(lib.vpp_box_filter(P(dev[d].desc), P(dev[s_].desc), 5, 5, sp))
+            capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(graph)))
+            assert _kernel_nodes(lib, graph) == want_nodes
+            capi.check(lib.vpp_graph_launch(graph, sp)); capi.check(lib.vpp_sync(sp))
+            for k in range(210):
+                np.testing.assert_array_equal(dev[k].download().raw, host[k].raw, err_msg=f"image {k} ({knobs})")
+            capi.check(lib.vpp_graph_destroy(graph))
+        finally:
+            for k in knobs:
+                lib.vpp_set_tuning(k, -1)
+
+
+def torch_stream():
+    import torch
+    return torch.cuda.Stream()
+
+
+def test_recorded_adds_are_batched(lib, orc):
+    """The same for `A = B + C` on flat int images: 20 recorded calls are 2 kernel nodes (16 + 4 triples), a call that reads an earlier sum gets its own."""
+    import torch
+    n = 20
+    B = [rand_image(64, 128, vi.I32, seed=400 + k, lo=0, hi=2**20) for k in range(n)]
+    C = [rand_image(64, 128, vi.I32, seed=440 + k, lo=0, hi=2**20) for k in range(n)]
+    dB, dC = [DeviceImage.from_host(x) for x in B], [DeviceImage.from_host(x) for x in C]
+    dA = [DeviceImage(64, 128, vi.I32) for _ in range(n + 1)]
+    st = torch_stream(); sp = ctypes.c_void_p(st.cuda_stream)
+    torch.cuda.synchronize()
+    graph = ctypes.c_void_p()
+    capi.check(lib.vpp_graph_begin(sp))
+    for k in range(n):
+        capi.check(lib.vpp_pixelwise_binary(0, P(dA[k].desc), P(dB[k].desc), P(dC[k].desc), sp))
+    capi.check(lib.vpp_pixelwise_binary(0, P(dA[n].desc), P(dA[3].desc), P(dA[17].desc), sp))     # reads two earlier sums
+    capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(graph)))
+    assert _kernel_nodes(lib, graph) == 3
+    capi.check(lib.vpp_graph_launch(graph, sp)); capi.check(lib.vpp_sync(sp))
+    for k in range(n):
+        np.testing.assert_array_equal(dA[k].download().view(), B[k].view() + C[k].view())
+    np.testing.assert_array_equal(dA[n].download().view(), B[3].view() + C[3].view() + B[17].view() + C[17].view())
+    capi.check(lib.vpp_graph_destroy(graph))

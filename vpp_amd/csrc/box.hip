@@ -16,7 +16,11 @@
 //  * box_generic_kernel<T,S> — any dtype / window: LDS tile (+halo), taps summed in row-major order in the promoted
 //    type (order matters for float), C++ `/ (R*C)`.
 #include "common.hpp"
+#include <hip/hip_ext.h>
+#include <algorithm>
+#include <map>
 #include <type_traits>
+#include <vector>
 using namespace vpp_amd;
 
 namespace {
@@ -717,7 +721,10 @@ void launch_wide_cfg(const vpp_image_desc* dst, const vpp_image_desc* src, hipSt
       fr.sbase[k] = (const uint8_t*)src[b0 + k].first_pixel - (ptrdiff_t)src[b0 + k].border * src[b0 + k].pitch - 16;
       fr.dbase[k] = (uint8_t*)dst[b0 + k].first_pixel;
     }
-    box_u8_wide_kernel<CH, KR, KC, RW, WX, SAUX, LAUX, HALO, OCC, PROBE, NW><<<g.nbx * g.nby * nb, 64 * NW, 0, st>>>(g, fr, nb);
+    if (tuning("box.anyorder", 0))   // experiment (tools/overlap_lab.hip): the AQL packet without its barrier bit — may start before the stream's previous packet has completed
+      hipExtLaunchKernelGGL((box_u8_wide_kernel<CH, KR, KC, RW, WX, SAUX, LAUX, HALO, OCC, PROBE, NW>), dim3(g.nbx * g.nby * nb), dim3(64 * NW), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, g, fr, nb);
+    else
+      box_u8_wide_kernel<CH, KR, KC, RW, WX, SAUX, LAUX, HALO, OCC, PROBE, NW><<<g.nbx * g.nby * nb, 64 * NW, 0, st>>>(g, fr, nb);
   }
 }
 template <int CH, int RW, int WX, bool HALO, int NW>
@@ -917,6 +924,60 @@ template <int CH> int launch_stream_windows(const vpp_image_desc* dst, const vpp
   return -1;  // not a streaming window: the caller falls back to the LDS-tiled generic kernel
 }
 
+#ifndef VPP_BOX_LAB
+// ---- record-time batching of the per-frame call form ---------------------------------------------------------------------------------------------------
+// The reference filters one frame per call (benchmarks/box_5x5_filter2.cc:43-69).  Eagerly that is one launch per call, and a 50 MB launch reaches 47 % of
+// the HBM peak (ramp + drain behind a kernel boundary; tools/overlap_lab.hip: the AQL barrier bit cannot be dropped on this chip, two queues reach 59 %).
+// While a stream is being RECORDED, nothing runs yet — so a call whose frame is unrelated to everything recorded since the previous box call's node (or
+// related only to calls that node was itself recorded behind) does not add a node: the node of the previous call is re-parameterised to carry one frame
+// more (hipGraphKernelNodeSetParams on the graph under capture: the frame becomes another slot of the batch kernel's frame table, up to kBoxBatchMax).
+// A recorded loop of per-frame calls thereby replays as the batched launches of vpp_box_filter_batch, with the results of the calls in sequence.
+namespace {
+struct BoxCoalesce {
+  unsigned long long window = 0; hipGraphNode_t node = nullptr; int lane = 0; std::vector<hipGraphNode_t> behind;
+  int ch = 0, n = 0; vpp_image_desc d0{}, s0{}; BoxBatch frames{};
+};
+thread_local std::map<hipStream_t, BoxCoalesce> g_box_coalesce;
+template <int CH, int RW, int OCC> hipError_t set_batch_node(const BoxCoalesce& c) {
+  BoxGeom g = wide_geometry<CH, RW, 4, false, 4>(&c.d0, &c.s0, tuning("box.order", 0), tuning("box.mix", 0), tuning("box.slots", 8192));
+  BoxBatch fr = c.frames; int n = c.n;
+  void* args[3] = {&g, &fr, &n};
+  hipKernelNodeParams kp{};
+  kp.func = (void*)box_u8_wide_kernel<CH, 5, 5, RW, 4, kAuxNT, kAuxDefault, false, OCC, 0, 4>;
+  kp.gridDim = dim3((unsigned)(g.nbx * g.nby * n)); kp.blockDim = dim3(256); kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
+  return hipGraphKernelNodeSetParams(c.node, &kp);
+}
+template <int CH> hipError_t set_batch_node(const BoxCoalesce& c) {   // the instance launch_wide picks for c.n frames
+  if (c.n >= 4) return set_batch_node<CH, 6, 4>(c);
+  if (c.n >= 2) return set_batch_node<CH, 3, 8>(c);
+  return set_batch_node<CH, 2, 8>(c);
+}
+inline bool same_box_geometry(const vpp_image_desc& a, const vpp_image_desc& b) {
+  return a.nrows == b.nrows && a.ncols == b.ncols && a.pitch == b.pitch && a.border == b.border && a.dtype == b.dtype && a.channels == b.channels;
+}
+// true: the frame was folded into the node recorded by the previous box call
+bool coalesce_frame(IndependentCall& side, hipStream_t st, const vpp_image_desc* dst, const vpp_image_desc* src) {
+  BoxCoalesce& c = g_box_coalesce[st];
+  if (!(c.n > 0 && c.n < kBoxBatchMax && c.window == side.window() && c.ch == dst->channels && same_box_geometry(*dst, c.d0) && same_box_geometry(*src, c.s0))) return false;
+  for (hipGraphNode_t x : side.conflicts())
+    if (x == c.node || std::find(c.behind.begin(), c.behind.end(), x) == c.behind.end()) return false;   // related to the batch itself, or to something the batch does not wait for
+  c.frames.sbase[c.n] = (const uint8_t*)src->first_pixel - (ptrdiff_t)src->border * src->pitch - 16;
+  c.frames.dbase[c.n] = (uint8_t*)dst->first_pixel;
+  c.n++;
+  hipError_t e = hipErrorInvalidValue;
+  switch (c.ch) {
+    case 1: e = set_batch_node<1>(c); break;
+    case 2: e = set_batch_node<2>(c); break;
+    case 3: e = set_batch_node<3>(c); break;
+    case 4: e = set_batch_node<4>(c); break;
+  }
+  if (e != hipSuccess) { (void)hipGetLastError(); c.n = 0; return false; }   // this runtime cannot edit the node: the call records its own node (the old node still carries its frames)
+  side.absorbed_into(c.node, c.lane);
+  return true;
+}
+}  // namespace
+#endif
+
 // n frames of one geometry, one launch (u8 5x5 images the streaming kernel serves; anything else goes out as n calls of vpp_box_filter)
 extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream);
 extern "C" int vpp_box_filter_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int R, int C, void* stream) {
@@ -948,6 +1009,21 @@ extern "C" int vpp_box_filter_batch(const vpp_image_desc* dst, const vpp_image_d
   return VPP_OK;
 }
 
+// diagnostics (not part of include/vpp_amd.h): the data movement of the batched 4K vuchar3 kernel alone — the same instance (6 rows per wave, 4 strips per
+// workgroup, one XCD remap over the batch, the same descriptor loads and non-temporal stores) with the arithmetic compiled out: every lane stores the
+// centre row's 16 bytes it loaded.  bench.py times it beside the headline so that a roofline fraction can be read against what a plain copy of the
+// same geometry reaches on the same box in the same run (roofline.copy_frac).
+extern "C" int vpp_debug_box_copy_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, void* stream) {
+  VPP_REQUIRE(n >= 1 && dst && src, VPP_ERR_INVALID_ARG, "vpp_debug_box_copy_batch: invalid argument");
+  for (int k = 0; k < n; k++)
+    VPP_REQUIRE(valid_desc(&dst[k]) && valid_desc(&src[k]) && dst[k].dtype == VPP_U8 && dst[k].channels == 3 && same_domain(&dst[k], &dst[0]) && same_domain(&src[k], &dst[0]) &&
+                same_type(&src[k], &dst[0]) && src[k].pitch == src[0].pitch && dst[k].pitch == dst[0].pitch && src[k].border == src[0].border && src[k].border >= 2 &&
+                aligned16(&dst[k]) && aligned16(&src[k]) && fits_descriptor(&dst[k], &src[k]), VPP_ERR_UNSUPPORTED, "vpp_debug_box_copy_batch: frame %d: 16-byte aligned vuchar3 frames of one geometry", k);
+  launch_wide_cfg<3, 6, 4, kAuxNT, false, 4, 1>(dst, src, as_stream(stream), tuning("box.order", 0), 0, 8192, n);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
 extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream) {
   VPP_REQUIRE(valid_desc(dst) && valid_desc(src), VPP_ERR_INVALID_ARG, "vpp_box_filter: invalid descriptor");
   VPP_REQUIRE(same_domain(dst, src) && same_type(dst, src), VPP_ERR_INVALID_ARG, "vpp_box_filter: domain/type mismatch");
@@ -955,6 +1031,31 @@ extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* s
   VPP_REQUIRE(src->border >= (R > C ? R : C) / 2, VPP_ERR_BORDER_TOO_SMALL, "vpp_box_filter: src border %d < %d", src->border, (R > C ? R : C) / 2);
   VPP_REQUIRE(dst->first_pixel != src->first_pixel, VPP_ERR_INVALID_ARG, "vpp_box_filter: in-place not supported");
   hipStream_t st = as_stream(stream);
+  // while the stream is recorded into a launch graph: calls on unrelated images become sibling nodes (common.hpp, IndependentCall)
+#ifndef VPP_BOX_LAB
+  const Extent wr = extent_of(*dst), rd = extent_of(*src);
+  IndependentCall side_by_side(st, &wr, 1, &rd, 1);
+  // the frames the batched streaming kernel serves (the test of vpp_box_filter_batch): candidates for record-time batching
+  const bool batchable = side_by_side.active() && dst->dtype == VPP_U8 && R == 5 && C == 5 && dst->channels <= 4 && src->border >= 2 && aligned16(dst) && aligned16(src) &&
+                         fits_descriptor(dst, src) && !tuning("box.force_generic", 0) && tuning("box.impl", 2) == 2 && tuning("box.batch", 1) && tuning("box.coalesce", 1);
+  if (batchable && coalesce_frame(side_by_side, st, dst, src)) return VPP_OK;
+  struct Remember {   // after the call's own launch: its node becomes the one the next calls may join
+    IndependentCall& side; hipStream_t st; const vpp_image_desc *dst, *src; bool on;
+    ~Remember() {
+      if (!side.active()) return;
+      BoxCoalesce& c = g_box_coalesce[st];
+      c.n = 0;
+      if (!on) return;
+      int lane = 0; std::vector<hipGraphNode_t> behind;
+      const unsigned long long window = side.window();
+      hipGraphNode_t node = side.finish(&lane, &behind);
+      if (!node) return;
+      c.window = window; c.node = node; c.lane = lane; c.behind = behind; c.ch = dst->channels; c.n = 1; c.d0 = *dst; c.s0 = *src;
+      c.frames.sbase[0] = (const uint8_t*)src->first_pixel - (ptrdiff_t)src->border * src->pitch - 16;
+      c.frames.dbase[0] = (uint8_t*)dst->first_pixel;
+    }
+  } remember{side_by_side, st, dst, src, batchable};
+#endif
   if (dst->dtype == VPP_U8 && R == 5 && C == 5 && dst->channels <= 4 && aligned16(dst) && aligned16(src) && !tuning("box.force_generic", 0)) {
     switch (dst->channels) {
       case 1: return launch_fast<1>(dst, src, st);

@@ -41,6 +41,10 @@ int comm_group_end();
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// memset by a kernel of this library (runtime.hip), for every fill that may be recorded into a launch graph: on ROCm 7.2 the runtime's memset NODES were
+// not ordered with the kernel nodes around them (a replayed flow read a half-zeroed control block and faulted), and eagerly hipMemsetAsync is two dispatches.
+int device_fill(void* dst, int byte, size_t bytes, hipStream_t st);
+
 __host__ __device__ inline int dtype_size(int dt) {
   switch (dt) { case VPP_U8: case VPP_I8: return 1; case VPP_U16: case VPP_I16: return 2; default: return 4; }
 }
@@ -101,6 +105,46 @@ inline bool batch_frames_interfere(int n, const vpp_image_desc* dst, const vpp_i
   }
   return false;
 }
+
+// ---- independent calls recorded side by side -------------------------------------------------------------------------------------------------------
+// A stream orders every call behind the one before it, and a 4K streaming launch pays ~4.6 us of ramp and drain that the next launch cannot hide
+// behind a kernel boundary (one 50 MB launch per call reaches 47 % of the HBM peak, 64 frames in one launch 70-75 %).  When a
+// stream is being RECORDED into a launch graph, the order only has to hold where data flows: a call that brackets its launches with an
+// IndependentCall — stating the byte extents it writes and reads — is recorded behind (a) whatever the stream depended on when the window opened
+// (work of callers this library cannot see), (b) the last recorded call of its lane (at most `launch.capture_width` calls side by side) and (c) every
+// recorded call whose extents its own overlap (write / write, write / read, read / write): data flow is kept exactly, independent calls become
+// sibling nodes whose tails overlap when the graph runs.  After each call the stream's dependency set is the join of all lanes, so anything recorded
+// by anyone else afterwards waits for all of them — for every other observer the stream's semantics are unchanged.  Outside a capture it does nothing.
+struct Extent { uintptr_t lo, hi; };
+inline Extent extent_of(const vpp_image_desc& d) {   // the whole bordered area
+  const uintptr_t p = (uintptr_t)d.first_pixel;
+  const size_t es = (size_t)elem_bytes(&d);
+  return Extent{p - (size_t)d.border * d.pitch - (size_t)d.border * es, p + (size_t)(d.nrows - 1 + d.border) * d.pitch + (size_t)(d.ncols + d.border) * es};
+}
+class IndependentCall {
+ public:
+  IndependentCall(hipStream_t st, const Extent* writes, int nw, const Extent* reads, int nr);
+  ~IndependentCall() { if (active_) (void)finish(); }
+  IndependentCall(const IndependentCall&) = delete;
+  IndependentCall& operator=(const IndependentCall&) = delete;
+  // --- for calls that can fold themselves into a node they recorded earlier (record-time batching: vpp_box_filter, vpp_pixelwise_binary) ---
+  bool active() const { return active_; }                 // the stream is being recorded and a window is open
+  unsigned long long window() const { return window_; }   // identifies the window: a node of an earlier window must not be extended
+  // recorded calls (nodes) whose extents this call's overlap: it may only join a node that is none of them and was itself recorded behind all of them
+  const std::vector<hipGraphNode_t>& conflicts() const { return conflicts_; }
+  // this call's work was folded into `node` (recorded by an earlier call of this window in `lane`): its extents are booked on that node, nothing new is recorded
+  void absorbed_into(hipGraphNode_t node, int lane);
+  // the call's launches are recorded: books them, rejoins the lanes; returns the call's (last) node — nullptr when there is no single one — its lane and what it was recorded behind
+  hipGraphNode_t finish(int* lane = nullptr, std::vector<hipGraphNode_t>* recorded_behind = nullptr);
+ private:
+  hipStream_t st_;
+  bool active_ = false;
+  int lane_ = 0;
+  unsigned long long window_ = 0;
+  std::vector<hipGraphNode_t> conflicts_;
+  Extent w_[2], r_[3];
+  int nw_ = 0, nr_ = 0;
+};
 
 // Bumped whenever something may have left ANY scratch buffer in an unknown state (a device-side protocol that gave up, check_device_error): every note
 // taken before the bump stops being believed.

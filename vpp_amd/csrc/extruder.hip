@@ -396,7 +396,7 @@ static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
       ve_count_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum);
       ve_scan_kernel<<<1, 1024, 0, st>>>(nblocks, ve->blocksum, ve->dcount);
       ve_index_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum, ve->newidx);
-    } else VPP_HIP_TRY(hipMemsetAsync(ve->dcount, 0, 4, st));
+    } else { rc = device_fill(ve->dcount, 0, 4, st); if (rc != VPP_OK) return rc; }
     if (det_cap > ve->det_cap) {
       ve_quiesce(ve);
       dfree(ve->det);

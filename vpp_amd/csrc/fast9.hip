@@ -741,7 +741,7 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
   const bool keys_clean = keyed && sl.note(0, key_sig);
   sl.set_note(0, 0);   // until this call's write pass is queued (an error return in between must not leave a wrong note)
   const uint32_t bs_magic = block_size >= 2 ? (uint32_t)((1ull << 32) / (unsigned)block_size) + 1u : 0u;   // x / bs = umulhi(x, magic), exact for x < 2^16
-  if (keyed && !keys_clean) VPP_HIP_TRY(hipMemsetAsync(blkkey, 0, (size_t)nblocks * 8, st));
+  if (keyed && !keys_clean) { const int rf = device_fill(blkkey, 0, (size_t)nblocks * 8, st); if (rf != VPP_OK) return rf; }
   if (impl == 2) {
 #define VPP_FAST_DETECT2(R)                                                                                                                             \
     if (keyed) fast9_detect2_kernel<R, VPP_FAST9_BLOCKWISE><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot);           \

@@ -109,7 +109,7 @@ template <class V> int run(const vpp_image_desc* img, hipStream_t st) {
   uint8_t* state = base;
   int32_t *list[2] = {(int32_t*)(base + off_list0), (int32_t*)(base + off_list1)}, *cnt = (int32_t*)(base + off_cnt);
   Img2<V> a{(uint8_t*)img->first_pixel, img->pitch, img->nrows, img->ncols};
-  VPP_HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
+  { const int rf = device_fill(cnt, 0, 8, st); if (rf != VPP_OK) return rf; }
   dim3 grid((img->ncols + 255) / 256, img->nrows);
   lm_classify_kernel<V><<<grid, 256, 0, st>>>(a, state, list[0], cnt);
   int n = 0, cur = 0;
@@ -117,7 +117,7 @@ template <class V> int run(const vpp_image_desc* img, hipStream_t st) {
   VPP_HIP_TRY(hipStreamSynchronize(st));
   while (n > 0) {
     if (n <= 65536) { lm_resolve_kernel<V><<<1, 1024, 0, st>>>(a, state, list[cur], n); break; }
-    VPP_HIP_TRY(hipMemsetAsync(cnt + (1 - cur), 0, 4, st));
+    { const int rf = device_fill(cnt + (1 - cur), 0, 4, st); if (rf != VPP_OK) return rf; }
     lm_round_kernel<V><<<(n + 255) / 256, 256, 0, st>>>(a, state, list[cur], n, list[1 - cur], cnt + (1 - cur));
     cur = 1 - cur;
     VPP_HIP_TRY(hipMemcpyAsync(&n, cnt + cur, 4, hipMemcpyDeviceToHost, st));

@@ -1,5 +1,6 @@
 // runtime.hip — device/runtime entry points of the C ABI (include/vpp_amd.h "runtime" block).
 #include "common.hpp"
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <map>
@@ -44,6 +45,151 @@ int check_device_error(const char* where) {
 static std::atomic<unsigned> g_notes_epoch{1};
 unsigned notes_epoch() { return g_notes_epoch.load(std::memory_order_relaxed); }
 void invalidate_scratch_notes() { g_notes_epoch.fetch_add(1, std::memory_order_relaxed); }
+
+// ---- device_fill (common.hpp): 16-byte units for the aligned body, the first workgroup also writes the unaligned head and tail bytes
+namespace {
+__global__ __launch_bounds__(256) void fill_bytes_kernel(uint8_t* __restrict__ p, size_t head, size_t units, size_t tail, uint32_t v32) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < units) ((uint4*)(p + head))[i] = make_uint4(v32, v32, v32, v32);
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < head) p[threadIdx.x] = (uint8_t)v32;
+    if (threadIdx.x < tail) p[head + units * 16 + threadIdx.x] = (uint8_t)v32;
+  }
+}
+}  // namespace
+int device_fill(void* dst, int byte, size_t bytes, hipStream_t st) {
+  if (!bytes) return VPP_OK;
+  VPP_REQUIRE(dst, VPP_ERR_INVALID_ARG, "device_fill: null");
+  const size_t head = std::min(bytes, (size_t)((16 - ((uintptr_t)dst & 15)) & 15)), units = (bytes - head) / 16, tail = bytes - head - units * 16;
+  const uint32_t v32 = 0x01010101u * (uint32_t)(byte & 255);
+  fill_bytes_kernel<<<(unsigned)std::max<size_t>(1, (units + 255) / 256), 256, 0, st>>>((uint8_t*)dst, head, units, tail, v32);
+  VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+// ---- IndependentCall (common.hpp) --------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kMaxLanes = 16;
+struct Lane { hipGraphNode_t last = nullptr; };
+// what the recorded calls of this window touched: per distinct extent its last writer and, per lane, the last reader since that write
+struct Touch { Extent e; hipGraphNode_t writer = nullptr; hipGraphNode_t reader[kMaxLanes] = {}; };
+struct CaptureWindow {
+  unsigned long long id = 0;
+  std::vector<hipGraphNode_t> base, join;
+  Lane lanes[kMaxLanes];
+  int nlanes = 0;
+  size_t count = 0;
+  std::vector<Touch> touched;
+  std::vector<hipGraphNode_t> deps;   // of the call being recorded
+  unsigned long long serial = 0;      // of this window (a node recorded in an earlier window must not be extended any more)
+};
+thread_local std::map<hipStream_t, CaptureWindow> g_windows;
+thread_local unsigned long long g_window_serial = 0;
+inline bool overlap(const Extent& a, const Extent& b) { return a.lo < b.hi && b.lo < a.hi; }
+inline bool same_set(const std::vector<hipGraphNode_t>& a, const hipGraphNode_t* b, size_t nb) {
+  if (a.size() != nb) return false;
+  for (size_t i = 0; i < nb; i++) if (std::find(a.begin(), a.end(), b[i]) == a.end()) return false;
+  return true;
+}
+inline void add_unique(std::vector<hipGraphNode_t>& v, hipGraphNode_t n) { if (n && std::find(v.begin(), v.end(), n) == v.end()) v.push_back(n); }
+}  // namespace
+
+IndependentCall::IndependentCall(hipStream_t st, const Extent* writes, int nw, const Extent* reads, int nr) : st_(st) {
+  const int W = std::min(tuning("launch.capture_width", 2), kMaxLanes);
+  if (W < 1 || nw > 2 || nr > 3) return;
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  if (hipStreamGetCaptureInfo_v2(st, &status, &id, &graph, &deps, &ndeps) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (status != hipStreamCaptureStatusActive) return;
+  CaptureWindow& cw = g_windows[st];
+  // a new capture, or somebody else has recorded on the stream since the last bracketed call: a new window opens behind whatever the stream depends on now
+  if (cw.id != id || !same_set(cw.join, deps, ndeps) || cw.touched.size() > 4096) {
+    cw = CaptureWindow();
+    cw.id = id;
+    cw.serial = ++g_window_serial;
+    cw.base.assign(deps, deps + ndeps);
+  }
+  window_ = cw.serial;
+  lane_ = cw.nlanes < W ? cw.nlanes : (int)(cw.count % (size_t)W);
+  for (const Touch& t : cw.touched) {
+    bool ww = false, rw = false;   // this call writes what was touched / reads what was written
+    for (int i = 0; i < nw; i++) ww = ww || overlap(writes[i], t.e);
+    for (int i = 0; i < nr; i++) rw = rw || overlap(reads[i], t.e);
+    if (ww || rw) add_unique(conflicts_, t.writer);
+    if (ww) for (hipGraphNode_t r : t.reader) add_unique(conflicts_, r);
+  }
+  cw.deps = cw.base;
+  if (lane_ < cw.nlanes) add_unique(cw.deps, cw.lanes[lane_].last);
+  for (hipGraphNode_t c : conflicts_) add_unique(cw.deps, c);
+  if (hipStreamUpdateCaptureDependencies(st, cw.deps.data(), cw.deps.size(), hipStreamSetCaptureDependencies) != hipSuccess) { (void)hipGetLastError(); cw = CaptureWindow(); return; }
+  nw_ = nw; nr_ = nr;
+  for (int i = 0; i < nw; i++) w_[i] = writes[i];
+  for (int i = 0; i < nr; i++) r_[i] = reads[i];
+  active_ = true;
+}
+
+namespace {
+void book(CaptureWindow& cw, hipGraphNode_t node, int lane, const Extent* w, int nw, const Extent* r, int nr) {
+  auto touch = [&](const Extent& e) -> Touch& {
+    for (Touch& t : cw.touched) if (t.e.lo == e.lo && t.e.hi == e.hi) return t;
+    cw.touched.push_back(Touch()); cw.touched.back().e = e;
+    return cw.touched.back();
+  };
+  for (int i = 0; i < nw; i++) { Touch& t = touch(w[i]); t.writer = node; for (hipGraphNode_t& x : t.reader) x = nullptr; }
+  for (int i = 0; i < nr; i++) touch(r[i]).reader[lane] = node;
+}
+// after a call: the stream depends on every lane's last node (and on what the window opened behind), so whatever anyone records next waits for all of them
+bool rejoin(CaptureWindow& cw, hipStream_t st) {
+  cw.join = cw.base;
+  for (int l = 0; l < cw.nlanes; l++) add_unique(cw.join, cw.lanes[l].last);
+  if (hipStreamUpdateCaptureDependencies(st, cw.join.data(), cw.join.size(), hipStreamSetCaptureDependencies) == hipSuccess) return true;
+  (void)hipGetLastError();
+  return false;
+}
+}  // namespace
+
+void IndependentCall::absorbed_into(hipGraphNode_t node, int lane) {
+  if (!active_) return;
+  active_ = false;
+  CaptureWindow& cw = g_windows[st_];
+  book(cw, node, lane, w_, nw_, r_, nr_);
+  if (!rejoin(cw, st_)) cw = CaptureWindow();
+}
+
+hipGraphNode_t IndependentCall::finish(int* lane, std::vector<hipGraphNode_t>* recorded_behind) {
+  if (!active_) return nullptr;
+  active_ = false;
+  CaptureWindow& cw = g_windows[st_];
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  const bool ok = hipStreamGetCaptureInfo_v2(st_, &status, &id, &graph, &deps, &ndeps) == hipSuccess && status == hipStreamCaptureStatusActive && id == cw.id;
+  if (!ok) { (void)hipGetLastError(); cw = CaptureWindow(); return nullptr; }   // the capture ended or failed inside the call: nothing to join
+  // the call's launches were recorded one behind the other: its last node is now the stream's only dependency (nothing recorded: the set is unchanged)
+  if (!(ndeps == 1 && !same_set(cw.deps, deps, ndeps))) {
+    // no single new node to name (an empty call, or a call that forked internally): close the window — the stream continues behind everything recorded so far
+    std::vector<hipGraphNode_t> all(deps, deps + ndeps);
+    for (hipGraphNode_t b : cw.base) add_unique(all, b);
+    for (int l = 0; l < cw.nlanes; l++) add_unique(all, cw.lanes[l].last);
+    if (hipStreamUpdateCaptureDependencies(st_, all.data(), all.size(), hipStreamSetCaptureDependencies) != hipSuccess) (void)hipGetLastError();
+    cw = CaptureWindow();
+    return nullptr;
+  }
+  const hipGraphNode_t node = deps[0];
+  if (lane_ == cw.nlanes) cw.nlanes++;
+  cw.lanes[lane_].last = node;
+  cw.count++;
+  book(cw, node, lane_, w_, nw_, r_, nr_);
+  if (lane) *lane = lane_;
+  if (recorded_behind) *recorded_behind = cw.deps;
+  if (!rejoin(cw, st_)) { cw = CaptureWindow(); return nullptr; }
+  return node;
+}
 }  // namespace vpp_amd
 using namespace vpp_amd;
 
@@ -232,8 +378,7 @@ int vpp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
   return VPP_OK;
 }
 int vpp_memset(void* dst, int byte, size_t bytes, void* stream) {
-  VPP_HIP_TRY(hipMemsetAsync(dst, byte, bytes, as_stream(stream)));
-  return VPP_OK;
+  return device_fill(dst, byte, bytes, as_stream(stream));   // a kernel of this library: recordable into launch graphs (see common.hpp)
 }
 int vpp_sync(void* stream) { VPP_HIP_TRY(hipStreamSynchronize(as_stream(stream))); return check_device_error("vpp_sync"); }
 int vpp_stream_create(void** stream) {
@@ -289,6 +434,18 @@ int vpp_graph_end(void* stream, int timed, vpp_graph** out) {
   e = hipGraphInstantiate(&gr->exec, gr->g, nullptr, nullptr, 0);
   if (e != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); (void)hipGraphDestroy(gr->g); delete gr; return VPP_ERR_HIP; }
   *out = gr;
+  return VPP_OK;
+}
+// diagnostics (not part of include/vpp_amd.h): kernel nodes of a recorded graph — how many launches a replay makes (record-time batching, tests)
+int vpp_debug_graph_kernel_nodes(vpp_graph* gr, int* count) {
+  VPP_REQUIRE(gr && gr->g && count, VPP_ERR_INVALID_ARG, "vpp_debug_graph_kernel_nodes: null");
+  size_t nn = 0;
+  VPP_HIP_TRY(hipGraphGetNodes(gr->g, nullptr, &nn));
+  std::vector<hipGraphNode_t> nodes(nn);
+  if (nn) VPP_HIP_TRY(hipGraphGetNodes(gr->g, nodes.data(), &nn));
+  int k = 0;
+  for (hipGraphNode_t n : nodes) { hipGraphNodeType t; if (hipGraphNodeGetType(n, &t) == hipSuccess && t == hipGraphNodeTypeKernel) k++; }
+  *count = k;
   return VPP_OK;
 }
 int vpp_graph_launch(vpp_graph* gr, void* stream) {

@@ -857,10 +857,15 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   {  // the queue flags clean themselves up and the control block is left zeroed by every sweep: zeroed here once per (buffer, layout).  A call that is
      // being recorded into a launch graph, and every call on a buffer that a graph has been recorded on, carries the reset itself (Scratch::Slot::note):
      // a replay runs between arbitrary other calls, whose layouts may have left anything in this region.
+    // (Reset by a kernel of this file, not by hipMemsetAsync: recorded into a launch graph the runtime's memset nodes were not ordered with the kernel
+    // nodes around them on ROCm 7.2 — replays read a half-zeroed control block and faulted; tests/test_gpu_sdof.py::test_sdof_graph_replays_between_...)
     Scratch::Slot& sl = *g_scratch.cur;
     const unsigned long long sig = ((unsigned long long)ra_flags_off << 24) ^ (unsigned long long)ra_flags_bytes ^ 1ull;
     if (!sl.note(0, sig)) {
-      VPP_HIP_TRY(hipMemsetAsync((uint8_t*)g_scratch.p + ra_flags_off, 0, ra_flags_bytes, st));
+      ResetArgs z; z.nseg = 1; z.p[0] = (uint4*)((uint8_t*)g_scratch.p + ra_flags_off); z.units[0] = (uint32_t)(ra_flags_bytes / 16); z.value[0] = 0u;
+      z.first_block[0] = 0; z.first_block[1] = (z.units[0] + 255) / 256;
+      sdof_reset_kernel<<<z.first_block[1], 256, 0, st>>>(z);
+      VPP_LAUNCH_CHECK();
       sl.set_note(0, sig);
     }
   }
@@ -914,8 +919,16 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
     }
     ra.first_block[ra.nseg] = blocks;
     if (self_cleaning) {
-      if (!owner_known_clean)
-        for (int s_ = min_scale; s_ < nscales; s_++) VPP_HIP_TRY(hipMemsetAsync((uint8_t*)g_scratch.p + ow_off[s_], 0xFF, ow_bytes[s_], st));
+      if (!owner_known_clean) {   // one launch for the owner maps of all scales (before the launch that claims into them)
+        ResetArgs z; z.nseg = 0; uint32_t zb = 0;
+        for (int s_ = min_scale; s_ < nscales; s_++) {
+          const int q = z.nseg++;
+          z.p[q] = (uint4*)((uint8_t*)g_scratch.p + ow_off[s_]); z.units[q] = (uint32_t)(ow_bytes[s_] / 16); z.value[q] = 0xFFFFFFFFu;
+          z.first_block[q] = zb; zb += (z.units[q] + 255) / 256;
+        }
+        z.first_block[z.nseg] = zb;
+        sdof_reset_kernel<<<zb, 256, 0, st>>>(z);
+      }
       ClaimAll ca; ca.first = min_scale; ca.last = nscales - 1;
       for (int s_ = min_scale; s_ < nscales; s_++) ca.owner[s_] = dimg(&OW(0, s_));
       sdof_reset_claim_kernel<<<blocks + (unsigned)((n + 255) / 256), 256, 0, st>>>(ra, kps, n, patchsize, ca);
@@ -942,7 +955,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
         if (world > 1) { const int per = (fr + world - 1) / world; lo = rank * per; hi = rank + 1 == world ? INT_MAX : (rank + 1) * per; }
         if (!reset_up_front) {
           int r2 = vpp_fill(&MK(k, scale), &zero, 1, (void*)sk); if (r2) return r2;  // fill_with_border(flow_map_mark, 0), :111
-          VPP_HIP_TRY(hipMemsetAsync(OW(k, scale).first_pixel, 0xFF, (size_t)OW(k, scale).pitch * OW(k, scale).nrows, sk));
+          { const int rf = device_fill(OW(k, scale).first_pixel, 0xFF, (size_t)OW(k, scale).pitch * OW(k, scale).nrows, sk); if (rf != VPP_OK) return rf; }
         }
         if (!claim_up_front) sdof_claim_kernel<<<(n + 255) / 256, 256, 0, sk>>>(kps, n, scale_div, patchsize, dimg(&OW(k, scale)), lo, hi);
         const long long cells = (long long)OW(k, scale).nrows * OW(k, scale).ncols;
