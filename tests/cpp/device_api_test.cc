@@ -71,6 +71,53 @@ static void test_pixel_wise_functors() {
   for (auto p : D.domain()) CHECK(H(p) == D(p));
 }
 
+// Stacks of frames under pixel_wise (vpp/core/pixel_wise.hh): an image3d (slice = frame) and a std::vector<image2d> evaluate the whole stack in ONE
+// device launch for the tagged functors (vpp_box_filter_batch / vpp_pixelwise_binary_batch: the entry points the 4K roofline numbers are measured on,
+// reached here without touching vpp_amd.h), and frame by frame for opaque lambdas.  Checker: the oracle per frame.
+static void test_frame_stacks() {
+  const int n = 9, nr = 96, nc = 200;
+  image3d<vuchar3> S(n, nr, nc, _border = 2, _aligned = 16), D(n, nr, nc, _aligned = 16), H(n, nr, nc, _aligned = 16);
+  for (int k = 0; k < n; k++) {
+    image2d<vuchar3> f = S.slice(k);
+    CHECK(&f(0, 0) == &S(k, 0, 0) && &f(nr - 1, nc - 1) == &S(k, nr - 1, nc - 1) && f.border() == 2 && f.pitch() == S.pitch());
+    for (auto p : f.domain()) f(p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
+    fill_border_mirror(f);                                                 // device, on the slice's rows of the shared mirror
+  }
+  pixel_wise(D, relative_access(S)) | ops::box_mean<5, 5>();                 // ONE launch: vpp_box_filter_batch over the 9 frames
+  pixel_wise(H, relative_access(S)) | [](vuchar3& o, auto nb) { ops::box_mean<5, 5>()(o, nb); };   // host engine, frame by frame
+  for (int k = 0; k < n; k++) {
+    image2d<vuchar3> W(nr, nc, _aligned = 16);
+    const image2d<vuchar3> sk = S.slice(k);
+    const vpp_image_desc ds = host_desc(sk), dw = host_desc(W);
+    CHECK(orc_box_filter(&dw, &ds, 5, 5) == 0);
+    for (auto p : W.domain()) CHECK(D(k, p[0], p[1]) == W(p) && H(k, p[0], p[1]) == W(p));
+  }
+  // frames allocated one by one (a decoder's ring): std::vector<image2d>
+  std::vector<image2d<int>> A, B, C;
+  for (int k = 0; k < 5; k++) {
+    A.emplace_back(135, 240); B.emplace_back(135, 240); C.emplace_back(135, 240);
+    for (auto p : B[k].domain()) { B[k](p) = int(rng() >> 3); C[k](p) = int(rng() >> 3); }
+  }
+  pixel_wise(A, B, C) | ops::add();                                          // ONE launch: vpp_pixelwise_binary_batch
+  for (int k = 0; k < 5; k++) for (auto p : A[k].domain()) CHECK(A[k](p) == B[k](p) + C[k](p));
+  std::vector<image2d<vuchar3>> VS, VD;
+  for (int k = 0; k < 4; k++) {
+    VS.emplace_back(64, 128, _border = 2, _aligned = 16); VD.emplace_back(64, 128, _aligned = 16);
+    for (auto p : VS[k].domain()) VS[k](p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
+    fill_border_mirror(VS[k]);
+  }
+  pixel_wise(VD, relative_access(VS)) | ops::box_mean<5, 5>();
+  for (int k = 0; k < 4; k++) {
+    image2d<vuchar3> W(64, 128, _aligned = 16);
+    const vpp_image_desc ds = host_desc(VS[k]), dw = host_desc(W);
+    CHECK(orc_box_filter(&dw, &ds, 5, 5) == 0);
+    for (auto p : W.domain()) CHECK(VD[k](p) == W(p));
+  }
+  bool thrown = false;
+  try { VD.pop_back(); pixel_wise(VD, relative_access(VS)) | ops::box_mean<5, 5>(); } catch (const std::runtime_error&) { thrown = true; }
+  CHECK(thrown);                                                             // stacks of different sizes
+}
+
 static void test_fast9() {
   image2d<unsigned char> img = texture(240, 320, 0, 0);
   for (int k = 0; k < 60; k++) { int r = rng() % 200, c = rng() % 280, v = rng() & 255; for (int i = 0; i < 20; i++) for (int j = 0; j < 24; j++) img(r + i, c + j) = (unsigned char)v; }
@@ -348,6 +395,7 @@ int main() {
   test_lbp();
   test_frame_ingest();
   test_pixel_wise_functors();
+  test_frame_stacks();
   test_fast9();
   test_pyrlk();
   test_lucas_kanade_golden();

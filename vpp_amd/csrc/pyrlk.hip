@@ -186,15 +186,27 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kLkRecords = 16 * 3;   // per group, after its two term arrays: 8 row + 8 column coordinate records of 3 dwords
+// per group, after its two term arrays: R row + R column coordinate records of 3 dwords, R = 8 for windows up to 7 x 7 (8 x 8), 16 up to 15 x 15
+__host__ __device__ constexpr int lk_rec_half(int ws) { return ws <= 8 ? 8 : 16; }
+__host__ __device__ constexpr int lk_records(int ws) { return 2 * lk_rec_half(ws) * 3; }
+// validity bits of a window's offsets (the group kernels serve windows up to 11 x 11 = 121 offsets)
+struct OffsetMask {
+  unsigned long long lo = 0, hi = 0;
+  __device__ __forceinline__ void set(int i) { if (i < 64) lo |= 1ull << i; else hi |= 1ull << (i - 64); }
+  __device__ __forceinline__ bool test(int i) const { return i < 64 ? (lo >> i) & 1ull : (hi >> (i - 64)) & 1ull; }
+  template <int N> __device__ __forceinline__ bool all() const {
+    if constexpr (N <= 64) return lo == (N == 64 ? ~0ull : (1ull << (N & 63)) - 1ull);
+    else return lo == ~0ull && hi == (N == 128 ? ~0ull : (1ull << ((N - 64) & 63)) - 1ull);
+  }
+};
 // LDS block of a group (round 3): the two term arrays of an offset sit in two planes — T0[i] at dword i, T1[i] at lk_plane(ns) + i — so that
 // the ordered sums fetch FOUR consecutive terms of their chain with one ds_read_b128 (13 LDS instructions per 49-term sum instead of 25
 // ds_read2_b32 on the interleaved layout; the kernel is issue bound and LDS instructions were 19 % of its issue cycles).  The reads are
 // broadcasts inside a group, so the 64 / LPK groups x 2 planes must start on different banks: planes 4 dwords apart (mod 32), groups 8 apart
 // (LPK >= 16: 4 groups x 2 planes = the eight 16-byte slots of the 32 banks) or 4 apart (LPK = 8: 16 chunks, two per slot at best).
 __host__ __device__ constexpr int lk_plane(int ns) { return ns + 4; }
-__host__ __device__ constexpr int lk_group_stride(int ns, int lpk) {
-  int g = lk_plane(ns) + ns + kLkRecords;
+__host__ __device__ constexpr int lk_group_stride(int ns, int lpk, int ws) {
+  int g = lk_plane(ns) + ns + lk_records(ws);
   const int want = lpk >= 16 ? 8 : 4;
   while (lpk < 64 && g % 32 != want) g++;
   return g;
@@ -224,11 +236,25 @@ template <int K> __device__ __forceinline__ float quad_bcast(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), K * 0x55, 0xf, 0xf, false));
 }
 
-template <int WS, class GT, bool PYRLK, int LPK>
-__device__ Match lk_match_group(  // WS*WS <= 64
+// sum over the LPK lanes of a group, every lane ends up with the total: symmetric DPP exchanges inside a 16-lane row (quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror, row_mirror), cross-lane permutes above it.  A balanced TREE, not the reference's left-to-right chain: only used by the opt-in
+// fast-sums variant (vpp_set_tuning("pyrlk.fast_sums", 1)).
+template <int LPK> __device__ __forceinline__ float group_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
+  if constexpr (LPK >= 8) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
+  if constexpr (LPK >= 16) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
+  if constexpr (LPK >= 32) x += __shfl_xor(x, 16);
+  if constexpr (LPK >= 64) x += __shfl_xor(x, 32);
+  return x;
+}
+
+template <int WS, class GT, bool PYRLK, int LPK, bool FAST = false>
+__device__ Match lk_match_group(  // WS <= 11 (OffsetMask: 128 offsets)
     float p0, float p1, float tr0, float tr1, const DImg& A_, const DImg& B_, const DImg& Ag_, float min_ev_th,
                                 int max_it, float delta, float* lds, int gl, float norm_T) {
-  constexpr int hws = WS / 2, N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK, TP = lk_plane(NS);
+  constexpr int hws = WS / 2, N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK, TP = lk_plane(NS), RH = lk_rec_half(WS);
+  static_assert(N <= 128, "OffsetMask holds 128 offsets");
   float* const lds1 = lds + TP;   // the second term plane (see lk_group_stride)
   // the level's descriptors by value: the callers index a kernel-argument array with the (runtime) level, and through the
   // references every use inside the iteration loop was a fresh scalar load + wait
@@ -236,7 +262,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
   const bool a_safe = window_inside(A, p0, p1, hws);
   float gs0[PPL], gs1[PPL];
   int as[PPL];
-  unsigned long long mine = 0;  // validity bits of this lane's offsets
+  OffsetMask mine;  // validity bits of this lane's offsets
   // this lane's window offsets as (row, column) of the window (a lane past the window repeats the window's last offset); kept as the
   // dword index of the tap's row / column record in the group's coordinate records (see the iteration), the float offsets of the
   // per-tap form are derived where that form is used (once per level, and on the rare unsafe paths)
@@ -244,10 +270,10 @@ __device__ Match lk_match_group(  // WS*WS <= 64
 #pragma unroll
   for (int q = 0; q < PPL; q++) {
     const int i = gl + q * LPK, ii = i < N ? i : N - 1;
-    rec_r[q] = 3 * (ii / WS); rec_c[q] = 3 * (8 + ii % WS);
+    rec_r[q] = 3 * (ii / WS); rec_c[q] = 3 * (RH + ii % WS);
   }
   auto off_r = [&](int q) { return (float)(rec_r[q] / 3 - hws); };
-  auto off_c = [&](int q) { return (float)(rec_c[q] / 3 - 8 - hws); };
+  auto off_c = [&](int q) { return (float)(rec_c[q] / 3 - RH - hws); };
   if (a_safe) {  // every tap lies in the bordered area: request all rounds before using any (one round trip, no branch around the loads)
     GT g[PPL][2]; uint8_t a[PPL];
 #pragma unroll
@@ -257,7 +283,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
       const int i = gl + k * LPK;
       const bool ok = i < N && A.has((int)(p0 + off_r(k)), (int)(p1 + off_c(k)));
       gs0[k] = ok ? (float)g[k][0] : 0.f; gs1[k] = ok ? (float)g[k][1] : 0.f; as[k] = ok ? (int)a[k] : 0;
-      if (ok) mine |= 1ull << i;
+      if (ok) mine.set(i);
       lds[i] = gs0[k]; lds1[i] = gs1[k];
     }
   } else {
@@ -271,19 +297,23 @@ __device__ Match lk_match_group(  // WS*WS <= 64
           GT g[2]; uint8_t a;
           interp<GT, 2, false>(Ag, n0, n1, g); interp<uint8_t, 1, false>(A, n0, n1, &a);
           gs0[k] = (float)g[0]; gs1[k] = (float)g[1]; as[k] = (int)a;
-          mine |= 1ull << i;
+          mine.set(i);
         }
       }
       lds[i] = gs0[k]; lds1[i] = gs1[k];
     }
   }
-  unsigned long long mask = mine;  // OR over the group's lanes (xor-butterfly stays inside aligned groups of LPK lanes)
+  OffsetMask mask = mine;  // OR over the group's lanes (xor-butterfly stays inside aligned groups of LPK lanes)
 #pragma unroll
   for (int d = 1; d < LPK; d <<= 1) {
-    const unsigned lo = __shfl_xor((unsigned)mask, d), hi = __shfl_xor((unsigned)(mask >> 32), d);
-    mask |= ((unsigned long long)hi << 32) | lo;
+    const unsigned lo = __shfl_xor((unsigned)mask.lo, d), hi = __shfl_xor((unsigned)(mask.lo >> 32), d);
+    mask.lo |= ((unsigned long long)hi << 32) | lo;
+    if constexpr (N > 64) {
+      const unsigned lo2 = __shfl_xor((unsigned)mask.hi, d), hi2 = __shfl_xor((unsigned)(mask.hi >> 32), d);
+      mask.hi |= ((unsigned long long)hi2 << 32) | lo2;
+    }
   }
-  const bool all_valid = mask == ((1ull << N) - 1ull);
+  const bool all_valid = mask.template all<N>();
   wave_lds_fence();
   // Every sum over the window is the reference's left-to-right float chain, so it cannot be split — but the independent chains can
   // sit on different lanes of the group (all lanes of a group would otherwise repeat all of them): lane gl & 3 = 0 / 1 / 2 accumulates
@@ -299,7 +329,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
     } else {
 #pragma unroll 1
       for (int i = 0; i < N; i++) {
-        if ((mask >> i) & 1ull) { acc += lds[ia * TP + i] * lds[ib * TP + i]; cpt++; }
+        if (mask.test(i)) { acc += lds[ia * TP + i] * lds[ib * TP + i]; cpt++; }
       }
     }
     G00 = quad_bcast<0>(acc); G01 = quad_bcast<1>(acc); G11 = quad_bcast<2>(acc); G10 = G01;
@@ -324,22 +354,24 @@ __device__ Match lk_match_group(  // WS*WS <= 64
   for (int k = 0; k <= max_it && (nk0 * nk0 + nk1 * nk1) >= norm_T; k++) {  // lk.hh:116 (norm >= delta, see norm_threshold)
     const bool b_safe = window_inside(B, v0, v1, hws);
     wave_lds_fence();  // the previous pass' reads are done before its terms are overwritten
+    bool fast_done = false; float bk0f = 0.f, bk1f = 0.f;
     if (b_safe && all_valid) {
       // The common case without a branch around the loads: all PPL rounds of taps are requested back to back and the lane pays
       // ONE memory round trip per iteration instead of PPL dependent ones (a lane past the window samples the window's last
       // offset and stages a term nobody reads).
       if constexpr (LPK >= 16) {
+        float fs0 = 0.f, fs1 = 0.f;
         // The coordinate part of linear_interpolate (imageNd.hpp:282-290) depends on the tap's row OR its column only: the WS row
         // records {a0, 1 - a0, byte offset of row x0} and the WS column records {a1, 1 - a1, x1} are evaluated once per group (one
         // record per lane, the same float operations on the same inputs as the per-tap form) and every tap reads its two records from
         // LDS: 1 address add per tap instead of 13 VALU operations (adds, conversions, fractions, the row multiply).
         float* xl = lds1 + NS;
 #pragma unroll
-        for (int t = 0; t < (LPK >= 16 ? 1 : 16 / LPK); t++) {
+        for (int t = 0; t < (LPK >= 2 * RH ? 1 : 2 * RH / LPK); t++) {
           const int rec = gl + t * LPK;
-          if (rec < 16) {
-            const bool isrow = rec < 8;
-            const int k = (rec & 7) < WS ? (rec & 7) : WS - 1;
+          if (rec < 2 * RH) {
+            const bool isrow = rec < RH;
+            const int k = (rec & (RH - 1)) < WS ? (rec & (RH - 1)) : WS - 1;
             const float nn = (isrow ? v0 : v1) + (float)(k - hws);
             const int x = (int)nn;
             const float a = nn - x;
@@ -366,7 +398,14 @@ __device__ Match lk_match_group(  // WS*WS <= 64
                           (a0 * a1) * (float)(uint8_t)(t1[q] >> 8);
           const uint8_t b = (uint8_t)v;
           const float dt = (float)as[q] - (float)b;  // lk.hh:130
-          lds[i] = gs0[q] * dt; lds1[i] = gs1[q] * dt;
+          if constexpr (FAST) { if (i < N) { fs0 += gs0[q] * dt; fs1 += gs1[q] * dt; } }
+          else { lds[i] = gs0[q] * dt; lds1[i] = gs1[q] * dt; }
+        }
+        if constexpr (FAST) {
+          // opt-in: the two sums of lk.hh:124-133 as a lane-local partial + a DPP tree over the group instead of the 49-term left-to-right chain that every
+          // lane repeats — no term staging, no LDS reads, ~8 dependent adds instead of 49.  Same terms, another association: NOT bit-identical.
+          bk0f = group_sum<LPK>(fs0); bk1f = group_sum<LPK>(fs1);
+          fast_done = true;
         }
       } else {
         // 7 taps per lane (LPK = 8): the wave's LDS pipe is as busy as its VALU with the 49 broadcast term reads alone, the record reads
@@ -386,7 +425,7 @@ __device__ Match lk_match_group(  // WS*WS <= 64
       for (int q = 0; q < PPL; q++) {
         const int i = gl + q * LPK;
         float t0 = 0.f, t1 = 0.f;
-        if (i < N && (all_valid || ((mine >> i) & 1ull))) {
+        if (i < N && (all_valid || mine.test(i))) {
           uint8_t b;
           if (b_safe) interp<uint8_t, 1, true>(B, v0 + off_r(q), v1 + off_c(q), &b);
           else interp<uint8_t, 1, false>(B, v0 + off_r(q), v1 + off_c(q), &b);
@@ -396,16 +435,17 @@ __device__ Match lk_match_group(  // WS*WS <= 64
         lds[i] = t0; lds1[i] = t1;
       }
     }
-    wave_lds_fence();
     float bk0, bk1;
-    {
+    if (FAST && fast_done) { bk0 = bk0f; bk1 = bk1f; }   // (wave-uniform per group only: the other groups of the wave may take the staged path below)
+    else {
+      wave_lds_fence();
       float acc = 0.f;   // even lanes: bk[0], odd lanes: bk[1]
       if (all_valid) {
         acc = ordered_sum<N>(lds + (gl & 1) * TP, acc);
       } else {
 #pragma unroll 1
         for (int i = 0; i < N; i++)
-          if ((mask >> i) & 1ull) acc += lds[(gl & 1) * TP + i];
+          if (mask.test(i)) acc += lds[(gl & 1) * TP + i];
       }
       bk0 = quad_bcast<0>(acc); bk1 = quad_bcast<1>(acc);
     }
@@ -460,16 +500,16 @@ __device__ Match lk_match_group(  // WS*WS <= 64
 }
 
 // at least 4 waves per SIMD (<= 128 VGPRs): left alone, the 7-taps-per-lane instance took 138-163 registers for no gain in issue rate
-template <int WS, int LPK>
+template <int WS, int LPK, bool FAST = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pyrlk_match_group_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, vpp_keypoint_f32* __restrict__ kps, int n,
                                                                float min_ev, float max_err, int max_it, float delta, int min_scale,
                                                                float* __restrict__ out_dist) {
   constexpr int N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
-  __shared__ __attribute__((aligned(16))) float smem[(64 / LPK) * lk_group_stride(NS, LPK)];
+  __shared__ __attribute__((aligned(16))) float smem[(64 / LPK) * lk_group_stride(NS, LPK, WS)];
   const int gl = threadIdx.x % LPK, grp = threadIdx.x / LPK;
   const int i = blockIdx.x * (64 / LPK) + grp;
   if (i >= n) return;
-  float* lds = smem + grp * lk_group_stride(NS, LPK);
+  float* lds = smem + grp * lk_group_stride(NS, LPK, WS);
   vpp_keypoint_f32 kp = kps[i];
   if (!(kp.age > 0)) { if (out_dist && gl == 0) out_dist[i] = 0.f; return; }
   float tr0 = 0.f, tr1 = 0.f, dist = 0.f;
@@ -477,7 +517,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void py
   for (int S = nlevels - 1; S >= min_scale; S--) {
     tr0 *= 2.f; tr1 *= 2.f;
     const float sc = (float)(1 << S);
-    const Match m = lk_match_group<WS, float, true, LPK>(kp.pos_r / sc, kp.pos_c / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, max_it, delta, lds, gl, norm_T);
+    const Match m = lk_match_group<WS, float, true, LPK, FAST>(kp.pos_r / sc, kp.pos_c / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, max_it, delta, lds, gl, norm_T);
     if (m.err < max_err) { tr0 = m.f0; tr1 = m.f1; }
     dist = m.err;
   }
@@ -494,11 +534,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lu
                                                                 const float* __restrict__ pred, int n, float min_ev, int niter, float delta,
                                                                 float* __restrict__ out_flow, float* __restrict__ out_dist) {
   constexpr int N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
-  __shared__ __attribute__((aligned(16))) float smem[(64 / LPK) * lk_group_stride(NS, LPK)];
+  __shared__ __attribute__((aligned(16))) float smem[(64 / LPK) * lk_group_stride(NS, LPK, WS)];
   const int gl = threadIdx.x % LPK, grp = threadIdx.x / LPK;
   const int i = blockIdx.x * (64 / LPK) + grp;
   if (i >= n) return;
-  float* lds = smem + grp * lk_group_stride(NS, LPK);
+  float* lds = smem + grp * lk_group_stride(NS, LPK, WS);
   const float k0 = pts[2 * i], k1 = pts[2 * i + 1];
   const float d = (float)(1 << nlevels);
   float tr0 = (pred ? pred[2 * i] : 0.f) / d, tr1 = (pred ? pred[2 * i + 1] : 0.f) / d;
@@ -592,24 +632,43 @@ int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, cons
   // lanes per keypoint: enough waves to cover the 1024 SIMDs a few times over, no more (total work grows with LPK)
   int lpk = tuning("pyrlk.lpk", 0);
   if (lpk == 0) lpk = n >= 80000 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));  // measured: tools/tune_pyrlk.py (round 2: 16 lanes win up to 40 k keypoints, 8 from 100 k; 8 also beats 1 lane per keypoint at 400 k)
-  if (winsize > 7) lpk = 1;  // the group kernels keep a 64-bit validity mask (WS*WS <= 64); larger windows: one lane per keypoint
+  if (winsize > 11) lpk = 1;                  // the group kernels hold up to 128 window offsets (11 x 11 = 121: the window of the reference's own benchmark,
+  else if (winsize > 7 && lpk == 8) lpk = 16;  // benchmarks/pyrlk_opencv_comparison.cc:47); 8 lanes per keypoint would hold 11-16 taps per lane in registers: 16 at least
+  // Opt-in (default off, results NOT bit-identical to the reference's summation order — north_star asks for 1e-4 relative on the displacements; bench.py reports
+  // the fraction of keypoints outside that bound): the per-iteration window sums as a DPP tree (lk_match_group, FAST).  7 x 7 and 11 x 11, 16+ lanes per keypoint.
+  if (tuning("pyrlk.fast_sums", 0) && lpk >= 16 && (winsize == 7 || winsize == 11)) {
+#define VPP_LK_FAST(W)                                                                                                                               \
+    if (lpk == 64) pyrlk_match_group_kernel<W, 64, true><<<n, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
+    else if (lpk == 32) pyrlk_match_group_kernel<W, 32, true><<<(n + 1) / 2, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
+    else pyrlk_match_group_kernel<W, 16, true><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist);
+    if (winsize == 7) { VPP_LK_FAST(7) } else { VPP_LK_FAST(11) }
+#undef VPP_LK_FAST
+    VPP_LAUNCH_CHECK();
+    return VPP_OK;
+  }
 #define VPP_LK_LAUNCH(W)                                                                                                                           \
   if (lpk == 64) pyrlk_match_group_kernel<W, 64><<<n, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
   else if (lpk == 32) pyrlk_match_group_kernel<W, 32><<<(n + 1) / 2, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
   else if (lpk == 16) pyrlk_match_group_kernel<W, 16><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
   else if (lpk == 8) pyrlk_match_group_kernel<W, 8><<<(n + 7) / 8, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
   else pyrlk_match_kernel<W><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist);
+#define VPP_LK_LAUNCH_WIDE(W)  /* 9 x 9 and 11 x 11: 16, 32 or 64 lanes per keypoint */                                                              \
+  if (lpk == 64) pyrlk_match_group_kernel<W, 64><<<n, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
+  else if (lpk == 32) pyrlk_match_group_kernel<W, 32><<<(n + 1) / 2, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
+  else if (lpk == 16) pyrlk_match_group_kernel<W, 16><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
+  else pyrlk_match_kernel<W><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist);
   switch (winsize) {
     case 3: VPP_LK_LAUNCH(3) break;
     case 5: VPP_LK_LAUNCH(5) break;
     case 7: VPP_LK_LAUNCH(7) break;
-    case 9: pyrlk_match_kernel<9><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); break;
-    case 11: pyrlk_match_kernel<11><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); break;
+    case 9: VPP_LK_LAUNCH_WIDE(9) break;
+    case 11: VPP_LK_LAUNCH_WIDE(11) break;
     case 15: pyrlk_match_kernel<15><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); break;
     case 21: pyrlk_match_kernel<21><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); break;
     default: set_error("vpp_pyrlk_match: unsupported window size %d (3,5,7,9,11,15,21)", winsize); return VPP_ERR_UNSUPPORTED;
   }
 #undef VPP_LK_LAUNCH
+#undef VPP_LK_LAUNCH_WIDE
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }
@@ -625,7 +684,8 @@ int vpp_lucas_kanade(const vpp_image_desc* prev, const vpp_image_desc* grad, con
   hipStream_t st = as_stream(stream);
   int lpk = tuning("pyrlk.lpk", 0);
   if (lpk == 0) lpk = n >= 80000 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));  // measured: tools/tune_pyrlk.py (round 2: 16 lanes win up to 40 k keypoints, 8 from 100 k; 8 also beats 1 lane per keypoint at 400 k)
-  if (winsize > 7) lpk = 1;
+  if (winsize > 11) lpk = 1;
+  else if (winsize > 7 && lpk == 8) lpk = 16;
   const float fev = (float)min_ev, fdelta = (float)delta;
 #define VPP_LK_LAUNCH(W)                                                                                                                           \
   if (lpk == 64) lucas_kanade_group_kernel<W, 64><<<n, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
@@ -633,17 +693,23 @@ int vpp_lucas_kanade(const vpp_image_desc* prev, const vpp_image_desc* grad, con
   else if (lpk == 16) lucas_kanade_group_kernel<W, 16><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
   else if (lpk == 8) lucas_kanade_group_kernel<W, 8><<<(n + 7) / 8, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
   else lucas_kanade_kernel<W><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist);
+#define VPP_LK_LAUNCH_WIDE(W)                                                                                                                      \
+  if (lpk == 64) lucas_kanade_group_kernel<W, 64><<<n, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
+  else if (lpk == 32) lucas_kanade_group_kernel<W, 32><<<(n + 1) / 2, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
+  else if (lpk == 16) lucas_kanade_group_kernel<W, 16><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); \
+  else lucas_kanade_kernel<W><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist);
   switch (winsize) {
     case 3: VPP_LK_LAUNCH(3) break;
     case 5: VPP_LK_LAUNCH(5) break;
     case 7: VPP_LK_LAUNCH(7) break;
-    case 9: lucas_kanade_kernel<9><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); break;
-    case 11: lucas_kanade_kernel<11><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); break;
+    case 9: VPP_LK_LAUNCH_WIDE(9) break;
+    case 11: VPP_LK_LAUNCH_WIDE(11) break;
     case 15: lucas_kanade_kernel<15><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); break;
     case 21: lucas_kanade_kernel<21><<<(n + 63) / 64, 64, 0, st>>>(P, G, N, nlevels, pts, prediction, n, fev, niterations, fdelta, out_flow, out_dist); break;
     default: set_error("vpp_lucas_kanade: unsupported window size %d (3,5,7,9,11,15,21)", winsize); return VPP_ERR_UNSUPPORTED;
   }
 #undef VPP_LK_LAUNCH
+#undef VPP_LK_LAUNCH_WIDE
   VPP_LAUNCH_CHECK();
   return VPP_OK;
 }

@@ -133,6 +133,25 @@ template <class V, unsigned N> class imageNd {
   }
   const self const_subimage(const boxNd<N>& d) const { return subimage(d); }
 
+  // Frame k of a stack of frames (image3d: slices x rows x cols) as an image2d over the same pixels: the slice's rows, its border rows included (with
+  // border b every slice carries its own b rows above and below, imageNd.hpp:151-196), share the buffer, its owner and its HBM mirror.  This is what
+  // lets `pixel_wise` treat an image3d as a batch of frames (vpp/core/pixel_wise.hh) — one device launch for the whole stack.
+  imageNd<V, 2> slice(int k) const {
+    static_assert(N == 3, "slice(k): the frames of an image3d");
+    imageNd<V, 2> res;
+    res.ptr_ = std::make_shared<imageNd_data<V, 2>>();
+    auto& d = *res.ptr_;
+    const auto& s = *ptr_;
+    vint<N> p = vint<N>::Zero(); p[0] = k;
+    d.data_ = s.data_; d.data_end_ = s.data_end_; d.begin_ = const_cast<V*>(address_of_(p));
+    d.data_sptr_ = s.data_sptr_; d.store_ = s.store_;
+    d.domain_ = boxNd<2>(vint2(0, 0), vint2(s.domain_.size(1) - 1, s.domain_.size(2) - 1));
+    d.buffer_domain_ = d.domain_;
+    d.border_ = s.border_; d.pitch_ = s.pitch_; d.alignment_ = s.alignment_;
+    res.index_rows();
+    return res;
+  }
+
   const void* storage_id() const { return ptr_ ? (const void*)ptr_->store_.get() : nullptr; }  // identity of the pixel buffer (shared by sub-images)
   void set_external_data_holder(void* data, void (*deleter)(void*)) { ptr_->data_sptr_ = std::shared_ptr<void>(data, deleter); }
   void swap(imageNd& o) { o.ptr_.swap(ptr_); }

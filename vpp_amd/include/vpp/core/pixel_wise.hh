@@ -9,6 +9,9 @@
 //    gfx950 kernel (vpp/core/pixel_wise_device.hh) when it carries no state (a by-reference capture would hold host addresses;
 //    `_device` vouches for a by-value one), the traversal options are the defaults and the ranges do not alias; `_host` keeps a
 //    call on the host (a callable that uses host-only functions such as rand() must say so, since it cannot be compiled for the GPU);
+//  * STACKS OF FRAMES (extension; the reference's pixel_wise is 2-d only, pixel_wise.hpp:146-165): when the ranges are image3d<V> (slices = frames) or
+//    std::vector<image2d<V>>, the kernel is applied to every frame as the 2-d expression it would be on that frame — and a tagged functor evaluates
+//    the WHOLE stack in one device launch (vpp_box_filter_batch / vpp_pixelwise_binary_batch: the form the 4K roofline numbers are measured on);
 //  * a tagged functor from vpp::ops (add, sub, mul, min, max, absdiff, box_mean<R,C>) is, in a -DVPP_AMD_DEVICE build,
 //    dispatched through the C ABI to the hand-written gfx950 kernels (vpp_pixelwise_binary, vpp_box_filter).  A failing
 //    device call throws; it never silently re-runs on the host.
@@ -16,8 +19,10 @@
 #include <tuple>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 #include <vpp/core/image2d.hh>
+#include <vpp/core/image3d.hh>
 #include <vpp/core/relative_accessor.hh>
 #include <vpp/core/pixel_wise_device.hh>
 
@@ -117,6 +122,20 @@ inline const void* storage_of(const box2d&) { return nullptr; }
 template <class V> const void* storage_of(const relative_access_<image2d<V>>& r) { return r.img.storage_id(); }
 template <class V, int R, int C> const void* storage_of(const box_nbh2d<V, R, C>& n) { return n.img.storage_id(); }
 #endif
+// stacks of frames: image3d<V> (frame k = slice k, vpp/core/imageNd.hh: slice) and std::vector<image2d<V>>; relative_access / of a stack = of every frame
+template <class T> struct stack : std::false_type {};
+template <class V> struct stack<imageNd<V, 3>> : std::true_type {
+  static int size(const imageNd<V, 3>& s) { return s.nslices(); }
+  static imageNd<V, 2> frame(const imageNd<V, 3>& s, int k) { return s.slice(k); }
+};
+template <class V> struct stack<std::vector<imageNd<V, 2>>> : std::true_type {
+  static int size(const std::vector<imageNd<V, 2>>& s) { return (int)s.size(); }
+  static imageNd<V, 2> frame(const std::vector<imageNd<V, 2>>& s, int k) { return s[k]; }
+};
+template <class I> struct stack<relative_access_<I>> : stack<I> {
+  static int size(const relative_access_<I>& r) { return stack<I>::size(r.img); }
+  static auto frame(const relative_access_<I>& r, int k) { return relative_access(stack<I>::frame(r.img, k)); }
+};
 template <class T> struct is_image2d : std::false_type {};
 template <class V> struct is_image2d<imageNd<V, 2>> : std::true_type { typedef V value_type; };
 }  // namespace pw
@@ -127,10 +146,18 @@ template <class OPTS, class... R> class pixel_wise_impl {
   template <class... A> auto operator()(A... o) const { auto n = opt::make(o...); return pixel_wise_impl<decltype(n), R...>(ranges_, n); }
   template <class... B> auto operator()(opt::set<B...> n) const { return pixel_wise_impl<opt::set<B...>, R...>(ranges_, n); }
 
-  template <class F> using kernel_return_type = decltype(std::declval<F&>()(std::declval<decltype(pw::row_access(std::declval<R&>(), 0)(0))&>()...));
+  // (the ranges enter through a type that depends on F: for stacks of frames there is no row_access, and the expression must not be looked at before a kernel is applied)
+  template <class F, class X> struct later { typedef X type; };
+  template <class F> using kernel_return_type = decltype(std::declval<F&>()(std::declval<decltype(pw::row_access(std::declval<typename later<F, R>::type&>(), 0)(0))&>()...));
+
+  static constexpr bool stacked = (pw::stack<R>::value || ...);   // ranges are stacks of frames: the expression is the 2-d one on every frame
 
   // opaque callable (pixel_wise.hpp:146-165,188-213): host evaluation, or — single-source hipcc build — the generic device kernel
   template <class F> auto operator|(F fun) {
+    if constexpr (stacked) { for_each_frame(fun, std::index_sequence_for<R...>()); return; }
+    else return apply(fun);
+  }
+  template <class F> auto apply(F fun) {
 #if defined(VPP_AMD_DEVICE) && defined(__HIPCC__) && defined(VPP_AMD_HIPCC)
     if constexpr (device_eligible<F>()) {
       if (!ranges_alias(std::index_sequence_for<R...>())) return eval_device(fun, std::is_void<kernel_return_type<F>>());
@@ -140,9 +167,13 @@ template <class OPTS, class... R> class pixel_wise_impl {
   }
 
 #ifdef VPP_AMD_DEVICE
-  // tagged functors: gfx950 kernels through the C ABI
-  template <int OP> void operator|(ops::binary<OP>) { device_binary(OP, std::index_sequence_for<R...>()); }
-  template <int RR, int CC> void operator|(ops::box_mean<RR, CC>) { device_box(RR, CC); }
+  // tagged functors: gfx950 kernels through the C ABI (a stack of frames: ONE launch for all of them)
+  template <int OP> void operator|(ops::binary<OP>) {
+    if constexpr (stacked) device_binary_stack(OP); else device_binary(OP, std::index_sequence_for<R...>());
+  }
+  template <int RR, int CC> void operator|(ops::box_mean<RR, CC>) {
+    if constexpr (stacked) device_box_stack(RR, CC); else device_box(RR, CC);
+  }
 #endif
 
 #if defined(VPP_AMD_DEVICE) && defined(__HIPCC__) && defined(VPP_AMD_HIPCC)
@@ -226,6 +257,45 @@ template <class OPTS, class... R> class pixel_wise_impl {
     auto& d = std::get<0>(ranges_); auto& n = std::get<1>(ranges_);
     const vpp_image_desc ds = n.img.device_desc(false), dd = d.device_desc(true);
     device::check(vpp_box_filter(&dd, &ds, rr, cc, device::stream()), "vpp_box_filter");
+    device::check(vpp_sync(device::stream()), "vpp_sync");
+  }
+#endif
+  // a stack: the same expression on every frame (a kernel that returns a pixel value would have to build a stack: not provided)
+  template <class F, std::size_t... I> void for_each_frame(F& fun, std::index_sequence<I...>) {
+    static_assert((pw::stack<R>::value && ...), "pixel_wise over stacks of frames: every range must be an image3d, a std::vector<image2d> or relative_access of one");
+    const int n = pw::stack<typename std::tuple_element<0, std::tuple<R...>>::type>::size(std::get<0>(ranges_));
+    for (int k = 0; k < n; k++) {
+      auto frames = std::make_tuple(pw::stack<R>::frame(std::get<I>(ranges_), k)...);
+      pixel_wise_impl<OPTS, typename std::decay<decltype(pw::stack<R>::frame(std::get<I>(ranges_), k))>::type...> sub(frames, options_);
+      static_assert(std::is_void<decltype(sub | fun)>::value, "pixel_wise over stacks of frames: the kernel must return void");
+      sub | fun;
+    }
+  }
+#ifdef VPP_AMD_DEVICE
+  template <class S> static int stack_size(const S& s) { return pw::stack<S>::size(s); }
+  void device_binary_stack(int op) {
+    static_assert(sizeof...(R) == 3 && (pw::stack<R>::value && ...), "ops::binary on stacks needs pixel_wise(dst, a, b) with three stacks of frames");
+    auto& d = std::get<0>(ranges_); auto& a = std::get<1>(ranges_); auto& b = std::get<2>(ranges_);
+    const int n = stack_size(d);
+    if (stack_size(a) != n || stack_size(b) != n) throw std::runtime_error("pixel_wise: stacks of different sizes");
+    std::vector<vpp_image_desc> dd(n), da(n), db(n);
+    for (int k = 0; k < n; k++) {   // sources first: a destination frame that shares its storage with a source must not mark the mirror newer before the upload
+      da[k] = pw::stack<typename std::decay<decltype(a)>::type>::frame(a, k).device_desc(false);
+      db[k] = pw::stack<typename std::decay<decltype(b)>::type>::frame(b, k).device_desc(false);
+    }
+    for (int k = 0; k < n; k++) dd[k] = pw::stack<typename std::decay<decltype(d)>::type>::frame(d, k).device_desc(true);
+    device::check(vpp_pixelwise_binary_batch(op, dd.data(), da.data(), db.data(), n, device::stream()), "vpp_pixelwise_binary_batch");
+    device::check(vpp_sync(device::stream()), "vpp_sync");
+  }
+  void device_box_stack(int rr, int cc) {
+    static_assert(sizeof...(R) == 2 && (pw::stack<R>::value && ...), "ops::box_mean on stacks needs pixel_wise(dst, relative_access(src)) with two stacks of frames");
+    auto& d = std::get<0>(ranges_); auto& nb = std::get<1>(ranges_);
+    const int n = stack_size(d);
+    if (stack_size(nb) != n) throw std::runtime_error("pixel_wise: stacks of different sizes");
+    std::vector<vpp_image_desc> dd(n), ds(n);
+    for (int k = 0; k < n; k++) ds[k] = pw::stack<typename std::decay<decltype(nb)>::type>::frame(nb, k).img.device_desc(false);
+    for (int k = 0; k < n; k++) dd[k] = pw::stack<typename std::decay<decltype(d)>::type>::frame(d, k).device_desc(true);
+    device::check(vpp_box_filter_batch(dd.data(), ds.data(), n, rr, cc, device::stream()), "vpp_box_filter_batch");
     device::check(vpp_sync(device::stream()), "vpp_sync");
   }
 #endif
