@@ -75,6 +75,7 @@ static void test_pixel_wise_functors() {
 // device launch for the tagged functors (vpp_box_filter_batch / vpp_pixelwise_binary_batch: the entry points the 4K roofline numbers are measured on,
 // reached here without touching vpp_amd.h), and frame by frame for opaque lambdas.  Checker: the oracle per frame.
 static void test_frame_stacks() {
+  std::mt19937 rng(77);   // its own generator: the later tests' scenes are drawn from the global one
   const int n = 9, nr = 96, nc = 200;
   image3d<vuchar3> S(n, nr, nc, _border = 2, _aligned = 16), D(n, nr, nc, _aligned = 16), H(n, nr, nc, _aligned = 16);
   for (int k = 0; k < n; k++) {

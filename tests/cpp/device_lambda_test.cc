@@ -172,6 +172,46 @@ static void test_block_wise_device() {
   }
 }
 
+// neighbourhoods out of the LDS tile (pixel_wise_device.hh: pixel_wise_tile_kernel): every border the tile path takes (1..4: windows up to 9 x 9 read the
+// whole halo) and one it leaves to the global taps (5), shapes cut by the tile edges (16 rows x 64 or 256 pixels), 1-, 3-, 4- and 8-byte pixels, the legacy
+// box_nbh2d spelling, and a sub-image view (unaligned: one pixel per lane) — all against the host engine of the same headers, bit for bit.
+template <class V, class MK> static void tile_case(int nr, int nc, int border, MK make) {
+  image2d<V> S(nr, nc, _border = border), D(S.domain()), H(S.domain());
+  for (auto p : S.domain_with_border()) S(p) = make();
+  auto k = [border] (V& out, auto nbh) {   // the extreme taps of the widest legal window + the centre: position-sensitive, so a misplaced tile shows
+    out = nbh(0, 0);
+    for (int i = -border; i <= border; i += border) for (int j = -border; j <= border; j += border) out = V(out + nbh(i, j) * (i * 3 + j + 7));
+  };
+  pixel_wise(D, relative_access(S))(_device) | k;
+  pixel_wise(H, relative_access(S))(_host) | k;
+  if (!same_pixels(D, H)) { std::fprintf(stderr, "tile_case %d x %d border %d, %d-byte pixels\n", nr, nc, border, (int)sizeof(V)); std::exit(1); }
+}
+static void test_neighbourhood_tiles() {
+  for (int border : {1, 2, 3, 4, 5})
+    for (auto shape : {std::pair<int, int>{16, 256}, {17, 259}, {50, 1030}, {3, 5}, {33, 64}}) {
+      tile_case<unsigned char>(shape.first, shape.second, border, [] { return (unsigned char)(rng() & 255); });
+      tile_case<int>(shape.first, shape.second, border, [] { return int(rng() % 1000); });
+      tile_case<vuchar3>(shape.first, shape.second, border, [] { return vuchar3(rng() & 255, rng() & 255, rng() & 255); });
+      tile_case<vfloat2>(shape.first, shape.second, border, [] { return vfloat2(float(rng() % 512), float(rng() % 64)); });
+    }
+  {  // full 5 x 5 sums through the legacy accessor, and on a sub-image whose first column is odd (unaligned view)
+    image2d<int> S(70, 300, _border = 2), D(S.domain()), H(S.domain());
+    for (auto p : S.domain_with_border()) S(p) = int(rng() % 1000);
+    auto k = [] (int& out, auto nbh) { int s = 0; nbh.for_all([&s] (int v) { s += v; }); out = s / 25; };
+    pixel_wise(D, box_nbh2d<int, 5, 5>(S)) | k;
+    pixel_wise(H, box_nbh2d<int, 5, 5>(S))(_host) | k;
+    CHECK(same_pixels(D, H));
+    image2d<int> D2(S.domain()), H2(S.domain());
+    fill(D2, -1); fill(H2, -1);
+    const box2d win(vint2(5, 7), vint2(60, 290));
+    auto sd = D2 | win, sh = H2 | win, ss = S | win;
+    auto k2 = [] (int& out, auto nbh) { out = nbh(-2, -2) + 2 * nbh(2, 2) - nbh(0, 1); };
+    pixel_wise(sd, relative_access(ss)) | k2;
+    pixel_wise(sh, relative_access(ss))(_host) | k2;
+    CHECK(same_pixels(D2, H2));
+  }
+}
+
 static double seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static void time_4k() {
@@ -245,6 +285,7 @@ int main(int argc, char** argv) {
   test_reference_bodies();
   test_device_equals_host();
   test_block_wise_device();
+  test_neighbourhood_tiles();
   if (argc > 1 && !std::strcmp(argv[1], "time")) time_4k();
   std::printf("device_lambda_test ok\n");
   return 0;

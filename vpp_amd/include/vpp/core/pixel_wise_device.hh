@@ -17,6 +17,7 @@
 #pragma once
 #if defined(VPP_AMD_DEVICE) && defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <tuple>
 #include <type_traits>
 
@@ -28,8 +29,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // ---- device-side accessors, built on the host from the ranges (mirror pointers) ----------------------------------
 template <class V> struct image_acc { V* p0; int pitch; };                    // p0 = pixel (0, 0) in HBM
 struct box_acc {};
-template <class V> struct nbh_acc { V* p0; int pitch; };
-template <class V, int R, int C> struct boxnbh_acc { V* p0; int pitch; };
+template <class V> struct nbh_acc { V* p0; int pitch, border, nr, nc; };      // + the source's border and domain: what a neighbourhood may reach (the LDS tile path)
+template <class V, int R, int C> struct boxnbh_acc { V* p0; int pitch, border, nr, nc; };
 
 template <class V> struct nbh_px {  // relative_access_kernel on the device (relative_accessor.hh:26-33)
   V* p; int pitch;
@@ -48,6 +49,28 @@ template <class V, int R, int C> struct boxnbh_px {  // box_nbh2d<V,R,C> at a po
       for (int dc = -(C / 2); dc <= C / 2; dc++) f((*this)(dr, dc));
   }
 };
+
+// The same two accessors over an LDS tile (pixel_wise_tile_kernel): the row pitch is a compile-time constant, so the taps of an unrolled window are
+// ds_read instructions with immediate offsets from ONE base register.  (Reads only: a write through a neighbourhood reaches the tile, not the image.)
+template <class V, int LP> struct nbh_tile_px {
+  char* p;
+  __device__ V& operator()(int dr, int dc) const { return *(V*)(p + dr * LP + dc * (int)sizeof(V)); }
+  __device__ V& operator()(vint2 d) const { return (*this)(d[0], d[1]); }
+};
+template <class V, int R, int C, int LP> struct boxnbh_tile_px {
+  char* p;
+  __device__ V& operator()(int dr, int dc) const { return *(V*)(p + dr * LP + dc * (int)sizeof(V)); }
+  __device__ V& north() const { return (*this)(-1, 0); }
+  __device__ V& south() const { return (*this)(1, 0); }
+  __device__ V& east() const { return (*this)(0, 1); }
+  __device__ V& west() const { return (*this)(0, -1); }
+  template <class F> __device__ void for_all(F f) const {
+    for (int dr = -(R / 2); dr <= R / 2; dr++)
+      for (int dc = -(C / 2); dc <= C / 2; dc++) f((*this)(dr, dc));
+  }
+};
+template <class V, int LP> struct nbh_tile_acc { char* p00; int r00, c00; };                      // p00: the tile byte of pixel (r00, c00)
+template <class V, int R, int C, int LP> struct boxnbh_tile_acc { char* p00; int r00, c00; };
 
 template <class A> struct is_image_acc : std::false_type {};
 template <class V> struct is_image_acc<image_acc<V>> : std::true_type {};
@@ -101,6 +124,12 @@ template <class V, int NPX> __device__ nbh_px<V> arg(stage<nbh_acc<V>, NPX>&, co
 template <class V, int R, int C, int NPX> __device__ boxnbh_px<V, R, C> arg(stage<boxnbh_acc<V, R, C>, NPX>&, const boxnbh_acc<V, R, C>& a, int r, int c, int i) {
   return boxnbh_px<V, R, C>{(V*)((char*)a.p0 + (ptrdiff_t)r * a.pitch) + c + i, a.pitch};
 }
+template <class V, int LP, int NPX> __device__ nbh_tile_px<V, LP> arg(stage<nbh_tile_acc<V, LP>, NPX>&, const nbh_tile_acc<V, LP>& a, int r, int c, int i) {
+  return nbh_tile_px<V, LP>{a.p00 + (r - a.r00) * LP + (c + i - a.c00) * (int)sizeof(V)};
+}
+template <class V, int R, int C, int LP, int NPX> __device__ boxnbh_tile_px<V, R, C, LP> arg(stage<boxnbh_tile_acc<V, R, C, LP>, NPX>&, const boxnbh_tile_acc<V, R, C, LP>& a, int r, int c, int i) {
+  return boxnbh_tile_px<V, R, C, LP>{a.p00 + (r - a.r00) * LP + (c + i - a.c00) * (int)sizeof(V)};
+}
 template <class F, class... X> __device__ __forceinline__ void call_lvalues(F& f, X&&... x) { f(x...); }  // kernels may take `auto&`
 
 // NPX consecutive pixels of row r starting at column c: stage, apply, write back
@@ -127,6 +156,79 @@ __global__ __launch_bounds__(256) void pixel_wise_kernel(F f, int r0, int c0, in
   }
 }
 
+// ---- neighbourhoods out of LDS ------------------------------------------------------------------------------------------------------------------------
+// A callable that reads a neighbourhood (benchmarks/box_5x5_filter2.cc:71-81: 25 taps per pixel) issued every tap as a global load: 4K vuchar3 5 x 5 mean 64 us
+// against 13 us for the hand-written kernel.  Here a workgroup first stages the source rows of its TH x (64 NPX) pixel tile plus a halo of H pixels in LDS
+// (16-byte loads, every byte fetched once per tile), and the callable's taps read the tile.  H = 4 covers windows up to 9 x 9; the launcher takes this path only
+// when the source's border is at most H (a tap cannot legally reach beyond the border), its pitch is a multiple of 16 and there is exactly one neighbourhood range.
+constexpr int kTileH = 4, kTileRows = 16;
+template <class V, int NPXK> struct tile_geom {
+  static constexpr int ES = (int)sizeof(V), TW = 64 * NPXK;
+  static constexpr int LP = (((TW + 2 * kTileH) * ES + 15 + 15) / 16) * 16 + 16;   // row bytes + the alignment shift, in 16-byte units, + 16: consecutive rows start 4 banks apart
+};
+template <class A> struct nbh_traits { static constexpr bool value = false; };
+template <class V> struct nbh_traits<nbh_acc<V>> {
+  static constexpr bool value = true; typedef V pixel;
+  template <int LP> using tile = nbh_tile_acc<V, LP>;
+};
+template <class V, int R, int C> struct nbh_traits<boxnbh_acc<V, R, C>> {
+  static constexpr bool value = true; typedef V pixel;
+  template <int LP> using tile = boxnbh_tile_acc<V, R, C, LP>;
+};
+template <class... A> struct first_nbh;
+template <class A0, class... A> struct first_nbh<A0, A...> {
+  typedef typename std::conditional<nbh_traits<A0>::value, A0, typename first_nbh<A...>::type>::type type;
+  __device__ __host__ static const type& get(const A0& a0, const A&... a) { if constexpr (nbh_traits<A0>::value) return a0; else return first_nbh<A...>::get(a...); }
+};
+template <> struct first_nbh<> { typedef void type; };
+// the tile accessor in place of the neighbourhood range, everything else as it is
+template <class A, class T> __device__ __forceinline__ const typename std::conditional<nbh_traits<A>::value, T, A>::type& tile_swap(const A& a, const T& t) {
+  if constexpr (nbh_traits<A>::value) return t; else return a;
+}
+
+template <int NPXK, class F, class... A>
+__global__ __launch_bounds__(256) void pixel_wise_tile_kernel(F f, int r0, int c0, int nrows, int ncols, A... acc) {
+  typedef typename first_nbh<A...>::type NA;
+  typedef typename nbh_traits<NA>::pixel V;
+  typedef tile_geom<V, NPXK> G;
+  constexpr int ES = G::ES, TW = G::TW, LP = G::LP, H = kTileH, TH = kTileRows, ROWS = TH + 2 * H, CPR = LP / 16;
+  __shared__ __attribute__((aligned(16))) char lds[ROWS * LP];
+  const NA& nb = first_nbh<A...>::get(acc...);
+  const int tr = r0 + blockIdx.y * TH, tc = c0 + blockIdx.x * TW;
+  // ---- stage: tile row rr holds image row tr - H + rr from pixel column tc - H on, at the byte offset `shift` (its global address modulo 16)
+  const char* g0 = (const char*)nb.p0 + (ptrdiff_t)(tr - H) * nb.pitch + (ptrdiff_t)(tc - H) * ES;
+  const int shift = (int)((size_t)g0 & 15);
+  const char* ga = g0 - shift;
+  // bytes of a staged row that belong to the image's bordered area, as offsets from ga (the same on every row)
+  const int vlo = (-nb.border - (tc - H)) * ES + shift, vhi = (nb.nc + nb.border - (tc - H)) * ES + shift;
+  const int want_hi = min(vhi, shift + (TW + 2 * H) * ES);
+  for (int k = threadIdx.x; k < ROWS * CPR; k += 256) {
+    const int rr = k / CPR, off = (k - rr * CPR) * 16;
+    const int r = tr - H + rr;
+    if (r < -nb.border || r >= nb.nr + nb.border || off >= want_hi || off + 16 <= vlo) continue;
+    const char* src = ga + (ptrdiff_t)rr * nb.pitch + off;
+    char* dst = lds + rr * LP + off;
+    if (off >= vlo && off + 16 <= vhi) *(u32x4*)dst = *(const u32x4*)src;
+    else
+      for (int b = max(off, vlo); b < min(off + 16, vhi); b++) lds[rr * LP + b] = ga[(ptrdiff_t)rr * nb.pitch + b];   // a chunk cut by the row's first / last bordered byte
+  }
+  __syncthreads();
+  // ---- compute: wave w takes rows [w TH/4, (w + 1) TH/4) of the tile, a lane NPXK consecutive pixels
+  const typename nbh_traits<NA>::template tile<LP> ta{lds + shift + H * LP + H * ES, tr, tc};
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = tc + lane * NPXK;
+  if (c >= c0 + ncols) return;
+  const int n = min(NPXK, c0 + ncols - c);
+#pragma unroll 1
+  for (int j = 0; j < TH / 4; j++) {
+    const int r = tr + wv * (TH / 4) + j;
+    if (r >= r0 + nrows) break;
+    if (n == NPXK) pixel_step<NPXK>(f, r, c, tile_swap(acc, ta)...);
+    else
+      for (int i = 0; i < n; i++) pixel_step<1>(f, r, c + i, tile_swap(acc, ta)...);
+  }
+}
+
 constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
 constexpr int lcm_(int a, int b) { return a / gcd_(a, b) * b; }
 template <class A> struct npx_of { enum { value = 1 }; };
@@ -149,6 +251,26 @@ template <class F, class... A> void launch(F f, int r0, int c0, int nrows, int n
   bool al = true;
   (void)std::initializer_list<int>{(al = al && aligned16(acc, c0), 0)...};
   const int gy = nrows < 65535 ? nrows : 65535;
+  if constexpr (kNbh && ((nbh_traits<A>::value ? 1 : 0) + ...) == 1) {   // one neighbourhood range: its taps out of an LDS tile when the window cannot leave the halo
+    const auto& nb = first_nbh<A...>::get(acc...);
+    static const bool off = [] { const char* e = getenv("VPP_PW_TILE"); return e && e[0] == '0'; }();   // A/B switch for the tests and the benchmark
+    // Measured (4K 5 x 5 mean through the opaque lambda, synchronous calls, same box): vuchar3 64.2 us with global taps -> 56.9 us out of the tile (its taps are
+    // byte loads: the tile turns 75 of them per pixel into a handful of wide LDS reads, the rest is the callable's own per-component arithmetic); `int` 27.1 us
+    // with global taps -> 39.3 us out of the tile (dword taps already come out of L1 / L2 at near the streaming rate; the staging pass, the barrier and the
+    // 1.5 x halo rows only add).  So: pixel types that are not dword multiples take the tile, the others keep the global taps.
+    typedef typename nbh_traits<typename first_nbh<A...>::type>::pixel PV;
+    if (!off && sizeof(PV) % 4 != 0 && nb.border <= kTileH && nb.pitch % 16 == 0) {
+      constexpr int NPXK = NPX % 4 == 0 ? 4 : 1;
+      const bool vec = al && NPXK > 1;
+      dim3 grid((ncols + 64 * (vec ? NPXK : 1) - 1) / (64 * (vec ? NPXK : 1)), (nrows + kTileRows - 1) / kTileRows);
+      if (vec) hipLaunchKernelGGL((pixel_wise_tile_kernel<NPXK, F, A...>), grid, dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
+      else hipLaunchKernelGGL((pixel_wise_tile_kernel<1, F, A...>), grid, dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) throw std::runtime_error(std::string("pixel_wise (device, tiled): launch failed: ") + hipGetErrorString(e));
+      device::check(vpp_sync(device::stream()), "vpp_sync");
+      return;
+    }
+  }
   // A callable that reads a neighbourhood issues its taps per pixel, so with NPX pixels per lane the lanes of a wave sit NPX pixels apart and every
   // tap of the wave is spread over NPX times as many cache lines.  For pixel types whose 16-byte chunk is many pixels (vuchar3: 16 px = 48 B per lane,
   // a byte load per component and tap) four pixels per lane (12 B, moved pixel by pixel: packing them into dwords made the compiler keep the
