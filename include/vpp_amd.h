@@ -69,6 +69,14 @@ int vpp_sync(void* stream);
  * the null stream): launch graphs are recorded on one, and independent frame pairs overlap on several. */
 int vpp_stream_create(void** stream);
 int vpp_stream_destroy(void* stream);
+/* Completion events (no reference counterpart: the reference's calls are synchronous, vpp/core/pixel_wise.hpp:146-165 joins its OpenMP loop before it
+ * returns).  The C++ drop-in surface uses them to bound how many of its calls are queued (vpp/core/device.hh: call_done) instead of draining the
+ * GPU after every call; vpp_stream_wait_event orders one stream behind work recorded on another. */
+int vpp_event_create(void** event);
+int vpp_event_record(void* event, void* stream);
+int vpp_event_synchronize(void* event);          /* returns once the work recorded before the event has completed (at once if never recorded) */
+int vpp_event_destroy(void* event);
+int vpp_stream_wait_event(void* stream, void* event);
 /* Launch graphs (no reference counterpart: the reference's frame loops call the algorithms directly, e.g.
  * examples/video_extruder.cc:40-60; on a stream the per-launch host cost is what a graph removes).  Everything queued on
  * `stream` between vpp_graph_begin and vpp_graph_end is recorded instead of run; vpp_graph_launch replays it with one

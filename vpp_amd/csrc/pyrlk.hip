@@ -634,6 +634,8 @@ int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, cons
   if (lpk == 0) lpk = n >= 80000 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));  // measured: tools/tune_pyrlk.py (round 2: 16 lanes win up to 40 k keypoints, 8 from 100 k; 8 also beats 1 lane per keypoint at 400 k)
   if (winsize > 11) lpk = 1;                  // the group kernels hold up to 128 window offsets (11 x 11 = 121: the window of the reference's own benchmark,
   else if (winsize > 7 && lpk == 8) lpk = 16;  // benchmarks/pyrlk_opencv_comparison.cc:47); 8 lanes per keypoint would hold 11-16 taps per lane in registers: 16 at least
+  // 9 x 9 / 11 x 11 hold 2.5 x the taps: 32 lanes per keypoint stay ahead of 16 at every count measured (11 x 11, 4 levels, us: 10 k 334 vs 345, 20 k 534 vs 648, 40 k 952 vs 1 011)
+  if (winsize > 7 && winsize <= 11 && tuning("pyrlk.lpk", 0) == 0 && lpk == 16) lpk = 32;
   // Opt-in (default off, results NOT bit-identical to the reference's summation order — north_star asks for 1e-4 relative on the displacements; bench.py reports
   // the fraction of keypoints outside that bound): the per-iteration window sums as a DPP tree (lk_match_group, FAST).  7 x 7 and 11 x 11, 16+ lanes per keypoint.
   if (tuning("pyrlk.fast_sums", 0) && lpk >= 16 && (winsize == 7 || winsize == 11)) {

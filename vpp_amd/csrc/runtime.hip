@@ -392,6 +392,32 @@ int vpp_stream_destroy(void* stream) {
   if (stream) VPP_HIP_TRY(hipStreamDestroy(as_stream(stream)));
   return VPP_OK;
 }
+int vpp_event_create(void** event) {
+  VPP_REQUIRE(event, VPP_ERR_INVALID_ARG, "vpp_event_create: null");
+  hipEvent_t e;
+  VPP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *event = (void*)e;
+  return VPP_OK;
+}
+int vpp_event_record(void* event, void* stream) {
+  VPP_REQUIRE(event, VPP_ERR_INVALID_ARG, "vpp_event_record: null");
+  VPP_HIP_TRY(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+  return VPP_OK;
+}
+int vpp_event_synchronize(void* event) {
+  VPP_REQUIRE(event, VPP_ERR_INVALID_ARG, "vpp_event_synchronize: null");
+  VPP_HIP_TRY(hipEventSynchronize((hipEvent_t)event));
+  return check_device_error("vpp_event_synchronize");
+}
+int vpp_event_destroy(void* event) {
+  if (event) VPP_HIP_TRY(hipEventDestroy((hipEvent_t)event));
+  return VPP_OK;
+}
+int vpp_stream_wait_event(void* stream, void* event) {
+  VPP_REQUIRE(event, VPP_ERR_INVALID_ARG, "vpp_stream_wait_event: null");
+  VPP_HIP_TRY(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)event, 0));
+  return VPP_OK;
+}
 
 // Launch graphs for C / C++ hosts: every entry point of this ABI is stream-ordered and allocation-free on its fast paths, so a
 // frame loop (or K benchmark launches) can be recorded once and replayed with one submission.  With `timed`, the graph gets an

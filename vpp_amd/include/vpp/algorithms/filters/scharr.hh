@@ -17,7 +17,7 @@ template <class U, class V> void scharr(const image2d<U>& in, image2d<vector<V, 
   static_assert(sizeof(U) == 1, "scharr: 8-bit single-channel input");
   const vpp_image_desc di = in.device_desc(false), dout = out.device_desc(true);
   device::check(vpp_scharr(&dout, &di, device::stream()), "vpp_scharr");
-  device::check(vpp_sync(device::stream()), "vpp_sync");
+  device::call_done();   // queued, not drained: vpp/core/device.hh
 }
 template <class U, class V> void scharr(const image2d<vector<U, 1>>& in, image2d<vector<V, 2>>& out) { scharr(*(const image2d<U>*)&in, out); }
 }  // namespace vpp

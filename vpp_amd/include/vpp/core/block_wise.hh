@@ -35,7 +35,7 @@ template <class OPTS, class... R> class block_wise_runner {
     if (block_size_[0] != block_size_[1]) throw std::runtime_error("block_wise | ops::block_maxima: square blocks only");
     const vpp_image_desc d = img.device_desc(true);
     device::check(vpp_blockwise_maxima_filter(&d, block_size_[0], device::stream()), "vpp_blockwise_maxima_filter");
-    device::check(vpp_sync(device::stream()), "vpp_sync");
+    device::call_done();   // queued, not drained: vpp/core/device.hh
   }
 #endif
  private:

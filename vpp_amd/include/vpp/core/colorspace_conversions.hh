@@ -20,7 +20,7 @@ template <class T, class U, unsigned N, unsigned C> imageNd<T, N> rgb_to_graylev
   if constexpr (N == 2 && std::is_same<U, unsigned char>::value && colorspace_internals::is_u8_gray<T>::value) {
     const vpp_image_desc di = in.device_desc(false), dout = out.device_desc(true, true);
     device::check(vpp_rgb_to_graylevel(&dout, &di, 0, device::stream()), "vpp_rgb_to_graylevel");
-    device::check(vpp_sync(device::stream()), "vpp_sync");
+    device::call_done();   // queued, not drained: vpp/core/device.hh
     return out;
   }
 #endif
@@ -41,7 +41,7 @@ template <unsigned C> image2d<unsigned char> rgb_to_graylevel_mirror(const image
   image2d<unsigned char> out(frame.domain(), _border = border, _aligned = aligned);
   const vpp_image_desc di = frame.device_desc(false), dout = out.device_desc(true, true);
   device::check(vpp_rgb_to_graylevel(&dout, &di, 1, device::stream()), "vpp_rgb_to_graylevel");
-  device::check(vpp_sync(device::stream()), "vpp_sync");
+  device::call_done();   // queued, not drained: vpp/core/device.hh
   return out;
 }
 #endif

@@ -5,6 +5,7 @@
 // re-implementation of the hot-path algorithms in these headers to fall back to.
 #pragma once
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -24,6 +25,25 @@ inline void check(int status, const char* what) {
   throw std::runtime_error(status == VPP_ERR_BORDER_TOO_SMALL ? std::string(vpp_last_error()) : std::string(what) + ": " + vpp_last_error());
 }
 inline void* stream() { return nullptr; }
+// What every device call of the drop-in surface ends with.  The reference's calls are synchronous (pixel_wise joins its OpenMP loop); what a caller can
+// OBSERVE of that is kept without draining the GPU after every call (a drained 4K call costs ~6 us more than its kernel, and nothing overlaps):
+//  * pixels: every host accessor waits for the image's mirror (storage::to_host copies on the same stream and waits for the copy);
+//  * the wall clock of a loop of calls: a call returns once the call BEFORE THE PREVIOUS ONE has completed — at most kCallsInFlight calls are queued, so a
+//    timed loop measures the device's sustained rate to within that many calls, and memory handed back by a dying image is reused in stream order;
+//  * errors: a failing launch throws from the call itself, a fault in a running kernel from one of the next calls (or the next host access).
+// VPP_AMD_SYNC_CALLS=1 in the environment: every call waits for its own completion (the behaviour up to round 3).
+constexpr int kCallsInFlight = 2;
+inline void call_done() {
+  static const bool sync_all = [] { const char* e = std::getenv("VPP_AMD_SYNC_CALLS"); return e && e[0] == '1'; }();
+  if (sync_all) { check(vpp_sync(stream()), "vpp_sync"); return; }
+  struct ring { void* ev[kCallsInFlight] = {}; bool set[kCallsInFlight] = {}; int k = 0; };
+  static thread_local ring r;   // (events live as long as the process: the HIP runtime may be gone before thread-exit destructors run)
+  if (!r.ev[r.k]) check(vpp_event_create(&r.ev[r.k]), "vpp_event_create");
+  check(vpp_event_record(r.ev[r.k], stream()), "vpp_event_record");
+  r.set[r.k] = true;
+  r.k = (r.k + 1) % kCallsInFlight;
+  if (r.set[r.k]) check(vpp_event_synchronize(r.ev[r.k]), "vpp_event_synchronize");   // the oldest call still queued
+}
 template <class T> struct dtype_of { static_assert(sizeof(T) == 0, "pixel component type not supported on the device"); };
 template <> struct dtype_of<unsigned char> { enum { value = VPP_U8 }; };
 template <> struct dtype_of<signed char> { enum { value = VPP_I8 }; };

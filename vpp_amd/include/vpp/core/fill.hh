@@ -33,7 +33,7 @@ template <class V> void fill_border_any(image2d<V>& img, int mode, const V* valu
 #ifdef VPP_AMD_DEVICE
   const vpp_image_desc d = img.device_desc(true);
   device::check(vpp_fill_border(&d, mode, value, device::stream()), "vpp_fill_border");
-  device::check(vpp_sync(device::stream()), "vpp_sync");
+  device::call_done();   // queued, not drained: vpp/core/device.hh
 #else
   fill_border_host(img, mode, value);
 #endif

@@ -250,14 +250,14 @@ template <class OPTS, class... R> class pixel_wise_impl {
     auto& d = std::get<0>(ranges_); auto& a = std::get<1>(ranges_); auto& b = std::get<2>(ranges_);
     const vpp_image_desc da = a.device_desc(false), db = b.device_desc(false), dd = d.device_desc(true);
     device::check(vpp_pixelwise_binary(op, &dd, &da, &db, device::stream()), "vpp_pixelwise_binary");
-    device::check(vpp_sync(device::stream()), "vpp_sync");
+    device::call_done();   // queued, not drained: vpp/core/device.hh
   }
   void device_box(int rr, int cc) {
     static_assert(sizeof...(R) == 2, "ops::box_mean needs pixel_wise(dst, relative_access(src)) or pixel_wise(dst, box_nbh2d(src))");
     auto& d = std::get<0>(ranges_); auto& n = std::get<1>(ranges_);
     const vpp_image_desc ds = n.img.device_desc(false), dd = d.device_desc(true);
     device::check(vpp_box_filter(&dd, &ds, rr, cc, device::stream()), "vpp_box_filter");
-    device::check(vpp_sync(device::stream()), "vpp_sync");
+    device::call_done();   // queued, not drained: vpp/core/device.hh
   }
 #endif
   // a stack: the same expression on every frame (a kernel that returns a pixel value would have to build a stack: not provided)
@@ -285,7 +285,7 @@ template <class OPTS, class... R> class pixel_wise_impl {
     }
     for (int k = 0; k < n; k++) dd[k] = pw::stack<typename std::decay<decltype(d)>::type>::frame(d, k).device_desc(true);
     device::check(vpp_pixelwise_binary_batch(op, dd.data(), da.data(), db.data(), n, device::stream()), "vpp_pixelwise_binary_batch");
-    device::check(vpp_sync(device::stream()), "vpp_sync");
+    device::call_done();   // queued, not drained: vpp/core/device.hh
   }
   void device_box_stack(int rr, int cc) {
     static_assert(sizeof...(R) == 2 && (pw::stack<R>::value && ...), "ops::box_mean on stacks needs pixel_wise(dst, relative_access(src)) with two stacks of frames");
@@ -296,7 +296,7 @@ template <class OPTS, class... R> class pixel_wise_impl {
     for (int k = 0; k < n; k++) ds[k] = pw::stack<typename std::decay<decltype(nb)>::type>::frame(nb, k).img.device_desc(false);
     for (int k = 0; k < n; k++) dd[k] = pw::stack<typename std::decay<decltype(d)>::type>::frame(d, k).device_desc(true);
     device::check(vpp_box_filter_batch(dd.data(), ds.data(), n, rr, cc, device::stream()), "vpp_box_filter_batch");
-    device::check(vpp_sync(device::stream()), "vpp_sync");
+    device::call_done();   // queued, not drained: vpp/core/device.hh
   }
 #endif
   std::tuple<R...> ranges_;

@@ -267,7 +267,7 @@ template <class F, class... A> void launch(F f, int r0, int c0, int nrows, int n
       else hipLaunchKernelGGL((pixel_wise_tile_kernel<1, F, A...>), grid, dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
       const hipError_t e = hipGetLastError();
       if (e != hipSuccess) throw std::runtime_error(std::string("pixel_wise (device, tiled): launch failed: ") + hipGetErrorString(e));
-      device::check(vpp_sync(device::stream()), "vpp_sync");
+      device::call_done();   // queued, not drained: vpp/core/device.hh
       return;
     }
   }
@@ -287,7 +287,7 @@ template <class F, class... A> void launch(F f, int r0, int c0, int nrows, int n
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) throw std::runtime_error(std::string("pixel_wise (device): launch failed: ") + hipGetErrorString(e));
-  device::check(vpp_sync(device::stream()), "vpp_sync");
+  device::call_done();   // queued, not drained: vpp/core/device.hh
 }
 
 // ---- block_wise on the device (vpp/core/block_wise.hh:26-56): one lane per block, the callable sees one view per range --------
@@ -332,7 +332,7 @@ template <class F, class... A> void launch_blocks(F f, int rstart, int cstart, i
   hipLaunchKernelGGL((block_wise_kernel<F, A...>), dim3((gr * gc + 63) / 64), dim3(64), 0, (hipStream_t)device::stream(), f, rstart, cstart, rend, cend, bsr, bsc, gr, gc, acc...);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) throw std::runtime_error(std::string("block_wise (device): launch failed: ") + hipGetErrorString(e));
-  device::check(vpp_sync(device::stream()), "vpp_sync");
+  device::call_done();   // queued, not drained: vpp/core/device.hh
 }
 
 }  // namespace pwdev

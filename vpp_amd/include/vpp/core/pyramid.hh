@@ -64,7 +64,7 @@ template <class V, unsigned N> struct pyramid {
       const vpp_image_desc prev = src.device_desc(false), next = levels_[i].device_desc(true);
       device::check(vpp_pyr_down(&next, &prev, device::stream()), "vpp_pyr_down");
     }
-    device::check(vpp_sync(device::stream()), "vpp_sync");
+    device::call_done();   // queued, not drained: vpp/core/device.hh
 #else
     static_assert(sizeof(V) == 0, "pyramid::propagate_level0 runs on the device: build with -DVPP_AMD_DEVICE and link libvpp_amd");
 #endif
@@ -78,7 +78,7 @@ template <class V, unsigned N> struct pyramid {
       for (size_t i = 0; i < levels_.size(); i++) d[i] = levels_[i].device_desc(true, true);
       const vpp_image_desc s = in.device_desc(false);
       device::check(vpp_pyramid_build(d.data(), int(d.size()), &s, device::stream()), "vpp_pyramid_build");
-      device::check(vpp_sync(device::stream()), "vpp_sync");
+      device::call_done();   // queued, not drained: vpp/core/device.hh
       return;
     }
 #endif
