@@ -2,7 +2,7 @@
 # Summarise gpurun_out/prof_<tag> (written by tools/profile_round.sh, same call, on the GPU box) into <dest> (default profiles/);
 # the summaries are then copied into the tracked profiles/ directory.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 D=${2:-profiles}
 P=gpurun_out/prof_$TAG
 { echo "# Round ${TAG#r} — rocprofv3 --kernel-trace --stats of \`python bench.py --no-cpu\` (defaults: 500 steps, 50 warm-up), of the driver's"

@@ -44,3 +44,19 @@ for i in range(6):
     capi.check(lib.vpp_pyrlk_match(vi.desc_array(p1), vi.desc_array(gr), vi.desc_array(p2), L, V(k.data_ptr()), 10000, 7, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30,
                                    ctypes.c_float(0.01), 0, None, st))
 torch.cuda.synchronize()
+# round 4: the latency floor (1 250 keypoints = one of 8 ranks' share of configs[3]: 64 lanes per keypoint) and the reference's own benchmark
+# configuration (11 x 11 window, 4 levels: benchmarks/pyrlk_opencv_comparison.cc:47,64-65) — kernels of other symbols, so the PMC passes see them separately
+kps_s = pyr.make_keypoints(pyr.grid_keypoints(NR, NC, 1250, margin=32))
+ks0 = torch.from_numpy(kps_s.view(np.uint8).reshape(-1).copy()).cuda()
+p1 = pyr.device_pyramid(lib, q1, L, B); p2 = pyr.device_pyramid(lib, q2, L, B); gr = pyr.device_grad_pyramid(lib, p1[0], L, B, vi.F32)
+for i in range(6):
+    k = ks0.clone()
+    capi.check(lib.vpp_pyrlk_match(vi.desc_array(p1), vi.desc_array(gr), vi.desc_array(p2), L, V(k.data_ptr()), 1250, 7, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30,
+                                   ctypes.c_float(0.01), 0, None, st))
+L4, B4 = 4, 8
+r1 = pyr.device_pyramid(lib, q1, L4, B4); r2 = pyr.device_pyramid(lib, q2, L4, B4); rg = pyr.device_grad_pyramid(lib, r1[0], L4, B4, vi.F32)
+for i in range(6):
+    k = k0.clone()
+    capi.check(lib.vpp_pyrlk_match(vi.desc_array(r1), vi.desc_array(rg), vi.desc_array(r2), L4, V(k.data_ptr()), 10000, 11, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30,
+                                   ctypes.c_float(0.01), 0, None, st))
+torch.cuda.synchronize()
