@@ -290,3 +290,29 @@ def test_sdof_graph_replays_between_eager_calls_of_another_layout(lib, orc):
     if g2:
         lib.vpp_graph_destroy(g2)
     call_c(); check_c("eager C after the refused recording")
+
+
+def test_a_device_side_timeout_is_reported_once_and_resets_the_scratch(lib, orc):
+    """The propagation rounds' grid barrier gives up instead of hanging the GPU and raises a bit in the sticky device error word (pinned host memory);
+    the host's next vpp_sync returns VPP_ERR_HIP with a readable message — once — and every scratch note is invalidated, so the next flow call resets
+    the control block itself and is exact again.  (The bit is raised from the host here: a real timeout needs a broken GPU.)"""
+    f1, f2, kps = flow_scene(150, 200, seed=61, spacing=5)
+    i1, i2 = u8_image(f1, border=3), u8_image(f2, border=3)
+    n = len(kps)
+    want = (np.zeros((n, 2), np.int32), np.zeros(n, np.int32), np.zeros(n, np.uint8))
+    assert orc.orc_semi_dense_optical_flow(P(i1.desc), P(i2.desc), kps.ctypes.data_as(ctypes.c_void_p), n, 9, 3, 0, 2, 5,
+                                           want[0].ctypes.data_as(ctypes.c_void_p), want[1].ctypes.data_as(ctypes.c_void_p), want[2].ctypes.data_as(ctypes.c_void_p)) == 0
+    d1, d2, dk = DeviceImage.from_host(i1), DeviceImage.from_host(i2), torch.from_numpy(kps).cuda()
+    out = (torch.zeros((n, 2), dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda"))
+    st = capi.stream_ptr()
+
+    def call():
+        capi.check(lib.vpp_semi_dense_optical_flow(P(d1.desc), P(d2.desc), ctypes.c_void_p(dk.data_ptr()), n, 9, 3, 0, 2, 5,
+                                                   ctypes.c_void_p(out[0].data_ptr()), ctypes.c_void_p(out[1].data_ptr()), ctypes.c_void_p(out[2].data_ptr()), st))
+    call(); capi.check(lib.vpp_sync(st))
+    assert lib.vpp_debug_raise_device_error(1) == 0
+    assert lib.vpp_sync(st) == capi.ERR_HIP and b"grid barrier" in lib.vpp_last_error()
+    assert lib.vpp_sync(st) == capi.OK                                   # reported once
+    call(); capi.check(lib.vpp_sync(st))                                  # the notes were dropped: this call carries its own resets
+    for g, w in zip(out, want):
+        np.testing.assert_array_equal(g.cpu().numpy(), w)

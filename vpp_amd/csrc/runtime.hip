@@ -462,6 +462,13 @@ int vpp_graph_end(void* stream, int timed, vpp_graph** out) {
   *out = gr;
   return VPP_OK;
 }
+// diagnostics (not part of include/vpp_amd.h): raise bits of the sticky device error word from the host, as a kernel whose protocol gave up would (tests)
+int vpp_debug_raise_device_error(unsigned bits) {
+  unsigned* w = device_error_word();
+  VPP_REQUIRE(w, VPP_ERR_HIP, "vpp_debug_raise_device_error: no error word");
+  __atomic_fetch_or(w, bits, __ATOMIC_RELEASE);
+  return VPP_OK;
+}
 // diagnostics (not part of include/vpp_amd.h): kernel nodes of a recorded graph — how many launches a replay makes (record-time batching, tests)
 int vpp_debug_graph_kernel_nodes(vpp_graph* gr, int* count) {
   VPP_REQUIRE(gr && gr->g && count, VPP_ERR_INVALID_ARG, "vpp_debug_graph_kernel_nodes: null");
