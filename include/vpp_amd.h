@@ -245,6 +245,9 @@ int vpp_semi_dense_optical_flow_strips(const vpp_image_desc* i1, const vpp_image
  * `clone(frame, _border = b); fill_border_mirror(frame); rgb_to_graylevel<uchar>(frame)` in one pass; src's border
  * is not read (it may be 0). */
 int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream);
+/* n frames of one geometry in ONE launch (a 33 MB launch alone pays its ramp and drain: 54 % of the HBM peak); results are those of the n calls in sequence —
+ * mixed geometries and frames that feed each other go out as the n calls.  Per-frame calls recorded into a launch graph fold into such launches by themselves. */
+int vpp_rgb_to_graylevel_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int mirror, void* stream);
 /* The ingest fused with the image pyramid it feeds (examples/video_extruder.cc:46-48 followed by pyramid<uchar>::update, vpp/core/pyramid.hh:
  * 169-198): levels[0] (u8 x1, any border <= its extents) = rgb_to_graylevel<uchar>(rgb) with a mirror-filled border, levels[1..] = propagate_level0.
  * Bit-identical to vpp_rgb_to_graylevel(gray, rgb, 1) + vpp_pyramid_build(levels, nlevels, gray); one launch for 2 or 3 levels. */

@@ -438,3 +438,57 @@ def test_a_refused_update_does_not_advance_the_tracker(lib):
     assert states[1][0] == states[0][0]
     for g, w in zip(states[1][1:], states[0][1:]):
         np.testing.assert_array_equal(g, w)
+
+
+@pytest.mark.parametrize("ch,mirror,n", [(3, 1, 5), (4, 1, 3), (3, 0, 70)])
+def test_rgb_to_graylevel_batch_and_recorded_calls(lib, orc, ch, mirror, n):
+    """vpp_rgb_to_graylevel_batch: n frames of one geometry in one launch (70 > the 64 a launch carries: two launches), every frame against the oracle; the same
+    frames as per-frame calls recorded into a launch graph fold into batched nodes (record-time batching, video.hip: coalesce_gray) with the same bytes; a
+    frame of another geometry in the batch sends it out as the calls in sequence."""
+    shape, border = (45, 150), 3
+    srcs = [rand_image(*shape, vi.U8, ch, border=0 if mirror else border, seed=500 + k, fill_border=True) for k in range(n)]
+    wants = []
+    for s_ in srcs:
+        w = HostImage(*shape, vi.U8, 1, border); w.raw[:] = 0x5A
+        assert orc.orc_rgb_to_graylevel(P(w.desc), P(s_.desc), mirror) == 0
+        wants.append(w)
+    dsrc = [DeviceImage.from_host(x) for x in srcs]
+
+    def fresh():
+        out = []
+        for _ in range(n):
+            h = HostImage(*shape, vi.U8, 1, border); h.raw[:] = 0x5A
+            out.append(DeviceImage.from_host(h))
+        return out
+    ddst = fresh()
+    capi.check(lib.vpp_rgb_to_graylevel_batch(vi.desc_array(ddst), vi.desc_array(dsrc), n, mirror, capi.stream_ptr()))
+    capi.check(lib.vpp_sync(capi.stream_ptr()))
+    for d, w in zip(ddst, wants):
+        np.testing.assert_array_equal(d.download().raw, w.raw)
+    # recorded per-frame calls
+    ddst = fresh()
+    st = torch.cuda.Stream(); sp = ctypes.c_void_p(st.cuda_stream)
+    torch.cuda.synchronize()
+    graph = ctypes.c_void_p()
+    capi.check(lib.vpp_graph_begin(sp))
+    for k in range(n):
+        capi.check(lib.vpp_rgb_to_graylevel(P(ddst[k].desc), P(dsrc[k].desc), mirror, sp))
+    capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(graph)))
+    nodes = ctypes.c_int()
+    capi.check(lib.vpp_debug_graph_kernel_nodes(graph, ctypes.byref(nodes)))
+    assert nodes.value == (n + 63) // 64
+    capi.check(lib.vpp_graph_launch(graph, sp)); capi.check(lib.vpp_sync(sp))
+    for d, w in zip(ddst, wants):
+        np.testing.assert_array_equal(d.download().raw, w.raw)
+    capi.check(lib.vpp_graph_destroy(graph))
+    # mixed geometries
+    odd = rand_image(shape[0] + 2, shape[1], vi.U8, ch, border=0 if mirror else border, seed=599, fill_border=True)
+    wodd = HostImage(shape[0] + 2, shape[1], vi.U8, 1, border); wodd.raw[:] = 0x5A
+    assert orc.orc_rgb_to_graylevel(P(wodd.desc), P(odd.desc), mirror) == 0
+    h = HostImage(shape[0] + 2, shape[1], vi.U8, 1, border); h.raw[:] = 0x5A
+    d2 = fresh()[:2] + [DeviceImage.from_host(h)]
+    s2 = dsrc[:2] + [DeviceImage.from_host(odd)]
+    capi.check(lib.vpp_rgb_to_graylevel_batch(vi.desc_array(d2), vi.desc_array(s2), 3, mirror, capi.stream_ptr()))
+    capi.check(lib.vpp_sync(capi.stream_ptr()))
+    for d, w in zip(d2, [wants[0], wants[1], wodd]):
+        np.testing.assert_array_equal(d.download().raw, w.raw)

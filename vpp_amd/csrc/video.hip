@@ -10,7 +10,10 @@
 //    border, then the [r - s, r + s) x [c - s, c + s) square of every keypoint is zeroed.
 #include "common.hpp"
 #include "tracker_device.hpp"
+#include <algorithm>
 #include <cstring>
+#include <map>
+#include <vector>
 using namespace vpp_amd;
 
 namespace {
@@ -52,11 +55,18 @@ template <int CH> __device__ __forceinline__ void gray_chunk(const uint32_t* w, 
 // loads, one 16-byte store) are numbered densely over (row, chunk) — no idle lanes at row ends, no divergence in those waves; the
 // chunks that cross the left / right end of a row ("edge", 2 per row: mirrored / clipped columns, per-pixel form) are handled by
 // the FIRST blocks of the same launch, so that their dependent byte loads run under the main stream instead of after it.
+// One launch serves a BATCH of frames of one geometry (vpp_rgb_to_graylevel_batch; the single call = a batch of one): the block grid is the frames' grids back
+// to back (`blocks_per_frame` each), so the chip does not drain between frames — a 33 MB launch alone reaches 54 % of the HBM peak (ramp + drain).
+constexpr int kGrayBatchMax = 64;
+struct GrayBatch { uint8_t* d[kGrayBatchMax]; const uint8_t* s[kGrayBatchMax]; };
 template <int CH, bool MIRROR>
-__global__ __launch_bounds__(256) void rgb_to_gray_kernel(DImg dst, DImg src, int ext, int c_start, int nchunks, int n_left, int n_main, int edge_blocks, int vec_ok) {
+__global__ __launch_bounds__(256) void rgb_to_gray_kernel(DImg dst, DImg src, int ext, int c_start, int nchunks, int n_left, int n_main, int edge_blocks, int vec_ok,
+                                                          const GrayBatch frames, unsigned blocks_per_frame) {
   const int nrows_out = dst.nr + 2 * ext;
-  if ((int)blockIdx.x < edge_blocks) {
-    const int n_edge = nchunks - n_main, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned frame = blockIdx.x / blocks_per_frame, fblock = blockIdx.x - frame * blocks_per_frame;
+  dst.p0 = frames.d[frame]; src.p0 = const_cast<uint8_t*>(frames.s[frame]);
+  if ((int)fblock < edge_blocks) {
+    const int n_edge = nchunks - n_main, t = fblock * blockDim.x + threadIdx.x;
     const int row = t / n_edge, e = t - row * n_edge;
     if (row >= nrows_out) return;
     const int r = row - ext, c0 = c_start + kGrayChunk * (e < n_left ? e : e + n_main);
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(256) void rgb_to_gray_kernel(DImg dst, DImg src, in
     }
     return;
   }
-  const long long t = (long long)(blockIdx.x - edge_blocks) * blockDim.x + threadIdx.x;
+  const long long t = (long long)(fblock - edge_blocks) * blockDim.x + threadIdx.x;
   const int row = (int)(t / n_main), chunk = n_left + (int)(t - (long long)row * n_main);
   if (row >= nrows_out) return;
   const int r = row - ext, c0 = c_start + kGrayChunk * chunk;
@@ -136,7 +146,10 @@ __global__ __launch_bounds__(256) void keypoint_mask_kernel(DImg mask, const int
 
 }  // namespace
 
-extern "C" int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream) {
+namespace {
+// geometry of one frame's launch (shared by every frame of a batch) and the kernel to launch / to re-parameterise a recorded node with
+struct GrayGeom { DImg d, s; int ext, c_start, nchunks, n_left, n_main, edge_blocks, vec_ok, bsz, ch, mirror; unsigned blocks_per_frame; };
+int gray_geometry(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, GrayGeom* g) {
   VPP_REQUIRE(valid_desc(dst) && valid_desc(src) && same_domain(dst, src), VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel: invalid descriptors / domain mismatch");
   VPP_REQUIRE(dst->dtype == VPP_U8 && dst->channels == 1 && src->dtype == VPP_U8 && (src->channels == 3 || src->channels == 4), VPP_ERR_UNSUPPORTED,
               "vpp_rgb_to_graylevel: u8 x3 / x4 -> u8 x1 only");
@@ -145,7 +158,6 @@ extern "C" int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_d
   VPP_REQUIRE(!mirror || (ext <= dst->nrows && ext <= dst->ncols), VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel: border larger than the image");
   const int c_start = -((ext + kGrayChunk - 1) / kGrayChunk) * kGrayChunk;   // chunks are 16-B aligned relative to dst's first pixel
   const int nchunks = (dst->ncols + ext - c_start + kGrayChunk - 1) / kGrayChunk;
-  const int dword_ok = aligned16(dst) ? 1 : 0;
   // main chunks: c0 >= lo && c0 + 16 <= hi with [lo, hi) = the source columns that map to themselves
   const int lo = mirror ? 0 : -ext, hi = mirror ? src->ncols : src->ncols + ext;
   const int n_left = (lo - c_start + kGrayChunk - 1) / kGrayChunk;                                 // first chunk with c0 >= lo
@@ -155,18 +167,94 @@ extern "C" int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_d
   if (bsz != 128 && bsz != 256) bsz = 64;
   const int edge_blocks = (int)(((long long)nrows_out * (nchunks - n_main) + bsz - 1) / bsz);
   const long long main_blocks = ((long long)nrows_out * n_main + bsz - 1) / bsz;
-  VPP_REQUIRE(edge_blocks + main_blocks < (1ll << 31), VPP_ERR_UNSUPPORTED, "vpp_rgb_to_graylevel: image too large for one launch");
-  const unsigned grid = (unsigned)(edge_blocks + main_blocks);
+  VPP_REQUIRE(edge_blocks + main_blocks < (1ll << 31) / kGrayBatchMax, VPP_ERR_UNSUPPORTED, "vpp_rgb_to_graylevel: image too large for one launch");
+  *g = GrayGeom{dimg(dst), dimg(src), ext, c_start, nchunks, n_left, n_main, edge_blocks, aligned16(dst) ? 1 : 0, bsz, src->channels, mirror ? 1 : 0, (unsigned)(edge_blocks + main_blocks)};
+  return VPP_OK;
+}
+void* gray_kernel(const GrayGeom& g) {
+  if (g.ch == 3) return g.mirror ? (void*)rgb_to_gray_kernel<3, true> : (void*)rgb_to_gray_kernel<3, false>;
+  return g.mirror ? (void*)rgb_to_gray_kernel<4, true> : (void*)rgb_to_gray_kernel<4, false>;
+}
+int gray_launch(const GrayGeom& g0, const GrayBatch& fr, int n, hipStream_t st) {
+  GrayGeom g = g0; GrayBatch frames = fr;
+  void* args[11] = {&g.d, &g.s, &g.ext, &g.c_start, &g.nchunks, &g.n_left, &g.n_main, &g.edge_blocks, &g.vec_ok, &frames, &g.blocks_per_frame};
+  VPP_HIP_TRY(hipLaunchKernel(gray_kernel(g), dim3(g.blocks_per_frame * (unsigned)n), dim3((unsigned)g.bsz), args, 0, st));
+  return VPP_OK;
+}
+inline bool same_gray_geometry(const vpp_image_desc& a, const vpp_image_desc& b) {
+  return a.nrows == b.nrows && a.ncols == b.ncols && a.pitch == b.pitch && a.border == b.border && a.channels == b.channels && (((uintptr_t)a.first_pixel ^ (uintptr_t)b.first_pixel) & 15) == 0;
+}
+// record-time batching of per-frame calls (the mechanism of box.hip: coalesce_frame): a recorded frame loop's ingests fold into one batched node
+struct GrayCoalesce {
+  unsigned long long window = 0; hipGraphNode_t node = nullptr; int lane = 0; std::vector<hipGraphNode_t> behind;
+  int n = 0, mirror = 0; vpp_image_desc d0{}, s0{}; GrayGeom g{}; GrayBatch frames{};
+};
+thread_local std::map<hipStream_t, GrayCoalesce> g_gray_coalesce;
+bool coalesce_gray(IndependentCall& side, hipStream_t st, const vpp_image_desc* dst, const vpp_image_desc* src, int mirror) {
+  GrayCoalesce& c = g_gray_coalesce[st];
+  if (!(c.n > 0 && c.n < kGrayBatchMax && c.window == side.window() && c.mirror == (mirror ? 1 : 0) && same_gray_geometry(*dst, c.d0) && same_gray_geometry(*src, c.s0))) return false;
+  for (hipGraphNode_t x : side.conflicts())
+    if (x == c.node || std::find(c.behind.begin(), c.behind.end(), x) == c.behind.end()) return false;
+  c.frames.d[c.n] = (uint8_t*)dst->first_pixel; c.frames.s[c.n] = (const uint8_t*)src->first_pixel;
+  c.n++;
+  GrayGeom g = c.g; GrayBatch frames = c.frames;
+  void* args[11] = {&g.d, &g.s, &g.ext, &g.c_start, &g.nchunks, &g.n_left, &g.n_main, &g.edge_blocks, &g.vec_ok, &frames, &g.blocks_per_frame};
+  hipKernelNodeParams kp{};
+  kp.func = gray_kernel(g); kp.gridDim = dim3(g.blocks_per_frame * (unsigned)c.n); kp.blockDim = dim3((unsigned)g.bsz); kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
+  if (hipGraphKernelNodeSetParams(c.node, &kp) != hipSuccess) { (void)hipGetLastError(); c.n = 0; return false; }
+  side.absorbed_into(c.node, c.lane);
+  return true;
+}
+}  // namespace
+
+extern "C" int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream) {
+  GrayGeom g;
+  int rc = gray_geometry(dst, src, mirror, &g);
+  if (rc != VPP_OK) return rc;
   hipStream_t st = as_stream(stream);
-  DImg d = dimg(dst), s = dimg(src);
-  if (src->channels == 3) {
-    if (mirror) rgb_to_gray_kernel<3, true><<<grid, bsz, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
-    else rgb_to_gray_kernel<3, false><<<grid, bsz, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
-  } else {
-    if (mirror) rgb_to_gray_kernel<4, true><<<grid, bsz, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
-    else rgb_to_gray_kernel<4, false><<<grid, bsz, 0, st>>>(d, s, ext, c_start, nchunks, n_left, n_main, edge_blocks, dword_ok);
+  const Extent wr = extent_of(*dst), rd = extent_of(*src);
+  IndependentCall side(st, &wr, 1, &rd, 1);
+  const bool batchable = side.active() && tuning("ingest.coalesce", 1);
+  if (batchable && coalesce_gray(side, st, dst, src, mirror)) return VPP_OK;
+  GrayBatch fr{};
+  fr.d[0] = (uint8_t*)dst->first_pixel; fr.s[0] = (const uint8_t*)src->first_pixel;
+  rc = gray_launch(g, fr, 1, st);
+  if (side.active()) {
+    GrayCoalesce& c = g_gray_coalesce[st];
+    c.n = 0;
+    if (batchable && rc == VPP_OK) {
+      int lane = 0; std::vector<hipGraphNode_t> behind;
+      const unsigned long long window = side.window();
+      hipGraphNode_t node = side.finish(&lane, &behind);
+      if (node) { c.window = window; c.node = node; c.lane = lane; c.behind = behind; c.n = 1; c.mirror = mirror ? 1 : 0; c.d0 = *dst; c.s0 = *src; c.g = g; c.frames = fr; }
+    }
   }
-  VPP_LAUNCH_CHECK();
+  return rc;
+}
+
+// n frames of one geometry (same sizes, pitches, borders, channel count, 16-byte phase of the first pixels) in ONE launch; anything else, and frames that feed
+// each other, go out as the n calls in sequence (whose results are the contract)
+extern "C" int vpp_rgb_to_graylevel_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int mirror, void* stream) {
+  VPP_REQUIRE(n >= 0 && (n == 0 || (dst && src)), VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel_batch: invalid argument");
+  if (n == 0) return VPP_OK;
+  bool same = n > 1 && tuning("ingest.batch", 1);
+  for (int k = 0; same && k < n; k++) same = valid_desc(&dst[k]) && valid_desc(&src[k]) && same_gray_geometry(dst[k], dst[0]) && same_gray_geometry(src[k], src[0]);
+  if (same) { const vpp_image_desc* srcs[1] = {src}; same = !batch_frames_interfere(n, dst, srcs, 1); }
+  if (same) {
+    GrayGeom g;
+    int rc = gray_geometry(&dst[0], &src[0], mirror, &g);
+    if (rc != VPP_OK) return rc;
+    for (int k = 1; k < n; k++) VPP_REQUIRE(dst[k].first_pixel != src[k].first_pixel, VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel_batch: in-place not supported (frame %d)", k);
+    for (int b0 = 0; b0 < n; b0 += kGrayBatchMax) {
+      const int nb = std::min(kGrayBatchMax, n - b0);
+      GrayBatch fr{};
+      for (int k = 0; k < nb; k++) { fr.d[k] = (uint8_t*)dst[b0 + k].first_pixel; fr.s[k] = (const uint8_t*)src[b0 + k].first_pixel; }
+      rc = gray_launch(g, fr, nb, as_stream(stream));
+      if (rc != VPP_OK) return rc;
+    }
+    return VPP_OK;
+  }
+  for (int k = 0; k < n; k++) { const int rc = vpp_rgb_to_graylevel(&dst[k], &src[k], mirror, stream); if (rc) return rc; }
   return VPP_OK;
 }
 
