@@ -12,6 +12,18 @@ from vpp_amd import capi
 pytestmark = pytest.mark.gpu
 
 
+def run_gpu(lib, f1, f2, kps, ws, nscales, min_scale, prop, patch):
+    i1, i2 = u8_image(f1, border=3), u8_image(f2, border=3)
+    n = len(kps)
+    d1, d2 = DeviceImage.from_host(i1), DeviceImage.from_host(i2)
+    dk = torch.from_numpy(kps).cuda()
+    gp = torch.zeros((n, 2), dtype=torch.int32, device="cuda"); gd = torch.zeros(n, dtype=torch.int32, device="cuda"); gv = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    capi.check(lib.vpp_semi_dense_optical_flow(P(d1.desc), P(d2.desc), ctypes.c_void_p(dk.data_ptr()), n, ws, nscales, min_scale, prop, patch,
+                                               ctypes.c_void_p(gp.data_ptr()), ctypes.c_void_p(gd.data_ptr()), ctypes.c_void_p(gv.data_ptr()), capi.stream_ptr()))
+    capi.check(lib.vpp_sync(capi.stream_ptr()))   # (also reports a device-side protocol that gave up)
+    return gp.cpu().numpy(), gd.cpu().numpy(), gv.cpu().numpy()
+
+
 def run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch):
     i1, i2 = u8_image(f1, border=3), u8_image(f2, border=3)
     n = len(kps)
@@ -23,8 +35,22 @@ def run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch):
     gp = torch.zeros((n, 2), dtype=torch.int32, device="cuda"); gd = torch.zeros(n, dtype=torch.int32, device="cuda"); gv = torch.zeros(n, dtype=torch.uint8, device="cuda")
     capi.check(lib.vpp_semi_dense_optical_flow(P(d1.desc), P(d2.desc), ctypes.c_void_p(dk.data_ptr()), n, ws, nscales, min_scale, prop, patch,
                                                ctypes.c_void_p(gp.data_ptr()), ctypes.c_void_p(gd.data_ptr()), ctypes.c_void_p(gv.data_ptr()), capi.stream_ptr()))
-    torch.cuda.synchronize()
+    capi.check(lib.vpp_sync(capi.stream_ptr()))   # (also reports a device-side protocol that gave up)
     return (gp.cpu().numpy(), gd.cpu().numpy(), gv.cpu().numpy()), (wp, wd, wv)
+
+
+# The propagation sweeps' implementations: Jacobi rounds to the fixed point as ONE launch per sweep (default: round 0 in every workgroup, the rest on the last one to
+# finish), the same with every workgroup that has work staying for the rounds behind the grid barrier (the path of long tails, forced), classify + rounds as two launches
+# per sweep (the strips' / ranks' path), the lock-step wavefront on one workgroup (on-device cross-check).
+SWEEP_IMPLS = {"fused": {}, "fused_grid": {b"sdof.sweep_stay": 0}, "two_launches": {b"sdof.fused_sweep": 0}, "wavefront": {b"sdof.propagate": 1}}
+
+
+def set_sweep_impl(lib, name):
+    for knobs in SWEEP_IMPLS.values():
+        for k in knobs:
+            lib.vpp_set_tuning(k, -1)
+    for k, v in SWEEP_IMPLS[name or "fused"].items():
+        lib.vpp_set_tuning(k, v)
 
 
 @pytest.mark.parametrize("shape,ws,nscales,min_scale,prop,patch", [
@@ -34,9 +60,9 @@ def run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch):
     ((96, 128), 5, 2, 0, 0, 3),      # no propagation
     ((270, 480), 9, 3, 0, 2, 5),
 ])
-@pytest.mark.parametrize("propagate_impl", [0, 1])  # Jacobi rounds to the fixed point (default); lock-step wavefront on one workgroup
-def test_sdof_matches_oracle(lib, orc, shape, ws, nscales, min_scale, prop, patch, propagate_impl):
-    lib.vpp_set_tuning(b"sdof.propagate", propagate_impl)
+@pytest.mark.parametrize("impl", list(SWEEP_IMPLS))
+def test_sdof_matches_oracle(lib, orc, shape, ws, nscales, min_scale, prop, patch, impl):
+    set_sweep_impl(lib, impl)
     f1, f2, kps = flow_scene(*shape)
     rng = np.random.default_rng(0)
     extra = np.stack([rng.integers(0, shape[0], 300), rng.integers(0, shape[1], 300)], 1).astype(np.int32)  # several keypoints per cell
@@ -45,7 +71,7 @@ def test_sdof_matches_oracle(lib, orc, shape, ws, nscales, min_scale, prop, patc
     assert want[2].mean() > 0.9
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
-    lib.vpp_set_tuning(b"sdof.propagate", -1)
+    set_sweep_impl(lib, None)
     moved = (want[0] != kps).any(axis=1).mean()
     assert moved > 0.5  # the scene really moves
 
@@ -65,13 +91,24 @@ def test_sdof_1080p_frame(lib, orc):
 
 def test_sdof_4k_bench_scene_matches_oracle(lib, orc):
     """The exact frame pair and keypoint set bench_pyrlk.py times (BASELINE configs[4] shapes): 81 748 keypoints, winsize 9, 3 scales,
-    2 sweeps.  Its middle scale's first sweep changes ~350 cells along the motion boundaries (6 propagation rounds over ~4 000 jobs)."""
-    lib.vpp_set_tuning(b"sdof.propagate", -1)
+    2 sweeps.  Its middle scale's first sweep changes ~350 cells along the motion boundaries (6 propagation rounds over ~4 000 jobs).
+    Then the same frames with a keypoint every 5 px (329 380 keypoints: every cell of the finest scale is claimed, the sweeps' queues are several times longer),
+    through each of the multi-workgroup sweep implementations."""
+    set_sweep_impl(lib, None)
     f1, f2, kps = flow_scene(2160, 3840, spacing=10)
     got, want = run_both(lib, orc, f1, f2, kps, 9, 3, 0, 2, 5)
     assert want[2].mean() > 0.9
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
+    f1, f2, kps = flow_scene(2160, 3840, spacing=5)
+    want = None
+    for impl in ("fused", "fused_grid", "two_launches"):
+        set_sweep_impl(lib, impl)
+        got, w = run_both(lib, orc, f1, f2, kps, 9, 3, 0, 2, 5) if want is None else (run_gpu(lib, f1, f2, kps, 9, 3, 0, 2, 5), want)
+        want = w
+        for g, w1 in zip(got, want):
+            np.testing.assert_array_equal(g, w1)
+    set_sweep_impl(lib, None)
 
 
 @pytest.mark.parametrize("shape,ws,nscales,border,ch", [((120, 160), 9, 3, 4, 1), ((121, 163), 7, 4, 18, 3), ((1080, 1920), 9, 3, 18, 4), ((96, 128), 5, 2, 2, 1)])
@@ -183,9 +220,11 @@ def test_strip_sharded_flow_equals_the_single_strip_result(lib, orc, shape, nstr
         np.testing.assert_array_equal(outs[1][1][wv == 1], wd[wv == 1])
 
 
-def test_sdof_unrelated_noise_frames_many_rounds(lib, orc):
+@pytest.mark.parametrize("impl", ["fused", "fused_grid", "two_launches"])
+def test_sdof_unrelated_noise_frames_many_rounds(lib, orc, impl):
     """Two unrelated noise frames with a keypoint in every cell: nearly every cell has a neighbour of a different flow, the propagation
     needs many rounds (18 at 1080p in tools/sdof_rounds_sim.cpp) over tens of thousands of jobs — still identical to the serial sweep."""
+    set_sweep_impl(lib, impl)
     rng = np.random.default_rng(1)
     nr, nc = 540, 960
     f1 = rng.integers(0, 256, (nr, nc)).astype(np.uint8); f2 = rng.integers(0, 256, (nr, nc)).astype(np.uint8)
@@ -201,6 +240,7 @@ def test_sdof_unrelated_noise_frames_many_rounds(lib, orc):
     run_both(lib, orc, f1, f2, kps, 9, 3, 0, 2, 5)
     lib.vpp_debug_sdof_round_stats(st4, 1); lib.vpp_set_tuning(b"sdof.stats", 0)
     rounds, jobs, evaluated, changes = list(st4)
+    set_sweep_impl(lib, None)
     assert rounds > 20 and jobs > 20000 and changes > 2000, list(st4)   # the hard regime really was exercised
 
 

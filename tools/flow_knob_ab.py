@@ -23,6 +23,8 @@ for shape, spacing in (((2160, 3840), 10), ((2160, 3840), 5), ((1080, 1920), 10)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             capi.check(lib.vpp_semi_dense_optical_flow(P(e1.desc), P(e2.desc), V(dk.data_ptr()), m, 9, 3, 0, 2, 5, V(gp.data_ptr()), V(gd.data_ptr()), V(gv.data_ptr()), st))
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        rc = lib.vpp_sync(st)   # (reports a device-side protocol that gave up)
+        if rc: print("  vpp_sync:", rc, lib.vpp_last_error().decode(), flush=True)
         sums.setdefault(v, set()).add((int(gp.sum()), int(gd.sum()), int(gv.sum())))
         print(f"{shape} spacing {spacing} ({m} kps) {knob.decode()}={v}: min {min(ts[2:]) * 1e3:.3f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2] * 1e3:.3f} ms", flush=True)
     print("  identical:", len(set.union(*sums.values())) == 1)

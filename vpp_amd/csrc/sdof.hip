@@ -115,6 +115,14 @@ __device__ __forceinline__ int distance_fn(const DImg& i1, const DImg& i2, int a
   return err;
 }
 
+struct Cell { int f0, f1, dist, mark; };  // mark: low byte = flow_map_mark value; bits 8.. see kTagShift
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Cell load_cell16(const Cell* p) { const v4i v = *(const v4i*)p; return Cell{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void store_cell16(Cell* p, const Cell& c) { *(v4i*)p = v4i{c.f0, c.f1, c.dist, c.mark}; }
+// The sweeps' cell records of one scale (fused sweeps, round 4): three arrays of one 16-byte record per cell of the sweep domain (row pitch nj) that
+// every writer of the maps keeps equal to them between sweeps — `pre` and the two round buffers of sdof_sweep_kernel.  p[0] == nullptr: not kept.
+struct Mirrors { Cell* p[3]; int nj; };
+
 struct GdMatch { int f0, f1, distance; };
 
 // gradient_descent_match (gradient_descent.hh:10-89), neighbour tables verbatim
@@ -338,7 +346,7 @@ __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa
 // groups occupied 3/4 of every wave of the coarsest scale).
 template <int WS, bool BYCELL = false>
 __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
-                                                                DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi, int clean_owner) {
+                                                                DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi, int clean_owner, Mirrors mir) {
   __shared__ uint4 s_union[8][kUnionRows];   // per group: the (WS + 2)-row patch of the current search step
   const int grp = blockIdx.x * 8 + (threadIdx.x >> 3), j = threadIdx.x & 7;
   int i = grp;
@@ -386,6 +394,11 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
   f[0] = g.f0; f[1] = g.f1;                        // :137-139
   cur.dist.row<int32_t>(pf0)[pf1] = g.distance;    // :140
   cur.mark.row<uint8_t>(pf0)[pf1] = 2;               // :141
+  if (mir.p[0]) {   // the sweeps' records of the cell (the reset launch left the records of unclaimed cells at mark 0)
+    const Cell rec{g.f0, g.f1, g.distance, 2};
+    const size_t at = (size_t)pf0 * mir.nj + pf1;
+    store_cell16(mir.p[0] + at, rec); store_cell16(mir.p[1] + at, rec); store_cell16(mir.p[2] + at, rec);
+  }
 }
 
 __device__ __forceinline__ int inorm(int a, int b) { return (int)sqrt((double)(a * a + b * b)); }  // Eigen norm() on vint2
@@ -439,8 +452,6 @@ __global__ __launch_bounds__(1024) void sdof_propagate_kernel(DImg i1, DImg i2, 
   }
 }
 
-struct Cell { int f0, f1, dist, mark; };  // mark: low byte = flow_map_mark value; bits 8.. see kTagShift
-
 __device__ __forceinline__ Cell load_map_cell(const Maps& m, int ci, int cj) {
   Cell c;
   const int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
@@ -465,22 +476,23 @@ __device__ __forceinline__ Cell load_map_cell(const Maps& m, int ci, int cj) {
 // 8 candidates of every descent step side by side), jobs pulled from a device queue, a grid barrier between rounds.  The barrier only
 // waits for workgroups that have REGISTERED, and registration closes at the first arrival: a workgroup that was not yet resident when
 // the others finished round 0 simply leaves, so the kernel cannot deadlock whatever else shares the GPU (other streams, other ranks).
-struct SweepCtl { unsigned count[2], head[2], reg, nreg, arrive, pad; unsigned long long gen; };   // zero between sweeps (see the exits)
+// zero between sweeps (see the exits).  done / nchanged / flushn / ack: sdof_sweep_kernel only.
+struct SweepCtl { unsigned count[2], head[2], reg, nreg, arrive, pad; unsigned long long gen; unsigned done, nchanged, flushn, ack; };
 constexpr unsigned kRegClosed = 0x80000000u;
 constexpr int kTagShift = 8;            // Cell::mark bits 8..: round + 1 in which the value last changed (0: unchanged this sweep)
 constexpr int kJobsPerGroup = 32;       // 256 threads / 8 lanes
 constexpr unsigned kSpinLimit = 1u << 22;   // polls of a barrier wait: a poll is s_sleep(1) + an L2 load, ~1 us under load, so ~4 s — far beyond any legitimate wait; on a timeout the
                                             // workgroup raises kDevErrSweepBarrier in the sticky device error word (common.hpp) and leaves: the host's next vpp_sync reports VPP_ERR_HIP
-struct RoundArrays { Cell* pre; Cell* B[2]; uint32_t* Q[2]; uint32_t* qflag[2]; SweepCtl* ctl; unsigned* err; };   // err: the sticky device error word (pinned host memory) or nullptr
+// err: the sticky device error word (pinned host memory) or nullptr.  chg / cflag (sdof_sweep_kernel): the cells whose value changed in this sweep, listed once each.
+// sub (sdof_sweep_kernel): the arrival counters below ctl->done, one per 128 bytes.
+struct RoundArrays { Cell* pre; Cell* B[2]; uint32_t* Q[2]; uint32_t* qflag[2]; SweepCtl* ctl; unsigned* err; uint32_t* chg; uint32_t* cflag; unsigned* sub; };
+constexpr int kSubCounters = 64, kSubStride = 32;   // words
 __device__ __forceinline__ void raise_barrier_timeout(const RoundArrays& a) {
   a.ctl->pad = 1;
   if (a.err) __hip_atomic_fetch_or(a.err, (unsigned)kDevErrSweepBarrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ unsigned g_round_stats[4];   // [0] rounds, [1] jobs, [2] jobs evaluated, [3] changes
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ Cell load_cell16(const Cell* p) { const v4i v = *(const v4i*)p; return Cell{v.x, v.y, v.z, v.w}; }
-__device__ __forceinline__ void store_cell16(Cell* p, const Cell& c) { *(v4i*)p = v4i{c.f0, c.f1, c.dist, c.mark}; }
 
 // Pass over all cells: copies the pre-sweep maps into the round buffers and lists the cells whose loop_body can do anything at all
 // against the pre-sweep maps (a marked neighbour whose flow differs by more than 2 px, :164-165 with flow_map(pf) == prev_flow).
@@ -517,20 +529,107 @@ __global__ __launch_bounds__(256) void sdof_classify_kernel(Maps m, int NI, int 
   }
 }
 
-// Append the lanes' targets (-1: none) to the queue of round parity `q`: the flag exchange keeps a cell from being listed twice, and the
+// Append the lanes' targets (-1: none) to a list, each at most once: the flag exchange keeps a cell from being listed twice, and the
 // slots are taken with ONE atomic per wave (the counter is a single word: returning atomics on one address retire at ~11 ns each, and a
 // changed cell lists up to five cells).  Called at a point every lane of the wave reaches.
-__device__ __forceinline__ void enqueue_targets(const RoundArrays& a, SweepCtl* ctl, int q, int target) {
+__device__ __forceinline__ void append_unique(uint32_t* __restrict__ flags, unsigned* counter, uint32_t* __restrict__ list, int target) {
   bool push = false;
-  if (target >= 0) push = __hip_atomic_exchange(&a.qflag[q][target], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+  if (target >= 0) push = __hip_atomic_exchange(&flags[target], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
   const unsigned long long b = __ballot(push);
   if (b) {
     const int lane = __lane_id(), leader = __ffsll((long long)b) - 1;
     unsigned base = 0;
-    if (lane == leader) base = __hip_atomic_fetch_add(&ctl->count[q], (unsigned)__popcll(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == leader) base = __hip_atomic_fetch_add(counter, (unsigned)__popcll(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     base = __shfl(base, leader);
-    if (push) a.Q[q][base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)target;
+    if (push) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)target;
   }
+}
+// the queue of round parity `q`
+__device__ __forceinline__ void enqueue_targets(const RoundArrays& a, SweepCtl* ctl, int q, int target) { append_unique(a.qflag[q], &ctl->count[q], a.Q[q], target); }
+
+// One job of round k: loop_body (:149-189) of `cell` on the 8 lanes of a group (j = lane in the group) — S_k(cell) = F(cell; pre on the later neighbours and
+// the cell itself, S_{k-1} = Bprev on the earlier ones), written to Bcur and to the maps.  Returns the cell this lane wants in the next round's queue (-1: none);
+// *changed_out: the cell's value differs from S_{k-1}(cell).  clear_flag: the cell came out of round k's queue (its flag is handed back).
+template <int WS>
+__device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws, const Maps& m, int patch, int forward, int NI, int NJ, const RoundArrays& a, int k,
+                                         const Cell* __restrict__ Bprev, Cell* __restrict__ Bcur, int cell, int j, uint4* __restrict__ slot, int stats, bool clear_flag,
+                                         bool* changed_out) {
+  const int par = k & 1;
+  const int ci = cell / NJ, cj = cell - ci * NJ;
+  if (clear_flag && j == 0) a.qflag[par][cell] = 0;   // set by whoever enqueued the cell for this round (nobody enqueues for round k during round k)
+  const Cell pre = load_cell16(a.pre + cell);
+  const Cell old = load_cell16(Bprev + cell);
+  // lane j holds neighbour j in loop_body's order: (-1,-1) (-1,0) (-1,1) (0,-1) (0,1) (1,-1) (1,0) (1,1)
+  const int jj = j + (j >= 4 ? 1 : 0);
+  const int dr = jj / 3 - 1, dc = jj % 3 - 1;
+  const int q0 = ci + dr, q1 = cj + dc;
+  const bool in = q0 >= 0 && q1 >= 0 && q0 < NI && q1 < NJ;
+  const bool earlier = forward ? j < 4 : j >= 4;   // raster / reverse raster visiting order
+  Cell nb{0, 0, 0, 0};
+  if (in) nb = load_cell16((earlier ? Bprev : a.pre) + (size_t)q0 * NJ + q1);
+  const bool nbm = (nb.mark & 0xFF) != 0;
+  // does any earlier neighbour hold a value that changed in round k - 1?  (round 0: everything is evaluated once)
+  const unsigned long long grp = 0xFFull << (__lane_id() & ~7);
+  const bool need = k == 0 || (__ballot(in && earlier && (nb.mark >> kTagShift) == k) & grp) != 0;
+  Cell cur = Cell{old.f0, old.f1, old.dist, old.mark & 0xFF};
+  const int r = forward ? ci * patch : i1.nr - 1 - (NI - 1 - ci) * patch, c = forward ? cj * patch : i1.nc - 1 - (NJ - 1 - cj) * patch;
+  WindowRegs<WS> wa;
+  bool a_ok = false, okb = false, need_walk = false;
+  int d2 = INT_MAX;
+  auto dist = [&](int b0, int b1, int th) -> int {
+    if constexpr (WS != 0) {
+      if (!(a_ok && i2.has(b0, b1))) return INT_MAX;
+      return sad_rows_against<WS>(wa, i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2), i2.pitch, th);
+    } else return distance_fn<WS>(i1, i2, r, c, b0, b1, ws, th);
+  };
+  if (need) {
+    a_ok = i1.has(r, c);
+    if (WS != 0 && a_ok) load_window<WS>(wa, i1.row<uint8_t>(r - ws / 2) + (c - ws / 2), i1.pitch);
+    // static part of the test at :164-165: the neighbour is marked and differs from prev_flow; its d2 (:169) depends on nothing else
+    const int b0 = pre.f0 - nb.f0, b1 = pre.f1 - nb.f1;
+    okb = nbm && b0 * b0 + b1 * b1 >= 9;
+    d2 = okb ? dist(r + nb.f0, c + nb.f1, INT_MAX) : INT_MAX;
+    cur = Cell{pre.f0, pre.f1, pre.dist, pre.mark & 0xFF};
+    need_walk = true;
+  }
+  // loop_body's walk over the neighbours (:160-187).  Each group keeps its OWN cursor: it skips ahead to its next neighbour that passes the
+  // tests at :164-170 against its running best, and the groups of the wave then run their descents TOGETHER, whatever neighbour each of them
+  // is at.  (With one loop over kk for the whole wave, a descent was executed once per kk at which ANY of the 8 groups needed one — up to 8
+  // descents of up to 5 dependent search steps per wave, most lanes idle: a round lasted as long as that chain, ~17 us on the 4K bench scene.)
+  // Per group the sequence of tests, descents and updates is exactly the sequential one.
+  int kk = 0;
+  for (;;) {
+    bool found = false;
+    int n0 = 0, n1 = 0, d2k = 0;
+    while (need_walk && kk < 8) {
+      const int ok = __shfl((int)okb, kk, 8);
+      n0 = __shfl(nb.f0, kk, 8); n1 = __shfl(nb.f1, kk, 8); d2k = __shfl(d2, kk, 8);
+      kk++;
+      const int a0 = cur.f0 - n0, a1 = cur.f1 - n1;
+      if (ok && a0 * a0 + a1 * a1 >= 9 && d2k < cur.dist) { found = true; break; }
+    }
+    if (!__ballot(found)) break;   // no group of this wave has a descent left
+    if (found) {
+      GdMatch g;   // :173-175; its first distance is d2 itself
+      if constexpr (WS != 0) g = group_descent_staged<WS>(wa, a_ok, i2, r, c, r + n0, c + n1, true, d2k, j, slot, dist);
+      else g = group_descent(dist, r, c, r + n0, c + n1, d2k, j);
+      if (g.distance < cur.dist) { cur.mark = 1; cur.f0 = g.f0; cur.f1 = g.f1; cur.dist = g.distance; }   // :179-184
+    }
+  }
+  const bool changed = cur.f0 != old.f0 || cur.f1 != old.f1 || cur.dist != old.dist || cur.mark != (old.mark & 0xFF);
+  if (j == 0) {
+    store_cell16(Bcur + cell, Cell{cur.f0, cur.f1, cur.dist, cur.mark | (changed ? (k + 1) << kTagShift : 0)});
+    int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
+    f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)cur.mark;
+    if (stats == 1) { atomicAdd(&g_round_stats[1], 1u); if (need) atomicAdd(&g_round_stats[2], 1u); if (changed) atomicAdd(&g_round_stats[3], 1u); }
+  }
+  *changed_out = changed;
+  int target = -1;
+  if (changed) {   // next round: this cell (its value must reach the other buffer) and the marked cells that read it as an earlier neighbour
+    if (j == (forward ? 0 : 7)) target = cell;                       // one of the earlier-neighbour lanes speaks for the cell itself
+    else if (!earlier && in && nbm) target = q0 * NJ + q1;
+  }
+  return target;
 }
 
 template <int WS>
@@ -573,79 +672,8 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
       const unsigned job = base + (unsigned)(tid >> 3);
       int target = -1;   // the cell this lane wants in the next round's queue
       if (job < n) {
-        const int cell = (int)Qcur[job];
-        const int ci = cell / NJ, cj = cell - ci * NJ;
-        if (j == 0) a.qflag[par][cell] = 0;   // set by whoever enqueued the cell for this round (nobody enqueues for round k during round k)
-        const Cell pre = load_cell16(a.pre + cell);
-        const Cell old = load_cell16(Bprev + cell);
-        // lane j holds neighbour j in loop_body's order: (-1,-1) (-1,0) (-1,1) (0,-1) (0,1) (1,-1) (1,0) (1,1)
-        const int jj = j + (j >= 4 ? 1 : 0);
-        const int dr = jj / 3 - 1, dc = jj % 3 - 1;
-        const int q0 = ci + dr, q1 = cj + dc;
-        const bool in = q0 >= 0 && q1 >= 0 && q0 < NI && q1 < NJ;
-        const bool earlier = forward ? j < 4 : j >= 4;   // raster / reverse raster visiting order
-        Cell nb{0, 0, 0, 0};
-        if (in) nb = load_cell16((earlier ? Bprev : a.pre) + (size_t)q0 * NJ + q1);
-        const bool nbm = (nb.mark & 0xFF) != 0;
-        // does any earlier neighbour hold a value that changed in round k - 1?  (round 0: everything is evaluated once)
-        const unsigned long long grp = 0xFFull << (__lane_id() & ~7);
-        const bool need = k == 0 || (__ballot(in && earlier && (nb.mark >> kTagShift) == k) & grp) != 0;
-        Cell cur = Cell{old.f0, old.f1, old.dist, old.mark & 0xFF};
-        const int r = forward ? ci * patch : i1.nr - 1 - (NI - 1 - ci) * patch, c = forward ? cj * patch : i1.nc - 1 - (NJ - 1 - cj) * patch;
-        WindowRegs<WS> wa;
-        bool a_ok = false, okb = false, need_walk = false;
-        int d2 = INT_MAX;
-        auto dist = [&](int b0, int b1, int th) -> int {
-          if constexpr (WS != 0) {
-            if (!(a_ok && i2.has(b0, b1))) return INT_MAX;
-            return sad_rows_against<WS>(wa, i2.row<uint8_t>(b0 - ws / 2) + (b1 - ws / 2), i2.pitch, th);
-          } else return distance_fn<WS>(i1, i2, r, c, b0, b1, ws, th);
-        };
-        if (need) {
-          a_ok = i1.has(r, c);
-          if (WS != 0 && a_ok) load_window<WS>(wa, i1.row<uint8_t>(r - ws / 2) + (c - ws / 2), i1.pitch);
-          // static part of the test at :164-165: the neighbour is marked and differs from prev_flow; its d2 (:169) depends on nothing else
-          const int b0 = pre.f0 - nb.f0, b1 = pre.f1 - nb.f1;
-          okb = nbm && b0 * b0 + b1 * b1 >= 9;
-          d2 = okb ? dist(r + nb.f0, c + nb.f1, INT_MAX) : INT_MAX;
-          cur = Cell{pre.f0, pre.f1, pre.dist, pre.mark & 0xFF};
-          need_walk = true;
-        }
-        // loop_body's walk over the neighbours (:160-187).  Each group keeps its OWN cursor: it skips ahead to its next neighbour that passes the
-        // tests at :164-170 against its running best, and the groups of the wave then run their descents TOGETHER, whatever neighbour each of them
-        // is at.  (With one loop over kk for the whole wave, a descent was executed once per kk at which ANY of the 8 groups needed one — up to 8
-        // descents of up to 5 dependent search steps per wave, most lanes idle: a round lasted as long as that chain, ~17 us on the 4K bench scene.)
-        // Per group the sequence of tests, descents and updates is exactly the sequential one.
-        int kk = 0;
-        for (;;) {
-          bool found = false;
-          int n0 = 0, n1 = 0, d2k = 0;
-          while (need_walk && kk < 8) {
-            const int ok = __shfl((int)okb, kk, 8);
-            n0 = __shfl(nb.f0, kk, 8); n1 = __shfl(nb.f1, kk, 8); d2k = __shfl(d2, kk, 8);
-            kk++;
-            const int a0 = cur.f0 - n0, a1 = cur.f1 - n1;
-            if (ok && a0 * a0 + a1 * a1 >= 9 && d2k < cur.dist) { found = true; break; }
-          }
-          if (!__ballot(found)) break;   // no group of this wave has a descent left
-          if (found) {
-            GdMatch g;   // :173-175; its first distance is d2 itself
-            if constexpr (WS != 0) g = group_descent_staged<WS>(wa, a_ok, i2, r, c, r + n0, c + n1, true, d2k, j, s_union[tid >> 3], dist);
-            else g = group_descent(dist, r, c, r + n0, c + n1, d2k, j);
-            if (g.distance < cur.dist) { cur.mark = 1; cur.f0 = g.f0; cur.f1 = g.f1; cur.dist = g.distance; }   // :179-184
-          }
-        }
-        const bool changed = cur.f0 != old.f0 || cur.f1 != old.f1 || cur.dist != old.dist || cur.mark != (old.mark & 0xFF);
-        if (j == 0) {
-          store_cell16(Bcur + cell, Cell{cur.f0, cur.f1, cur.dist, cur.mark | (changed ? (k + 1) << kTagShift : 0)});
-          int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
-          f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)cur.mark;
-          if (stats == 1) { atomicAdd(&g_round_stats[1], 1u); if (need) atomicAdd(&g_round_stats[2], 1u); if (changed) atomicAdd(&g_round_stats[3], 1u); }
-        }
-        if (changed) {   // next round: this cell (its value must reach the other buffer) and the marked cells that read it as an earlier neighbour
-          if (j == (forward ? 0 : 7)) target = cell;                       // one of the earlier-neighbour lanes speaks for the cell itself
-          else if (!earlier && in && nbm) target = q0 * NJ + q1;
-        }
+        bool changed;
+        target = round_job<WS>(i1, i2, ws, m, patch, forward, NI, NJ, a, k, Bprev, Bcur, (int)Qcur[job], j, s_union[tid >> 3], stats, true, &changed);
       }
       enqueue_targets(a, ctl, par ^ 1, target);
     }
@@ -695,6 +723,260 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
   }
 }
 
+// ---- a whole sweep in ONE launch (round 4) -------------------------------------------------------------------------------------------------------------
+// sdof_classify_kernel + sdof_rounds_kernel are two dependent launches per sweep, 12 of the 18 of a 3-scale pair, and a dependent launch costs ~4.5 us
+// whatever it does.  Fusing them behind an in-kernel grid barrier was measured slower: on this chip the barrier costs more than
+// the boundary.  This kernel has NO barrier on its common path:
+//   * the cells' records (`pre`, B[0], B[1] of the scale: Mirrors) are kept equal to the maps BETWEEN sweeps by everyone who writes the maps — the reset
+//     launch (mark 0), the descents, and the end of every sweep (the changed cells are written back) — so there is no copy pass, and the pre-sweep values
+//     stay readable in `pre` while round 0 already writes B[0] and the maps;
+//   * every workgroup classifies its own 256 cells against `pre` and runs ROUND 0 for its own candidates at once: S_0(c) = F(c; pre) reads pre-sweep
+//     values only, so round 0 needs nothing from any other workgroup;
+//   * a workgroup that is done arrives on a counter and LEAVES; the last one to arrive (it alone knows that round 0 is complete) runs the remaining
+//     rounds by itself — on the scenes measured a sweep's later rounds are a handful of cells — with workgroup-scoped synchronisation, writes the
+//     changed cells' final values back to the three record arrays and hands the control block back zeroed.
+// Long tails (unrelated frames: thousands of changes per round, tens of rounds) must not run on one workgroup: a workgroup that finds more than
+// kStayThreshold jobs queued for round 1 when it is done STAYS (at most kMaxStay do: the others, and with them the last arriver, always find a free
+// slot — the wait cannot deadlock), and the rounds then run on the stayers + the last arriver behind the grid barrier of sdof_rounds_kernel.
+// Every registered workgroup stays until the sweep is over (parked once a round fits one batch), takes its share of the write-back and acknowledges;
+// ticket 0 zeroes the control block after the last acknowledgement.
+constexpr unsigned kStayThreshold = kJobsPerGroup;   // (a round that fits one batch is run by one workgroup anyway)
+constexpr unsigned kMaxStay = 48;
+constexpr int kSweepTile = 16;   // a workgroup's cells: a 16 x 16 tile of the sweep domain (a motion boundary along a row of cells would hand one workgroup of 256 consecutive
+                                 // cells 256 candidates, 8 passes of round 0 one after the other: measured 90 us for the middle scale of the 4K bench scene)
+constexpr unsigned kGenFinal = 0xFFFFFFFFu;   // round field of the message that ends the sweep for parked workgroups
+
+template <int WS>
+__global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats, int nsub, unsigned stay_above) {
+  __shared__ unsigned s_val, s_nreg, s_flags, s_ncand, s_flushn, s_giveup;
+  __shared__ unsigned long long s_gen;
+  __shared__ uint32_t s_cand[256];
+  __shared__ uint4 s_union[kJobsPerGroup][kUnionRows];   // per 8-lane group: the candidate patch of a descent step (group_descent_staged)
+  SweepCtl* const ctl = a.ctl;
+  const int tid = threadIdx.x, j = tid & 7;
+  if (tid == 0) { s_ncand = 0; s_giveup = 0; }
+  __syncthreads();
+  {  // ---- this workgroup's cells: which of them can loop_body change at all (sdof_classify_kernel's test, on the records)
+    const int tiles_x = (NJ + kSweepTile - 1) / kSweepTile;
+    const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+    const int ci = ty * kSweepTile + tid / kSweepTile, cj = tx * kSweepTile + tid % kSweepTile;
+    const int idx = ci * NJ + cj;
+    bool cand = false;
+    if (ci < NI && cj < NJ) {
+      const Cell cur = load_cell16(a.pre + idx);
+      if (cur.mark & 0xFF) {
+#pragma unroll
+        for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
+          for (int dc = -1; dc <= 1; dc++) {
+            if (!dr && !dc) continue;
+            const int q0 = ci + dr, q1 = cj + dc;
+            if (q0 < 0 || q1 < 0 || q0 >= NI || q1 >= NJ) continue;
+            const Cell nb = load_cell16(a.pre + (size_t)q0 * NJ + q1);
+            const int a0 = cur.f0 - nb.f0, a1 = cur.f1 - nb.f1;
+            if ((nb.mark & 0xFF) && a0 * a0 + a1 * a1 >= 9) cand = true;
+          }
+      }
+    }
+    const unsigned long long b = __ballot(cand);
+    if (b) {
+      const int lane = __lane_id(), leader = __ffsll((long long)b) - 1;
+      unsigned base = 0;
+      if (lane == leader) base = atomicAdd(&s_ncand, (unsigned)__popcll(b));
+      base = __shfl(base, leader);
+      if (cand) s_cand[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+    }
+  }
+  __syncthreads();
+  const unsigned n0 = s_ncand;
+  // ---- round 0 on this workgroup's candidates: reads `pre` (and B[1], equal to it), writes B[0], the maps, round 1's queue and the list of changes
+  for (unsigned base = 0; base < n0; base += (unsigned)kJobsPerGroup) {
+    const unsigned job = base + (unsigned)(tid >> 3);
+    int target = -1, chg = -1;
+    if (job < n0) {
+      const int cell = (int)s_cand[job];
+      bool changed;
+      target = round_job<WS>(i1, i2, ws, m, patch, forward, NI, NJ, a, 0, a.B[1], a.B[0], cell, j, s_union[tid >> 3], stats, false, &changed);
+      if (changed && j == 0) chg = cell;
+    }
+    enqueue_targets(a, ctl, 1, target);
+    append_unique(a.cflag, &ctl->nchanged, a.chg, chg);
+  }
+  // ---- arrive; everybody but the last arriver and the stayers leaves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    unsigned flags = 0, ticket = 0;
+    if (n0) {   // this workgroup wrote records, maps or lists: released before the arrival
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // (only a workgroup that had candidates itself looks at the queue: the others — nearly all of them at the finest scale — arrive one memory round trip earlier)
+    if (n0 && __hip_atomic_load(&ctl->count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > stay_above) {
+      const unsigned t = __hip_atomic_fetch_add(&ctl->reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // before the arrival: the last arriver reads the final count
+      if (t < kMaxStay) { ticket = t; flags |= 1u; }
+    }
+    // Two-level arrival: returning atomics on ONE word retire at ~11 ns each (1 300 workgroups at the finest 4K scale: 14 us, measured 30 us per empty sweep); the
+    // workgroups arrive on nsub counters, 128 bytes apart, and the last one of each (which also hands its counter back zeroed) on ctl->done.
+    const unsigned sc = blockIdx.x % (unsigned)nsub, expect = gridDim.x / (unsigned)nsub + (sc < gridDim.x % (unsigned)nsub ? 1u : 0u);
+    if (__hip_atomic_fetch_add(&a.sub[sc * kSubStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1) {
+      __hip_atomic_store(&a.sub[sc * kSubStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nsub - 1) flags |= 2u;
+    }
+    s_flags = flags; s_val = ticket;
+  }
+  __syncthreads();
+  const unsigned flags = s_flags;
+  if (!flags) return;
+  if (tid == 0) {
+    unsigned ticket = s_val;
+    unsigned long long g;
+    if (flags & 2u) {   // round 0 is complete everywhere
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const unsigned n1 = __hip_atomic_load(&ctl->count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned R = min(__hip_atomic_load(&ctl->reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kMaxStay);
+      unsigned N = R;
+      if (!(flags & 1u)) { ticket = R; N = R + 1; }
+      __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g = (1ull << 32) | n1;
+      if (N > 1) {
+        __hip_atomic_store(&ctl->nreg, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->flushn, __hip_atomic_load(&ctl->nchanged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ctl->gen, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s_nreg = N;
+      if (stats == 1) atomicAdd(&g_round_stats[0], 1u);
+    } else {   // a stayer: the last arriver publishes the size of round 1
+      unsigned spin = 0;
+      while (((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != 1ull && (g >> 32) != (unsigned long long)kGenFinal && ++spin < kSpinLimit)
+        __builtin_amdgcn_s_sleep(1);
+      if (spin >= kSpinLimit) { raise_barrier_timeout(a); s_giveup = 1; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      s_nreg = __hip_atomic_load(&ctl->nreg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_gen = g; s_val = ticket;
+  }
+  __syncthreads();
+  if (s_giveup) return;   // gave up waiting (a bug or a dead GPU): leave without touching anything
+  const unsigned N0 = s_nreg, ticket = s_val;
+  unsigned n = (unsigned)s_gen;
+  bool solo = N0 == 1, parked = (s_gen >> 32) == (unsigned long long)kGenFinal;   // (a message this workgroup was too slow to read was followed by the sweep's last one)
+  if (parked) n = 0;
+  __syncthreads();
+  for (int k = 1; n != 0; k++) {
+    // A round that fits one batch is left to ticket 0 alone (workgroup-scoped synchronisation: no L2 write-back, no invalidation in front of the next
+    // round's loads); the others wait for the end of the sweep.  Once alone, always alone: longer lists are walked in passes.
+    if (!solo && n <= min(stay_above, (unsigned)kJobsPerGroup)) {
+      if (ticket != 0) { parked = true; break; }
+      solo = true;
+    }
+    const int par = k & 1;
+    const Cell* __restrict__ Bprev = a.B[par ^ 1];
+    Cell* __restrict__ Bcur = a.B[par];
+    const uint32_t* __restrict__ Qcur = a.Q[par];
+    const unsigned stride = solo ? 1u : N0;
+    for (unsigned batch = solo ? 0u : ticket; batch * (unsigned)kJobsPerGroup < n; batch += stride) {
+      const unsigned job = batch * (unsigned)kJobsPerGroup + (unsigned)(tid >> 3);
+      int target = -1, chg = -1;
+      if (job < n) {
+        const int cell = (int)Qcur[job];
+        bool changed;
+        target = round_job<WS>(i1, i2, ws, m, patch, forward, NI, NJ, a, k, Bprev, Bcur, cell, j, s_union[tid >> 3], stats, true, &changed);
+        if (changed && j == 0) chg = cell;
+      }
+      enqueue_targets(a, ctl, par ^ 1, target);
+      append_unique(a.cflag, &ctl->nchanged, a.chg, chg);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long g;
+      if (solo) {   // this workgroup's own stores and atomics only: in order, through its own L1
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const unsigned nn = __hip_atomic_load(&ctl->count[par ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->count[par], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        g = nn;
+        if (stats == 1) atomicAdd(&g_round_stats[0], 1u);
+      } else {   // the grid barrier of sdof_rounds_kernel over the N0 registered workgroups
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned arrived = __hip_atomic_fetch_add(&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == N0 - 1) {
+          const unsigned nn = __hip_atomic_load(&ctl->count[par ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&ctl->count[par], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&ctl->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&ctl->flushn, __hip_atomic_load(&ctl->nchanged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          g = ((unsigned long long)(k + 1) << 32) | nn;
+          __hip_atomic_store(&ctl->gen, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (stats == 1) atomicAdd(&g_round_stats[0], 1u);
+        } else {
+          unsigned spin = 0;
+          // (the sweep's last message instead: ticket 0, alone since this barrier, was done before this workgroup read the barrier's own message)
+          while (((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned long long)(k + 1) && (g >> 32) != (unsigned long long)kGenFinal &&
+                 ++spin < kSpinLimit)
+            __builtin_amdgcn_s_sleep(1);
+          if (spin >= kSpinLimit) { g = 0; raise_barrier_timeout(a); s_giveup = 1; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      s_gen = g;
+    }
+    __syncthreads();
+    n = (unsigned)s_gen;
+    const bool final_seen = (s_gen >> 32) == (unsigned long long)kGenFinal, gave_up = s_giveup != 0;
+    __syncthreads();
+    if (gave_up) return;
+    if (final_seen) { parked = true; break; }
+  }
+  // ---- the sweep is over (or this workgroup is parked until it is): the changed cells' final values go back into the three record arrays, tags cleared
+  if (tid == 0) {
+    unsigned fn;
+    if (parked) {
+      unsigned long long g;
+      unsigned spin = 0;
+      while (((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned long long)kGenFinal && ++spin < kSpinLimit) __builtin_amdgcn_s_sleep(1);
+      if (spin >= kSpinLimit) { raise_barrier_timeout(a); s_giveup = 1; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      fn = __hip_atomic_load(&ctl->flushn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (solo) {
+      fn = __hip_atomic_load(&ctl->nchanged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (N0 > 1) {   // wake the parked workgroups: what this workgroup wrote alone is released first
+        __hip_atomic_store(&ctl->flushn, fn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ctl->gen, (unsigned long long)kGenFinal << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else fn = __hip_atomic_load(&ctl->flushn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // published with the barrier's last message (n == 0)
+    s_flushn = fn;
+  }
+  __syncthreads();
+  if (s_giveup) return;
+  const unsigned fn = s_flushn;
+  for (unsigned i = ticket * 256u + (unsigned)tid; i < fn; i += N0 * 256u) {
+    const uint32_t cell = a.chg[i];
+    Cell c = load_cell16(a.B[0] + cell);   // a changed cell is carried into the round after its change: both round buffers hold its final value
+    c.mark &= 0xFF;
+    store_cell16(a.pre + cell, c); store_cell16(a.B[0] + cell, c); store_cell16(a.B[1] + cell, c);
+    a.cflag[cell] = 0;
+  }
+  if (ticket != 0) {   // registered and done: ticket 0 may hand the control block back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(&ctl->ack, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (tid == 0 && N0 > 1) {
+    unsigned spin = 0;
+    while (__hip_atomic_load(&ctl->ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != N0 - 1 && ++spin < kSpinLimit) __builtin_amdgcn_s_sleep(1);
+    if (spin >= kSpinLimit) raise_barrier_timeout(a);
+  }
+  __syncthreads();
+  if (tid < (int)(sizeof(SweepCtl) / 4)) ((unsigned*)ctl)[tid] = 0u;   // zero between sweeps
+}
+
 // LINK (the tracker's step): the keypoint's match is also threaded onto the merge step's per-cell list (merge_link_one: the first pass of
 // video_extruder.hpp:60-84 needs exactly what this thread holds — the keypoint's old and new position and whether it matched)
 template <bool LINK>
@@ -730,7 +1012,8 @@ struct Carver {
 
 // One launch resets the maps of every scale that the per-scale phases used to reset one by one (fill_with_border(mark, 0) and the
 // owner map's 0xFF fill: 2 launches per scale, ~5 us each for a few hundred KB): the segments are whole carved blocks, written as 16-byte units.
-struct ResetArgs { uint4* p[16]; uint32_t first_block[17]; uint32_t units[16]; uint32_t value[16]; int nseg; };
+constexpr int kResetSegs = 28;
+struct ResetArgs { uint4* p[kResetSegs]; uint32_t first_block[kResetSegs + 1]; uint32_t units[kResetSegs]; uint32_t value[kResetSegs]; int nseg; };
 __global__ __launch_bounds__(256) void sdof_reset_kernel(ResetArgs a) {
   int sgm = 0;
   while (sgm + 1 < a.nseg && blockIdx.x >= a.first_block[sgm + 1]) sgm++;
@@ -822,7 +1105,9 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   auto MK = [&](int k, int s_) -> vpp_image_desc& { return MKs[(size_t)k * kMaxScales + s_]; };
   auto DM = [&](int k, int s_) -> vpp_image_desc& { return DMs[(size_t)k * kMaxScales + s_]; };
   auto OW = [&](int k, int s_) -> vpp_image_desc& { return OWs[(size_t)k * kMaxScales + s_]; };
-  RoundArrays ra{};   // the fixed-point rounds' buffers, sized for the finest scale
+  RoundArrays ra{};   // the fixed-point rounds' queues and flags, sized for the finest scale; the cells' records per scale (rec_*)
+  Cell* rec[kMaxScales][3] = {};   // pre, B[0], B[1] of a scale: one block, zeroed by the reset launch when the sweeps are fused (Mirrors)
+  size_t rec_off[kMaxScales] = {}, rec_bytes[kMaxScales] = {};
   size_t ra_flags_off = 0, ra_flags_bytes = 0;
   size_t mk_off[kMaxScales] = {}, mk_bytes[kMaxScales] = {}, ow_off[kMaxScales] = {}, ow_bytes[kMaxScales] = {};   // strip 0's mark / owner blocks
   for (int pass = 0; pass < 2; pass++) {
@@ -839,28 +1124,44 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
         DM(k, s_) = cv.image(fr_mem, fc, VPP_I32, 1, nscales); DM(k, s_).nrows = fr;
         OW(k, s_) = cv.image(fr, fc, VPP_U32, 1, 0); if (k == 0) { ow_off[s_] = cv.last_off; ow_bytes[s_] = cv.last_bytes; }
       }
+      {  // the scale's cell records: one entry per cell of its sweep domain (:192-200)
+        const size_t cells = (size_t)((ir - 1) / patchsize + 1) * ((ic - 1) / patchsize + 1), each = (cells * sizeof(Cell) + 255) / 256 * 256;
+        rec_off[s_] = cv.off; rec_bytes[s_] = 3 * each;
+        for (int q = 0; q < 3; q++) { rec[s_][q] = cv.base ? (Cell*)(cv.base + cv.off) : nullptr; cv.off += each; }
+      }
       fr = 1 + fr / 2; fc = 1 + fc / 2; ir = 1 + ir / 2; ic = 1 + ic / 2;  // pyramid.hh:154
     }
     {  // the rounds' buffers: one entry per cell of the finest scale's sweep domain
       const size_t cells = (size_t)((i1->nrows - 1) / patchsize + 1) * ((i1->ncols - 1) / patchsize + 1);
       auto take = [&](size_t bytes) { uint8_t* q = cv.base ? cv.base + cv.off : nullptr; cv.off += (bytes + 255) / 256 * 256; return q; };
-      ra.pre = (Cell*)take(cells * sizeof(Cell)); ra.B[0] = (Cell*)take(cells * sizeof(Cell)); ra.B[1] = (Cell*)take(cells * sizeof(Cell));
-      ra.Q[0] = (uint32_t*)take(cells * 4); ra.Q[1] = (uint32_t*)take(cells * 4);
-      ra_flags_off = cv.off;   // zero between sweeps: queue flags (self-cleaning) and the control block
-      ra.qflag[0] = (uint32_t*)take(cells * 4); ra.qflag[1] = (uint32_t*)take(cells * 4); ra.ctl = (SweepCtl*)take(sizeof(SweepCtl));
+      ra.Q[0] = (uint32_t*)take(cells * 4); ra.Q[1] = (uint32_t*)take(cells * 4); ra.chg = (uint32_t*)take(cells * 4);
+      ra_flags_off = cv.off;   // zero between sweeps: queue / change flags (self-cleaning) and the control block
+      ra.qflag[0] = (uint32_t*)take(cells * 4); ra.qflag[1] = (uint32_t*)take(cells * 4); ra.cflag = (uint32_t*)take(cells * 4); ra.sub = (unsigned*)take((size_t)kSubCounters * kSubStride * 4); ra.ctl = (SweepCtl*)take(sizeof(SweepCtl));
       ra_flags_bytes = cv.off - ra_flags_off;
       ra.err = device_error_word();
     }
     if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
   if (nstrips > 1) { int rc = g_strips.ensure(nstrips - 1); if (rc != VPP_OK) return rc; }
+  // single strip: the mark and owner maps of all scales are reset here in one launch (nothing writes a scale's maps before its own phase)
+  const bool reset_up_front = nstrips == 1 && 3 * (nscales - min_scale) + 1 <= kResetSegs && tuning("sdof.reset_up_front", 1);
+  const bool claim_up_front = reset_up_front && world == 1 && tuning("sdof.claim_up_front", 1);
+  // Self-cleaning owner maps (single strip, single rank): every descent hands its cell back empty, so the owner maps are not part of the reset and the
+  // mark reset shares ONE launch with the claims.  The slot's note says whether the maps of this layout were left clean by a call that ran to its end;
+  // anything else (first use, another layout, another code path, a call that returned early) gets a plain 0xFF fill first.
+  const bool self_cleaning = claim_up_front && tuning("sdof.self_cleaning_owner", 1);
+  // Fused sweeps (sdof_sweep_kernel): single strip, single rank (the strips' and ranks' rows of the maps are completed by copies / all-gathers that know
+  // nothing of the records), 8 lanes per keypoint in the descent (the kernel that writes the records)
+  const bool fused_sweeps = reset_up_front && world == 1 && propagation > 0 && tuning("sdof.descent_lanes", 8) == 8 && tuning("sdof.propagate", 0) != 1 &&
+                            tuning("sdof.fused_sweep", 1);
   {  // the queue flags clean themselves up and the control block is left zeroed by every sweep: zeroed here once per (buffer, layout).  A call that is
      // being recorded into a launch graph, and every call on a buffer that a graph has been recorded on, carries the reset itself (Scratch::Slot::note):
      // a replay runs between arbitrary other calls, whose layouts may have left anything in this region.
     // (Reset by a kernel of this file, not by hipMemsetAsync: recorded into a launch graph the runtime's memset nodes were not ordered with the kernel
     // nodes around them on ROCm 7.2 — replays read a half-zeroed control block and faulted; tests/test_gpu_sdof.py::test_sdof_graph_replays_between_...)
     Scratch::Slot& sl = *g_scratch.cur;
-    const unsigned long long sig = ((unsigned long long)ra_flags_off << 24) ^ (unsigned long long)ra_flags_bytes ^ 1ull;
+    // (per kind of sweep: the two-launch sweeps leave reg / nreg / gen of the control block behind — their classify pass resets them — the fused sweep expects zeros)
+    const unsigned long long sig = ((unsigned long long)ra_flags_off << 24) ^ (unsigned long long)ra_flags_bytes ^ 1ull ^ (fused_sweeps ? 1ull << 62 : 0ull);
     if (!sl.note(0, sig)) {
       ResetArgs z; z.nseg = 1; z.p[0] = (uint4*)((uint8_t*)g_scratch.p + ra_flags_off); z.units[0] = (uint32_t)(ra_flags_bytes / 16); z.value[0] = 0u;
       z.first_block[0] = 0; z.first_block[1] = (z.units[0] + 255) / 256;
@@ -891,13 +1192,6 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
     rc = vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream); if (rc) return rc;   // one launch for both when the packed kernel takes them
   }
   auto maps = [&](int k, int s_) { return Maps{dimg(&FL(k, s_)), dimg(&MK(k, s_)), dimg(&DM(k, s_))}; };
-  // single strip: the mark and owner maps of all scales are reset here in one launch (nothing writes a scale's maps before its own phase)
-  const bool reset_up_front = nstrips == 1 && 2 * (nscales - min_scale) + 1 <= 16 && tuning("sdof.reset_up_front", 1);
-  const bool claim_up_front = reset_up_front && world == 1 && tuning("sdof.claim_up_front", 1);
-  // Self-cleaning owner maps (single strip, single rank): every descent hands its cell back empty, so the owner maps are not part of the reset and the
-  // mark reset shares ONE launch with the claims.  The slot's note says whether the maps of this layout were left clean by a call that ran to its end;
-  // anything else (first use, another layout, another code path, a call that returned early) gets a plain 0xFF fill first.
-  const bool self_cleaning = claim_up_front && tuning("sdof.self_cleaning_owner", 1);
   Scratch::Slot& slot = *g_scratch.cur;
   unsigned long long owner_sig = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(nscales * 16 + min_scale);
   for (int s_ = min_scale; s_ < nscales; s_++) owner_sig = (owner_sig * 1099511628211ull) ^ ((unsigned long long)ow_off[s_] << 20) ^ (unsigned long long)ow_bytes[s_];
@@ -905,13 +1199,19 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   slot.set_note(1, 0);   // until this call has queued every descent
   if (reset_up_front) {
     ResetArgs ra; ra.nseg = 0; uint32_t blocks = 0;
-    for (int s_ = min_scale; s_ < nscales; s_++)
+    for (int s_ = min_scale; s_ < nscales; s_++) {
       for (int w = 0; w < (self_cleaning ? 1 : 2); w++) {
         const int q = ra.nseg++;
         ra.p[q] = (uint4*)((uint8_t*)g_scratch.p + (w ? ow_off[s_] : mk_off[s_]));
         ra.units[q] = (uint32_t)((w ? ow_bytes[s_] : mk_bytes[s_]) / 16); ra.value[q] = w ? 0xFFFFFFFFu : 0u;
         ra.first_block[q] = blocks; blocks += (ra.units[q] + 255) / 256;
       }
+      if (fused_sweeps) {   // the cells' records: mark 0 wherever no descent writes
+        const int q = ra.nseg++;
+        ra.p[q] = (uint4*)((uint8_t*)g_scratch.p + rec_off[s_]); ra.units[q] = (uint32_t)(rec_bytes[s_] / 16); ra.value[q] = 0u;
+        ra.first_block[q] = blocks; blocks += (ra.units[q] + 255) / 256;
+      }
+    }
     if (link) {   // the merge lists' heads (-1), beside the mark maps
       const int q = ra.nseg++;
       ra.p[q] = (uint4*)link->head; ra.units[q] = (uint32_t)link_head_units; ra.value[q] = 0xFFFFFFFFu;
@@ -959,12 +1259,14 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
         }
         if (!claim_up_front) sdof_claim_kernel<<<(n + 255) / 256, 256, 0, sk>>>(kps, n, scale_div, patchsize, dimg(&OW(k, scale)), lo, hi);
         const long long cells = (long long)OW(k, scale).nrows * OW(k, scale).ncols;
+        Mirrors mir{{nullptr, nullptr, nullptr}, 0};
+        if (fused_sweeps) mir = Mirrors{{rec[scale][0], rec[scale][1], rec[scale][2]}, (P1[scale].ncols - 1) / patchsize + 1};
         if (tuning("sdof.descent_lanes", 8) == 8 && cells * 2 <= n && tuning("sdof.descent_bycell", 1))
           sdof_descent_group_kernel<WS, true><<<(unsigned)((cells + 7) / 8), 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                                                         maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0);
+                                                                                         maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0, mir);
         else if (tuning("sdof.descent_lanes", 8) == 8)
           sdof_descent_group_kernel<WS><<<(n + 7) / 8, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                                    maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0);
+                                                                    maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0, mir);
         else
           sdof_descent_kernel<WS><<<(n + 63) / 64, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
                                                                maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0);
@@ -1000,11 +1302,20 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
         const int NJ = (P1[scale].ncols - 1) / patchsize + 1;
         if (mode != 1) {
           const int cells = NI * NJ;
+          RoundArrays rs = ra;
+          rs.pre = rec[scale][0]; rs.B[0] = rec[scale][1]; rs.B[1] = rec[scale][2];
           // most sweeps have nothing or a few hundred cells to do: a small grid keeps the empty launch cheap; long lists are walked in passes
           const int grid = std::min(tuning("sdof.rounds_grid", 256), (cells + kJobsPerGroup - 1) / kJobsPerGroup);
           for (int Ki = 0; Ki < propagation; Ki++) {
-            sdof_classify_kernel<<<(cells + 255) / 256, 256, 0, st>>>(maps(0, scale), NI, NJ, ra);
-            sdof_rounds_kernel<WS><<<grid, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, ra, tuning("sdof.stats", 0));
+            if (fused_sweeps) {   // one launch per sweep: every workgroup classifies its tile of cells and runs round 0 on them, the last one to finish runs the rest
+              const int tiles = ((NI + kSweepTile - 1) / kSweepTile) * ((NJ + kSweepTile - 1) / kSweepTile);
+              const int nsub = std::max(1, std::min(kSubCounters, tiles / 16));
+              sdof_sweep_kernel<WS><<<tiles, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs, tuning("sdof.stats", 0), nsub,
+                                                                  (unsigned)tuning("sdof.sweep_stay", (int)kStayThreshold));
+              continue;
+            }
+            sdof_classify_kernel<<<(cells + 255) / 256, 256, 0, st>>>(maps(0, scale), NI, NJ, rs);
+            sdof_rounds_kernel<WS><<<grid, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs, tuning("sdof.stats", 0));
           }
         } else
           sdof_propagate_kernel<WS><<<1, 1024, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, propagation);
