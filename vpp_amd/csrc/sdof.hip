@@ -119,6 +119,21 @@ struct Cell { int f0, f1, dist, mark; };  // mark: low byte = flow_map_mark valu
 typedef int v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ Cell load_cell16(const Cell* p) { const v4i v = *(const v4i*)p; return Cell{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ void store_cell16(Cell* p, const Cell& c) { *(v4i*)p = v4i{c.f0, c.f1, c.dist, c.mark}; }
+// Write-through stores and L1-bypassing loads (relaxed agent-scope atomics lower to `sc1` accesses on gfx950): what one workgroup stores this way every other
+// workgroup reads this way without an agent-scope release (an L2 write-back) on the one side and an acquire (an L1 invalidation) on the other —
+// MI355X_MICROARCH.md, "inter-workgroup visibility": sc1 stores AND sc1 loads.  A record goes as two 8-byte halves; nobody reads it while it is written.
+__device__ __forceinline__ Cell load_cell_sc1(const Cell* p) {
+  unsigned long long* q = (unsigned long long*)p;
+  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return Cell{(int)(unsigned)lo, (int)(unsigned)(lo >> 32), (int)(unsigned)hi, (int)(unsigned)(hi >> 32)};
+}
+__device__ __forceinline__ void store_cell_sc1(Cell* p, const Cell& c) {
+  unsigned long long* q = (unsigned long long*)p;
+  __hip_atomic_store(q, ((unsigned long long)(unsigned)c.f1 << 32) | (unsigned)c.f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, ((unsigned long long)(unsigned)c.mark << 32) | (unsigned)c.dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t load_u32_sc1(const uint32_t* p) { return __hip_atomic_load((uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_u32_sc1(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // The sweeps' cell records of one scale (fused sweeps, round 4): three arrays of one 16-byte record per cell of the sweep domain (row pitch nj) that
 // every writer of the maps keeps equal to them between sweeps — `pre` and the two round buffers of sdof_sweep_kernel.  p[0] == nullptr: not kept.
 struct Mirrors { Cell* p[3]; int nj; };
@@ -541,7 +556,7 @@ __device__ __forceinline__ void append_unique(uint32_t* __restrict__ flags, unsi
     unsigned base = 0;
     if (lane == leader) base = __hip_atomic_fetch_add(counter, (unsigned)__popcll(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     base = __shfl(base, leader);
-    if (push) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)target;
+    if (push) store_u32_sc1(list + base + __popcll(b & ((1ull << lane) - 1ull)), (uint32_t)target);
   }
 }
 // the queue of round parity `q`
@@ -550,15 +565,17 @@ __device__ __forceinline__ void enqueue_targets(const RoundArrays& a, SweepCtl* 
 // One job of round k: loop_body (:149-189) of `cell` on the 8 lanes of a group (j = lane in the group) — S_k(cell) = F(cell; pre on the later neighbours and
 // the cell itself, S_{k-1} = Bprev on the earlier ones), written to Bcur and to the maps.  Returns the cell this lane wants in the next round's queue (-1: none);
 // *changed_out: the cell's value differs from S_{k-1}(cell).  clear_flag: the cell came out of round k's queue (its flag is handed back).
-template <int WS>
+// MAPS: the value also goes into the maps (sdof_rounds_kernel: every round writes them, ordered by the barriers' releases; sdof_sweep_kernel has no releases —
+// two rounds' plain stores to one cell from two XCDs could reach memory in either order — and writes the maps once, at the end of the sweep).
+template <int WS, bool MAPS>
 __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws, const Maps& m, int patch, int forward, int NI, int NJ, const RoundArrays& a, int k,
                                          const Cell* __restrict__ Bprev, Cell* __restrict__ Bcur, int cell, int j, uint4* __restrict__ slot, int stats, bool clear_flag,
                                          bool* changed_out) {
   const int par = k & 1;
   const int ci = cell / NJ, cj = cell - ci * NJ;
-  if (clear_flag && j == 0) a.qflag[par][cell] = 0;   // set by whoever enqueued the cell for this round (nobody enqueues for round k during round k)
-  const Cell pre = load_cell16(a.pre + cell);
-  const Cell old = load_cell16(Bprev + cell);
+  if (clear_flag && j == 0) store_u32_sc1(a.qflag[par] + cell, 0u);   // set by whoever enqueued the cell for this round (nobody enqueues for round k during round k)
+  const Cell pre = load_cell16(a.pre + cell);   // (nobody writes `pre` during a sweep: plain loads)
+  const Cell old = load_cell_sc1(Bprev + cell);
   // lane j holds neighbour j in loop_body's order: (-1,-1) (-1,0) (-1,1) (0,-1) (0,1) (1,-1) (1,0) (1,1)
   const int jj = j + (j >= 4 ? 1 : 0);
   const int dr = jj / 3 - 1, dc = jj % 3 - 1;
@@ -566,7 +583,7 @@ __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws,
   const bool in = q0 >= 0 && q1 >= 0 && q0 < NI && q1 < NJ;
   const bool earlier = forward ? j < 4 : j >= 4;   // raster / reverse raster visiting order
   Cell nb{0, 0, 0, 0};
-  if (in) nb = load_cell16((earlier ? Bprev : a.pre) + (size_t)q0 * NJ + q1);
+  if (in) nb = earlier ? load_cell_sc1(Bprev + (size_t)q0 * NJ + q1) : load_cell16(a.pre + (size_t)q0 * NJ + q1);
   const bool nbm = (nb.mark & 0xFF) != 0;
   // does any earlier neighbour hold a value that changed in round k - 1?  (round 0: everything is evaluated once)
   const unsigned long long grp = 0xFFull << (__lane_id() & ~7);
@@ -618,9 +635,11 @@ __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws,
   }
   const bool changed = cur.f0 != old.f0 || cur.f1 != old.f1 || cur.dist != old.dist || cur.mark != (old.mark & 0xFF);
   if (j == 0) {
-    store_cell16(Bcur + cell, Cell{cur.f0, cur.f1, cur.dist, cur.mark | (changed ? (k + 1) << kTagShift : 0)});
-    int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
-    f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)cur.mark;
+    store_cell_sc1(Bcur + cell, Cell{cur.f0, cur.f1, cur.dist, cur.mark | (changed ? (k + 1) << kTagShift : 0)});
+    if constexpr (MAPS) {
+      int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
+      f[0] = cur.f0; f[1] = cur.f1; m.dist.row<int32_t>(ci)[cj] = cur.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)cur.mark;
+    }
     if (stats == 1) { atomicAdd(&g_round_stats[1], 1u); if (need) atomicAdd(&g_round_stats[2], 1u); if (changed) atomicAdd(&g_round_stats[3], 1u); }
   }
   *changed_out = changed;
@@ -673,7 +692,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
       int target = -1;   // the cell this lane wants in the next round's queue
       if (job < n) {
         bool changed;
-        target = round_job<WS>(i1, i2, ws, m, patch, forward, NI, NJ, a, k, Bprev, Bcur, (int)Qcur[job], j, s_union[tid >> 3], stats, true, &changed);
+        target = round_job<WS, true>(i1, i2, ws, m, patch, forward, NI, NJ, a, k, Bprev, Bcur, (int)load_u32_sc1(Qcur + job), j, s_union[tid >> 3], stats, true, &changed);
       }
       enqueue_targets(a, ctl, par ^ 1, target);
     }
@@ -789,14 +808,14 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   }
   __syncthreads();
   const unsigned n0 = s_ncand;
-  // ---- round 0 on this workgroup's candidates: reads `pre` (and B[1], equal to it), writes B[0], the maps, round 1's queue and the list of changes
+  // ---- round 0 on this workgroup's candidates: reads `pre` (and B[1], equal to it), writes B[0], round 1's queue and the list of changes
   for (unsigned base = 0; base < n0; base += (unsigned)kJobsPerGroup) {
     const unsigned job = base + (unsigned)(tid >> 3);
     int target = -1, chg = -1;
     if (job < n0) {
       const int cell = (int)s_cand[job];
       bool changed;
-      target = round_job<WS>(i1, i2, ws, m, patch, forward, NI, NJ, a, 0, a.B[1], a.B[0], cell, j, s_union[tid >> 3], stats, false, &changed);
+      target = round_job<WS, false>(i1, i2, ws, m, patch, forward, NI, NJ, a, 0, a.B[1], a.B[0], cell, j, s_union[tid >> 3], stats, false, &changed);
       if (changed && j == 0) chg = cell;
     }
     enqueue_targets(a, ctl, 1, target);
@@ -807,10 +826,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   __syncthreads();
   if (tid == 0) {
     unsigned flags = 0, ticket = 0;
-    if (n0) {   // this workgroup wrote records, maps or lists: released before the arrival
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // (what this workgroup wrote for the others — records, queue, lists — went out as write-through stores and every wave has waited for its own: no release)
     // (only a workgroup that had candidates itself looks at the queue: the others — nearly all of them at the finest scale — arrive one memory round trip earlier)
     if (n0 && __hip_atomic_load(&ctl->count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > stay_above) {
       const unsigned t = __hip_atomic_fetch_add(&ctl->reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // before the arrival: the last arriver reads the final count
@@ -831,8 +847,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   if (tid == 0) {
     unsigned ticket = s_val;
     unsigned long long g;
-    if (flags & 2u) {   // round 0 is complete everywhere
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (flags & 2u) {   // round 0 is complete everywhere (what the others wrote is read with L1-bypassing loads: no acquire)
       const unsigned n1 = __hip_atomic_load(&ctl->count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned R = min(__hip_atomic_load(&ctl->reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kMaxStay);
       unsigned N = R;
@@ -852,7 +867,6 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
       while (((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != 1ull && (g >> 32) != (unsigned long long)kGenFinal && ++spin < kSpinLimit)
         __builtin_amdgcn_s_sleep(1);
       if (spin >= kSpinLimit) { raise_barrier_timeout(a); s_giveup = 1; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       s_nreg = __hip_atomic_load(&ctl->nreg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     s_gen = g; s_val = ticket;
@@ -880,9 +894,9 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
       const unsigned job = batch * (unsigned)kJobsPerGroup + (unsigned)(tid >> 3);
       int target = -1, chg = -1;
       if (job < n) {
-        const int cell = (int)Qcur[job];
+        const int cell = (int)load_u32_sc1(Qcur + job);
         bool changed;
-        target = round_job<WS>(i1, i2, ws, m, patch, forward, NI, NJ, a, k, Bprev, Bcur, cell, j, s_union[tid >> 3], stats, true, &changed);
+        target = round_job<WS, false>(i1, i2, ws, m, patch, forward, NI, NJ, a, k, Bprev, Bcur, cell, j, s_union[tid >> 3], stats, true, &changed);
         if (changed && j == 0) chg = cell;
       }
       enqueue_targets(a, ctl, par ^ 1, target);
@@ -899,9 +913,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         g = nn;
         if (stats == 1) atomicAdd(&g_round_stats[0], 1u);
-      } else {   // the grid barrier of sdof_rounds_kernel over the N0 registered workgroups
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {   // the grid barrier of sdof_rounds_kernel over the N0 registered workgroups, without its fences (write-through stores, L1-bypassing loads)
         const unsigned arrived = __hip_atomic_fetch_add(&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == N0 - 1) {
           const unsigned nn = __hip_atomic_load(&ctl->count[par ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -920,7 +932,6 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
             __builtin_amdgcn_s_sleep(1);
           if (spin >= kSpinLimit) { g = 0; raise_barrier_timeout(a); s_giveup = 1; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       s_gen = g;
     }
@@ -939,13 +950,11 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
       unsigned spin = 0;
       while (((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned long long)kGenFinal && ++spin < kSpinLimit) __builtin_amdgcn_s_sleep(1);
       if (spin >= kSpinLimit) { raise_barrier_timeout(a); s_giveup = 1; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       fn = __hip_atomic_load(&ctl->flushn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (solo) {
       fn = __hip_atomic_load(&ctl->nchanged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (N0 > 1) {   // wake the parked workgroups: what this workgroup wrote alone is released first
+      if (N0 > 1) {   // wake the parked workgroups (every wave of this workgroup has waited for its write-through stores at the round's end)
         __hip_atomic_store(&ctl->flushn, fn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&ctl->gen, (unsigned long long)kGenFinal << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -956,10 +965,13 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   if (s_giveup) return;
   const unsigned fn = s_flushn;
   for (unsigned i = ticket * 256u + (unsigned)tid; i < fn; i += N0 * 256u) {
-    const uint32_t cell = a.chg[i];
-    Cell c = load_cell16(a.B[0] + cell);   // a changed cell is carried into the round after its change: both round buffers hold its final value
+    const uint32_t cell = load_u32_sc1(a.chg + i);
+    Cell c = load_cell_sc1(a.B[0] + cell);   // a changed cell is carried into the round after its change: both round buffers hold its final value
     c.mark &= 0xFF;
-    store_cell16(a.pre + cell, c); store_cell16(a.B[0] + cell, c); store_cell16(a.B[1] + cell, c);
+    store_cell16(a.pre + cell, c); store_cell16(a.B[0] + cell, c); store_cell16(a.B[1] + cell, c);   // (read by later launches only)
+    const int ci = (int)cell / NJ, cj = (int)cell - ci * NJ;
+    int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;   // the maps: written here only, one writer per cell
+    f[0] = c.f0; f[1] = c.f1; m.dist.row<int32_t>(ci)[cj] = c.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)c.mark;
     a.cflag[cell] = 0;
   }
   if (ticket != 0) {   // registered and done: ticket 0 may hand the control block back
