@@ -473,12 +473,44 @@ def main():
         else:
             run_cpu = lambda: orc.orc_box_filter(P(dst_h.desc), P(src_h.desc), 5, 5)
             kind, what = "port", "oracle/liboracle_omp.so (-O3 -fopenmp)"
+        # Threads: what this process may really use — its affinity mask, capped by the container's CPU quota (cgroup cpu.max).  The GPU boxes of this pool show 256
+        # CPUs behind a quota of 16: with one OpenMP thread per visible CPU the runtime's 256 spinning threads share 16 CPUs' worth of time and a 4K pass takes 96 ms
+        # instead of 5 (tools/cpu_ref_threads.py; rounds 1-3 quoted that figure, 1.3-1.5 Gpx/s).  `value` is the sustained rate at the quota's thread count; `burst`
+        # is the best of a few thread counts over 3 passes each — shorter than one quota period, i.e. what the same code does on that many unthrottled cores.
+        host = {"cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": None}
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                host["cgroup_cpu_quota"] = float(q) / float(per)
+        except (OSError, ValueError):
+            pass
+        avail = host["affinity"] if not host["cgroup_cpu_quota"] else max(1, min(host["affinity"], int(host["cgroup_cpu_quota"] + 0.5)))
+        gomp = None
+        try:
+            gomp = ctypes.CDLL("libgomp.so.1")   # the OpenMP runtime both CPU libraries are linked to
+            gomp.omp_set_num_threads(avail)
+        except (OSError, AttributeError):
+            avail = int(orc.orc_num_threads())
         run_cpu()  # warm-up (benchmarks/box_5x5_filter.cc:193-203 protocol: K timed iterations after one warm-up call)
         iters = 10
         t0 = time.perf_counter()
         for _ in range(iters):
             run_cpu()
         dt = (time.perf_counter() - t0) / iters
+        burst = None
+        if gomp is not None:
+            for th in sorted({avail, 32, 64, 128}):
+                if th > host["affinity"]:
+                    continue
+                gomp.omp_set_num_threads(th)
+                run_cpu()
+                tb = []
+                for _ in range(3):
+                    t0 = time.perf_counter(); run_cpu(); tb.append(time.perf_counter() - t0)
+                if burst is None or npx / min(tb) / 1e9 > burst["value"]:
+                    burst = {"value": npx / min(tb) / 1e9, "unit": "Gpixels/s", "threads": th, "sample": "best of 3 single passes (shorter than the CPU quota's period)"}
+                time.sleep(0.2)   # let the quota's period roll over
+            gomp.omp_set_num_threads(avail)
         import bench_pyrlk as _bp
         cpu_extra = _bp.cpu_baseline(orc)
         # BASELINE configs[0]: pixel_wise A = B + C on 1920x1080 image2d<int> through the CPU / OpenMP plumbing, the protocol of
@@ -494,8 +526,9 @@ def main():
         dta = (time.perf_counter() - t0) / 10
         cpu_extra["add_1080p_int_gpixels_per_s"] = 1080 * 1920 / dta / 1e9
         cpu_extra["add_1080p_sample"] = "BASELINE configs[0]: 10 calls after 1 warm-up (benchmarks/image_add.cc:77-88), " + ("the reference's pixel_wise, OpenMP" if refomp is not None else "oracle port, OpenMP")
-        cpu = {"value": npx / dt / 1e9, "unit": "Gpixels/s", "cores": os.cpu_count() if kind == "reference" else int(orc.orc_num_threads()), "kind": kind,
-               "sample": f"{iters} passes of the same 3840x2160 vuchar3 box5x5 after 1 warm-up, {what}", **cpu_extra}
+        cpu = {"value": npx / dt / 1e9, "unit": "Gpixels/s", "cores": avail, "kind": kind,
+               "sample": f"{iters} passes of the same 3840x2160 vuchar3 box5x5 after 1 warm-up on {avail} OpenMP threads (affinity and cgroup CPU quota of this process), {what}",
+               "host": host, "burst": burst, **cpu_extra}
 
     if rank == 0:
         out = {"metric": "Gpixels/s (4K box5x5 vuchar3)", "value": value, "unit": "Gpixels/s", "n_gpus": world, "steps": args.steps,
