@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from vpp_amd.synth import P, rand_image, HostImage, DeviceImage, u8_image, rects_image
-from test_gpu_sdof import flow_scene, run_both
+from test_gpu_sdof import flow_scene, run_both, SWEEP_IMPLS, set_sweep_impl
 from test_oracle_algos import run_detect
 from test_gpu_algos import gpu_detect
 from vpp_amd import capi, image as vi
@@ -35,12 +35,12 @@ for case in range(N):
     ws = int(rng.choice([5, 7, 9, 11])); nscales = int(rng.integers(1, 4)); min_scale = int(rng.integers(0, nscales)); prop = int(rng.integers(0, 4)); patch = int(rng.choice([3, 5, 7]))
     shape = (int(rng.integers(60, 200)), int(rng.integers(60, 260)))
     f1, f2, kps = flow_scene(*shape, seed=int(rng.integers(1 << 30)), spacing=int(rng.integers(3, 9)))
-    for impl in (0, 1):
-        lib.vpp_set_tuning(b"sdof.propagate", impl)
+    for impl in SWEEP_IMPLS:   # one launch per sweep, the same with every workgroup staying for the rounds, two launches per sweep, the one-workgroup wavefront
+        set_sweep_impl(lib, impl)
         got, want = run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch)
         ok = all(np.array_equal(g, w) for g, w in zip(got, want))
         print(f"sdof {shape} ws={ws} nscales={nscales} min={min_scale} prop={prop} patch={patch} impl={impl}: valid={int(want[2].sum())} {'ok' if ok else 'MISMATCH'}"); bad += not ok
-    lib.vpp_set_tuning(b"sdof.propagate", -1)
+    set_sweep_impl(lib, None)
     # box 5x5 on u8 x ch and int32, rgb->gray ingest
     ch = int(rng.integers(1, 5)); border = int(rng.integers(2, 5)); nr, nc = int(rng.integers(1, 200)), int(rng.integers(1, 1500))
     for dtype, c in ((vi.U8, ch), (vi.I32, 1)):
