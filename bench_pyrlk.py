@@ -256,7 +256,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     dt = (time.perf_counter() - t0) / it
     res["semi_dense_flow_4k"] = {"ms_per_frame_pair": dt * 1e3, "frame_pairs_per_s": world / dt, "keypoints": m,
                                  "note": "one frame pair per GPU (replicas); serial-order semantics, bit-exact vs the oracle",
-                                 "roofline": issue_roofline("sdof_descent_group_kernel<9, false>"), "roofline_rounds": issue_roofline("sdof_rounds_kernel<9>")}
+                                 "roofline": issue_roofline("sdof_descent_group_kernel<9, false>"), "roofline_sweeps": issue_roofline("sdof_sweep_kernel<9>")}
     # several independent frame pairs in flight on one GPU: each on its own stream (its own scratch: common.hpp Scratch is per stream); a pair is a
     # chain of ~25 short launches (pyramids, claim, descent, classify, propagation rounds), so independent pairs fill each other's launch gaps
     conc = {}
