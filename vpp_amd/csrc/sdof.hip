@@ -582,8 +582,13 @@ __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws,
   const int q0 = ci + dr, q1 = cj + dc;
   const bool in = q0 >= 0 && q1 >= 0 && q0 < NI && q1 < NJ;
   const bool earlier = forward ? j < 4 : j >= 4;   // raster / reverse raster visiting order
+  // Whether the neighbour is marked at all is read from its `pre` record (a sweep only ever turns a 2 into a 1, :179): the round buffers' records are written for
+  // marked cells only (descents, the end of a sweep) and never reset — an unmarked cell's entry there holds anything and is not looked at.
   Cell nb{0, 0, 0, 0};
-  if (in) nb = earlier ? load_cell_sc1(Bprev + (size_t)q0 * NJ + q1) : load_cell16(a.pre + (size_t)q0 * NJ + q1);
+  if (in) {
+    nb = load_cell16(a.pre + (size_t)q0 * NJ + q1);
+    if (earlier) { const Cell bq = load_cell_sc1(Bprev + (size_t)q0 * NJ + q1); if ((nb.mark & 0xFF) != 0) nb = bq; }
+  }
   const bool nbm = (nb.mark & 0xFF) != 0;
   // does any earlier neighbour hold a value that changed in round k - 1?  (round 0: everything is evaluated once)
   const unsigned long long grp = 0xFFull << (__lane_id() & ~7);
@@ -1118,7 +1123,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   auto DM = [&](int k, int s_) -> vpp_image_desc& { return DMs[(size_t)k * kMaxScales + s_]; };
   auto OW = [&](int k, int s_) -> vpp_image_desc& { return OWs[(size_t)k * kMaxScales + s_]; };
   RoundArrays ra{};   // the fixed-point rounds' queues and flags, sized for the finest scale; the cells' records per scale (rec_*)
-  Cell* rec[kMaxScales][3] = {};   // pre, B[0], B[1] of a scale: one block, zeroed by the reset launch when the sweeps are fused (Mirrors)
+  Cell* rec[kMaxScales][3] = {};   // pre, B[0], B[1] of a scale: one block; `pre` is zeroed by the reset launch when the sweeps are fused (Mirrors)
   size_t rec_off[kMaxScales] = {}, rec_bytes[kMaxScales] = {};
   size_t ra_flags_off = 0, ra_flags_bytes = 0;
   size_t mk_off[kMaxScales] = {}, mk_bytes[kMaxScales] = {}, ow_off[kMaxScales] = {}, ow_bytes[kMaxScales] = {};   // strip 0's mark / owner blocks
@@ -1218,9 +1223,9 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
         ra.units[q] = (uint32_t)((w ? ow_bytes[s_] : mk_bytes[s_]) / 16); ra.value[q] = w ? 0xFFFFFFFFu : 0u;
         ra.first_block[q] = blocks; blocks += (ra.units[q] + 255) / 256;
       }
-      if (fused_sweeps) {   // the cells' records: mark 0 wherever no descent writes
+      if (fused_sweeps) {   // the cells' `pre` records: mark 0 wherever no descent writes (the round buffers' records of unmarked cells are never looked at)
         const int q = ra.nseg++;
-        ra.p[q] = (uint4*)((uint8_t*)g_scratch.p + rec_off[s_]); ra.units[q] = (uint32_t)(rec_bytes[s_] / 16); ra.value[q] = 0u;
+        ra.p[q] = (uint4*)((uint8_t*)g_scratch.p + rec_off[s_]); ra.units[q] = (uint32_t)(rec_bytes[s_] / 3 / 16); ra.value[q] = 0u;
         ra.first_block[q] = blocks; blocks += (ra.units[q] + 255) / 256;
       }
     }
