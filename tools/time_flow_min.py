@@ -9,8 +9,8 @@ V = ctypes.c_void_p
 if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]
 lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
 out = []
-for shape in ((2160, 3840), (1080, 1920)):
-    s1, s2, sk = flow_scene(*shape, spacing=10)
+for shape, spacing in (((2160, 3840), 10), ((1080, 1920), 10), ((2160, 3840), 5)):   # the last one: every cell of the finest scale claimed, long queues in the sweeps
+    s1, s2, sk = flow_scene(*shape, spacing=spacing)
     e1, e2 = DeviceImage.from_host(u8_image(s1, border=3)), DeviceImage.from_host(u8_image(s2, border=3))
     m = len(sk); dk = torch.from_numpy(sk).cuda()
     gp = torch.zeros((m, 2), dtype=torch.int32, device="cuda"); gd = torch.zeros(m, dtype=torch.int32, device="cuda"); gv = torch.zeros(m, dtype=torch.uint8, device="cuda")
@@ -21,5 +21,5 @@ for shape in ((2160, 3840), (1080, 1920)):
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     capi.check(lib.vpp_sync(st))
     ts = sorted(ts[10:])
-    out.append(f"{shape[0]}p min {ts[0] * 1e3:.4f} median {ts[len(ts) // 2] * 1e3:.4f} ms (checksum {int(gp.sum())} {int(gd.sum())})")
+    out.append(f"{shape[0]}p/{spacing} min {ts[0] * 1e3:.4f} median {ts[len(ts) // 2] * 1e3:.4f} ms (checksum {int(gp.sum())} {int(gd.sum())})")
 print("  ".join(out), flush=True)
