@@ -166,8 +166,12 @@ def test_sdof_tall_narrow_map(lib, orc, ws):
     assert int(want[2].sum()) > 1000
 
 
-def test_concurrent_frame_pairs_on_streams_are_each_exact(lib, orc):
-    """Four independent frame pairs in flight on four streams (each call carves its scratch per stream): every result equals the serial oracle."""
+@pytest.mark.parametrize("impl", ["fused", "fused_grid", "two_launches"])
+def test_concurrent_frame_pairs_on_streams_are_each_exact(lib, orc, impl):
+    """Four independent frame pairs in flight on four streams (each call carves its scratch per stream): every result equals the serial oracle — also with the
+    sweeps' workgroups forced to stay for the rounds behind their grid barriers (four launches' worth of spinning workgroups share the chip: nobody may wait for a
+    workgroup that cannot be scheduled)."""
+    set_sweep_impl(lib, impl)
     scenes = [flow_scene(240 + 20 * j, 320 + 10 * j, seed=31 + j, spacing=5) for j in range(4)]
     streams = [torch.cuda.Stream() for _ in scenes]
     want, dev, outs = [], [], []
@@ -186,6 +190,9 @@ def test_concurrent_frame_pairs_on_streams_are_each_exact(lib, orc):
             capi.check(lib.vpp_semi_dense_optical_flow(P(d1.desc), P(d2.desc), ctypes.c_void_p(dk.data_ptr()), len(dk), 9, 3, 0, 2, 5, ctypes.c_void_p(o[0].data_ptr()),
                                                        ctypes.c_void_p(o[1].data_ptr()), ctypes.c_void_p(o[2].data_ptr()), ctypes.c_void_p(streams[j].cuda_stream)))
     torch.cuda.synchronize()
+    set_sweep_impl(lib, None)
+    for s_ in streams:
+        capi.check(lib.vpp_sync(ctypes.c_void_p(s_.cuda_stream)))   # (reports a device-side protocol that gave up)
     for (wp, wd, wv), o in zip(want, outs):
         np.testing.assert_array_equal(o[2].cpu().numpy(), wv)
         np.testing.assert_array_equal(o[0].cpu().numpy()[wv == 1], wp[wv == 1])
