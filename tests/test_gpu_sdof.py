@@ -76,6 +76,22 @@ def test_sdof_matches_oracle(lib, orc, shape, ws, nscales, min_scale, prop, patc
     assert moved > 0.5  # the scene really moves
 
 
+@pytest.mark.parametrize("group", [4, 8])
+@pytest.mark.parametrize("shape,ws,nscales", [((120, 160), 9, 3), ((121, 163), 7, 4), ((96, 128), 5, 2), ((270, 480), 11, 3)])
+def test_sdof_descent_with_4_and_8_lanes_per_keypoint(lib, orc, shape, ws, nscales, group):
+    """The per-keypoint descent with 8 lanes per keypoint (a candidate of a search step per lane) and with 4 (two candidates per lane, the form of the 4K scales:
+    half the waves): small frames, where many walks run along the frame's edge (the patch of a step partly outside the bordered area) and several keypoints share a cell."""
+    lib.vpp_set_tuning(b"sdof.descent_group", group)
+    f1, f2, kps = flow_scene(*shape, spacing=3)
+    rng = np.random.default_rng(5)
+    edge = np.stack([rng.integers(0, shape[0], 200), rng.choice([0, 1, 2, shape[1] - 3, shape[1] - 2, shape[1] - 1], 200)], 1).astype(np.int32)   # keypoints on the left / right edge
+    kps = np.concatenate([edge, kps])
+    got, want = run_both(lib, orc, f1, f2, kps, ws, nscales, 0, 2, 5)
+    lib.vpp_set_tuning(b"sdof.descent_group", -1)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+
+
 def test_sdof_1080p_frame(lib, orc):
     """One 1920x1080 frame pair with a keypoint every 10 px (video_extruder keypoint_spacing), defaults."""
     f1, f2, kps = flow_scene(1080, 1920, spacing=10)

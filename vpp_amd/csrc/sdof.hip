@@ -271,10 +271,12 @@ constexpr int kUnionRows = 13;   // (WS + 2) rows of 16 bytes for WS <= 11; 13 x
 // read and three v_alignbyte per row).  Same windows, same row-wise early-out rule, same first-of-minima selection: bit-identical.
 // A patch that is not entirely inside the bordered area (a walk along the frame's edge) takes the per-lane form `dist` for that step.
 // have_start: `start` = distance(p, pr) is known (the sweeps pass d2); otherwise it is taken from the first staged patch's centre.
-template <int WS, class DIST>
+// G: lanes per group, 8 (a candidate per lane) or 4 (lane j takes the candidates j and j + 4 of a step one after the other: half the waves for the same walks)
+template <int WS, int G = 8, class DIST>
 __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa, bool a_ok, const DImg& i2, int p0, int p1, int pr0, int pr1,
                                                         bool have_start, int start, int j, uint4* __restrict__ slot, DIST dist) {
   static_assert(WS >= 3 && WS + 2 <= kUnionRows, "the patch of a step is (WS + 2) rows of at most 16 bytes");
+  static_assert(G == 8 || G == 4, "8 or 4 lanes per group");
   constexpr int H = WS / 2, UR = WS + 2, ND = (WS + 3) / 4;
   constexpr uint32_t tail_mask = (WS % 4) ? ((1u << (8 * (WS % 4))) - 1u) : 0xFFFFFFFFu;
   constexpr unsigned kFirst = 0xd22406u, kEnd = 0x27fb5bu, kDr = 0x9224u, kDc = 0x16au;
@@ -288,11 +290,12 @@ __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa
     if (staged) {
       wave_lds_fence();   // the previous step's reads are done
       const uint8_t* src = i2.row<uint8_t>(ur0 + j) + uc0;
-      uint4 v0, v1;
-      __builtin_memcpy(&v0, src, 16);
-      if (j + 8 < UR) __builtin_memcpy(&v1, src + (ptrdiff_t)8 * i2.pitch, 16);
-      slot[j] = v0;
-      if (j + 8 < UR) slot[j + 8] = v1;
+      constexpr int NV = (UR + G - 1) / G;   // rows per lane: j, j + G, ...
+      uint4 v[NV];
+#pragma unroll
+      for (int q = 0; q < NV; q++) if (j + q * G < UR) __builtin_memcpy(&v[q], src + (ptrdiff_t)(q * G) * i2.pitch, 16);
+#pragma unroll
+      for (int q = 0; q < NV; q++) if (j + q * G < UR) slot[j + q * G] = v[q];
       wave_lds_fence();
     }
     // sad_distance of the keypoint's window against the window centred (dr, dc) from the step's centre, cut out of the staged patch
@@ -327,14 +330,20 @@ __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa
     }
     const unsigned first = (kFirst >> (3 * match_i)) & 7u, end = (kEnd >> (3 * match_i)) & 7u;
     const unsigned count = ((end - first - 1u) & 7u) + 1u;
-    const unsigned ci = (first + (unsigned)j) & 7u;
-    const int cdr = (int)((kDr >> (2 * ci)) & 3u) - 1, cdc = (int)((kDc >> (2 * ci)) & 3u) - 1;
-    const int n0 = pr0 + cdr, n1 = pr1 + cdc;
-    int d = INT_MAX;
-    if ((unsigned)j < count) d = staged ? (i2.has(n0, n1) ? sad_at(cdr, cdc, match_distance) : INT_MAX) : dist(n0, n1, match_distance);
-    unsigned long long key = ((unsigned long long)(unsigned)d << 3) | (unsigned)j;
+    unsigned long long key = ~0ull;
 #pragma unroll
-    for (int x = 1; x < 8; x <<= 1) {
+    for (int q = 0; q < 8 / G; q++) {   // this lane's candidates of the step, by position in the walk
+      const unsigned jq = (unsigned)j + (unsigned)(q * G);
+      const unsigned ci = (first + jq) & 7u;
+      const int cdr = (int)((kDr >> (2 * ci)) & 3u) - 1, cdc = (int)((kDc >> (2 * ci)) & 3u) - 1;
+      const int n0 = pr0 + cdr, n1 = pr1 + cdc;
+      int d = INT_MAX;
+      if (jq < count) d = staged ? (i2.has(n0, n1) ? sad_at(cdr, cdc, match_distance) : INT_MAX) : dist(n0, n1, match_distance);
+      const unsigned long long kq = ((unsigned long long)(unsigned)d << 3) | jq;
+      key = kq < key ? kq : key;
+    }
+#pragma unroll
+    for (int x = 1; x < G; x <<= 1) {
       const unsigned lo = __shfl_xor((unsigned)key, x), hi = __shfl_xor((unsigned)(key >> 32), x);
       const unsigned long long ok = ((unsigned long long)hi << 32) | lo;
       key = ok < key ? ok : key;
@@ -359,11 +368,14 @@ __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa
 // BYCELL: a group per flow-map cell instead of per keypoint — the same set of descents (a cell's owner is the keypoint that descends for it), launched
 // where the cells are fewer than the keypoints (coarse scales: several keypoints share a cell and all but the owner would leave at once, yet their
 // groups occupied 3/4 of every wave of the coarsest scale).
-template <int WS, bool BYCELL = false>
+// G = 4 lanes per keypoint (window sizes with a register window only): 16 keypoints per wave, each lane two candidates of a step — the 10 k waves of a 4K scale's
+// 82 k keypoints are two generations of resident waves at this kernel's 5 waves per SIMD, the 5 k waves of the 4-lane form are one.
+template <int WS, bool BYCELL = false, int G = 8>
 __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
                                                                 DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi, int clean_owner, Mirrors mir) {
-  __shared__ uint4 s_union[8][kUnionRows];   // per group: the (WS + 2)-row patch of the current search step
-  const int grp = blockIdx.x * 8 + (threadIdx.x >> 3), j = threadIdx.x & 7;
+  static_assert(G == 8 || (G == 4 && WS != 0), "4 lanes per keypoint: staged walks only");
+  __shared__ uint4 s_union[64 / G][kUnionRows];   // per group: the (WS + 2)-row patch of the current search step
+  const int grp = blockIdx.x * (64 / G) + (threadIdx.x / G), j = threadIdx.x & (G - 1);
   int i = grp;
   if constexpr (BYCELL) {
     if (grp >= owner.nr * owner.nc) return;
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
     } else return distance_fn<WS>(i1, i2, p0, p1, b0, b1, ws, th);
   };
   GdMatch g;
-  if constexpr (WS != 0) g = group_descent_staged<WS>(wa, a_ok, i2, p0, p1, pr0, pr1, false, INT_MAX, j, s_union[threadIdx.x >> 3], dist);
+  if constexpr (WS != 0) g = group_descent_staged<WS, G>(wa, a_ok, i2, p0, p1, pr0, pr1, false, INT_MAX, j, s_union[threadIdx.x / G], dist);
   else g = group_descent(dist, p0, p1, pr0, pr1, dist(pr0, pr1, INT_MAX), j);
   if (j != 0) return;
   int32_t* f = cur.flow.row<int32_t>(pf0) + 2 * pf1;
@@ -1278,7 +1290,21 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
         const long long cells = (long long)OW(k, scale).nrows * OW(k, scale).ncols;
         Mirrors mir{{nullptr, nullptr, nullptr}, 0};
         if (fused_sweeps) mir = Mirrors{{rec[scale][0], rec[scale][1], rec[scale][2]}, (P1[scale].ncols - 1) / patchsize + 1};
-        if (tuning("sdof.descent_lanes", 8) == 8 && cells * 2 <= n && tuning("sdof.descent_bycell", 1))
+        // 4 lanes per keypoint / cell instead of 8 where 8 would be more waves than the chip holds at once (6 144 at this kernel's 6 waves per SIMD): 4K, 82 k keypoints
+        // per scale 10 219 -> 5 110 waves, pair 0.208 -> 0.203 ms, with a keypoint every 5 px 0.481 -> 0.459 ms; below that 8 lanes keep the walks' steps shorter
+        // (1080p, 20 k keypoints: 0.164 against 0.167 ms with 4).  sdof.descent_group = 8 / 4 forces one.
+        const long long groups = (cells * 2 <= n && tuning("sdof.descent_bycell", 1)) ? cells : (long long)n;
+        const int want_g = tuning("sdof.descent_group", 0);
+        const bool four = WS != 0 && tuning("sdof.descent_lanes", 8) == 8 && (want_g == 4 || (want_g == 0 && groups > 6144 * 8));
+        if (four && cells * 2 <= n && tuning("sdof.descent_bycell", 1)) {
+          if constexpr (WS != 0)
+            sdof_descent_group_kernel<WS, true, 4><<<(unsigned)((cells + 15) / 16), 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
+                                                                                              maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0, mir);
+        } else if (four) {
+          if constexpr (WS != 0)
+            sdof_descent_group_kernel<WS, false, 4><<<(n + 15) / 16, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
+                                                                               maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0, mir);
+        } else if (tuning("sdof.descent_lanes", 8) == 8 && cells * 2 <= n && tuning("sdof.descent_bycell", 1))
           sdof_descent_group_kernel<WS, true><<<(unsigned)((cells + 7) / 8), 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
                                                                                          maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0, mir);
         else if (tuning("sdof.descent_lanes", 8) == 8)
