@@ -220,10 +220,18 @@ def main():
     # ---------------- box5x5 on 4K vuchar3 (headline) ----------------
     NR, NC = 2160, 3840
     npx = NR * NC
+    METRIC = "Gpixels/s (4K add+box5x5) and pyrLK tracks/s at 1/2/4/8 MI355X"   # BASELINE.json's metric; `value` = its box5x5 leg (configs[1]), the add leg = roofline.add4k, pyrLK = roofline.legs
     src_h = rand_image(NR, NC, vi.U8, 3, border=2, seed=3, align=16)
     FPS = 64                              # frames per step: one step = a batch of 64 frames filtered by ONE launch (vpp_box_filter_batch; kBoxBatchMax)
     nsets = max(FPS, args.sets // FPS * FPS)  # one step alone reads 64 x 25.0 MB = 1.6 GB and writes as much: no part of it survives in the 256 MiB Infinity Cache until the next step
+    # the frame sets are DISTINCT images (base ^ mask_k, as tests/test_gpu_core.py::test_box_filter_batch_4k_at_the_benchmarked_geometry builds them): a frame-index
+    # mix-up inside the batch kernel cannot pass the check below
+    masks = [(k * 37 + 1) & 255 for k in range(nsets)]
+    workload = ("box_nbh2d 5x5 mean on 3840x2160 vuchar3 (BASELINE configs[1]), border 2 mirror-filled, "
+                f"one step = a batch of {FPS} distinct frames in one launch, over {nsets} distinct frame sets ({nsets * 25} MB of sources + {nsets * 25} MB of results)")
     srcs = [DeviceImage.from_host(src_h, dev) for _ in range(nsets)]
+    for s, m in zip(srcs, masks):
+        s.store.bitwise_xor_(m)           # the whole allocation; the border is rewritten by vpp_fill_border just below
     dsts = [DeviceImage(NR, NC, vi.U8, 3, 0, 16, dev) for _ in range(nsets)]
     for s in srcs:
         capi.check(lib.vpp_fill_border(P(s.desc), 0, None, st))
@@ -239,19 +247,24 @@ def main():
         box_batch(darr[i % nb], sarr[i % nb], FPS, 5, 5, stream)
 
     # ---- self-check (benchmarks/box_5x5_filter2.cc:26-41 checks its result inline): what the TIMED launches left in HBM is compared, frame by frame and
-    # byte by byte, with the oracle's result for the same source (the oracle is the checker here, never the thing measured)
+    # byte by byte, with the oracle's result for THAT frame's source (the oracle is the checker here, never the thing measured)
     from oracle import binding as _orc_binding
     _chk = _orc_binding.load(omp=True)
-    _chk.orc_fill_border(P(src_h.desc), 0, None)
-    want_h = src_h.like(border=0)
-    assert _chk.orc_box_filter(P(want_h.desc), P(src_h.desc), 5, 5) == 0
-    want_d = DeviceImage.from_host(want_h, dev)
-    checked = {"how": "after the timed regions every result frame in HBM is compared byte for byte with the oracle's box5x5 of the same source (torch.equal on the device), "
-                      "the results are zeroed between the batch leg and the per-frame leg; add: every timed triple against the oracle's A = B + C"}
+    want_d = []
+    _h = src_h.like()
+    for m in masks:
+        _h.view()[...] = src_h.view() ^ np.uint8(m)
+        _chk.orc_fill_border(P(_h.desc), 0, None)
+        _w = _h.like(border=0)
+        assert _chk.orc_box_filter(P(_w.desc), P(_h.desc), 5, 5) == 0
+        want_d.append(DeviceImage.from_host(_w, dev))
+    _chk.orc_fill_border(P(src_h.desc), 0, None)   # src_h itself feeds the cpu_baseline leg
+    checked = {"how": f"after the timed regions each of the {nsets} result frames in HBM (distinct sources: base ^ mask_k) is compared byte for byte with the oracle's box5x5 of "
+                      "ITS source (torch.equal on the device), the results are zeroed between the batch leg and the per-frame leg; add: every timed triple (distinct operands) "
+                      "against the oracle's A = B + C"}
 
     def check_box(tag):
-        w = want_d.store[want_d.shift:want_d.shift + want_d.alloc_bytes]
-        bad = [k for k, d in enumerate(dsts) if not torch.equal(d.store[d.shift:d.shift + d.alloc_bytes], w)]
+        bad = [k for k, (d, w) in enumerate(zip(dsts, want_d)) if not torch.equal(d.store[d.shift:d.shift + d.alloc_bytes], w.store[w.shift:w.shift + w.alloc_bytes])]
         checked[tag] = not bad
         if bad:
             sys.stderr.write(f"[bench] SELF-CHECK FAILED ({tag}): frames {bad[:8]} differ from the oracle\n")
@@ -305,14 +318,17 @@ def main():
         roof["copy_error"] = f"{type(e).__name__}: {e}"
 
     def pmc_traffic(prefix):
-        """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json, tools/make_traffic_json.py:
-        FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate --pmc runs), keyed by kernel symbol: None when no committed profile
-        was taken on a kernel of this name (the number would be another kernel's)."""
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        """HBM bytes per launch from the committed rocprofv3 PMC passes of the CURRENT round only (profiles/<round>_traffic.json, tools/make_traffic_json.py:
+        FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate --pmc runs), keyed by kernel symbol: None when the current round's file has no kernel
+        of this name (an older round's entry would be another kernel's number)."""
+        try:
+            rnd = open(os.path.join(ROOT, "profiles", "CURRENT")).read().strip()
+            path = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
             for k, v in json.load(open(path)).items():
                 if k.startswith(prefix):
                     return v["hbm_bytes_per_launch"], os.path.basename(path)
+        except (OSError, ValueError):
+            pass
         return None, None
     roof["traffic"], roof["traffic_source"] = pmc_traffic("box_u8_wide_kernel<3, 5, 5, 6")
     if roof["traffic_source"]:
@@ -420,8 +436,15 @@ def main():
     nadd_sets = 16  # 16 x 66 MB of operands = 1.06 GB, all read by every step (a larger rotation only adds address-translation misses)
     A = [DeviceImage(NR, NC, vi.I32, 1, 0, 32, dev) for _ in range(nadd_sets)]
     b_h = rand_image(NR, NC, vi.I32, seed=2, lo=0, hi=2**30 - 1)
-    B = [DeviceImage.from_host(b_h, dev) for _ in range(nadd_sets)]
-    C = [DeviceImage.from_host(b_h, dev) for _ in range(nadd_sets)]
+    c_h = rand_image(NR, NC, vi.I32, seed=7, lo=0, hi=2**30 - 1)
+    # distinct operands per triple: B_k = b ^ k, C_k = c ^ 3k (both stay below 2^30: image_add.cc's rand() inputs may overflow, SURVEY a2 keeps them below)
+    B, C, a_want_d = [], [], []
+    for k in range(nadd_sets):
+        bk, ck = b_h.like(), c_h.like()
+        bk.view()[...] = b_h.view() ^ np.int32(k); ck.view()[...] = c_h.view() ^ np.int32(3 * k)
+        ak = bk.like()
+        assert _chk.orc_pixelwise_binary(0, P(ak.desc), P(bk.desc), P(ck.desc)) == 0
+        B.append(DeviceImage.from_host(bk, dev)); C.append(DeviceImage.from_host(ck, dev)); a_want_d.append(DeviceImage.from_host(ak, dev))
     ad, bd, cd = [x.desc for x in A], [x.desc for x in B], [x.desc for x in C]
     add = lib.vpp_pixelwise_binary
 
@@ -436,11 +459,7 @@ def main():
         add_batch(0, aarr[j], barr[j], carr[j], nadd, stream)   # one step = 16 triples, one launch
 
     awall, aev = timed(launch_add, args.steps, args.warmup, preheat_s=args.preheat, c_graph=True)
-    a_want = b_h.like()
-    assert _chk.orc_pixelwise_binary(0, P(a_want.desc), P(b_h.desc), P(b_h.desc)) == 0
-    a_want_d = DeviceImage.from_host(a_want, dev)
-    w = a_want_d.store[a_want_d.shift:a_want_d.shift + a_want_d.alloc_bytes]
-    checked["add4k"] = all(torch.equal(x.store[x.shift:x.shift + x.alloc_bytes], w) for x in A)
+    checked["add4k"] = all(torch.equal(x.store[x.shift:x.shift + x.alloc_bytes], w.store[w.shift:w.shift + w.alloc_bytes]) for x, w in zip(A, a_want_d))
     add_s = aev / args.steps
     add_sus = region_log[-1]["sample"]["us_per_launch"] * 1e-6
     add4k = {"gpixels_per_s": npx * nadd * world / (awall / args.steps) / 1e9, "frames_per_step": nadd, "avg_launch_us": add_s * 1e6,
@@ -531,17 +550,86 @@ def main():
                "host": host, "burst": burst, **cpu_extra}
 
     if rank == 0:
-        out = {"metric": "Gpixels/s (4K box5x5 vuchar3)", "value": value, "unit": "Gpixels/s", "n_gpus": world, "steps": args.steps,
+        ok = all(v for k, v in checked.items() if k != "how")
+        # ---- everything measured, in full: gpurun_out/bench_detail.json and one "[bench detail]" line on stderr (the driver keeps only the known keys of the LAST
+        # stdout line and an 8 KB tail, so the final line below is the compact headline: both of north_star's HBM targets inside `roofline`)
+        detail = {"metric": METRIC, "value": value, "unit": "Gpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+                  "config": {"workload": workload, "frames_per_step": FPS, "parallelism": f"replicas x{world}", "launch": box_mode["mode"], "events": box_mode["events"],
+                             "timed_regions": {"count": max(1, args.regions), "reported": "median by wall clock", "wall_ms": box_regions["wall_ms"], "event_ms": box_regions["event_ms"]},
+                             "preheat": {"untimed_ms": round(preheat["ms"], 1), "untimed_launches": preheat["launches"],
+                                         "note": "replays of the same graphs before the timed regions (clock ramp); not part of steps / value"}},
+                  "roofline": roof, "cpu_baseline": cpu, "add4k": add4k, "box5x5_one_launch_per_frame": per_frame, "checked": ok, "checks": checked}
+        detail.update(extras)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"bench_detail_n{world}.json"), "w") as f:
+                json.dump(detail, f)
+        except OSError as e:
+            sys.stderr.write(f"[bench] could not write gpurun_out/bench_detail_n{world}.json: {e}\n")
+        sys.stderr.write("[bench detail] " + json.dumps(detail) + "\n")
+        sys.stderr.flush()
+
+        def rnd(x, n=4):
+            return round(x, n) if isinstance(x, float) else x
+
+        def pick(d, *keys):
+            return {k: rnd(d[k]) for k in keys if isinstance(d, dict) and d.get(k) is not None}
+        ar = add4k["roofline"]
+        roof_c = pick(roof, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "frames_per_launch", "avg_launch_us",
+                      "frac_sustained", "copy_frac", "frac_of_copy", "traffic_source")
+        roof_c["how"] = "algorithmic bytes / mean duration of the K timed launches (HIP event-record nodes around them, on the launch stream)"
+        # north_star's second target: 4K int32 pixel_wise add (12 B/px), 16 distinct triples per launch
+        roof_c["add4k"] = {"kernel": ar["kernel"], "gpixels_per_s": rnd(add4k["gpixels_per_s"]), "avg_launch_us": rnd(add4k["avg_launch_us"]), "achieved": rnd(ar["achieved"]),
+                           "frac": rnd(ar["frac"]), "frac_sustained": rnd(ar["frac_sustained"]), "traffic": ar["traffic"], "triples_per_launch": nadd, "algorithmic_bytes_per_launch": 12 * npx * nadd}
+        # the reference's call form: one frame per call (benchmarks/box_5x5_filter2.cc:43-81), recorded on one stream
+        roof_c["per_frame_call"] = {"us_per_frame": rnd(per_frame["avg_launch_us_sustained"]), "frac": rnd(per_frame["frac_sustained"]),
+                                    "one_launch_per_call": per_frame["without_record_time_batching"]["one_stream_serial"],
+                                    "form": "vpp_box_filter per 4K frame, recorded: folded into 64-frame launches at record time; one_launch_per_call = the same with the folding off"}
+        legs = {}
+        px = extras.get("pyrlk") if isinstance(extras.get("pyrlk"), dict) else {}
+        if "tracks_per_s" in px:
+            legs["pyrlk_1080p_10k"] = {"tracks_per_s": round(px["tracks_per_s"]), "ms_per_frame": rnd(px["ms_per_frame"]), "keypoints_per_rank": px.get("keypoints_per_rank"),
+                                       "roofline": pick(px.get("roofline") or {}, "bound", "kernel", "frac", "source", "stale")}
+            if "weak_scaling" in px:
+                legs["pyrlk_1080p_10k"]["weak_scaling_tracks_per_s"] = round(px["weak_scaling"]["tracks_per_s"])
+            if "cpp_harness" in px:
+                legs["pyrlk_1080p_10k"]["cpp_harness"] = pick(px["cpp_harness"], "tracks_per_s", "ms_per_step", "error")
+        f9 = px.get("fast9_4k") or {}
+        if "raw" in f9:
+            legs["fast9_4k"] = {"raw_ms": rnd(f9["raw"]["ms"]), "blockwise10_ms": rnd(f9["blockwise10"]["ms"]), "keypoints": f9["raw"]["keypoints"], "corner_density": rnd(f9["raw"]["keypoints"] / npx),
+                                "roofline": pick(f9["raw"].get("roofline") or {}, "bound", "kernel", "frac", "source", "stale")}
+        fl = px.get("semi_dense_flow_4k") or {}
+        if "ms_per_frame_pair" in fl:
+            legs["semi_dense_flow_4k"] = {"ms_per_frame_pair": rnd(fl["ms_per_frame_pair"]), "roofline": pick(fl.get("roofline") or {}, "bound", "kernel", "frac", "source", "stale")}
+            ve = px.get("video_extruder_4k") or {}
+            if "ms_per_update_median_steady" in ve:
+                legs["semi_dense_flow_4k"]["tracker_ms_per_update_median_steady"] = rnd(ve["ms_per_update_median_steady"])
+        if "flow_strips_4k" in px:
+            legs["flow_strips_4k"] = pick(px["flow_strips_4k"], "ms_per_pair", "pairs_per_s", "ranks", "error")
+        ig = px.get("ingest_4k") or {}
+        if "us_per_frame" in ig:
+            legs["ingest_4k"] = {"us_per_frame": rnd(ig["us_per_frame"]), "frac": rnd(ig["roofline"]["frac"]), "one_launch_per_call": pick(ig["one_launch_per_call"], "us_per_frame", "frac")}
+        if "error" in px:
+            legs["error"] = px["error"]
+        roof_c["legs"] = legs
+        cpu_c = None
+        if cpu:
+            cpu_c = pick(cpu, "value", "unit", "cores", "kind", "pyrlk_tracks_per_s", "fast9_raw_gpixels_per_s", "semi_dense_flow_4k_frame_pairs_per_s", "add_1080p_int_gpixels_per_s")
+            cpu_c["sample"] = f"{10} passes of the same 4K vuchar3 box5x5 after 1 warm-up, {cpu['cores']} OpenMP threads (cgroup quota), " + ("the reference's headers (oracle/_ref, -O3 -fopenmp)" if cpu["kind"] == "reference" else "oracle port")
+        out = {"metric": METRIC, "value": value, "unit": "Gpixels/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
-               "config": {"workload": "box_nbh2d 5x5 mean on 3840x2160 vuchar3 (BASELINE configs[1]), border 2 mirror-filled, "
-                                      f"one step = a batch of {FPS} frames in one launch, over {nsets} distinct frame sets ({nsets * 25} MB of sources + {nsets * 25} MB of results)", "frames_per_step": FPS, "parallelism": f"replicas x{world}", "launch": box_mode["mode"], "events": box_mode["events"], "timed_regions": {"count": max(1, args.regions), "reported": "median by wall clock", "wall_ms": box_regions["wall_ms"], "event_ms": box_regions["event_ms"]},
-                          "preheat": {"untimed_ms": round(preheat["ms"], 1), "untimed_launches": preheat["launches"],
-                                      "note": "replays of the same graphs before the timed regions (clock ramp); not part of steps / value"}},
-               "roofline": roof, "cpu_baseline": cpu, "add4k": add4k, "box5x5_one_launch_per_frame": per_frame,
-               "checked": all(v for k, v in checked.items() if k != "how"), "checks": checked}
-        out.update(extras)
-        print(json.dumps(out))
+               "config": {"workload": workload, "frames_per_step": FPS, "parallelism": f"replicas x{world}", "launch": box_mode["mode"],
+                          "timed_regions": {"count": max(1, args.regions), "reported": "median by wall clock", "wall_ms": box_regions["wall_ms"]},
+                          "detail": f"gpurun_out/bench_detail_n{world}.json and the '[bench detail]' stderr line hold every leg in full"},
+               "roofline": roof_c, "cpu_baseline": cpu_c, "checked": ok}
+        line = json.dumps(out)
+        if len(line) > 4000:   # the headline line must survive the driver's 8 KB tail whole: drop the secondary legs first
+            sys.stderr.write(f"[bench] final line {len(line)} B > 4000: dropping roofline.legs\n")
+            roof_c["legs"] = {"dropped": "see the detail file"}
+            line = json.dumps(out)
+        print(line)
+        sys.stdout.flush()
     if multi:
         dist.destroy_process_group()
     if not all(v for k, v in checked.items() if k != "how"):

@@ -12,28 +12,38 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
+def profile_round():
+    """The round whose committed rocprofv3 summaries (profiles/<round>_*) describe the kernels of THIS tree: profiles/CURRENT, written by tools/publish_profiles.sh."""
+    try:
+        return open(os.path.join(ROOT, "profiles", "CURRENT")).read().strip()
+    except OSError:
+        return None
+
+
 def issue_roofline(prefix):
     """Per-leg roofline of a kernel that is bound by the SIMDs' instruction issue, not by HBM: the fraction of the chip's
-    VALU issue cycles the kernel uses while it runs, from the committed rocprofv3 PMC passes of the round (profiles/*_issue.json, written by
-    tools/make_issue_json.py from the passes of tools/profile_round.sh; the same numbers are readable in profiles/*_pmc.md):
+    VALU issue cycles the kernel uses while it runs, from the committed rocprofv3 PMC passes of the CURRENT round only (profiles/<round>_issue.json,
+    written by tools/make_issue_json.py from the passes of tools/profile_round.sh; the same numbers are readable in profiles/<round>_pmc.md):
       frac = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs  /  (SQ_BUSY_CYCLES / 32 counter instances)      [both per dispatch]
-    Keyed by kernel symbol: None when no committed pass was taken on a kernel of this name."""
-    import glob
+    A static quote from a committed profile, not measured in this run; keyed by kernel symbol prefix.  When the current round's file has no kernel of this
+    name (the symbol changed, or no pass was taken yet) the answer is {"stale": true} — never an older round's entry."""
     import json
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue.json")), reverse=True):
+    rnd = profile_round()
+    path = os.path.join(ROOT, "profiles", f"{rnd}_issue.json")
+    if rnd and os.path.exists(path):
         for k, v in json.load(open(path)).items():
             if k.startswith(prefix):
                 return {"bound": "valu_issue", "kernel": k, "frac": v["valu_issue_frac"], "lds_issue_frac": v.get("lds_issue_frac"),
                         "valu_wave_instructions": v.get("insts_valu"), "kernel_cycles": v.get("kernel_cycles"), "unit": "fraction of the SIMD issue cycles",
-                        "source": os.path.basename(path) + " (rocprofv3 --pmc SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / SQ_ACTIVE_INST_LDS / SQ_INSTS_VALU, separate passes; recompute from the *_pmc.md of the same round)"}
-    return None
+                        "source": os.path.basename(path) + " (committed rocprofv3 --pmc SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / SQ_ACTIVE_INST_LDS / SQ_INSTS_VALU passes, not measured in this run)"}
+    return {"bound": "valu_issue", "stale": True, "frac": None, "wanted": prefix, "note": f"profiles/{rnd}_issue.json has no kernel with this symbol prefix"}
 
 
 def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     import torch
     import torch.distributed as dist
     from vpp_amd import pyr
-    from vpp_amd.synth import P, u8_image, DeviceImage, texture, translate, rects_image
+    from vpp_amd.synth import P, u8_image, DeviceImage, texture, translate, rects_image, fast9_bench_frame
     from vpp_amd import capi, image as vi, multi_gpu as mg
 
     V = ctypes.c_void_p
@@ -66,7 +76,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
            "tracks_per_s": NK / (wall / steps), "ms_per_frame": wall / steps * 1e3, "keypoints_per_rank": n_local,
            "exchange": "rccl all_gather of 20-byte keypoint records" if world > 1 else "none (1 GPU)"}
 
-    res["roofline"] = issue_roofline("pyrlk_match_group_kernel<7, 16>")
+    res["roofline"] = issue_roofline("pyrlk_match_group_kernel<7, 16,")
 
     # keypoint-count sweep on one GPU (where tracks/s saturates; 1 250 = what one of 8 ranks sees of the 10 k keypoints of configs[3])
     if world == 1:
@@ -90,37 +100,6 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
         res["scaling_bound_8gpu"] = res["scaling_bound"].get("8", {}).get("tracks_per_s_upper_bound")
         res["scaling_bound"]["note"] = ("strong scaling of 10 000 keypoints over G ranks: G x this GPU's rate at 10 000 / G keypoints, before the all-gather; "
                                         "weak scaling (10 000 keypoints per rank) keeps the 1-GPU rate per rank")
-
-        # ---- opt-in fast sums (vpp_set_tuning("pyrlk.fast_sums", 1)): the per-iteration window sums as a DPP tree instead of the reference's left-to-right chain.
-        # NOT bit-identical; north_star's bound is 1e-4 relative on the displacements: measured here against the strict result (which the parity tests pin to the oracle)
-        def run_once(fast, kh, ws=WS, pyrs=(dp1, dg1, dp2), levels=L):
-            lib.vpp_set_tuning(b"pyrlk.fast_sums", 1 if fast else -1)
-            k = torch.from_numpy(kh.view(np.uint8).reshape(-1).copy()).to(dev)
-            match(pyrs[0], pyrs[1], pyrs[2], levels, V(k.data_ptr()), len(kh), ws, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None, st)
-            torch.cuda.synchronize()
-            lib.vpp_set_tuning(b"pyrlk.fast_sums", -1)
-            return k.cpu().numpy().view(pyr.KP_DTYPE)
-
-        def accuracy(strict, fastr):
-            alive = (strict["age"] > 0) & (fastr["age"] > 0)
-            dv = np.stack([fastr["vel_r"] - strict["vel_r"], fastr["vel_c"] - strict["vel_c"]], 1)[alive]
-            mag = np.maximum(np.hypot(strict["vel_r"], strict["vel_c"])[alive], 1e-12)
-            rel = np.hypot(dv[:, 0], dv[:, 1]) / mag
-            return {"keypoints": int(len(strict)), "alive_in_both": int(alive.sum()), "fate_differs": int(((strict["age"] > 0) != (fastr["age"] > 0)).sum()),
-                    "bit_identical_fraction": float(((dv[:, 0] == 0) & (dv[:, 1] == 0)).mean()) if alive.any() else None,
-                    "fraction_beyond_1e-4_relative": float((rel > 1e-4).mean()) if alive.any() else None,
-                    "max_abs_displacement_difference_px": float(np.abs(dv).max()) if alive.any() else None,
-                    "median_relative_difference": float(np.median(rel)) if alive.any() else None}
-        try:
-            strict_r, fast_r = run_once(False, kps_h), run_once(True, kps_h)
-            lib.vpp_set_tuning(b"pyrlk.fast_sums", 1)
-            fw, _ = timed(step_match, steps, warmup, graph=True)
-            lib.vpp_set_tuning(b"pyrlk.fast_sums", -1)
-            res["fast_sums"] = {"opt_in": "vpp_set_tuning(\"pyrlk.fast_sums\", 1); default off (strict = the reference's summation order, bit-identical)",
-                                "tracks_per_s": NK / (fw / steps), "ms_per_frame": fw / steps * 1e3, "vs_strict": accuracy(strict_r, fast_r)}
-        except Exception as e:  # noqa: BLE001
-            lib.vpp_set_tuning(b"pyrlk.fast_sums", -1)
-            res["fast_sums"] = {"error": f"{type(e).__name__}: {e}"}
 
         # ---- the reference's OWN pyrLK benchmark configuration (benchmarks/pyrlk_opencv_comparison.cc:47,64-65): 11 x 11 window, 4 scales, min_ev 1e-4, max_err 500,
         # 30 iterations, delta 0.01 — on the same 1080p scene and 10 000 keypoints; pyramids with a border of 8 (the benchmark's border(3) is narrower than the window's
@@ -146,14 +125,9 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
             e1.record(); torch.cuda.synchronize()
             lib.vpp_set_tuning(b"pyrlk.lpk", -1)
             a11["one_lane_per_keypoint_ms"] = e0.elapsed_time(e1) / 3
-            lib.vpp_set_tuning(b"pyrlk.fast_sums", 1)
-            w11f, _ = timed(step_11, 20, 3, graph=True)
-            lib.vpp_set_tuning(b"pyrlk.fast_sums", -1)
-            a11["fast_sums"] = {"tracks_per_s": NK / (w11f / 20), "ms_per_frame": w11f / 20 * 1e3,
-                                "vs_strict": accuracy(run_once(False, kps_h, WS11, (dq1, dh1, dq2), L4), run_once(True, kps_h, WS11, (dq1, dh1, dq2), L4))}
             res["authors_config_ws11_4scales"] = a11
         except Exception as e:  # noqa: BLE001
-            lib.vpp_set_tuning(b"pyrlk.lpk", -1); lib.vpp_set_tuning(b"pyrlk.fast_sums", -1)
+            lib.vpp_set_tuning(b"pyrlk.lpk", -1)
             res["authors_config_ws11_4scales"] = {"error": f"{type(e).__name__}: {e}"}
 
     if world > 1:
@@ -212,7 +186,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     res["tracks_per_s_incl_pyramids"] = NK / ((wall + pwall) / steps)
 
     # FAST-9 on 4K (replicas): raw and blockwise(10); each call ends with the host read of the keypoint count
-    im = u8_image(rects_image(2160, 3840, seed=4), border=3)
+    im = u8_image(fast9_bench_frame(), border=3)
     v = im.view(with_border=True)[..., 0]
     v[...] = np.pad(im.view()[..., 0], 3, mode="symmetric")
     dim = DeviceImage.from_host(im, dev)
@@ -256,7 +230,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     dt = (time.perf_counter() - t0) / it
     res["semi_dense_flow_4k"] = {"ms_per_frame_pair": dt * 1e3, "frame_pairs_per_s": world / dt, "keypoints": m,
                                  "note": "one frame pair per GPU (replicas); serial-order semantics, bit-exact vs the oracle",
-                                 "roofline": issue_roofline("sdof_descent_group_kernel<9, false>"), "roofline_sweeps": issue_roofline("sdof_sweep_kernel<9>")}
+                                 "roofline": issue_roofline("sdof_descent_group_kernel<9, false,"), "roofline_sweeps": issue_roofline("sdof_sweep_kernel<9>")}
     # several independent frame pairs in flight on one GPU: each on its own stream (its own scratch: common.hpp Scratch is per stream); a pair is a
     # chain of ~25 short launches (pyramids, claim, descent, classify, propagation rounds), so independent pairs fill each other's launch gaps
     conc = {}
@@ -339,7 +313,7 @@ def cpu_baseline(orc):
     """Oracle (OpenMP build) timed on the host: pyrlk_match on a 1000-keypoint sample of the same scene, and FAST-9 raw on one 4K frame."""
     from vpp_amd import pyr
     from oracle import pyramid as opyr
-    from vpp_amd.synth import P, u8_image, texture, translate, rects_image
+    from vpp_amd.synth import P, u8_image, texture, translate, rects_image, fast9_bench_frame
     from vpp_amd import image as vi
     V = ctypes.c_void_p
     NR, NC, L, B = 1080, 1920, 3, 3
@@ -356,7 +330,7 @@ def cpu_baseline(orc):
         orc.orc_pyrlk_match(vi.desc_array(hp1), vi.desc_array(hg), vi.desc_array(hp2), L, k.ctypes.data_as(V), len(k), 7, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None)
     dt = (time.perf_counter() - t0) / it
     out = {"pyrlk_tracks_per_s": len(kps) / dt, "pyrlk_sample": f"{it} passes over the same 10k keypoints (pyramids prebuilt)"}
-    im = u8_image(rects_image(2160, 3840, seed=4), border=3)
+    im = u8_image(fast9_bench_frame(), border=3)
     orc.orc_fill_border(P(im.desc), 0, None)
     rc = np.zeros((3000000, 2), np.int32); n = ctypes.c_int(0)
     t0 = time.perf_counter()

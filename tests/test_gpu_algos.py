@@ -450,24 +450,15 @@ def test_fast9_detect_async_and_graph_replay(lib, orc, mode):
     capi.check(lib.vpp_graph_destroy(graph))
 
 
-@pytest.mark.parametrize("ws,L", [(7, 3), (11, 4)])
-def test_pyrlk_fast_sums_are_opt_in_and_close(lib, orc, ws, L):
-    """vpp_set_tuning("pyrlk.fast_sums", 1): the per-iteration window sums of lk.hh:124-133 as a DPP tree instead of the reference's left-to-right chain — another
-    association of the same terms, so NOT bit-identical (the default stays strict: test_pyrlk_match_matches_oracle).  What is promised: the same keypoints survive
-    (but for a handful at the max_err / min_ev gates), and the displacements stay within a small fraction of a pixel of the reference's; bench.py reports the
-    fraction outside north_star's 1e-4 relative bound on configs[3]."""
+def test_no_tuning_knob_changes_the_lk_summation_order(lib, orc):
+    """Round 4 shipped vpp_set_tuning("pyrlk.fast_sums", 1) (the window sums of lk.hh:124-133 as a DPP tree): 26 % of configs[3]'s keypoints ended beyond
+    north_star's 1e-4 relative bound, so the variant was removed from the library (DESIGN.md / LABNOTES.md keep the measurement).  Setting the old knob must now change
+    nothing: the result stays bit-identical to the oracle's."""
     f1, f2, kps = lk_scene(240, 320, 500)
-    B = max(5, ws // 2 + 6)
-    strict, want, _, _ = _run_pyrlk_both(lib, orc, f1, f2, kps, L=L, ws=ws, B=B)
     lib.vpp_set_tuning(b"pyrlk.fast_sums", 1)
     try:
-        fast, _, _, _ = _run_pyrlk_both(lib, orc, f1, f2, kps, L=L, ws=ws, B=B)
+        got, want, _, _ = _run_pyrlk_both(lib, orc, f1, f2, kps, L=3, ws=7, B=9)
     finally:
         lib.vpp_set_tuning(b"pyrlk.fast_sums", -1)
-    both = (fast["age"] > 0) & (want["age"] > 0)
-    assert ((fast["age"] > 0) != (want["age"] > 0)).sum() <= 5 and both.sum() > 300
-    d = np.hypot(fast["vel_r"] - want["vel_r"], fast["vel_c"] - want["vel_c"])[both]
-    # Measured (bench.py, configs[3]): the median relative difference is ~6e-6, but ~25 % of the keypoints end more than 1e-4 relative away and a few
-    # anywhere at all — on these scenes the u8-quantised residual never falls below `delta`, every keypoint runs all 31 iterations around a small limit cycle,
-    # and where it stands after the last one depends on every rounding.  The strict order is therefore the only one that meets north_star's bound.
-    assert np.median(d) < 1e-3 and (d > 0.05).mean() < 0.15, (np.median(d), d.max(), (d > 0.05).mean())
+    for f in ("pos_r", "pos_c", "vel_r", "vel_c", "age"):
+        np.testing.assert_array_equal(got[f], want[f])

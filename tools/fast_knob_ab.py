@@ -4,12 +4,12 @@ import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from vpp_amd.synth import P, u8_image, DeviceImage, rects_image
+from vpp_amd.synth import P, u8_image, DeviceImage, rects_image, fast9_bench_frame
 from vpp_amd import capi
 V = ctypes.c_void_p
 knob = sys.argv[1].encode(); values = [int(x) for x in sys.argv[2:]]
 lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
-im = u8_image(rects_image(2160, 3840, seed=4), border=3)
+im = u8_image(fast9_bench_frame(), border=3)
 im.view(with_border=True)[..., 0] = np.pad(im.view()[..., 0], 3, mode="symmetric")
 d = DeviceImage.from_host(im)
 cap = 3000000

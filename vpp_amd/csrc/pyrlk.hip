@@ -236,20 +236,7 @@ template <int K> __device__ __forceinline__ float quad_bcast(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), K * 0x55, 0xf, 0xf, false));
 }
 
-// sum over the LPK lanes of a group, every lane ends up with the total: symmetric DPP exchanges inside a 16-lane row (quad_perm [1,0,3,2], [2,3,0,1],
-// row_half_mirror, row_mirror), cross-lane permutes above it.  A balanced TREE, not the reference's left-to-right chain: only used by the opt-in
-// fast-sums variant (vpp_set_tuning("pyrlk.fast_sums", 1)).
-template <int LPK> __device__ __forceinline__ float group_sum(float x) {
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
-  if constexpr (LPK >= 8) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
-  if constexpr (LPK >= 16) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
-  if constexpr (LPK >= 32) x += __shfl_xor(x, 16);
-  if constexpr (LPK >= 64) x += __shfl_xor(x, 32);
-  return x;
-}
-
-template <int WS, class GT, bool PYRLK, int LPK, bool FAST = false>
+template <int WS, class GT, bool PYRLK, int LPK>
 __device__ Match lk_match_group(  // WS <= 11 (OffsetMask: 128 offsets)
     float p0, float p1, float tr0, float tr1, const DImg& A_, const DImg& B_, const DImg& Ag_, float min_ev_th,
                                 int max_it, float delta, float* lds, int gl, float norm_T) {
@@ -354,13 +341,11 @@ __device__ Match lk_match_group(  // WS <= 11 (OffsetMask: 128 offsets)
   for (int k = 0; k <= max_it && (nk0 * nk0 + nk1 * nk1) >= norm_T; k++) {  // lk.hh:116 (norm >= delta, see norm_threshold)
     const bool b_safe = window_inside(B, v0, v1, hws);
     wave_lds_fence();  // the previous pass' reads are done before its terms are overwritten
-    bool fast_done = false; float bk0f = 0.f, bk1f = 0.f;
     if (b_safe && all_valid) {
       // The common case without a branch around the loads: all PPL rounds of taps are requested back to back and the lane pays
       // ONE memory round trip per iteration instead of PPL dependent ones (a lane past the window samples the window's last
       // offset and stages a term nobody reads).
       if constexpr (LPK >= 16) {
-        float fs0 = 0.f, fs1 = 0.f;
         // The coordinate part of linear_interpolate (imageNd.hpp:282-290) depends on the tap's row OR its column only: the WS row
         // records {a0, 1 - a0, byte offset of row x0} and the WS column records {a1, 1 - a1, x1} are evaluated once per group (one
         // record per lane, the same float operations on the same inputs as the per-tap form) and every tap reads its two records from
@@ -398,14 +383,7 @@ __device__ Match lk_match_group(  // WS <= 11 (OffsetMask: 128 offsets)
                           (a0 * a1) * (float)(uint8_t)(t1[q] >> 8);
           const uint8_t b = (uint8_t)v;
           const float dt = (float)as[q] - (float)b;  // lk.hh:130
-          if constexpr (FAST) { if (i < N) { fs0 += gs0[q] * dt; fs1 += gs1[q] * dt; } }
-          else { lds[i] = gs0[q] * dt; lds1[i] = gs1[q] * dt; }
-        }
-        if constexpr (FAST) {
-          // opt-in: the two sums of lk.hh:124-133 as a lane-local partial + a DPP tree over the group instead of the 49-term left-to-right chain that every
-          // lane repeats — no term staging, no LDS reads, ~8 dependent adds instead of 49.  Same terms, another association: NOT bit-identical.
-          bk0f = group_sum<LPK>(fs0); bk1f = group_sum<LPK>(fs1);
-          fast_done = true;
+          lds[i] = gs0[q] * dt; lds1[i] = gs1[q] * dt;
         }
       } else {
         // 7 taps per lane (LPK = 8): the wave's LDS pipe is as busy as its VALU with the 49 broadcast term reads alone, the record reads
@@ -436,8 +414,7 @@ __device__ Match lk_match_group(  // WS <= 11 (OffsetMask: 128 offsets)
       }
     }
     float bk0, bk1;
-    if (FAST && fast_done) { bk0 = bk0f; bk1 = bk1f; }   // (wave-uniform per group only: the other groups of the wave may take the staged path below)
-    else {
+    {
       wave_lds_fence();
       float acc = 0.f;   // even lanes: bk[0], odd lanes: bk[1]
       if (all_valid) {
@@ -500,7 +477,7 @@ __device__ Match lk_match_group(  // WS <= 11 (OffsetMask: 128 offsets)
 }
 
 // at least 4 waves per SIMD (<= 128 VGPRs): left alone, the 7-taps-per-lane instance took 138-163 registers for no gain in issue rate
-template <int WS, int LPK, bool FAST = false>
+template <int WS, int LPK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pyrlk_match_group_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, vpp_keypoint_f32* __restrict__ kps, int n,
                                                                float min_ev, float max_err, int max_it, float delta, int min_scale,
                                                                float* __restrict__ out_dist) {
@@ -517,7 +494,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void py
   for (int S = nlevels - 1; S >= min_scale; S--) {
     tr0 *= 2.f; tr1 *= 2.f;
     const float sc = (float)(1 << S);
-    const Match m = lk_match_group<WS, float, true, LPK, FAST>(kp.pos_r / sc, kp.pos_c / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, max_it, delta, lds, gl, norm_T);
+    const Match m = lk_match_group<WS, float, true, LPK>(kp.pos_r / sc, kp.pos_c / sc, tr0, tr1, P.l[S], Nx.l[S], G.l[S], min_ev, max_it, delta, lds, gl, norm_T);
     if (m.err < max_err) { tr0 = m.f0; tr1 = m.f1; }
     dist = m.err;
   }
@@ -636,18 +613,6 @@ int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, cons
   else if (winsize > 7 && lpk == 8) lpk = 16;  // benchmarks/pyrlk_opencv_comparison.cc:47); 8 lanes per keypoint would hold 11-16 taps per lane in registers: 16 at least
   // 9 x 9 / 11 x 11 hold 2.5 x the taps: 32 lanes per keypoint stay ahead of 16 at every count measured (11 x 11, 4 levels, us: 10 k 334 vs 345, 20 k 534 vs 648, 40 k 952 vs 1 011)
   if (winsize > 7 && winsize <= 11 && tuning("pyrlk.lpk", 0) == 0 && lpk == 16) lpk = 32;
-  // Opt-in (default off, results NOT bit-identical to the reference's summation order — north_star asks for 1e-4 relative on the displacements; bench.py reports
-  // the fraction of keypoints outside that bound): the per-iteration window sums as a DPP tree (lk_match_group, FAST).  7 x 7 and 11 x 11, 16+ lanes per keypoint.
-  if (tuning("pyrlk.fast_sums", 0) && lpk >= 16 && (winsize == 7 || winsize == 11)) {
-#define VPP_LK_FAST(W)                                                                                                                               \
-    if (lpk == 64) pyrlk_match_group_kernel<W, 64, true><<<n, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
-    else if (lpk == 32) pyrlk_match_group_kernel<W, 32, true><<<(n + 1) / 2, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
-    else pyrlk_match_group_kernel<W, 16, true><<<(n + 3) / 4, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist);
-    if (winsize == 7) { VPP_LK_FAST(7) } else { VPP_LK_FAST(11) }
-#undef VPP_LK_FAST
-    VPP_LAUNCH_CHECK();
-    return VPP_OK;
-  }
 #define VPP_LK_LAUNCH(W)                                                                                                                           \
   if (lpk == 64) pyrlk_match_group_kernel<W, 64><<<n, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \
   else if (lpk == 32) pyrlk_match_group_kernel<W, 32><<<(n + 1) / 2, 64, 0, st>>>(P, G, N, nlevels, kps, n, min_ev, max_err, max_iterations, convergence_delta, min_scale, out_dist); \

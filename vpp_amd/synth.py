@@ -61,6 +61,12 @@ def rects_image(nrows, ncols, seed=4, n=None):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def fast9_bench_frame(nrows=2160, ncols=3840, seed=4):
+    """The FAST-9 bench / profile frame (SURVEY 8d C3): rectangles + noise at a corner density of ~2.2 % at th = 20 (C3 asks for 1-3 %;
+    rects_image's default rectangle count gives 5.5 %, which rounds 1-4 benched)."""
+    return rects_image(nrows, ncols, seed=seed, n=(nrows * ncols) // 2400)
+
+
 def u8_image(arr, border=0, align=vi.DEFAULT_ALIGN):
     im = HostImage(arr.shape[0], arr.shape[1], vi.U8, 1, border, align)
     im.view()[..., 0] = arr
