@@ -573,7 +573,8 @@ def main():
             return round(x, n) if isinstance(x, float) else x
 
         def pick(d, *keys):
-            return {k: rnd(d[k]) for k in keys if isinstance(d, dict) and d.get(k) is not None}
+            # (source strings: the file name only — the detail file has the sentence)
+            return {k: (d[k].split(" (")[0] if k in ("source", "traffic_source") else rnd(d[k])) for k in keys if isinstance(d, dict) and d.get(k) is not None}
         ar = add4k["roofline"]
         roof_c = pick(roof, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "frames_per_launch", "avg_launch_us",
                       "frac_sustained", "copy_frac", "frac_of_copy", "traffic_source")

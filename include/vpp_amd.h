@@ -82,7 +82,15 @@ int vpp_stream_wait_event(void* stream, void* event);
  * `stream` between vpp_graph_begin and vpp_graph_end is recorded instead of run; vpp_graph_launch replays it with one
  * submission.  timed != 0 adds an event-record node in front of the first and behind the last recorded node (the reference
  * times with clock_gettime around host calls, benchmarks/get_time.hh:2-7): vpp_graph_elapsed_ms then returns the device-clock
- * duration of the last replay.  VPP_ERR_UNSUPPORTED when the runtime has no event-record nodes (retry with timed = 0). */
+ * duration of the last replay.  VPP_ERR_UNSUPPORTED when the runtime has no event-record nodes (retry with timed = 0).
+ * Scratch rule: entry points that need device scratch (FAST-9, the flow, the tracker, local maxima) keep one grow-only buffer per (host thread, stream), and a
+ * recorded call bakes that buffer's ADDRESS into the graph.  So (a) run a call once eagerly on the stream before recording it (a capture cannot allocate:
+ * VPP_ERR_UNSUPPORTED says so), and (b) a later eager call on that stream that needs MORE scratch — or a 17th stream, which evicts the least recently used
+ * buffer — frees the recorded buffer: every graph recorded before that is then refused by vpp_graph_launch (VPP_ERR_INVALID_ARG, "record it again") instead of
+ * replaying into freed memory.
+ * Device-side faults: a kernel whose in-kernel protocol gives up (the flow's grid barrier after ~4 s) raises a bit in ONE process-global sticky word; the first
+ * vpp_sync / vpp_event_synchronize on ANY stream afterwards returns VPP_ERR_HIP once and clears it — the fault is reported to whoever synchronises first, not to
+ * the stream that raised it, and never to a caller that only synchronises outside this ABI. */
 typedef struct vpp_graph vpp_graph;
 int vpp_graph_begin(void* stream);
 int vpp_graph_end(void* stream, int timed, vpp_graph** graph);

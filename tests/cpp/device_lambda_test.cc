@@ -9,6 +9,7 @@
 #include <random>
 
 #include <vpp/vpp.hh>
+#include "../../oracle/oracle.h"   // the CPU oracle: the checker of the 5 x 5 cases below (test infrastructure, never the product path)
 
 using namespace vpp;
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
@@ -172,19 +173,35 @@ static void test_block_wise_device() {
   }
 }
 
-// neighbourhoods out of the LDS tile (pixel_wise_device.hh: pixel_wise_tile_kernel): every border the tile path takes (1..4: windows up to 9 x 9 read the
-// whole halo) and one it leaves to the global taps (5), shapes cut by the tile edges (16 rows x 64 or 256 pixels), 1-, 3-, 4- and 8-byte pixels, the legacy
-// box_nbh2d spelling, and a sub-image view (unaligned: one pixel per lane) — all against the host engine of the same headers, bit for bit.
+// neighbourhoods out of the LDS tile (pixel_wise_device.hh: pixel_wise_tile_kernel, taken under `_nbh_read_only` only): every reach the tile covers (1..4: windows
+// up to 9 x 9 read the whole halo) with borders narrower, equal and wider than the reach, and one reach it must leave to the global taps (5: no option), shapes cut
+// by the tile edges (16 rows x 64 or 256 pixels), 1-, 3-, 4- and 8-byte pixels, the legacy box_nbh2d spelling, and a sub-image view (unaligned: one pixel per lane)
+// — each against the host engine of the same headers AND the global-tap device kernel, bit for bit.
 template <class V, class MK> static void tile_case(int nr, int nc, int border, MK make) {
-  image2d<V> S(nr, nc, _border = border), D(S.domain()), H(S.domain());
+  image2d<V> S(nr, nc, _border = border), D(S.domain()), G(S.domain()), H(S.domain());
   for (auto p : S.domain_with_border()) S(p) = make();
   auto k = [border] (V& out, auto nbh) {   // the extreme taps of the widest legal window + the centre: position-sensitive, so a misplaced tile shows
     out = nbh(0, 0);
     for (int i = -border; i <= border; i += border) for (int j = -border; j <= border; j += border) out = V(out + nbh(i, j) * (i * 3 + j + 7));
   };
-  pixel_wise(D, relative_access(S))(_device) | k;
+  pixel_wise(G, relative_access(S))(_device) | k;                                       // global taps
+  if (border <= 4) pixel_wise(D, relative_access(S))(_device, _nbh_read_only) | k;      // LDS tile (byte-sized pixel types; the others keep the global taps)
+  else pixel_wise(D, relative_access(S))(_device) | k;
   pixel_wise(H, relative_access(S))(_host) | k;
-  if (!same_pixels(D, H)) { std::fprintf(stderr, "tile_case %d x %d border %d, %d-byte pixels\n", nr, nc, border, (int)sizeof(V)); std::exit(1); }
+  if (!same_pixels(D, H) || !same_pixels(G, H)) { std::fprintf(stderr, "tile_case %d x %d border %d, %d-byte pixels\n", nr, nc, border, (int)sizeof(V)); std::exit(1); }
+}
+// a reach of 2 inside a border of 6 and inside a border of 1 (interior domain only): the halo, not the border, bounds what the tile serves
+template <class V, class MK> static void tile_reach_case(int nr, int nc, int border, MK make) {
+  image2d<V> S(nr, nc, _border = border), D(S.domain()), H(S.domain());
+  for (auto p : S.domain_with_border()) S(p) = make();
+  fill(D, V(make())); copy(D, H);
+  const int m = border >= 2 ? 0 : 2;   // border narrower than the reach: run on the interior where every tap stays inside the image
+  const box2d win(vint2(m, m), vint2(nr - 1 - m, nc - 1 - m));
+  auto k = [] (V& out, auto nbh) { out = V(nbh(-2, -2) + nbh(2, 2) * 3 + nbh(0, -2) * 5 + nbh(-2, 1) * 7); };
+  auto sd = D | win, sh = H | win, ss = S | win;
+  pixel_wise(sd, relative_access(ss))(_nbh_read_only) | k;
+  pixel_wise(sh, relative_access(ss))(_host) | k;
+  if (!same_pixels(D, H)) { std::fprintf(stderr, "tile_reach_case %d x %d border %d, %d-byte pixels\n", nr, nc, border, (int)sizeof(V)); std::exit(1); }
 }
 static void test_neighbourhood_tiles() {
   for (int border : {1, 2, 3, 4, 5})
@@ -193,6 +210,11 @@ static void test_neighbourhood_tiles() {
       tile_case<int>(shape.first, shape.second, border, [] { return int(rng() % 1000); });
       tile_case<vuchar3>(shape.first, shape.second, border, [] { return vuchar3(rng() & 255, rng() & 255, rng() & 255); });
       tile_case<vfloat2>(shape.first, shape.second, border, [] { return vfloat2(float(rng() % 512), float(rng() % 64)); });
+    }
+  for (int border : {1, 6})
+    for (auto shape : {std::pair<int, int>{48, 512}, {21, 131}}) {
+      tile_reach_case<unsigned char>(shape.first, shape.second, border, [] { return (unsigned char)(rng() & 255); });
+      tile_reach_case<vuchar3>(shape.first, shape.second, border, [] { return vuchar3(rng() & 255, rng() & 255, rng() & 255); });
     }
   {  // full 5 x 5 sums through the legacy accessor, and on a sub-image whose first column is odd (unaligned view)
     image2d<int> S(70, 300, _border = 2), D(S.domain()), H(S.domain());
@@ -209,6 +231,73 @@ static void test_neighbourhood_tiles() {
     pixel_wise(sd, relative_access(ss)) | k2;
     pixel_wise(sh, relative_access(ss))(_host) | k2;
     CHECK(same_pixels(D2, H2));
+  }
+}
+
+// A neighbourhood is a reference into the image (relative_accessor.hh:26-33 returns V&; distance_transforms.hh:33-59 writes `sn(0, 0) = ...`): a write through
+// it must reach the image on the device exactly as on the host — also for the byte-sized pixel types, which round 4 silently served from a read-only LDS copy
+// (advisor finding).  Only the pixel's own position is written, so the parallel evaluation is race-free.
+static void test_writes_through_a_neighbourhood() {
+  for (auto shape : {std::pair<int, int>{40, 300}, {17, 67}}) {
+    {
+      image2d<unsigned char> A(shape.first, shape.second, _border = 2), B(shape.first, shape.second, _border = 2);
+      for (auto p : A.domain_with_border()) A(p) = (unsigned char)(rng() & 255);
+      copy(A, B);
+      auto k = [] (auto n) { n(0, 0) = (unsigned char)(n(0, 0) / 2 + 3); };
+      pixel_wise(relative_access(A)) | k;
+      pixel_wise(relative_access(B))(_host) | k;
+      CHECK(same_pixels(A, B));
+      CHECK(A(1, 1) == B(1, 1));
+    }
+    {
+      image2d<vuchar3> A(shape.first, shape.second, _border = 2), B(shape.first, shape.second, _border = 2), O(shape.first, shape.second), O2(shape.first, shape.second);
+      for (auto p : A.domain_with_border()) A(p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
+      copy(A, B);
+      auto k = [] (vuchar3& o, auto n) { o = n(0, 0); n(0, 0) = vuchar3(o[2], o[0], o[1]); };
+      pixel_wise(O, relative_access(A)) | k;
+      pixel_wise(O2, relative_access(B))(_host) | k;
+      CHECK(same_pixels(A, B) && same_pixels(O, O2));
+    }
+    {
+      image2d<unsigned char> A(shape.first, shape.second, _border = 1), B(shape.first, shape.second, _border = 1);
+      for (auto p : A.domain_with_border()) A(p) = (unsigned char)(rng() & 255);
+      copy(A, B);
+      auto k = [] (auto n) { n(0, 0) = (unsigned char)(255 - n(0, 0)); };
+      pixel_wise(box_nbh2d<unsigned char, 3, 3>(A)) | k;
+      pixel_wise(box_nbh2d<unsigned char, 3, 3>(B))(_host) | k;
+      CHECK(same_pixels(A, B));
+    }
+  }
+}
+
+// The 5 x 5 mean lambdas (benchmarks/box_5x5_filter2.cc:71-81 on int, examples/box_filter.cc:23-32 on vuchar3) against the CPU ORACLE's box filter — not only
+// against this product's own host engine: global-tap kernel and LDS-tile kernel, 4K and a ragged small shape.
+template <class V> static vpp_image_desc host_desc_of(image2d<V>& im) { (void)im(0, 0); return im.host_desc(); }   // (the host accessor brings the host pixels up to date)
+static void test_box_lambdas_against_the_oracle() {
+  for (auto shape : {std::pair<int, int>{2160, 3840}, {37, 61}}) {
+    {
+      image2d<vuchar3> S(shape.first, shape.second, _border = 2), D(S.domain()), T(S.domain()), W(S.domain());
+      for (auto p : S.domain_with_border()) S(p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
+      auto k3 = [] (vuchar3& out, auto nbh) {
+        vint3 sum = vint3::Zero();
+        for (int i = -2; i <= 2; i++) for (int j = -2; j <= 2; j++) sum += nbh(i, j).template cast<int>();
+        out = (sum / 25).template cast<unsigned char>();
+      };
+      pixel_wise(D, relative_access(S)) | k3;                       // global taps
+      pixel_wise(T, relative_access(S))(_nbh_read_only) | k3;       // LDS tile
+      vpp_image_desc ds = host_desc_of(S), dw = host_desc_of(W);
+      CHECK(orc_box_filter(&dw, &ds, 5, 5) == 0);
+      CHECK(same_pixels(D, W) && same_pixels(T, W));
+    }
+    {
+      image2d<int> S(shape.first, shape.second, _border = 2), D(S.domain()), T(S.domain()), W(S.domain());
+      for (auto p : S.domain_with_border()) S(p) = int(rng() % 1000);
+      vpp_pixel_wise(D, S);                                         // the reference's benchmark body, verbatim (global taps)
+      pixel_wise(T, box_nbh2d<int, 5, 5>(S))(_nbh_read_only) | [] (int& out, auto nbh) { int s = 0; nbh.for_all([&s] (int v) { s += v; }); out = s / 25; };
+      vpp_image_desc ds = host_desc_of(S), dw = host_desc_of(W);
+      CHECK(orc_box_filter(&dw, &ds, 5, 5) == 0);
+      CHECK(same_pixels(D, W) && same_pixels(T, W));
+    }
   }
 }
 
@@ -268,7 +357,11 @@ static void time_4k() {
     for (int k = 0; k < K; k++) pixel_wise(T, relative_access(S)) | ops::box_mean<5, 5>();
     vpp_sync(nullptr);
     const double btag = (seconds() - t0) / K;
-    std::printf("4K vuchar3 box 5x5, back-to-back calls (at most 2 queued): lambda %.2f us, ops::box_mean<5,5> %.2f us (ratio %.2f)\n", blam * 1e6, btag * 1e6, blam / btag);
+    t0 = seconds();
+    for (int k = 0; k < K; k++) pixel_wise(D, relative_access(S))(_nbh_read_only) | k3;
+    vpp_sync(nullptr);
+    const double bro = (seconds() - t0) / K;
+    std::printf("4K vuchar3 box 5x5, back-to-back calls (at most 2 queued): lambda %.2f us, lambda with _nbh_read_only (LDS tile) %.2f us, ops::box_mean<5,5> %.2f us (ratio %.2f)\n", blam * 1e6, bro * 1e6, btag * 1e6, blam / btag);
   }
   // block_wise on the device: 16 x 16 block sums (one wave per block) and 4 x 4 (one lane per block)
   for (int bs : {16, 4}) {
@@ -293,6 +386,8 @@ int main(int argc, char** argv) {
   test_device_equals_host();
   test_block_wise_device();
   test_neighbourhood_tiles();
+  test_writes_through_a_neighbourhood();
+  test_box_lambdas_against_the_oracle();
   if (argc > 1 && !std::strcmp(argv[1], "time")) time_4k();
   std::printf("device_lambda_test ok\n");
   return 0;

@@ -66,8 +66,8 @@ def single_source_program(src, name):
     """The user's translation unit compiled by hipcc: -DVPP_AMD_DEVICE -DVPP_AMD_HIPCC turns opaque pixel_wise lambdas into gfx950 kernels."""
     exe, path = os.path.join(OUT, name), os.path.join(CPP, src)
     cmd = ["hipcc", "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-result", "-Wno-unused-command-line-argument", "-DVPP_AMD_DEVICE", "-DVPP_AMD_HIPCC",
-           "-I" + INC, "-I" + os.path.join(ROOT, "include"), path, "-o", exe] + _device_link()
-    return _run(cmd, exe, _deps(path, True), "hipcc")
+           "-I" + INC, "-I" + os.path.join(ROOT, "include"), path, "-o", exe, "-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")] + _device_link()
+    return _run(cmd, exe, _deps(path, True) + [p for p in [os.path.join(ROOT, "oracle", "liboracle.so")] if os.path.exists(p)], "hipcc")
 
 
 def video_extruder_parity():

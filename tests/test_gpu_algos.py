@@ -450,6 +450,34 @@ def test_fast9_detect_async_and_graph_replay(lib, orc, mode):
     capi.check(lib.vpp_graph_destroy(graph))
 
 
+def test_graph_is_refused_after_its_scratch_buffer_was_reallocated(lib, orc):
+    """A recorded call bakes its stream's scratch ADDRESS into the graph (include/vpp_amd.h, "Scratch rule").  A later eager call on that stream that needs a
+    larger buffer frees it: the old graph must be refused readably (VPP_ERR_INVALID_ARG), not replayed into freed memory (round-4 advisor finding); a graph
+    recorded afterwards runs, and equals the synchronous call."""
+    small = DeviceImage.from_host(u8_image(rects_image(120, 160, seed=3), border=3))
+    big = DeviceImage.from_host(u8_image(rects_image(1080, 1920, seed=5), border=3))
+    cap = 400000
+    rc = torch.zeros((cap, 2), dtype=torch.int32, device="cuda"); sc = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream(); sp = ctypes.c_void_p(st.cuda_stream)   # a fresh stream: a fresh scratch slot, sized by the first call
+    call = lambda d: capi.check(lib.vpp_fast9_detect_async(P(d.desc), 20, None, 0, 10, 0, ctypes.c_void_p(rc.data_ptr()), ctypes.c_void_p(sc.data_ptr()), cap,
+                                                           ctypes.c_void_p(cnt.data_ptr()), sp))
+    call(small); capi.check(lib.vpp_sync(sp))
+    g1 = ctypes.c_void_p()
+    capi.check(lib.vpp_graph_begin(sp)); call(small); capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(g1)))
+    capi.check(lib.vpp_graph_launch(g1, sp)); capi.check(lib.vpp_sync(sp))          # fine while the buffer lives
+    call(big); capi.check(lib.vpp_sync(sp))                                          # needs more scratch: the recorded buffer is freed
+    assert lib.vpp_graph_launch(g1, sp) == capi.ERR_INVALID_ARG and b"record it again" in lib.vpp_last_error()
+    g2 = ctypes.c_void_p()
+    capi.check(lib.vpp_graph_begin(sp)); call(small); capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(g2)))
+    capi.check(lib.vpp_graph_launch(g2, sp)); capi.check(lib.vpp_sync(sp))
+    n = int(cnt.item())
+    want_rc, want_sc = gpu_detect(lib, small, 20, mode=0, bs=10)
+    assert n == len(want_rc) and n > 20
+    np.testing.assert_array_equal(rc[:n].cpu().numpy(), want_rc)
+    capi.check(lib.vpp_graph_destroy(g1)); capi.check(lib.vpp_graph_destroy(g2))
+
+
 def test_no_tuning_knob_changes_the_lk_summation_order(lib, orc):
     """Round 4 shipped vpp_set_tuning("pyrlk.fast_sums", 1) (the window sums of lk.hh:124-133 as a DPP tree): 26 % of configs[3]'s keypoints ended beyond
     north_star's 1e-4 relative bound, so the variant was removed from the library (DESIGN.md / LABNOTES.md keep the measurement).  Setting the old knob must now change

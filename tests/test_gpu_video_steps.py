@@ -68,6 +68,14 @@ def test_rgb_to_graylevel_rejects_bad_arguments(lib):
     assert lib.vpp_rgb_to_graylevel(P(c.desc), P(a.desc), 0, None) != 0            # domain mismatch
     d = DeviceImage(2, 2, vi.U8, 1, 3)
     assert lib.vpp_rgb_to_graylevel(P(d.desc), P(DeviceImage(2, 2, vi.U8, 3).desc), 1, None) != 0  # mirror border > image
+    # the batch entry point answers as the n calls would: a frame k > 0 of another element type is not folded into frame 0's launch (round-4 advisor finding)
+    srcs = [DeviceImage(8, 16, vi.U8, 3) for _ in range(3)]
+    dsts = [DeviceImage(8, 16, vi.U8, 1), DeviceImage(8, 16, vi.U8, 1), DeviceImage(8, 8, vi.U16, 1)]   # same pitch and extent, u16 pixels
+    single = lib.vpp_rgb_to_graylevel(P(dsts[2].desc), P(srcs[2].desc), 0, None)
+    assert single != 0
+    assert lib.vpp_rgb_to_graylevel_batch(vi.desc_array(dsts), vi.desc_array(srcs), 3, 0, None) == single
+    inpl = [DeviceImage(8, 16, vi.U8, 3) for _ in range(2)]
+    assert lib.vpp_rgb_to_graylevel_batch(vi.desc_array(inpl), vi.desc_array(inpl), 2, 0, None) != 0   # in place, frame 0 included
 
 
 @pytest.mark.parametrize("shape,border,spacing,n", [((60, 80), 10, 10, 4), ((2160, 3840), 10, 10, 80000), ((50, 50), 3, 5, 40), ((20, 20), 10, 10, 0)])

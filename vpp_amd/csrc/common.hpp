@@ -150,6 +150,11 @@ class IndependentCall {
 // taken before the bump stops being believed.
 unsigned notes_epoch();
 void invalidate_scratch_notes();
+// Launch graphs hold the ADDRESS of the scratch buffer their calls were recorded on.  Whenever such a buffer (Slot::recorded) is freed — grown by a later, larger
+// eager call, or evicted — this generation is bumped; a vpp_graph remembers the generation it was recorded under and vpp_graph_launch refuses a stale one
+// (VPP_ERR_INVALID_ARG, "re-record") instead of replaying into freed memory.  Conservative: graphs that never touched that buffer are refused as well.
+unsigned recorded_scratch_generation();
+void recorded_scratch_freed();
 
 struct Scratch {
   static constexpr int kSlots = 16;   // one per (device, stream) that has called in: 8 was the ceiling of the frame-pairs-in-flight case (the 9th stream evicted — and synchronised — every call)
@@ -195,11 +200,11 @@ struct Scratch {
     }
     s->used = ++tick;
     if (bytes > s->cap) {
-      if (s->p) { VPP_HIP_TRY(hipStreamSynchronize(st)); VPP_HIP_TRY(hipFree(s->p)); s->p = nullptr; s->cap = 0; }
+      if (s->p) { VPP_HIP_TRY(hipStreamSynchronize(st)); if (s->recorded) recorded_scratch_freed(); VPP_HIP_TRY(hipFree(s->p)); s->p = nullptr; s->cap = 0; }
       VPP_HIP_TRY(hipMalloc(&s->p, bytes));
       s->cap = bytes;
       for (unsigned long long& u : s->user) u = 0;
-      s->recorded = false;   // graphs recorded on the old buffer are invalid from here on (they hold its address): documented in include/vpp_amd.h
+      s->recorded = false;   // graphs recorded on the old buffer are invalid from here on (they hold its address): vpp_graph_launch refuses them (include/vpp_amd.h)
     }
     s->capturing = capturing;
     if (capturing) { s->recorded = true; for (unsigned long long& u : s->user) u = 0; }
@@ -212,6 +217,7 @@ struct Scratch {
     VPP_HIP_TRY(hipGetDevice(&cur));
     if (cur != c.dev) VPP_HIP_TRY(hipSetDevice(c.dev));
     (void)hipDeviceSynchronize();
+    if (c.recorded) recorded_scratch_freed();
     const hipError_t e = hipFree(c.p);
     if (cur != c.dev) VPP_HIP_TRY(hipSetDevice(cur));
     c = Slot();
@@ -224,8 +230,12 @@ struct Scratch {
 // Sticky device-side error word (runtime.hip): one 32-bit word in pinned, device-visible host memory that kernels raise bits of when a device-side
 // protocol gives up (a grid barrier's poll limit); vpp_sync and the tracker's count read-back check it after the stream has drained and return
 // VPP_ERR_HIP once (the word is cleared by the report).  nullptr when the allocation failed (the kernels then skip the store).
+// The word is PROCESS-GLOBAL: whichever stream's synchronisation through this ABI comes first reports (and clears) a fault raised by any stream's kernels
+// (include/vpp_amd.h says so).  A caller that synchronises outside the ABI never has it reported; the flow entry points therefore also peek at it before they
+// queue anything (peek_device_error: no clearing) and stop trusting their scratch notes while a bit is up.
 unsigned* device_error_word();
 int check_device_error(const char* where);   // VPP_OK, or VPP_ERR_HIP + vpp_last_error() when a bit is up
+unsigned peek_device_error();                // the bits that are up, left as they are (0 when the word was never allocated)
 enum { kDevErrSweepBarrier = 1u };
 
 // blockIdx remap so that consecutive logical blocks share an XCD (hardware places block b on XCD b % 8;

@@ -42,6 +42,13 @@ int check_device_error(const char* where) {
             (bits & kDevErrSweepBarrier) ? " grid barrier of the semi-dense flow's propagation rounds" : "");
   return VPP_ERR_HIP;
 }
+unsigned peek_device_error() {
+  unsigned* w = g_deverr;
+  return w ? __atomic_load_n(w, __ATOMIC_ACQUIRE) : 0u;
+}
+static std::atomic<unsigned> g_recorded_scratch_gen{1};
+unsigned recorded_scratch_generation() { return g_recorded_scratch_gen.load(std::memory_order_acquire); }
+void recorded_scratch_freed() { g_recorded_scratch_gen.fetch_add(1, std::memory_order_acq_rel); }
 static std::atomic<unsigned> g_notes_epoch{1};
 unsigned notes_epoch() { return g_notes_epoch.load(std::memory_order_relaxed); }
 void invalidate_scratch_notes() { g_notes_epoch.fetch_add(1, std::memory_order_relaxed); }
@@ -423,7 +430,7 @@ int vpp_stream_wait_event(void* stream, void* event) {
 // frame loop (or K benchmark launches) can be recorded once and replayed with one submission.  With `timed`, the graph gets an
 // event-record node in front of its root nodes and one behind its leaves: the pair brackets the recorded kernels on the
 // device's own clock at every replay, excluding the host's submission latency.
-struct vpp_graph { hipGraph_t g = nullptr; hipGraphExec_t exec = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; bool timed = false; };
+struct vpp_graph { hipGraph_t g = nullptr; hipGraphExec_t exec = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; bool timed = false; unsigned scratch_gen = 0; };
 int vpp_graph_begin(void* stream) {
   VPP_HIP_TRY(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
   return VPP_OK;
@@ -431,6 +438,7 @@ int vpp_graph_begin(void* stream) {
 int vpp_graph_end(void* stream, int timed, vpp_graph** out) {
   VPP_REQUIRE(out, VPP_ERR_INVALID_ARG, "vpp_graph_end: null");
   vpp_graph* gr = new vpp_graph();
+  gr->scratch_gen = recorded_scratch_generation();   // (a capture cannot grow or evict a scratch buffer — Scratch::ensure refuses — so this is the generation of everything recorded)
   hipError_t e = hipStreamEndCapture(as_stream(stream), &gr->g);
   if (e != hipSuccess || !gr->g) { delete gr; set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return VPP_ERR_HIP; }
   if (timed) {
@@ -483,6 +491,9 @@ int vpp_debug_graph_kernel_nodes(vpp_graph* gr, int* count) {
 }
 int vpp_graph_launch(vpp_graph* gr, void* stream) {
   VPP_REQUIRE(gr && gr->exec, VPP_ERR_INVALID_ARG, "vpp_graph_launch: null");
+  VPP_REQUIRE(gr->scratch_gen == recorded_scratch_generation(), VPP_ERR_INVALID_ARG,
+              "vpp_graph_launch: a scratch buffer that launch graphs were recorded on has been reallocated since this graph was recorded (a later eager call needed a larger "
+              "one, or more than 16 streams were in use): the graph may hold a freed address - record it again");
   VPP_HIP_TRY(hipGraphLaunch(gr->exec, as_stream(stream)));
   return VPP_OK;
 }

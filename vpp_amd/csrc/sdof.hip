@@ -847,6 +847,10 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
     // (only a workgroup that had candidates itself looks at the queue: the others — nearly all of them at the finest scale — arrive one memory round trip earlier)
     if (n0 && __hip_atomic_load(&ctl->count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > stay_above) {
       const unsigned t = __hip_atomic_fetch_add(&ctl->reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // before the arrival: the last arriver reads the final count
+      // The registration must be PERFORMED before this workgroup's arrival below is: the two atomics go to different cache lines (different channels), and nothing
+      // else orders them — an arrival that overtook the registration would let the last arriver read a short `reg` and publish a wrong nreg.  A returning atomic
+      // has been performed when its value is back: wait for it (stayers only; the asm form, because the compiler drops waits it believes redundant).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (t < kMaxStay) { ticket = t; flags |= 1u; }
     }
     // Two-level arrival: returning atomics on ONE word retire at ~11 ns each (1 300 workgroups at the finest 4K scale: 14 us, measured 30 us per empty sweep); the
@@ -1171,6 +1175,9 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
     }
     if (!pass) { int rc = g_scratch.ensure(cv.off, st); if (rc != VPP_OK) return rc; }
   }
+  // a device-side fault nobody has collected yet (a caller that synchronises outside this ABI never does): whatever the faulting kernel left in ANY scratch
+  // region is unknown — stop believing the notes (the bits stay up for the next vpp_sync to report)
+  if (peek_device_error()) invalidate_scratch_notes();
   if (nstrips > 1) { int rc = g_strips.ensure(nstrips - 1); if (rc != VPP_OK) return rc; }
   // single strip: the mark and owner maps of all scales are reset here in one launch (nothing writes a scale's maps before its own phase)
   const bool reset_up_front = nstrips == 1 && 3 * (nscales - min_scale) + 1 <= kResetSegs && tuning("sdof.reset_up_front", 1);

@@ -182,7 +182,7 @@ int gray_launch(const GrayGeom& g0, const GrayBatch& fr, int n, hipStream_t st) 
   return VPP_OK;
 }
 inline bool same_gray_geometry(const vpp_image_desc& a, const vpp_image_desc& b) {
-  return a.nrows == b.nrows && a.ncols == b.ncols && a.pitch == b.pitch && a.border == b.border && a.channels == b.channels && (((uintptr_t)a.first_pixel ^ (uintptr_t)b.first_pixel) & 15) == 0;
+  return a.nrows == b.nrows && a.ncols == b.ncols && a.pitch == b.pitch && a.border == b.border && a.dtype == b.dtype && a.channels == b.channels && (((uintptr_t)a.first_pixel ^ (uintptr_t)b.first_pixel) & 15) == 0;
 }
 // record-time batching of per-frame calls (the mechanism of box.hip: coalesce_frame): a recorded frame loop's ingests fold into one batched node
 struct GrayCoalesce {
@@ -244,7 +244,7 @@ extern "C" int vpp_rgb_to_graylevel_batch(const vpp_image_desc* dst, const vpp_i
     GrayGeom g;
     int rc = gray_geometry(&dst[0], &src[0], mirror, &g);
     if (rc != VPP_OK) return rc;
-    for (int k = 1; k < n; k++) VPP_REQUIRE(dst[k].first_pixel != src[k].first_pixel, VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel_batch: in-place not supported (frame %d)", k);
+    for (int k = 0; k < n; k++) VPP_REQUIRE(dst[k].first_pixel != src[k].first_pixel, VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel_batch: in-place not supported (frame %d)", k);
     for (int b0 = 0; b0 < n; b0 += kGrayBatchMax) {
       const int nb = std::min(kGrayBatchMax, n - b0);
       GrayBatch fr{};

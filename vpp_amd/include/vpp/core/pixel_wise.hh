@@ -192,7 +192,7 @@ template <class OPTS, class... R> class pixel_wise_impl {
   template <class F, std::size_t... I> void run_device(F& fun, std::index_sequence<I...>) {
     const auto p1 = std::get<0>(ranges_).first_point_coordinates();
     const auto p2 = std::get<0>(ranges_).last_point_coordinates();
-    pwdev::launch(fun, p1[0], p1[1], p2[0] - p1[0] + 1, p2[1] - p1[1] + 1, pw::device_accessor(std::get<I>(ranges_))...);
+    pwdev::launch<OPTS::has(_nbh_read_only)>(fun, p1[0], p1[1], p2[0] - p1[0] + 1, p2[1] - p1[1] + 1, pw::device_accessor(std::get<I>(ranges_))...);
   }
   template <class F> void eval_device(F& fun, std::true_type) { run_device(fun, std::index_sequence_for<R...>()); }
   template <class F> auto eval_device(F& fun, std::false_type) {

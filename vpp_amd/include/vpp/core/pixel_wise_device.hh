@@ -51,19 +51,20 @@ template <class V, int R, int C> struct boxnbh_px {  // box_nbh2d<V,R,C> at a po
 };
 
 // The same two accessors over an LDS tile (pixel_wise_tile_kernel): the row pitch is a compile-time constant, so the taps of an unrolled window are
-// ds_read instructions with immediate offsets from ONE base register.  (Reads only: a write through a neighbourhood reaches the tile, not the image.)
+// ds_read instructions with immediate offsets from ONE base register.  READ-ONLY by type (const V&): the tile is a copy, a write through it would never reach
+// the image — so this path is only taken under the caller's `_nbh_read_only` option (launch), and a callable that assigns through it anyway does not compile.
 template <class V, int LP> struct nbh_tile_px {
-  char* p;
-  __device__ V& operator()(int dr, int dc) const { return *(V*)(p + dr * LP + dc * (int)sizeof(V)); }
-  __device__ V& operator()(vint2 d) const { return (*this)(d[0], d[1]); }
+  const char* p;
+  __device__ const V& operator()(int dr, int dc) const { return *(const V*)(p + dr * LP + dc * (int)sizeof(V)); }
+  __device__ const V& operator()(vint2 d) const { return (*this)(d[0], d[1]); }
 };
 template <class V, int R, int C, int LP> struct boxnbh_tile_px {
-  char* p;
-  __device__ V& operator()(int dr, int dc) const { return *(V*)(p + dr * LP + dc * (int)sizeof(V)); }
-  __device__ V& north() const { return (*this)(-1, 0); }
-  __device__ V& south() const { return (*this)(1, 0); }
-  __device__ V& east() const { return (*this)(0, 1); }
-  __device__ V& west() const { return (*this)(0, -1); }
+  const char* p;
+  __device__ const V& operator()(int dr, int dc) const { return *(const V*)(p + dr * LP + dc * (int)sizeof(V)); }
+  __device__ const V& north() const { return (*this)(-1, 0); }
+  __device__ const V& south() const { return (*this)(1, 0); }
+  __device__ const V& east() const { return (*this)(0, 1); }
+  __device__ const V& west() const { return (*this)(0, -1); }
   template <class F> __device__ void for_all(F f) const {
     for (int dr = -(R / 2); dr <= R / 2; dr++)
       for (int dc = -(C / 2); dc <= C / 2; dc++) f((*this)(dr, dc));
@@ -159,20 +160,25 @@ __global__ __launch_bounds__(256) void pixel_wise_kernel(F f, int r0, int c0, in
 // ---- neighbourhoods out of LDS ------------------------------------------------------------------------------------------------------------------------
 // A callable that reads a neighbourhood (benchmarks/box_5x5_filter2.cc:71-81: 25 taps per pixel) issued every tap as a global load: 4K vuchar3 5 x 5 mean 64 us
 // against 13 us for the hand-written kernel.  Here a workgroup first stages the source rows of its TH x (64 NPX) pixel tile plus a halo of H pixels in LDS
-// (16-byte loads, every byte fetched once per tile), and the callable's taps read the tile.  H = 4 covers windows up to 9 x 9; the launcher takes this path only
-// when the source's border is at most H (a tap cannot legally reach beyond the border), its pitch is a multiple of 16 and there is exactly one neighbourhood range.
+// (16-byte loads, every byte fetched once per tile), and the callable's taps read the tile.  H = 4 covers windows up to 9 x 9.  The tile is a COPY: the launcher
+// takes this path only under the caller's `_nbh_read_only` option (the callable reads through the neighbourhood, never writes, and no tap reaches further than H
+// pixels — in the image's interior a tap may legally reach further than the border, and a neighbourhood is a V& the reference's own code writes through,
+// distance_transforms.hh), for a box_nbh2d<V, R, C> only when R / 2 and C / 2 are at most H, when the source's pitch is a multiple of 16 and there is exactly one
+// neighbourhood range.
 constexpr int kTileH = 4, kTileRows = 16;
 template <class V, int NPXK> struct tile_geom {
   static constexpr int ES = (int)sizeof(V), TW = 64 * NPXK;
   static constexpr int LP = (((TW + 2 * kTileH) * ES + 15 + 15) / 16) * 16 + 16;   // row bytes + the alignment shift, in 16-byte units, + 16: consecutive rows start 4 banks apart
 };
-template <class A> struct nbh_traits { static constexpr bool value = false; };
+template <class A> struct nbh_traits { static constexpr bool value = false; static constexpr int reach = 0; };
 template <class V> struct nbh_traits<nbh_acc<V>> {
   static constexpr bool value = true; typedef V pixel;
+  static constexpr int reach = 0;   // unknown: vouched for by `_nbh_read_only`
   template <int LP> using tile = nbh_tile_acc<V, LP>;
 };
 template <class V, int R, int C> struct nbh_traits<boxnbh_acc<V, R, C>> {
   static constexpr bool value = true; typedef V pixel;
+  static constexpr int reach = (R / 2 > C / 2 ? R / 2 : C / 2);
   template <int LP> using tile = boxnbh_tile_acc<V, R, C, LP>;
 };
 template <class... A> struct first_nbh;
@@ -244,14 +250,16 @@ template <class A> struct is_nbh_acc : std::false_type {};
 template <class V> struct is_nbh_acc<nbh_acc<V>> : std::true_type {};
 template <class V, int R, int C> struct is_nbh_acc<boxnbh_acc<V, R, C>> : std::true_type {};
 
-template <class F, class... A> void launch(F f, int r0, int c0, int nrows, int ncols, A... acc) {
+// NBH_RO: the call carries `_nbh_read_only` (see pixel_wise_tile_kernel)
+template <bool NBH_RO, class F, class... A> void launch(F f, int r0, int c0, int nrows, int ncols, A... acc) {
   if (nrows <= 0 || ncols <= 0) return;
   constexpr int NPX = npx_all<A...>::value;
   constexpr bool kNbh = (is_nbh_acc<A>::value || ...);
   bool al = true;
   (void)std::initializer_list<int>{(al = al && aligned16(acc, c0), 0)...};
   const int gy = nrows < 65535 ? nrows : 65535;
-  if constexpr (kNbh && ((nbh_traits<A>::value ? 1 : 0) + ...) == 1) {   // one neighbourhood range: its taps out of an LDS tile when the window cannot leave the halo
+  if constexpr (NBH_RO && kNbh && ((nbh_traits<A>::value ? 1 : 0) + ...) == 1) {   // one read-only neighbourhood range: its taps out of an LDS tile
+   if constexpr (nbh_traits<typename first_nbh<A...>::type>::reach <= kTileH) {
     const auto& nb = first_nbh<A...>::get(acc...);
     static const bool off = [] { const char* e = getenv("VPP_PW_TILE"); return e && e[0] == '0'; }();   // A/B switch for the tests and the benchmark
     // Measured (4K 5 x 5 mean through the opaque lambda, synchronous calls, same box): vuchar3 64.2 us with global taps -> 56.9 us out of the tile (its taps are
@@ -259,7 +267,7 @@ template <class F, class... A> void launch(F f, int r0, int c0, int nrows, int n
     // with global taps -> 39.3 us out of the tile (dword taps already come out of L1 / L2 at near the streaming rate; the staging pass, the barrier and the
     // 1.5 x halo rows only add).  So: pixel types that are not dword multiples take the tile, the others keep the global taps.
     typedef typename nbh_traits<typename first_nbh<A...>::type>::pixel PV;
-    if (!off && sizeof(PV) % 4 != 0 && nb.border <= kTileH && nb.pitch % 16 == 0) {
+    if (!off && sizeof(PV) % 4 != 0 && nb.pitch % 16 == 0) {
       constexpr int NPXK = NPX % 4 == 0 ? 4 : 1;
       const bool vec = al && NPXK > 1;
       dim3 grid((ncols + 64 * (vec ? NPXK : 1) - 1) / (64 * (vec ? NPXK : 1)), (nrows + kTileRows - 1) / kTileRows);
@@ -270,6 +278,7 @@ template <class F, class... A> void launch(F f, int r0, int c0, int nrows, int n
       device::call_done();   // queued, not drained: vpp/core/device.hh
       return;
     }
+   }
   }
   // A callable that reads a neighbourhood issues its taps per pixel, so with NPX pixels per lane the lanes of a wave sit NPX pixels apart and every
   // tap of the wave is spread over NPX times as many cache lines.  For pixel types whose 16-byte chunk is many pixels (vuchar3: 16 px = 48 B per lane,

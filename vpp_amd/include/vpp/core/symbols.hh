@@ -18,5 +18,9 @@ VPP_DEFINE_SYMBOL(tie_arguments)
 // not in the reference: where an opaque pixel_wise callable runs in a TU compiled by hipcc (vpp/core/pixel_wise_device.hh)
 VPP_DEFINE_SYMBOL(host)
 VPP_DEFINE_SYMBOL(device)
+// not in the reference: pixel_wise(...)(_nbh_read_only) vouches that the callable only READS through its relative_access / box_nbh2d range and that no tap
+// reaches further than 4 pixels from the centre — the device engine may then serve the taps from an LDS tile (pixel_wise_device.hh: pixel_wise_tile_kernel).
+// Without it a neighbourhood is a reference into the image, as in the reference (relative_accessor.hh:26-33 returns V&; distance_transforms.hh writes through it).
+VPP_DEFINE_SYMBOL(nbh_read_only)
 
 namespace vpp { using namespace s; }
