@@ -70,7 +70,7 @@ def test_rgb_to_graylevel_rejects_bad_arguments(lib):
     assert lib.vpp_rgb_to_graylevel(P(d.desc), P(DeviceImage(2, 2, vi.U8, 3).desc), 1, None) != 0  # mirror border > image
     # the batch entry point answers as the n calls would: a frame k > 0 of another element type is not folded into frame 0's launch (round-4 advisor finding)
     srcs = [DeviceImage(8, 16, vi.U8, 3) for _ in range(3)]
-    dsts = [DeviceImage(8, 16, vi.U8, 1), DeviceImage(8, 16, vi.U8, 1), DeviceImage(8, 8, vi.U16, 1)]   # same pitch and extent, u16 pixels
+    dsts = [DeviceImage(8, 16, vi.U8, 1), DeviceImage(8, 16, vi.U8, 1), DeviceImage(8, 16, vi.U16, 1)]   # same domain and pitch (32), u16 pixels
     single = lib.vpp_rgb_to_graylevel(P(dsts[2].desc), P(srcs[2].desc), 0, None)
     assert single != 0
     assert lib.vpp_rgb_to_graylevel_batch(vi.desc_array(dsts), vi.desc_array(srcs), 3, 0, None) == single
