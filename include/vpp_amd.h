@@ -139,6 +139,26 @@ int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* src, int R, 
  * serve go out as exactly those calls. */
 int vpp_box_filter_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int R, int C, void* stream);
 
+/* ---- deferred per-frame calls: the reference's call form (ONE frame per call: benchmarks/box_5x5_filter2.cc:43-81, benchmarks/image_add.cc:51-57,
+ *      examples/video_extruder.cc:44-48; vpp/core/pixel_wise.hpp:188-213 evaluates at operator|) at the batched kernels' rate, without a launch graph ----
+ * A *_deferred entry point validates its arguments as its plain namesake does and returns; its launch is held back in a window of the CALLING HOST THREAD and goes
+ * out together with later deferred calls of the same entry point, parameters, stream and geometry as ONE batched launch (vpp_*_batch: "the results of the n calls
+ * one after the other").  A call joins the window only while no data flows between it and the pending calls (no pending result overlaps its operands or result,
+ * its result overlaps no pending operand; bordered extents); otherwise the window is launched first.  The window is also launched when it holds 64 frames, by
+ * vpp_flush, and before ANYTHING else the same thread queues through this ABI — every entry point that takes a stream (copies, events, vpp_sync, graphs, every
+ * kernel) and vpp_free — so stream order, results and what a vpp_sync waits for are exactly those of the plain calls.  What is NOT covered: work queued on the
+ * stream by other means (raw HIP calls) or from another host thread before a vpp_flush.  Frames the batched kernels do not serve, and calls on a stream that is
+ * being recorded into a launch graph (record-time batching does the same job there), run as the plain call at once.
+ * The C++ drop-in surface (vpp/core/pixel_wise.hh: ops::box_mean, ops::add/sub; colorspace_conversions.hh) calls these: a frame loop written like the
+ * reference's reaches the batch rate (4K vuchar3 box5x5: 8.3 us per frame instead of 13.5).  A launch failure of a window that another call flushed is reported
+ * by this thread's next vpp_flush / vpp_sync. */
+int vpp_box_filter_deferred(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream);
+int vpp_pixelwise_binary_deferred(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, void* stream);
+int vpp_rgb_to_graylevel_deferred(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream);
+int vpp_flush(void* stream);                       /* launches the calling thread's window (whatever its stream); VPP_OK when there is none */
+unsigned long long vpp_deferred_flushes(void);     /* batches launched for the calling thread so far (the C++ surface throttles per batch, not per call) */
+int vpp_deferred_pending(void);                    /* calls held back in the calling thread's window right now */
+
 /* ---- borders (vpp/core/fill.hh:31-122) ---- */
 typedef enum vpp_border_mode { VPP_BORDER_MIRROR = 0, VPP_BORDER_CLOSEST = 1, VPP_BORDER_VALUE = 2 } vpp_border_mode;
 int vpp_fill_border(const vpp_image_desc* img, int mode, const void* value /* VALUE mode: one pixel, host */, void* stream);

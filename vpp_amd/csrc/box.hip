@@ -1024,6 +1024,25 @@ extern "C" int vpp_debug_box_copy_batch(const vpp_image_desc* dst, const vpp_ima
   return VPP_OK;
 }
 
+#ifndef VPP_BOX_LAB
+// The per-frame call form without its per-frame launch (common.hpp, "deferred per-frame calls"): the frame joins the calling thread's window; argument errors
+// are reported here, at the call, as vpp_box_filter reports them.  Frames the batched streaming kernel does not serve, and calls on a stream that is being
+// recorded (record-time batching does the same job there), go out at once — behind the window, which as_stream() launches first.
+extern "C" int vpp_box_filter_deferred(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream) {
+  VPP_REQUIRE(valid_desc(dst) && valid_desc(src), VPP_ERR_INVALID_ARG, "vpp_box_filter: invalid descriptor");
+  VPP_REQUIRE(same_domain(dst, src) && same_type(dst, src), VPP_ERR_INVALID_ARG, "vpp_box_filter: domain/type mismatch");
+  VPP_REQUIRE(R > 0 && C > 0 && (R & 1) && (C & 1), VPP_ERR_INVALID_ARG, "vpp_box_filter: window must be odd x odd");
+  VPP_REQUIRE(src->border >= (R > C ? R : C) / 2, VPP_ERR_BORDER_TOO_SMALL, "vpp_box_filter: src border %d < %d", src->border, (R > C ? R : C) / 2);
+  VPP_REQUIRE(dst->first_pixel != src->first_pixel, VPP_ERR_INVALID_ARG, "vpp_box_filter: in-place not supported");
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  const bool batchable = cap == hipStreamCaptureStatusNone && tuning("defer", 1) && dst->dtype == VPP_U8 && R == 5 && C == 5 && dst->channels <= 4 && src->border >= 2 &&
+                         aligned16(dst) && aligned16(src) && fits_descriptor(dst, src) && !tuning("box.force_generic", 0) && tuning("box.impl", 2) == 2 && tuning("box.batch", 1);
+  if (!batchable) return vpp_box_filter(dst, src, R, C, stream);
+  return defer_call(kDeferBox, R, C, stream, dst, src, nullptr);
+}
+#endif
+
 extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream) {
   VPP_REQUIRE(valid_desc(dst) && valid_desc(src), VPP_ERR_INVALID_ARG, "vpp_box_filter: invalid descriptor");
   VPP_REQUIRE(same_domain(dst, src) && same_type(dst, src), VPP_ERR_INVALID_ARG, "vpp_box_filter: domain/type mismatch");

@@ -39,7 +39,34 @@ int comm_allgather_inplace(vpp_comm* comm, void* base, size_t bytes_per_rank, hi
 int comm_group_begin();
 int comm_group_end();
 
-inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// ---- deferred per-frame calls (vpp_*_deferred, include/vpp_amd.h) --------------------------------------------------------------------------------------
+// The reference's call form is one frame per call (benchmarks/box_5x5_filter2.cc:43-81, benchmarks/image_add.cc:51-57); eagerly that is one launch per call, and
+// a 50 MB launch reaches 46 % of the HBM peak where 64 frames in one launch reach 74 %.  A *_deferred entry point does not launch: it appends its frame to the
+// calling thread's window while the frame is unrelated to the pending ones (no pending result overlaps its source or result, its result overlaps no pending
+// source) and has their geometry; the window goes out as ONE batched launch (the vpp_*_batch kernels: "the results of the n calls one after the other") when
+// it holds kDeferMax frames, when a call that cannot join arrives, at vpp_flush — and before ANYTHING else this thread queues through this ABI on any stream:
+// every entry point turns its stream argument into a hipStream_t with as_stream(), which flushes first.  Stream order is therefore exactly that of the calls.
+constexpr int kDeferMax = 64;
+enum { kDeferNone = 0, kDeferBox = 1, kDeferBinary = 2, kDeferGray = 3 };
+struct DeferWindow {
+  int n = 0;                       // pending calls
+  int kind = kDeferNone, p0 = 0, p1 = 0;   // the entry point and its scalar parameters (box: R, C; binary: op; gray: mirror)
+  int nsrc = 0;
+  void* stream = nullptr;
+  unsigned long long flushes = 0;  // batches launched for this thread so far (vpp_deferred_flushes: the C++ surface throttles per batch, not per call)
+  int last_rc = VPP_OK;            // of a flush that another call triggered: reported by the next vpp_flush / vpp_sync of this thread
+  vpp_image_desc dst[kDeferMax], src[2][kDeferMax];
+};
+extern thread_local DeferWindow g_defer;
+int defer_flush();   // runtime.hip: launches the window (if any) and empties it; the launch's status (also kept in last_rc when it failed)
+// the call joins the window (flushing it first when it cannot: another entry point / parameters / stream / geometry, or data flow between it and a pending
+// call); returns the flush's status, VPP_OK when nothing had to go out.  When the window is full afterwards it is launched.
+int defer_call(int kind, int p0, int p1, void* stream, const vpp_image_desc* dst, const vpp_image_desc* src0, const vpp_image_desc* src1);
+
+inline hipStream_t as_stream(void* s) {
+  if (g_defer.n) (void)defer_flush();   // whatever this call queues comes after the deferred calls made before it
+  return reinterpret_cast<hipStream_t>(s);
+}
 
 // memset by a kernel of this library (runtime.hip), for every fill that may be recorded into a launch graph: on ROCm 7.2 the runtime's memset NODES were
 // not ordered with the kernel nodes around them (a replayed flow read a half-zeroed control block and faulted), and eagerly hipMemsetAsync is two dispatches.

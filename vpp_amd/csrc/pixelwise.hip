@@ -413,6 +413,20 @@ int vpp_pixelwise_binary_batch(int op, const vpp_image_desc* dst, const vpp_imag
   return VPP_OK;
 }
 
+// The per-call form without its per-call launch (common.hpp, "deferred per-frame calls"): the triple joins the calling thread's window; argument errors are
+// reported here, at the call, as vpp_pixelwise_binary reports them.  Triples the batched kernel does not serve, and calls on a stream that is being recorded
+// (record-time batching does the same job there), go out at once — behind the window, which as_stream() launches first.
+int vpp_pixelwise_binary_deferred(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, void* stream) {
+  VPP_REQUIRE(valid_desc(dst) && valid_desc(a) && valid_desc(b), VPP_ERR_INVALID_ARG, "vpp_pixelwise_binary: invalid descriptor");
+  VPP_REQUIRE(same_domain(dst, a) && same_domain(dst, b), VPP_ERR_INVALID_ARG, "vpp_pixelwise_binary: domains differ");
+  VPP_REQUIRE(same_type(dst, a) && same_type(dst, b), VPP_ERR_UNSUPPORTED, "vpp_pixelwise_binary: mixed element types");
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  if (cap != hipStreamCaptureStatusNone || !tuning("defer", 1) || !pw_batchable(op, dst, a, b) || dst->first_pixel == a->first_pixel || dst->first_pixel == b->first_pixel)
+    return vpp_pixelwise_binary(op, dst, a, b, stream);
+  return defer_call(kDeferBinary, op, 0, stream, dst, a, b);
+}
+
 int vpp_copy(const vpp_image_desc* dst, const vpp_image_desc* src, int with_border, void* stream) {
   VPP_REQUIRE(valid_desc(dst) && valid_desc(src), VPP_ERR_INVALID_ARG, "vpp_copy: invalid descriptor");
   VPP_REQUIRE(same_domain(dst, src) && same_type(dst, src), VPP_ERR_INVALID_ARG, "vpp_copy: domain/type mismatch");

@@ -53,6 +53,57 @@ static std::atomic<unsigned> g_notes_epoch{1};
 unsigned notes_epoch() { return g_notes_epoch.load(std::memory_order_relaxed); }
 void invalidate_scratch_notes() { g_notes_epoch.fetch_add(1, std::memory_order_relaxed); }
 
+// ---- deferred per-frame calls (common.hpp) ----------------------------------------------------------------------------------------------------------
+thread_local DeferWindow g_defer;
+extern "C" int vpp_box_filter_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int R, int C, void* stream);
+extern "C" int vpp_pixelwise_binary_batch(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, int n, void* stream);
+extern "C" int vpp_rgb_to_graylevel_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int mirror, void* stream);
+int defer_flush() {
+  DeferWindow& w = g_defer;
+  const int n = w.n;
+  if (!n) return VPP_OK;
+  w.n = 0;   // first: the batch entry points call as_stream() themselves
+  int rc = VPP_OK;
+  switch (w.kind) {
+    case kDeferBox: rc = vpp_box_filter_batch(w.dst, w.src[0], n, w.p0, w.p1, w.stream); break;
+    case kDeferBinary: rc = vpp_pixelwise_binary_batch(w.p0, w.dst, w.src[0], w.src[1], n, w.stream); break;
+    case kDeferGray: rc = vpp_rgb_to_graylevel_batch(w.dst, w.src[0], n, w.p0, w.stream); break;
+    default: break;
+  }
+  w.flushes++;
+  if (rc != VPP_OK) w.last_rc = rc;
+  return rc;
+}
+namespace {
+inline bool same_frame_geometry(const vpp_image_desc& a, const vpp_image_desc& b) {
+  return a.nrows == b.nrows && a.ncols == b.ncols && a.pitch == b.pitch && a.border == b.border && a.dtype == b.dtype && a.channels == b.channels &&
+         (((uintptr_t)a.first_pixel ^ (uintptr_t)b.first_pixel) & 15) == 0;
+}
+inline bool extents_overlap(const Extent& a, const Extent& b) { return a.lo < b.hi && b.lo < a.hi; }
+}  // namespace
+int defer_call(int kind, int p0, int p1, void* stream, const vpp_image_desc* dst, const vpp_image_desc* src0, const vpp_image_desc* src1) {
+  DeferWindow& w = g_defer;
+  int rc = VPP_OK;
+  if (w.n) {
+    bool join = w.kind == kind && w.p0 == p0 && w.p1 == p1 && w.stream == stream && same_frame_geometry(*dst, w.dst[0]) && same_frame_geometry(*src0, w.src[0][0]) &&
+                (!src1 || same_frame_geometry(*src1, w.src[1][0]));
+    if (join) {   // no data flow between this frame and a pending one (reads of one source by several frames are fine)
+      const Extent d = extent_of(*dst), s0 = extent_of(*src0), s1 = src1 ? extent_of(*src1) : Extent{0, 0};
+      for (int k = 0; join && k < w.n; k++) {
+        const Extent pd = extent_of(w.dst[k]);
+        join = !extents_overlap(d, pd) && !extents_overlap(s0, pd) && !(src1 && extents_overlap(s1, pd)) && !extents_overlap(d, extent_of(w.src[0][k])) &&
+               !(w.nsrc > 1 && extents_overlap(d, extent_of(w.src[1][k])));
+      }
+    }
+    if (!join) rc = defer_flush();
+  }
+  if (!w.n) { w.kind = kind; w.p0 = p0; w.p1 = p1; w.stream = stream; w.nsrc = src1 ? 2 : 1; }
+  w.dst[w.n] = *dst; w.src[0][w.n] = *src0; if (src1) w.src[1][w.n] = *src1;
+  w.n++;
+  if (w.n == kDeferMax) { const int r2 = defer_flush(); if (rc == VPP_OK) rc = r2; }
+  return rc;
+}
+
 // ---- device_fill (common.hpp): 16-byte units for the aligned body, the first workgroup also writes the unaligned head and tail bytes
 namespace {
 __global__ __launch_bounds__(256) void fill_bytes_kernel(uint8_t* __restrict__ p, size_t head, size_t units, size_t tail, uint32_t v32) {
@@ -292,6 +343,7 @@ int vpp_malloc(size_t bytes, void** dptr) {
 
 int vpp_free(void* dptr) {
   if (!dptr) return VPP_OK;
+  if (g_defer.n) (void)defer_flush();   // a pending deferred call may use the block: launched before the block can be handed out again (callers order reuse on streams)
   const size_t cap = (size_t)tuning("runtime.pool_mb", 2048) << 20;
   // the block goes back to the pool of the device it was allocated on, whichever device is current now
   DevicePool* P = nullptr;
@@ -387,7 +439,20 @@ int vpp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
 int vpp_memset(void* dst, int byte, size_t bytes, void* stream) {
   return device_fill(dst, byte, bytes, as_stream(stream));   // a kernel of this library: recordable into launch graphs (see common.hpp)
 }
-int vpp_sync(void* stream) { VPP_HIP_TRY(hipStreamSynchronize(as_stream(stream))); return check_device_error("vpp_sync"); }
+int vpp_sync(void* stream) {
+  VPP_HIP_TRY(hipStreamSynchronize(as_stream(stream)));   // (as_stream launches this thread's deferred calls first)
+  if (g_defer.last_rc != VPP_OK) { const int rc = g_defer.last_rc; g_defer.last_rc = VPP_OK; set_error("vpp_sync: a deferred batch (vpp_*_deferred) failed to launch, status %d", rc); return rc; }
+  return check_device_error("vpp_sync");
+}
+int vpp_flush(void* stream) {
+  (void)stream;   // one window per host thread, whatever the stream
+  int rc = defer_flush();
+  if (rc == VPP_OK && g_defer.last_rc != VPP_OK) rc = g_defer.last_rc;
+  g_defer.last_rc = VPP_OK;
+  return rc;
+}
+unsigned long long vpp_deferred_flushes(void) { return g_defer.flushes; }
+int vpp_deferred_pending(void) { return g_defer.n; }
 int vpp_stream_create(void** stream) {
   VPP_REQUIRE(stream, VPP_ERR_INVALID_ARG, "vpp_stream_create: null");
   hipStream_t s;

@@ -232,6 +232,18 @@ extern "C" int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_d
   return rc;
 }
 
+// The per-frame call form without its per-frame launch (common.hpp, "deferred per-frame calls"); argument errors are reported at the call (gray_geometry is
+// what vpp_rgb_to_graylevel checks with).
+extern "C" int vpp_rgb_to_graylevel_deferred(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream) {
+  GrayGeom g;
+  const int rc = gray_geometry(dst, src, mirror, &g);
+  if (rc != VPP_OK) return rc;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  if (cap != hipStreamCaptureStatusNone || !tuning("defer", 1) || !tuning("ingest.batch", 1) || dst->first_pixel == src->first_pixel) return vpp_rgb_to_graylevel(dst, src, mirror, stream);
+  return defer_call(kDeferGray, mirror ? 1 : 0, 0, stream, dst, src, nullptr);
+}
+
 // n frames of one geometry (same sizes, pitches, borders, channel count, 16-byte phase of the first pixels) in ONE launch; anything else, and frames that feed
 // each other, go out as the n calls in sequence (whose results are the contract)
 extern "C" int vpp_rgb_to_graylevel_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int mirror, void* stream) {

@@ -19,8 +19,8 @@ template <class T, class U, unsigned N, unsigned C> imageNd<T, N> rgb_to_graylev
 #ifdef VPP_AMD_DEVICE
   if constexpr (N == 2 && std::is_same<U, unsigned char>::value && colorspace_internals::is_u8_gray<T>::value) {
     const vpp_image_desc di = in.device_desc(false), dout = out.device_desc(true, true);
-    device::check(vpp_rgb_to_graylevel(&dout, &di, 0, device::stream()), "vpp_rgb_to_graylevel");
-    device::call_done();   // queued, not drained: vpp/core/device.hh
+    device::check(vpp_rgb_to_graylevel_deferred(&dout, &di, 0, device::stream()), "vpp_rgb_to_graylevel");
+    device::deferred_call_done();   // held back and launched in batches by the library: vpp/core/device.hh
     return out;
   }
 #endif
@@ -40,8 +40,8 @@ template <unsigned C> image2d<unsigned char> rgb_to_graylevel_mirror(const image
   static_assert(C == 3 || C == 4, "rgb or rgba");
   image2d<unsigned char> out(frame.domain(), _border = border, _aligned = aligned);
   const vpp_image_desc di = frame.device_desc(false), dout = out.device_desc(true, true);
-  device::check(vpp_rgb_to_graylevel(&dout, &di, 1, device::stream()), "vpp_rgb_to_graylevel");
-  device::call_done();   // queued, not drained: vpp/core/device.hh
+  device::check(vpp_rgb_to_graylevel_deferred(&dout, &di, 1, device::stream()), "vpp_rgb_to_graylevel");
+  device::deferred_call_done();   // held back and launched in batches by the library: vpp/core/device.hh
   return out;
 }
 #endif

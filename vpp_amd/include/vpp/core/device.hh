@@ -44,6 +44,28 @@ inline void call_done() {
   r.k = (r.k + 1) % kCallsInFlight;
   if (r.set[r.k]) check(vpp_event_synchronize(r.ev[r.k]), "vpp_event_synchronize");   // the oldest call still queued
 }
+// Deferred per-frame calls (include/vpp_amd.h: vpp_*_deferred): the tagged functors and rgb_to_graylevel do not launch per call — the library holds the frame back
+// and launches whole batches (up to 64 frames), always before anything else this thread queues (so every host accessor, every other call and sync() see the
+// results exactly as with per-call launches).  The queue bound of call_done() then applies per BATCH: after a call that made the library launch a window.
+inline void deferred_call_done() {
+  static thread_local unsigned long long seen = 0;
+  static thread_local int unthrottled = 0;
+  const unsigned long long f = vpp_deferred_flushes();
+  if (f == seen) return;
+  seen = f;
+  // (call_done records an event, which would launch a window that has just been opened: throttle when nothing is pending — the full-window case — or after
+  // many small windows in a row, a chain of dependent calls)
+  if (vpp_deferred_pending() == 0 || ++unthrottled >= 64) { unthrottled = 0; call_done(); }
+}
+// Everything queued so far — deferred frames included — has completed when sync() returns.
+inline void sync() { check(vpp_sync(stream()), "vpp_sync"); }
+// RAII: the deferred frames of the enclosed calls are launched when the scope ends (they are launched earlier whenever order demands it; see above).
+struct batch_scope {
+  batch_scope() {}
+  ~batch_scope() { (void)vpp_flush(stream()); }
+  batch_scope(const batch_scope&) = delete;
+  batch_scope& operator=(const batch_scope&) = delete;
+};
 template <class T> struct dtype_of { static_assert(sizeof(T) == 0, "pixel component type not supported on the device"); };
 template <> struct dtype_of<unsigned char> { enum { value = VPP_U8 }; };
 template <> struct dtype_of<signed char> { enum { value = VPP_I8 }; };
