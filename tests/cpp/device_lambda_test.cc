@@ -382,13 +382,15 @@ static void time_4k() {
 }
 
 int main(int argc, char** argv) {
-  test_reference_bodies();
-  test_device_equals_host();
-  test_block_wise_device();
-  test_neighbourhood_tiles();
-  test_writes_through_a_neighbourhood();
-  test_box_lambdas_against_the_oracle();
-  if (argc > 1 && !std::strcmp(argv[1], "time")) time_4k();
+  std::setvbuf(stdout, nullptr, _IOLBF, 0);
+#define STEP(f) do { std::fprintf(stderr, "[device_lambda_test] " #f "\n"); f(); } while (0)
+  STEP(test_reference_bodies);
+  STEP(test_device_equals_host);
+  STEP(test_block_wise_device);
+  STEP(test_neighbourhood_tiles);
+  STEP(test_writes_through_a_neighbourhood);
+  STEP(test_box_lambdas_against_the_oracle);
+  if (argc > 1 && !std::strcmp(argv[1], "time")) STEP(time_4k);
   std::printf("device_lambda_test ok\n");
   return 0;
 }

@@ -193,6 +193,9 @@ template <class V, unsigned N> class imageNd {
     d.dtype = device::dtype_of<typename PT::component>::value; d.channels = PT::channels;
     return d;
   }
+  // [first, one past the last) byte of the HBM mirror of the WHOLE buffer this image (or view) lives in — what device code may read around a view
+  // (valid after a device_desc call: the mirror exists)
+  void device_allocation(const char** lo, const char** hi) const { *lo = (const char*)ptr_->store_->dev; *hi = *lo + ptr_->store_->bytes; }
 #endif
 
  protected:

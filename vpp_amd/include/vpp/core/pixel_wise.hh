@@ -115,8 +115,18 @@ template <class V> struct device_range<relative_access_<imageNd<V, 2>>> : std::i
 template <class V, int R, int C> struct device_range<box_nbh2d<V, R, C>> : std::is_trivially_copyable<V> {};
 template <class V> pwdev::image_acc<V> device_accessor(const image2d<V>& i) { const vpp_image_desc d = i.device_desc(true); return pwdev::image_acc<V>{(V*)d.first_pixel, d.pitch}; }
 inline pwdev::box_acc device_accessor(const box2d&) { return pwdev::box_acc{}; }
-template <class V> pwdev::nbh_acc<V> device_accessor(const relative_access_<image2d<V>>& r) { const vpp_image_desc d = r.img.device_desc(true); return pwdev::nbh_acc<V>{(V*)d.first_pixel, d.pitch, d.border, d.nrows, d.ncols}; }
-template <class V, int R, int C> pwdev::boxnbh_acc<V, R, C> device_accessor(const box_nbh2d<V, R, C>& n) { const vpp_image_desc d = n.img.device_desc(true); return pwdev::boxnbh_acc<V, R, C>{(V*)d.first_pixel, d.pitch, d.border, d.nrows, d.ncols}; }
+template <class V> pwdev::nbh_acc<V> device_accessor(const relative_access_<image2d<V>>& r) {
+  const vpp_image_desc d = r.img.device_desc(true);
+  pwdev::nbh_acc<V> a{(V*)d.first_pixel, d.pitch, nullptr, nullptr};
+  r.img.device_allocation(&a.lo, &a.hi);
+  return a;
+}
+template <class V, int R, int C> pwdev::boxnbh_acc<V, R, C> device_accessor(const box_nbh2d<V, R, C>& n) {
+  const vpp_image_desc d = n.img.device_desc(true);
+  pwdev::boxnbh_acc<V, R, C> a{(V*)d.first_pixel, d.pitch, nullptr, nullptr};
+  n.img.device_allocation(&a.lo, &a.hi);
+  return a;
+}
 template <class V> const void* storage_of(const image2d<V>& i) { return i.storage_id(); }
 inline const void* storage_of(const box2d&) { return nullptr; }
 template <class V> const void* storage_of(const relative_access_<image2d<V>>& r) { return r.img.storage_id(); }

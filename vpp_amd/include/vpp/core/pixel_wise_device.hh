@@ -29,8 +29,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // ---- device-side accessors, built on the host from the ranges (mirror pointers) ----------------------------------
 template <class V> struct image_acc { V* p0; int pitch; };                    // p0 = pixel (0, 0) in HBM
 struct box_acc {};
-template <class V> struct nbh_acc { V* p0; int pitch, border, nr, nc; };      // + the source's border and domain: what a neighbourhood may reach (the LDS tile path)
-template <class V, int R, int C> struct boxnbh_acc { V* p0; int pitch, border, nr, nc; };
+template <class V> struct nbh_acc { V* p0; int pitch; const char *lo, *hi; };   // + the byte range of the whole buffer's mirror: what a neighbourhood of a view may reach (the LDS tile path)
+template <class V, int R, int C> struct boxnbh_acc { V* p0; int pitch; const char *lo, *hi; };
 
 template <class V> struct nbh_px {  // relative_access_kernel on the device (relative_accessor.hh:26-33)
   V* p; int pitch;
@@ -205,18 +205,17 @@ __global__ __launch_bounds__(256) void pixel_wise_tile_kernel(F f, int r0, int c
   const char* g0 = (const char*)nb.p0 + (ptrdiff_t)(tr - H) * nb.pitch + (ptrdiff_t)(tc - H) * ES;
   const int shift = (int)((size_t)g0 & 15);
   const char* ga = g0 - shift;
-  // bytes of a staged row that belong to the image's bordered area, as offsets from ga (the same on every row)
-  const int vlo = (-nb.border - (tc - H)) * ES + shift, vhi = (nb.nc + nb.border - (tc - H)) * ES + shift;
-  const int want_hi = min(vhi, shift + (TW + 2 * H) * ES);
+  // Staged: every byte of the tile's rows that lies inside the buffer's mirror [nb.lo, nb.hi) — for a view (sub-image) that is more than the view's own
+  // bordered area, as on the host, where a tap may reach whatever the parent image holds there; bytes outside the buffer are never touched (nor legally tapped).
+  const int want_hi = shift + (TW + 2 * H) * ES;
   for (int k = threadIdx.x; k < ROWS * CPR; k += 256) {
     const int rr = k / CPR, off = (k - rr * CPR) * 16;
-    const int r = tr - H + rr;
-    if (r < -nb.border || r >= nb.nr + nb.border || off >= want_hi || off + 16 <= vlo) continue;
+    if (off >= want_hi) continue;
     const char* src = ga + (ptrdiff_t)rr * nb.pitch + off;
     char* dst = lds + rr * LP + off;
-    if (off >= vlo && off + 16 <= vhi) *(u32x4*)dst = *(const u32x4*)src;
-    else
-      for (int b = max(off, vlo); b < min(off + 16, vhi); b++) lds[rr * LP + b] = ga[(ptrdiff_t)rr * nb.pitch + b];   // a chunk cut by the row's first / last bordered byte
+    if (src >= nb.lo && src + 16 <= nb.hi) *(u32x4*)dst = *(const u32x4*)src;
+    else if (src + 16 > nb.lo && src < nb.hi)
+      for (int b = 0; b < 16; b++) if (src + b >= nb.lo && src + b < nb.hi) dst[b] = src[b];   // a chunk cut by the buffer's first / last byte
   }
   __syncthreads();
   // ---- compute: wave w takes rows [w TH/4, (w + 1) TH/4) of the tile, a lane NPXK consecutive pixels
