@@ -190,14 +190,16 @@ template <class V, class MK> static void tile_case(int nr, int nc, int border, M
   pixel_wise(H, relative_access(S))(_host) | k;
   if (!same_pixels(D, H) || !same_pixels(G, H)) { std::fprintf(stderr, "tile_case %d x %d border %d, %d-byte pixels\n", nr, nc, border, (int)sizeof(V)); std::exit(1); }
 }
-// a reach of 2 inside a border of 6 and inside a border of 1 (interior domain only): the halo, not the border, bounds what the tile serves
+// The halo, not the border, bounds what the tile serves: taps two columns away inside a border of 6, and inside a border of 1 on the interior columns of the
+// domain (a row tap may never leave the border — the neighbourhood walks the row-pointer table, relative_accessor.hh:18-22 — a column tap may reach whatever the
+// row holds), on a view whose first column is odd.
 template <class V, class MK> static void tile_reach_case(int nr, int nc, int border, MK make) {
   image2d<V> S(nr, nc, _border = border), D(S.domain()), H(S.domain());
   for (auto p : S.domain_with_border()) S(p) = make();
   fill(D, V(make())); copy(D, H);
-  const int m = border >= 2 ? 0 : 2;   // border narrower than the reach: run on the interior where every tap stays inside the image
-  const box2d win(vint2(m, m), vint2(nr - 1 - m, nc - 1 - m));
-  auto k = [] (V& out, auto nbh) { out = V(nbh(-2, -2) + nbh(2, 2) * 3 + nbh(0, -2) * 5 + nbh(-2, 1) * 7); };
+  const int m = border >= 2 ? 0 : 3;   // border narrower than the column reach: the columns where every tap stays inside the row
+  const box2d win(vint2(0, m), vint2(nr - 1, nc - 1 - m));
+  auto k = [] (V& out, auto nbh) { out = V(nbh(-1, -2) + nbh(1, 2) * 3 + nbh(0, -2) * 5 + nbh(-1, 1) * 7); };
   auto sd = D | win, sh = H | win, ss = S | win;
   pixel_wise(sd, relative_access(ss))(_nbh_read_only) | k;
   pixel_wise(sh, relative_access(ss))(_host) | k;

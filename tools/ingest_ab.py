@@ -1,6 +1,7 @@
-"""A/B of the frame-ingest kernels (vpp_rgb_to_graylevel, 4K vuchar3 -> uchar + mirror border 3): ingest.impl 0 = one lane per 16-pixel chunk (rounds 1-4),
-1 = a wave per 64 chunks of a row through its own LDS (round 5), ingest.rows = rows per wave.  Per variant: every byte against the oracle once, then event-timed
-launch graphs of 1024 per-frame calls over 64 frame sets — folded into 64-frame launches at record time, and as one launch per call."""
+"""A/B of the frame-ingest launch geometry (vpp_rgb_to_graylevel, 4K vuchar3 -> uchar + mirror border 3): threads per workgroup (ingest.block; default 64 for a
+single frame, 256 for launches of 4 frames and more).  Per variant: every byte against the oracle once, then event-timed launch graphs of 1024 per-frame calls
+over 64 frame sets — folded into 64-frame launches at record time, and as one launch per call.  (Round 5 also measured a wave-cooperative kernel here —
+coalesced 16-byte loads turned around through LDS: 5.89 / 9.79 us against 5.85 / 9.19 for the better block size of the lane-per-chunk kernel; not kept.)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -30,8 +31,8 @@ def graph_us(ncalls):
     return sorted(ts[1:])[1] * 1e3 / ncalls
 
 
-for impl, rows, block in ((0, 0, 64), (0, 0, 256), (1, 1, 0), (1, 2, 0), (1, 4, 0)):
-    lib.vpp_set_tuning(b"ingest.impl", impl); lib.vpp_set_tuning(b"ingest.rows", rows if rows else -1); lib.vpp_set_tuning(b"ingest.block", block if block else -1)
+for block in (0, 64, 128, 256):
+    lib.vpp_set_tuning(b"ingest.block", block if block else -1)
     for g in grays[:2]:
         g.store.zero_()
     capi.check(lib.vpp_rgb_to_graylevel(P(grays[0].desc), P(rgbs[0].desc), 1, capi.stream_ptr()))
@@ -44,4 +45,4 @@ for impl, rows, block in ((0, 0, 64), (0, 0, 256), (1, 1, 0), (1, 2, 0), (1, 4, 
     one = graph_us(1024)
     lib.vpp_set_tuning(b"ingest.coalesce", -1); lib.vpp_set_tuning(b"launch.capture_width", -1)
     b = NR * NC * 4
-    print(f"impl {impl} rows {rows} block {block}: {'ok' if ok else 'MISMATCH'}  recorded (64-frame launches) {rec:.2f} us = {b / rec / 8e6:.3f}   one launch per call {one:.2f} us = {b / one / 8e6:.3f}", flush=True)
+    print(f"block {block or 'default'}: {'ok' if ok else 'MISMATCH'}  recorded (64-frame launches) {rec:.2f} us = {b / rec / 8e6:.3f}   one launch per call {one:.2f} us = {b / one / 8e6:.3f}", flush=True)

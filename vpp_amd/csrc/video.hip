@@ -98,78 +98,6 @@ __global__ __launch_bounds__(256) void rgb_to_gray_kernel(DImg dst, DImg src, in
   }
 }
 
-// Round 5: the main chunks by whole waves.  In rgb_to_gray_kernel a lane loads ITS 48 bytes: every one of the wave's three load instructions walks all 24 cache
-// lines of the wave's 3 KB span at a third of their bytes.  Here a wave owns 64 consecutive main chunks of one row (times RW rows): lane i loads the pieces
-// i, i + 64, i + 128 of the span (16 bytes each: three perfectly coalesced instructions), the wave turns the pieces around through 3 KB of its own LDS — written
-// contiguously, read back as lane i's pieces 3 i .. 3 i + 2 (ds_read_b128 at a stride of 12 dwords: conflict-free over the instruction's lane groups,
-// MI355X_MICROARCH.md LDS table) — and the arithmetic and the 16-byte non-temporal store are the old kernel's.  LDS operations of one wave execute in order:
-// no workgroup barrier anywhere, the buffer is reused row after row.  256-thread workgroups (4 independent waves); the edge chunks keep their blocks in front.
-template <int RW, bool MIRROR>
-__global__ __launch_bounds__(256) void rgb3_to_gray_rows_kernel(DImg dst, DImg src, int ext, int c_start, int nchunks, int n_left, int n_main, int edge_blocks, int vec_ok,
-                                                                const GrayBatch frames, unsigned blocks_per_frame, int segs, long long units) {
-  constexpr int CH = 3;
-  __shared__ u32x4 lds[4][64 * CH];
-  const int nrows_out = dst.nr + 2 * ext;
-  const unsigned frame = blockIdx.x / blocks_per_frame, fblock = blockIdx.x - frame * blocks_per_frame;
-  dst.p0 = frames.d[frame]; src.p0 = const_cast<uint8_t*>(frames.s[frame]);
-  if ((int)fblock < edge_blocks) {
-    const int n_edge = nchunks - n_main, t = fblock * 256 + threadIdx.x;
-    const int row = t / n_edge, e = t - row * n_edge;
-    if (row >= nrows_out) return;
-    const int r = row - ext, c0 = c_start + kGrayChunk * (e < n_left ? e : e + n_main);
-    const uint8_t* srow = src.row<uint8_t>(MIRROR ? mirror_index(r, src.nr) : r);
-    uint8_t* drow = dst.row<uint8_t>(r);
-    for (int k = 0; k < kGrayChunk; k++) {
-      const int c = c0 + k;
-      if (c < -ext || c >= dst.nc + ext) continue;
-      const uint8_t* p = srow + (ptrdiff_t)(MIRROR ? mirror_index(c, src.nc) : c) * CH;
-      drow[c] = (uint8_t)div3((uint32_t)p[0] + p[1] + p[2]);
-    }
-    return;
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long u = (long long)(fblock - edge_blocks) * 4 + wave;
-  if (u >= units) return;   // (wave-uniform)
-  const int rg = (int)(u / segs), seg = (int)(u - (long long)rg * segs);
-  const int m0 = seg * 64, nact = min(64, n_main - m0);
-  const int c0w = c_start + kGrayChunk * (n_left + m0);   // the wave's first column
-  const int npieces = nact * CH;
-  u32x4 ld[RW][CH];
-#pragma unroll
-  for (int k = 0; k < RW; k++) {
-    const int row = rg * RW + k;
-    const int r = min(row, nrows_out - 1) - ext;   // (a row past the end re-reads the last one and stores nothing)
-    const uint8_t* sp = src.row<uint8_t>(MIRROR ? mirror_index(r, src.nr) : r) + (ptrdiff_t)c0w * CH;
-#pragma unroll
-    for (int j = 0; j < CH; j++) {
-      ld[k][j] = u32x4{0u, 0u, 0u, 0u};
-      if (lane + 64 * j < npieces) __builtin_memcpy(&ld[k][j], sp + 16 * (lane + 64 * j), 16);
-    }
-  }
-  u32x4* const buf = lds[wave];
-#pragma unroll
-  for (int k = 0; k < RW; k++) {
-    const int row = rg * RW + k;
-#pragma unroll
-    for (int j = 0; j < CH; j++) buf[lane + 64 * j] = ld[k][j];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t w[4 * CH];
-#pragma unroll
-    for (int j = 0; j < CH; j++) { const u32x4 v = buf[CH * lane + j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t o[4];
-    gray_chunk<CH>(w, o);
-    if (row < nrows_out && lane < nact) {
-      uint8_t* dp = dst.row<uint8_t>(row - ext) + c0w + kGrayChunk * lane;
-      if (vec_ok & 1) __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, (u32x4*)dp);
-      else {
-#pragma unroll
-        for (int q = 0; q < kGrayChunk; q++) dp[q] = (uint8_t)(o[q >> 2] >> (8 * (q & 3)));
-      }
-    }
-  }
-}
-
 // lbp_transform (vpp/algorithms/lbp/lbp_transform.hh:6-38): bit k of B(r, c) = neighbour k > centre, neighbours in row-major
 // order without the centre ((-1,-1) = bit 0 ... (1,1) = bit 7).  Four pixels per lane: three 8-byte row loads (columns
 // c-1 .. c+6), one dword store; ragged row ends per pixel.
@@ -220,8 +148,12 @@ __global__ __launch_bounds__(256) void keypoint_mask_kernel(DImg mask, const int
 
 namespace {
 // geometry of one frame's launch (shared by every frame of a batch) and the kernel to launch / to re-parameterise a recorded node with
-struct GrayGeom { DImg d, s; int ext, c_start, nchunks, n_left, n_main, edge_blocks, vec_ok, bsz, ch, mirror; unsigned blocks_per_frame; int rows, segs; long long units; };
-int gray_geometry(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, GrayGeom* g) {
+struct GrayGeom { DImg d, s; int ext, c_start, nchunks, n_left, n_main, edge_blocks, vec_ok, bsz, ch, mirror; unsigned blocks_per_frame; };
+// bsz: threads per workgroup.  Measured at 4K (tools/ingest_ab.py, round 5): ONE frame per launch 64 threads 9.19 us, 256 threads 10.05 (more, shorter workgroups:
+// the single resident round of waves ends more evenly); 64 frames per launch 64 threads 6.14 us = 0.676 of the HBM peak, 256 threads 5.85 us = 0.709 (a quarter
+// of the workgroups to dispatch).  A wave-cooperative variant (coalesced 16-byte loads turned around through LDS, 256 threads) measured 5.89 / 9.79 us: the
+// lane-per-chunk loads were never the limit, it was not kept.  So: 64 threads for single frames, 256 once a launch carries several (`frames`).
+int gray_geometry(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, GrayGeom* g, int frames = 1) {
   VPP_REQUIRE(valid_desc(dst) && valid_desc(src) && same_domain(dst, src), VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel: invalid descriptors / domain mismatch");
   VPP_REQUIRE(dst->dtype == VPP_U8 && dst->channels == 1 && src->dtype == VPP_U8 && (src->channels == 3 || src->channels == 4), VPP_ERR_UNSUPPORTED,
               "vpp_rgb_to_graylevel: u8 x3 / x4 -> u8 x1 only");
@@ -235,42 +167,22 @@ int gray_geometry(const vpp_image_desc* dst, const vpp_image_desc* src, int mirr
   const int n_left = (lo - c_start + kGrayChunk - 1) / kGrayChunk;                                 // first chunk with c0 >= lo
   const int n_main = std::max(0, std::min(nchunks, (hi - c_start) / kGrayChunk) - n_left);            // chunks [n_left, n_left + n_main)
   const int nrows_out = dst->nrows + 2 * ext;
-  // rows kernel (3 channels, rows of at least one wave's worth of main chunks): rows = rows per wave (0: the lane-per-chunk kernel)
-  int rows = tuning("ingest.rows", 2);
-  if (rows != 1 && rows != 2 && rows != 4) rows = 0;
-  if (src->channels != 3 || n_main < 32 || !tuning("ingest.impl", 1)) rows = 0;
-  int bsz = rows ? 256 : tuning("ingest.block", 64);   // lane-per-chunk kernel, measured 4K: 256 threads 8.19 us, 128: 7.88, 64: 7.70 (more, shorter workgroups: the single resident round ends more evenly)
+  int bsz = tuning("ingest.block", frames >= 4 ? 256 : 64);
   if (bsz != 128 && bsz != 256) bsz = 64;
   const int edge_blocks = (int)(((long long)nrows_out * (nchunks - n_main) + bsz - 1) / bsz);
-  const int segs = (n_main + 63) / 64;
-  const long long units = rows ? (long long)((nrows_out + rows - 1) / rows) * segs : 0;
-  const long long main_blocks = rows ? (units + 3) / 4 : ((long long)nrows_out * n_main + bsz - 1) / bsz;
+  const long long main_blocks = ((long long)nrows_out * n_main + bsz - 1) / bsz;
   VPP_REQUIRE(edge_blocks + main_blocks < (1ll << 31) / kGrayBatchMax, VPP_ERR_UNSUPPORTED, "vpp_rgb_to_graylevel: image too large for one launch");
-  *g = GrayGeom{dimg(dst), dimg(src), ext, c_start, nchunks, n_left, n_main, edge_blocks, aligned16(dst) ? 1 : 0, bsz, src->channels, mirror ? 1 : 0, (unsigned)(edge_blocks + main_blocks),
-                rows, segs, units};
+  *g = GrayGeom{dimg(dst), dimg(src), ext, c_start, nchunks, n_left, n_main, edge_blocks, aligned16(dst) ? 1 : 0, bsz, src->channels, mirror ? 1 : 0, (unsigned)(edge_blocks + main_blocks)};
   return VPP_OK;
 }
 void* gray_kernel(const GrayGeom& g) {
-  if (g.rows) {
-    switch (g.rows) {
-      case 1: return g.mirror ? (void*)rgb3_to_gray_rows_kernel<1, true> : (void*)rgb3_to_gray_rows_kernel<1, false>;
-      case 4: return g.mirror ? (void*)rgb3_to_gray_rows_kernel<4, true> : (void*)rgb3_to_gray_rows_kernel<4, false>;
-      default: return g.mirror ? (void*)rgb3_to_gray_rows_kernel<2, true> : (void*)rgb3_to_gray_rows_kernel<2, false>;
-    }
-  }
   if (g.ch == 3) return g.mirror ? (void*)rgb_to_gray_kernel<3, true> : (void*)rgb_to_gray_kernel<3, false>;
   return g.mirror ? (void*)rgb_to_gray_kernel<4, true> : (void*)rgb_to_gray_kernel<4, false>;
 }
-// the kernels' argument lists share their first 11 entries; the rows kernel takes two more
-struct GrayArgs { void* a[13]; int n; };
-inline GrayArgs gray_args(GrayGeom& g, GrayBatch& frames) {
-  GrayArgs r{{&g.d, &g.s, &g.ext, &g.c_start, &g.nchunks, &g.n_left, &g.n_main, &g.edge_blocks, &g.vec_ok, &frames, &g.blocks_per_frame, &g.segs, &g.units}, g.rows ? 13 : 11};
-  return r;
-}
 int gray_launch(const GrayGeom& g0, const GrayBatch& fr, int n, hipStream_t st) {
   GrayGeom g = g0; GrayBatch frames = fr;
-  GrayArgs ga = gray_args(g, frames);
-  VPP_HIP_TRY(hipLaunchKernel(gray_kernel(g), dim3(g.blocks_per_frame * (unsigned)n), dim3((unsigned)g.bsz), ga.a, 0, st));
+  void* args[11] = {&g.d, &g.s, &g.ext, &g.c_start, &g.nchunks, &g.n_left, &g.n_main, &g.edge_blocks, &g.vec_ok, &frames, &g.blocks_per_frame};
+  VPP_HIP_TRY(hipLaunchKernel(gray_kernel(g), dim3(g.blocks_per_frame * (unsigned)n), dim3((unsigned)g.bsz), args, 0, st));
   return VPP_OK;
 }
 inline bool same_gray_geometry(const vpp_image_desc& a, const vpp_image_desc& b) {
@@ -290,9 +202,10 @@ bool coalesce_gray(IndependentCall& side, hipStream_t st, const vpp_image_desc* 
   c.frames.d[c.n] = (uint8_t*)dst->first_pixel; c.frames.s[c.n] = (const uint8_t*)src->first_pixel;
   c.n++;
   GrayGeom g = c.g; GrayBatch frames = c.frames;
-  GrayArgs ga = gray_args(g, frames);
+  if (gray_geometry(&c.d0, &c.s0, c.mirror, &g, c.n) != VPP_OK) { c.n = 0; return false; }   // (the workgroup size follows the number of frames the node carries)
+  void* args[11] = {&g.d, &g.s, &g.ext, &g.c_start, &g.nchunks, &g.n_left, &g.n_main, &g.edge_blocks, &g.vec_ok, &frames, &g.blocks_per_frame};
   hipKernelNodeParams kp{};
-  kp.func = gray_kernel(g); kp.gridDim = dim3(g.blocks_per_frame * (unsigned)c.n); kp.blockDim = dim3((unsigned)g.bsz); kp.sharedMemBytes = 0; kp.kernelParams = ga.a; kp.extra = nullptr;
+  kp.func = gray_kernel(g); kp.gridDim = dim3(g.blocks_per_frame * (unsigned)c.n); kp.blockDim = dim3((unsigned)g.bsz); kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
   if (hipGraphKernelNodeSetParams(c.node, &kp) != hipSuccess) { (void)hipGetLastError(); c.n = 0; return false; }
   side.absorbed_into(c.node, c.lane);
   return true;
@@ -346,7 +259,7 @@ extern "C" int vpp_rgb_to_graylevel_batch(const vpp_image_desc* dst, const vpp_i
   if (same) { const vpp_image_desc* srcs[1] = {src}; same = !batch_frames_interfere(n, dst, srcs, 1); }
   if (same) {
     GrayGeom g;
-    int rc = gray_geometry(&dst[0], &src[0], mirror, &g);
+    int rc = gray_geometry(&dst[0], &src[0], mirror, &g, std::min(n, kGrayBatchMax));
     if (rc != VPP_OK) return rc;
     for (int k = 0; k < n; k++) VPP_REQUIRE(dst[k].first_pixel != src[k].first_pixel, VPP_ERR_INVALID_ARG, "vpp_rgb_to_graylevel_batch: in-place not supported (frame %d)", k);
     for (int b0 = 0; b0 < n; b0 += kGrayBatchMax) {
