@@ -85,9 +85,9 @@ int vpp_stream_wait_event(void* stream, void* event);
  * duration of the last replay.  VPP_ERR_UNSUPPORTED when the runtime has no event-record nodes (retry with timed = 0).
  * Scratch rule: entry points that need device scratch (FAST-9, the flow, the tracker, local maxima) keep one grow-only buffer per (host thread, stream), and a
  * recorded call bakes that buffer's ADDRESS into the graph.  So (a) run a call once eagerly on the stream before recording it (a capture cannot allocate:
- * VPP_ERR_UNSUPPORTED says so), and (b) a later eager call on that stream that needs MORE scratch — or a 17th stream, which evicts the least recently used
- * buffer — frees the recorded buffer: every graph recorded before that is then refused by vpp_graph_launch (VPP_ERR_INVALID_ARG, "record it again") instead of
- * replaying into freed memory.
+ * VPP_ERR_UNSUPPORTED says so); (b) a later eager call on that stream that needs MORE scratch gets a new buffer and the recorded one stays alive for its graphs
+ * (until the host thread ends); (c) only a 17th stream on one host thread, which evicts the least recently used buffer, frees a recorded buffer: every graph
+ * recorded before that is then refused by vpp_graph_launch (VPP_ERR_INVALID_ARG, "record it again") instead of replaying into freed memory.
  * Device-side faults: a kernel whose in-kernel protocol gives up (the flow's grid barrier after ~4 s) raises a bit in ONE process-global sticky word; the first
  * vpp_sync / vpp_event_synchronize on ANY stream afterwards returns VPP_ERR_HIP once and clears it — the fault is reported to whoever synchronises first, not to
  * the stream that raised it, and never to a caller that only synchronises outside this ABI. */

@@ -450,32 +450,49 @@ def test_fast9_detect_async_and_graph_replay(lib, orc, mode):
     capi.check(lib.vpp_graph_destroy(graph))
 
 
-def test_graph_is_refused_after_its_scratch_buffer_was_reallocated(lib, orc):
+def test_graph_survives_a_larger_eager_call_and_is_refused_after_an_eviction(lib, orc):
     """A recorded call bakes its stream's scratch ADDRESS into the graph (include/vpp_amd.h, "Scratch rule").  A later eager call on that stream that needs a
-    larger buffer frees it: the old graph must be refused readably (VPP_ERR_INVALID_ARG), not replayed into freed memory (round-4 advisor finding); a graph
-    recorded afterwards runs, and equals the synchronous call."""
+    larger buffer must not free it (round-4 advisor finding: a replay was a use-after-free): the old buffer is retired alive, the graph keeps replaying with the
+    right result.  A 17th stream on the same host thread evicts the least recently used buffer — a recorded one is then really freed, and every older graph is
+    refused readably (VPP_ERR_INVALID_ARG) instead of replaying into freed memory; a graph recorded afterwards runs."""
     small = DeviceImage.from_host(u8_image(rects_image(120, 160, seed=3), border=3))
     big = DeviceImage.from_host(u8_image(rects_image(1080, 1920, seed=5), border=3))
     cap = 400000
     rc = torch.zeros((cap, 2), dtype=torch.int32, device="cuda"); sc = torch.zeros(cap, dtype=torch.int32, device="cuda")
     cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
     st = torch.cuda.Stream(); sp = ctypes.c_void_p(st.cuda_stream)   # a fresh stream: a fresh scratch slot, sized by the first call
-    call = lambda d: capi.check(lib.vpp_fast9_detect_async(P(d.desc), 20, None, 0, 10, 0, ctypes.c_void_p(rc.data_ptr()), ctypes.c_void_p(sc.data_ptr()), cap,
-                                                           ctypes.c_void_p(cnt.data_ptr()), sp))
+    call = lambda d, s=sp: capi.check(lib.vpp_fast9_detect_async(P(d.desc), 20, None, 0, 10, 0, ctypes.c_void_p(rc.data_ptr()), ctypes.c_void_p(sc.data_ptr()), cap,
+                                                                 ctypes.c_void_p(cnt.data_ptr()), s))
+    want_rc, want_sc = gpu_detect(lib, small, 20, mode=0, bs=10)
+
+    def check_replay(g):
+        rc.zero_(); cnt.zero_()
+        capi.check(lib.vpp_graph_launch(g, sp)); capi.check(lib.vpp_sync(sp))
+        n = int(cnt.item())
+        assert n == len(want_rc) and n > 20
+        np.testing.assert_array_equal(rc[:n].cpu().numpy(), want_rc)
     call(small); capi.check(lib.vpp_sync(sp))
     g1 = ctypes.c_void_p()
     capi.check(lib.vpp_graph_begin(sp)); call(small); capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(g1)))
-    capi.check(lib.vpp_graph_launch(g1, sp)); capi.check(lib.vpp_sync(sp))          # fine while the buffer lives
-    call(big); capi.check(lib.vpp_sync(sp))                                          # needs more scratch: the recorded buffer is freed
-    assert lib.vpp_graph_launch(g1, sp) == capi.ERR_INVALID_ARG and b"record it again" in lib.vpp_last_error()
+    check_replay(g1)
+    call(big); capi.check(lib.vpp_sync(sp))                       # needs more scratch: a new buffer, the recorded one is retired alive
+    check_replay(g1)
+    call(small); capi.check(lib.vpp_sync(sp)); check_replay(g1)   # (eager calls now live on the new buffer)
+    # 17 more streams on this thread: the 16 slots roll over, the recorded buffer of `st` (re-recorded below on the new buffer first) is evicted
     g2 = ctypes.c_void_p()
     capi.check(lib.vpp_graph_begin(sp)); call(small); capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(g2)))
-    capi.check(lib.vpp_graph_launch(g2, sp)); capi.check(lib.vpp_sync(sp))
-    n = int(cnt.item())
-    want_rc, want_sc = gpu_detect(lib, small, 20, mode=0, bs=10)
-    assert n == len(want_rc) and n > 20
-    np.testing.assert_array_equal(rc[:n].cpu().numpy(), want_rc)
-    capi.check(lib.vpp_graph_destroy(g1)); capi.check(lib.vpp_graph_destroy(g2))
+    others = [torch.cuda.Stream() for _ in range(17)]
+    for o in others:
+        call(small, ctypes.c_void_p(o.cuda_stream))
+    torch.cuda.synchronize()
+    assert lib.vpp_graph_launch(g2, sp) == capi.ERR_INVALID_ARG and b"record it again" in lib.vpp_last_error()
+    assert lib.vpp_graph_launch(g1, sp) == capi.ERR_INVALID_ARG   # conservative: every older graph
+    call(small); capi.check(lib.vpp_sync(sp))
+    g3 = ctypes.c_void_p()
+    capi.check(lib.vpp_graph_begin(sp)); call(small); capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(g3)))
+    check_replay(g3)
+    for g in (g1, g2, g3):
+        capi.check(lib.vpp_graph_destroy(g))
 
 
 def test_no_tuning_knob_changes_the_lk_summation_order(lib, orc):

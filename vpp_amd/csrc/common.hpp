@@ -177,9 +177,10 @@ class IndependentCall {
 // taken before the bump stops being believed.
 unsigned notes_epoch();
 void invalidate_scratch_notes();
-// Launch graphs hold the ADDRESS of the scratch buffer their calls were recorded on.  Whenever such a buffer (Slot::recorded) is freed — grown by a later, larger
-// eager call, or evicted — this generation is bumped; a vpp_graph remembers the generation it was recorded under and vpp_graph_launch refuses a stale one
-// (VPP_ERR_INVALID_ARG, "re-record") instead of replaying into freed memory.  Conservative: graphs that never touched that buffer are refused as well.
+// Launch graphs hold the ADDRESS of the scratch buffer their calls were recorded on.  A later, larger eager call on the stream gets a NEW buffer and the recorded
+// one is retired alive (Scratch::ensure), so those graphs keep replaying.  Only the eviction of a recorded buffer (a 17th stream on one host thread) frees it:
+// this generation is then bumped; a vpp_graph remembers the generation it was recorded under and vpp_graph_launch refuses a stale one (VPP_ERR_INVALID_ARG,
+// "record it again") instead of replaying into freed memory.  Conservative: graphs that never touched that buffer are refused as well.
 unsigned recorded_scratch_generation();
 void recorded_scratch_freed();
 
@@ -227,11 +228,12 @@ struct Scratch {
     }
     s->used = ++tick;
     if (bytes > s->cap) {
-      if (s->p) { VPP_HIP_TRY(hipStreamSynchronize(st)); if (s->recorded) recorded_scratch_freed(); VPP_HIP_TRY(hipFree(s->p)); s->p = nullptr; s->cap = 0; }
+      if (s->p && s->recorded) { retired.push_back(s->p); s->p = nullptr; s->cap = 0; }   // launch graphs hold this buffer's address: it stays alive (and is never handed out again) until the thread's scratch dies
+      if (s->p) { VPP_HIP_TRY(hipStreamSynchronize(st)); VPP_HIP_TRY(hipFree(s->p)); s->p = nullptr; s->cap = 0; }
       VPP_HIP_TRY(hipMalloc(&s->p, bytes));
       s->cap = bytes;
       for (unsigned long long& u : s->user) u = 0;
-      s->recorded = false;   // graphs recorded on the old buffer are invalid from here on (they hold its address): vpp_graph_launch refuses them (include/vpp_amd.h)
+      s->recorded = false;   // (graphs recorded on the old buffer keep replaying on it: retired above, not freed)
     }
     s->capturing = capturing;
     if (capturing) { s->recorded = true; for (unsigned long long& u : s->user) u = 0; }
@@ -251,7 +253,8 @@ struct Scratch {
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("scratch: hipFree failed: %s", hipGetErrorString(e)); return VPP_ERR_HIP; }
     return VPP_OK;
   }
-  ~Scratch() { for (Slot& c : slots) if (c.p) (void)hipFree(c.p); }
+  std::vector<void*> retired;   // buffers that launch graphs were recorded on and that a larger eager call has since replaced
+  ~Scratch() { for (Slot& c : slots) if (c.p) (void)hipFree(c.p); for (void* q : retired) (void)hipFree(q); }
 };
 
 // Sticky device-side error word (runtime.hip): one 32-bit word in pinned, device-visible host memory that kernels raise bits of when a device-side

@@ -557,8 +557,8 @@ int vpp_debug_graph_kernel_nodes(vpp_graph* gr, int* count) {
 int vpp_graph_launch(vpp_graph* gr, void* stream) {
   VPP_REQUIRE(gr && gr->exec, VPP_ERR_INVALID_ARG, "vpp_graph_launch: null");
   VPP_REQUIRE(gr->scratch_gen == recorded_scratch_generation(), VPP_ERR_INVALID_ARG,
-              "vpp_graph_launch: a scratch buffer that launch graphs were recorded on has been reallocated since this graph was recorded (a later eager call needed a larger "
-              "one, or more than 16 streams were in use): the graph may hold a freed address - record it again");
+              "vpp_graph_launch: a scratch buffer that launch graphs were recorded on has been evicted since this graph was recorded (more than 16 streams in use on "
+              "one host thread): the graph may hold a freed address - record it again");
   VPP_HIP_TRY(hipGraphLaunch(gr->exec, as_stream(stream)));
   return VPP_OK;
 }
