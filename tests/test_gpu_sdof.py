@@ -46,10 +46,7 @@ def run_both(lib, orc, f1, f2, kps, ws, nscales, min_scale, prop, patch):
 # The propagation sweeps' implementations: Jacobi rounds to the fixed point as ONE launch per sweep (default: round 0 in every workgroup, the rest on the last one to
 # finish), the same with every workgroup that has work staying for the rounds behind the grid barrier (the path of long tails, forced), classify + rounds as two launches
 # per sweep (the strips' / ranks' path), the lock-step wavefront on one workgroup (on-device cross-check).
-# Round 5: a job's descents run side by side on up to 8 groups of lanes (default); "fused_seq" = the sequential walk of rounds 1-4 (sdof.spread 1), "fused_grid_wide" =
-# everybody stays AND up to 256 workgroups run the rounds (sdof.max_stay), so the later rounds have lanes to spread over as well.
-SWEEP_IMPLS = {"fused": {}, "fused_seq": {b"sdof.spread": 1}, "fused_grid": {b"sdof.sweep_stay": 0}, "fused_grid_wide": {b"sdof.sweep_stay": 0, b"sdof.max_stay": 256},
-               "fused_tile16": {b"sdof.sweep_tile": 16}, "two_launches": {b"sdof.fused_sweep": 0}, "wavefront": {b"sdof.propagate": 1}}
+SWEEP_IMPLS = {"fused": {}, "fused_grid": {b"sdof.sweep_stay": 0}, "two_launches": {b"sdof.fused_sweep": 0}, "wavefront": {b"sdof.propagate": 1}}
 
 
 def set_sweep_impl(lib, name):

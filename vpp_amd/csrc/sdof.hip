@@ -519,12 +519,14 @@ __device__ __forceinline__ void raise_barrier_timeout(const RoundArrays& a) {
   if (a.err) __hip_atomic_fetch_or(a.err, (unsigned)kDevErrSweepBarrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ unsigned g_round_stats[4];   // [0] rounds, [1] jobs, [2] jobs evaluated, [3] changes
-// diagnostics (stats == 1 only): a log of the fused sweeps' rounds — {sweep launch, round, jobs of that round, 100 MHz wall clock} per entry, the launch's start as round 255
-__device__ unsigned long long g_sweep_log[512];
+// diagnostics (stats == 1 only, tools/sweep_log.py): a log of the fused sweeps — {code, count, 100 MHz wall clock} per entry.  code 255: a launch starts (count =
+// workgroups); 253 / 252: a workgroup with `count` candidates has classified its tile / finished round 0 on them; 1..250: the size of that round is published;
+// 254: `count` workgroups run the rounds; 251: workgroup `ticket` (count >> 8) has finished its share of round (count & 255)
+__device__ unsigned long long g_sweep_log[4096];
 __device__ unsigned g_sweep_log_n;
-__device__ __forceinline__ void sweep_log(unsigned round, unsigned n) {
+__device__ __forceinline__ void sweep_log(unsigned code, unsigned n) {
   const unsigned i = atomicAdd(&g_sweep_log_n, 1u);
-  if (i < 512) g_sweep_log[i] = ((unsigned long long)round << 56) | ((unsigned long long)(n & 0xFFFFFFu) << 32) | (unsigned long long)(unsigned)wall_clock64();
+  if (i < 4096) g_sweep_log[i] = ((unsigned long long)code << 56) | ((unsigned long long)(n & 0xFFFFFFu) << 32) | (unsigned long long)(unsigned)wall_clock64();
 }
 
 
@@ -586,20 +588,13 @@ __device__ __forceinline__ void enqueue_targets(const RoundArrays& a, SweepCtl* 
 // *changed_out: the cell's value differs from S_{k-1}(cell).  clear_flag: the cell came out of round k's queue (its flag is handed back).
 // MAPS: the value also goes into the maps (sdof_rounds_kernel: every round writes them, ordered by the barriers' releases; sdof_sweep_kernel has no releases —
 // two rounds' plain stores to one cell from two XCDs could reach memory in either order — and writes the maps once, at the end of the sweep).
-// ns / sub (round 5): the job runs on ns = 1, 2, 4 or 8 groups of 8 lanes (8 ns consecutive lanes of one wave), `sub` = this lane's group.  A cell's descents are
-// walked one after the other by the reference (:160-187), and a sweep round lasts as long as its longest such chain — up to 8 descents of up to 5 dependent search
-// steps while the chip idles (4 % of the VALU issue cycles).  But a descent from neighbour kk depends on the cell and on kk's flow and first distance only, NOT on
-// the running best: so the groups of a job run the descents of DIFFERENT neighbours side by side — for every neighbour that can pass the tests at all (marked,
-// different from prev_flow, d2 below the cell's starting distance: the running best only ever falls, a neighbour that fails this never passes later) — and the
-// reference's sequence of tests and updates is then replayed on the finished results, in order, without touching an image.  Same decisions, same values; some
-// descents are computed that the sequential walk would have skipped.  Every group loads the job's operands itself (no hand-off); group 0 writes and enqueues.
 template <int WS, bool MAPS>
 __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws, const Maps& m, int patch, int forward, int NI, int NJ, const RoundArrays& a, int k,
                                          const Cell* __restrict__ Bprev, Cell* __restrict__ Bcur, int cell, int j, uint4* __restrict__ slot, int stats, bool clear_flag,
-                                         bool* changed_out, int ns = 1, int sub = 0) {
+                                         bool* changed_out) {
   const int par = k & 1;
   const int ci = cell / NJ, cj = cell - ci * NJ;
-  if (clear_flag && j == 0 && sub == 0) store_u32_sc1(a.qflag[par] + cell, 0u);   // set by whoever enqueued the cell for this round (nobody enqueues for round k during round k)
+  if (clear_flag && j == 0) store_u32_sc1(a.qflag[par] + cell, 0u);   // set by whoever enqueued the cell for this round (nobody enqueues for round k during round k)
   const Cell pre = load_cell16(a.pre + cell);   // (nobody writes `pre` during a sweep: plain loads)
   const Cell old = load_cell_sc1(Bprev + cell);
   // lane j holds neighbour j in loop_body's order: (-1,-1) (-1,0) (-1,1) (0,-1) (0,1) (1,-1) (1,0) (1,1)
@@ -645,47 +640,8 @@ __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws,
   // is at.  (With one loop over kk for the whole wave, a descent was executed once per kk at which ANY of the 8 groups needed one — up to 8
   // descents of up to 5 dependent search steps per wave, most lanes idle: a round lasted as long as that chain, ~17 us on the 4K bench scene.)
   // Per group the sequence of tests, descents and updates is exactly the sequential one.
-  if (ns > 1) {
-    // ---- the job's descents side by side on its ns groups, then the reference's walk replayed on the results ----
-    unsigned q = 0;   // bit kk: neighbour kk can pass the tests at :164-170 at all
-#pragma unroll
-    for (int kk = 0; kk < 8; kk++) {
-      const int ok = __shfl((int)okb, kk, 8), d2k = __shfl(d2, kk, 8);
-      if (need_walk && ok && d2k < cur.dist) q |= 1u << kk;
-    }
-    GdMatch mine{0, 0, INT_MAX};   // lane kk of the group that ran neighbour kk's descent keeps its result
-    unsigned rest = q;
-    int seen = 0;
-    for (;;) {
-      int kk = -1;   // this group's next neighbour: the seen-th set bit of q with seen % ns == sub
-      while (rest) {
-        const int b = __ffs(rest) - 1;
-        rest &= rest - 1;
-        if ((seen++ & (ns - 1)) == sub) { kk = b; break; }
-      }
-      if (!__ballot(kk >= 0)) break;   // no group of this wave has a descent left
-      if (kk >= 0) {
-        const int n0 = __shfl(nb.f0, kk, 8), n1 = __shfl(nb.f1, kk, 8), d2k = __shfl(d2, kk, 8);
-        GdMatch g;
-        if constexpr (WS != 0) g = group_descent_staged<WS>(wa, a_ok, i2, r, c, r + n0, c + n1, true, d2k, j, slot, dist);
-        else g = group_descent(dist, r, c, r + n0, c + n1, d2k, j);
-        if (j == kk) mine = g;
-      }
-    }
-    // the walk, on every lane of the job alike: neighbour kk's result sits in lane kk of group (rank of kk in q) % ns
-    const int job_lane0 = (int)__lane_id() - sub * 8 - j;
-#pragma unroll
-    for (int kk = 0; kk < 8; kk++) {
-      const int owner = __popc(q & ((1u << kk) - 1u)) & (ns - 1);
-      const int src = job_lane0 + owner * 8 + kk;
-      const int g0 = __shfl(mine.f0, src), g1 = __shfl(mine.f1, src), gd = __shfl(mine.distance, src);
-      const int n0 = __shfl(nb.f0, kk, 8), n1 = __shfl(nb.f1, kk, 8), d2k = __shfl(d2, kk, 8);
-      const int a0 = cur.f0 - n0, a1 = cur.f1 - n1;
-      if (((q >> kk) & 1u) && a0 * a0 + a1 * a1 >= 9 && d2k < cur.dist && gd < cur.dist) { cur.mark = 1; cur.f0 = g0; cur.f1 = g1; cur.dist = gd; }   // :164-184
-    }
-  }
   int kk = 0;
-  for (; ns == 1;) {
+  for (;;) {
     bool found = false;
     int n0 = 0, n1 = 0, d2k = 0;
     while (need_walk && kk < 8) {
@@ -704,7 +660,7 @@ __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws,
     }
   }
   const bool changed = cur.f0 != old.f0 || cur.f1 != old.f1 || cur.dist != old.dist || cur.mark != (old.mark & 0xFF);
-  if (j == 0 && sub == 0) {
+  if (j == 0) {
     store_cell_sc1(Bcur + cell, Cell{cur.f0, cur.f1, cur.dist, cur.mark | (changed ? (k + 1) << kTagShift : 0)});
     if constexpr (MAPS) {
       int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;
@@ -712,9 +668,9 @@ __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws,
     }
     if (stats == 1) { atomicAdd(&g_round_stats[1], 1u); if (need) atomicAdd(&g_round_stats[2], 1u); if (changed) atomicAdd(&g_round_stats[3], 1u); }
   }
-  *changed_out = changed && sub == 0;
+  *changed_out = changed;
   int target = -1;
-  if (changed && sub == 0) {   // next round: this cell (its value must reach the other buffer) and the marked cells that read it as an earlier neighbour
+  if (changed) {   // next round: this cell (its value must reach the other buffer) and the marked cells that read it as an earlier neighbour
     if (j == (forward ? 0 : 7)) target = cell;                       // one of the earlier-neighbour lanes speaks for the cell itself
     else if (!earlier && in && nbm) target = q0 * NJ + q1;
   }
@@ -831,29 +787,28 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
 // ticket 0 zeroes the control block after the last acknowledgement.
 constexpr unsigned kStayThreshold = kJobsPerGroup;   // (a round that fits one batch is run by one workgroup anyway)
 constexpr unsigned kMaxStay = 48;
-constexpr int kSweepTile = 16;   // a workgroup's cells: a TILE x TILE tile of the sweep domain, 16 or 8 (round 5: 8 where the grid stays small, see the launch site) ( (a motion boundary along a row of cells would hand one workgroup of 256 consecutive
+constexpr int kSweepTile = 16;   // a workgroup's cells: a 16 x 16 tile of the sweep domain (a motion boundary along a row of cells would hand one workgroup of 256 consecutive
                                  // cells 256 candidates, 8 passes of round 0 one after the other: measured 90 us for the middle scale of the 4K bench scene)
 constexpr unsigned kGenFinal = 0xFFFFFFFFu;   // round field of the message that ends the sweep for parked workgroups
 
-template <int WS, int TILE>
-__global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats, int nsub, unsigned stay_above, unsigned max_stay, unsigned spread_max) {
-  static_assert(TILE * TILE <= 256, "one lane classifies one cell");
-  if (stats == 1 && blockIdx.x == 0 && threadIdx.x == 0) sweep_log(255u, gridDim.x);
+template <int WS>
+__global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats, int nsub, unsigned stay_above) {
   __shared__ unsigned s_val, s_nreg, s_flags, s_ncand, s_flushn, s_giveup;
   __shared__ unsigned long long s_gen;
   __shared__ uint32_t s_cand[256];
   __shared__ uint4 s_union[kJobsPerGroup][kUnionRows];   // per 8-lane group: the candidate patch of a descent step (group_descent_staged)
   SweepCtl* const ctl = a.ctl;
   const int tid = threadIdx.x, j = tid & 7;
+  if (stats == 1 && blockIdx.x == 0 && tid == 0) sweep_log(255u, gridDim.x);
   if (tid == 0) { s_ncand = 0; s_giveup = 0; }
   __syncthreads();
   {  // ---- this workgroup's cells: which of them can loop_body change at all (sdof_classify_kernel's test, on the records)
-    const int tiles_x = (NJ + TILE - 1) / TILE;
+    const int tiles_x = (NJ + kSweepTile - 1) / kSweepTile;
     const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
-    const int ci = ty * TILE + tid / TILE, cj = tx * TILE + tid % TILE;
+    const int ci = ty * kSweepTile + tid / kSweepTile, cj = tx * kSweepTile + tid % kSweepTile;
     const int idx = ci * NJ + cj;
     bool cand = false;
-    if (tid < TILE * TILE && ci < NI && cj < NJ) {
+    if (ci < NI && cj < NJ) {
       const Cell cur = load_cell16(a.pre + idx);
       if (cur.mark & 0xFF) {
 #pragma unroll
@@ -880,17 +835,15 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   }
   __syncthreads();
   const unsigned n0 = s_ncand;
-  // groups per job (round_job: ns): as many as the workgroup's 32 groups allow for its candidates
-  const int spread = (int)spread_max;
-  const int ns0 = spread <= 1 ? 1 : min(spread, n0 <= 4 ? 8 : (n0 <= 8 ? 4 : (n0 <= 16 ? 2 : 1)));
+  if (stats == 1 && tid == 0 && n0) sweep_log(253u, n0);
   // ---- round 0 on this workgroup's candidates: reads `pre` (and B[1], equal to it), writes B[0], round 1's queue and the list of changes
-  for (unsigned base = 0; base < n0; base += (unsigned)(kJobsPerGroup / ns0)) {
-    const unsigned job = base + (unsigned)((tid >> 3) / ns0);
+  for (unsigned base = 0; base < n0; base += (unsigned)kJobsPerGroup) {
+    const unsigned job = base + (unsigned)(tid >> 3);
     int target = -1, chg = -1;
     if (job < n0) {
       const int cell = (int)s_cand[job];
       bool changed;
-      target = round_job<WS, false>(i1, i2, ws, m, patch, forward, NI, NJ, a, 0, a.B[1], a.B[0], cell, j, s_union[tid >> 3], stats, false, &changed, ns0, (tid >> 3) & (ns0 - 1));
+      target = round_job<WS, false>(i1, i2, ws, m, patch, forward, NI, NJ, a, 0, a.B[1], a.B[0], cell, j, s_union[tid >> 3], stats, false, &changed);
       if (changed && j == 0) chg = cell;
     }
     enqueue_targets(a, ctl, 1, target);
@@ -899,6 +852,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   // ---- arrive; everybody but the last arriver and the stayers leaves
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (stats == 1 && tid == 0 && n0) sweep_log(252u, n0);
   if (tid == 0) {
     unsigned flags = 0, ticket = 0;
     // (what this workgroup wrote for the others — records, queue, lists — went out as write-through stores and every wave has waited for its own: no release)
@@ -909,7 +863,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
       // else orders them — an arrival that overtook the registration would let the last arriver read a short `reg` and publish a wrong nreg.  A returning atomic
       // has been performed when its value is back: wait for it (stayers only; the asm form, because the compiler drops waits it believes redundant).
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (t < max_stay) { ticket = t; flags |= 1u; }
+      if (t < kMaxStay) { ticket = t; flags |= 1u; }
     }
     // Two-level arrival: returning atomics on ONE word retire at ~11 ns each (1 300 workgroups at the finest 4K scale: 14 us, measured 30 us per empty sweep); the
     // workgroups arrive on nsub counters, 128 bytes apart, and the last one of each (which also hands its counter back zeroed) on ctl->done.
@@ -928,7 +882,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
     unsigned long long g;
     if (flags & 2u) {   // round 0 is complete everywhere (what the others wrote is read with L1-bypassing loads: no acquire)
       const unsigned n1 = __hip_atomic_load(&ctl->count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned R = min(__hip_atomic_load(&ctl->reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), max_stay);
+      const unsigned R = min(__hip_atomic_load(&ctl->reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kMaxStay);
       unsigned N = R;
       if (!(flags & 1u)) { ticket = R; N = R + 1; }
       __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -969,17 +923,13 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
     Cell* __restrict__ Bcur = a.B[par];
     const uint32_t* __restrict__ Qcur = a.Q[par];
     const unsigned stride = solo ? 1u : N0;
-    // groups per job: what the round's workgroups have to spare for its n jobs (the same number on every one of them: n and N0 are common knowledge)
-    const unsigned room = (solo ? 1u : N0) * (unsigned)kJobsPerGroup / n;   // (n != 0 here)
-    const int nsr = spread <= 1 ? 1 : min(spread, room >= 8u ? 8 : (room >= 4u ? 4 : (room >= 2u ? 2 : 1)));
-    const unsigned jpb = (unsigned)(kJobsPerGroup / nsr);   // jobs per batch
-    for (unsigned batch = solo ? 0u : ticket; batch * jpb < n; batch += stride) {
-      const unsigned job = batch * jpb + (unsigned)((tid >> 3) / nsr);
+    for (unsigned batch = solo ? 0u : ticket; batch * (unsigned)kJobsPerGroup < n; batch += stride) {
+      const unsigned job = batch * (unsigned)kJobsPerGroup + (unsigned)(tid >> 3);
       int target = -1, chg = -1;
-      if (job < n && (unsigned)((tid >> 3) / nsr) < jpb) {
+      if (job < n) {
         const int cell = (int)load_u32_sc1(Qcur + job);
         bool changed;
-        target = round_job<WS, false>(i1, i2, ws, m, patch, forward, NI, NJ, a, k, Bprev, Bcur, cell, j, s_union[tid >> 3], stats, true, &changed, nsr, (tid >> 3) & (nsr - 1));
+        target = round_job<WS, false>(i1, i2, ws, m, patch, forward, NI, NJ, a, k, Bprev, Bcur, cell, j, s_union[tid >> 3], stats, true, &changed);
         if (changed && j == 0) chg = cell;
       }
       enqueue_targets(a, ctl, par ^ 1, target);
@@ -987,6 +937,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (stats == 1 && tid == 0) sweep_log(251u, (unsigned)k | (ticket << 8));
     if (tid == 0) {
       unsigned long long g;
       if (solo) {   // this workgroup's own stores and atomics only: in order, through its own L1
@@ -1420,22 +1371,10 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
           const int grid = std::min(tuning("sdof.rounds_grid", 256), (cells + kJobsPerGroup - 1) / kJobsPerGroup);
           for (int Ki = 0; Ki < propagation; Ki++) {
             if (fused_sweeps) {   // one launch per sweep: every workgroup classifies its tile of cells and runs round 0 on them, the last one to finish runs the rest
-              // A workgroup runs round 0 for its own tile's candidates, 32 per pass: along a motion boundary a 16 x 16 tile holds 60+ of them (three passes of ~8 us
-              // on one workgroup while the chip idles: the middle scale of the 4K bench scene, 52 us for the sweep).  8 x 8 tiles quarter the longest list; they are
-              // taken where their number still fits one resident generation of workgroups (finer grids pay more in arrivals than the balance returns).
-              const unsigned max_stay = (unsigned)std::max(1, std::min(tuning("sdof.max_stay", (int)kMaxStay), 1024));
-              const unsigned spread_max = (unsigned)tuning("sdof.spread", 8);   // groups per job at most (1: the sequential walk of rounds 1-4)
-              const int want_tile = tuning("sdof.sweep_tile", 0);
-              const int tiles8 = ((NI + 7) / 8) * ((NJ + 7) / 8);
-              const int tile = want_tile == 8 || want_tile == 16 ? want_tile : (tiles8 <= 2048 ? 8 : kSweepTile);
-              const int tiles = ((NI + tile - 1) / tile) * ((NJ + tile - 1) / tile);
+              const int tiles = ((NI + kSweepTile - 1) / kSweepTile) * ((NJ + kSweepTile - 1) / kSweepTile);
               const int nsub = std::max(1, std::min(kSubCounters, tiles / 16));
-              if (tile == 8)
-                sdof_sweep_kernel<WS, 8><<<tiles, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs, tuning("sdof.stats", 0), nsub,
-                                                                (unsigned)tuning("sdof.sweep_stay", (int)kStayThreshold), max_stay, spread_max);
-              else
-                sdof_sweep_kernel<WS, kSweepTile><<<tiles, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs, tuning("sdof.stats", 0), nsub,
-                                                                         (unsigned)tuning("sdof.sweep_stay", (int)kStayThreshold), max_stay, spread_max);
+              sdof_sweep_kernel<WS><<<tiles, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs, tuning("sdof.stats", 0), nsub,
+                                                                  (unsigned)tuning("sdof.sweep_stay", (int)kStayThreshold));
               continue;
             }
             sdof_classify_kernel<<<(cells + 255) / 256, 256, 0, st>>>(maps(0, scale), NI, NJ, rs);
@@ -1515,10 +1454,10 @@ extern "C" int vpp_semi_dense_optical_flow_sharded(vpp_comm* comm, const vpp_ima
 }
 
 // diagnostics (not part of include/vpp_amd.h): counters of the propagation rounds, enabled by tuning "sdof.stats"
-// diagnostics (not part of include/vpp_amd.h): the round log of the fused sweeps since the last reset (tools/sweep_log.py); returns the entry count through *n
-extern "C" int vpp_debug_sdof_sweep_log(unsigned long long* out512, unsigned* n, int reset) {
+// diagnostics (not part of include/vpp_amd.h): the log of the fused sweeps since the last reset (tools/sweep_log.py); 4096 entries, the count through *n
+extern "C" int vpp_debug_sdof_sweep_log(unsigned long long* out4096, unsigned* n, int reset) {
   VPP_HIP_TRY(hipDeviceSynchronize());
-  VPP_HIP_TRY(hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_sweep_log), 512 * sizeof(unsigned long long)));
+  VPP_HIP_TRY(hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_sweep_log), 4096 * sizeof(unsigned long long)));
   VPP_HIP_TRY(hipMemcpyFromSymbol(n, HIP_SYMBOL(g_sweep_log_n), sizeof(unsigned)));
   if (reset) { unsigned z = 0; VPP_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_log_n), &z, sizeof z)); }
   return VPP_OK;
