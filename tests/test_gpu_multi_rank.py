@@ -40,14 +40,14 @@ def run_ranks(exe, world, args, timeout=300):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])   # 8: the node's rank count — 1 250 keypoints per rank of configs[3]'s 10 000
 def test_pyrlk_keypoint_shards_and_rccl_all_gather_two_ranks_one_gpu(world):
     res = run_ranks(os.path.join(ROOT, "benchmarks", "pyrlk_shard_bench"), world, [3, 10000])
     assert res["mismatched_vs_single_rank"] == 0, res
     assert res["keypoints_per_rank"] == -(-10000 // world)
 
 
-@pytest.mark.parametrize("world,shape", [(2, (480, 640)), (3, (540, 960)), (2, (2160, 3840))])
+@pytest.mark.parametrize("world,shape", [(2, (480, 640)), (3, (540, 960)), (2, (2160, 3840)), (8, (480, 640)), (8, (1120, 1280))])   # 8 ranks (the node), strips of 60 and 140 rows
 def test_flow_strips_halo_exchange_and_map_gathers_two_ranks_one_gpu(world, shape):
     """Row exchange + sharded semi-dense flow + halo exchange + FAST-9 on strips: identical to the single-rank calls (BASELINE configs[4] at 4K)."""
     res = run_ranks(os.path.join(ROOT, "benchmarks", "flow_strip_bench"), world, [2, shape[0], shape[1]], timeout=600)
