@@ -76,7 +76,9 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
            "tracks_per_s": NK / (wall / steps), "ms_per_frame": wall / steps * 1e3, "keypoints_per_rank": n_local,
            "exchange": "rccl all_gather of 20-byte keypoint records" if world > 1 else "none (1 GPU)"}
 
-    res["roofline"] = issue_roofline("pyrlk_match_group_kernel<7, 16,")
+    # the instance the library launches for this many keypoints per rank (pyrlk.hip: 16 lanes per keypoint from 8 000, 32 from 3 500, 64 below)
+    lpk = 8 if n_local >= 80000 else (16 if n_local >= 8000 else (32 if n_local >= 3500 else 64))
+    res["roofline"] = issue_roofline(f"pyrlk_match_group_kernel<7, {lpk},")
 
     # keypoint-count sweep on one GPU (where tracks/s saturates; 1 250 = what one of 8 ranks sees of the 10 k keypoints of configs[3])
     if world == 1:
