@@ -1,6 +1,6 @@
 // overlap_lab.hip — how can CONSECUTIVE, INDEPENDENT 4K launches overlap their ramps and tails?  GPU box only; measurement tooling, not product.
 // The reference's call form is one frame per call (benchmarks/box_5x5_filter2.cc:43-69); a 50 MB launch pays ~4.6 us of ramp + drain behind a kernel
-// boundary, so one launch per frame reaches 47 % of the HBM peak where 64 frames in one launch reach 70-75 %.
+// boundary, so one launch per frame reaches 47 % of the HBM peak where 64 frames in one launch reach 70-75 % (LABNOTES.md section 5).
 // This program times the same 256 per-frame calls of the product library (vpp_box_filter on 64 rotating 4K vuchar3 frame sets = 1.6 GB + 1.6 GB)
 //   defaults    recorded with the library's defaults: consecutive unrelated calls fold into one batched node at record time (box.hip, coalesce_frame)
 //   serial      one stream, eager / recorded into a graph with launch.capture_width = 1 (every node behind the previous one)

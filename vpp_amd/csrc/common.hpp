@@ -135,7 +135,7 @@ inline bool batch_frames_interfere(int n, const vpp_image_desc* dst, const vpp_i
 
 // ---- independent calls recorded side by side -------------------------------------------------------------------------------------------------------
 // A stream orders every call behind the one before it, and a 4K streaming launch pays ~4.6 us of ramp and drain that the next launch cannot hide
-// behind a kernel boundary (one 50 MB launch per call reaches 47 % of the HBM peak, 64 frames in one launch 70-75 %).  When a
+// behind a kernel boundary (LABNOTES.md section 5: one 50 MB launch per call reaches 47 % of the HBM peak, 64 frames in one launch 70-75 %).  When a
 // stream is being RECORDED into a launch graph, the order only has to hold where data flows: a call that brackets its launches with an
 // IndependentCall — stating the byte extents it writes and reads — is recorded behind (a) whatever the stream depended on when the window opened
 // (work of callers this library cannot see), (b) the last recorded call of its lane (at most `launch.capture_width` calls side by side) and (c) every

@@ -23,7 +23,7 @@
 //                            workgroup sums the per-workgroup counts before it: no scan launch) gives the output index, so the list comes out row-major (pixels / blocks) like the serial reference,
 //                            which the OpenMP reference itself does not guarantee.  4K, 454k corners: RAW
 //                            5 + 5 + 12 us, LOCAL 18 + 5 + 6 us, BLOCKWISE 13 + 5 + 6 us after the 30 us detect kernel.
-// VALU-bound (the ring test is ~100 lane-ops per pixel against 1 B/px of HBM traffic); see DESIGN.md.
+// VALU-bound (the ring test is ~100 lane-ops per pixel against 1 B/px of HBM traffic); see LABNOTES.md section 3.
 #include "common.hpp"
 #include "tracker_device.hpp"
 #include <mutex>

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
 
 // ---- a whole sweep in ONE launch (round 4) -------------------------------------------------------------------------------------------------------------
 // sdof_classify_kernel + sdof_rounds_kernel are two dependent launches per sweep, 12 of the 18 of a 3-scale pair, and a dependent launch costs ~4.5 us
-// whatever it does.  Fusing them behind an in-kernel grid barrier was measured slower: on this chip the barrier costs more than
+// whatever it does.  Fusing them behind an in-kernel grid barrier was measured slower (LABNOTES.md section 3, K12): on this chip the barrier costs more than
 // the boundary.  This kernel has NO barrier on its common path:
 //   * the cells' records (`pre`, B[0], B[1] of the scale: Mirrors) are kept equal to the maps BETWEEN sweeps by everyone who writes the maps — the reset
 //     launch (mark 0), the descents, and the end of every sweep (the changed cells are written back) — so there is no copy pass, and the pre-sweep values
