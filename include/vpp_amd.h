@@ -147,7 +147,9 @@ int vpp_box_filter_batch(const vpp_image_desc* dst, const vpp_image_desc* src, i
  * its result overlaps no pending operand; bordered extents); otherwise the window is launched first.  The window is also launched when it holds 64 frames, by
  * vpp_flush, and before ANYTHING else the same thread queues through this ABI — every entry point that takes a stream (copies, events, vpp_sync, graphs, every
  * kernel) and vpp_free — so stream order, results and what a vpp_sync waits for are exactly those of the plain calls.  What is NOT covered: work queued on the
- * stream by other means (raw HIP calls) or from another host thread before a vpp_flush.  Frames the batched kernels do not serve, and calls on a stream that is
+ * stream by other means (raw HIP calls) or from another host thread before a vpp_flush — so a thread calls vpp_flush before it ends, before it hands the stream to another
+ * thread, and before it releases an image's memory by any other means than vpp_free.  A window belongs to the device that was current when it opened; it is launched there
+ * whatever device is current later.  Frames the batched kernels do not serve, and calls on a stream that is
  * being recorded into a launch graph (record-time batching does the same job there), run as the plain call at once.
  * The C++ drop-in surface (vpp/core/pixel_wise.hh: ops::box_mean, ops::add/sub; colorspace_conversions.hh) calls these: a frame loop written like the
  * reference's reaches the batch rate (4K vuchar3 box5x5: 8.3 us per frame instead of 13.5).  A launch failure of a window that another call flushed is reported

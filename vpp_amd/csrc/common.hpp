@@ -53,6 +53,7 @@ struct DeferWindow {
   int kind = kDeferNone, p0 = 0, p1 = 0;   // the entry point and its scalar parameters (box: R, C; binary: op; gray: mirror)
   int nsrc = 0;
   void* stream = nullptr;
+  int dev = 0;                     // the device that was current when the window opened (its stream's device)
   unsigned long long flushes = 0;  // batches launched for this thread so far (vpp_deferred_flushes: the C++ surface throttles per batch, not per call)
   int last_rc = VPP_OK;            // of a flush that another call triggered: reported by the next vpp_flush / vpp_sync of this thread
   vpp_image_desc dst[kDeferMax], src[2][kDeferMax];

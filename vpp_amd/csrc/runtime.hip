@@ -64,12 +64,16 @@ int defer_flush() {
   if (!n) return VPP_OK;
   w.n = 0;   // first: the batch entry points call as_stream() themselves
   int rc = VPP_OK;
+  int cur = w.dev;
+  if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = w.dev; }
+  if (cur != w.dev && hipSetDevice(w.dev) != hipSuccess) { (void)hipGetLastError(); w.flushes++; w.last_rc = VPP_ERR_HIP; set_error("deferred calls: cannot return to device %d to launch them", w.dev); return VPP_ERR_HIP; }
   switch (w.kind) {
     case kDeferBox: rc = vpp_box_filter_batch(w.dst, w.src[0], n, w.p0, w.p1, w.stream); break;
     case kDeferBinary: rc = vpp_pixelwise_binary_batch(w.p0, w.dst, w.src[0], w.src[1], n, w.stream); break;
     case kDeferGray: rc = vpp_rgb_to_graylevel_batch(w.dst, w.src[0], n, w.p0, w.stream); break;
     default: break;
   }
+  if (cur != w.dev) (void)hipSetDevice(cur);   // the caller has moved to another device since: back to it
   w.flushes++;
   if (rc != VPP_OK) w.last_rc = rc;
   return rc;
@@ -84,8 +88,10 @@ inline bool extents_overlap(const Extent& a, const Extent& b) { return a.lo < b.
 int defer_call(int kind, int p0, int p1, void* stream, const vpp_image_desc* dst, const vpp_image_desc* src0, const vpp_image_desc* src1) {
   DeferWindow& w = g_defer;
   int rc = VPP_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
   if (w.n) {
-    bool join = w.kind == kind && w.p0 == p0 && w.p1 == p1 && w.stream == stream && same_frame_geometry(*dst, w.dst[0]) && same_frame_geometry(*src0, w.src[0][0]) &&
+    bool join = w.dev == dev && w.kind == kind && w.p0 == p0 && w.p1 == p1 && w.stream == stream && same_frame_geometry(*dst, w.dst[0]) && same_frame_geometry(*src0, w.src[0][0]) &&
                 (!src1 || same_frame_geometry(*src1, w.src[1][0]));
     if (join) {   // no data flow between this frame and a pending one (reads of one source by several frames are fine)
       const Extent d = extent_of(*dst), s0 = extent_of(*src0), s1 = src1 ? extent_of(*src1) : Extent{0, 0};
@@ -97,7 +103,7 @@ int defer_call(int kind, int p0, int p1, void* stream, const vpp_image_desc* dst
     }
     if (!join) rc = defer_flush();
   }
-  if (!w.n) { w.kind = kind; w.p0 = p0; w.p1 = p1; w.stream = stream; w.nsrc = src1 ? 2 : 1; }
+  if (!w.n) { w.kind = kind; w.p0 = p0; w.p1 = p1; w.stream = stream; w.dev = dev; w.nsrc = src1 ? 2 : 1; }
   w.dst[w.n] = *dst; w.src[0][w.n] = *src0; if (src1) w.src[1][w.n] = *src1;
   w.n++;
   if (w.n == kDeferMax) { const int r2 = defer_flush(); if (rc == VPP_OK) rc = r2; }
