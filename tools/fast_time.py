@@ -7,6 +7,7 @@ from vpp_amd.synth import P, u8_image, DeviceImage, rects_image, fast9_bench_fra
 from vpp_amd import capi
 V = ctypes.c_void_p
 if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]
+if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]
 lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
 im = u8_image(fast9_bench_frame(), border=3)
 im.view(with_border=True)[..., 0] = np.pad(im.view()[..., 0], 3, mode="symmetric")
