@@ -5,7 +5,7 @@
 # Run on the GPU box from the repo root: bash tools/profile_round.sh <tag>; outputs under gpurun_out/prof_<tag>.
 # Every rocprofv3 run is its own process with --kernel-trace + --pmc only (no other trace domains) and a timeout.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -2,7 +2,7 @@
 # Summarise gpurun_out/prof_<tag> (written by tools/profile_round.sh, same call, on the GPU box) into <dest> (default profiles/);
 # the summaries are then copied into the tracked profiles/ directory.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 D=${2:-profiles}
 P=gpurun_out/prof_$TAG
 { echo "# Round ${TAG#r} — rocprofv3 --kernel-trace --stats of \`python bench.py --no-cpu\` (defaults: 500 steps, 50 warm-up), of the driver's"
@@ -22,3 +22,4 @@ tail -1 $P/bench_under_rocprof.json > $D/${TAG}_bench_under_rocprof.json
 tail -1 $P/bench_s20_under_rocprof.json > $D/${TAG}_bench_s20_under_rocprof.json
 python tools/make_traffic_json.py $P/pmc_fetch/p_results.db $P/pmc_write/p_results.db $D/${TAG}_traffic.json > /dev/null
 python tools/make_issue_json.py $D/${TAG}_issue.json $P/pmc_busy/p_results.db $P/pmc_wait/p_results.db $P/pmc_sq/p_results.db $P/pmc_busy_algos/p_results.db $P/pmc_wait_algos/p_results.db $P/pmc_sq_algos/p_results.db > /dev/null
+echo $TAG > $D/CURRENT   # the round whose summaries describe this tree: what bench.py's static roofline quotes read (bench_pyrlk.py: profile_round)
