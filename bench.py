@@ -364,6 +364,29 @@ def main():
         lib.vpp_graph_destroy(gh)
         return sorted(ts[1:])[1] * 1e3 / ncalls, nodes.value
 
+    # the same calls EAGERLY through the deferred window (vpp_box_filter_deferred: the library holds the frames back and launches whole windows of 64; what the C++
+    # drop-in surface's `pixel_wise | ops::box_mean<5,5>` calls): no launch graph, one call per frame from this (Python) host, HIP events on the stream around 20 x 64 calls
+    try:
+        dbox = lib.vpp_box_filter_deferred
+        for i in range(2 * FPS):
+            dbox(P(ddesc[i % nsets]), P(sdesc[i % nsets]), 5, 5, st)
+        capi.check(lib.vpp_flush(st)); torch.cuda.synchronize()
+        ncalls = 20 * FPS
+        d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tw0 = time.perf_counter()
+        d0.record()
+        for i in range(ncalls):
+            dbox(P(ddesc[i % nsets]), P(sdesc[i % nsets]), 5, 5, st)
+        capi.check(lib.vpp_flush(st))
+        d1.record(); torch.cuda.synchronize()
+        tw = time.perf_counter() - tw0
+        dus = d0.elapsed_time(d1) * 1e3 / ncalls
+        per_frame["deferred_eager"] = {"us_per_frame": round(dus, 3), "frac": round(6.0 * npx / (dus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "host_us_per_call": round(tw / ncalls * 1e6, 3),
+                                       "how": "20 x 64 eager vpp_box_filter_deferred calls + vpp_flush between one HIP event pair on the stream (no launch graph); "
+                                              "host_us_per_call = wall clock of the same loop per call, this Python host's ctypes cost included"}
+        check_box("box5x5_deferred_eager")
+    except AttributeError:
+        per_frame["deferred_eager"] = None
     us_rec, nodes_rec = graph_us_per_call(256, launch_box_single)
     per_frame["kernel_nodes_per_256_calls"] = nodes_rec
     # the same calls with the record-time batching switched off: REALLY one launch per call, every launch behind the previous one (what an eager caller gets from one
@@ -585,7 +608,8 @@ def main():
         # the reference's call form: one frame per call (benchmarks/box_5x5_filter2.cc:43-81), recorded on one stream
         roof_c["per_frame_call"] = {"us_per_frame": rnd(per_frame["avg_launch_us_sustained"]), "frac": rnd(per_frame["frac_sustained"]),
                                     "one_launch_per_call": per_frame["without_record_time_batching"]["one_stream_serial"],
-                                    "form": "vpp_box_filter per 4K frame, recorded: folded into 64-frame launches at record time; one_launch_per_call = the same with the folding off"}
+                                    "deferred_eager": pick(per_frame.get("deferred_eager") or {}, "us_per_frame", "frac", "host_us_per_call"),
+                                    "form": "vpp_box_filter per 4K frame, recorded: folded into 64-frame launches; one_launch_per_call: folding off; deferred_eager: vpp_box_filter_deferred, no graph"}
         legs = {}
         px = extras.get("pyrlk") if isinstance(extras.get("pyrlk"), dict) else {}
         if "tracks_per_s" in px:
