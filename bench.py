@@ -633,7 +633,8 @@ def main():
             legs["flow_strips_4k"] = pick(px["flow_strips_4k"], "ms_per_pair", "pairs_per_s", "ranks", "error")
         ig = px.get("ingest_4k") or {}
         if "us_per_frame" in ig:
-            legs["ingest_4k"] = {"us_per_frame": rnd(ig["us_per_frame"]), "frac": rnd(ig["roofline"]["frac"]), "one_launch_per_call": pick(ig["one_launch_per_call"], "us_per_frame", "frac")}
+            legs["ingest_4k"] = {"us_per_frame": rnd(ig["us_per_frame"]), "frac": rnd(ig["roofline"]["frac"]), "one_launch_per_call": pick(ig["one_launch_per_call"], "us_per_frame", "frac"),
+                                 "deferred_eager": pick(ig.get("deferred_eager") or {}, "us_per_frame", "frac")}
         if "error" in px:
             legs["error"] = px["error"]
         roof_c["legs"] = legs
