@@ -413,3 +413,35 @@ def test_fused_sweep_with_every_workgroup_staying_many_rounds(lib, orc):
                     np.testing.assert_array_equal(g, x)
     finally:
         lib.vpp_set_tuning(b"sdof.sweep_stay", -1)
+
+
+def test_a_sweep_behind_an_empty_sweep_is_skipped_and_changes_nothing(lib, orc):
+    """Round 5: a fused sweep that found no candidate says so, and the next sweep of the same scale returns at once (same test, same maps: it would find none
+    either).  A scene with ONE translation has no motion boundary, so every first sweep is empty: with 3 and 4 sweeps per scale the later ones are skipped
+    (the sweep log shows it), and the result equals both the oracle's and the unskipped run's (sdof.skip_empty 0); a scene with boundaries skips nothing it needs."""
+    tex = texture(160, 220, seed=9, sigma=1.5)
+    f1 = np.clip(np.rint(tex), 0, 255).astype(np.uint8)
+    f2 = np.clip(np.rint(translate(tex, 2.0, -3.0)), 0, 255).astype(np.uint8)
+    rr, cc = np.meshgrid(np.arange(5, 155, 5), np.arange(5, 215, 5), indexing="ij")
+    kps = np.stack([rr.ravel(), cc.ravel()], 1).astype(np.int32)
+    log = (ctypes.c_ulonglong * 4096)(); n = ctypes.c_uint(0)
+    for prop in (2, 3, 4):
+        lib.vpp_set_tuning(b"sdof.stats", 1); lib.vpp_debug_sdof_sweep_log(log, ctypes.byref(n), 1)
+        got, want = run_both(lib, orc, f1, f2, kps, 9, 3, 0, prop, 5)
+        lib.vpp_debug_sdof_sweep_log(log, ctypes.byref(n), 1); lib.vpp_set_tuning(b"sdof.stats", -1)
+        codes = [int(e >> 56) for e in list(log)[:n.value]]
+        launches, skipped = codes.count(255), codes.count(250)
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
+        lib.vpp_set_tuning(b"sdof.skip_empty", 0)
+        try:
+            plain, _ = run_both(lib, None, f1, f2, kps, 9, 3, 0, prop, 5)
+        finally:
+            lib.vpp_set_tuning(b"sdof.skip_empty", -1)
+        for g, w in zip(got, plain):
+            np.testing.assert_array_equal(g, w)
+        assert launches == 3 * prop and skipped >= prop - 1, (prop, launches, skipped)   # (a skipped launch logs its start too) at least one scale skips all its later sweeps
+    f1, f2, kps = flow_scene(150, 210)
+    got, want = run_both(lib, orc, f1, f2, kps, 9, 3, 0, 3, 5)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)

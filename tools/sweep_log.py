@@ -36,5 +36,5 @@ for t, rnd, cnt in ent:
         if done:
             print(f"            round 0 done on them between {(done[0][0] - t0) * 0.01:.2f} and {(done[-1][0] - t0) * 0.01:.2f} us; the last five: " + ", ".join(f"{(t_ - t0) * 0.01:.2f} us ({c} cand.)" for t_, c in done[-5:]))
         cls, done = [], []
-    what = {255: f"launch start, {cnt} workgroups", 254: f"  {cnt} workgroups run the rounds"}.get(rnd, f"  round {rnd}: {cnt} jobs")
+    what = {255: f"launch start, {cnt} workgroups", 254: f"  {cnt} workgroups run the rounds", 250: "  skipped: the previous sweep of this scale found no candidate"}.get(rnd, f"  round {rnd}: {cnt} jobs")
     print(f"{(t - t0) * 0.01:8.2f} us  {what}")

@@ -13,6 +13,7 @@
 //     independent, one barrier per step) is kept as an independent on-device cross-check (tuning sdof.propagate = 1).
 // Integer arithmetic throughout: bit-exact.  SAD windows are L2-resident; the path is integer-VALU / latency bound.
 #include "common.hpp"
+#include <atomic>
 #include "tracker_device.hpp"
 #include <climits>
 #include <vector>
@@ -504,7 +505,7 @@ __device__ __forceinline__ Cell load_map_cell(const Maps& m, int ci, int cj) {
 // waits for workgroups that have REGISTERED, and registration closes at the first arrival: a workgroup that was not yet resident when
 // the others finished round 0 simply leaves, so the kernel cannot deadlock whatever else shares the GPU (other streams, other ranks).
 // zero between sweeps (see the exits).  done / nchanged / flushn / ack: sdof_sweep_kernel only.
-struct SweepCtl { unsigned count[2], head[2], reg, nreg, arrive, pad; unsigned long long gen; unsigned done, nchanged, flushn, ack; };
+struct SweepCtl { unsigned count[2], head[2], reg, nreg, arrive, pad; unsigned long long gen; unsigned done, nchanged, flushn, ack, ncand, pad2; };   // ncand: sdof_sweep_kernel, the candidates all tiles found
 constexpr unsigned kRegClosed = 0x80000000u;
 constexpr int kTagShift = 8;            // Cell::mark bits 8..: round + 1 in which the value last changed (0: unchanged this sweep)
 constexpr int kJobsPerGroup = 32;       // 256 threads / 8 lanes
@@ -512,7 +513,8 @@ constexpr unsigned kSpinLimit = 1u << 22;   // polls of a barrier wait: a poll i
                                             // workgroup raises kDevErrSweepBarrier in the sticky device error word (common.hpp) and leaves: the host's next vpp_sync reports VPP_ERR_HIP
 // err: the sticky device error word (pinned host memory) or nullptr.  chg / cflag (sdof_sweep_kernel): the cells whose value changed in this sweep, listed once each.
 // sub (sdof_sweep_kernel): the arrival counters below ctl->done, one per 128 bytes.
-struct RoundArrays { Cell* pre; Cell* B[2]; uint32_t* Q[2]; uint32_t* qflag[2]; SweepCtl* ctl; unsigned* err; uint32_t* chg; uint32_t* cflag; unsigned* sub; };
+// skip (sdof_sweep_kernel): one word, written by EVERY fused sweep — id + 1 when the sweep found no candidate at all (the next sweep of the same scale then finds none either), else 0
+struct RoundArrays { Cell* pre; Cell* B[2]; uint32_t* Q[2]; uint32_t* qflag[2]; SweepCtl* ctl; unsigned* err; uint32_t* chg; uint32_t* cflag; unsigned* sub; unsigned* skip; };
 constexpr int kSubCounters = 64, kSubStride = 32;   // words
 __device__ __forceinline__ void raise_barrier_timeout(const RoundArrays& a) {
   a.ctl->pad = 1;
@@ -792,7 +794,7 @@ constexpr int kSweepTile = 16;   // a workgroup's cells: a 16 x 16 tile of the s
 constexpr unsigned kGenFinal = 0xFFFFFFFFu;   // round field of the message that ends the sweep for parked workgroups
 
 template <int WS>
-__global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats, int nsub, unsigned stay_above) {
+__global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats, int nsub, unsigned stay_above, unsigned sweep_id, int may_skip) {
   __shared__ unsigned s_val, s_nreg, s_flags, s_ncand, s_flushn, s_giveup;
   __shared__ unsigned long long s_gen;
   __shared__ uint32_t s_cand[256];
@@ -801,7 +803,14 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   const int tid = threadIdx.x, j = tid & 7;
   if (stats == 1 && blockIdx.x == 0 && tid == 0) sweep_log(255u, gridDim.x);
   if (tid == 0) { s_ncand = 0; s_giveup = 0; }
+  // (round 5) A sweep that found no candidate at all changed nothing, so the next sweep of the same scale (same test, same maps) finds none either: the earlier
+  // sweep says so in a.skip and this one returns after one load instead of classifying, arriving and handing the control block back (9 us -> the launch's own cost).
+  const unsigned skip_word = may_skip ? load_u32_sc1(a.skip) : 0u;   // (requested beside the classification's loads; every lane: one address, one broadcast)
   __syncthreads();
+  if (may_skip && (skip_word == sweep_id || skip_word == sweep_id + 1u)) {   // (+ 1: what workgroup 0 of this very launch writes below — every workgroup decides alike)
+    if (blockIdx.x == 0 && tid == 0) { store_u32_sc1(a.skip, sweep_id + 1u); if (stats == 1) sweep_log(250u, gridDim.x); }   // still nothing: the next one may skip as well
+    return;
+  }
   {  // ---- this workgroup's cells: which of them can loop_body change at all (sdof_classify_kernel's test, on the records)
     const int tiles_x = (NJ + kSweepTile - 1) / kSweepTile;
     const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
@@ -835,6 +844,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   }
   __syncthreads();
   const unsigned n0 = s_ncand;
+  if (tid == 0 && n0) (void)__hip_atomic_fetch_add(&ctl->ncand, n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (waited for with this workgroup's other accesses before it arrives)
   if (stats == 1 && tid == 0 && n0) sweep_log(253u, n0);
   // ---- round 0 on this workgroup's candidates: reads `pre` (and B[1], equal to it), writes B[0], round 1's queue and the list of changes
   for (unsigned base = 0; base < n0; base += (unsigned)kJobsPerGroup) {
@@ -882,6 +892,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
     unsigned long long g;
     if (flags & 2u) {   // round 0 is complete everywhere (what the others wrote is read with L1-bypassing loads: no acquire)
       const unsigned n1 = __hip_atomic_load(&ctl->count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      store_u32_sc1(a.skip, __hip_atomic_load(&ctl->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u ? sweep_id + 1u : 0u);   // for the next sweep of this scale
       const unsigned R = min(__hip_atomic_load(&ctl->reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kMaxStay);
       unsigned N = R;
       if (!(flags & 1u)) { ticket = R; N = R + 1; }
@@ -1182,7 +1193,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
       auto take = [&](size_t bytes) { uint8_t* q = cv.base ? cv.base + cv.off : nullptr; cv.off += (bytes + 255) / 256 * 256; return q; };
       ra.Q[0] = (uint32_t*)take(cells * 4); ra.Q[1] = (uint32_t*)take(cells * 4); ra.chg = (uint32_t*)take(cells * 4);
       ra_flags_off = cv.off;   // zero between sweeps: queue / change flags (self-cleaning) and the control block
-      ra.qflag[0] = (uint32_t*)take(cells * 4); ra.qflag[1] = (uint32_t*)take(cells * 4); ra.cflag = (uint32_t*)take(cells * 4); ra.sub = (unsigned*)take((size_t)kSubCounters * kSubStride * 4); ra.ctl = (SweepCtl*)take(sizeof(SweepCtl));
+      ra.qflag[0] = (uint32_t*)take(cells * 4); ra.qflag[1] = (uint32_t*)take(cells * 4); ra.cflag = (uint32_t*)take(cells * 4); ra.sub = (unsigned*)take((size_t)kSubCounters * kSubStride * 4); ra.ctl = (SweepCtl*)take(sizeof(SweepCtl)); ra.skip = (unsigned*)take(4);
       ra_flags_bytes = cv.off - ra_flags_off;
       ra.err = device_error_word();
     }
@@ -1369,12 +1380,16 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
           rs.pre = rec[scale][0]; rs.B[0] = rec[scale][1]; rs.B[1] = rec[scale][2];
           // most sweeps have nothing or a few hundred cells to do: a small grid keeps the empty launch cheap; long lists are walked in passes
           const int grid = std::min(tuning("sdof.rounds_grid", 256), (cells + kJobsPerGroup - 1) / kJobsPerGroup);
+          // consecutive ids for this scale's sweeps (a.skip): sweep Ki + 1 skips only on the word sweep Ki wrote
+          static std::atomic<unsigned> g_sweep_seq{1};
+          const unsigned sweep_base = g_sweep_seq.fetch_add((unsigned)propagation + 1u, std::memory_order_relaxed);
           for (int Ki = 0; Ki < propagation; Ki++) {
             if (fused_sweeps) {   // one launch per sweep: every workgroup classifies its tile of cells and runs round 0 on them, the last one to finish runs the rest
               const int tiles = ((NI + kSweepTile - 1) / kSweepTile) * ((NJ + kSweepTile - 1) / kSweepTile);
               const int nsub = std::max(1, std::min(kSubCounters, tiles / 16));
               sdof_sweep_kernel<WS><<<tiles, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs, tuning("sdof.stats", 0), nsub,
-                                                                  (unsigned)tuning("sdof.sweep_stay", (int)kStayThreshold));
+                                                                  (unsigned)tuning("sdof.sweep_stay", (int)kStayThreshold), sweep_base + (unsigned)Ki,
+                                                                  Ki > 0 && tuning("sdof.skip_empty", 1) ? 1 : 0);
               continue;
             }
             sdof_classify_kernel<<<(cells + 255) / 256, 256, 0, st>>>(maps(0, scale), NI, NJ, rs);
