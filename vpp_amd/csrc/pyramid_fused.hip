@@ -16,6 +16,7 @@
 // the same type and order, from the same truncated intermediate values as the chain of per-level kernels, so the result is
 // bit-identical; the halo recomputation costs (2T+3)^2 / (2T)^2 per level, all of it on chip.
 #include "common.hpp"
+#include "sdof_tail.hpp"
 using namespace vpp_amd;
 
 namespace {
@@ -432,6 +433,16 @@ __global__ __launch_bounds__(256) void pyramid_swar3_pair_kernel(Swar3 a, Swar3 
   else pyramid_swar3_body<FAST, SRC>(b, (int)blockIdx.x - blocks_a);
 }
 
+// the pair + `tail_blocks` blocks of the flow's map reset and claims (sdof_tail.hpp): independent work in one launch.  The tail's blocks come FIRST — short,
+// memory-only workgroups that are gone by the time the pyramid tiles (VALU-bound, ~25 us at 4K) have ramped up
+template <class FAST, class SRC>
+__global__ __launch_bounds__(256) void pyramid_swar3_pair_tail_kernel(Swar3 a, Swar3 b, int blocks_a, unsigned tail_blocks, ResetClaimTail t) {
+  if (blockIdx.x < tail_blocks) { reset_claim_block(t.a, t.kps, t.n, t.patch, t.c, blockIdx.x); return; }
+  const int bid = (int)(blockIdx.x - tail_blocks);
+  if (bid < blocks_a) pyramid_swar3_body<FAST, SRC>(a, bid);
+  else pyramid_swar3_body<FAST, SRC>(b, bid - blocks_a);
+}
+
 // the packed kernel's arguments for one pyramid; false: unaligned levels or no interior tile (the tile kernel takes the pyramid); *blocks = its grid
 inline bool swar3_args(const vpp_image_desc* levels, const vpp_image_desc* src, Swar3* out, int* blocks) {
   auto al4 = [](const vpp_image_desc& d) { return ((uintptr_t)d.first_pixel & 3) == 0 && (d.pitch & 3) == 0; };
@@ -524,6 +535,26 @@ int vpp_pyramid_build_pair(const vpp_image_desc* levels_a, const vpp_image_desc*
   if (rc == VPP_OK) rc = vpp_pyramid_build(levels_b, nlevels, src_b, stream);
   return rc;
 }
+
+}  // extern "C"
+namespace vpp_amd {
+int pyramid_pair_with_tail(const vpp_image_desc* levels_a, const vpp_image_desc* src_a, const vpp_image_desc* levels_b, const vpp_image_desc* src_b, int nlevels,
+                           const ResetClaimTail& tail, unsigned tail_blocks, hipStream_t st, bool* fused) {
+  *fused = false;
+  if (!(nlevels == 3 && levels_a && levels_b && src_a && src_b && tuning("pyr.fused", 1) && tuning("pyr.swar", 1) && tuning("pyr.pair", 1))) return VPP_OK;
+  bool ok = true;
+  for (int l = 0; l < 3 && ok; l++) ok = valid_desc(&levels_a[l]) && valid_desc(&levels_b[l]) && same_type(&levels_a[l], src_a) && same_type(&levels_b[l], src_b);
+  ok = ok && valid_desc(src_a) && valid_desc(src_b) && src_a->dtype == VPP_U8 && src_a->channels == 1 && src_b->dtype == VPP_U8 && src_b->channels == 1 &&
+       same_domain(&levels_a[0], src_a) && same_domain(&levels_b[0], src_b) && chain_shape_ok(levels_a, 3) && chain_shape_ok(levels_b, 3);
+  Swar3 a, b; int na = 0, nb = 0;
+  if (!(ok && swar3_args(levels_a, src_a, &a, &na) && swar3_args(levels_b, src_b, &b, &nb))) return VPP_OK;
+  pyramid_swar3_pair_tail_kernel<CopyFast, CopySrc<uint8_t, 1>><<<tail_blocks + (unsigned)(na + nb), 256, 0, st>>>(a, b, na, tail_blocks, tail);
+  VPP_LAUNCH_CHECK();
+  *fused = true;
+  return VPP_OK;
+}
+}  // namespace vpp_amd
+extern "C" {
 
 // Frame ingest fused with the pyramid it feeds (examples/video_extruder.cc:46-48 + pyramid.hh:169-198): levels[0] = rgb_to_graylevel<uchar> of
 // the u8 x3 / x4 frame `rgb` (its border is not read) with a mirror-filled border — exactly what vpp_rgb_to_graylevel(mirror = 1) into a gray

@@ -13,6 +13,7 @@
 //     independent, one barrier per step) is kept as an independent on-device cross-check (tuning sdof.propagate = 1).
 // Integer arithmetic throughout: bit-exact.  SAD windows are L2-resident; the path is integer-VALU / latency bound.
 #include "common.hpp"
+#include "sdof_tail.hpp"
 #include <atomic>
 #include "tracker_device.hpp"
 #include <climits>
@@ -26,7 +27,6 @@ namespace vpp_amd { int launch_fill_border(const vpp_image_desc* img, int mode, 
 
 namespace {
 
-constexpr int kMaxScales = 8;
 
 struct Maps { DImg flow, mark, dist; };  // i32x2, u8, i32 per flow-map cell
 
@@ -183,8 +183,6 @@ __global__ __launch_bounds__(256) void sdof_claim_kernel(const int32_t* __restri
   atomicMin(owner.row<uint32_t>(pf0) + pf1, (uint32_t)i);
 }
 
-// the claims of every scale in one launch (single strip, single rank): a claim depends on the keypoint list and the scale only, not on any flow
-struct ClaimAll { DImg owner[kMaxScales]; int first, last; };
 __global__ __launch_bounds__(256) void sdof_claim_all_kernel(const int32_t* __restrict__ kps, int n, int patch, ClaimAll c) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -1067,10 +1065,7 @@ struct Carver {
   size_t last_off = 0, last_bytes = 0;   // the block of the image carved last (whole allocation, a multiple of 256 bytes)
 };
 
-// One launch resets the maps of every scale that the per-scale phases used to reset one by one (fill_with_border(mark, 0) and the
-// owner map's 0xFF fill: 2 launches per scale, ~5 us each for a few hundred KB): the segments are whole carved blocks, written as 16-byte units.
-constexpr int kResetSegs = 28;
-struct ResetArgs { uint4* p[kResetSegs]; uint32_t first_block[kResetSegs + 1]; uint32_t units[kResetSegs]; uint32_t value[kResetSegs]; int nseg; };
+// (ResetArgs, ClaimAll, reset_claim_block: sdof_tail.hpp — the pyramid pair launch can carry these blocks)
 __global__ __launch_bounds__(256) void sdof_reset_kernel(ResetArgs a) {
   int sgm = 0;
   while (sgm + 1 < a.nseg && blockIdx.x >= a.first_block[sgm + 1]) sgm++;
@@ -1080,22 +1075,7 @@ __global__ __launch_bounds__(256) void sdof_reset_kernel(ResetArgs a) {
 // The mark maps' reset and the claims of every scale in ONE launch: the first blocks fill the mark blocks, the others claim — the two touch different maps.
 // The owner maps need no reset here: every descent hands its cell back empty (clean_owner), so a call finds them as the previous one left them.
 __global__ __launch_bounds__(256) void sdof_reset_claim_kernel(ResetArgs a, const int32_t* __restrict__ kps, int n, int patch, ClaimAll c) {
-  const uint32_t reset_blocks = a.first_block[a.nseg];
-  if (blockIdx.x < reset_blocks) {
-    int sgm = 0;
-    while (sgm + 1 < a.nseg && blockIdx.x >= a.first_block[sgm + 1]) sgm++;
-    const uint32_t u = (blockIdx.x - a.first_block[sgm]) * 256 + threadIdx.x;
-    if (u < a.units[sgm]) { const uint32_t v = a.value[sgm]; a.p[sgm][u] = make_uint4(v, v, v, v); }
-    return;
-  }
-  const int i = (int)(blockIdx.x - reset_blocks) * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int k0 = kps[2 * i], k1 = kps[2 * i + 1];
-  for (int s = c.first; s <= c.last; s++) {
-    const int div = 1 << s;
-    const int pf0 = (k0 / div) / patch, pf1 = (k1 / div) / patch;
-    if (c.owner[s].has(pf0, pf1)) atomicMin(c.owner[s].row<uint32_t>(pf0) + pf1, (uint32_t)i);
-  }
+  reset_claim_block(a, kps, n, patch, c, blockIdx.x);
 }
 
 }  // namespace
@@ -1235,6 +1215,8 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   // (window centres must lie inside the domain, :102-108): the mirror fill is limited to that (>= 2: the per-level low-pass of other pyramid depths reads 2) —
   // with the full 18 pixels three rings of the one-launch pyramid kernel's tiles took its slow edge path (16.4 vs 13.5 us per 4K pyramid).
   int rc = VPP_OK;
+  bool pyr_pending = false;
+  vpp_image_desc B1[kMaxScales], B2[kMaxScales];
   if (pre1) {
     for (int s_ = 0; s_ < nscales; s_++) {   // the levels must be the ones pyramid.hh:154 halves to, with the pixels a SAD can reach (see above) in their border
       for (const vpp_image_desc* L : {&pre1[s_], &pre2[s_]})
@@ -1244,12 +1226,14 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
       P1[s_] = pre1[s_]; P2[s_] = pre2[s_];
     }
   } else {
-    vpp_image_desc B1[kMaxScales], B2[kMaxScales];
     for (int s_ = 0; s_ < nscales; s_++) {
       B1[s_] = P1[s_]; B2[s_] = P2[s_];
       B1[s_].border = B2[s_].border = std::min(P1[s_].border, std::max(winsize / 2, 2));
     }
-    rc = vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream); if (rc) return rc;   // one launch for both when the packed kernel takes them
+    // (round 5) the mark reset + claims of all scales are independent of the pyramids: where they are one launch of their own (self_cleaning) they ride in the
+    // pyramids' launch as extra workgroups — queued below, where their arguments are known
+    pyr_pending = self_cleaning && nscales == 3 && tuning("sdof.tail_in_pyramid", 1);
+    if (!pyr_pending) { rc = vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream); if (rc) return rc; }   // one launch for both when the packed kernel takes them
   }
   auto maps = [&](int k, int s_) { return Maps{dimg(&FL(k, s_)), dimg(&MK(k, s_)), dimg(&DM(k, s_))}; };
   Scratch::Slot& slot = *g_scratch.cur;
@@ -1257,6 +1241,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   for (int s_ = min_scale; s_ < nscales; s_++) owner_sig = (owner_sig * 1099511628211ull) ^ ((unsigned long long)ow_off[s_] << 20) ^ (unsigned long long)ow_bytes[s_];
   const bool owner_known_clean = self_cleaning && slot.note(1, owner_sig);   // never while recording / on a buffer a graph was recorded on
   slot.set_note(1, 0);   // until this call has queued every descent
+  if (pyr_pending && !(reset_up_front && self_cleaning)) { pyr_pending = false; rc = vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream); if (rc) return rc; }   // (cannot happen: self_cleaning implies both)
   if (reset_up_front) {
     ResetArgs ra; ra.nseg = 0; uint32_t blocks = 0;
     for (int s_ = min_scale; s_ < nscales; s_++) {
@@ -1291,7 +1276,14 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
       }
       ClaimAll ca; ca.first = min_scale; ca.last = nscales - 1;
       for (int s_ = min_scale; s_ < nscales; s_++) ca.owner[s_] = dimg(&OW(0, s_));
-      sdof_reset_claim_kernel<<<blocks + (unsigned)((n + 255) / 256), 256, 0, st>>>(ra, kps, n, patchsize, ca);
+      bool fused = false;
+      if (pyr_pending) {
+        pyr_pending = false;
+        ResetClaimTail tail{ra, kps, n, patchsize, ca};
+        rc = pyramid_pair_with_tail(B1, i1, B2, i2, nscales, tail, blocks + (unsigned)((n + 255) / 256), st, &fused); if (rc) return rc;
+        if (!fused) { rc = vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream); if (rc) return rc; }
+      }
+      if (!fused) sdof_reset_claim_kernel<<<blocks + (unsigned)((n + 255) / 256), 256, 0, st>>>(ra, kps, n, patchsize, ca);
     } else sdof_reset_kernel<<<blocks, 256, 0, st>>>(ra);
     VPP_LAUNCH_CHECK();
   }
