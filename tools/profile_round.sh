@@ -40,3 +40,11 @@ PUB=$R/gpurun_out/pub_$TAG
 mkdir -p $PUB
 bash tools/publish_profiles.sh $TAG $PUB
 rm -rf $OUT/*/ 
+# per-dispatch timelines of one 4K flow pair and of the tracker's updates, and the fused sweeps' own event log
+{ echo "# Round ${TAG#r} — per-dispatch timeline of one 4K frame pair of vpp_semi_dense_optical_flow (tools/flow_timeline.sh: rocprofv3 --kernel-trace of tools/rounds_ab.py, the 10th call; durations include the dispatch's ramp)"; echo
+  bash tools/flow_timeline.sh 2>/dev/null | grep "^|"; echo; echo "## The fused sweeps' event log of the same scene (tools/sweep_log.py, tuning sdof.stats = 1: 100 MHz wall clock, no profiler)"; echo; echo '```'
+  timeout 120 python tools/sweep_log.py 2>/dev/null | grep " us "; echo '```'; } > $PUB/${TAG}_flow_timeline.md
+{ echo "# Round ${TAG#r} — per-dispatch timelines of the 4K tracker (benchmarks/video_extruder_bench under rocprofv3 --kernel-trace, tools/tracker_timeline.sh)"; echo
+  echo "## A steady update (no re-detection)"; echo; bash tools/tracker_timeline.sh 2>/dev/null | grep "^|"; echo
+  echo "## From a re-detection frame's ve_finish_kernel to the end of the next update's flow"; echo; DETECT=1 bash tools/tracker_timeline.sh 2>/dev/null | grep "^|"; } > $PUB/${TAG}_tracker_timeline.md
+rm -rf $R/gpurun_out/flow_tl $R/gpurun_out/ve_tl
