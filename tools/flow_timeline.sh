@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/flow_tl
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $R/tools/rounds_ab.py > $OUT/run.log 2>&1
+timeout -k 10 150 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $R/tools/rounds_ab.py > $OUT/run.log 2>&1
 cd $R
 F=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python - "$F" <<'PY'

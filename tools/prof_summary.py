@@ -10,7 +10,10 @@ def short(name):
     return n[: n.index("(")] if "(" in n else n
 
 
+import os
 for path in sys.argv[1:]:
+    if not os.path.exists(path):
+        continue   # a pass that was not taken this round
     con = sqlite3.connect(path)
     rows = con.execute("select name, duration, vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x from kernels").fetchall()
     # one row per (kernel symbol, grid size): launches of one symbol that carry different amounts of work (1 ... 64 frames per launch, the sweeps of the three

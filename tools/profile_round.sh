@@ -10,8 +10,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-T="timeout 300"
-$T rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python $R/bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+T="timeout -k 10 ${PASS_LIMIT:-150}"   # -k: round 5 lost 40 GPU-minutes to a profiled process that ignored TERM after the profiler's own worker thread had aborted
+# (the default-flag run — 500 steps, 32 000 recorded per-frame calls — aborted inside rocprofv3's worker thread in round 5 ("corrupted size vs. prev_size"); the driver's command is the one profiled)
 $T rocprofv3 --kernel-trace --stats -d $OUT/kt20 -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $OUT/bench_s20_under_rocprof.json 2> $OUT/bench_s20_under_rocprof.err
 $T rocprofv3 --kernel-trace --stats -d $OUT/kt_algos -o algos -- python $R/tools/run_algos.py > $OUT/run_algos.log 2>&1
 pmc() {  # pmc <dir> <script> <counters...>
@@ -23,13 +23,13 @@ pmc pmc_write "run_kernels.py all 16" WRITE_SIZE
 pmc pmc_sq "run_kernels.py all 16" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 pmc pmc_busy "run_kernels.py all 16" SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU
 pmc pmc_wait "run_kernels.py all 16" SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS
-pmc pmc_wait2 "run_kernels.py all 16" SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+[ -n "${WAIT2:-}" ] && pmc pmc_wait2 "run_kernels.py all 16" SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 pmc pmc_sq_algos "run_algos.py x" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 pmc pmc_busy_algos "run_algos.py x" SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU
 pmc pmc_wait_algos "run_algos.py x" SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS
-pmc pmc_wait2_algos "run_algos.py x" SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+[ -n "${WAIT2:-}" ] && pmc pmc_wait2_algos "run_algos.py x" SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 # L2 request mix, one counter per pass (a multi-counter TCC pass hung the profiler in round 1)
-for c in TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum; do
+for c in ${TCC_PASSES:-}; do   # e.g. TCC_PASSES="TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" (off by default: the box kernel has not changed since r04_tcc.md)
   pmc pmc_tcc_$c "run_kernels.py box 16" $c
 done
 cd $R
