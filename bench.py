@@ -70,6 +70,12 @@ def main():
         torch.cuda.synchronize()
 
     launch_mode = {"mode": "hipGraph"}
+    trace_on = os.environ.get("VPP_BENCH_TRACE", "0") == "1"
+    t_start = time.perf_counter()
+
+    def stage(name):   # VPP_BENCH_TRACE=1: where the run is, on stderr (diagnosing a run that dies under a profiler)
+        if trace_on and rank == 0:
+            sys.stderr.write(f"[bench stage {time.perf_counter() - t_start:7.2f} s] {name}\n"); sys.stderr.flush()
 
     preheat = {"ms": 0.0, "launches": 0}
     region_log = []
@@ -217,6 +223,7 @@ def main():
         region_log.append({"wall_ms": [round(r[0] * 1e3, 4) for r in regions], "event_ms": [round(r[1] * 1e3, 4) for r in regions], "sample": sample})
         return wall, ev
 
+    stage('setup: box frames')
     # ---------------- box5x5 on 4K vuchar3 (headline) ----------------
     NR, NC = 2160, 3840
     npx = NR * NC
@@ -276,6 +283,7 @@ def main():
         k = i % nsets
         box(P(ddesc[k]), P(sdesc[k]), 5, 5, stream)
 
+    stage('box batch: timed regions')
     wall, ev = timed(launch_box, args.steps, args.warmup, preheat_s=args.preheat, c_graph=True)
     if args.steps + args.warmup >= nb:   # every frame set was written by a timed or warm-up launch
         check_box("box5x5_batch")
@@ -333,6 +341,7 @@ def main():
     roof["traffic"], roof["traffic_source"] = pmc_traffic("box_u8_wide_kernel<3, 5, 5, 6")
     if roof["traffic_source"]:
         roof["traffic_source"] += " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this kernel symbol, FETCH doubled per the gfx950 note)"
+    stage('box: copy leg done; per-frame recorded leg')
     # the same frames one launch per frame (the reference's call form, benchmarks/box_5x5_filter2.cc:43-69): K x FPS launches in the region
     swall, sev = timed(launch_box_single, args.steps * FPS, args.warmup, preheat_s=0.0, c_graph=True)
     check_box("box5x5_one_launch_per_frame")
@@ -364,6 +373,7 @@ def main():
         lib.vpp_graph_destroy(gh)
         return sorted(ts[1:])[1] * 1e3 / ncalls, nodes.value
 
+    stage('box: deferred eager leg')
     # the same calls EAGERLY through the deferred window (vpp_box_filter_deferred: the library holds the frames back and launches whole windows of 64; what the C++
     # drop-in surface's `pixel_wise | ops::box_mean<5,5>` calls): no launch graph, one call per frame from this (Python) host, HIP events on the stream around 20 x 64 calls
     try:
@@ -387,6 +397,7 @@ def main():
         check_box("box5x5_deferred_eager")
     except AttributeError:
         per_frame["deferred_eager"] = None
+    stage('box: per-frame forms, sweeps, streams')
     us_rec, nodes_rec = graph_us_per_call(256, launch_box_single)
     per_frame["kernel_nodes_per_256_calls"] = nodes_rec
     # the same calls with the record-time batching switched off: REALLY one launch per call, every launch behind the previous one (what an eager caller gets from one
@@ -454,6 +465,7 @@ def main():
     per_frame["one_launch_per_frame_on_n_streams"] = on_streams
     lib.vpp_set_tuning(b"box.coalesce", -1); lib.vpp_set_tuning(b"launch.capture_width", -1)
 
+    stage('add4k')
     # ---------------- 4K int32 pixel_wise add ----------------
     nadd = 16  # triples per step (16 x 99.5 MB = 1.6 GB per launch, like the box step; kPwBatchMax)
     nadd_sets = 16  # 16 x 66 MB of operands = 1.06 GB, all read by every step (a larger rotation only adds address-translation misses)
@@ -490,6 +502,7 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 12.0 * npx * nadd / add_s / 1e9 / HBM_PEAK_GBS,
                           "frac_sustained": 12.0 * npx * nadd / add_sus / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("binary_flat_batch_kernel<0, int")[0]}}
 
+    stage('secondary legs (bench_pyrlk)')
     extras = {}
     try:
         import bench_pyrlk
@@ -500,6 +513,7 @@ def main():
         import traceback
         extras["pyrlk"] = {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().strip().splitlines()[-3:]}
 
+    stage('cpu baseline')
     # ---------------- CPU baseline: the oracle restatement on the host cores (rank 0, N=1 only) ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

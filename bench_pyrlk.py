@@ -48,6 +48,12 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
 
     V = ctypes.c_void_p
     st = capi.stream_ptr()
+    trace_on = os.environ.get("VPP_BENCH_TRACE", "0") == "1" and rank == 0
+
+    def stage(name):
+        if trace_on:
+            sys.stderr.write(f"[bench stage] pyrlk leg: {name}\n"); sys.stderr.flush()
+    stage("pyrlk match")
     NR, NC, L, B, WS, NK = 1080, 1920, 3, 3, 7, 10000
     tex = texture(NR, NC, seed=5)
     f1 = np.clip(np.rint(tex), 0, 255).astype(np.uint8)
@@ -176,6 +182,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
         res["weak_scaling"] = {"keypoints_per_rank": NK, "tracks_per_s": NK * world / (wwall / steps), "ms_per_frame": wwall / steps * 1e3,
                                "exchange": f"rccl all_gather of {NK * world} 20-byte records"}
 
+    stage("pyramids")
     # pyramids + gradient of a frame pair (what a caller pays per new frame besides the match)
     dp2_, dg1_ = vi.desc_array(p2), vi.desc_array(g1)
 
@@ -187,6 +194,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     res["pyramids_ms_per_frame"] = pwall / steps * 1e3
     res["tracks_per_s_incl_pyramids"] = NK / ((wall + pwall) / steps)
 
+    stage("fast9")
     # FAST-9 on 4K (replicas): raw and blockwise(10); each call ends with the host read of the keypoint count
     im = u8_image(fast9_bench_frame(), border=3)
     v = im.view(with_border=True)[..., 0]
@@ -211,6 +219,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     fast["blockwise10"]["roofline"] = issue_roofline("fast9_detect2_kernel<true, 2>")
     res["fast9_4k"] = fast
 
+    stage("flow")
     # semi-dense optical flow on one 4K frame pair (BASELINE configs[4] on a single GPU): a keypoint every 10 px
     # (video_extruder keypoint_spacing), winsize 9, 3 scales, propagation 2, patch 5 (video_extruder.hpp:35-41,54)
     from vpp_amd.synth import flow_scene
@@ -233,6 +242,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     res["semi_dense_flow_4k"] = {"ms_per_frame_pair": dt * 1e3, "frame_pairs_per_s": world / dt, "keypoints": m,
                                  "note": "one frame pair per GPU (replicas); serial-order semantics, bit-exact vs the oracle",
                                  "roofline": issue_roofline("sdof_descent_group_kernel<9, false,"), "roofline_sweeps": issue_roofline("sdof_sweep_kernel<9>")}
+    stage("flow: concurrent streams")
     # several independent frame pairs in flight on one GPU: each on its own stream (its own scratch: common.hpp Scratch is per stream); a pair is a
     # chain of ~25 short launches (pyramids, claim, descent, classify, propagation rounds), so independent pairs fill each other's launch gaps
     conc = {}
@@ -259,6 +269,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     res["semi_dense_flow_4k"]["concurrent_streams"] = conc
     res["semi_dense_flow_4k"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")
 
+    stage("ingest")
     # frame ingest: 4K vuchar3 frame -> gray with a mirror-filled border of 3 in one pass; 4 B/px algorithmic.  One call per frame, recorded on one stream:
     # the library folds the calls into batched launches at record time (video.hip: coalesce_gray); the same calls as one launch each are reported beside it
     from vpp_amd.synth import rand_image
@@ -296,6 +307,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
                         "one_launch_per_call": {"us_per_frame": sev / isteps * 1e6, "frac": ibytes / (sev / isteps) / 1e9 / 8000.0},
                         "how": "the calls fold into 64-frame launches at record time (video.hip: coalesce_gray); one_launch_per_call = the same calls with the batching off"}
 
+    stage("ingest + pyramid")
     # ingest fused with the image pyramid it feeds (vpp_rgb_pyramid_build: one launch) against the two-call chain, 4K, border 3, 3 levels
     try:
         npy = 12
@@ -315,6 +327,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
     except Exception as e:  # noqa: BLE001
         res["ingest_pyramid_4k"] = {"error": f"{type(e).__name__}: {e}"}
 
+    stage("video_extruder_bench")
     # video_extruder_update on 4K frames through the C++ drop-in surface (benchmarks/video_extruder_bench.cc), rank 0 only
     exe = os.path.join(ROOT, "benchmarks", "video_extruder_bench")
     if rank == 0 and os.path.exists(exe):
