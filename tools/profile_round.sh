@@ -12,7 +12,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 T="timeout -k 10 ${PASS_LIMIT:-150}"   # -k: round 5 lost 40 GPU-minutes to a profiled process that ignored TERM after the profiler's own worker thread had aborted
 # (the default-flag run — 500 steps, 32 000 recorded per-frame calls — aborted inside rocprofv3's worker thread in round 5 ("corrupted size vs. prev_size"); the driver's command is the one profiled)
-$T rocprofv3 --kernel-trace --stats -d $OUT/kt20 -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $OUT/bench_s20_under_rocprof.json 2> $OUT/bench_s20_under_rocprof.err
+# (bench.py under rocprofv3 died twice in round 5 — a glibc heap-check abort in a non-main thread within the first seconds, 2 of 9 runs, never without the profiler
+# and never under MALLOC_CHECK_=3: up to three attempts; tools/bench_under_rocprof_debug.sh is the script that chases it)
+for attempt in 1 2 3; do
+  rm -rf $OUT/kt20
+  $T rocprofv3 --kernel-trace --stats -d $OUT/kt20 -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $OUT/bench_s20_under_rocprof.json 2> $OUT/bench_s20_under_rocprof.err
+  [ -s $OUT/bench_s20_under_rocprof.json ] && break
+  echo "bench under rocprofv3: attempt $attempt failed" >> $OUT/failed.txt
+done
 $T rocprofv3 --kernel-trace --stats -d $OUT/kt_algos -o algos -- python $R/tools/run_algos.py > $OUT/run_algos.log 2>&1
 pmc() {  # pmc <dir> <script> <counters...>
   local d=$1 s=$2; shift 2
