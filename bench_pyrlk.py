@@ -84,7 +84,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
 
     # the instance the library launches for this many keypoints per rank (pyrlk.hip: 16 lanes per keypoint from 8 000, 32 from 3 500, 64 below)
     lpk = 8 if n_local >= 80000 else (16 if n_local >= 8000 else (32 if n_local >= 3500 else 64))
-    res["roofline"] = issue_roofline(f"pyrlk_match_group_kernel<7, {lpk},")
+    res["roofline"] = issue_roofline(f"pyrlk_match_group_kernel<7, {lpk}>")
 
     # keypoint-count sweep on one GPU (where tracks/s saturates; 1 250 = what one of 8 ranks sees of the 10 k keypoints of configs[3])
     if world == 1:
