@@ -528,3 +528,52 @@ def test_recorded_adds_are_batched(lib, orc):
         np.testing.assert_array_equal(dA[k].download().view(), B[k].view() + C[k].view())
     np.testing.assert_array_equal(dA[n].download().view(), B[3].view() + C[3].view() + B[17].view() + C[17].view())
     capi.check(lib.vpp_graph_destroy(graph))
+
+
+def test_deferred_per_frame_calls_through_the_c_abi(lib, orc):
+    """vpp_box_filter_deferred / vpp_pixelwise_binary_deferred / vpp_rgb_to_graylevel_deferred (include/vpp_amd.h, round 5): the reference's one-frame-per-call form
+    without a launch per call.  70 frames: a window of 64 goes out by itself, the rest at vpp_flush; a frame that reads a pending result does not join it; argument
+    errors are reported at the call; any other entry point (here vpp_fill_border, vpp_sync) launches the window first; every result against the oracle."""
+    lib.vpp_deferred_flushes.restype = ctypes.c_ulonglong
+    st = capi.stream_ptr()
+    n, nr, nc = 70, 64, 176
+    srcs, wants = [], []
+    for k in range(n):
+        h = rand_image(nr, nc, vi.U8, 3, border=2, seed=500 + k, align=16, fill_border=True)
+        w = h.like(border=0); assert orc.orc_box_filter(P(w.desc), P(h.desc), 5, 5) == 0
+        srcs.append(DeviceImage.from_host(h)); wants.append(w)
+    dsts = [DeviceImage(nr, nc, vi.U8, 3, 0, 16) for _ in range(n)]
+    _sync(lib)
+    assert lib.vpp_deferred_pending() == 0
+    f0 = lib.vpp_deferred_flushes()
+    for k in range(n):
+        capi.check(lib.vpp_box_filter_deferred(P(dsts[k].desc), P(srcs[k].desc), 5, 5, st))
+        assert lib.vpp_deferred_pending() == (k + 1) % 64
+    assert lib.vpp_deferred_flushes() == f0 + 1
+    capi.check(lib.vpp_flush(st)); _sync(lib)
+    assert lib.vpp_deferred_pending() == 0 and lib.vpp_deferred_flushes() == f0 + 2
+    for d, w in zip(dsts, wants):
+        np.testing.assert_array_equal(d.download().view(), w.view())
+    # errors at the call, nothing joins the window
+    bad = DeviceImage(nr, nc, vi.U8, 3, 1, 16)   # border 1 < 2
+    assert lib.vpp_box_filter_deferred(P(dsts[0].desc), P(bad.desc), 5, 5, st) == capi.ERR_BORDER_TOO_SMALL and lib.vpp_deferred_pending() == 0
+    assert lib.vpp_box_filter_deferred(P(dsts[0].desc), P(dsts[0].desc), 5, 5, st) != 0
+    # data flow: the second call reads the first one's pending result -> the first is launched, the second opens a new window; another entry point flushes it
+    a, b, c, e = (rand_image(135, 240, vi.I32, seed=600 + q, lo=0, hi=2**29) for q in range(4))
+    da, db, dc, de = (DeviceImage.from_host(x) for x in (a, b, c, e))
+    capi.check(lib.vpp_pixelwise_binary_deferred(0, P(da.desc), P(db.desc), P(dc.desc), st)); assert lib.vpp_deferred_pending() == 1
+    capi.check(lib.vpp_pixelwise_binary_deferred(0, P(de.desc), P(da.desc), P(db.desc), st)); assert lib.vpp_deferred_pending() == 1
+    capi.check(lib.vpp_fill_border(P(srcs[0].desc), 0, None, st)); assert lib.vpp_deferred_pending() == 0     # anything else this thread queues comes after the window
+    _sync(lib)
+    np.testing.assert_array_equal(da.download().view(), b.view() + c.view())
+    np.testing.assert_array_equal(de.download().view(), b.view() + c.view() + b.view())
+    # the frame ingest, 5 frames, against the oracle; vpp_sync alone launches and waits
+    frames = [rand_image(72, 160, vi.U8, 3, border=0, seed=700 + k) for k in range(5)]
+    dfr = [DeviceImage.from_host(f) for f in frames]; dg = [DeviceImage(72, 160, vi.U8, 1, 3, 32) for _ in range(5)]
+    for k in range(5):
+        capi.check(lib.vpp_rgb_to_graylevel_deferred(P(dg[k].desc), P(dfr[k].desc), 1, st))
+    assert lib.vpp_deferred_pending() == 5
+    capi.check(lib.vpp_sync(st)); assert lib.vpp_deferred_pending() == 0
+    for k in range(5):
+        want = HostImage(72, 160, vi.U8, 1, 3); assert orc.orc_rgb_to_graylevel(P(want.desc), P(frames[k].desc), 1) == 0
+        np.testing.assert_array_equal(dg[k].download().view(with_border=True), want.view(with_border=True))
