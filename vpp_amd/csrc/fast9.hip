@@ -176,6 +176,21 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
   const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
   const int lo = -A.border, hi = A.nc + A.border;
   const bool aligned = (((uintptr_t)A.p0 | (uintptr_t)A.pitch) & 3) == 0;
+  // (round 5) A tile whose 38 x 72-byte patch lies inside the bordered area — every tile but the frame's last column / row of tiles — loads it without the per-dword
+  // guards and without a division per dword: thread t owns dword t % 18 of the rows t / 18, + 14, + 28 (252 threads, three loads in flight each).  ~20 instead of
+  // ~54 instructions per thread for the staging, of the kernel's ~580 per thread.
+  if (aligned && c0 - 4 >= lo && c0 + TW + 4 <= hi && r0 + TH + HALO <= A.nr + A.border) {   // (r0 - HALO >= -border always: border >= 3; wave-uniform)
+    const int t = threadIdx.x;
+    if (t < 14 * LDW) {
+      const int lr = t / LDW, ld = t - lr * LDW;
+      const uint8_t* src = A.p0 + (ptrdiff_t)(r0 - HALO + lr) * A.pitch + (c0 - 4 + 4 * ld);
+      const uint32_t v0 = *(const uint32_t*)src, v1 = *(const uint32_t*)(src + (ptrdiff_t)14 * A.pitch);
+      uint32_t v2 = 0;
+      if (lr + 28 < LROWS) v2 = *(const uint32_t*)(src + (ptrdiff_t)28 * A.pitch);
+      ((uint32_t*)tile)[t] = v0; ((uint32_t*)tile)[t + 14 * LDW] = v1;
+      if (lr + 28 < LROWS) ((uint32_t*)tile)[t + 28 * LDW] = v2;
+    }
+  } else
   for (int i = threadIdx.x; i < LROWS * LDW; i += 256) {
     const int lr = i / LDW, ld = i - lr * LDW;
     const int r = r0 - HALO + lr;
