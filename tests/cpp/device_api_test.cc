@@ -243,7 +243,7 @@ static void test_deferred_per_frame_calls() {
     }
     std::printf("4K vuchar3 box 5x5, one frame per call through pixel_wise | ops::box_mean<5,5> over 64 frame sets: %.2f us per frame (%.3f of the HBM peak)\n",
                 best * 1e6, 6.0 * nr * nc / best / 8e12);
-    CHECK(best * 1e6 < 11.0);   // per-call launches: 11.9-13.5 us; the batched rate is 8.3-9.1 us by box
+    CHECK(best * 1e6 < 11.5);   // per-call launches: 11.9-13.5 us by box; the batched rate is 8.3-9.7 us by box (8.91 measured): the bound separates the two on every box
     for (int k = 0; k < n; k += 1) {
       image2d<vuchar3> W(nr, nc, _aligned = 16);
       const vpp_image_desc ds = host_desc(S[k]), dw = host_desc(W);
