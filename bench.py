@@ -352,8 +352,9 @@ def main():
                  "frac_in_region": 6.0 * npx / (sev / (args.steps * FPS)) / 1e9 / HBM_PEAK_GBS, "frac_sustained": 6.0 * npx / single_s / 1e9 / HBM_PEAK_GBS,
                  "launch": per_frame_mode["mode"],
                  "how": "K x 64 calls of vpp_box_filter on ONE stream, one 4K frame per call (the reference's call form), recorded into a launch graph through the C ABI with the "
-                        "library's defaults: while a stream is recorded, a call whose frame is unrelated to what was recorded since the previous call's node is folded into that node "
-                        "(record-time batching, box.hip: the node is re-parameterised to carry one frame more, up to 64), so the replay makes one launch per 64 calls; data flow is kept "
+                        "library's defaults: on a stream recorded through vpp_graph_begin a per-frame call is held back in the calling thread's window while its frame is unrelated to the "
+                        "pending ones, and a window that closes (64 frames, a related frame, any other call, vpp_graph_end) records ONE node of the batched kernel (box.hip, common.hpp; no node "
+                        "of the graph under capture is edited), so the replay makes one launch per 64 calls; data flow is kept "
                         "exactly (tests/test_gpu_core.py::test_recorded_per_frame_calls_are_batched_and_keep_their_data_flow).  'without_record_time_batching' = the same calls as one "
                         "launch each; eager callers get 'one_stream_serial' (tools/overlap_lab.hip: the AQL barrier bit cannot be dropped on gfx950, hipExtAnyOrderLaunch does not overlap)"}
     def graph_us_per_call(ncalls, launch):
@@ -400,7 +401,7 @@ def main():
     stage('box: per-frame forms, sweeps, streams')
     us_rec, nodes_rec = graph_us_per_call(256, launch_box_single)
     per_frame["kernel_nodes_per_256_calls"] = nodes_rec
-    # the same calls with the record-time batching switched off: REALLY one launch per call, every launch behind the previous one (what an eager caller gets from one
+    # the same calls with the held-back window switched off for recorded streams: REALLY one launch per call, every launch behind the previous one (what an eager caller gets from one
     # stream), and as two lanes of sibling nodes (IndependentCall without the batching)
     lib.vpp_set_tuning(b"box.coalesce", 0)
     forms = {}
@@ -623,7 +624,7 @@ def main():
         roof_c["per_frame_call"] = {"us_per_frame": rnd(per_frame["avg_launch_us_sustained"]), "frac": rnd(per_frame["frac_sustained"]),
                                     "one_launch_per_call": per_frame["without_record_time_batching"]["one_stream_serial"],
                                     "deferred_eager": pick(per_frame.get("deferred_eager") or {}, "us_per_frame", "frac", "host_us_per_call"),
-                                    "form": "vpp_box_filter per 4K frame, recorded: folded into 64-frame launches; one_launch_per_call: folding off; deferred_eager: vpp_box_filter_deferred, no graph"}
+                                    "form": "vpp_box_filter per 4K frame, recorded: held back and recorded as 64-frame launches; one_launch_per_call: that off; deferred_eager: vpp_box_filter_deferred, no graph"}
         legs = {}
         px = extras.get("pyrlk") if isinstance(extras.get("pyrlk"), dict) else {}
         if "tracks_per_s" in px:

@@ -271,7 +271,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
 
     stage("ingest")
     # frame ingest: 4K vuchar3 frame -> gray with a mirror-filled border of 3 in one pass; 4 B/px algorithmic.  One call per frame, recorded on one stream:
-    # the library folds the calls into batched launches at record time (video.hip: coalesce_gray); the same calls as one launch each are reported beside it
+    # the library holds the calls back and records batched launches (common.hpp: the held-back window); the same calls as one launch each are reported beside it
     from vpp_amd.synth import rand_image
     nin = 64  # 64 x (24.9 + 8.3 MB) = 2.1 GB, all touched by every 64 calls: nothing survives in the Infinity Cache
     rgb_h = rand_image(2160, 3840, vi.U8, 3, border=0, seed=6)
@@ -305,7 +305,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
                         "us_per_frame": iev / isteps * 1e6, "gpixels_per_s": 2160 * 3840 * world / (iwall / isteps) / 1e9,
                         "roofline": {"bound": "hbm", "achieved": ibytes / (iev / isteps) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": ibytes / (iev / isteps) / 1e9 / 8000.0},
                         "one_launch_per_call": {"us_per_frame": sev / isteps * 1e6, "frac": ibytes / (sev / isteps) / 1e9 / 8000.0},
-                        "how": "the calls fold into 64-frame launches at record time (video.hip: coalesce_gray); one_launch_per_call = the same calls with the batching off"}
+                        "how": "the calls are held back and recorded as 64-frame launches (common.hpp); one_launch_per_call = the same calls with the batching off"}
 
     stage("ingest + pyramid")
     # ingest fused with the image pyramid it feeds (vpp_rgb_pyramid_build: one launch) against the two-call chain, 4K, border 3, 3 levels

@@ -141,23 +141,28 @@ int vpp_box_filter_batch(const vpp_image_desc* dst, const vpp_image_desc* src, i
 
 /* ---- deferred per-frame calls: the reference's call form (ONE frame per call: benchmarks/box_5x5_filter2.cc:43-81, benchmarks/image_add.cc:51-57,
  *      examples/video_extruder.cc:44-48; vpp/core/pixel_wise.hpp:188-213 evaluates at operator|) at the batched kernels' rate, without a launch graph ----
- * A *_deferred entry point validates its arguments as its plain namesake does and returns; its launch is held back in a window of the CALLING HOST THREAD and goes
- * out together with later deferred calls of the same entry point, parameters, stream and geometry as ONE batched launch (vpp_*_batch: "the results of the n calls
- * one after the other").  A call joins the window only while no data flows between it and the pending calls (no pending result overlaps its operands or result,
+ * A *_deferred entry point validates its arguments as its plain namesake does and returns VPP_OK; its launch is held back in a window of the CALLING HOST THREAD and
+ * goes out together with later deferred calls of the same entry point, parameters, stream and geometry as ONE batched launch (vpp_*_batch: "the results of the n
+ * calls one after the other").  A call joins the window only while no data flows between it and the pending calls (no pending result overlaps its operands or result,
  * its result overlaps no pending operand; bordered extents); otherwise the window is launched first.  The window is also launched when it holds 64 frames, by
- * vpp_flush, and before ANYTHING else the same thread queues through this ABI — every entry point that takes a stream (copies, events, vpp_sync, graphs, every
- * kernel) and vpp_free — so stream order, results and what a vpp_sync waits for are exactly those of the plain calls.  What is NOT covered: work queued on the
- * stream by other means (raw HIP calls) or from another host thread before a vpp_flush — so a thread calls vpp_flush before it ends, before it hands the stream to another
- * thread, and before it releases an image's memory by any other means than vpp_free.  A window belongs to the device that was current when it opened; it is launched there
- * whatever device is current later.  Frames the batched kernels do not serve, and calls on a stream that is
- * being recorded into a launch graph (record-time batching does the same job there), run as the plain call at once.
- * The C++ drop-in surface (vpp/core/pixel_wise.hh: ops::box_mean, ops::add/sub; colorspace_conversions.hh) calls these: a frame loop written like the
- * reference's reaches the batch rate (4K vuchar3 box5x5: 8.3 us per frame instead of 13.5).  A launch failure of a window that another call flushed is reported
- * by this thread's next vpp_flush / vpp_sync. */
+ * vpp_flush, when its thread ends, and before ANYTHING else is queued through this ABI by the same thread (on any stream) or by ANY host thread on the window's
+ * stream — every entry point that takes a stream (copies, events, vpp_sync, graphs, every kernel) and vpp_free — so stream order, results and what a vpp_sync waits
+ * for are exactly those of the plain calls, also when one host thread makes the calls and another one (which the first has handed the stream to) synchronises.
+ * What is NOT covered: work queued on the stream by other means than this ABI (raw HIP calls, another library) — call vpp_flush before such work, and before an
+ * image's memory is released by any other means than vpp_free.  A window belongs to the device that was current when it opened; it is launched there whatever device
+ * is current later.  Frames the batched kernels do not serve run as the plain call at once.
+ * Recorded streams: on a stream that the calling thread records through vpp_graph_begin, the PLAIN per-frame entry points (vpp_box_filter, vpp_pixelwise_binary,
+ * vpp_rgb_to_graylevel) hold their frames back in the same window, and a window that closes (as above, or at vpp_graph_end) records ONE node of the batched
+ * kernel: a recorded frame loop replays as batched launches.  On a stream captured by other means (hipStreamBeginCapture by the caller) every call records its own
+ * node at once, deferred or not — the library cannot see that capture end.
+ * The C++ drop-in surface (vpp/core/pixel_wise.hh: ops::box_mean, ops::add/sub; colorspace_conversions.hh) calls these (its `_immediate` option selects the plain
+ * call): a frame loop written like the reference's reaches the batch rate (4K vuchar3 box5x5: 8.3 us per frame instead of 13.5).
+ * Errors: argument errors are reported at the call.  A window that fails to LAUNCH is never reported as the failure of the call that happened to close it: the
+ * status, the entry point and the number of dropped frames are kept and returned (once) by the owning thread's next vpp_flush / vpp_sync. */
 int vpp_box_filter_deferred(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream);
 int vpp_pixelwise_binary_deferred(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, void* stream);
 int vpp_rgb_to_graylevel_deferred(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream);
-int vpp_flush(void* stream);                       /* launches the calling thread's window (whatever its stream); VPP_OK when there is none */
+int vpp_flush(void* stream);                       /* launches the calling thread's window (whatever its stream) and any thread's window that waits on `stream`; VPP_OK when there is none */
 unsigned long long vpp_deferred_flushes(void);     /* batches launched for the calling thread so far (the C++ surface throttles per batch, not per call) */
 int vpp_deferred_pending(void);                    /* calls held back in the calling thread's window right now */
 

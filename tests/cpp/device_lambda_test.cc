@@ -303,6 +303,56 @@ static void test_box_lambdas_against_the_oracle() {
   }
 }
 
+// Stream order between the held-back tagged functors and the kernels this translation unit launches itself (advisor, round 5): with every mirror already resident
+// no ABI call sits between `pixel_wise | ops::add()` (held back in the thread's window) and the lambda's own hipLaunchKernelGGL, so the lambda used to run BEFORE the
+// add whose result it reads.  Both directions, pixel_wise and block_wise, with values that differ per call (a stale read cannot pass), and the `_immediate` option.
+static void test_held_back_calls_and_lambdas_keep_their_order() {
+  const int nr = 300, nc = 512;
+  image2d<int> A(nr, nc), B(A.domain()), C(A.domain()), D(A.domain()), E(A.domain());
+  for (auto p : B.domain()) { B(p) = int(rng() % 1000); C(p) = int(rng() % 1000); }
+  fill(A, 0); fill(D, 0); fill(E, 0);
+  // make every mirror resident and current (state 1 or 2): no upload — hence no ABI call — will sit between the calls below
+  pixel_wise(A, B, C) | ops::add();
+  pixel_wise(D, A) | [] (int& d, int& a) { d = a; };
+  pixel_wise(E, A) | [] (int& e, int& a) { e = a; };
+  vpp::device::sync();
+  const image2d<int> &cA = A, &cB = B, &cC = C, &cD = D, &cE = E;   // const accessors download a newer mirror and leave it current: the images stay resident
+  for (int round = 1; round <= 3; round++) {
+    CHECK(A.device_current() && B.device_current() && C.device_current() && D.device_current() && E.device_current());
+    // tagged functor feeds a lambda: A = B - C (held back), then D = A * round through the opaque kernel
+    pixel_wise(A, B, C) | ops::sub();
+    CHECK(vpp_deferred_pending() == 1);
+    if (round == 1) pixel_wise(D, A) | [] (int& d, int& a) { d = a * 1; };
+    if (round == 2) pixel_wise(D, A) | [] (int& d, int& a) { d = a * 2; };
+    if (round == 3) pixel_wise(D, A) | [] (int& d, int& a) { d = a * 3; };
+    CHECK(vpp_deferred_pending() == 0);
+    // lambda feeds a tagged functor, which feeds a block_wise lambda: E = B + round (lambda), A = E + C (held back), then the first pixel of every 4 x 4 block of E = A's
+    if (round == 1) pixel_wise(E, B) | [] (int& e, int& b) { e = b + 1; };
+    if (round == 2) pixel_wise(E, B) | [] (int& e, int& b) { e = b + 2; };
+    if (round == 3) pixel_wise(E, B) | [] (int& e, int& b) { e = b + 3; };
+    pixel_wise(A, E, C) | ops::add();
+    CHECK(vpp_deferred_pending() == 1);
+    block_wise(vint2(4, 4), E, A) | [] (auto e, auto a) { e(0, 0) = a(0, 0) * 5; };
+    CHECK(vpp_deferred_pending() == 0);
+    for (int r = 0; r < nr; r += 7) for (int c = 0; c < nc; c += 5) {
+      CHECK(cD(r, c) == (cB(r, c) - cC(r, c)) * round);
+      CHECK(cA(r, c) == cB(r, c) + round + cC(r, c));
+      CHECK(cE(r, c) == ((r % 4 == 0 && c % 4 == 0) ? cA(r, c) * 5 : cB(r, c) + round));
+    }
+  }
+  // `_immediate`: the tagged functor launches at once, nothing is held back
+  pixel_wise(A, B, C)(_immediate) | ops::add();
+  CHECK(vpp_deferred_pending() == 0);
+  image2d<vuchar3> S(64, 160, _border = 2), T(S.domain()), W(S.domain());
+  for (auto p : S.domain_with_border()) S(p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
+  pixel_wise(T, relative_access(S))(_immediate) | ops::box_mean<5, 5>();
+  CHECK(vpp_deferred_pending() == 0);
+  pixel_wise(W, relative_access(S)) | ops::box_mean<5, 5>();
+  CHECK(vpp_deferred_pending() == 1);
+  CHECK(same_pixels(T, W));
+  for (auto p : A.domain()) CHECK(A(p) == B(p) + C(p));
+}
+
 static double seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static void time_4k() {
@@ -392,6 +442,7 @@ int main(int argc, char** argv) {
   STEP(test_neighbourhood_tiles);
   STEP(test_writes_through_a_neighbourhood);
   STEP(test_box_lambdas_against_the_oracle);
+  STEP(test_held_back_calls_and_lambdas_keep_their_order);
   if (argc > 1 && !std::strcmp(argv[1], "time")) STEP(time_4k);
   std::printf("device_lambda_test ok\n");
   return 0;

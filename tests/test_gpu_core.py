@@ -465,12 +465,12 @@ def _kernel_nodes(lib, graph):
 
 
 def test_recorded_per_frame_calls_are_batched_and_keep_their_data_flow(lib, orc):
-    """Record-time batching (box.hip): per-frame vpp_box_filter calls recorded into a launch graph fold into the previous call's node while their
-    frames are unrelated to everything recorded in between — and only then.  A sequence with 70 independent frames, a frame that reads an earlier
-    result (RAW on the batch), frames related only to what the current node already waits for (they join it), a frame that overwrites a source the
-    first batch read (WAR) and a frame that reads what the current node writes (a node of its own): results equal the calls made one after the other
-    (the oracle applies them in sequence), and the graph has the 4 kernel nodes the data flow needs instead of 75.  With the knobs off: 75 nodes,
-    same results."""
+    """Recorded per-frame calls (box.hip, common.hpp): vpp_box_filter calls on a stream recorded through vpp_graph_begin are held back in the thread's window and
+    a window that closes records ONE batched node — no node of the graph under capture is ever edited (rounds 4-5 did, with hipGraphKernelNodeSetParams).  A
+    sequence with 70 independent frames, frames that read results of the node already recorded (they join the open window), a frame that overwrites a source the
+    first batch read (WAR against a recorded node: joins), a frame that reads a PENDING result (closes the window) and one that reads that frame's result (again):
+    results equal the calls made one after the other (the oracle applies them in sequence), and the graph has the 4 kernel nodes the data flow needs instead of
+    75 (64 | 6 + 3 | 1 | 1; round 5's node editing needed 5).  With the knobs off: 75 nodes, same results."""
     shape, ch = (48, 200), 3
     rng_ims = lambda: [rand_image(*shape, vi.U8, ch, border=2, seed=300 + k, align=16, fill_border=True) for k in range(210)]
     seq = [(100 + k, k) for k in range(70)] + [(200, 103), (201, 104), (5, 150), (202, 5), (203, 202)]
@@ -479,7 +479,7 @@ def test_recorded_per_frame_calls_are_batched_and_keep_their_data_flow(lib, orc)
         assert orc.orc_box_filter(P(host[d].desc), P(host[s_].desc), 5, 5) == 0
     st = torch_stream()
     sp = ctypes.c_void_p(st.cuda_stream)
-    for knobs, want_nodes in (({}, 5), ({b"box.coalesce": 0, b"launch.capture_width": 1}, 75)):
+    for knobs, want_nodes in (({}, 4), ({b"box.coalesce": 0, b"launch.capture_width": 1}, 75)):
         for k, v in knobs.items():
             lib.vpp_set_tuning(k, v)
         try:
@@ -491,6 +491,7 @@ def test_recorded_per_frame_calls_are_batched_and_keep_their_data_flow(lib, orc)
             for d, s_ in seq:
                 capi.check(lib.vpp_box_filter(P(dev[d].desc), P(dev[s_].desc), 5, 5, sp))
             capi.check(lib.vpp_graph_end(sp, 0, ctypes.byref(graph)))
+            assert lib.vpp_deferred_pending() == 0          # vpp_graph_end recorded the last window
             assert _kernel_nodes(lib, graph) == want_nodes
             capi.check(lib.vpp_graph_launch(graph, sp)); capi.check(lib.vpp_sync(sp))
             for k in range(210):
@@ -577,3 +578,77 @@ def test_deferred_per_frame_calls_through_the_c_abi(lib, orc):
     for k in range(5):
         want = HostImage(72, 160, vi.U8, 1, 3); assert orc.orc_rgb_to_graylevel(P(want.desc), P(frames[k].desc), 1) == 0
         np.testing.assert_array_equal(dg[k].download().view(with_border=True), want.view(with_border=True))
+
+
+def test_held_back_calls_cross_host_threads(lib, orc):
+    """The window is per host thread, the ORDER is per stream (round 6): frames one thread has held back are launched by whatever any other thread queues on that
+    stream afterwards (here the main thread's vpp_sync — the first thread has returned from its calls and handed the stream over, it has neither flushed nor
+    ended), and a thread that ends with frames held back launches them (it used to drop them silently)."""
+    import threading
+    import torch
+    st = torch_stream(); sp = ctypes.c_void_p(st.cuda_stream)
+    n, nr, nc = 15, 64, 176
+    srcs, wants = [], []
+    for k in range(n):
+        h = rand_image(nr, nc, vi.U8, 3, border=2, seed=900 + k, align=16, fill_border=True)
+        w = h.like(border=0); assert orc.orc_box_filter(P(w.desc), P(h.desc), 5, 5) == 0
+        srcs.append(DeviceImage.from_host(h)); wants.append(w)
+    dsts = [DeviceImage(nr, nc, vi.U8, 3, 0, 16) for _ in range(n)]
+    capi.check(lib.vpp_sync(sp)); torch.cuda.synchronize()
+    handed_over, go_on = threading.Event(), threading.Event()
+    seen = {}
+
+    def worker():
+        try:
+            torch.cuda.set_device(0)
+            for k in range(10):
+                capi.check(lib.vpp_box_filter_deferred(P(dsts[k].desc), P(srcs[k].desc), 5, 5, sp))
+            seen["pending_at_hand_over"] = lib.vpp_deferred_pending()
+            handed_over.set()
+            assert go_on.wait(60)
+            seen["pending_after_foreign_sync"] = lib.vpp_deferred_pending()
+            for k in range(10, n):
+                capi.check(lib.vpp_box_filter_deferred(P(dsts[k].desc), P(srcs[k].desc), 5, 5, sp))
+            seen["pending_at_exit"] = lib.vpp_deferred_pending()
+        except BaseException as e:   # noqa: BLE001 — reported by the main thread
+            seen["error"] = e
+            handed_over.set()
+
+    t = threading.Thread(target=worker); t.start()
+    assert handed_over.wait(60) and "error" not in seen, seen.get("error")
+    assert lib.vpp_deferred_pending() == 0                      # (the main thread's own window)
+    capi.check(lib.vpp_sync(sp))                                 # launches the worker's 10 frames, then waits for them
+    for k in range(10):
+        np.testing.assert_array_equal(dsts[k].download().view(), wants[k].view(), err_msg=f"frame {k}: held back by the worker, synchronised by the main thread")
+    go_on.set(); t.join(60)
+    assert not t.is_alive() and "error" not in seen, seen.get("error")
+    assert seen == {"pending_at_hand_over": 10, "pending_after_foreign_sync": 0, "pending_at_exit": 5}
+    capi.check(lib.vpp_sync(sp))                                 # the worker has ended: its last 5 frames were launched when it did
+    for k in range(10, n):
+        np.testing.assert_array_equal(dsts[k].download().view(), wants[k].view(), err_msg=f"frame {k}: held back when its thread ended")
+
+
+def test_a_capture_the_library_did_not_begin_records_every_call_at_once(lib, orc):
+    """vpp_graph_end closes the last held-back window of a recorded stream; a capture begun by other means (here torch's) ends where the library cannot see it, so
+    there nothing may be held back: plain and deferred per-frame calls record their own node each, and the replayed graph carries all of them."""
+    import torch
+    n, nr, nc = 6, 48, 176
+    srcs, wants = [], []
+    for k in range(n):
+        h = rand_image(nr, nc, vi.U8, 3, border=2, seed=950 + k, align=16, fill_border=True)
+        w = h.like(border=0); assert orc.orc_box_filter(P(w.desc), P(h.desc), 5, 5) == 0
+        srcs.append(DeviceImage.from_host(h)); wants.append(w)
+    dsts = [DeviceImage(nr, nc, vi.U8, 3, 0, 16) for _ in range(n)]
+    st = torch_stream(); sp = ctypes.c_void_p(st.cuda_stream)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+        for k in range(n):
+            f = lib.vpp_box_filter if k % 2 == 0 else lib.vpp_box_filter_deferred
+            capi.check(f(P(dsts[k].desc), P(srcs[k].desc), 5, 5, sp))
+            assert lib.vpp_deferred_pending() == 0
+    for d in dsts:
+        assert not d.download().view().any()        # recorded, not run
+    g.replay(); torch.cuda.synchronize()
+    for d, w in zip(dsts, wants):
+        np.testing.assert_array_equal(d.download().view(), w.view())

@@ -451,7 +451,7 @@ def test_a_refused_update_does_not_advance_the_tracker(lib):
 @pytest.mark.parametrize("ch,mirror,n", [(3, 1, 5), (4, 1, 3), (3, 0, 70)])
 def test_rgb_to_graylevel_batch_and_recorded_calls(lib, orc, ch, mirror, n):
     """vpp_rgb_to_graylevel_batch: n frames of one geometry in one launch (70 > the 64 a launch carries: two launches), every frame against the oracle; the same
-    frames as per-frame calls recorded into a launch graph fold into batched nodes (record-time batching, video.hip: coalesce_gray) with the same bytes; a
+    frames as per-frame calls recorded into a launch graph are recorded as batched nodes (the held-back window of common.hpp) with the same bytes; a
     frame of another geometry in the batch sends it out as the calls in sequence."""
     shape, border = (45, 150), 3
     srcs = [rand_image(*shape, vi.U8, ch, border=0 if mirror else border, seed=500 + k, fill_border=True) for k in range(n)]

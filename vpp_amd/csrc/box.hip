@@ -925,55 +925,17 @@ template <int CH> int launch_stream_windows(const vpp_image_desc* dst, const vpp
 }
 
 #ifndef VPP_BOX_LAB
-// ---- record-time batching of the per-frame call form ---------------------------------------------------------------------------------------------------
+// ---- the per-frame call form on a recorded stream ----------------------------------------------------------------------------------------------------------
 // The reference filters one frame per call (benchmarks/box_5x5_filter2.cc:43-69).  Eagerly that is one launch per call, and a 50 MB launch reaches 47 % of
 // the HBM peak (ramp + drain behind a kernel boundary; tools/overlap_lab.hip: the AQL barrier bit cannot be dropped on this chip, two queues reach 59 %).
-// While a stream is being RECORDED, nothing runs yet — so a call whose frame is unrelated to everything recorded since the previous box call's node (or
-// related only to calls that node was itself recorded behind) does not add a node: the node of the previous call is re-parameterised to carry one frame
-// more (hipGraphKernelNodeSetParams on the graph under capture: the frame becomes another slot of the batch kernel's frame table, up to kBoxBatchMax).
-// A recorded loop of per-frame calls thereby replays as the batched launches of vpp_box_filter_batch, with the results of the calls in sequence.
+// While a stream is being RECORDED through vpp_graph_begin nothing runs yet, so vpp_box_filter holds its frame back in the calling thread's window (common.hpp:
+// the mechanism of the *_deferred entry points) and a window that closes — 64 frames, a frame related to a pending one, any other call, vpp_graph_end — records
+// ONE node of the batched kernel.  A recorded loop of per-frame calls thereby replays as the launches of vpp_box_filter_batch, with the results of the calls in
+// sequence.  (Rounds 4-5 re-parameterised the previous call's node instead — hipGraphKernelNodeSetParams on a graph under capture; see LABNOTES.md, round 6.)
 namespace {
-struct BoxCoalesce {
-  unsigned long long window = 0; hipGraphNode_t node = nullptr; int lane = 0; std::vector<hipGraphNode_t> behind;
-  int ch = 0, n = 0; vpp_image_desc d0{}, s0{}; BoxBatch frames{};
-};
-thread_local std::map<hipStream_t, BoxCoalesce> g_box_coalesce;
-template <int CH, int RW, int OCC> hipError_t set_batch_node(const BoxCoalesce& c) {
-  BoxGeom g = wide_geometry<CH, RW, 4, false, 4>(&c.d0, &c.s0, tuning("box.order", 0), tuning("box.mix", 0), tuning("box.slots", 8192));
-  BoxBatch fr = c.frames; int n = c.n;
-  void* args[3] = {&g, &fr, &n};
-  hipKernelNodeParams kp{};
-  kp.func = (void*)box_u8_wide_kernel<CH, 5, 5, RW, 4, kAuxNT, kAuxDefault, false, OCC, 0, 4>;
-  kp.gridDim = dim3((unsigned)(g.nbx * g.nby * n)); kp.blockDim = dim3(256); kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
-  return hipGraphKernelNodeSetParams(c.node, &kp);
-}
-template <int CH> hipError_t set_batch_node(const BoxCoalesce& c) {   // the instance launch_wide picks for c.n frames
-  if (c.n >= 4) return set_batch_node<CH, 6, 4>(c);
-  if (c.n >= 2) return set_batch_node<CH, 3, 8>(c);
-  return set_batch_node<CH, 2, 8>(c);
-}
-inline bool same_box_geometry(const vpp_image_desc& a, const vpp_image_desc& b) {
-  return a.nrows == b.nrows && a.ncols == b.ncols && a.pitch == b.pitch && a.border == b.border && a.dtype == b.dtype && a.channels == b.channels;
-}
-// true: the frame was folded into the node recorded by the previous box call
-bool coalesce_frame(IndependentCall& side, hipStream_t st, const vpp_image_desc* dst, const vpp_image_desc* src) {
-  BoxCoalesce& c = g_box_coalesce[st];
-  if (!(c.n > 0 && c.n < kBoxBatchMax && c.window == side.window() && c.ch == dst->channels && same_box_geometry(*dst, c.d0) && same_box_geometry(*src, c.s0))) return false;
-  for (hipGraphNode_t x : side.conflicts())
-    if (x == c.node || std::find(c.behind.begin(), c.behind.end(), x) == c.behind.end()) return false;   // related to the batch itself, or to something the batch does not wait for
-  c.frames.sbase[c.n] = (const uint8_t*)src->first_pixel - (ptrdiff_t)src->border * src->pitch - 16;
-  c.frames.dbase[c.n] = (uint8_t*)dst->first_pixel;
-  c.n++;
-  hipError_t e = hipErrorInvalidValue;
-  switch (c.ch) {
-    case 1: e = set_batch_node<1>(c); break;
-    case 2: e = set_batch_node<2>(c); break;
-    case 3: e = set_batch_node<3>(c); break;
-    case 4: e = set_batch_node<4>(c); break;
-  }
-  if (e != hipSuccess) { (void)hipGetLastError(); c.n = 0; return false; }   // this runtime cannot edit the node: the call records its own node (the old node still carries its frames)
-  side.absorbed_into(c.node, c.lane);
-  return true;
+inline bool box_batchable(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C) {   // the frames the batched streaming kernel serves (the test of vpp_box_filter_batch)
+  return dst->dtype == VPP_U8 && R == 5 && C == 5 && dst->channels <= 4 && src->border >= 2 && aligned16(dst) && aligned16(src) && fits_descriptor(dst, src) &&
+         !tuning("box.force_generic", 0) && tuning("box.impl", 2) == 2 && tuning("box.batch", 1);
 }
 }  // namespace
 #endif
@@ -1025,20 +987,21 @@ extern "C" int vpp_debug_box_copy_batch(const vpp_image_desc* dst, const vpp_ima
 }
 
 #ifndef VPP_BOX_LAB
-// The per-frame call form without its per-frame launch (common.hpp, "deferred per-frame calls"): the frame joins the calling thread's window; argument errors
-// are reported here, at the call, as vpp_box_filter reports them.  Frames the batched streaming kernel does not serve, and calls on a stream that is being
-// recorded (record-time batching does the same job there), go out at once — behind the window, which as_stream() launches first.
+// The per-frame call form without its per-frame launch (common.hpp, "held-back per-frame calls"): the frame joins the calling thread's window; argument errors
+// are reported here, at the call, as vpp_box_filter reports them.  Frames the batched streaming kernel does not serve go out at once — behind the window, which
+// as_stream() launches first.
 extern "C" int vpp_box_filter_deferred(const vpp_image_desc* dst, const vpp_image_desc* src, int R, int C, void* stream) {
   VPP_REQUIRE(valid_desc(dst) && valid_desc(src), VPP_ERR_INVALID_ARG, "vpp_box_filter: invalid descriptor");
   VPP_REQUIRE(same_domain(dst, src) && same_type(dst, src), VPP_ERR_INVALID_ARG, "vpp_box_filter: domain/type mismatch");
   VPP_REQUIRE(R > 0 && C > 0 && (R & 1) && (C & 1), VPP_ERR_INVALID_ARG, "vpp_box_filter: window must be odd x odd");
   VPP_REQUIRE(src->border >= (R > C ? R : C) / 2, VPP_ERR_BORDER_TOO_SMALL, "vpp_box_filter: src border %d < %d", src->border, (R > C ? R : C) / 2);
   VPP_REQUIRE(dst->first_pixel != src->first_pixel, VPP_ERR_INVALID_ARG, "vpp_box_filter: in-place not supported");
+  // (a stream captured by other means than vpp_graph_begin ends its capture where this library cannot see it: nothing is held back there)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-  const bool batchable = cap == hipStreamCaptureStatusNone && tuning("defer", 1) && dst->dtype == VPP_U8 && R == 5 && C == 5 && dst->channels <= 4 && src->border >= 2 &&
-                         aligned16(dst) && aligned16(src) && fits_descriptor(dst, src) && !tuning("box.force_generic", 0) && tuning("box.impl", 2) == 2 && tuning("box.batch", 1);
-  if (!batchable) return vpp_box_filter(dst, src, R, C, stream);
+  const bool hold = !g_defer_bypass && tuning("defer", 1) && box_batchable(dst, src, R, C) &&
+                    (cap == hipStreamCaptureStatusNone || (defer_recording(stream) && tuning("box.coalesce", 1)));
+  if (!hold) return vpp_box_filter(dst, src, R, C, stream);
   return defer_call(kDeferBox, R, C, stream, dst, src, nullptr);
 }
 #endif
@@ -1049,31 +1012,15 @@ extern "C" int vpp_box_filter(const vpp_image_desc* dst, const vpp_image_desc* s
   VPP_REQUIRE(R > 0 && C > 0 && (R & 1) && (C & 1), VPP_ERR_INVALID_ARG, "vpp_box_filter: window must be odd x odd");
   VPP_REQUIRE(src->border >= (R > C ? R : C) / 2, VPP_ERR_BORDER_TOO_SMALL, "vpp_box_filter: src border %d < %d", src->border, (R > C ? R : C) / 2);
   VPP_REQUIRE(dst->first_pixel != src->first_pixel, VPP_ERR_INVALID_ARG, "vpp_box_filter: in-place not supported");
-  hipStream_t st = as_stream(stream);
-  // while the stream is recorded into a launch graph: calls on unrelated images become sibling nodes (common.hpp, IndependentCall)
 #ifndef VPP_BOX_LAB
+  // on a stream this thread records through vpp_graph_begin: the frame is held back and recorded as part of ONE batched node (above)
+  if (!g_defer_bypass && defer_recording(stream) && tuning("box.coalesce", 1) && box_batchable(dst, src, R, C)) return defer_call(kDeferBox, R, C, stream, dst, src, nullptr);
+#endif
+  hipStream_t st = as_stream(stream);
+#ifndef VPP_BOX_LAB
+  // while the stream is recorded into a launch graph: calls on unrelated images become sibling nodes (common.hpp, IndependentCall)
   const Extent wr = extent_of(*dst), rd = extent_of(*src);
   IndependentCall side_by_side(st, &wr, 1, &rd, 1);
-  // the frames the batched streaming kernel serves (the test of vpp_box_filter_batch): candidates for record-time batching
-  const bool batchable = side_by_side.active() && dst->dtype == VPP_U8 && R == 5 && C == 5 && dst->channels <= 4 && src->border >= 2 && aligned16(dst) && aligned16(src) &&
-                         fits_descriptor(dst, src) && !tuning("box.force_generic", 0) && tuning("box.impl", 2) == 2 && tuning("box.batch", 1) && tuning("box.coalesce", 1);
-  if (batchable && coalesce_frame(side_by_side, st, dst, src)) return VPP_OK;
-  struct Remember {   // after the call's own launch: its node becomes the one the next calls may join
-    IndependentCall& side; hipStream_t st; const vpp_image_desc *dst, *src; bool on;
-    ~Remember() {
-      if (!side.active()) return;
-      BoxCoalesce& c = g_box_coalesce[st];
-      c.n = 0;
-      if (!on) return;
-      int lane = 0; std::vector<hipGraphNode_t> behind;
-      const unsigned long long window = side.window();
-      hipGraphNode_t node = side.finish(&lane, &behind);
-      if (!node) return;
-      c.window = window; c.node = node; c.lane = lane; c.behind = behind; c.ch = dst->channels; c.n = 1; c.d0 = *dst; c.s0 = *src;
-      c.frames.sbase[0] = (const uint8_t*)src->first_pixel - (ptrdiff_t)src->border * src->pitch - 16;
-      c.frames.dbase[0] = (uint8_t*)dst->first_pixel;
-    }
-  } remember{side_by_side, st, dst, src, batchable};
 #endif
   if (dst->dtype == VPP_U8 && R == 5 && C == 5 && dst->channels <= 4 && aligned16(dst) && aligned16(src) && !tuning("box.force_generic", 0)) {
     switch (dst->channels) {

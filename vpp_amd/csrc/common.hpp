@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <algorithm>
+#include <atomic>
 #include <vector>
 #include "../../include/vpp_amd.h"
 
@@ -39,33 +40,43 @@ int comm_allgather_inplace(vpp_comm* comm, void* base, size_t bytes_per_rank, hi
 int comm_group_begin();
 int comm_group_end();
 
-// ---- deferred per-frame calls (vpp_*_deferred, include/vpp_amd.h) --------------------------------------------------------------------------------------
+// ---- held-back per-frame calls (vpp_*_deferred, and the plain per-frame entry points on a stream recorded through vpp_graph_begin) ------------------------
 // The reference's call form is one frame per call (benchmarks/box_5x5_filter2.cc:43-81, benchmarks/image_add.cc:51-57); eagerly that is one launch per call, and
-// a 50 MB launch reaches 46 % of the HBM peak where 64 frames in one launch reach 74 %.  A *_deferred entry point does not launch: it appends its frame to the
-// calling thread's window while the frame is unrelated to the pending ones (no pending result overlaps its source or result, its result overlaps no pending
-// source) and has their geometry; the window goes out as ONE batched launch (the vpp_*_batch kernels: "the results of the n calls one after the other") when
-// it holds kDeferMax frames, when a call that cannot join arrives, at vpp_flush — and before ANYTHING else this thread queues through this ABI on any stream:
-// every entry point turns its stream argument into a hipStream_t with as_stream(), which flushes first.  Stream order is therefore exactly that of the calls.
+// a 50 MB launch reaches 46 % of the HBM peak where 64 frames in one launch reach 74 %.  A held-back call does not launch: it appends its frame to the calling
+// thread's window while the frame is unrelated to the pending ones (no pending result overlaps its source or result, its result overlaps no pending source) and
+// has their geometry; the window goes out as ONE batched launch (the vpp_*_batch kernels: "the results of the n calls one after the other") when it holds
+// kDeferMax frames, when a call that cannot join arrives, at vpp_flush / vpp_graph_end — and before ANYTHING else is queued through this ABI by the same thread (on
+// any stream) or by ANY thread on the window's stream: every entry point turns its stream argument into a hipStream_t with as_stream(), which launches those
+// windows first.  Stream order is therefore exactly that of the calls, also when one host thread makes the calls and another one synchronises the stream.
+// ONE mechanism serves the eager and the recorded form (round 6; until then a recorded call re-parameterised the previous call's node with
+// hipGraphKernelNodeSetParams while the graph was under capture): on a stream this thread records through vpp_graph_begin the plain per-frame entry points hold
+// their frames back the same way, and a window that closes records ONE kernel node.  No node of a graph under capture is ever edited.
 constexpr int kDeferMax = 64;
 enum { kDeferNone = 0, kDeferBox = 1, kDeferBinary = 2, kDeferGray = 3 };
-struct DeferWindow {
+struct DeferBatch {                // what one launch carries
   int n = 0;                       // pending calls
   int kind = kDeferNone, p0 = 0, p1 = 0;   // the entry point and its scalar parameters (box: R, C; binary: op; gray: mirror)
   int nsrc = 0;
   void* stream = nullptr;
   int dev = 0;                     // the device that was current when the window opened (its stream's device)
-  unsigned long long flushes = 0;  // batches launched for this thread so far (vpp_deferred_flushes: the C++ surface throttles per batch, not per call)
-  int last_rc = VPP_OK;            // of a flush that another call triggered: reported by the next vpp_flush / vpp_sync of this thread
   vpp_image_desc dst[kDeferMax], src[2][kDeferMax];
 };
-extern thread_local DeferWindow g_defer;
-int defer_flush();   // runtime.hip: launches the window (if any) and empties it; the launch's status (also kept in last_rc when it failed)
-// the call joins the window (flushing it first when it cannot: another entry point / parameters / stream / geometry, or data flow between it and a pending
-// call); returns the flush's status, VPP_OK when nothing had to go out.  When the window is full afterwards it is launched.
+struct DeferWindow;
+DeferWindow& defer_window();       // the calling thread's (created and registered at first use, launched and unregistered when the thread ends)
+extern std::atomic<int> g_defer_pending;   // frames held back by ALL threads: the one word as_stream() reads on the common path
+extern thread_local int g_defer_bypass;    // > 0 while this thread launches a window (the batch entry points are ordinary entry points: they must not hold back or flush again)
+int defer_flush();                 // launches the calling thread's window (if any) and empties it; the launch's status (kept as the window's sticky error when it failed)
+int defer_flush_stream(void* stream);   // + every other thread's window that waits on `stream`
+// the call joins the calling thread's window (which is launched first when the call cannot join it: another entry point / parameters / stream / geometry, or
+// data flow between the call and a pending one) and launches it when it is full.  Always VPP_OK: a window that fails to launch is not THIS call's failure — it
+// is kept as the window's sticky error (status, entry point, frame count) and reported by this thread's next vpp_flush / vpp_sync.
 int defer_call(int kind, int p0, int p1, void* stream, const vpp_image_desc* dst, const vpp_image_desc* src0, const vpp_image_desc* src1);
+// true: `stream` is being recorded by this thread between vpp_graph_begin and vpp_graph_end (then vpp_graph_end closes the last window, so frames may be held
+// back; a capture begun by other means ends where this library cannot see it: every call records its own node there)
+bool defer_recording(void* stream);
 
 inline hipStream_t as_stream(void* s) {
-  if (g_defer.n) (void)defer_flush();   // whatever this call queues comes after the deferred calls made before it
+  if (g_defer_pending.load(std::memory_order_acquire) && !g_defer_bypass) (void)defer_flush_stream(s);   // whatever this call queues comes after the calls held back before it
   return reinterpret_cast<hipStream_t>(s);
 }
 
@@ -155,21 +166,12 @@ class IndependentCall {
   ~IndependentCall() { if (active_) (void)finish(); }
   IndependentCall(const IndependentCall&) = delete;
   IndependentCall& operator=(const IndependentCall&) = delete;
-  // --- for calls that can fold themselves into a node they recorded earlier (record-time batching: vpp_box_filter, vpp_pixelwise_binary) ---
-  bool active() const { return active_; }                 // the stream is being recorded and a window is open
-  unsigned long long window() const { return window_; }   // identifies the window: a node of an earlier window must not be extended
-  // recorded calls (nodes) whose extents this call's overlap: it may only join a node that is none of them and was itself recorded behind all of them
-  const std::vector<hipGraphNode_t>& conflicts() const { return conflicts_; }
-  // this call's work was folded into `node` (recorded by an earlier call of this window in `lane`): its extents are booked on that node, nothing new is recorded
-  void absorbed_into(hipGraphNode_t node, int lane);
-  // the call's launches are recorded: books them, rejoins the lanes; returns the call's (last) node — nullptr when there is no single one — its lane and what it was recorded behind
-  hipGraphNode_t finish(int* lane = nullptr, std::vector<hipGraphNode_t>* recorded_behind = nullptr);
+  // the call's launches are recorded: books them, rejoins the lanes; returns the call's (last) node — nullptr when there is no single one
+  hipGraphNode_t finish();
  private:
   hipStream_t st_;
   bool active_ = false;
   int lane_ = 0;
-  unsigned long long window_ = 0;
-  std::vector<hipGraphNode_t> conflicts_;
   Extent w_[2], r_[3];
   int nw_ = 0, nr_ = 0;
 };

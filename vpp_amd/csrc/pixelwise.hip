@@ -306,23 +306,8 @@ template <int OP, class T> int launch_flat_batch(const vpp_image_desc* dst, cons
 }
 }  // namespace
 
-// ---- record-time batching of the per-call form (see box.hip: the same mechanism for `A = B + C` on flat 32-bit integer images) ----
+// ---- the per-call form on a recorded stream / without its per-call launch (see box.hip and common.hpp: the same window for `A = B + C` on flat 32-bit images) ----
 namespace {
-struct PwCoalesce {
-  unsigned long long window = 0; hipGraphNode_t node = nullptr; int lane = 0; std::vector<hipGraphNode_t> behind;
-  int op = 0, n = 0; size_t nvec = 0; PwBatch frames{};
-};
-thread_local std::map<hipStream_t, PwCoalesce> g_pw_coalesce;
-template <int OP> hipError_t set_pw_node(const PwCoalesce& c) {
-  constexpr int UN = 8;
-  PwBatch fr = c.frames; size_t nvec = c.nvec;
-  unsigned bpf = (unsigned)((nvec + 256 * UN - 1) / (256 * UN));
-  void* args[3] = {&fr, &nvec, &bpf};
-  hipKernelNodeParams kp{};
-  kp.func = (void*)binary_flat_batch_kernel<OP, int32_t, UN, true>;
-  kp.gridDim = dim3(bpf * (unsigned)c.n); kp.blockDim = dim3(256); kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
-  return hipGraphKernelNodeSetParams(c.node, &kp);
-}
 inline bool pw_batchable(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b) {   // the frames launch_flat_batch serves
   if (!((op == VPP_OP_ADD || op == VPP_OP_SUB) && (dst->dtype == VPP_I32 || dst->dtype == VPP_U32) && tuning("add.batch", 1) && tuning("add.coalesce", 1) &&
         tuning("add.unroll", 8) == 8 && tuning("add.nt", 1) == 1)) return false;
@@ -333,19 +318,6 @@ inline bool pw_batchable(int op, const vpp_image_desc* dst, const vpp_image_desc
   }
   return true;
 }
-bool coalesce_triple(IndependentCall& side, hipStream_t st, int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b) {
-  PwCoalesce& c = g_pw_coalesce[st];
-  const size_t nvec = ((size_t)dst->ncols * elem_bytes(dst) * dst->nrows) >> 4;
-  if (!(c.n > 0 && c.n < kPwBatchMax && c.window == side.window() && c.op == op && c.nvec == nvec)) return false;
-  for (hipGraphNode_t x : side.conflicts())
-    if (x == c.node || std::find(c.behind.begin(), c.behind.end(), x) == c.behind.end()) return false;
-  c.frames.d[c.n] = (u32x4*)dst->first_pixel; c.frames.a[c.n] = (const u32x4*)a->first_pixel; c.frames.b[c.n] = (const u32x4*)b->first_pixel;
-  c.n++;
-  const hipError_t e = op == VPP_OP_ADD ? set_pw_node<VPP_OP_ADD>(c) : set_pw_node<VPP_OP_SUB>(c);
-  if (e != hipSuccess) { (void)hipGetLastError(); c.n = 0; return false; }
-  side.absorbed_into(c.node, c.lane);
-  return true;
-}
 }  // namespace
 
 extern "C" {
@@ -354,28 +326,13 @@ int vpp_pixelwise_binary(int op, const vpp_image_desc* dst, const vpp_image_desc
   VPP_REQUIRE(valid_desc(dst) && valid_desc(a) && valid_desc(b), VPP_ERR_INVALID_ARG, "vpp_pixelwise_binary: invalid descriptor");
   VPP_REQUIRE(same_domain(dst, a) && same_domain(dst, b), VPP_ERR_INVALID_ARG, "vpp_pixelwise_binary: domains differ");
   VPP_REQUIRE(same_type(dst, a) && same_type(dst, b), VPP_ERR_UNSUPPORTED, "vpp_pixelwise_binary: mixed element types");
+  // on a stream this thread records through vpp_graph_begin: the triple is held back and recorded as part of ONE batched node (box.hip, common.hpp)
+  if (!g_defer_bypass && defer_recording(stream) && pw_batchable(op, dst, a, b) && dst->first_pixel != a->first_pixel && dst->first_pixel != b->first_pixel)
+    return defer_call(kDeferBinary, op, 0, stream, dst, a, b);
   hipStream_t st = as_stream(stream);
   // while the stream is recorded into a launch graph: calls on unrelated images become sibling nodes (common.hpp, IndependentCall)
   const Extent wr = extent_of(*dst), rd[2] = {extent_of(*a), extent_of(*b)};
   IndependentCall side_by_side(st, &wr, 1, rd, 2);
-  const bool batchable = side_by_side.active() && pw_batchable(op, dst, a, b) && dst->first_pixel != a->first_pixel && dst->first_pixel != b->first_pixel;
-  if (batchable && coalesce_triple(side_by_side, st, op, dst, a, b)) return VPP_OK;
-  struct Remember {   // after the call's own launch: its node becomes the one the next calls may join
-    IndependentCall& side; hipStream_t st; int op; const vpp_image_desc *dst, *a, *b; bool on;
-    ~Remember() {
-      if (!side.active()) return;
-      PwCoalesce& c = g_pw_coalesce[st];
-      c.n = 0;
-      if (!on) return;
-      int lane = 0; std::vector<hipGraphNode_t> behind;
-      const unsigned long long window = side.window();
-      hipGraphNode_t node = side.finish(&lane, &behind);
-      if (!node) return;
-      c.window = window; c.node = node; c.lane = lane; c.behind = behind; c.op = op; c.n = 1;
-      c.nvec = ((size_t)dst->ncols * elem_bytes(dst) * dst->nrows) >> 4;
-      c.frames.d[0] = (u32x4*)dst->first_pixel; c.frames.a[0] = (const u32x4*)a->first_pixel; c.frames.b[0] = (const u32x4*)b->first_pixel;
-    }
-  } remember{side_by_side, st, op, dst, a, b, batchable};
   switch (dst->dtype) {
     case VPP_U8: return dispatch_op<uint8_t>(op, dst, a, b, st);
     case VPP_I8: return dispatch_op<int8_t>(op, dst, a, b, st);
@@ -414,15 +371,16 @@ int vpp_pixelwise_binary_batch(int op, const vpp_image_desc* dst, const vpp_imag
 }
 
 // The per-call form without its per-call launch (common.hpp, "deferred per-frame calls"): the triple joins the calling thread's window; argument errors are
-// reported here, at the call, as vpp_pixelwise_binary reports them.  Triples the batched kernel does not serve, and calls on a stream that is being recorded
-// (record-time batching does the same job there), go out at once — behind the window, which as_stream() launches first.
+// reported here, at the call, as vpp_pixelwise_binary reports them.  Triples the batched kernel does not serve go out at once — behind the window, which
+// as_stream() launches first.
 int vpp_pixelwise_binary_deferred(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, void* stream) {
   VPP_REQUIRE(valid_desc(dst) && valid_desc(a) && valid_desc(b), VPP_ERR_INVALID_ARG, "vpp_pixelwise_binary: invalid descriptor");
   VPP_REQUIRE(same_domain(dst, a) && same_domain(dst, b), VPP_ERR_INVALID_ARG, "vpp_pixelwise_binary: domains differ");
   VPP_REQUIRE(same_type(dst, a) && same_type(dst, b), VPP_ERR_UNSUPPORTED, "vpp_pixelwise_binary: mixed element types");
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-  if (cap != hipStreamCaptureStatusNone || !tuning("defer", 1) || !pw_batchable(op, dst, a, b) || dst->first_pixel == a->first_pixel || dst->first_pixel == b->first_pixel)
+  if ((cap != hipStreamCaptureStatusNone && !defer_recording(stream)) || g_defer_bypass || !tuning("defer", 1) || !pw_batchable(op, dst, a, b) || dst->first_pixel == a->first_pixel ||
+      dst->first_pixel == b->first_pixel)
     return vpp_pixelwise_binary(op, dst, a, b, stream);
   return defer_call(kDeferBinary, op, 0, stream, dst, a, b);
 }

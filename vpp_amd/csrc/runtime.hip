@@ -53,29 +53,84 @@ static std::atomic<unsigned> g_notes_epoch{1};
 unsigned notes_epoch() { return g_notes_epoch.load(std::memory_order_relaxed); }
 void invalidate_scratch_notes() { g_notes_epoch.fetch_add(1, std::memory_order_relaxed); }
 
-// ---- deferred per-frame calls (common.hpp) ----------------------------------------------------------------------------------------------------------
-thread_local DeferWindow g_defer;
+// ---- held-back per-frame calls (common.hpp) ------------------------------------------------------------------------------------------------------------
+std::atomic<int> g_defer_pending{0};
+thread_local int g_defer_bypass = 0;
 extern "C" int vpp_box_filter_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int R, int C, void* stream);
 extern "C" int vpp_pixelwise_binary_batch(int op, const vpp_image_desc* dst, const vpp_image_desc* a, const vpp_image_desc* b, int n, void* stream);
 extern "C" int vpp_rgb_to_graylevel_batch(const vpp_image_desc* dst, const vpp_image_desc* src, int n, int mirror, void* stream);
-int defer_flush() {
-  DeferWindow& w = g_defer;
-  const int n = w.n;
+// A window belongs to the thread that fills it.  Everything that touches it — an append, a launch — happens under `mu`: the owner takes it for every call
+// (uncontended: tens of nanoseconds), another thread only when it queues something on the window's stream while frames are pending (it then launches them
+// itself, and the owner's next call waits for that launch to be queued: the frames of one thread never overtake each other).
+struct DeferWindow {
+  std::mutex mu;
+  DeferBatch b;
+  std::atomic<unsigned long long> flushes{0};   // batches launched for this thread so far (vpp_deferred_flushes: the C++ surface throttles per batch, not per call)
+  int last_rc = VPP_OK;                         // sticky: a window of this thread failed to launch; reported (once) by its next vpp_flush / vpp_sync
+  char last_msg[200] = "";
+};
+namespace {
+std::mutex g_defer_reg_mu;               // lock order: registry, then a window
+std::vector<DeferWindow*> g_defer_reg;   // every live thread's window
+const char* defer_kind_name(int kind) { return kind == kDeferBox ? "vpp_box_filter" : kind == kDeferBinary ? "vpp_pixelwise_binary" : kind == kDeferGray ? "vpp_rgb_to_graylevel" : "?"; }
+// launches the window and empties it (w.mu held by the caller)
+int defer_launch_locked(DeferWindow& w) {
+  DeferBatch& b = w.b;
+  const int n = b.n;
   if (!n) return VPP_OK;
-  w.n = 0;   // first: the batch entry points call as_stream() themselves
+  g_defer_pending.fetch_sub(n, std::memory_order_acq_rel);
+  b.n = 0;
   int rc = VPP_OK;
-  int cur = w.dev;
-  if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = w.dev; }
-  if (cur != w.dev && hipSetDevice(w.dev) != hipSuccess) { (void)hipGetLastError(); w.flushes++; w.last_rc = VPP_ERR_HIP; set_error("deferred calls: cannot return to device %d to launch them", w.dev); return VPP_ERR_HIP; }
-  switch (w.kind) {
-    case kDeferBox: rc = vpp_box_filter_batch(w.dst, w.src[0], n, w.p0, w.p1, w.stream); break;
-    case kDeferBinary: rc = vpp_pixelwise_binary_batch(w.p0, w.dst, w.src[0], w.src[1], n, w.stream); break;
-    case kDeferGray: rc = vpp_rgb_to_graylevel_batch(w.dst, w.src[0], n, w.p0, w.stream); break;
-    default: break;
+  int cur = b.dev;
+  if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = b.dev; }
+  if (cur != b.dev && hipSetDevice(b.dev) != hipSuccess) { (void)hipGetLastError(); set_error("cannot return to device %d", b.dev); rc = VPP_ERR_HIP; }
+  if (rc == VPP_OK) {
+    g_defer_bypass++;   // the batch entry points are ordinary entry points: they neither hold back nor flush while a window is being launched
+    switch (b.kind) {
+      case kDeferBox: rc = vpp_box_filter_batch(b.dst, b.src[0], n, b.p0, b.p1, b.stream); break;
+      case kDeferBinary: rc = vpp_pixelwise_binary_batch(b.p0, b.dst, b.src[0], b.src[1], n, b.stream); break;
+      case kDeferGray: rc = vpp_rgb_to_graylevel_batch(b.dst, b.src[0], n, b.p0, b.stream); break;
+      default: break;
+    }
+    g_defer_bypass--;
+    if (cur != b.dev) (void)hipSetDevice(cur);   // the caller has moved to another device since: back to it
   }
-  if (cur != w.dev) (void)hipSetDevice(cur);   // the caller has moved to another device since: back to it
-  w.flushes++;
-  if (rc != VPP_OK) w.last_rc = rc;
+  w.flushes.fetch_add(1, std::memory_order_release);
+  if (rc != VPP_OK) {   // the n frames were not queued: say so at the thread's next vpp_flush / vpp_sync
+    w.last_rc = rc;
+    snprintf(w.last_msg, sizeof w.last_msg, "a held-back batch of %d %s call%s failed to launch and was dropped (status %d): %.80s", n, defer_kind_name(b.kind), n == 1 ? "" : "s", rc, g_err);
+  }
+  return rc;
+}
+struct DeferOwner {
+  DeferWindow* w;
+  DeferOwner() : w(new DeferWindow()) { std::lock_guard<std::mutex> l(g_defer_reg_mu); g_defer_reg.push_back(w); }
+  // a thread that ends with frames held back launches them (until round 6 it had to vpp_flush before it ended, and silently dropped its calls when it did not)
+  ~DeferOwner() {
+    { std::lock_guard<std::mutex> l(w->mu); (void)defer_launch_locked(*w); }
+    { std::lock_guard<std::mutex> l(g_defer_reg_mu); g_defer_reg.erase(std::find(g_defer_reg.begin(), g_defer_reg.end(), w)); }
+    delete w;
+  }
+};
+}  // namespace
+DeferWindow& defer_window() { static thread_local DeferOwner owner; return *owner.w; }
+int defer_flush() {
+  DeferWindow& w = defer_window();
+  std::lock_guard<std::mutex> l(w.mu);
+  return defer_launch_locked(w);
+}
+int defer_flush_stream(void* stream) {
+  int rc = defer_flush();   // this thread's own window, whatever its stream
+  if (!g_defer_pending.load(std::memory_order_acquire)) return rc;
+  // other threads' windows that wait on this stream: this thread is about to queue behind calls they have already made (the threads ordered themselves — a
+  // thread that hands a stream over has returned from its calls).  Under the registry lock: an owner cannot end, and free its window, meanwhile.
+  DeferWindow* mine = &defer_window();
+  std::lock_guard<std::mutex> lr(g_defer_reg_mu);
+  for (DeferWindow* o : g_defer_reg) {
+    if (o == mine) continue;
+    std::lock_guard<std::mutex> l(o->mu);
+    if (o->b.n && o->b.stream == stream) { const int r2 = defer_launch_locked(*o); if (rc == VPP_OK) rc = r2; }
+  }
   return rc;
 }
 namespace {
@@ -86,29 +141,34 @@ inline bool same_frame_geometry(const vpp_image_desc& a, const vpp_image_desc& b
 inline bool extents_overlap(const Extent& a, const Extent& b) { return a.lo < b.hi && b.lo < a.hi; }
 }  // namespace
 int defer_call(int kind, int p0, int p1, void* stream, const vpp_image_desc* dst, const vpp_image_desc* src0, const vpp_image_desc* src1) {
-  DeferWindow& w = g_defer;
-  int rc = VPP_OK;
+  DeferWindow& w = defer_window();
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
-  if (w.n) {
-    bool join = w.dev == dev && w.kind == kind && w.p0 == p0 && w.p1 == p1 && w.stream == stream && same_frame_geometry(*dst, w.dst[0]) && same_frame_geometry(*src0, w.src[0][0]) &&
-                (!src1 || same_frame_geometry(*src1, w.src[1][0]));
+  std::lock_guard<std::mutex> l(w.mu);
+  DeferBatch& b = w.b;
+  if (b.n) {
+    bool join = b.dev == dev && b.kind == kind && b.p0 == p0 && b.p1 == p1 && b.stream == stream && same_frame_geometry(*dst, b.dst[0]) && same_frame_geometry(*src0, b.src[0][0]) &&
+                (!src1 || same_frame_geometry(*src1, b.src[1][0]));
     if (join) {   // no data flow between this frame and a pending one (reads of one source by several frames are fine)
       const Extent d = extent_of(*dst), s0 = extent_of(*src0), s1 = src1 ? extent_of(*src1) : Extent{0, 0};
-      for (int k = 0; join && k < w.n; k++) {
-        const Extent pd = extent_of(w.dst[k]);
-        join = !extents_overlap(d, pd) && !extents_overlap(s0, pd) && !(src1 && extents_overlap(s1, pd)) && !extents_overlap(d, extent_of(w.src[0][k])) &&
-               !(w.nsrc > 1 && extents_overlap(d, extent_of(w.src[1][k])));
+      for (int k = 0; join && k < b.n; k++) {
+        const Extent pd = extent_of(b.dst[k]);
+        join = !extents_overlap(d, pd) && !extents_overlap(s0, pd) && !(src1 && extents_overlap(s1, pd)) && !extents_overlap(d, extent_of(b.src[0][k])) &&
+               !(b.nsrc > 1 && extents_overlap(d, extent_of(b.src[1][k])));
       }
     }
-    if (!join) rc = defer_flush();
+    if (!join) (void)defer_launch_locked(w);   // (its failure is the window's sticky error, not this call's: this call's frame is only held back)
   }
-  if (!w.n) { w.kind = kind; w.p0 = p0; w.p1 = p1; w.stream = stream; w.dev = dev; w.nsrc = src1 ? 2 : 1; }
-  w.dst[w.n] = *dst; w.src[0][w.n] = *src0; if (src1) w.src[1][w.n] = *src1;
-  w.n++;
-  if (w.n == kDeferMax) { const int r2 = defer_flush(); if (rc == VPP_OK) rc = r2; }
-  return rc;
+  if (!b.n) { b.kind = kind; b.p0 = p0; b.p1 = p1; b.stream = stream; b.dev = dev; b.nsrc = src1 ? 2 : 1; }
+  b.dst[b.n] = *dst; b.src[0][b.n] = *src0; if (src1) b.src[1][b.n] = *src1;
+  b.n++;
+  g_defer_pending.fetch_add(1, std::memory_order_acq_rel);
+  if (b.n == kDeferMax) (void)defer_launch_locked(w);
+  return VPP_OK;
 }
+// streams this thread records through vpp_graph_begin, with the recorded-scratch generation at the start of the capture
+static thread_local std::map<void*, unsigned> g_recording;
+bool defer_recording(void* stream) { return !g_recording.empty() && g_recording.count(stream) != 0; }
 
 // ---- device_fill (common.hpp): 16-byte units for the aligned body, the first workgroup also writes the unaligned head and tail bytes
 namespace {
@@ -176,18 +236,16 @@ IndependentCall::IndependentCall(hipStream_t st, const Extent* writes, int nw, c
     cw.serial = ++g_window_serial;
     cw.base.assign(deps, deps + ndeps);
   }
-  window_ = cw.serial;
   lane_ = cw.nlanes < W ? cw.nlanes : (int)(cw.count % (size_t)W);
-  for (const Touch& t : cw.touched) {
+  cw.deps = cw.base;
+  if (lane_ < cw.nlanes) add_unique(cw.deps, cw.lanes[lane_].last);
+  for (const Touch& t : cw.touched) {   // recorded calls whose extents this call's overlap: recorded behind them
     bool ww = false, rw = false;   // this call writes what was touched / reads what was written
     for (int i = 0; i < nw; i++) ww = ww || overlap(writes[i], t.e);
     for (int i = 0; i < nr; i++) rw = rw || overlap(reads[i], t.e);
-    if (ww || rw) add_unique(conflicts_, t.writer);
-    if (ww) for (hipGraphNode_t r : t.reader) add_unique(conflicts_, r);
+    if (ww || rw) add_unique(cw.deps, t.writer);
+    if (ww) for (hipGraphNode_t r : t.reader) add_unique(cw.deps, r);
   }
-  cw.deps = cw.base;
-  if (lane_ < cw.nlanes) add_unique(cw.deps, cw.lanes[lane_].last);
-  for (hipGraphNode_t c : conflicts_) add_unique(cw.deps, c);
   if (hipStreamUpdateCaptureDependencies(st, cw.deps.data(), cw.deps.size(), hipStreamSetCaptureDependencies) != hipSuccess) { (void)hipGetLastError(); cw = CaptureWindow(); return; }
   nw_ = nw; nr_ = nr;
   for (int i = 0; i < nw; i++) w_[i] = writes[i];
@@ -215,15 +273,7 @@ bool rejoin(CaptureWindow& cw, hipStream_t st) {
 }
 }  // namespace
 
-void IndependentCall::absorbed_into(hipGraphNode_t node, int lane) {
-  if (!active_) return;
-  active_ = false;
-  CaptureWindow& cw = g_windows[st_];
-  book(cw, node, lane, w_, nw_, r_, nr_);
-  if (!rejoin(cw, st_)) cw = CaptureWindow();
-}
-
-hipGraphNode_t IndependentCall::finish(int* lane, std::vector<hipGraphNode_t>* recorded_behind) {
+hipGraphNode_t IndependentCall::finish() {
   if (!active_) return nullptr;
   active_ = false;
   CaptureWindow& cw = g_windows[st_];
@@ -249,8 +299,6 @@ hipGraphNode_t IndependentCall::finish(int* lane, std::vector<hipGraphNode_t>* r
   cw.lanes[lane_].last = node;
   cw.count++;
   book(cw, node, lane_, w_, nw_, r_, nr_);
-  if (lane) *lane = lane_;
-  if (recorded_behind) *recorded_behind = cw.deps;
   if (!rejoin(cw, st_)) { cw = CaptureWindow(); return nullptr; }
   return node;
 }
@@ -349,7 +397,7 @@ int vpp_malloc(size_t bytes, void** dptr) {
 
 int vpp_free(void* dptr) {
   if (!dptr) return VPP_OK;
-  if (g_defer.n) (void)defer_flush();   // a pending deferred call may use the block: launched before the block can be handed out again (callers order reuse on streams)
+  if (g_defer_pending.load(std::memory_order_acquire) && !g_defer_bypass) (void)defer_flush();   // a held-back call may use the block: launched before the block can be handed out again (callers order reuse on streams)
   const size_t cap = (size_t)tuning("runtime.pool_mb", 2048) << 20;
   // the block goes back to the pool of the device it was allocated on, whichever device is current now
   DevicePool* P = nullptr;
@@ -445,20 +493,30 @@ int vpp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
 int vpp_memset(void* dst, int byte, size_t bytes, void* stream) {
   return device_fill(dst, byte, bytes, as_stream(stream));   // a kernel of this library: recordable into launch graphs (see common.hpp)
 }
+namespace {
+// this thread's sticky held-back failure, reported once
+int defer_report(const char* where) {
+  DeferWindow& w = defer_window();
+  std::lock_guard<std::mutex> l(w.mu);
+  if (w.last_rc == VPP_OK) return VPP_OK;
+  const int rc = w.last_rc;
+  w.last_rc = VPP_OK;
+  set_error("%s: %s", where, w.last_msg);
+  return rc;
+}
+}  // namespace
 int vpp_sync(void* stream) {
-  VPP_HIP_TRY(hipStreamSynchronize(as_stream(stream)));   // (as_stream launches this thread's deferred calls first)
-  if (g_defer.last_rc != VPP_OK) { const int rc = g_defer.last_rc; g_defer.last_rc = VPP_OK; set_error("vpp_sync: a deferred batch (vpp_*_deferred) failed to launch, status %d", rc); return rc; }
+  VPP_HIP_TRY(hipStreamSynchronize(as_stream(stream)));   // (as_stream launches the held-back calls first: this thread's, and any thread's on this stream)
+  const int rc = defer_report("vpp_sync");
+  if (rc != VPP_OK) return rc;
   return check_device_error("vpp_sync");
 }
 int vpp_flush(void* stream) {
-  (void)stream;   // one window per host thread, whatever the stream
-  int rc = defer_flush();
-  if (rc == VPP_OK && g_defer.last_rc != VPP_OK) rc = g_defer.last_rc;
-  g_defer.last_rc = VPP_OK;
-  return rc;
+  (void)defer_flush_stream(stream);   // this thread's window whatever its stream, and other threads' windows on `stream`
+  return defer_report("vpp_flush");
 }
-unsigned long long vpp_deferred_flushes(void) { return g_defer.flushes; }
-int vpp_deferred_pending(void) { return g_defer.n; }
+unsigned long long vpp_deferred_flushes(void) { return defer_window().flushes.load(std::memory_order_acquire); }
+int vpp_deferred_pending(void) { DeferWindow& w = defer_window(); std::lock_guard<std::mutex> l(w.mu); return w.b.n; }
 int vpp_stream_create(void** stream) {
   VPP_REQUIRE(stream, VPP_ERR_INVALID_ARG, "vpp_stream_create: null");
   hipStream_t s;
@@ -504,13 +562,19 @@ int vpp_stream_wait_event(void* stream, void* event) {
 struct vpp_graph { hipGraph_t g = nullptr; hipGraphExec_t exec = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; bool timed = false; unsigned scratch_gen = 0; };
 int vpp_graph_begin(void* stream) {
   VPP_HIP_TRY(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
+  g_recording[stream] = recorded_scratch_generation();   // per-frame calls on this stream are held back until their window closes (common.hpp); vpp_graph_end closes the last one
   return VPP_OK;
 }
 int vpp_graph_end(void* stream, int timed, vpp_graph** out) {
   VPP_REQUIRE(out, VPP_ERR_INVALID_ARG, "vpp_graph_end: null");
   vpp_graph* gr = new vpp_graph();
-  gr->scratch_gen = recorded_scratch_generation();   // (a capture cannot grow or evict a scratch buffer — Scratch::ensure refuses — so this is the generation of everything recorded)
-  hipError_t e = hipStreamEndCapture(as_stream(stream), &gr->g);
+  hipStream_t st = as_stream(stream);   // the last held-back window is recorded here
+  // The generation the capture STARTED under: an eager call of this thread on another stream may evict (free) a recorded buffer while this capture is open — the
+  // graph then holds a freed address and must be refused, which stamping the generation current at the end would hide.
+  auto rec = g_recording.find(stream);
+  gr->scratch_gen = rec != g_recording.end() ? rec->second : recorded_scratch_generation();
+  if (rec != g_recording.end()) g_recording.erase(rec);
+  hipError_t e = hipStreamEndCapture(st, &gr->g);
   if (e != hipSuccess || !gr->g) { delete gr; set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return VPP_ERR_HIP; }
   if (timed) {
     size_t nn = 0, ne = 0;

@@ -188,56 +188,23 @@ int gray_launch(const GrayGeom& g0, const GrayBatch& fr, int n, hipStream_t st) 
 inline bool same_gray_geometry(const vpp_image_desc& a, const vpp_image_desc& b) {
   return a.nrows == b.nrows && a.ncols == b.ncols && a.pitch == b.pitch && a.border == b.border && a.dtype == b.dtype && a.channels == b.channels && (((uintptr_t)a.first_pixel ^ (uintptr_t)b.first_pixel) & 15) == 0;
 }
-// record-time batching of per-frame calls (the mechanism of box.hip: coalesce_frame): a recorded frame loop's ingests fold into one batched node
-struct GrayCoalesce {
-  unsigned long long window = 0; hipGraphNode_t node = nullptr; int lane = 0; std::vector<hipGraphNode_t> behind;
-  int n = 0, mirror = 0; vpp_image_desc d0{}, s0{}; GrayGeom g{}; GrayBatch frames{};
-};
-thread_local std::map<hipStream_t, GrayCoalesce> g_gray_coalesce;
-bool coalesce_gray(IndependentCall& side, hipStream_t st, const vpp_image_desc* dst, const vpp_image_desc* src, int mirror) {
-  GrayCoalesce& c = g_gray_coalesce[st];
-  if (!(c.n > 0 && c.n < kGrayBatchMax && c.window == side.window() && c.mirror == (mirror ? 1 : 0) && same_gray_geometry(*dst, c.d0) && same_gray_geometry(*src, c.s0))) return false;
-  for (hipGraphNode_t x : side.conflicts())
-    if (x == c.node || std::find(c.behind.begin(), c.behind.end(), x) == c.behind.end()) return false;
-  c.frames.d[c.n] = (uint8_t*)dst->first_pixel; c.frames.s[c.n] = (const uint8_t*)src->first_pixel;
-  c.n++;
-  GrayGeom g = c.g; GrayBatch frames = c.frames;
-  if (gray_geometry(&c.d0, &c.s0, c.mirror, &g, c.n) != VPP_OK) { c.n = 0; return false; }   // (the workgroup size follows the number of frames the node carries)
-  void* args[11] = {&g.d, &g.s, &g.ext, &g.c_start, &g.nchunks, &g.n_left, &g.n_main, &g.edge_blocks, &g.vec_ok, &frames, &g.blocks_per_frame};
-  hipKernelNodeParams kp{};
-  kp.func = gray_kernel(g); kp.gridDim = dim3(g.blocks_per_frame * (unsigned)c.n); kp.blockDim = dim3((unsigned)g.bsz); kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
-  if (hipGraphKernelNodeSetParams(c.node, &kp) != hipSuccess) { (void)hipGetLastError(); c.n = 0; return false; }
-  side.absorbed_into(c.node, c.lane);
-  return true;
-}
 }  // namespace
 
 extern "C" int vpp_rgb_to_graylevel(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream) {
   GrayGeom g;
   int rc = gray_geometry(dst, src, mirror, &g);
   if (rc != VPP_OK) return rc;
+  // on a stream this thread records through vpp_graph_begin: the frame is held back and recorded as part of ONE batched node (box.hip, common.hpp)
+  if (!g_defer_bypass && defer_recording(stream) && tuning("ingest.coalesce", 1) && tuning("ingest.batch", 1)) return defer_call(kDeferGray, mirror ? 1 : 0, 0, stream, dst, src, nullptr);
   hipStream_t st = as_stream(stream);
   const Extent wr = extent_of(*dst), rd = extent_of(*src);
-  IndependentCall side(st, &wr, 1, &rd, 1);
-  const bool batchable = side.active() && tuning("ingest.coalesce", 1);
-  if (batchable && coalesce_gray(side, st, dst, src, mirror)) return VPP_OK;
+  IndependentCall side(st, &wr, 1, &rd, 1);   // recorded streams: calls on unrelated images become sibling nodes (common.hpp)
   GrayBatch fr{};
   fr.d[0] = (uint8_t*)dst->first_pixel; fr.s[0] = (const uint8_t*)src->first_pixel;
-  rc = gray_launch(g, fr, 1, st);
-  if (side.active()) {
-    GrayCoalesce& c = g_gray_coalesce[st];
-    c.n = 0;
-    if (batchable && rc == VPP_OK) {
-      int lane = 0; std::vector<hipGraphNode_t> behind;
-      const unsigned long long window = side.window();
-      hipGraphNode_t node = side.finish(&lane, &behind);
-      if (node) { c.window = window; c.node = node; c.lane = lane; c.behind = behind; c.n = 1; c.mirror = mirror ? 1 : 0; c.d0 = *dst; c.s0 = *src; c.g = g; c.frames = fr; }
-    }
-  }
-  return rc;
+  return gray_launch(g, fr, 1, st);
 }
 
-// The per-frame call form without its per-frame launch (common.hpp, "deferred per-frame calls"); argument errors are reported at the call (gray_geometry is
+// The per-frame call form without its per-frame launch (common.hpp, "held-back per-frame calls"); argument errors are reported at the call (gray_geometry is
 // what vpp_rgb_to_graylevel checks with).
 extern "C" int vpp_rgb_to_graylevel_deferred(const vpp_image_desc* dst, const vpp_image_desc* src, int mirror, void* stream) {
   GrayGeom g;
@@ -245,7 +212,8 @@ extern "C" int vpp_rgb_to_graylevel_deferred(const vpp_image_desc* dst, const vp
   if (rc != VPP_OK) return rc;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-  if (cap != hipStreamCaptureStatusNone || !tuning("defer", 1) || !tuning("ingest.batch", 1) || dst->first_pixel == src->first_pixel) return vpp_rgb_to_graylevel(dst, src, mirror, stream);
+  if ((cap != hipStreamCaptureStatusNone && !defer_recording(stream)) || g_defer_bypass || !tuning("defer", 1) || !tuning("ingest.batch", 1) || dst->first_pixel == src->first_pixel)
+    return vpp_rgb_to_graylevel(dst, src, mirror, stream);
   return defer_call(kDeferGray, mirror ? 1 : 0, 0, stream, dst, src, nullptr);
 }
 

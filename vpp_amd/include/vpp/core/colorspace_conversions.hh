@@ -14,11 +14,13 @@ namespace colorspace_internals {
 template <class T> struct is_u8_gray : std::integral_constant<bool, sizeof(T) == 1 && (std::is_same<T, unsigned char>::value || std::is_same<T, vector<unsigned char, 1>>::value)> {};
 }
 
-template <class T, class U, unsigned N, unsigned C> imageNd<T, N> rgb_to_graylevel_impl(const imageNd<vector<U, C>, N>& in) {
+// immediate: launch at once instead of holding the frame back for a batched launch (vpp/core/device.hh; the `_immediate` option of the overloads below)
+template <class T, class U, unsigned N, unsigned C> imageNd<T, N> rgb_to_graylevel_impl(const imageNd<vector<U, C>, N>& in, bool immediate = false) {
   imageNd<T, N> out(in.domain(), _border = in.border(), _aligned = in.alignment());
 #ifdef VPP_AMD_DEVICE
   if constexpr (N == 2 && std::is_same<U, unsigned char>::value && colorspace_internals::is_u8_gray<T>::value) {
     const vpp_image_desc di = in.device_desc(false), dout = out.device_desc(true, true);
+    if (immediate) { device::check(vpp_rgb_to_graylevel(&dout, &di, 0, device::stream()), "vpp_rgb_to_graylevel"); device::call_done(); return out; }
     device::check(vpp_rgb_to_graylevel_deferred(&dout, &di, 0, device::stream()), "vpp_rgb_to_graylevel");
     device::deferred_call_done();   // held back and launched in batches by the library: vpp/core/device.hh
     return out;
@@ -32,6 +34,8 @@ template <class T, class U, unsigned N, unsigned C> imageNd<T, N> rgb_to_graylev
 }
 template <class T, class U, unsigned N> imageNd<T, N> rgb_to_graylevel(const imageNd<vector<U, 3>, N>& in) { return rgb_to_graylevel_impl<T, U, N, 3>(in); }
 template <class T, class U, unsigned N> imageNd<T, N> rgb_to_graylevel(const imageNd<vector<U, 4>, N>& in) { return rgb_to_graylevel_impl<T, U, N, 4>(in); }
+template <class T, class U, unsigned N> imageNd<T, N> rgb_to_graylevel(const imageNd<vector<U, 3>, N>& in, s::_immediate_t) { return rgb_to_graylevel_impl<T, U, N, 3>(in, true); }
+template <class T, class U, unsigned N> imageNd<T, N> rgb_to_graylevel(const imageNd<vector<U, 4>, N>& in, s::_immediate_t) { return rgb_to_graylevel_impl<T, U, N, 4>(in, true); }
 
 #ifdef VPP_AMD_DEVICE
 // Frame ingest, one pass on the device: the result of `auto f = clone(frame, _border = border); fill_border_mirror(f);

@@ -45,8 +45,10 @@ inline void call_done() {
   if (r.set[r.k]) check(vpp_event_synchronize(r.ev[r.k]), "vpp_event_synchronize");   // the oldest call still queued
 }
 // Deferred per-frame calls (include/vpp_amd.h: vpp_*_deferred): the tagged functors and rgb_to_graylevel do not launch per call — the library holds the frame back
-// and launches whole batches (up to 64 frames), always before anything else this thread queues (so every host accessor, every other call and sync() see the
-// results exactly as with per-call launches).  The queue bound of call_done() then applies per BATCH: after a call that made the library launch a window.
+// and launches whole batches (up to 64 frames), always before anything else this thread queues, before anything ANY thread queues on the same stream (a host
+// accessor or sync() on another thread, once this thread has handed the image over) and when the thread ends — so every host accessor, every other call and sync()
+// see the results exactly as with per-call launches.  `pixel_wise(...)(_immediate) | ops::...` launches that call at once instead (symbols.hh).
+// The queue bound of call_done() then applies per BATCH: after a call that made the library launch a window.
 inline void deferred_call_done() {
   static thread_local unsigned long long seen = 0;
   static thread_local int unthrottled = 0;
@@ -57,6 +59,9 @@ inline void deferred_call_done() {
   // many small windows in a row, a chain of dependent calls)
   if (vpp_deferred_pending() == 0 || ++unthrottled >= 64) { unthrottled = 0; call_done(); }
 }
+// Kernels that the CALLER's translation unit launches itself (the opaque-lambda engines of pixel_wise_device.hh) do not pass through the ABI, so nothing would
+// launch the frames this thread's tagged functors have held back before them: every such launch calls this first (stream order = call order).
+inline void flush_held_back() { if (vpp_deferred_pending()) check(vpp_flush(stream()), "vpp_flush"); }
 // Everything queued so far — deferred frames included — has completed when sync() returns.
 inline void sync() { check(vpp_sync(stream()), "vpp_sync"); }
 // RAII: the deferred frames of the enclosed calls are launched when the scope ends (they are launched earlier whenever order demands it; see above).

@@ -259,6 +259,7 @@ template <class OPTS, class... R> class pixel_wise_impl {
     static_assert(sizeof...(R) == 3, "ops::binary needs pixel_wise(dst, a, b)");
     auto& d = std::get<0>(ranges_); auto& a = std::get<1>(ranges_); auto& b = std::get<2>(ranges_);
     const vpp_image_desc da = a.device_desc(false), db = b.device_desc(false), dd = d.device_desc(true);
+    if (OPTS::has(_immediate)) { device::check(vpp_pixelwise_binary(op, &dd, &da, &db, device::stream()), "vpp_pixelwise_binary"); device::call_done(); return; }
     device::check(vpp_pixelwise_binary_deferred(op, &dd, &da, &db, device::stream()), "vpp_pixelwise_binary");
     device::deferred_call_done();   // held back and launched in batches by the library, queued not drained: vpp/core/device.hh
   }
@@ -266,6 +267,7 @@ template <class OPTS, class... R> class pixel_wise_impl {
     static_assert(sizeof...(R) == 2, "ops::box_mean needs pixel_wise(dst, relative_access(src)) or pixel_wise(dst, box_nbh2d(src))");
     auto& d = std::get<0>(ranges_); auto& n = std::get<1>(ranges_);
     const vpp_image_desc ds = n.img.device_desc(false), dd = d.device_desc(true);
+    if (OPTS::has(_immediate)) { device::check(vpp_box_filter(&dd, &ds, rr, cc, device::stream()), "vpp_box_filter"); device::call_done(); return; }
     device::check(vpp_box_filter_deferred(&dd, &ds, rr, cc, device::stream()), "vpp_box_filter");
     device::deferred_call_done();   // held back and launched in batches by the library, queued not drained: vpp/core/device.hh
   }

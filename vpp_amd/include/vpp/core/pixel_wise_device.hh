@@ -252,6 +252,7 @@ template <class V, int R, int C> struct is_nbh_acc<boxnbh_acc<V, R, C>> : std::t
 // NBH_RO: the call carries `_nbh_read_only` (see pixel_wise_tile_kernel)
 template <bool NBH_RO, class F, class... A> void launch(F f, int r0, int c0, int nrows, int ncols, A... acc) {
   if (nrows <= 0 || ncols <= 0) return;
+  device::flush_held_back();   // these kernels are launched by the caller's TU, not through the ABI: frames the tagged functors have held back go first
   constexpr int NPX = npx_all<A...>::value;
   constexpr bool kNbh = (is_nbh_acc<A>::value || ...);
   bool al = true;
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(64) void block_wise_kernel(F f, int rstart, int cst
 template <class F, class... A> void launch_blocks(F f, int rstart, int cstart, int rend, int cend, int bsr, int bsc, A... acc) {
   const int gr = (rend - rstart) / bsr + 1, gc = (cend - cstart) / bsc + 1;   // block_wise.hh:37-38
   if (gr <= 0 || gc <= 0) return;
+  device::flush_held_back();   // (see launch)
   hipLaunchKernelGGL((block_wise_kernel<F, A...>), dim3((gr * gc + 63) / 64), dim3(64), 0, (hipStream_t)device::stream(), f, rstart, cstart, rend, cend, bsr, bsc, gr, gc, acc...);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) throw std::runtime_error(std::string("block_wise (device): launch failed: ") + hipGetErrorString(e));

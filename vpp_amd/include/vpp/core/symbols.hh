@@ -22,5 +22,8 @@ VPP_DEFINE_SYMBOL(device)
 // reaches further than 4 pixels from the centre — the device engine may then serve the taps from an LDS tile (pixel_wise_device.hh: pixel_wise_tile_kernel).
 // Without it a neighbourhood is a reference into the image, as in the reference (relative_accessor.hh:26-33 returns V&; distance_transforms.hh writes through it).
 VPP_DEFINE_SYMBOL(nbh_read_only)
+// not in the reference: pixel_wise(...)(_immediate) | ops::add() / ops::box_mean<R, C>() launches this call's kernel at once (the reference's "the call has
+// happened when operator| returns", as far as a stream can say it) instead of holding the frame back for a batched launch (vpp/core/device.hh)
+VPP_DEFINE_SYMBOL(immediate)
 
 namespace vpp { using namespace s; }
