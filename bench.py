@@ -630,10 +630,16 @@ def main():
         if "tracks_per_s" in px:
             legs["pyrlk_1080p_10k"] = {"tracks_per_s": round(px["tracks_per_s"]), "ms_per_frame": rnd(px["ms_per_frame"]), "keypoints_per_rank": px.get("keypoints_per_rank"),
                                        "roofline": pick(px.get("roofline") or {}, "bound", "kernel", "frac", "source", "stale")}
+            fpb = px.get("frame_pair_batches") or {}
+            if "8" in fpb:   # F frame pairs x 1 250 keypoints per launch (a rank's slice on 8 GPUs): M tracks/s per rank, and 8 ranks projected at F = 8
+                legs["pyrlk_1080p_10k"]["frame_pairs_x1250_mtracks_per_rank"] = {F: round(fpb[F]["tracks_per_s_per_rank"] / 1e6, 1) for F in ("1", "4", "8", "16") if F in fpb}
+                legs["pyrlk_1080p_10k"]["projected_8_ranks_f8_mtracks"] = round(fpb["8"]["projected_8_ranks_tracks_per_s"] / 1e6, 1)
             if "weak_scaling" in px:
                 legs["pyrlk_1080p_10k"]["weak_scaling_tracks_per_s"] = round(px["weak_scaling"]["tracks_per_s"])
             if "cpp_harness" in px:
                 legs["pyrlk_1080p_10k"]["cpp_harness"] = pick(px["cpp_harness"], "tracks_per_s", "ms_per_step", "error")
+            if "cpp_harness_8_frame_pairs" in px:
+                legs["pyrlk_1080p_10k"]["cpp_harness_8_frame_pairs"] = pick(px["cpp_harness_8_frame_pairs"], "tracks_per_s", "ms_per_step", "error")
         f9 = px.get("fast9_4k") or {}
         if "raw" in f9:
             legs["fast9_4k"] = {"raw_ms": rnd(f9["raw"]["ms"]), "blockwise10_ms": rnd(f9["blockwise10"]["ms"]), "keypoints": f9["raw"]["keypoints"], "corner_density": rnd(f9["raw"]["keypoints"] / npx),

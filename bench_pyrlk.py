@@ -109,6 +109,40 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
         res["scaling_bound"]["note"] = ("strong scaling of 10 000 keypoints over G ranks: G x this GPU's rate at 10 000 / G keypoints, before the all-gather; "
                                         "weak scaling (10 000 keypoints per rank) keeps the 1-GPU rate per rank")
 
+        # ---- frame-pair batches (vpp_pyrlk_match_batch): a rank's slice of configs[3] on 8 GPUs is 1 250 keypoints, whose match costs the latency of ONE keypoint's
+        # chain (the sweep above: 1 250 keypoints take what 5 000 do) — strong scaling of one pair is bounded at ~1.5 x on 8 GPUs.  With F DISTINCT frame pairs per
+        # launch (own frames, own pyramids, own keypoints) a rank leaves that floor: tracks/s per rank at F = 1 / 4 / 8 / 16 x 1 250 keypoints, and the keypoint-sharded
+        # job's projection on 8 ranks (8 x this GPU's rate; the all-gather of F x 200 KB of records comes on top).
+        try:
+            NSL, FMAX = NK // 8, 16
+            pairs = []
+            for f in range(FMAX):
+                texf = texture(NR, NC, seed=60 + f)
+                a = DeviceImage.from_host(u8_image(np.clip(np.rint(texf), 0, 255).astype(np.uint8)), dev)
+                b = DeviceImage.from_host(u8_image(np.clip(np.rint(translate(texf, 1.5 - 0.1 * f, -2.25 + 0.2 * f)), 0, 255).astype(np.uint8)), dev)
+                pa = pyr.device_pyramid(lib, a, L, B); ga = pyr.device_grad_pyramid(lib, pa[0], L, B, vi.F32); pb = pyr.device_pyramid(lib, b, L, B)
+                kf = torch.from_numpy(kps_h[f % 8::8][:NSL].view(np.uint8).reshape(-1).copy()).to(dev)
+                pairs.append((pa, ga, pb, kf, kf.clone()))
+            batch = lib.vpp_pyrlk_match_batch
+            fb = {}
+            for F in (1, 4, 8, 16):
+                sel = pairs[:F]
+                dP = vi.desc_array([l_ for q in sel for l_ in q[0]]); dG = vi.desc_array([l_ for q in sel for l_ in q[1]]); dN = vi.desc_array([l_ for q in sel for l_ in q[2]])
+                kp_ptrs = (ctypes.c_void_p * F)(*[q[4].data_ptr() for q in sel]); counts = (ctypes.c_int * F)(*([NSL] * F))
+
+                def step_b(i, stream, sel=sel, dP=dP, dG=dG, dN=dN, kp_ptrs=kp_ptrs, counts=counts, F=F):
+                    for q in sel:
+                        q[4].copy_(q[3], non_blocking=True)
+                    capi.check(batch(dP, dG, dN, F, L, kp_ptrs, counts, WS, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None, stream))
+                w, _ = timed(step_b, 20, 3, graph=True)
+                rate = F * NSL / (w / 20)
+                fb[str(F)] = {"ms_per_launch": round(w / 20 * 1e3, 4), "tracks_per_s_per_rank": round(rate), "projected_8_ranks_tracks_per_s": round(8 * rate)}
+            fb["how"] = (f"F distinct 1080p frame pairs x {NSL} keypoints (every 8th keypoint of configs[3]'s 10 k: one of 8 ranks' slice) in ONE launch of pyrlk_match_batch_kernel; "
+                         "the F restoring copies of the keypoint records are inside the timed region; projected = 8 x this GPU's rate, before the all-gather")
+            res["frame_pair_batches"] = fb
+        except Exception as e:  # noqa: BLE001
+            res["frame_pair_batches"] = {"error": f"{type(e).__name__}: {e}"}
+
         # ---- the reference's OWN pyrLK benchmark configuration (benchmarks/pyrlk_opencv_comparison.cc:47,64-65): 11 x 11 window, 4 scales, min_ev 1e-4, max_err 500,
         # 30 iterations, delta 0.01 — on the same 1080p scene and 10 000 keypoints; pyramids with a border of 8 (the benchmark's border(3) is narrower than the window's
         # reach: the reference then reads outside its border, this engine clamps — a border the window fits in keeps every tap on the fast, unclamped path)
@@ -145,14 +179,17 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
         if os.path.exists(exe) and os.environ.get("VPP_BENCH_ONE_DEVICE", "0") != "1":
             import json as _json, subprocess as _sp
             uid = f"/tmp/vpp_uid_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-            try:
-                out = _sp.run([exe, str(rank), str(world), uid, "200", str(NK)], capture_output=True, text=True, timeout=120)
-                if rank == 0:
-                    res["cpp_harness"] = _json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else {"error": (out.stderr or out.stdout)[-300:], "rc": out.returncode}
-            except Exception as e:  # noqa: BLE001
-                if rank == 0:
-                    res["cpp_harness"] = {"error": f"{type(e).__name__}: {e}"}
-            barrier()
+            # F = 1: configs[3] as stated (one pair, 10 k keypoints over the ranks: latency bound per rank); F = 8: eight distinct pairs per step (one
+            # vpp_pyrlk_match_batch launch + one all-gather per rank) — the form in which the keypoint-sharded job scales
+            for key, nsteps, pairs in (("cpp_harness", "200", "1"), ("cpp_harness_8_frame_pairs", "50", "8")):
+                try:
+                    out = _sp.run([exe, str(rank), str(world), uid + "_" + pairs, nsteps, str(NK), pairs], capture_output=True, text=True, timeout=180)
+                    if rank == 0:
+                        res[key] = _json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else {"error": (out.stderr or out.stdout)[-300:], "rc": out.returncode}
+                except Exception as e:  # noqa: BLE001
+                    if rank == 0:
+                        res[key] = {"error": f"{type(e).__name__}: {e}"}
+                barrier()
         # BASELINE configs[4] as a tile-sharded step (benchmarks/flow_strip_bench.cc, one C++ process per GPU): RCCL all-gather of the frames'
         # row strips, claim + descent sharded by flow-map row strips with one grouped all-gather of the maps per scale, halo exchange + FAST-9
         # on strips; every rank checks its results against its own single-rank calls.  Reported beside the replicas leg below.

@@ -1,7 +1,10 @@
 // pyrlk_shard_bench.cc — the keypoint-sharded pyrLK step of BASELINE configs[3] as one process per GPU, written against the C ABI only
 // (no Python on the step): vpp_pyrlk_match on this rank's slice + vpp_allgather_tracks (RCCL over xGMI) on one stream, recorded once
 // into a launch graph (vpp_graph_*) and replayed; falls back to eager launches if the collective cannot be recorded.
-//   usage: pyrlk_shard_bench <rank> <world> <uid_file> [steps] [keypoints]
+//   usage: pyrlk_shard_bench <rank> <world> <uid_file> [steps] [keypoints] [frame_pairs]
+// frame_pairs = F > 1 (round 6): the step covers F DISTINCT frame pairs — this rank's slice of each pair's keypoints in ONE vpp_pyrlk_match_batch launch and ONE
+// all-gather of the F x slice records.  A rank's 1 250 keypoints of one pair cost the latency of a single keypoint's chain (71 us); F pairs per launch leave that
+// floor, which is what lets the keypoint-sharded job scale (tracks/s = F x keypoints / step time).
 // Rank 0 creates the RCCL unique id and publishes it through <uid_file> (written to a temporary name, then renamed); the other
 // ranks wait for the file.  Every rank builds the same synthetic frame pair (1920x1080, a smooth random texture translated by
 // (1.5, -2.25) px) and both pyramids; rank 0 prints one JSON line.  Times are the maximum over ranks (gathered with the same collective).
@@ -36,10 +39,10 @@ static dev_image alloc_image(int nr, int nc, int dtype, int ch, int es, int bord
 }
 
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: %s <rank> <world> <uid_file> [steps] [keypoints]\n", argv[0]); return 1; }
+  if (argc < 4) { std::fprintf(stderr, "usage: %s <rank> <world> <uid_file> [steps] [keypoints] [frame_pairs]\n", argv[0]); return 1; }
   const int rank = g_rank = std::atoi(argv[1]), world = std::atoi(argv[2]);
   const std::string uid_file = argv[3];
-  const int steps = argc > 4 ? std::atoi(argv[4]) : 200, NK = argc > 5 ? std::atoi(argv[5]) : 10000;
+  const int steps = argc > 4 ? std::atoi(argv[4]) : 200, NK = argc > 5 ? std::atoi(argv[5]) : 10000, F = argc > 6 ? std::max(1, std::atoi(argv[6])) : 1;
   const int NR = 1080, NC = 1920, L = 3, B = 3, WS = 7;
   int ndev = 1;
   CK(vpp_device_count(&ndev));
@@ -79,20 +82,27 @@ int main(int argc, char** argv) {
     const float v = (1 - fy) * (1 - fx) * a[size_t(y0) * W + x0] + fy * (1 - fx) * a[size_t(y0 + 1) * W + x0] + (1 - fy) * fx * a[size_t(y0) * W + x0 + 1] + fy * fx * a[size_t(y0 + 1) * W + x0 + 1];
     return (unsigned char)std::min(255.f, std::max(0.f, (v - lo) / (hi - lo) * 255.f + 0.5f));
   };
-  std::vector<unsigned char> f1(size_t(NR) * NC), f2(f1.size());
-  for (int r = 0; r < NR; r++) for (int c = 0; c < NC; c++) { f1[size_t(r) * NC + c] = sample(r + 16.f, c + 16.f); f2[size_t(r) * NC + c] = sample(r + 16.f - 1.5f, c + 16.f + 2.25f); }
-  dev_image s1 = alloc_image(NR, NC, VPP_U8, 1, 1, 0), s2 = alloc_image(NR, NC, VPP_U8, 1, 1, 0);
-  for (int r = 0; r < NR; r++) {
-    CK(vpp_memcpy_h2d((char*)s1.d.first_pixel + size_t(r) * s1.d.pitch, &f1[size_t(r) * NC], NC, nullptr));
-    CK(vpp_memcpy_h2d((char*)s2.d.first_pixel + size_t(r) * s2.d.pitch, &f2[size_t(r) * NC], NC, nullptr));
+  // pair f: the texture seen 5 f px further along its diagonal, translated by (1.5 - 0.1 f, -2.25 + 0.2 f) px between its two frames (pair 0 = configs[3]'s scene)
+  std::vector<vpp_image_desc> P1(size_t(F) * L), P2(size_t(F) * L), G1(size_t(F) * L);
+  {
+    std::vector<unsigned char> f1(size_t(NR) * NC), f2(f1.size());
+    dev_image s1 = alloc_image(NR, NC, VPP_U8, 1, 1, 0), s2 = alloc_image(NR, NC, VPP_U8, 1, 1, 0);
+    for (int f = 0; f < F; f++) {
+      const float o = 10.f + 0.3f * f, tr = 1.5f - 0.1f * f, tc = -2.25f + 0.2f * f;   // (the 16-px margin of the texture holds every offset for F <= 16)
+      for (int r = 0; r < NR; r++) for (int c = 0; c < NC; c++) { f1[size_t(r) * NC + c] = sample(r + (f ? o : 16.f), c + (f ? o : 16.f)); f2[size_t(r) * NC + c] = sample(r + (f ? o : 16.f) - tr, c + (f ? o : 16.f) - tc); }
+      for (int r = 0; r < NR; r++) {
+        CK(vpp_memcpy_h2d((char*)s1.d.first_pixel + size_t(r) * s1.d.pitch, &f1[size_t(r) * NC], NC, nullptr));
+        CK(vpp_memcpy_h2d((char*)s2.d.first_pixel + size_t(r) * s2.d.pitch, &f2[size_t(r) * NC], NC, nullptr));
+      }
+      for (int l = 0, nr = NR, nc = NC; l < L; l++, nr = 1 + nr / 2, nc = 1 + nc / 2) {
+        P1[size_t(f) * L + l] = alloc_image(nr, nc, VPP_U8, 1, 1, B).d; P2[size_t(f) * L + l] = alloc_image(nr, nc, VPP_U8, 1, 1, B).d; G1[size_t(f) * L + l] = alloc_image(nr, nc, VPP_F32, 2, 4, B).d;
+      }
+      CK(vpp_pyramid_build(&P1[size_t(f) * L], L, &s1.d, nullptr));
+      CK(vpp_pyramid_build(&P2[size_t(f) * L], L, &s2.d, nullptr));
+      CK(vpp_scharr_pyramid_build(&G1[size_t(f) * L], L, &P1[size_t(f) * L], nullptr));
+      CK(vpp_sync(nullptr));   // (the staging frames are reused by the next pair)
+    }
   }
-  std::vector<vpp_image_desc> P1(L), P2(L), G1(L);
-  for (int l = 0, nr = NR, nc = NC; l < L; l++, nr = 1 + nr / 2, nc = 1 + nc / 2) {
-    P1[l] = alloc_image(nr, nc, VPP_U8, 1, 1, B).d; P2[l] = alloc_image(nr, nc, VPP_U8, 1, 1, B).d; G1[l] = alloc_image(nr, nc, VPP_F32, 2, 4, B).d;
-  }
-  CK(vpp_pyramid_build(P1.data(), L, &s1.d, nullptr));
-  CK(vpp_pyramid_build(P2.data(), L, &s2.d, nullptr));
-  CK(vpp_scharr_pyramid_build(G1.data(), L, &P1[0], nullptr));
 
   // ---- keypoints: jittered grid >= 32 px from every edge, this rank's padded slice
   std::vector<vpp_keypoint_f32> all(NK);
@@ -107,16 +117,20 @@ int main(int argc, char** argv) {
   }
   const vpp_shard::plan plan(NK, world);
   const std::vector<vpp_keypoint_f32> mine = plan.shard_of(all, rank);
+  // this rank's records of the F pairs, pair after pair: [f][i] (every pair tracks the same grid of keypoints on its own frames)
   void *d_src = nullptr, *d_shard = nullptr, *d_all = nullptr;
-  const size_t shard_bytes = size_t(plan.per_rank) * sizeof(vpp_keypoint_f32);
+  const size_t shard_bytes = size_t(plan.per_rank) * sizeof(vpp_keypoint_f32) * F;
   CK(vpp_malloc(shard_bytes, &d_src)); CK(vpp_malloc(shard_bytes, &d_shard)); CK(vpp_malloc(shard_bytes * world, &d_all));
-  CK(vpp_memcpy_h2d(d_src, mine.data(), shard_bytes, nullptr));
+  for (int f = 0; f < F; f++) CK(vpp_memcpy_h2d((char*)d_src + size_t(f) * plan.per_rank * sizeof(vpp_keypoint_f32), mine.data(), size_t(plan.per_rank) * sizeof(vpp_keypoint_f32), nullptr));
   CK(vpp_sync(nullptr));
+  std::vector<vpp_keypoint_f32*> kp_of(F); std::vector<int> n_of(F, plan.per_rank);
+  for (int f = 0; f < F; f++) kp_of[f] = (vpp_keypoint_f32*)d_shard + size_t(f) * plan.per_rank;
 
   auto step = [&](void* st) {
     CK(vpp_memcpy_d2d(d_shard, d_src, shard_bytes, st));   // restore the tracks: pyrlk_match moves them in place
-    CK(vpp_pyrlk_match(P1.data(), G1.data(), P2.data(), L, (vpp_keypoint_f32*)d_shard, plan.per_rank, WS, 1e-4f, 500.f, 30, 0.01f, 0, nullptr, st));
-    CK(vpp_allgather_tracks(comm, (const vpp_keypoint_f32*)d_shard, plan.per_rank, (vpp_keypoint_f32*)d_all, st));
+    if (F == 1) CK(vpp_pyrlk_match(P1.data(), G1.data(), P2.data(), L, (vpp_keypoint_f32*)d_shard, plan.per_rank, WS, 1e-4f, 500.f, 30, 0.01f, 0, nullptr, st));
+    else CK(vpp_pyrlk_match_batch(P1.data(), G1.data(), P2.data(), F, L, kp_of.data(), n_of.data(), WS, 1e-4f, 500.f, 30, 0.01f, 0, nullptr, st));
+    CK(vpp_allgather_tracks(comm, (const vpp_keypoint_f32*)d_shard, plan.per_rank * F, (vpp_keypoint_f32*)d_all, st));
   };
   for (int i = 0; i < 5; i++) step(nullptr);
   CK(vpp_sync(nullptr));
@@ -138,20 +152,25 @@ int main(int argc, char** argv) {
   CK(vpp_sync(side));
   const double ms_step = (now() - t0) * 1e3 / steps;
 
-  // ---- parity of the exchange: the gathered, unpadded records == a single-rank run over all keypoints (same kernel, same inputs)
-  std::vector<vpp_keypoint_f32> gathered(size_t(plan.per_rank) * world);
+  // ---- parity of the exchange: the gathered, unpadded records of every pair == a single-rank run over all of that pair's keypoints (single calls, same inputs)
+  std::vector<vpp_keypoint_f32> gathered(size_t(plan.per_rank) * world * F);
   CK(vpp_memcpy_d2h(gathered.data(), d_all, shard_bytes * world, nullptr)); CK(vpp_sync(nullptr));
-  const std::vector<vpp_keypoint_f32> got = plan.unpad(gathered);
   int mismatched = -1;
   if (rank == 0) {
     void* d_full = nullptr;
     CK(vpp_malloc(size_t(NK) * sizeof(vpp_keypoint_f32), &d_full));
-    CK(vpp_memcpy_h2d(d_full, all.data(), size_t(NK) * sizeof(vpp_keypoint_f32), nullptr));
-    CK(vpp_pyrlk_match(P1.data(), G1.data(), P2.data(), L, (vpp_keypoint_f32*)d_full, NK, WS, 1e-4f, 500.f, 30, 0.01f, 0, nullptr, nullptr));
-    std::vector<vpp_keypoint_f32> want(NK);
-    CK(vpp_memcpy_d2h(want.data(), d_full, size_t(NK) * sizeof(vpp_keypoint_f32), nullptr)); CK(vpp_sync(nullptr));
     mismatched = 0;
-    for (int i = 0; i < NK; i++) mismatched += std::memcmp(&want[i], &got[i], sizeof(vpp_keypoint_f32)) != 0;
+    for (int f = 0; f < F; f++) {
+      std::vector<vpp_keypoint_f32> of_pair(size_t(plan.per_rank) * world);   // rank g's block holds its F slices one after the other
+      for (int g = 0; g < world; g++)
+        std::memcpy(&of_pair[size_t(g) * plan.per_rank], &gathered[(size_t(g) * F + f) * plan.per_rank], size_t(plan.per_rank) * sizeof(vpp_keypoint_f32));
+      const std::vector<vpp_keypoint_f32> got = plan.unpad(of_pair);
+      CK(vpp_memcpy_h2d(d_full, all.data(), size_t(NK) * sizeof(vpp_keypoint_f32), nullptr));
+      CK(vpp_pyrlk_match(&P1[size_t(f) * L], &G1[size_t(f) * L], &P2[size_t(f) * L], L, (vpp_keypoint_f32*)d_full, NK, WS, 1e-4f, 500.f, 30, 0.01f, 0, nullptr, nullptr));
+      std::vector<vpp_keypoint_f32> want(NK);
+      CK(vpp_memcpy_d2h(want.data(), d_full, size_t(NK) * sizeof(vpp_keypoint_f32), nullptr)); CK(vpp_sync(nullptr));
+      for (int i = 0; i < NK; i++) mismatched += std::memcmp(&want[i], &got[i], sizeof(vpp_keypoint_f32)) != 0;
+    }
   }
 
   // ---- max over ranks of the step time, through the same collective (one record per rank carrying the time)
@@ -163,10 +182,10 @@ int main(int argc, char** argv) {
   CK(vpp_memcpy_d2h(tall.data(), d_tall, sizeof(vpp_keypoint_f32) * world, nullptr)); CK(vpp_sync(nullptr));
   double worst = 0; for (auto& t : tall) worst = std::max(worst, double(t.pos_r));
   if (rank == 0) {
-    std::printf("{\"workload\": \"pyrlk_match 1920x1080, 3 levels, %d keypoints, 7x7, sharded over %d ranks (C++ harness, one process per GPU)\", \"tracks_per_s\": %.1f, "
-                "\"ms_per_frame\": %.5f, \"keypoints_per_rank\": %d, \"exchange\": \"rccl all_gather of %d 20-byte records per rank (vpp_allgather_tracks)\", "
+    std::printf("{\"workload\": \"pyrlk_match 1920x1080, 3 levels, %d keypoints, 7x7, sharded over %d ranks (C++ harness, one process per GPU), %d frame pair%s per step\", \"tracks_per_s\": %.1f, "
+                "\"ms_per_step\": %.5f, \"ms_per_frame\": %.5f, \"frame_pairs_per_step\": %d, \"keypoints_per_rank\": %d, \"exchange\": \"rccl all_gather of %d 20-byte records per rank (vpp_allgather_tracks)\", "
                 "\"launch\": \"%s\", \"steps\": %d, \"mismatched_vs_single_rank\": %d}\n",
-                NK, world, NK / (worst * 1e-3), worst, plan.per_rank, plan.per_rank, mode, steps, mismatched);
+                NK, world, F, F == 1 ? "" : "s", double(F) * NK / (worst * 1e-3), worst, worst / F, F, plan.per_rank, plan.per_rank * F, mode, steps, mismatched);
     std::remove(uid_file.c_str());
   }
   CK(vpp_comm_destroy(comm));

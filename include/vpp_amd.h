@@ -242,6 +242,15 @@ typedef struct vpp_keypoint_f32 { float pos_r, pos_c, vel_r, vel_c; int32_t age;
 int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, const vpp_image_desc* next, int nlevels,
                     vpp_keypoint_f32* kps, int n, int winsize, float min_ev, float max_err, int max_iterations,
                     float convergence_delta, int min_scale, float* out_dist, void* stream);
+/* F independent frame pairs in ONE launch (no reference counterpart: the reference matches one pair per call, pyrlk_match.hh:15-55; a launch of a few thousand
+ * keypoints is bound by the latency of ONE keypoint's levels x iterations chain — 1 250 keypoints cost what 5 000 do — so a caller with several pairs in hand, e.g.
+ * a rank's share of a keypoint-sharded job over a group of frames, gets near-linear throughput from batching them).  prev / grad / next: nframes * nlevels
+ * descriptors, frame-major (frame f's level l at [f * nlevels + l]); kps[f]: frame f's n[f] records, updated in place; out_dist: NULL, or per frame NULL / n[f]
+ * floats.  Results per frame are exactly those of vpp_pyrlk_match on that frame.  Frames of one geometry (per level: sizes, pitches, borders) share a launch,
+ * up to 16 pairs (64 frame-levels) each; anything else — other geometries, windows > 11 — goes out as the nframes calls. */
+int vpp_pyrlk_match_batch(const vpp_image_desc* prev, const vpp_image_desc* grad, const vpp_image_desc* next, int nframes, int nlevels,
+                          vpp_keypoint_f32* const* kps, const int* n, int winsize, float min_ev, float max_err, int max_iterations,
+                          float convergence_delta, int min_scale, float* const* out_dist, void* stream);
 /* vpp_lucas_kanade = the per-keypoint loop of lucas_kanade (vpp/algorithms/lucas_kanade/lucas_kanade.hpp:159-183)
  * over pyramids the caller built (u8x1 images, i32x2 gradients; :150-157).  min_ev/delta are the already-truncated
  * ints of :143-144.  pts: n (row,col) f32 pairs; prediction: n (row,col) f32 pairs or NULL (= 0);

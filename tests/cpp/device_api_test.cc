@@ -344,6 +344,40 @@ static void test_pyrlk() {
   CHECK(alive > kc.size() * 0.9);  // parity with the oracle is the assertion above; the scene only has to keep most tracks alive
 }
 
+// pyrlk_match over several frame pairs in one launch (pyrlk_match.hh: the std::vector overload -> vpp_pyrlk_match_batch): every container against the oracle's
+// match of ITS pair (own frames, own translation, own keypoints; one container empty)
+static void test_pyrlk_frame_pairs() {
+  const int nr = 200, nc = 288, L = 3, F = 4;
+  std::vector<pyramid2d<unsigned char>> p1, p2; std::vector<pyramid2d<vfloat2>> gr; std::vector<pyrlk_keypoint_container> kcs;
+  std::vector<std::vector<vpp_keypoint_f32>> wants(F);
+  for (int f = 0; f < F; f++) {
+    image2d<unsigned char> f1 = texture(nr, nc, 0.3f * f, 0.2f * f), f2 = texture(nr, nc, 0.3f * f + 1.5f - 0.5f * f, 0.2f * f - 2.25f + 0.75f * f);
+    p1.emplace_back(f1, L, 2, _border = 5); p2.emplace_back(f2, L, 2, _border = 5);
+    gr.emplace_back(f1.domain(), L, 2, _border = 5);
+    scharr(p1[f][0], gr[f][0]);
+    gr[f].propagate_level0();
+    kcs.emplace_back(f1.domain());
+    if (f != 2) for (int r = 30 + f; r < nr - 30; r += 9 + f) for (int c = 30; c < nc - 30; c += 13 - f) kcs[f].add(vfloat2(r + 0.25f, c + 0.5f));
+    wants[f].resize(kcs[f].size());
+    for (int i = 0; i < kcs[f].size(); i++) wants[f][i] = vpp_keypoint_f32{kcs[f][i].position[0], kcs[f][i].position[1], 0, 0, 1};
+    std::vector<vpp_image_desc> P, G, N;
+    for (int l = 0; l < L; l++) { P.push_back(host_desc(p1[f][l])); G.push_back(host_desc(gr[f][l])); N.push_back(host_desc(p2[f][l])); }
+    if (!wants[f].empty()) CHECK(orc_pyrlk_match(P.data(), G.data(), N.data(), L, wants[f].data(), int(wants[f].size()), 7, 1e-4f, 500.f, 30, 0.01f, 0, nullptr) == 0);
+  }
+  pyrlk_match(p1, gr, p2, kcs, lk_match_point_square_win<7>(), 1e-4f, 500.f, 30, 0.01f);
+  for (int f = 0; f < F; f++) {
+    int alive = 0;
+    for (int i = 0; i < kcs[f].size(); i++) {
+      CHECK(kcs[f][i].age == wants[f][i].age);
+      if (!kcs[f][i].alive()) continue;
+      alive++;
+      CHECK(kcs[f][i].position[0] == wants[f][i].pos_r && kcs[f][i].position[1] == wants[f][i].pos_c);   // the same float chains as the oracle: bit-identical here
+      CHECK(kcs[f].index2d()(cast<vint2>(kcs[f][i].position)) >= 0);
+    }
+    CHECK(f == 2 ? kcs[f].size() == 0 : alive > kcs[f].size() * 0.8);
+  }
+}
+
 static void test_lucas_kanade_golden() {  // tests/pyrlk.cc:17-50
   image2d<unsigned char> raw[2] = {image2d<unsigned char>(100, 100), image2d<unsigned char>(100, 100)}, blur[2] = {image2d<unsigned char>(100, 100), image2d<unsigned char>(100, 100)};
   auto gk = [](float s, float* k) { float t = 0; for (int i = 0; i < 9; i++) { k[i] = std::exp(-(i - 4) * (i - 4) / (2 * s * s)); t += k[i]; } for (int i = 0; i < 9; i++) k[i] /= t; };
@@ -553,6 +587,7 @@ int main() {
   test_deferred_per_frame_calls();
   test_fast9();
   test_pyrlk();
+  test_pyrlk_frame_pairs();
   test_lucas_kanade_golden();
   test_sdof_and_video_extruder();
 #ifdef HAVE_VPP_REF

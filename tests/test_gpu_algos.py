@@ -353,6 +353,90 @@ def test_pyrlk_1080p_10k_keypoints(lib, orc):
     assert np.median(np.linalg.norm(vel - [1.5, -2.25], axis=1)) < 0.15  # size-independent property: recovers the translation
 
 
+def _pyrlk_batch_case(lib, orc, frames, kps_per_frame, L=3, B=3, ws=7, min_ev=1e-4, max_err=500.0, max_it=30, delta=0.01):
+    """(got, want, got_dist, want_dist) per frame pair: vpp_pyrlk_match_batch on all pairs in one call against orc_pyrlk_match pair by pair."""
+    F = len(frames)
+    wants, wdists, dps, dgs, dns, dks, dds = [], [], [], [], [], [], []
+    for (f1, f2), kps in zip(frames, kps_per_frame):
+        i1, i2 = u8_image(f1), u8_image(f2)
+        hp1, hp2 = pyr.host_pyramid(orc, i1, L, B), pyr.host_pyramid(orc, i2, L, B)
+        hg = pyr.host_grad_pyramid(orc, hp1[0], L, B, vi.F32)
+        want = kps.copy(); wd = np.zeros(len(kps), np.float32)
+        assert orc.orc_pyrlk_match(vi.desc_array(hp1), vi.desc_array(hg), vi.desc_array(hp2), L, want.ctypes.data_as(ctypes.c_void_p), len(kps), ws,
+                                   ctypes.c_float(min_ev), ctypes.c_float(max_err), max_it, ctypes.c_float(delta), 0, wd.ctypes.data_as(ctypes.c_void_p)) == 0
+        wants.append(want); wdists.append(wd)
+        dp1 = pyr.device_pyramid(lib, DeviceImage.from_host(i1), L, B)
+        dps.append(dp1); dns.append(pyr.device_pyramid(lib, DeviceImage.from_host(i2), L, B)); dgs.append(pyr.device_grad_pyramid(lib, dp1[0], L, B, vi.F32))
+        dks.append(torch.from_numpy(kps.view(np.uint8).reshape(-1).copy()).cuda() if len(kps) else torch.zeros(1, dtype=torch.uint8, device="cuda"))
+        dds.append(torch.zeros(max(1, len(kps)), device="cuda"))
+    flat = lambda pyrs: vi.desc_array([lvl for p_ in pyrs for lvl in p_])
+    kp_ptrs = (ctypes.c_void_p * F)(*[k.data_ptr() for k in dks])
+    dist_ptrs = (ctypes.c_void_p * F)(*[d.data_ptr() for d in dds])
+    counts = (ctypes.c_int * F)(*[len(k) for k in kps_per_frame])
+    capi.check(lib.vpp_pyrlk_match_batch(flat(dps), flat(dgs), flat(dns), F, L, kp_ptrs, counts, ws, ctypes.c_float(min_ev), ctypes.c_float(max_err), max_it,
+                                         ctypes.c_float(delta), 0, dist_ptrs, capi.stream_ptr()))
+    _sync(lib)
+    gots = [dk.cpu().numpy()[:len(k) * pyr.KP_DTYPE.itemsize].view(pyr.KP_DTYPE) for dk, k in zip(dks, kps_per_frame)]
+    return gots, wants, [d.cpu().numpy()[:len(k)] for d, k in zip(dds, kps_per_frame)], wdists
+
+
+def _assert_lk_parity(got, want, gd, wd, what):
+    np.testing.assert_array_equal(got["age"], want["age"], err_msg=what)
+    alive = want["age"] > 0
+    for f in ("pos_r", "pos_c", "vel_r", "vel_c"):
+        np.testing.assert_allclose(got[f][alive], want[f][alive], rtol=1e-4, atol=1e-4 if f.startswith("pos") else 0.0, err_msg=f"{what} {f}")   # north_star: 1e-4 relative
+        if len(got):
+            assert (got[f].view(np.uint32) == want[f].view(np.uint32)).mean() > 0.999, (what, f)
+    np.testing.assert_allclose(gd[alive], wd[alive], rtol=1e-4, err_msg=what)
+
+
+def test_pyrlk_match_batch_8_frame_pairs_of_1250_keypoints(lib, orc):
+    """vpp_pyrlk_match_batch at the shape the keypoint-sharded job needs (round 6): a rank's 1 250 keypoints of configs[3] over 8 frame pairs (1080p, 3 levels,
+    7 x 7) in ONE launch; every pair has its own frames, its own translation and its own keypoints; per pair against orc_pyrlk_match, bit-identical > 99.9 %."""
+    frames, kpss, shifts = [], [], []
+    for k in range(8):
+        tex = texture(1080, 1920, seed=40 + k)
+        dr, dc = 0.75 + 0.5 * k, -2.25 + 0.6 * k
+        frames.append((np.clip(np.rint(tex), 0, 255).astype(np.uint8), np.clip(np.rint(translate(tex, dr, dc)), 0, 255).astype(np.uint8)))
+        shifts.append((dr, dc))
+        pts = pyr.grid_keypoints(1080, 1920, 10000, margin=32)[k::8][:1250]     # a rank's slice: every 8th keypoint of the 10 k
+        kpss.append(pyr.make_keypoints(pts))
+    gots, wants, gds, wds = _pyrlk_batch_case(lib, orc, frames, kpss)
+    for k in range(8):
+        assert len(gots[k]) == 1250
+        _assert_lk_parity(gots[k], wants[k], gds[k], wds[k], f"pair {k}")
+        alive = wants[k]["age"] > 0
+        assert alive.mean() > 0.9
+        vel = np.stack([gots[k]["vel_r"], gots[k]["vel_c"]], 1)[alive]
+        assert np.median(np.linalg.norm(vel - shifts[k], axis=1)) < 0.2       # each pair recovers ITS translation: no pair read another pair's pyramids
+
+
+@pytest.mark.parametrize("ws,lpk", [(3, 8), (5, 16), (7, 0), (7, 8), (7, 32), (9, 0), (11, 64), (15, 0)])
+def test_pyrlk_match_batch_ragged(lib, orc, ws, lpk):
+    """Ragged batches: 19 pairs (more than the 16 a launch carries) with 0 ... 57 keypoints each, dead keypoints, windows leaving the image, every grouped window
+    size and lane grouping; 15 x 15 has no grouped instance and goes out as the calls.  Then one pair of another geometry in the batch: the calls in sequence."""
+    frames, kpss = [], []
+    for k in range(19):
+        f1, f2, kps = lk_scene(120, 160, 60, seed=100 + k, shift=(1.5 - 0.2 * k, -2.25 + 0.25 * k))
+        kps = kps[: (k * 3) % 58].copy()
+        if len(kps) > 6:
+            kps["age"][::5] = 0
+            kps["pos_r"][1], kps["pos_c"][1] = 1.5, 2.25
+            kps["pos_r"][2], kps["pos_c"][2] = 118.2, 157.9
+        frames.append((f1, f2)); kpss.append(kps)
+    lib.vpp_set_tuning(b"pyrlk.lpk", lpk if lpk else -1)
+    try:
+        gots, wants, gds, wds = _pyrlk_batch_case(lib, orc, frames, kpss, ws=ws, B=max(5, ws // 2 + 6))
+        for k in range(19):
+            _assert_lk_parity(gots[k], wants[k], gds[k], wds[k], f"ws {ws} lpk {lpk} pair {k}")
+        f1, f2, kps = lk_scene(96, 200, 30)
+        gots, wants, gds, wds = _pyrlk_batch_case(lib, orc, frames[:3] + [(f1, f2)], kpss[:3] + [kps], ws=ws, B=max(5, ws // 2 + 6))
+        for k in range(4):
+            _assert_lk_parity(gots[k], wants[k], gds[k], wds[k], f"mixed geometry, ws {ws} pair {k}")
+    finally:
+        lib.vpp_set_tuning(b"pyrlk.lpk", -1)
+
+
 @pytest.mark.parametrize("dtype,kind,shape", [(vi.U8, "sparse", (37, 53)), (vi.U8, "dense", (300, 1000)), (vi.I32, "signed", (64, 257)), (vi.F32, "ramp", (40, 3000)),
                                               (vi.U8, "plateau", (37, 53)), (vi.U8, "scores4k", (2160, 3840)), (vi.I16, "dense", (5, 7)), (vi.U8, "sparse", (1, 1))])
 def test_local_maxima_filter_matches_oracle(lib, orc, dtype, kind, shape):

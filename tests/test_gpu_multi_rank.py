@@ -47,6 +47,16 @@ def test_pyrlk_keypoint_shards_and_rccl_all_gather_two_ranks_one_gpu(world):
     assert res["keypoints_per_rank"] == -(-10000 // world)
 
 
+@pytest.mark.parametrize("world,pairs", [(8, 8), (3, 4)])
+def test_pyrlk_frame_pair_batches_sharded_over_ranks_one_gpu(world, pairs):
+    """Round 6: the keypoint-sharded step over F frame pairs — every rank matches its slice of all F pairs in ONE vpp_pyrlk_match_batch launch, ONE RCCL all-gather
+    carries the F x slice records; per pair the gathered records equal a single-rank vpp_pyrlk_match over all 10 000 keypoints (8 ranks x 8 pairs x 1 250: the
+    shape whose rate the bench line projects)."""
+    res = run_ranks(os.path.join(ROOT, "benchmarks", "pyrlk_shard_bench"), world, [2, 10000, pairs], timeout=600)
+    assert res["mismatched_vs_single_rank"] == 0, res
+    assert res["frame_pairs_per_step"] == pairs and res["keypoints_per_rank"] == -(-10000 // world)
+
+
 @pytest.mark.parametrize("world,shape", [(2, (480, 640)), (3, (540, 960)), (2, (2160, 3840)), (8, (480, 640)), (8, (1120, 1280))])   # 8 ranks (the node), strips of 60 and 140 rows
 def test_flow_strips_halo_exchange_and_map_gathers_two_ranks_one_gpu(world, shape):
     """Row exchange + sharded semi-dense flow + halo exchange + FAST-9 on strips: identical to the single-rank calls (BASELINE configs[4] at 4K)."""

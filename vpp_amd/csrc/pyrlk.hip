@@ -19,6 +19,7 @@
 // Not bandwidth bound: ~1 KB touched per keypoint-level, L2-resident; the metric is tracks/s.
 #include "common.hpp"
 #include <cfloat>
+#include <vector>
 using namespace vpp_amd;
 
 namespace {
@@ -506,6 +507,57 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void py
   kps[i] = kp;
 }
 
+// ---- F frame pairs per launch (vpp_pyrlk_match_batch) -------------------------------------------------------------------------------------------------
+// One match of 1 250 keypoints (a rank's slice of configs[3] on 8 GPUs) costs the same 71 us as one of 5 000: the launch is a single generation of waves whose
+// length is the chain of a keypoint's levels x iterations, not its width.  Frame pairs are independent (pyrlk_match.hh:15-55 touches its own pyramids and
+// container only), so F of them go out as ONE launch: the same group code, a keypoint group finds its frame from the launch's block table and takes its
+// pyramids' first pixels from the frame table; the per-level geometry is the launch's (frames of one stream share it).  Results per frame are those of the
+// single call — the same float chains in the same order.
+constexpr int kLkBatchFrames = 16;   // frame pairs per launch
+constexpr int kLkBatchSlots = 64;    // frames x levels per launch (16 x 4, 8 x 8): the table travels as kernel arguments (< 4 KB)
+struct LkBatch {
+  DImg gp[kMaxLevels], gg[kMaxLevels], gn[kMaxLevels];   // per-level geometry of every frame's prev / grad / next (p0 unused)
+  uint8_t* p[3][kLkBatchSlots];                           // first pixels: [prev | grad | next][frame * nlevels + level]
+  vpp_keypoint_f32* kps[kLkBatchFrames];
+  float* dist[kLkBatchFrames];
+  int n[kLkBatchFrames];
+  int first_block[kLkBatchFrames + 1];                    // a frame's groups fill whole workgroups: workgroup b serves frame f with first_block[f] <= b < first_block[f + 1]
+};
+template <int WS, int LPK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pyrlk_match_batch_kernel(LkBatch T, int nframes, int nlevels, float min_ev, float max_err, int max_it,
+                                                                                                       float delta, int min_scale) {
+  constexpr int N = WS * WS, PPL = (N + LPK - 1) / LPK, NS = PPL * LPK;
+  __shared__ __attribute__((aligned(16))) float smem[(64 / LPK) * lk_group_stride(NS, LPK, WS)];
+  const int gl = threadIdx.x % LPK, grp = threadIdx.x / LPK;
+  int f = 0;
+  while (f + 1 < nframes && (int)blockIdx.x >= T.first_block[f + 1]) f++;   // (wave-uniform: scalar loads of at most 16 words)
+  const int i = ((int)blockIdx.x - T.first_block[f]) * (64 / LPK) + grp;
+  if (i >= T.n[f]) return;
+  float* lds = smem + grp * lk_group_stride(NS, LPK, WS);
+  vpp_keypoint_f32* kps = T.kps[f];
+  float* out_dist = T.dist[f];
+  vpp_keypoint_f32 kp = kps[i];
+  if (!(kp.age > 0)) { if (out_dist && gl == 0) out_dist[i] = 0.f; return; }
+  float tr0 = 0.f, tr1 = 0.f, dist = 0.f;
+  const float norm_T = norm_threshold(delta);
+  for (int S = nlevels - 1; S >= min_scale; S--) {
+    tr0 *= 2.f; tr1 *= 2.f;
+    const float sc = (float)(1 << S);
+    DImg A = T.gp[S], Ag = T.gg[S], B = T.gn[S];
+    const int slot = f * nlevels + S;
+    A.p0 = T.p[0][slot]; Ag.p0 = T.p[1][slot]; B.p0 = T.p[2][slot];
+    const Match m = lk_match_group<WS, float, true, LPK>(kp.pos_r / sc, kp.pos_c / sc, tr0, tr1, A, B, Ag, min_ev, max_it, delta, lds, gl, norm_T);
+    if (m.err < max_err) { tr0 = m.f0; tr1 = m.f1; }
+    dist = m.err;
+  }
+  if (gl != 0) return;
+  const float q0 = kp.pos_r + tr0, q1 = kp.pos_c + tr1;
+  if (out_dist) out_dist[i] = dist;
+  if (dist > max_err || !T.gp[0].has((int)q0, (int)q1)) kp.age = 0;
+  else { kp.vel_r = q0 - kp.pos_r; kp.vel_c = q1 - kp.pos_c; kp.pos_r = q0; kp.pos_c = q1; kp.age++; }
+  kps[i] = kp;
+}
+
 template <int WS, int LPK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lucas_kanade_group_kernel(Pyr P, Pyr G, Pyr Nx, int nlevels, const float* __restrict__ pts,
                                                                 const float* __restrict__ pred, int n, float min_ev, int niter, float delta,
@@ -637,6 +689,71 @@ int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, cons
 #undef VPP_LK_LAUNCH
 #undef VPP_LK_LAUNCH_WIDE
   VPP_LAUNCH_CHECK();
+  return VPP_OK;
+}
+
+int vpp_pyrlk_match_batch(const vpp_image_desc* prev, const vpp_image_desc* grad, const vpp_image_desc* next, int nframes, int nlevels, vpp_keypoint_f32* const* kps,
+                          const int* n, int winsize, float min_ev, float max_err, int max_iterations, float convergence_delta, int min_scale, float* const* out_dist,
+                          void* stream) {
+  VPP_REQUIRE(nframes >= 0 && (nframes == 0 || (prev && grad && next && kps && n)) && min_scale >= 0, VPP_ERR_INVALID_ARG, "vpp_pyrlk_match_batch: invalid argument");
+  VPP_REQUIRE(nlevels >= 1 && nlevels <= kMaxLevels, VPP_ERR_INVALID_ARG, "vpp_pyrlk_match_batch: need 1..%d pyramid levels", kMaxLevels);
+  // every frame as the single call checks it; one launch serves frames of ONE geometry (per level: sizes, pitches, borders of the three pyramids)
+  std::vector<Pyr> P(nframes), G(nframes), N(nframes);
+  bool same = true;
+  long long total = 0;
+  for (int f = 0; f < nframes; f++) {
+    VPP_REQUIRE(n[f] >= 0 && (n[f] == 0 || kps[f]), VPP_ERR_INVALID_ARG, "vpp_pyrlk_match_batch: frame %d: invalid keypoint array", f);
+    const int rc = check_pyramids("vpp_pyrlk_match_batch", prev + (size_t)f * nlevels, grad + (size_t)f * nlevels, next + (size_t)f * nlevels, nlevels, VPP_F32, P[f], G[f], N[f]);
+    if (rc != VPP_OK) return rc;
+    auto geo = [](const DImg& a, const DImg& b) { return a.nr == b.nr && a.nc == b.nc && a.pitch == b.pitch && a.border == b.border; };
+    for (int l = 0; l < nlevels; l++) same = same && geo(P[f].l[l], P[0].l[l]) && geo(G[f].l[l], G[0].l[l]) && geo(N[f].l[l], N[0].l[l]);
+    total += n[f];
+  }
+  if (total == 0) return VPP_OK;
+  int lpk = tuning("pyrlk.lpk", 0);
+  if (lpk == 0) lpk = total >= 80000 ? 8 : (total >= 8000 ? 16 : (total >= 3500 ? 32 : 64));   // the single call's table (vpp_pyrlk_match), on the launch's total
+  if (winsize > 7 && lpk == 8) lpk = 16;
+  if (winsize > 7 && winsize <= 11 && tuning("pyrlk.lpk", 0) == 0 && lpk == 16) lpk = 32;
+  const bool grouped = (winsize == 3 || winsize == 5 || winsize == 7 || winsize == 9 || winsize == 11) && (lpk == 8 || lpk == 16 || lpk == 32 || lpk == 64);
+  if (!same || !grouped || nframes == 1 || !tuning("pyrlk.batch", 1)) {   // what one launch does not serve goes out as the calls (whose results are the contract)
+    for (int f = 0; f < nframes; f++) {
+      const int rc = vpp_pyrlk_match(prev + (size_t)f * nlevels, grad + (size_t)f * nlevels, next + (size_t)f * nlevels, nlevels, kps[f], n[f], winsize, min_ev, max_err, max_iterations,
+                                     convergence_delta, min_scale, out_dist ? out_dist[f] : nullptr, stream);
+      if (rc != VPP_OK) return rc;
+    }
+    return VPP_OK;
+  }
+  hipStream_t st = as_stream(stream);
+  const int per_launch = std::min(kLkBatchFrames, kLkBatchSlots / nlevels), gpb = 64 / lpk;   // frames per launch; keypoint groups per workgroup
+  for (int f0 = 0; f0 < nframes; f0 += per_launch) {
+    const int nf = std::min(per_launch, nframes - f0);
+    LkBatch T{};
+    for (int l = 0; l < nlevels; l++) { T.gp[l] = P[f0].l[l]; T.gg[l] = G[f0].l[l]; T.gn[l] = N[f0].l[l]; }
+    int blocks = 0;
+    for (int k = 0; k < nf; k++) {
+      const int f = f0 + k;
+      for (int l = 0; l < nlevels; l++) { T.p[0][k * nlevels + l] = P[f].l[l].p0; T.p[1][k * nlevels + l] = G[f].l[l].p0; T.p[2][k * nlevels + l] = N[f].l[l].p0; }
+      T.kps[k] = kps[f]; T.dist[k] = out_dist ? out_dist[f] : nullptr; T.n[k] = n[f];
+      T.first_block[k] = blocks;
+      blocks += (n[f] + gpb - 1) / gpb;
+    }
+    for (int k = nf; k <= kLkBatchFrames; k++) T.first_block[k] = blocks;
+    if (!blocks) continue;
+#define VPP_LKB_LAUNCH(W, L) pyrlk_match_batch_kernel<W, L><<<blocks, 64, 0, st>>>(T, nf, nlevels, min_ev, max_err, max_iterations, convergence_delta, min_scale)
+#define VPP_LKB_CASE(W, NARROW)                                \
+    case W:                                                   \
+      if (lpk == 64) VPP_LKB_LAUNCH(W, 64);                   \
+      else if (lpk == 32) VPP_LKB_LAUNCH(W, 32);              \
+      else if (lpk == 16) VPP_LKB_LAUNCH(W, 16);              \
+      else NARROW;                                            \
+      break;
+    switch (winsize) {   // (9 x 9 and 11 x 11 have no 8-lane instance: lpk was raised above)
+      VPP_LKB_CASE(3, VPP_LKB_LAUNCH(3, 8)) VPP_LKB_CASE(5, VPP_LKB_LAUNCH(5, 8)) VPP_LKB_CASE(7, VPP_LKB_LAUNCH(7, 8)) VPP_LKB_CASE(9, (void)0) VPP_LKB_CASE(11, (void)0)
+    }
+#undef VPP_LKB_CASE
+#undef VPP_LKB_LAUNCH
+    VPP_LAUNCH_CHECK();
+  }
   return VPP_OK;
 }
 
