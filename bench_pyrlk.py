@@ -121,7 +121,7 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
                 a = DeviceImage.from_host(u8_image(np.clip(np.rint(texf), 0, 255).astype(np.uint8)), dev)
                 b = DeviceImage.from_host(u8_image(np.clip(np.rint(translate(texf, 1.5 - 0.1 * f, -2.25 + 0.2 * f)), 0, 255).astype(np.uint8)), dev)
                 pa = pyr.device_pyramid(lib, a, L, B); ga = pyr.device_grad_pyramid(lib, pa[0], L, B, vi.F32); pb = pyr.device_pyramid(lib, b, L, B)
-                kf = torch.from_numpy(kps_h[f % 8::8][:NSL].view(np.uint8).reshape(-1).copy()).to(dev)
+                kf = torch.from_numpy(np.ascontiguousarray(kps_h[f % 8::8][:NSL]).view(np.uint8).reshape(-1).copy()).to(dev)
                 pairs.append((pa, ga, pb, kf, kf.clone()))
             batch = lib.vpp_pyrlk_match_batch
             fb = {}

@@ -1,7 +1,7 @@
 /* abort_bt.c — LD_PRELOAD diagnostic (round 6): when glibc's heap check aborts a process ("free(): invalid next size", "corrupted size vs. prev_size"), print the
  * ABORTING thread's backtrace with the module each frame lives in, so that the free() that tripped can be attributed (rocprofiler-sdk, the HIP runtime, torch, this
  * library).  rocprofv3 installs its own SIGABRT handler after us; sigaction() is interposed so that ours stays first and theirs is chained.
- * build: gcc -shared -fPIC -O1 tools/abort_bt.c -o tools/libabort_bt.so -ldl      use: LD_PRELOAD=tools/libabort_bt.so rocprofv3 ... */
+ * build: gcc -shared -fPIC -O1 tools/abort_bt.c -o tools/libabort_bt.so -ldl      use: rocprofv3 --preload tools/libabort_bt.so ... (rocprofv3 builds the application's LD_PRELOAD itself) */
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <execinfo.h>
@@ -36,7 +36,10 @@ static void on_abort(int sig, siginfo_t* si, void* uc) {
   }
   if (g_have_next && (g_next.sa_flags & SA_SIGINFO) && g_next.sa_sigaction) { g_next.sa_sigaction(sig, si, uc); return; }
   if (g_have_next && g_next.sa_handler && g_next.sa_handler != SIG_DFL && g_next.sa_handler != SIG_IGN) { g_next.sa_handler(sig); return; }
-  signal(SIGABRT, SIG_DFL);
+  struct sigaction dfl;                  /* (not signal(): that is interposed below) */
+  memset(&dfl, 0, sizeof dfl);
+  dfl.sa_handler = SIG_DFL;
+  real_sigaction(SIGABRT, &dfl, 0);
   raise(SIGABRT);
 }
 
@@ -48,6 +51,20 @@ int sigaction(int sig, const struct sigaction* act, struct sigaction* old) {
     return 0;
   }
   return real_sigaction(sig, act, old);
+}
+
+typedef void (*handler_t)(int);
+handler_t signal(int sig, handler_t h) {   /* the other way to take SIGABRT from us */
+  if (sig == SIGABRT) {
+    handler_t prev = g_have_next && !(g_next.sa_flags & SA_SIGINFO) ? g_next.sa_handler : SIG_DFL;
+    memset(&g_next, 0, sizeof g_next); g_next.sa_handler = h; g_have_next = 1;
+    return prev;
+  }
+  struct sigaction sa, old;
+  memset(&sa, 0, sizeof sa);
+  sa.sa_handler = h; sa.sa_flags = SA_RESTART; sigemptyset(&sa.sa_mask);
+  if (!real_sigaction) real_sigaction = (int (*)(int, const struct sigaction*, struct sigaction*))dlsym(RTLD_NEXT, "sigaction");
+  return real_sigaction(sig, &sa, &old) == 0 ? old.sa_handler : SIG_ERR;
 }
 
 __attribute__((constructor)) static void install(void) {

@@ -13,9 +13,9 @@ print(json.dumps(d.get("pyrlk", {}).get("frame_pair_batches"), indent=0))
 print({k: d.get("pyrlk", {}).get("sweep", {}).get(k) for k in ("1250", "10000")})
 PY
 cd /tmp && export TMPDIR=/tmp
-for i in $(seq 1 ${PASSES:-10}); do
+for i in $(seq 1 ${PASSES:-12}); do
   rm -rf $R/gpurun_out/kt_rp
-  LD_PRELOAD=$R/tools/libabort_bt.so timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt_rp -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $R/gpurun_out/bt_$i.json 2> $R/gpurun_out/bt_$i.err
+  timeout -k 10 120 rocprofv3 --preload $R/tools/libabort_bt.so --disable-signal-handlers true --kernel-trace --stats -d $R/gpurun_out/kt_rp -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $R/gpurun_out/bt_$i.json 2> $R/gpurun_out/bt_$i.err
   rc=$?; echo "profiled bench pass $i with abort_bt: exit $rc"
   if [ $rc -ne 0 ]; then grep -E "abort_bt|free\(\)|corrupt|malloc" $R/gpurun_out/bt_$i.err | head -60; cp $R/gpurun_out/bt_$i.err $R/gpurun_out/abort_backtrace.txt; break; fi
   rm -f $R/gpurun_out/bt_$i.err $R/gpurun_out/bt_$i.json
