@@ -62,6 +62,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(dev))
     lib = capi.lib()
     capi.check(lib.vpp_init(local_rank))
+    if os.environ.get("VPP_BENCH_FAULTHANDLER", "0") == "1":
+        # diagnosing an abort under a profiler (round 6): installed AFTER the HIP runtime (and a preloaded tool) have installed their own handlers, so that a SIGABRT
+        # raised by any thread first prints where the Python main thread is (which leg), then goes on to the handler that was there before
+        import faulthandler
+        torch.zeros(1, device=dev).item()
+        faulthandler.enable(file=sys.stderr, all_threads=True)
     st = capi.stream_ptr()
 
     def barrier():

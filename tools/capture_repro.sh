@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 EXE=$R/tools/capture_setparams_repro
 {
-for mode in edit deps plain; do
+for mode in ${MODES:-edit deps plain timed}; do
   timeout -k 5 60 $EXE $mode 40 > $OUT/${mode}_bare.log 2>&1; echo "$mode without profiler: exit $?"
   ok=0; bad=0
   for i in $(seq $RUNS); do

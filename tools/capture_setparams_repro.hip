@@ -5,6 +5,8 @@
 //   capture_setparams_repro edit   [graphs]   node editing under capture, 63 edits per graph        (the round-4/5 mechanism)
 //   capture_setparams_repro deps   [graphs]   only the dependency updates, one node per call       (IndependentCall alone)
 //   capture_setparams_repro plain  [graphs]   one node per batch, nothing edited                   (the round-6 mechanism)
+//   capture_setparams_repro timed  [graphs]   20 kernel nodes + the event-record nodes vpp_graph_end(timed = 1) adds in front of the roots and behind the
+//                                             leaves, hipEventElapsedTime after every replay         (what bench.py's timed regions are made of)
 // Run each under `rocprofv3 --kernel-trace` a few times and count aborts (tools/capture_repro.sh).  Build: make -C tools capture_setparams_repro
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,7 +25,7 @@ template <int VARIANT> __global__ __launch_bounds__(256) void batch_kernel(Frame
 int main(int argc, char** argv) {
   const char* mode = argc > 1 ? argv[1] : "edit";
   const int graphs = argc > 2 ? std::atoi(argv[2]) : 40;
-  const bool edit = !std::strcmp(mode, "edit"), deps_only = !std::strcmp(mode, "deps");
+  const bool edit = !std::strcmp(mode, "edit"), deps_only = !std::strcmp(mode, "deps"), timed = !std::strcmp(mode, "timed");
   const unsigned bpf = 64;
   Frames fr{};
   for (int k = 0; k < 64; k++) { CK(hipMalloc(&fr.p[k], bpf * 256 * sizeof(unsigned))); CK(hipMemset(fr.p[k], 0, bpf * 256 * sizeof(unsigned))); }
@@ -59,15 +61,41 @@ int main(int argc, char** argv) {
         if (lane_last.size() < 2) lane_last.push_back(deps[0]); else lane_last[n & 1] = deps[0];
         CK(hipStreamUpdateCaptureDependencies(st, lane_last.data(), lane_last.size(), hipStreamSetCaptureDependencies));
       }
+    } else if (timed) {
+      for (int k = 0; k < 20; k++) batch_kernel<2><<<bpf * 64, 256, 0, st>>>(fr, 64, bpf);
     } else {
       batch_kernel<2><<<bpf * 64, 256, 0, st>>>(fr, 64, bpf);
     }
     hipGraph_t graph; hipGraphExec_t exec;
     CK(hipStreamEndCapture(st, &graph));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {   // runtime.hip: vpp_graph_end(timed = 1)
+      size_t nn = 0, ne = 0;
+      CK(hipGraphGetNodes(graph, nullptr, &nn)); CK(hipGraphGetEdges(graph, nullptr, nullptr, &ne));
+      std::vector<hipGraphNode_t> nodes(nn), from(ne), to(ne);
+      CK(hipGraphGetNodes(graph, nodes.data(), &nn));
+      if (ne) CK(hipGraphGetEdges(graph, from.data(), to.data(), &ne));
+      CK(hipEventCreateWithFlags(&e0, hipEventReleaseToDevice)); CK(hipEventCreateWithFlags(&e1, hipEventReleaseToDevice));
+      std::vector<hipGraphNode_t> roots, leaves;
+      for (hipGraphNode_t n : nodes) {
+        bool has_in = false, has_out = false;
+        for (size_t k = 0; k < ne; k++) { has_in |= to[k] == n; has_out |= from[k] == n; }
+        if (!has_in) roots.push_back(n);
+        if (!has_out) leaves.push_back(n);
+      }
+      hipGraphNode_t n0 = nullptr, n1 = nullptr;
+      CK(hipGraphAddEventRecordNode(&n0, graph, nullptr, 0, e0));
+      for (hipGraphNode_t r : roots) CK(hipGraphAddDependencies(graph, &n0, &r, 1));
+      CK(hipGraphAddEventRecordNode(&n1, graph, leaves.data(), leaves.size(), e1));
+    }
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    for (int r = 0; r < 5; r++) CK(hipGraphLaunch(exec, st));
-    expect += 5;
+    for (int r = 0; r < 5; r++) {
+      CK(hipGraphLaunch(exec, st));
+      if (timed) { float ms = 0; CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); }
+    }
+    expect += timed ? 100 : 5;
     CK(hipStreamSynchronize(st));
+    if (e0) { CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1)); }
     CK(hipGraphExecDestroy(exec));
     CK(hipGraphDestroy(graph));
   }

@@ -269,7 +269,7 @@ struct Scratch {
 unsigned* device_error_word();
 int check_device_error(const char* where);   // VPP_OK, or VPP_ERR_HIP + vpp_last_error() when a bit is up
 unsigned peek_device_error();                // the bits that are up, left as they are (0 when the word was never allocated)
-enum { kDevErrSweepBarrier = 1u };
+enum { kDevErrSweepBarrier = 1u, kDevErrFastFuse = 2u };   // the flow's grid barrier; FAST-9's in-launch ordered write (fast9.hip)
 
 // blockIdx remap so that consecutive logical blocks share an XCD (hardware places block b on XCD b % 8;
 // MI355X_MICROARCH.md "Workgroup dispatch").  Speed only, never correctness.

@@ -166,13 +166,36 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
 // included); RAW reads F at the corners only (no zero fill: 16.6 MB of 2-byte stores less on a 4K frame); BLOCKWISE needs neither F
 // nor the bitmap — a corner raises the key (score / 16) << 32 | ~position of its bs x bs block with one 64-bit atomic max in L2
 // (keys all-zero before the launch: zeroed by the write pass of the previous call, or by a memset node), which is the reduction fast9_count_blocks_kernel did in a second pass over F.
-template <bool REF, int MODE>
+// FUSED (RAW only, round 6): the ordered write happens in THIS launch — no F map, no bitmap, no second kernel.  A corner's output index is
+//   (corners of the bands above) + (corners of the rows above it in its band) + (corners left of its tile in its row) + (its rank in the tile's row word).
+// Every tile publishes its 32 row counts (write-through bytes, row-major: a row's counts of all tiles are contiguous) and adds its total to its band's word,
+// then arrives on the band's counter.  The band's last arriver publishes {aggregate} for the band, looks back over the bands above (decoupled look-back: one
+// lane per predecessor, an {inclusive prefix} ends the walk) and publishes the band's {inclusive prefix}; every tile of the band waits for that word, sums the row
+// counts it needs (32 lanes, one row each) and writes its corners' records from LDS (scores stay in LDS: F is never written).  Workgroups are dispatched in
+// blockIdx order and a tile only ever waits for tiles of its own band (at most ntc - 1 blocks ahead) and for the bands above (all dispatched earlier), so the
+// waits complete as long as a band's tiles fit on the chip at once (ntc <= 1024 tiles of 4 waves); they are bounded like the flow's (kFuseSpinLimit, error word).
+// The last tile of the launch hands the control block back zeroed.
+struct RawFuse {
+  uint8_t* rowcnt; int ntcp;                    // [nby * TH rows][ntcp] corner counts per (row, tile); ntcp = ntc rounded up to 8
+  uint32_t *arrive, *tot;                       // per band: tiles arrived, corners
+  unsigned long long* state;                    // per band: flag << 32 | value; flag 1: value = the band's corners, flag 2: value = corners of this band and all above
+  uint32_t* finished;                           // tiles that are done with the control block
+  uint32_t* total; int32_t* out_rc; int32_t* out_scores; int capacity;
+  unsigned* err;                                // the sticky device error word (common.hpp)
+};
+constexpr unsigned kFuseSpinLimit = 1u << 22;
+__device__ __forceinline__ uint32_t ld_u32_sc1(const uint32_t* p) { return __hip_atomic_load((uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_u64_sc1(const unsigned long long* p) { return __hip_atomic_load((unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <bool REF, int MODE, bool FUSED = false>
 __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int has_mask, int th, DImg F, uint64_t* __restrict__ bitmap, int ntc,
                                                             unsigned long long* __restrict__ blkkey, uint32_t bs_magic, int nbc,
-                                                            uint8_t* __restrict__ rowcnt, uint16_t* __restrict__ tiletot) {
+                                                            uint8_t* __restrict__ rowcnt, uint16_t* __restrict__ tiletot, RawFuse fz) {
+  static_assert(!FUSED || MODE == VPP_FAST9_RAW, "the fused write serves RAW");
   __shared__ __attribute__((aligned(16))) uint8_t tile[LROWS * LP];
   __shared__ uint16_t cand[4][TH / 4 * TW];          // per wave: (row in the wave's band) * 64 + column
   __shared__ unsigned long long words[4][TH / 4];    // per wave: corner bitmap words of its TH / 4 rows
+  __shared__ uint16_t fsc[FUSED ? 4 : 1][FUSED ? TH / 4 * TW : 1];   // FUSED: F(p) = score + 1 of the wave's corners, at (row in the wave's band) * 64 + column
   const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH;
   const int lo = -A.border, hi = A.nc + A.border;
   const bool aligned = (((uintptr_t)A.p0 | (uintptr_t)A.pitch) & 3) == 0;
@@ -307,7 +330,8 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
             atomicMax(&blkkey[(size_t)br * nbc + bc], ((unsigned long long)s16 << 32) | (0xFFFFFFFFu - ((r << 16) | cc)));
           }
         } else {
-          F.row<uint16_t>(r0 + lr)[c0 + col] = (uint16_t)f;
+          if (FUSED) fsc[wv][id] = (uint16_t)f;
+          else F.row<uint16_t>(r0 + lr)[c0 + col] = (uint16_t)f;
           atomicOr(&words[wv][j], 1ull << col);
         }
       }
@@ -315,6 +339,102 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
   }
   if (MODE == VPP_FAST9_BLOCKWISE) return;
   wave_fence_lds();
+  if constexpr (FUSED) {
+    __shared__ uint32_t wtot[4], s_last, s_incl, s_btot, s_reset, rowbase[TH];
+    const int band = blockIdx.y, bx = blockIdx.x;
+    uint32_t nrow = 0;
+    if (lane < TH / 4) {   // rows past the frame's last one have no corners: their counts are written all the same (nobody reads a stale byte)
+      nrow = (uint32_t)__popcll(words[wv][lane]);
+      __hip_atomic_store(fz.rowcnt + (size_t)(band * TH + wv * (TH / 4) + lane) * fz.ntcp + bx, (uint8_t)nrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    nrow += __shfl_xor(nrow, 1); nrow += __shfl_xor(nrow, 2); nrow += __shfl_xor(nrow, 4);
+    if (lane == 0) wtot[wv] = nrow;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's counts have been performed (write-through) before the workgroup arrives
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t ttot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+      if (ttot) { (void)__hip_atomic_fetch_add(&fz.tot[band], ttot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // performed before the arrival (another channel)
+      s_last = __hip_atomic_fetch_add(&fz.arrive[band], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)ntc - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && wv == 0) {   // the band is complete: its prefix, by decoupled look-back over the bands above
+      const uint32_t btot = ld_u32_sc1(&fz.tot[band]);
+      if (lane == 0 && band > 0) __hip_atomic_store(&fz.state[band], (1ull << 32) | btot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t excl = 0;
+      bool gave_up = false;
+      for (int b = band - 1; b >= 0 && !gave_up;) {
+        const int mb = b - lane;
+        unsigned long long st = 2ull << 32;   // lanes past band 0: an inclusive prefix of 0
+        if (mb >= 0) {
+          unsigned spin = 0;
+          while (((st = ld_u64_sc1(&fz.state[mb])) >> 32) == 0ull && ++spin < kFuseSpinLimit) __builtin_amdgcn_s_sleep(1);
+          if (spin >= kFuseSpinLimit) gave_up = true;
+        }
+        gave_up = __ballot(gave_up) != 0ull;
+        const unsigned long long pm = __ballot((st >> 32) == 2ull);
+        const int first = pm ? __ffsll((long long)pm) - 1 : 64;   // the nearest band above whose inclusive prefix is known ends the walk
+        uint32_t v = lane <= first ? (uint32_t)st : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        excl += v;
+        if (pm) break;
+        b -= 64;
+      }
+      if (gave_up && lane == 0 && fz.err) __hip_atomic_fetch_or(fz.err, (unsigned)kDevErrFastFuse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (lane == 0) {
+        __hip_atomic_store(&fz.state[band], (2ull << 32) | (unsigned long long)(excl + btot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (band == (int)gridDim.y - 1) *fz.total = excl + btot;
+      }
+    }
+    if (threadIdx.x == 0) {   // every tile of the band: the band's inclusive prefix and its total
+      unsigned long long st;
+      unsigned spin = 0;
+      while (((st = ld_u64_sc1(&fz.state[band])) >> 32) != 2ull && ++spin < kFuseSpinLimit) __builtin_amdgcn_s_sleep(1);
+      if (spin >= kFuseSpinLimit && fz.err) __hip_atomic_fetch_or(fz.err, (unsigned)kDevErrFastFuse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      s_incl = (uint32_t)st; s_btot = ld_u32_sc1(&fz.tot[band]);
+    }
+    __syncthreads();
+    if (wv == 0) {   // lane j: corners of row j of the band in all tiles, and in the tiles left of this one
+      uint32_t rt = 0, left = 0;
+      if (lane < TH) {
+        const unsigned long long* row = (const unsigned long long*)(fz.rowcnt + (size_t)(band * TH + lane) * fz.ntcp);
+        for (int q = 0; q < fz.ntcp / 8; q++) {
+          const unsigned long long v = ld_u64_sc1(row + q);   // (bytes past ntc were zeroed with the control block and are never written)
+          const int nl = bx - 8 * q;                           // tiles of this group that lie left of bx
+          const unsigned long long lm = nl >= 8 ? ~0ull : (nl <= 0 ? 0ull : (1ull << (8 * nl)) - 1ull), vl = v & lm;
+          rt = __builtin_amdgcn_sad_u8((uint32_t)v, 0u, rt); rt = __builtin_amdgcn_sad_u8((uint32_t)(v >> 32), 0u, rt);
+          left = __builtin_amdgcn_sad_u8((uint32_t)vl, 0u, left); left = __builtin_amdgcn_sad_u8((uint32_t)(vl >> 32), 0u, left);
+        }
+      }
+      uint32_t inc = rt;   // inclusive scan of the rows' totals over lanes 0 .. 31
+#pragma unroll
+      for (int d = 1; d < TH; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+      if (lane < TH) rowbase[lane] = s_incl - s_btot + (inc - rt) + left;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < TH / 4; j++) {   // the tile's records, a wave per row: lane = column
+      const unsigned long long w = words[wv][j];
+      if ((w >> lane) & 1ull) {
+        const uint32_t k = rowbase[wv * (TH / 4) + j] + (uint32_t)__popcll(w & ((1ull << lane) - 1ull));
+        if ((int)k < fz.capacity) {
+          fz.out_rc[2 * (size_t)k] = r0 + wv * (TH / 4) + j; fz.out_rc[2 * (size_t)k + 1] = c0 + lane;
+          if (fz.out_scores) fz.out_scores[k] = (int32_t)fsc[wv][j * TW + lane] - 1;
+        }
+      }
+    }
+    // ---- hand the control block back: the launch's last tile zeroes it (every other tile has read what it needed)
+    if (threadIdx.x == 0) s_reset = __hip_atomic_fetch_add(fz.finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_reset) {
+      for (int b = threadIdx.x; b < (int)gridDim.y; b += 256) {
+        __hip_atomic_store(&fz.arrive[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&fz.tot[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&fz.state[b], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (threadIdx.x == 0) __hip_atomic_store(fz.finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   uint32_t nrow = 0;
   if (lane < TH / 4) {
     const int r = r0 + wv * (TH / 4) + lane;
@@ -731,7 +851,12 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
   const int nby = (nr + TH - 1) / TH;
   const bool raw2 = impl == 2 && mode == VPP_FAST9_RAW;   // the RAW instance of the two-phase kernel always writes its counts
   const size_t off_rc = off_uc + align_up((size_t)ngroups * 4, 256), off_tt = off_rc + align_up(raw2 ? (size_t)nwords : 0, 256);
-  const size_t total_bytes = off_tt + align_up(raw2 ? (size_t)nby * ntc * 2 : 0, 256);
+  // RAW in ONE launch (round 6): the detect kernel writes the ordered list itself (fast9_detect2_kernel<.., RAW, true>); its control block + row counts follow the rest
+  const bool fused_write = raw2 && ntc <= 1024 && tuning("fast9.raw_fused", 1);
+  const int ntcp = (ntc + 7) / 8 * 8;
+  const size_t off_fz = off_tt + align_up(raw2 ? (size_t)nby * ntc * 2 : 0, 256);
+  const size_t fz_ctl = 256 + align_up((size_t)nby * 4, 256) * 2 + align_up((size_t)nby * 8, 256), fz_bytes = fused_write ? fz_ctl + align_up((size_t)nby * TH * ntcp, 256) : 0;
+  const size_t total_bytes = off_fz + fz_bytes;
   int rc = g_scratch.ensure(total_bytes, st);
   if (rc != VPP_OK) return rc;
   uint8_t* base = (uint8_t*)g_scratch.p;
@@ -757,11 +882,33 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
   sl.set_note(0, 0);   // until this call's write pass is queued (an error return in between must not leave a wrong note)
   const uint32_t bs_magic = block_size >= 2 ? (uint32_t)((1ull << 32) / (unsigned)block_size) + 1u : 0u;   // x / bs = umulhi(x, magic), exact for x < 2^16
   if (keyed && !keys_clean) { const int rf = device_fill(blkkey, 0, (size_t)nblocks * 8, st); if (rf != VPP_OK) return rf; }
+  if (fused_write) {
+    // user[1]: the control block (and the padding bytes of the row counts) of THIS layout are all-zero — the launch's last tile hands them back that way, so
+    // back-to-back raw calls need no fill; any other layout, a recorded call (notes are not believed on a buffer a capture has recorded on) or a device-side fault
+    // (check_device_error bumps the notes' epoch) gets the fill
+    const unsigned long long fz_sig = (((unsigned long long)off_fz << 24) ^ ((unsigned long long)nby << 12) ^ (unsigned long long)ntcp) + 1ull;
+    const bool fz_clean = sl.note(1, fz_sig);
+    sl.set_note(1, 0);
+    if (!fz_clean) { const int rf = device_fill(base + off_fz, 0, fz_bytes, st); if (rf != VPP_OK) return rf; }
+    uint8_t* q = base + off_fz;
+    RawFuse fz{};
+    fz.finished = (uint32_t*)q; q += 256;
+    fz.arrive = (uint32_t*)q; q += align_up((size_t)nby * 4, 256);
+    fz.tot = (uint32_t*)q; q += align_up((size_t)nby * 4, 256);
+    fz.state = (unsigned long long*)q; q += align_up((size_t)nby * 8, 256);
+    fz.rowcnt = q; fz.ntcp = ntcp;
+    fz.total = d_total; fz.out_rc = out_rc; fz.out_scores = out_scores; fz.capacity = capacity; fz.err = device_error_word();
+    if (compat == VPP_FAST9_REFERENCE) fast9_detect2_kernel<true, VPP_FAST9_RAW, true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot, fz);
+    else fast9_detect2_kernel<false, VPP_FAST9_RAW, true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot, fz);
+    VPP_LAUNCH_CHECK();
+    sl.set_note(1, fz_sig);
+    return VPP_OK;
+  }
   if (impl == 2) {
 #define VPP_FAST_DETECT2(R)                                                                                                                             \
-    if (keyed) fast9_detect2_kernel<R, VPP_FAST9_BLOCKWISE><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot);           \
-    else if (mode == VPP_FAST9_RAW) fast9_detect2_kernel<R, VPP_FAST9_RAW><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot); \
-    else fast9_detect2_kernel<R, VPP_FAST9_LOCAL_MAXIMA><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot);
+    if (keyed) fast9_detect2_kernel<R, VPP_FAST9_BLOCKWISE><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot, RawFuse{});           \
+    else if (mode == VPP_FAST9_RAW) fast9_detect2_kernel<R, VPP_FAST9_RAW><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot, RawFuse{}); \
+    else fast9_detect2_kernel<R, VPP_FAST9_LOCAL_MAXIMA><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot, RawFuse{});
     if (compat == VPP_FAST9_REFERENCE) { VPP_FAST_DETECT2(true) } else { VPP_FAST_DETECT2(false) }
 #undef VPP_FAST_DETECT2
   } else if (compat == VPP_FAST9_REFERENCE) fast9_detect_kernel<true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc);

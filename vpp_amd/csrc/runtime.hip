@@ -38,8 +38,8 @@ int check_device_error(const char* where) {
   const unsigned bits = __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL);
   if (!bits) return VPP_OK;
   invalidate_scratch_notes();   // whatever that kernel left in its scratch region is unknown: the next call resets it
-  set_error("%s: a device-side protocol gave up waiting (bits 0x%x:%s) - the results of the calls queued before this point are not valid", where, bits,
-            (bits & kDevErrSweepBarrier) ? " grid barrier of the semi-dense flow's propagation rounds" : "");
+  set_error("%s: a device-side protocol gave up waiting (bits 0x%x:%s%s) - the results of the calls queued before this point are not valid", where, bits,
+            (bits & kDevErrSweepBarrier) ? " grid barrier of the semi-dense flow's propagation rounds" : "", (bits & kDevErrFastFuse) ? " FAST-9's in-launch ordered write" : "");
   return VPP_ERR_HIP;
 }
 unsigned peek_device_error() {
