@@ -209,6 +209,42 @@ def test_fast9_scratch_notes_state_machine(lib, orc):
         lib.vpp_set_tuning(b"fast9.block_keys", -1)
 
 
+def test_fast9_raw_in_one_launch_matches_the_two_launch_path_and_the_oracle(lib, orc):
+    """tuning fast9.raw_fused = 1 (off by default: measured slower, fast9.hip): the detect kernel stages its corners, the last tile of every 32-row band looks back
+    over the bands above and places the band's records — one launch, no F map.  Shapes with one band, bands cut by the frame's last row, 1 and 60 tile columns, a
+    mask, both rings, a capacity smaller than the list, back-to-back calls (the control block is handed back zeroed) and a size change in between."""
+    try:
+        lib.vpp_set_tuning(b"fast9.raw_fused", 1)
+        for shape, seed in (((60, 90), 4), ((31, 64), 5), ((130, 257), 6), ((480, 640), 7), ((2160, 3840), 4), ((97, 4096), 8), ((480, 640), 7)):
+            im = u8_image(rects_image(*shape, seed=seed), border=3)
+            orc.orc_fill_border(P(im.desc), 0, None)
+            d = DeviceImage.from_host(im)
+            for compat in (0, 1):
+                want_rc, want_sc = run_detect(orc, im, 20, mode=0, compat=compat, cap=3000000)
+                for rep in range(2):
+                    got_rc, got_sc = gpu_detect(lib, d, 20, mode=0, compat=compat, cap=3000000)
+                    np.testing.assert_array_equal(got_rc, want_rc, err_msg=f"{shape} compat {compat} call {rep}")
+                    np.testing.assert_array_equal(got_sc, want_sc, err_msg=f"{shape} compat {compat} call {rep}")
+            assert len(want_rc) > 0
+        # a mask, and a capacity below the count: VPP_ERR_CAPACITY, the first `cap` records written
+        im = u8_image(rects_image(200, 300, seed=14), border=3)
+        orc.orc_fill_border(P(im.desc), 0, None)
+        mask = HostImage(200, 300, vi.U8, 1, border=10); mask.view()[...] = 255; mask.view()[50:120, 100:250] = 0
+        want_rc, want_sc = run_detect(orc, im, 10, mask=mask, mode=0)
+        d, dm = DeviceImage.from_host(im), DeviceImage.from_host(mask)
+        got_rc, got_sc = gpu_detect(lib, d, 10, mask=dm, mode=0)
+        np.testing.assert_array_equal(got_rc, want_rc); np.testing.assert_array_equal(got_sc, want_sc)
+        cap = len(want_rc) // 2
+        rc = torch.zeros((cap, 2), dtype=torch.int32, device="cuda"); sc = torch.zeros(cap, dtype=torch.int32, device="cuda"); n = ctypes.c_int(0)
+        st = lib.vpp_fast9_detect(P(d.desc), 10, P(dm.desc), 0, 10, 0, ctypes.c_void_p(rc.data_ptr()), ctypes.c_void_p(sc.data_ptr()), cap, P(n), capi.stream_ptr())
+        assert st == capi.ERR_CAPACITY and n.value == len(want_rc)
+        np.testing.assert_array_equal(rc.cpu().numpy(), want_rc[:cap]); np.testing.assert_array_equal(sc.cpu().numpy(), want_sc[:cap])
+        got_rc, got_sc = gpu_detect(lib, d, 10, mask=dm, mode=0)     # and the next call is whole again
+        np.testing.assert_array_equal(got_rc, want_rc)
+    finally:
+        lib.vpp_set_tuning(b"fast9.raw_fused", -1)
+
+
 def test_fast9_4k_all_modes(lib, orc):
     """BASELINE config 3: 2160x3840, th 20, raw / local-max / blockwise(10), reference and corrected rings."""
     im = u8_image(rects_image(2160, 3840, seed=4), border=3)

@@ -9,6 +9,8 @@ V = ctypes.c_void_p
 if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]
 if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]
 lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
+for kv in sys.argv[1:]:   # tuning knobs: name=value (e.g. fast9.raw_fused=0)
+    k, v = kv.split("="); lib.vpp_set_tuning(k.encode(), int(v)); print("tuning", k, v)
 im = u8_image(fast9_bench_frame(), border=3)
 im.view(with_border=True)[..., 0] = np.pad(im.view()[..., 0], 3, mode="symmetric")
 d = DeviceImage.from_host(im)

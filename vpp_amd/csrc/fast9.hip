@@ -168,22 +168,29 @@ __global__ __launch_bounds__(256) void fast9_detect_kernel(DImg A, DImg M, int h
 // (keys all-zero before the launch: zeroed by the write pass of the previous call, or by a memset node), which is the reduction fast9_count_blocks_kernel did in a second pass over F.
 // FUSED (RAW only, round 6): the ordered write happens in THIS launch — no F map, no bitmap, no second kernel.  A corner's output index is
 //   (corners of the bands above) + (corners of the rows above it in its band) + (corners left of its tile in its row) + (its rank in the tile's row word).
-// Every tile publishes its 32 row counts (write-through bytes, row-major: a row's counts of all tiles are contiguous) and adds its total to its band's word,
-// then arrives on the band's counter.  The band's last arriver publishes {aggregate} for the band, looks back over the bands above (decoupled look-back: one
-// lane per predecessor, an {inclusive prefix} ends the walk) and publishes the band's {inclusive prefix}; every tile of the band waits for that word, sums the row
-// counts it needs (32 lanes, one row each) and writes its corners' records from LDS (scores stay in LDS: F is never written).  Workgroups are dispatched in
-// blockIdx order and a tile only ever waits for tiles of its own band (at most ntc - 1 blocks ahead) and for the bands above (all dispatched earlier), so the
-// waits complete as long as a band's tiles fit on the chip at once (ntc <= 1024 tiles of 4 waves); they are bounded like the flow's (kFuseSpinLimit, error word).
-// The last tile of the launch hands the control block back zeroed.
+// No tile ever waits for another one (a first version in which every tile waited for its band's prefix measured 98 us per 4K call instead of 42: thousands of
+// resident workgroups polling, and a slow tile stalling every later one — which keeps its slot — into a convoy).  Instead every tile STAGES its corners — packed
+// {score + 1, row in the band, column in the tile}, tile-major, in the tile's own 8 KB of a staging area — publishes its 32 row counts (write-through bytes,
+// row-major: a row's counts of all tiles are contiguous), adds its total to its band's word, arrives on the band's counter and leaves.  The band's LAST arriver
+// stays: it publishes {aggregate} for the band, looks back over the bands above (decoupled look-back: one lane per predecessor, an {inclusive prefix} ends the
+// walk — the only wait in the launch, for bands whose tiles were all dispatched earlier), publishes the band's {inclusive prefix}, builds the band's offset tables
+// from the 32 x ntc count matrix in LDS and moves the band's staged records (a few thousand) to their places in the output.  The gathers of all bands but the
+// last few overlap other tiles' detection.  The last tile of the launch hands the control block back zeroed.
+constexpr int kFuseMaxTiles = 64;             // tile columns the fused write serves (frames up to 4096 px wide): the band tables fit the detect phase's LDS
+constexpr int kStagePerTile = TW * TH;        // staged records per tile (u32 each): every pixel a corner
 struct RawFuse {
   uint8_t* rowcnt; int ntcp;                    // [nby * TH rows][ntcp] corner counts per (row, tile); ntcp = ntc rounded up to 8
-  uint32_t *arrive, *tot;                       // per band: tiles arrived, corners
-  unsigned long long* state;                    // per band: flag << 32 | value; flag 1: value = the band's corners, flag 2: value = corners of this band and all above
-  uint32_t* finished;                           // tiles that are done with the control block
+  uint32_t* stage;                              // [nby * ntc tiles][kStagePerTile] packed records
+  // per band, kBandStride words apart (returning atomics on one cache line retire one after the other, ~11 ns each: with the bands' counters side by side the
+  // 4 080 arrivals of a 4K frame alone took longer than the detection): [0] corners << 32 | tiles arrived — ONE atomic per tile; [1] flag << 32 | value; flag 1:
+  // value = the band's corners, flag 2: value = corners of this band and all above
+  unsigned long long* band;
+  uint32_t* finished;                           // bands whose gather is done
   uint32_t* total; int32_t* out_rc; int32_t* out_scores; int capacity;
   unsigned* err;                                // the sticky device error word (common.hpp)
 };
 constexpr unsigned kFuseSpinLimit = 1u << 22;
+constexpr int kBandStride = 32;   // 256 bytes
 __device__ __forceinline__ uint32_t ld_u32_sc1(const uint32_t* p) { return __hip_atomic_load((uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long ld_u64_sc1(const unsigned long long* p) { return __hip_atomic_load((unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -340,26 +347,58 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
   if (MODE == VPP_FAST9_BLOCKWISE) return;
   wave_fence_lds();
   if constexpr (FUSED) {
-    __shared__ uint32_t wtot[4], s_last, s_incl, s_btot, s_reset, rowbase[TH];
+    __shared__ uint32_t wtot[4], s_last, s_excl;
     const int band = blockIdx.y, bx = blockIdx.x;
+    // ---- this tile's counts, and its records staged tile-major (rows in order, a row's corners in column order)
     uint32_t nrow = 0;
     if (lane < TH / 4) {   // rows past the frame's last one have no corners: their counts are written all the same (nobody reads a stale byte)
       nrow = (uint32_t)__popcll(words[wv][lane]);
       __hip_atomic_store(fz.rowcnt + (size_t)(band * TH + wv * (TH / 4) + lane) * fz.ntcp + bx, (uint8_t)nrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    nrow += __shfl_xor(nrow, 1); nrow += __shfl_xor(nrow, 2); nrow += __shfl_xor(nrow, 4);
-    if (lane == 0) wtot[wv] = nrow;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's counts have been performed (write-through) before the workgroup arrives
+    uint32_t inc = nrow;   // inclusive scan over the wave's 8 rows (lanes 0 .. 7)
+    { uint32_t t = __shfl_up(inc, 1); if (lane >= 1) inc += t; t = __shfl_up(inc, 2); if (lane >= 2) inc += t; t = __shfl_up(inc, 4); if (lane >= 4) inc += t; }
+    if (lane == TH / 4 - 1) wtot[wv] = inc;
     __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wv; w++) wbase += wtot[w];
+    uint32_t* stg = fz.stage + (size_t)(band * ntc + bx) * kStagePerTile;
+#pragma unroll 1
+    for (int j = 0; j < TH / 4; j++) {
+      const unsigned long long w = words[wv][j];
+      const uint32_t rb = wbase + __shfl(inc - nrow, j);   // records of the tile's rows above this one
+      if ((w >> lane) & 1ull)
+        __hip_atomic_store(stg + rb + (uint32_t)__popcll(w & ((1ull << lane) - 1ull)), ((uint32_t)fsc[wv][j * TW + lane] << 16) | (uint32_t)((wv * (TH / 4) + j) << 6) | (uint32_t)lane,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's counts and records have been performed (write-through) before the workgroup arrives
+    __syncthreads();
+    unsigned long long* const bctl = fz.band + (size_t)band * kBandStride;
     if (threadIdx.x == 0) {
       const uint32_t ttot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-      if (ttot) { (void)__hip_atomic_fetch_add(&fz.tot[band], ttot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // performed before the arrival (another channel)
-      s_last = __hip_atomic_fetch_add(&fz.arrive[band], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)ntc - 1u ? 1u : 0u;
+      const unsigned long long old = __hip_atomic_fetch_add(bctl, ((unsigned long long)ttot << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (uint32_t)old == (uint32_t)ntc - 1u ? 1u : 0u;
+      s_excl = (uint32_t)(old >> 32) + ttot;   // (the last arriver's: the band's corners)
     }
     __syncthreads();
-    if (s_last && wv == 0) {   // the band is complete: its prefix, by decoupled look-back over the bands above
-      const uint32_t btot = ld_u32_sc1(&fz.tot[band]);
-      if (lane == 0 && band > 0) __hip_atomic_store(&fz.state[band], (1ull << 32) | btot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!s_last) return;
+    // ---- the band is complete; this workgroup places its records.  First the corners of the bands above, by decoupled look-back.
+    const uint32_t btot = s_excl;
+    __syncthreads();
+    // Everything this workgroup will read is requested NOW, before the look-back's wait: the first 64 staged records of the wave's tiles (wv, wv + 4, ...) and
+    // this thread's share of the count matrix — one memory round trip for the whole gather instead of one per step (the gather of the launch's last band is its tail)
+    constexpr int kTilesPerWave = kFuseMaxTiles / 4;
+    uint32_t rec[kTilesPerWave];
+#pragma unroll
+    for (int u = 0; u < kTilesPerWave; u++) {
+      const int t = wv + 4 * u;
+      rec[u] = t < ntc ? ld_u32_sc1(fz.stage + (size_t)(band * ntc + t) * kStagePerTile + lane) : 0u;   // (lanes past the tile's count read stale words and drop them)
+    }
+    static_assert(TH * (kFuseMaxTiles / 8) == 256, "one 8-byte word of the count matrix per thread");
+    unsigned long long cword = 0;
+    { const int j = threadIdx.x / (kFuseMaxTiles / 8), q = threadIdx.x - j * (kFuseMaxTiles / 8);
+      if (q < fz.ntcp / 8) cword = ld_u64_sc1((const unsigned long long*)(fz.rowcnt + (size_t)(band * TH + j) * fz.ntcp) + q); }   // (bytes past ntc: zeroed with the control block, never written)
+    if (wv == 0) {
+      if (lane == 0 && band > 0) __hip_atomic_store(bctl + 1, (1ull << 32) | btot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       uint32_t excl = 0;
       bool gave_up = false;
       for (int b = band - 1; b >= 0 && !gave_up;) {
@@ -367,7 +406,7 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
         unsigned long long st = 2ull << 32;   // lanes past band 0: an inclusive prefix of 0
         if (mb >= 0) {
           unsigned spin = 0;
-          while (((st = ld_u64_sc1(&fz.state[mb])) >> 32) == 0ull && ++spin < kFuseSpinLimit) __builtin_amdgcn_s_sleep(1);
+          while (((st = ld_u64_sc1(fz.band + (size_t)mb * kBandStride + 1)) >> 32) == 0ull && ++spin < kFuseSpinLimit) __builtin_amdgcn_s_sleep(2);
           if (spin >= kFuseSpinLimit) gave_up = true;
         }
         gave_up = __ballot(gave_up) != 0ull;
@@ -382,54 +421,71 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
       }
       if (gave_up && lane == 0 && fz.err) __hip_atomic_fetch_or(fz.err, (unsigned)kDevErrFastFuse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (lane == 0) {
-        __hip_atomic_store(&fz.state[band], (2ull << 32) | (unsigned long long)(excl + btot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(bctl + 1, (2ull << 32) | (unsigned long long)(excl + btot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (band == (int)gridDim.y - 1) *fz.total = excl + btot;
+        s_excl = excl;
       }
     }
-    if (threadIdx.x == 0) {   // every tile of the band: the band's inclusive prefix and its total
-      unsigned long long st;
-      unsigned spin = 0;
-      while (((st = ld_u64_sc1(&fz.state[band])) >> 32) != 2ull && ++spin < kFuseSpinLimit) __builtin_amdgcn_s_sleep(1);
-      if (spin >= kFuseSpinLimit && fz.err) __hip_atomic_fetch_or(fz.err, (unsigned)kDevErrFastFuse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      s_incl = (uint32_t)st; s_btot = ld_u32_sc1(&fz.tot[band]);
-    }
-    __syncthreads();
-    if (wv == 0) {   // lane j: corners of row j of the band in all tiles, and in the tiles left of this one
-      uint32_t rt = 0, left = 0;
-      if (lane < TH) {
-        const unsigned long long* row = (const unsigned long long*)(fz.rowcnt + (size_t)(band * TH + lane) * fz.ntcp);
-        for (int q = 0; q < fz.ntcp / 8; q++) {
-          const unsigned long long v = ld_u64_sc1(row + q);   // (bytes past ntc were zeroed with the control block and are never written)
-          const int nl = bx - 8 * q;                           // tiles of this group that lie left of bx
-          const unsigned long long lm = nl >= 8 ? ~0ull : (nl <= 0 ? 0ull : (1ull << (8 * nl)) - 1ull), vl = v & lm;
-          rt = __builtin_amdgcn_sad_u8((uint32_t)v, 0u, rt); rt = __builtin_amdgcn_sad_u8((uint32_t)(v >> 32), 0u, rt);
-          left = __builtin_amdgcn_sad_u8((uint32_t)vl, 0u, left); left = __builtin_amdgcn_sad_u8((uint32_t)(vl >> 32), 0u, left);
-        }
-      }
-      uint32_t inc = rt;   // inclusive scan of the rows' totals over lanes 0 .. 31
-#pragma unroll
-      for (int d = 1; d < TH; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-      if (lane < TH) rowbase[lane] = s_incl - s_btot + (inc - rt) + left;
-    }
+    // ---- the band's tables (the detect phase's LDS is free now: the count matrix and the two prefix tables take its place)
+    static_assert(sizeof(tile) >= TH * kFuseMaxTiles && sizeof(fsc) >= TH * kFuseMaxTiles * 2 && sizeof(cand) >= TH * kFuseMaxTiles * 2, "the band tables overlay the detect phase's LDS");
+    __syncthreads();   // (every wave is done with words / fsc)
+    uint8_t (*cnt)[kFuseMaxTiles] = (uint8_t (*)[kFuseMaxTiles])tile;       // corners of (row, tile)
+    uint16_t (*left)[kFuseMaxTiles] = (uint16_t (*)[kFuseMaxTiles])fsc;     // corners of the row in the tiles left of this one
+    uint16_t (*top)[kFuseMaxTiles] = (uint16_t (*)[kFuseMaxTiles])cand;     // corners of the tile in the rows above this one (= the record's place in the tile's staging block)
+    __shared__ uint32_t rowbase[TH], rowtot[TH];
+    { const int j = threadIdx.x / (kFuseMaxTiles / 8), q = threadIdx.x - j * (kFuseMaxTiles / 8);
+      *(unsigned long long*)&cnt[j][8 * q] = cword; }
     __syncthreads();
 #pragma unroll 1
-    for (int j = 0; j < TH / 4; j++) {   // the tile's records, a wave per row: lane = column
-      const unsigned long long w = words[wv][j];
-      if ((w >> lane) & 1ull) {
-        const uint32_t k = rowbase[wv * (TH / 4) + j] + (uint32_t)__popcll(w & ((1ull << lane) - 1ull));
-        if ((int)k < fz.capacity) {
-          fz.out_rc[2 * (size_t)k] = r0 + wv * (TH / 4) + j; fz.out_rc[2 * (size_t)k + 1] = c0 + lane;
-          if (fz.out_scores) fz.out_scores[k] = (int32_t)fsc[wv][j * TW + lane] - 1;
+    for (int jj = 0; jj < TH / 4; jj++) {   // a wave per row: exclusive scan along the tiles
+      const int j = wv * (TH / 4) + jj;
+      uint32_t carry = 0;
+      for (int t0 = 0; t0 < ntc; t0 += 64) {
+        const int t = t0 + lane;
+        const uint32_t c = t < ntc ? cnt[j][t] : 0u;
+        uint32_t sc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(sc, d); if (lane >= d) sc += u; }
+        if (t < ntc) left[j][t] = (uint16_t)(carry + sc - c);
+        carry += __shfl(sc, 63);
+      }
+      if (lane == 0) rowtot[j] = carry;
+    }
+    if ((int)threadIdx.x < ntc) {   // a lane per tile: down its rows
+      uint32_t acc = 0;
+#pragma unroll 4
+      for (int j = 0; j < TH; j++) { top[j][threadIdx.x] = (uint16_t)acc; acc += cnt[j][threadIdx.x]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t acc = s_excl; for (int j = 0; j < TH; j++) { rowbase[j] = acc; acc += rowtot[j]; } }
+    __syncthreads();
+    // ---- move the records: a wave takes tiles wv, wv + 4, ... (their first 64 records are in registers already)
+#pragma unroll
+    for (int u = 0; u < kTilesPerWave; u++) {
+      const int t = wv + 4 * u;
+      if (t >= ntc) break;
+      const int tt = (int)top[TH - 1][t] + (int)cnt[TH - 1][t];   // the tile's records
+      for (int i0 = 0; i0 < tt; i0 += 64) {
+        const int idx = i0 + lane;
+        if (idx < tt) {
+          const uint32_t x = i0 == 0 ? rec[u] : ld_u32_sc1(fz.stage + (size_t)(band * ntc + t) * kStagePerTile + idx);
+          const int j = (x >> 6) & (TH - 1), col = x & 63;
+          const uint32_t k = rowbase[j] + left[j][t] + (uint32_t)(idx - (int)top[j][t]);
+          if ((int)k < fz.capacity) {
+            fz.out_rc[2 * (size_t)k] = band * TH + j; fz.out_rc[2 * (size_t)k + 1] = t * TW + col;
+            if (fz.out_scores) fz.out_scores[k] = (int32_t)(x >> 16) - 1;
+          }
         }
       }
     }
-    // ---- hand the control block back: the launch's last tile zeroes it (every other tile has read what it needed)
-    if (threadIdx.x == 0) s_reset = __hip_atomic_fetch_add(fz.finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1u ? 1u : 0u;
+    // ---- hand the control block back: the launch's last band zeroes it (every band has read what it needed of the bands above)
     __syncthreads();
-    if (s_reset) {
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(fz.finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1u ? 2u : 1u;
+    __syncthreads();
+    if (s_last == 2u) {
       for (int b = threadIdx.x; b < (int)gridDim.y; b += 256) {
-        __hip_atomic_store(&fz.arrive[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&fz.tot[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&fz.state[b], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fz.band + (size_t)b * kBandStride, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fz.band + (size_t)b * kBandStride + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (threadIdx.x == 0) __hip_atomic_store(fz.finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -852,11 +908,18 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
   const bool raw2 = impl == 2 && mode == VPP_FAST9_RAW;   // the RAW instance of the two-phase kernel always writes its counts
   const size_t off_rc = off_uc + align_up((size_t)ngroups * 4, 256), off_tt = off_rc + align_up(raw2 ? (size_t)nwords : 0, 256);
   // RAW in ONE launch (round 6): the detect kernel writes the ordered list itself (fast9_detect2_kernel<.., RAW, true>); its control block + row counts follow the rest
-  const bool fused_write = raw2 && ntc <= 1024 && tuning("fast9.raw_fused", 1);
+  // OFF by default — measured (round 6, 4K frame with 183 k corners, same box, synchronous / 50 recorded calls): two launches 41.7 / 29.3 us per call; this form 98 us
+  // with every tile waiting for its band's prefix, 64 / 54 us as stage + band gather with the bands' counters side by side, 51 / 38 us with one atomic per tile on
+  // words 256 bytes apart, 47 / 35 us (incl. a 4.5 us fill node when recorded) with all of the gather's loads requested up front.  The last band's gather — one
+  // workgroup, a look-back, a table build and ~2 700 records — is a tail as long as the write launch it replaces, and every tile pays a returning atomic before it
+  // frees its slot.  Kept, parity-tested (tests/test_gpu_algos.py), as tuning fast9.raw_fused = 1.
+  const bool fused_write = raw2 && ntc <= kFuseMaxTiles && tuning("fast9.raw_fused", 0);
   const int ntcp = (ntc + 7) / 8 * 8;
   const size_t off_fz = off_tt + align_up(raw2 ? (size_t)nby * ntc * 2 : 0, 256);
-  const size_t fz_ctl = 256 + align_up((size_t)nby * 4, 256) * 2 + align_up((size_t)nby * 8, 256), fz_bytes = fused_write ? fz_ctl + align_up((size_t)nby * TH * ntcp, 256) : 0;
-  const size_t total_bytes = off_fz + fz_bytes;
+  // [control block | row counts] are kept zeroed between calls; the staging area behind them (8 KB per tile, touched only where there are corners) is not
+  const size_t fz_ctl = 256 + (size_t)nby * kBandStride * 8, fz_bytes = fused_write ? fz_ctl + align_up((size_t)nby * TH * ntcp, 256) : 0;
+  const size_t off_stage = off_fz + fz_bytes;
+  const size_t total_bytes = off_stage + (fused_write ? (size_t)nby * ntc * kStagePerTile * 4 : 0);
   int rc = g_scratch.ensure(total_bytes, st);
   if (rc != VPP_OK) return rc;
   uint8_t* base = (uint8_t*)g_scratch.p;
@@ -893,10 +956,9 @@ static int fast9_enqueue(const vpp_image_desc* src, int th, const vpp_image_desc
     uint8_t* q = base + off_fz;
     RawFuse fz{};
     fz.finished = (uint32_t*)q; q += 256;
-    fz.arrive = (uint32_t*)q; q += align_up((size_t)nby * 4, 256);
-    fz.tot = (uint32_t*)q; q += align_up((size_t)nby * 4, 256);
-    fz.state = (unsigned long long*)q; q += align_up((size_t)nby * 8, 256);
+    fz.band = (unsigned long long*)q; q += (size_t)nby * kBandStride * 8;
     fz.rowcnt = q; fz.ntcp = ntcp;
+    fz.stage = (uint32_t*)(base + off_stage);
     fz.total = d_total; fz.out_rc = out_rc; fz.out_scores = out_scores; fz.capacity = capacity; fz.err = device_error_word();
     if (compat == VPP_FAST9_REFERENCE) fast9_detect2_kernel<true, VPP_FAST9_RAW, true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot, fz);
     else fast9_detect2_kernel<false, VPP_FAST9_RAW, true><<<grid, 256, 0, st>>>(A, M, mask ? 1 : 0, th, F, bitmap, ntc, blkkey, bs_magic, nbc, rowcnt, tiletot, fz);
