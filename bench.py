@@ -633,6 +633,14 @@ def main():
                                     "form": "vpp_box_filter per 4K frame, recorded: held back and recorded as 64-frame launches; one_launch_per_call: that off; deferred_eager: vpp_box_filter_deferred, no graph"}
         legs = {}
         px = extras.get("pyrlk") if isinstance(extras.get("pyrlk"), dict) else {}
+        # the reference's LITERAL call form: its opaque 5 x 5 mean lambdas compiled single-source (benchmarks/lambda_call_bench.cc), one launch per 4K frame
+        lc = px.get("lambda_call") or {}
+        if "int_5x5" in lc:
+            roof_c["lambda_call"] = {"int_5x5": pick(lc["int_5x5"], "literal_us", "literal_frac", "nbh_read_only_us", "nbh_read_only_frac", "ops_box_mean_us"),
+                                     "vuchar3_5x5": pick(lc["vuchar3_5x5"], "literal_us", "literal_frac", "nbh_read_only_us", "nbh_read_only_frac", "ops_box_mean_us"),
+                                     "form": "box_5x5_filter2.cc:71-81 / box_filter.cc:23-32 lambdas, one launch per rotating 4K frame, host cost incl."}
+        elif "error" in lc:
+            roof_c["lambda_call"] = {"error": str(lc["error"])[:120]}
         if "tracks_per_s" in px:
             legs["pyrlk_1080p_10k"] = {"tracks_per_s": round(px["tracks_per_s"]), "ms_per_frame": rnd(px["ms_per_frame"]), "keypoints_per_rank": px.get("keypoints_per_rank"),
                                        "roofline": pick(px.get("roofline") or {}, "bound", "kernel", "frac", "source", "stale")}
@@ -656,6 +664,8 @@ def main():
             ve = px.get("video_extruder_4k") or {}
             if "ms_per_update_median_steady" in ve:
                 legs["semi_dense_flow_4k"]["tracker_ms_per_update_median_steady"] = rnd(ve["ms_per_update_median_steady"])
+            if "frames_per_s" in ve:   # ONE tracker rate: video_extruder_update on resident gray frames, frames 3 .. end incl. detection frames and the final wait
+                legs["semi_dense_flow_4k"]["tracker_frames_per_s"] = round(ve["frames_per_s"])
         if "flow_strips_4k" in px:
             legs["flow_strips_4k"] = pick(px["flow_strips_4k"], "ms_per_pair", "pairs_per_s", "ranks", "error")
         ig = px.get("ingest_4k") or {}

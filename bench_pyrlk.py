@@ -378,6 +378,16 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
             res["video_extruder_4k"].pop("per_update_ms", None)
         except Exception as e:  # noqa: BLE001
             res["video_extruder_4k"] = {"error": str(e)}
+    stage("lambda_call_bench")
+    # the reference's literal opaque lambdas (benchmarks/box_5x5_filter2.cc:71-81, examples/box_filter.cc:23-32) compiled single-source: us per 4K frame and fraction
+    exe = os.path.join(ROOT, "benchmarks", "lambda_call_bench")
+    if rank == 0 and os.path.exists(exe):
+        import json, subprocess
+        try:
+            out = subprocess.run([exe, "200"], capture_output=True, text=True, timeout=300)
+            res["lambda_call"] = json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 else {"error": (out.stderr or out.stdout)[-300:], "rc": out.returncode}
+        except Exception as e:  # noqa: BLE001
+            res["lambda_call"] = {"error": str(e)}
     return res
 
 

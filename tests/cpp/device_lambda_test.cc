@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <vector>
 
 #include <vpp/vpp.hh>
 #include "../../oracle/oracle.h"   // the CPU oracle: the checker of the 5 x 5 cases below (test infrastructure, never the product path)
@@ -275,6 +276,40 @@ static void test_writes_through_a_neighbourhood() {
 // The 5 x 5 mean lambdas (benchmarks/box_5x5_filter2.cc:71-81 on int, examples/box_filter.cc:23-32 on vuchar3) against the CPU ORACLE's box filter — not only
 // against this product's own host engine: global-tap kernel and LDS-tile kernel, 4K and a ragged small shape.
 template <class V> static vpp_image_desc host_desc_of(image2d<V>& im) { (void)im(0, 0); return im.host_desc(); }   // (the host accessor brings the host pixels up to date)
+// The register window (4-byte pixels under `_nbh_read_only`): constant-trip window bodies (taps index registers), the widest reach it serves (9 x 9), float pixels,
+// ragged widths (the row's last chunk pixel by pixel), heights cut by the 8-row marches and the 32-row workgroups, a view at a 4-pixel-aligned column and one at an
+// odd column (unaligned: falls back to the global taps) — against the host engine of the same headers.
+template <class V, class MK> static void window_case(int nr, int nc, MK make) {
+  image2d<V> S(nr, nc, _border = 4), D(S.domain()), E(S.domain()), H(S.domain()), G(S.domain());
+  for (auto p : S.domain_with_border()) S(p) = make();
+  auto k5 = [] (V& out, auto nbh) { V s = V(0); for (int i = -2; i <= 2; i++) for (int j = -2; j <= 2; j++) s = V(s + nbh(i, j) * V(i * 5 + j + 13)); out = s; };
+  auto k9 = [] (V& out, auto nbh) { V s = V(0); for (int i = -4; i <= 4; i += 2) for (int j = -4; j <= 4; j++) s = V(s + nbh(i, j) * V(i * 9 + j + 41)); out = s; };
+  pixel_wise(D, relative_access(S))(_nbh_read_only) | k5;
+  pixel_wise(H, relative_access(S))(_host) | k5;
+  if (!same_pixels(D, H)) { std::fprintf(stderr, "window_case 5x5 %d x %d\n", nr, nc); std::exit(1); }
+  pixel_wise(E, relative_access(S))(_nbh_read_only) | k9;
+  pixel_wise(G, relative_access(S))(_host) | k9;
+  if (!same_pixels(E, G)) { std::fprintf(stderr, "window_case 9x9 %d x %d\n", nr, nc); std::exit(1); }
+  if (nr > 20 && nc > 40) {
+    for (int c0 : {8, 7}) {
+      image2d<V> D2(S.domain()), H2(S.domain());
+      fill(D2, V(make())); copy(D2, H2);
+      const box2d win(vint2(3, c0), vint2(nr - 4, nc - 6));
+      auto sd = D2 | win, sh = H2 | win, ss = S | win;
+      pixel_wise(sd, relative_access(ss))(_nbh_read_only) | k5;
+      pixel_wise(sh, relative_access(ss))(_host) | k5;
+      if (!same_pixels(D2, H2)) { std::fprintf(stderr, "window_case view at column %d, %d x %d\n", c0, nr, nc); std::exit(1); }
+    }
+  }
+}
+static void test_register_window() {
+  for (auto shape : {std::pair<int, int>{64, 256}, {65, 257}, {33, 1030}, {7, 5}, {1, 1}, {8, 4}, {100, 300}, {31, 255}}) {
+    window_case<int>(shape.first, shape.second, [] { return int(rng() % 1000); });
+    window_case<float>(shape.first, shape.second, [] { return float(rng() % 512); });
+    window_case<unsigned int>(shape.first, shape.second, [] { return (unsigned int)(rng() % 4096); });
+  }
+}
+
 static void test_box_lambdas_against_the_oracle() {
   for (auto shape : {std::pair<int, int>{2160, 3840}, {37, 61}}) {
     {
@@ -372,48 +407,75 @@ static void time_4k() {
   const double tag = (seconds() - t0) / K;
   std::printf("4K int add, back-to-back calls (at most 2 queued): lambda %.2f us, ops::add %.2f us (ratio %.2f)\n", lam * 1e6, tag * 1e6, lam / tag);
   for (int r = 0; r < 2160; r += 97) for (int c = 0; c < 3840; c += 89) CHECK(A(r, c) == B(r, c) + C(r, c));
-  // the 5x5 box of benchmarks/box_5x5_filter2.cc:71-81 as the opaque lambda against ops::box_mean<5, 5> (the hand-written K2i kernel), 4K int
+  // the 5x5 box of benchmarks/box_5x5_filter2.cc:71-81 as the opaque lambda against ops::box_mean<5, 5> (the hand-written K2i kernel), 4K int.  The calls rotate
+  // over NS frame sets (NS x 66 MB: nothing survives in the 256 MiB Infinity Cache between two uses), like the bench's one-frame-per-call legs.
+  const int NS = 10;
   {
-    image2d<int> S(2160, 3840, _border = 2), D(S.domain()), T(S.domain());
-    for (auto p : S.domain_with_border()) S(p) = int(rng() % 1000);
-    vpp_pixel_wise(D, S);
-    pixel_wise(T, relative_access(S)) | ops::box_mean<5, 5>();
-    CHECK(same_pixels(D, T));
+    std::vector<image2d<int>> S, D, T, W;
+    for (int q = 0; q < NS; q++) { S.emplace_back(2160, 3840, _border = 2); D.emplace_back(S[q].domain()); }
+    T.emplace_back(S[0].domain()); W.emplace_back(S[0].domain());
+    for (auto p : S[0].domain_with_border()) S[0](p) = int(rng() % 1000);
+    for (int q = 1; q < NS; q++) copy(S[0], S[q]);   // (the same pixels in distinct buffers: one result to check, no cache reuse)
+    auto body = [] (int& b, auto a) {
+      int sum = 0;
+      for (int i = -2; i <= 2; i++)
+      for (int j = -2; j <= 2; j++)
+        sum += a(i, j);
+      b = sum / 25;
+    };
+    for (int q = 0; q < NS; q++) vpp_pixel_wise(D[q], S[q]);
+    pixel_wise(T[0], relative_access(S[0])) | ops::box_mean<5, 5>();
+    pixel_wise(W[0], relative_access(S[0]))(_nbh_read_only) | body;
+    CHECK(same_pixels(D[0], T[0]) && same_pixels(D[NS - 1], T[0]) && same_pixels(W[0], T[0]));
+    vpp_sync(nullptr);
     t0 = seconds();
-    for (int k = 0; k < K; k++) vpp_pixel_wise(D, S);
+    for (int k = 0; k < K; k++) vpp_pixel_wise(D[k % NS], S[k % NS]);
     vpp_sync(nullptr);
     const double blam = (seconds() - t0) / K;
     t0 = seconds();
-    for (int k = 0; k < K; k++) pixel_wise(T, relative_access(S)) | ops::box_mean<5, 5>();
+    for (int k = 0; k < K; k++) pixel_wise(D[k % NS], relative_access(S[k % NS]))(_immediate) | ops::box_mean<5, 5>();
     vpp_sync(nullptr);
     const double btag = (seconds() - t0) / K;
-    std::printf("4K int box 5x5, back-to-back calls (at most 2 queued): lambda %.2f us, ops::box_mean<5,5> %.2f us (ratio %.2f)\n", blam * 1e6, btag * 1e6, blam / btag);
+    // the same body under `_nbh_read_only`: 4-byte pixels take the register window (pixel_wise_device.hh: pixel_wise_window_kernel)
+    t0 = seconds();
+    for (int k = 0; k < K; k++) pixel_wise(D[k % NS], relative_access(S[k % NS]))(_nbh_read_only) | body;
+    vpp_sync(nullptr);
+    const double bwin = (seconds() - t0) / K;
+    CHECK(same_pixels(D[1], T[0]));
+    std::printf("4K int box 5x5, one launch per call over %d rotating frame sets: lambda %.2f us, lambda with _nbh_read_only (register window) %.2f us, ops::box_mean<5,5> %.2f us (ratio %.2f)\n", NS, blam * 1e6, bwin * 1e6, btag * 1e6, blam / btag);
+    std::printf("LAMBDA_JSON {\"int_5x5\": {\"literal_us\": %.2f, \"nbh_read_only_us\": %.2f, \"ops_box_mean_us\": %.2f}}\n", blam * 1e6, bwin * 1e6, btag * 1e6);
   }
-  // the same on vuchar3 (examples/box_filter.cc:23-32 body; BASELINE configs[1]'s pixel type)
+  // the same on vuchar3 (examples/box_filter.cc:23-32 body; BASELINE configs[1]'s pixel type), NS rotating frame sets of 50 MB
   {
-    image2d<vuchar3> S(2160, 3840, _border = 2), D(S.domain()), T(S.domain());
-    for (auto p : S.domain_with_border()) S(p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
+    std::vector<image2d<vuchar3>> S, D, T;
+    for (int q = 0; q < NS; q++) { S.emplace_back(2160, 3840, _border = 2); D.emplace_back(S[q].domain()); }
+    T.emplace_back(S[0].domain());
+    for (auto p : S[0].domain_with_border()) S[0](p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
+    for (int q = 1; q < NS; q++) copy(S[0], S[q]);
     auto k3 = [] (vuchar3& out, auto nbh) {
       vint3 sum = vint3::Zero();
       for (int i = -2; i <= 2; i++) for (int j = -2; j <= 2; j++) sum += nbh(i, j).template cast<int>();
       out = (sum / 25).template cast<unsigned char>();
     };
-    pixel_wise(D, relative_access(S)) | k3;
-    pixel_wise(T, relative_access(S)) | ops::box_mean<5, 5>();
-    CHECK(same_pixels(D, T));
+    for (int q = 0; q < NS; q++) pixel_wise(D[q], relative_access(S[q])) | k3;
+    pixel_wise(T[0], relative_access(S[0])) | ops::box_mean<5, 5>();
+    CHECK(same_pixels(D[0], T[0]) && same_pixels(D[NS - 1], T[0]));
+    vpp_sync(nullptr);
     t0 = seconds();
-    for (int k = 0; k < K; k++) pixel_wise(D, relative_access(S)) | k3;
+    for (int k = 0; k < K; k++) pixel_wise(D[k % NS], relative_access(S[k % NS])) | k3;
     vpp_sync(nullptr);
     const double blam = (seconds() - t0) / K;
     t0 = seconds();
-    for (int k = 0; k < K; k++) pixel_wise(T, relative_access(S)) | ops::box_mean<5, 5>();
+    for (int k = 0; k < K; k++) pixel_wise(D[k % NS], relative_access(S[k % NS]))(_immediate) | ops::box_mean<5, 5>();
     vpp_sync(nullptr);
     const double btag = (seconds() - t0) / K;
     t0 = seconds();
-    for (int k = 0; k < K; k++) pixel_wise(D, relative_access(S))(_nbh_read_only) | k3;
+    for (int k = 0; k < K; k++) pixel_wise(D[k % NS], relative_access(S[k % NS]))(_nbh_read_only) | k3;
     vpp_sync(nullptr);
     const double bro = (seconds() - t0) / K;
-    std::printf("4K vuchar3 box 5x5, back-to-back calls (at most 2 queued): lambda %.2f us, lambda with _nbh_read_only (LDS tile) %.2f us, ops::box_mean<5,5> %.2f us (ratio %.2f)\n", blam * 1e6, bro * 1e6, btag * 1e6, blam / btag);
+    CHECK(same_pixels(D[1], T[0]));
+    std::printf("4K vuchar3 box 5x5, one launch per call over %d rotating frame sets: lambda %.2f us, lambda with _nbh_read_only (LDS tile) %.2f us, ops::box_mean<5,5> %.2f us (ratio %.2f)\n", NS, blam * 1e6, bro * 1e6, btag * 1e6, blam / btag);
+    std::printf("LAMBDA_JSON {\"vuchar3_5x5\": {\"literal_us\": %.2f, \"nbh_read_only_us\": %.2f, \"ops_box_mean_us\": %.2f}}\n", blam * 1e6, bro * 1e6, btag * 1e6);
   }
   // block_wise on the device: 16 x 16 block sums (one wave per block) and 4 x 4 (one lane per block)
   for (int bs : {16, 4}) {
@@ -436,10 +498,12 @@ static void time_4k() {
 int main(int argc, char** argv) {
   std::setvbuf(stdout, nullptr, _IOLBF, 0);
 #define STEP(f) do { std::fprintf(stderr, "[device_lambda_test] " #f "\n"); f(); } while (0)
+  if (argc > 1 && !std::strcmp(argv[1], "timeonly")) { STEP(time_4k); std::printf("device_lambda_test ok\n"); return 0; }   // bench.py's lambda_call leg
   STEP(test_reference_bodies);
   STEP(test_device_equals_host);
   STEP(test_block_wise_device);
   STEP(test_neighbourhood_tiles);
+  STEP(test_register_window);
   STEP(test_writes_through_a_neighbourhood);
   STEP(test_box_lambdas_against_the_oracle);
   STEP(test_held_back_calls_and_lambdas_keep_their_order);

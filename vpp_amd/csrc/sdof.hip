@@ -516,6 +516,7 @@ struct RoundArrays { Cell* pre; Cell* B[2]; uint32_t* Q[2]; uint32_t* qflag[2]; 
 constexpr int kSubCounters = 64, kSubStride = 32;   // words
 __device__ __forceinline__ void raise_barrier_timeout(const RoundArrays& a) {
   a.ctl->pad = 1;
+  if (a.skip) __hip_atomic_store(a.skip, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // whatever an earlier sweep said about "no candidates" is void: no later sweep skips on it
   if (a.err) __hip_atomic_fetch_or(a.err, (unsigned)kDevErrSweepBarrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ unsigned g_round_stats[4];   // [0] rounds, [1] jobs, [2] jobs evaluated, [3] changes
@@ -1374,7 +1375,9 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
           const int grid = std::min(tuning("sdof.rounds_grid", 256), (cells + kJobsPerGroup - 1) / kJobsPerGroup);
           // consecutive ids for this scale's sweeps (a.skip): sweep Ki + 1 skips only on the word sweep Ki wrote
           static std::atomic<unsigned> g_sweep_seq{1};
-          const unsigned sweep_base = g_sweep_seq.fetch_add((unsigned)propagation + 1u, std::memory_order_relaxed);
+          unsigned sweep_base = g_sweep_seq.fetch_add((unsigned)propagation + 1u, std::memory_order_relaxed);
+          if (sweep_base + (unsigned)propagation + 1u < sweep_base || sweep_base == 0u)   // the counter wrapped: 0 means "nothing to skip on" in the word, never an id
+            sweep_base = g_sweep_seq.fetch_add((unsigned)propagation + 1u, std::memory_order_relaxed);
           for (int Ki = 0; Ki < propagation; Ki++) {
             if (fused_sweeps) {   // one launch per sweep: every workgroup classifies its tile of cells and runs round 0 on them, the last one to finish runs the rest
               const int tiles = ((NI + kSweepTile - 1) / kSweepTile) * ((NJ + kSweepTile - 1) / kSweepTile);

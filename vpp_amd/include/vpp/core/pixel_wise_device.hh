@@ -234,6 +234,111 @@ __global__ __launch_bounds__(256) void pixel_wise_tile_kernel(F f, int r0, int c
   }
 }
 
+// ---- neighbourhoods out of a register window (round 6: dword pixel types under `_nbh_read_only`) -----------------------------------------------------------
+// For 4-byte pixels the LDS tile LOSES to the global taps (39 vs 27 us on the 4K `int` 5 x 5 mean: dword taps already come out of L1 / L2 near the streaming
+// rate, the staging pass and its barrier only add) — but 25 taps per pixel are still 25 load instructions per pixel.  Here a lane owns 4 consecutive pixels of a
+// row and marches DOWN kWinRows rows: it keeps the rows r - 4 .. r + 4 of the columns c - 4 .. c + 7 (three 16-byte chunks per row) in registers, loads ONE new
+// row per output row and shifts the window (register renaming once the row loop is unrolled); the callable's taps index that window with constants once its
+// window loops are unrolled, so they cost no instruction at all, and the window entries a callable never reads are never loaded (dead loads: a 5 x 5 body keeps
+// 5 rows x 3 chunks live).  12 B of 16-byte loads per pixel instead of 100 B of dword loads.  READ-ONLY by type (taps are returned by value): taken only under
+// `_nbh_read_only` (reach <= 4, no writes through the neighbourhood), for one neighbourhood range of a 4-byte pixel type on a 16-byte aligned image.
+constexpr int kWinRows = 8;
+template <class V> struct win_regs { V px[2 * kTileH + 1][12]; };   // rows r - 4 .. r + 4, columns c - 4 .. c + 7 of the lane's 4-pixel chunk at (r, c)
+template <class V> struct nbh_win_px {
+  const win_regs<V>* w; int i;
+  __device__ __forceinline__ V operator()(int dr, int dc) const { return w->px[dr + kTileH][4 + i + dc]; }
+  __device__ __forceinline__ V operator()(vint2 d) const { return (*this)(d[0], d[1]); }
+};
+template <class V, int R, int C> struct boxnbh_win_px {
+  const win_regs<V>* w; int i;
+  __device__ __forceinline__ V operator()(int dr, int dc) const { return w->px[dr + kTileH][4 + i + dc]; }
+  __device__ __forceinline__ V north() const { return (*this)(-1, 0); }
+  __device__ __forceinline__ V south() const { return (*this)(1, 0); }
+  __device__ __forceinline__ V east() const { return (*this)(0, 1); }
+  __device__ __forceinline__ V west() const { return (*this)(0, -1); }
+  template <class F> __device__ __forceinline__ void for_all(F f) const {
+#pragma unroll
+    for (int dr = -(R / 2); dr <= R / 2; dr++)
+#pragma unroll
+      for (int dc = -(C / 2); dc <= C / 2; dc++) f((*this)(dr, dc));
+  }
+};
+template <class V> struct nbh_win_acc { const win_regs<V>* w; };
+template <class V, int R, int C> struct boxnbh_win_acc { const win_regs<V>* w; };
+template <class V, int NPX> __device__ __forceinline__ nbh_win_px<V> arg(stage<nbh_win_acc<V>, NPX>&, const nbh_win_acc<V>& a, int, int, int i) { return nbh_win_px<V>{a.w, i}; }
+template <class V, int R, int C, int NPX> __device__ __forceinline__ boxnbh_win_px<V, R, C> arg(stage<boxnbh_win_acc<V, R, C>, NPX>&, const boxnbh_win_acc<V, R, C>& a, int, int, int i) {
+  return boxnbh_win_px<V, R, C>{a.w, i};
+}
+template <class A> struct win_of;
+template <class V> struct win_of<nbh_acc<V>> { typedef nbh_win_acc<V> type; };
+template <class V, int R, int C> struct win_of<boxnbh_acc<V, R, C>> { typedef boxnbh_win_acc<V, R, C> type; };
+
+// one row of the window: the three 16-byte chunks at columns c - 4, c, c + 4 of image row r; bytes outside the buffer's mirror [lo, hi) are never touched
+template <class V> __device__ __forceinline__ void win_load_row(V (&dst)[12], const char* p0, int pitch, int r, int c, const char* lo, const char* hi) {
+  const char* src = p0 + (ptrdiff_t)r * pitch + (ptrdiff_t)(c - 4) * 4;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const char* s = src + 16 * q;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (s >= lo && s + 16 <= hi) v = *(const u32x4*)s;
+    else if (s + 16 > lo && s < hi) {   // a chunk cut by the buffer's first / last byte
+      unsigned int e[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (s + 4 * k >= lo && s + 4 * k + 4 <= hi) e[k] = *(const unsigned int*)(s + 4 * k);
+      v = u32x4{e[0], e[1], e[2], e[3]};
+    }
+    __builtin_memcpy(&dst[4 * q], &v, 16);
+  }
+}
+
+// (ragged tail of pixel_wise_window_kernel: ranges staged one pixel at a time — index 0 — while the window accessor still needs the pixel's place in the lane's chunk)
+template <class S, class A> __device__ __forceinline__ decltype(auto) win_arg(S& s, const A& a, int r, int c, int) { return arg(s, a, r, c, 0); }
+template <class V> __device__ __forceinline__ nbh_win_px<V> win_arg(stage<nbh_win_acc<V>, 1>&, const nbh_win_acc<V>& a, int, int, int i) { return nbh_win_px<V>{a.w, i}; }
+template <class V, int R, int C> __device__ __forceinline__ boxnbh_win_px<V, R, C> win_arg(stage<boxnbh_win_acc<V, R, C>, 1>&, const boxnbh_win_acc<V, R, C>& a, int, int, int i) {
+  return boxnbh_win_px<V, R, C>{a.w, i};
+}
+
+template <class F, class... A>
+__global__ __launch_bounds__(256) void pixel_wise_window_kernel(F f, int r0, int c0, int nrows, int ncols, A... acc) {
+  typedef typename first_nbh<A...>::type NA;
+  typedef typename nbh_traits<NA>::pixel V;
+  static_assert(sizeof(V) == 4, "the register window holds 4-byte pixels");
+  const NA& nb = first_nbh<A...>::get(acc...);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = c0 + (blockIdx.x * 64 + lane) * 4;
+  const int rw = r0 + (blockIdx.y * 4 + wv) * kWinRows;          // the wave's first output row
+  if (rw >= r0 + nrows) return;
+  const bool col_ok = c < c0 + ncols;
+  const int n = col_ok ? min(4, c0 + ncols - c) : 0;
+  const int cc = col_ok ? c : c0;                                  // (lanes past the row's end load in-range columns and drop them)
+  win_regs<V> w;
+#pragma unroll
+  for (int k = 0; k < 2 * kTileH; k++) win_load_row<V>(w.px[k + 1], (const char*)nb.p0, nb.pitch, rw - kTileH + k, cc, nb.lo, nb.hi);
+  const typename win_of<NA>::type wa{&w};
+#pragma unroll
+  for (int j = 0; j < kWinRows; j++) {
+    const int r = rw + j;
+#pragma unroll
+    for (int k = 0; k < 2 * kTileH; k++)
+#pragma unroll
+      for (int q = 0; q < 12; q++) w.px[k][q] = w.px[k + 1][q];
+    if (r < r0 + nrows) win_load_row<V>(w.px[2 * kTileH], (const char*)nb.p0, nb.pitch, r + kTileH, cc, nb.lo, nb.hi);
+    if (r < r0 + nrows && n) {
+      if (n == 4) pixel_step<4>(f, r, c, tile_swap(acc, wa)...);
+      else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) if (i < n) {   // the row's ragged tail, pixel by pixel (the window is the lane's: pixel i reads it at i)
+          const typename win_of<NA>::type wi{&w};
+          std::tuple<stage<typename std::conditional<nbh_traits<A>::value, typename win_of<NA>::type, A>::type, 1>...> st1;
+          std::apply([&](auto&... s_) { (void)std::initializer_list<int>{(s_.load(tile_swap(acc, wi), r, c + i), 0)...}; }, st1);
+          std::apply([&](auto&... s_) { call_lvalues(f, win_arg(s_, tile_swap(acc, wi), r, c + i, i)...); }, st1);
+          std::apply([&](auto&... s_) { (void)std::initializer_list<int>{(s_.store(tile_swap(acc, wi), r, c + i), 0)...}; }, st1);
+        }
+      }
+    }
+  }
+}
+
 constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
 constexpr int lcm_(int a, int b) { return a / gcd_(a, b) * b; }
 template <class A> struct npx_of { enum { value = 1 }; };
@@ -267,6 +372,17 @@ template <bool NBH_RO, class F, class... A> void launch(F f, int r0, int c0, int
     // with global taps -> 39.3 us out of the tile (dword taps already come out of L1 / L2 at near the streaming rate; the staging pass, the barrier and the
     // 1.5 x halo rows only add).  So: pixel types that are not dword multiples take the tile, the others keep the global taps.
     typedef typename nbh_traits<typename first_nbh<A...>::type>::pixel PV;
+    if constexpr (sizeof(PV) == 4 && NPX == 4) {   // 4-byte pixels, every image range 4-byte too: the register window (pixel_wise_window_kernel)
+      static const bool woff = [] { const char* e = getenv("VPP_PW_WINDOW"); return e && e[0] == '0'; }();   // A/B switch for the tests and the benchmark
+      if (!woff && al && nb.pitch % 16 == 0 && ((size_t)((const char*)nb.p0 + (ptrdiff_t)c0 * 4) % 16) == 0) {
+        dim3 grid((ncols + 255) / 256, (nrows + 4 * kWinRows - 1) / (4 * kWinRows));
+        hipLaunchKernelGGL((pixel_wise_window_kernel<F, A...>), grid, dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) throw std::runtime_error(std::string("pixel_wise (device, register window): launch failed: ") + hipGetErrorString(e));
+        device::call_done();   // queued, not drained: vpp/core/device.hh
+        return;
+      }
+    }
     if (!off && sizeof(PV) % 4 != 0 && nb.pitch % 16 == 0) {
       constexpr int NPXK = NPX % 4 == 0 ? 4 : 1;
       const bool vec = al && NPXK > 1;
