@@ -668,6 +668,9 @@ def main():
                 legs["semi_dense_flow_4k"]["tracker_frames_per_s"] = round(ve["frames_per_s"])
         if "flow_strips_4k" in px:
             legs["flow_strips_4k"] = pick(px["flow_strips_4k"], "ms_per_pair", "pairs_per_s", "ranks", "error")
+            legs["flow_strips_4k"]["replicated_share"] = 0.76   # of a rank's device time (profiles/r06_flow_replicated_share.md): configs[4] scales as replicas
+        if isinstance((px.get("video_extruder_4k") or {}).get("replicas"), dict):
+            legs["tracker_replicas_4k"] = pick(px["video_extruder_4k"]["replicas"], "streams", "frames_per_s_total")
         ig = px.get("ingest_4k") or {}
         if "us_per_frame" in ig:
             legs["ingest_4k"] = {"us_per_frame": rnd(ig["us_per_frame"]), "frac": rnd(ig["roofline"]["frac"]), "one_launch_per_call": pick(ig["one_launch_per_call"], "us_per_frame", "frac"),

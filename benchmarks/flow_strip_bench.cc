@@ -120,6 +120,13 @@ int main(int argc, char** argv) {
   };
   for (int i = 0; i < 3; i++) step(nullptr);
   CK(vpp_sync(nullptr));
+  if (std::getenv("VPP_STRIP_SHARE_ONLY")) {   // tools/flow_replicated_share.py: nothing but the sharded step in the process (no single-rank calls, no detector leg)
+    for (int i = 0; i < steps; i++) step(nullptr);
+    CK(vpp_sync(nullptr));
+    if (rank == 0) { std::printf("{\"share_only\": true, \"ranks\": %d, \"steps\": %d}\n", world, steps + 3); std::remove(uid_file.c_str()); }
+    CK(vpp_comm_destroy(comm));
+    return 0;
+  }
 
   // ---- parity of the row exchange and of the sharded flow (every rank, against its own single-rank call on the full frames)
   long bad_rows = 0, bad_flow = 0;

@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
     for (int q = 0; q < NS; q++) { S.emplace_back(NR, NC, _border = 2); D.emplace_back(S[q].domain()); }
     image2d<int> T(S[0].domain());
     for (auto p : S[0].domain_with_border()) S[0](p) = int(rng() % 1000);
-    for (int q = 1; q < NS; q++) copy(S[0], S[q]);
+    for (int q = 1; q < NS; q++) for (auto p : S[0].domain_with_border()) S[q](p) = S[0](p);
     auto body = [] (int& b, auto a) {
       int sum = 0;
       for (int i = -2; i <= 2; i++)
@@ -78,7 +78,7 @@ int main(int argc, char** argv) {
     for (int q = 0; q < NS; q++) { S.emplace_back(NR, NC, _border = 2); D.emplace_back(S[q].domain()); }
     image2d<vuchar3> T(S[0].domain());
     for (auto p : S[0].domain_with_border()) S[0](p) = vuchar3(rng() & 255, rng() & 255, rng() & 255);
-    for (int q = 1; q < NS; q++) copy(S[0], S[q]);
+    for (int q = 1; q < NS; q++) for (auto p : S[0].domain_with_border()) S[q](p) = S[0](p);
     auto k3 = [] (vuchar3& out, auto nbh) {   // examples/box_filter.cc:23-32
       vint3 sum = vint3::Zero();
       for (int i = -2; i <= 2; i++) for (int j = -2; j <= 2; j++) sum += nbh(i, j).template cast<int>();

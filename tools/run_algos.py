@@ -60,3 +60,17 @@ for i in range(6):
     capi.check(lib.vpp_pyrlk_match(vi.desc_array(r1), vi.desc_array(rg), vi.desc_array(r2), L4, V(k.data_ptr()), 10000, 11, ctypes.c_float(1e-4), ctypes.c_float(500.0), 30,
                                    ctypes.c_float(0.01), 0, None, st))
 torch.cuda.synchronize()
+# round 6: 8 frame pairs x 1 250 keypoints in ONE launch (vpp_pyrlk_match_batch: a rank's slice of configs[3] over a group of frames) — pyrlk_match_batch_kernel<7, 16>
+F = 8
+sets = []
+for f in range(F):
+    texf = texture(NR, NC, seed=60 + f)
+    a = DeviceImage.from_host(u8_image(np.clip(np.rint(texf), 0, 255).astype(np.uint8)))
+    b = DeviceImage.from_host(u8_image(np.clip(np.rint(translate(texf, 1.5 - 0.1 * f, -2.25 + 0.2 * f)), 0, 255).astype(np.uint8)))
+    pa = pyr.device_pyramid(lib, a, L, B); sets.append((pa, pyr.device_grad_pyramid(lib, pa[0], L, B, vi.F32), pyr.device_pyramid(lib, b, L, B)))
+dP = vi.desc_array([l_ for q in sets for l_ in q[0]]); dG = vi.desc_array([l_ for q in sets for l_ in q[1]]); dN = vi.desc_array([l_ for q in sets for l_ in q[2]])
+for i in range(6):
+    ks = [ks0.clone() for _ in range(F)]
+    capi.check(lib.vpp_pyrlk_match_batch(dP, dG, dN, F, L, (ctypes.c_void_p * F)(*[k_.data_ptr() for k_ in ks]), (ctypes.c_int * F)(*([1250] * F)), 7, ctypes.c_float(1e-4),
+                                         ctypes.c_float(500.0), 30, ctypes.c_float(0.01), 0, None, st))
+torch.cuda.synchronize()
