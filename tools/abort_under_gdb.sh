@@ -18,11 +18,16 @@ handle SIG34 nostop noprint pass
 run
 echo \n==== stopped: aborting thread ====\n
 bt 40
+echo \n==== where the libraries are loaded ====\n
+info sharedlibrary rocprofiler
+info sharedlibrary hsa-runtime
+info sharedlibrary vpp_amd
+info sharedlibrary amdhip
 echo \n==== main thread ====\n
 thread 1
 bt 25
-echo \n==== all threads, 8 frames ====\n
-thread apply all bt 8
+echo \n==== threads inside libvpp_amd / libamdhip64 (none expected) ====\n
+thread apply all -s -q bt 6
 kill
 quit
 GDB
@@ -32,7 +37,7 @@ for i in $(seq 1 $N); do
   rc=$?
   if grep -q "==== stopped" /tmp/gdb_$i.out && grep -qE "SIGABRT|SIGSEGV" /tmp/gdb_$i.out; then
     echo "pass $i: stopped on a signal (exit $rc)"
-    { echo "# pass $i of $N: bench.py under rocprofv3 --kernel-trace under rocgdb"; grep -E "free\(\)|corrupt|malloc" /tmp/gdb_$i.err | head -5; sed -n '/Thread .* received signal/,$p' /tmp/gdb_$i.out | head -400; } > $R/gpurun_out/abort_gdb.txt
+    { echo "# pass $i of $N: bench.py under rocprofv3 --kernel-trace under rocgdb"; grep -E "free\(\)|corrupt|malloc" /tmp/gdb_$i.err | head -5; sed -n '/Thread .* received signal/,$p' /tmp/gdb_$i.out | grep -v -A3 gomp_barrier_wait_end | head -400; } > $R/gpurun_out/abort_gdb.txt
     head -120 $R/gpurun_out/abort_gdb.txt
     exit 0
   fi

@@ -70,8 +70,10 @@ struct DeferWindow {
   char last_msg[200] = "";
 };
 namespace {
-std::mutex g_defer_reg_mu;               // lock order: registry, then a window
-std::vector<DeferWindow*> g_defer_reg;   // every live thread's window
+// lock order: registry, then a window.  Both objects are leaked on purpose: a thread that ends (or flushes) while the process is already running its static
+// destructors must still find them alive.
+std::mutex& g_defer_reg_mu = *new std::mutex;
+std::vector<DeferWindow*>& g_defer_reg = *new std::vector<DeferWindow*>;   // every live thread's window
 const char* defer_kind_name(int kind) { return kind == kDeferBox ? "vpp_box_filter" : kind == kDeferBinary ? "vpp_pixelwise_binary" : kind == kDeferGray ? "vpp_rgb_to_graylevel" : "?"; }
 // launches the window and empties it (w.mu held by the caller)
 int defer_launch_locked(DeferWindow& w) {
