@@ -628,6 +628,50 @@ def test_held_back_calls_cross_host_threads(lib, orc):
         np.testing.assert_array_equal(dsts[k].download().view(), wants[k].view(), err_msg=f"frame {k}: held back when its thread ended")
 
 
+def test_held_back_calls_of_several_threads_on_one_stream(lib, orc):
+    """Four host threads hold back frames on ONE stream at the same time and each of them also queues other work (vpp_fill_border, vpp_sync) on it, which launches
+    whatever window waits on that stream — its own or another thread's, while that thread may be appending to it.  Every thread's frames are its own, so every
+    result is defined whatever the interleaving: all of them against the oracle, over several rounds."""
+    import threading
+    import torch
+    st = torch_stream(); sp = ctypes.c_void_p(st.cuda_stream)
+    T, per, rounds, nr, nc = 4, 9, 6, 48, 176
+    srcs, dsts, wants = {}, {}, {}
+    for t in range(T):
+        for k in range(per):
+            h = rand_image(nr, nc, vi.U8, 3, border=2, seed=1200 + t * per + k, align=16, fill_border=True)
+            w = h.like(border=0); assert orc.orc_box_filter(P(w.desc), P(h.desc), 5, 5) == 0
+            srcs[t, k] = DeviceImage.from_host(h); dsts[t, k] = DeviceImage(nr, nc, vi.U8, 3, 0, 16); wants[t, k] = w
+    scratch = [DeviceImage.from_host(rand_image(32, 64, vi.U8, 1, border=3, seed=1300 + t)) for t in range(T)]
+    torch.cuda.synchronize()
+    errors = []
+    start = threading.Barrier(T)
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            start.wait(30)
+            for r in range(rounds):
+                for k in range(per):
+                    capi.check(lib.vpp_box_filter_deferred(P(dsts[t, k].desc), P(srcs[t, k].desc), 5, 5, sp))
+                    if (k + t + r) % 4 == 0:
+                        capi.check(lib.vpp_fill_border(P(scratch[t].desc), 0, None, sp))     # another entry point on the shared stream: launches the windows that wait on it
+                if (r + t) % 2 == 0:
+                    capi.check(lib.vpp_sync(sp))
+        except BaseException as e:   # noqa: BLE001
+            errors.append((t, e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert not errors, errors
+    capi.check(lib.vpp_sync(sp))          # (every worker has ended: whatever it still held back was launched when it did)
+    for key, d in dsts.items():
+        np.testing.assert_array_equal(d.download().view(), wants[key].view(), err_msg=f"thread {key[0]} frame {key[1]}")
+
+
 def test_a_capture_the_library_did_not_begin_records_every_call_at_once(lib, orc):
     """vpp_graph_end closes the last held-back window of a recorded stream; a capture begun by other means (here torch's) ends where the library cannot see it, so
     there nothing may be held back: plain and deferred per-frame calls record their own node each, and the replayed graph carries all of them."""
