@@ -255,8 +255,8 @@ def run(lib, dev, rank, world, timed, barrier, steps=50, warmup=5):
         barrier()
         dt = (time.perf_counter() - t0) / it
         fast[name] = {"ms": dt * 1e3, "gpixels_per_s": 2160 * 3840 * world / dt / 1e9, "keypoints": n.value}
-    fast["raw"]["roofline"] = issue_roofline("fast9_detect2_kernel<true, 0>")
-    fast["blockwise10"]["roofline"] = issue_roofline("fast9_detect2_kernel<true, 2>")
+    fast["raw"]["roofline"] = issue_roofline("fast9_detect2_kernel<true, 0")
+    fast["blockwise10"]["roofline"] = issue_roofline("fast9_detect2_kernel<true, 2")
     res["fast9_4k"] = fast
 
     stage("flow")

@@ -80,8 +80,9 @@ int defer_launch_locked(DeferWindow& w) {
   DeferBatch& b = w.b;
   const int n = b.n;
   if (!n) return VPP_OK;
-  g_defer_pending.fetch_sub(n, std::memory_order_acq_rel);
   b.n = 0;
+  // (the process-wide count goes down only when the launch has been QUEUED, below: a thread that reads 0 in as_stream() and queues its own work at once must come
+  // after these frames — while the count is up it comes here instead and waits for w.mu)
   int rc = VPP_OK;
   int cur = b.dev;
   if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = b.dev; }
@@ -97,6 +98,7 @@ int defer_launch_locked(DeferWindow& w) {
     g_defer_bypass--;
     if (cur != b.dev) (void)hipSetDevice(cur);   // the caller has moved to another device since: back to it
   }
+  g_defer_pending.fetch_sub(n, std::memory_order_acq_rel);
   w.flushes.fetch_add(1, std::memory_order_release);
   if (rc != VPP_OK) {   // the n frames were not queued: say so at the thread's next vpp_flush / vpp_sync
     w.last_rc = rc;
