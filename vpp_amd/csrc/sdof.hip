@@ -72,6 +72,42 @@ __device__ __forceinline__ void load_window(WindowRegs<WS>& w, const uint8_t* __
 #pragma unroll
     for (int d = 0; d < (WS + 3) / 4; d++) __builtin_memcpy(&w.d[r][d], row + (ptrdiff_t)r * pitch + 4 * d, 4);
 }
+// The same window loaded ONCE per group of G lanes (G = 4: a DPP quad, G = 8: half a DPP row) instead of once per lane: lane j fetches the rows j, j + G, ...
+// and every row goes round the group through DPP (quad_perm broadcast; for 8 lanes the quad broadcast and its row_half_mirror give the rows k and k + 4 together).
+// The descent kernels are bound by the address rate of their gathers (LABNOTES round 6): with every lane loading all WS rows a wave of 16 four-lane groups spent
+// 9 of its ~20 load instructions on 16 distinct windows; here it spends 3.  Every lane of a group must be active (the groups' control flow is group-uniform).
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false); }
+template <int WS, int G>
+__device__ __forceinline__ void load_window_group(WindowRegs<WS>& w, const uint8_t* __restrict__ row, int pitch, int j) {
+  static_assert(G == 4 || G == 8, "a quad or two");
+  constexpr int ND = (WS + 3) / 4, NV = (WS + G - 1) / G;
+  uint32_t v[NV][ND];
+#pragma unroll
+  for (int q = 0; q < NV; q++) {
+#pragma unroll
+    for (int d = 0; d < ND; d++) __builtin_memcpy(&v[q][d], row + (ptrdiff_t)(q * G + G <= WS ? j + q * G : min(j + q * G, WS - 1)) * pitch + 4 * d, 4);   // (no branch: rows past the window repeat its last one)
+  }
+#pragma unroll
+  for (int q = 0; q < NV; q++)
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+      const uint32_t x = v[q][d];
+      const uint32_t t0 = dpp_mov<0x00>(x), t1 = dpp_mov<0x55>(x), t2 = dpp_mov<0xAA>(x), t3 = dpp_mov<0xFF>(x);   // lane k of the lane's own quad
+      const uint32_t t[4] = {t0, t1, t2, t3};
+      if constexpr (G == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (q * 4 + k < WS) w.d[q * 4 + k][d] = t[k];
+      } else {
+        const bool lowq = j < 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t u = dpp_mov<0x141>(t[k]);   // row_half_mirror: lane i of 8 reads lane 7 - i, i.e. the OTHER quad's broadcast
+          if (q * 8 + k < WS) w.d[q * 8 + k][d] = lowq ? t[k] : u;
+          if (q * 8 + k + 4 < WS) w.d[q * 8 + k + 4][d] = lowq ? u : t[k];
+        }
+      }
+    }
+}
 template <int WS>
 __device__ __forceinline__ int sad_rows_against(const WindowRegs<WS>& a, const uint8_t* __restrict__ row2, int pitch2, int th) {
   constexpr int ND = (WS + 3) / 4;
@@ -369,6 +405,9 @@ __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa
 // groups occupied 3/4 of every wave of the coarsest scale).
 // G = 4 lanes per keypoint (window sizes with a register window only): 16 keypoints per wave, each lane two candidates of a step — the 10 k waves of a 4K scale's
 // 82 k keypoints are two generations of resident waves at this kernel's 5 waves per SIMD, the 5 k waves of the 4-lane form are one.
+// Register-window sizes (WS != 0, round 6): everything that depends on the keypoint alone — the owner entry, the coarser scale's mark and flow, the keypoint's window — is requested in ONE
+// memory round trip (the loads used to follow each other behind the tests: keypoint -> owner -> coarse mark -> coarse flow -> window + first patch), and the window is
+// loaded once per group (load_window_group) instead of once per lane.
 template <int WS, bool BYCELL = false, int G = 8>
 __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* __restrict__ kps, int n, int scale_div, int patch, int ws, DImg owner,
                                                                 DImg i1, DImg i2, Maps cur, Maps coarse, int has_coarse, int cell_lo, int cell_hi, int clean_owner, Mirrors mir) {
@@ -387,6 +426,26 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
   if (i >= n) return;
   const int p0 = kps[2 * i] / scale_div, p1 = kps[2 * i + 1] / scale_div;  // :116
   const int pf0 = p0 / patch, pf1 = p1 / patch;
+  int pr0 = p0, pr1 = p1;
+  WindowRegs<WS> wa;
+  const bool a_ok = i1.has(p0, p1);
+  if constexpr (WS != 0) {
+    // (unconditional loads at clamped coordinates: a load inside a branch is waited for at the branch's end, and the four would follow each other again)
+    const bool mine = BYCELL || (pf0 >= cell_lo && pf0 < cell_hi && owner.has(pf0, pf1));
+    uint32_t own = (uint32_t)i;
+    if constexpr (!BYCELL) own = owner.row<uint32_t>(min(max(pf0, 0), owner.nr - 1))[min(max(pf1, 0), owner.nc - 1)];
+    const int pfm0 = p0 / (2 * patch), pfm1 = p1 / (2 * patch);
+    const bool cin = has_coarse && coarse.mark.has(pfm0, pfm1);
+    const int cm0 = min(max(pfm0, 0), coarse.mark.nr - 1), cm1 = min(max(pfm1, 0), coarse.mark.nc - 1);
+    const uint32_t cmk = coarse.mark.row<uint8_t>(cm0)[cm1];
+    const int32_t* cfp = coarse.flow.row<int32_t>(cm0) + 2 * cm1;
+    const int cf0 = cfp[0], cf1 = cfp[1];
+    load_window_group<WS, G>(wa, i1.row<uint8_t>(min(max(p0, 0), i1.nr - 1) - ws / 2) + (min(max(p1, 0), i1.nc - 1) - ws / 2), i1.pitch, j);
+    asm volatile("" :: "v"(cmk), "v"(cf0), "v"(cf1));   // (keeps the coarse loads above the branch below: the compiler sinks them behind it otherwise)
+    if (!mine || (!BYCELL && own != (uint32_t)i)) return;  // :120 — first keypoint in index order claims
+    if (clean_owner && j == 0) owner.row<uint32_t>(pf0)[pf1] = 0xFFFFFFFFu;
+    if (cin && cmk) { pr0 = p0 + cf0 * 2; pr1 = p1 + cf1 * 2; }  // multiscale prediction, :126-128
+  } else {
   if constexpr (!BYCELL) {
     if (pf0 < cell_lo || pf0 >= cell_hi) return;
     if (!owner.has(pf0, pf1) || owner.row<uint32_t>(pf0)[pf1] != (uint32_t)i) return;  // :120 — first keypoint in index order claims
@@ -394,7 +453,6 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
   // clean_owner: the cell's one owner hands the owner map back empty (every lane of the group has read the entry: one wave, program order; the cell's other
   // keypoints compare against their own index and leave on either value) — the next call finds the maps as a reset would leave them
   if (clean_owner && j == 0) owner.row<uint32_t>(pf0)[pf1] = 0xFFFFFFFFu;
-  int pr0 = p0, pr1 = p1;
   if (has_coarse) {  // multiscale prediction, :126-128
     const int pfm0 = p0 / (2 * patch), pfm1 = p1 / (2 * patch);
     if (coarse.mark.has(pfm0, pfm1) && coarse.mark.row<uint8_t>(pfm0)[pfm1]) {
@@ -403,9 +461,8 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
     }
   }
   // the keypoint's own window (image 1 at p) is the same in every comparison of the walk: loaded once, the candidates cost one window each
-  WindowRegs<WS> wa;
-  const bool a_ok = i1.has(p0, p1);
   if (WS != 0 && a_ok) load_window<WS>(wa, i1.row<uint8_t>(p0 - ws / 2) + (p1 - ws / 2), i1.pitch);
+  }
   auto dist = [&](int b0, int b1, int th) -> int {
     if constexpr (WS != 0) {
       if (!(a_ok && i2.has(b0, b1))) return INT_MAX;
@@ -589,15 +646,23 @@ __device__ __forceinline__ void enqueue_targets(const RoundArrays& a, SweepCtl* 
 // *changed_out: the cell's value differs from S_{k-1}(cell).  clear_flag: the cell came out of round k's queue (its flag is handed back).
 // MAPS: the value also goes into the maps (sdof_rounds_kernel: every round writes them, ordered by the barriers' releases; sdof_sweep_kernel has no releases —
 // two rounds' plain stores to one cell from two XCDs could reach memory in either order — and writes the maps once, at the end of the sweep).
-template <int WS, bool MAPS>
+// TILE (round 0 inside sdof_sweep_kernel): every record the job reads — the cell's and its neighbours', `pre` and the round buffer alike (equal between sweeps) — is
+// in the workgroup's LDS copy of its tile + halo (tile_at: the cell's entry, row pitch kTilePitch, out-of-domain entries zero): no memory round trip before the windows.
+constexpr int kTilePitch = 18;   // kSweepTile + 2
+__device__ __forceinline__ Cell cell_of(const uint4& v) { return Cell{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
+template <int WS, bool MAPS, bool TILE = false>
 __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws, const Maps& m, int patch, int forward, int NI, int NJ, const RoundArrays& a, int k,
                                          const Cell* __restrict__ Bprev, Cell* __restrict__ Bcur, int cell, int j, uint4* __restrict__ slot, int stats, bool clear_flag,
-                                         bool* changed_out) {
+                                         bool* changed_out, const uint4* __restrict__ tile_at = nullptr) {
   const int par = k & 1;
   const int ci = cell / NJ, cj = cell - ci * NJ;
   if (clear_flag && j == 0) store_u32_sc1(a.qflag[par] + cell, 0u);   // set by whoever enqueued the cell for this round (nobody enqueues for round k during round k)
-  const Cell pre = load_cell16(a.pre + cell);   // (nobody writes `pre` during a sweep: plain loads)
-  const Cell old = load_cell_sc1(Bprev + cell);
+  Cell pre, old;
+  if constexpr (TILE) { pre = cell_of(tile_at[0]); old = pre; }
+  else {
+    pre = load_cell16(a.pre + cell);   // (nobody writes `pre` during a sweep: plain loads)
+    old = load_cell_sc1(Bprev + cell);
+  }
   // lane j holds neighbour j in loop_body's order: (-1,-1) (-1,0) (-1,1) (0,-1) (0,1) (1,-1) (1,0) (1,1)
   const int jj = j + (j >= 4 ? 1 : 0);
   const int dr = jj / 3 - 1, dc = jj % 3 - 1;
@@ -607,7 +672,8 @@ __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws,
   // Whether the neighbour is marked at all is read from its `pre` record (a sweep only ever turns a 2 into a 1, :179): the round buffers' records are written for
   // marked cells only (descents, the end of a sweep) and never reset — an unmarked cell's entry there holds anything and is not looked at.
   Cell nb{0, 0, 0, 0};
-  if (in) {
+  if constexpr (TILE) nb = cell_of(tile_at[dr * kTilePitch + dc]);
+  else if (in) {
     nb = load_cell16(a.pre + (size_t)q0 * NJ + q1);
     if (earlier) { const Cell bq = load_cell_sc1(Bprev + (size_t)q0 * NJ + q1); if ((nb.mark & 0xFF) != 0) nb = bq; }
   }
@@ -628,7 +694,9 @@ __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws,
   };
   if (need) {
     a_ok = i1.has(r, c);
-    if (WS != 0 && a_ok) load_window<WS>(wa, i1.row<uint8_t>(r - ws / 2) + (c - ws / 2), i1.pitch);
+    if constexpr (WS != 0) {
+      if (a_ok) load_window_group<WS, 8>(wa, i1.row<uint8_t>(r - ws / 2) + (c - ws / 2), i1.pitch, j);   // (`need` and a_ok are the same on the 8 lanes of a job)
+    }
     // static part of the test at :164-165: the neighbour is marked and differs from prev_flow; its d2 (:169) depends on nothing else
     const int b0 = pre.f0 - nb.f0, b1 = pre.f1 - nb.f1;
     okb = nbm && b0 * b0 + b1 * b1 >= 9;
@@ -798,39 +866,54 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   __shared__ unsigned long long s_gen;
   __shared__ uint32_t s_cand[256];
   __shared__ uint4 s_union[kJobsPerGroup][kUnionRows];   // per 8-lane group: the candidate patch of a descent step (group_descent_staged)
+  __shared__ uint4 s_tile[kTilePitch * kTilePitch];       // the `pre` records of the workgroup's tile + halo
+  static_assert(kTilePitch == kSweepTile + 2, "tile + 1-cell halo");
   SweepCtl* const ctl = a.ctl;
   const int tid = threadIdx.x, j = tid & 7;
   if (stats == 1 && blockIdx.x == 0 && tid == 0) sweep_log(255u, gridDim.x);
   if (tid == 0) { s_ncand = 0; s_giveup = 0; }
   // (round 5) A sweep that found no candidate at all changed nothing, so the next sweep of the same scale (same test, same maps) finds none either: the earlier
   // sweep says so in a.skip and this one returns after one load instead of classifying, arriving and handing the control block back (9 us -> the launch's own cost).
-  const unsigned skip_word = may_skip ? load_u32_sc1(a.skip) : 0u;   // (requested beside the classification's loads; every lane: one address, one broadcast)
+  const unsigned skip_word = may_skip ? load_u32_sc1(a.skip) : 0u;   // (every lane: one address, one broadcast)
+  // This workgroup's 16 x 16 cells and their 1-cell halo, `pre` records, into LDS: a thread's own cell + (threads 0 .. 67) one halo cell.  Requested BEFORE the skip word
+  // is looked at (one round trip for both), read by the classification below and by round 0's jobs (round 6: the classification used to load a marked cell's 8
+  // neighbours behind the cell's own record, and every job of round 0 its records again: two and three dependent round trips).
+  const int tiles_x = (NJ + kSweepTile - 1) / kSweepTile;
+  const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+  const int li = tid / kSweepTile, lj = tid % kSweepTile;
+  const int ci = ty * kSweepTile + li, cj = tx * kSweepTile + lj;
+  int hi_ = 0, hj_ = 0;   // the halo entry this thread fills
+  if (tid < kTilePitch) { hi_ = 0; hj_ = tid; } else if (tid < 2 * kTilePitch) { hi_ = kTilePitch - 1; hj_ = tid - kTilePitch; }
+  else if (tid < 2 * kTilePitch + kSweepTile) { hi_ = 1 + tid - 2 * kTilePitch; hj_ = 0; } else { hi_ = 1 + tid - 2 * kTilePitch - kSweepTile; hj_ = kTilePitch - 1; }
+  const int gi = ty * kSweepTile - 1 + hi_, gj = tx * kSweepTile - 1 + hj_;
+  const bool own_in = ci < NI && cj < NJ, halo_in = tid < 2 * kTilePitch + 2 * kSweepTile && gi >= 0 && gj >= 0 && gi < NI && gj < NJ;
+  uint4 own_rec = *(const uint4*)(a.pre + (size_t)min(ci, NI - 1) * NJ + min(cj, NJ - 1));
+  uint4 halo_rec = *(const uint4*)(a.pre + (size_t)min(max(gi, 0), NI - 1) * NJ + min(max(gj, 0), NJ - 1));
+  asm volatile("" ::: "memory");   // (the record loads stay above the skip test)
   __syncthreads();
   if (may_skip && (skip_word == sweep_id || skip_word == sweep_id + 1u)) {   // (+ 1: what workgroup 0 of this very launch writes below — every workgroup decides alike)
     if (blockIdx.x == 0 && tid == 0) { store_u32_sc1(a.skip, sweep_id + 1u); if (stats == 1) sweep_log(250u, gridDim.x); }   // still nothing: the next one may skip as well
     return;
   }
+  if (!own_in) own_rec = make_uint4(0u, 0u, 0u, 0u);
+  if (!halo_in) halo_rec = make_uint4(0u, 0u, 0u, 0u);
+  s_tile[(li + 1) * kTilePitch + lj + 1] = own_rec;
+  if (tid < 2 * kTilePitch + 2 * kSweepTile) s_tile[hi_ * kTilePitch + hj_] = halo_rec;
+  __syncthreads();
   {  // ---- this workgroup's cells: which of them can loop_body change at all (sdof_classify_kernel's test, on the records)
-    const int tiles_x = (NJ + kSweepTile - 1) / kSweepTile;
-    const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
-    const int ci = ty * kSweepTile + tid / kSweepTile, cj = tx * kSweepTile + tid % kSweepTile;
     const int idx = ci * NJ + cj;
     bool cand = false;
-    if (ci < NI && cj < NJ) {
-      const Cell cur = load_cell16(a.pre + idx);
-      if (cur.mark & 0xFF) {
+    const Cell cur = cell_of(own_rec);
+    if (cur.mark & 0xFF) {   // (an out-of-domain entry is unmarked)
 #pragma unroll
-        for (int dr = -1; dr <= 1; dr++)
+      for (int dr = -1; dr <= 1; dr++)
 #pragma unroll
-          for (int dc = -1; dc <= 1; dc++) {
-            if (!dr && !dc) continue;
-            const int q0 = ci + dr, q1 = cj + dc;
-            if (q0 < 0 || q1 < 0 || q0 >= NI || q1 >= NJ) continue;
-            const Cell nb = load_cell16(a.pre + (size_t)q0 * NJ + q1);
-            const int a0 = cur.f0 - nb.f0, a1 = cur.f1 - nb.f1;
-            if ((nb.mark & 0xFF) && a0 * a0 + a1 * a1 >= 9) cand = true;
-          }
-      }
+        for (int dc = -1; dc <= 1; dc++) {
+          if (!dr && !dc) continue;
+          const Cell nb = cell_of(s_tile[(li + 1 + dr) * kTilePitch + lj + 1 + dc]);
+          const int a0 = cur.f0 - nb.f0, a1 = cur.f1 - nb.f1;
+          if ((nb.mark & 0xFF) && a0 * a0 + a1 * a1 >= 9) cand = true;
+        }
     }
     const unsigned long long b = __ballot(cand);
     if (b) {
@@ -852,7 +935,9 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
     if (job < n0) {
       const int cell = (int)s_cand[job];
       bool changed;
-      target = round_job<WS, false>(i1, i2, ws, m, patch, forward, NI, NJ, a, 0, a.B[1], a.B[0], cell, j, s_union[tid >> 3], stats, false, &changed);
+      const int qi = cell / NJ, qj = cell - qi * NJ;
+      target = round_job<WS, false, true>(i1, i2, ws, m, patch, forward, NI, NJ, a, 0, a.B[1], a.B[0], cell, j, s_union[tid >> 3], stats, false, &changed,
+                                          s_tile + (qi - ty * kSweepTile + 1) * kTilePitch + (qj - tx * kSweepTile + 1));
       if (changed && j == 0) chg = cell;
     }
     enqueue_targets(a, ctl, 1, target);
@@ -1320,20 +1405,20 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
         const long long groups = (cells * 2 <= n && tuning("sdof.descent_bycell", 1)) ? cells : (long long)n;
         const int want_g = tuning("sdof.descent_group", 0);
         const bool four = WS != 0 && tuning("sdof.descent_lanes", 8) == 8 && (want_g == 4 || (want_g == 0 && groups > 6144 * 8));
-        if (four && cells * 2 <= n && tuning("sdof.descent_bycell", 1)) {
-          if constexpr (WS != 0)
-            sdof_descent_group_kernel<WS, true, 4><<<(unsigned)((cells + 15) / 16), 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                                                              maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0, mir);
-        } else if (four) {
-          if constexpr (WS != 0)
-            sdof_descent_group_kernel<WS, false, 4><<<(n + 15) / 16, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                                               maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0, mir);
-        } else if (tuning("sdof.descent_lanes", 8) == 8 && cells * 2 <= n && tuning("sdof.descent_bycell", 1))
-          sdof_descent_group_kernel<WS, true><<<(unsigned)((cells + 7) / 8), 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                                                         maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0, mir);
-        else if (tuning("sdof.descent_lanes", 8) == 8)
-          sdof_descent_group_kernel<WS><<<(n + 7) / 8, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
-                                                                    maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0, mir);
+        const bool bycell = cells * 2 <= n && tuning("sdof.descent_bycell", 1);
+        const bool grouped = tuning("sdof.descent_lanes", 8) == 8;
+        auto go = [&](auto Bc, auto Gc) {
+          constexpr bool BC = decltype(Bc)::value; constexpr int GG = decltype(Gc)::value;
+          if constexpr (WS != 0 || GG == 8) {
+            const long long ng = BC ? cells : (long long)n;
+            sdof_descent_group_kernel<WS, BC, GG><<<(unsigned)((ng + 64 / GG - 1) / (64 / GG)), 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
+                                                                                                   maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0, mir);
+          }
+        };
+        using T = std::true_type; using F = std::false_type; using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
+        if (grouped) {
+          if (four && bycell) go(T{}, I4{}); else if (four) go(F{}, I4{}); else if (bycell) go(T{}, I8{}); else go(F{}, I8{});
+        }
         else
           sdof_descent_kernel<WS><<<(n + 63) / 64, 64, 0, sk>>>(kps, n, scale_div, patchsize, winsize, dimg(&OW(k, scale)), dimg(&P1[scale]), dimg(&P2[scale]),
                                                                maps(k, scale), maps(k, has_coarse ? scale + 1 : scale), has_coarse ? 1 : 0, lo, hi, self_cleaning ? 1 : 0);
