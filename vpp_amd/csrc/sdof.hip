@@ -377,11 +377,13 @@ __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa
       const unsigned long long kq = ((unsigned long long)(unsigned)d << 3) | jq;
       key = kq < key ? kq : key;
     }
-#pragma unroll
-    for (int x = 1; x < G; x <<= 1) {
-      const unsigned lo = __shfl_xor((unsigned)key, x), hi = __shfl_xor((unsigned)(key >> 32), x);
-      const unsigned long long ok = ((unsigned long long)hi << 32) | lo;
-      key = ok < key ? ok : key;
+    // minimum over the group by DPP (quad_perm for lanes ^ 1 and ^ 2, row_half_mirror to meet the other quad of an 8-lane group): a few cycles per exchange where
+    // __shfl_xor's ds_bpermute was an LDS round trip, three of them in a row in every search step's chain
+    {
+      auto take_min = [&](unsigned lo, unsigned hi) { const unsigned long long ok = ((unsigned long long)hi << 32) | lo; key = ok < key ? ok : key; };
+      take_min(dpp_mov<0xB1>((unsigned)key), dpp_mov<0xB1>((unsigned)(key >> 32)));
+      take_min(dpp_mov<0x4E>((unsigned)key), dpp_mov<0x4E>((unsigned)(key >> 32)));
+      if constexpr (G == 8) take_min(dpp_mov<0x141>((unsigned)key), dpp_mov<0x141>((unsigned)(key >> 32)));
     }
     const int best = (int)(unsigned)(key >> 3);
     if (best < match_distance) {
@@ -854,18 +856,23 @@ __global__ __launch_bounds__(256) void sdof_rounds_kernel(DImg i1, DImg i2, int 
 // slot — the wait cannot deadlock), and the rounds then run on the stayers + the last arriver behind the grid barrier of sdof_rounds_kernel.
 // Every registered workgroup stays until the sweep is over (parked once a round fits one batch), takes its share of the write-back and acknowledges;
 // ticket 0 zeroes the control block after the last acknowledgement.
-constexpr unsigned kStayThreshold = kJobsPerGroup;   // (a round that fits one batch is run by one workgroup anyway)
+[[maybe_unused]] constexpr unsigned kStayThreshold = kJobsPerGroup;   // (a round that fits one batch is run by one workgroup anyway)
 constexpr unsigned kMaxStay = 48;
 constexpr int kSweepTile = 16;   // a workgroup's cells: a 16 x 16 tile of the sweep domain (a motion boundary along a row of cells would hand one workgroup of 256 consecutive
                                  // cells 256 candidates, 8 passes of round 0 one after the other: measured 90 us for the middle scale of the 4K bench scene)
 constexpr unsigned kGenFinal = 0xFFFFFFFFu;   // round field of the message that ends the sweep for parked workgroups
 
-template <int WS>
-__global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats, int nsub, unsigned stay_above, unsigned sweep_id, int may_skip) {
+// NT threads per workgroup = NT / 8 jobs per pass (round 6).  512 where two such workgroups per CU hold every tile at once (at most 512 tiles; the kernel's ~106 VGPRs
+// leave a SIMD 4 waves): round 0 of a tile with 33 ... 64 candidates is ONE pass instead of two one after the other — the passes are latency chains, not work, and on the
+// 4K bench scene the middle scale's tiles that set round 0's length have 40-66 candidates (round 0 ends 15.7 instead of 21 us after the classification).  256 where the
+// tiles are more (the finest 4K scale: 1 296).  1 024 threads (one workgroup per CU, a second generation of tiles) measured 0.197 against 0.180 ms per pair.
+template <int WS, int NT = 256>
+__global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats, int nsub, unsigned stay_above, unsigned sweep_id, int may_skip) {
   __shared__ unsigned s_val, s_nreg, s_flags, s_ncand, s_flushn, s_giveup;
   __shared__ unsigned long long s_gen;
   __shared__ uint32_t s_cand[256];
-  __shared__ uint4 s_union[kJobsPerGroup][kUnionRows];   // per 8-lane group: the candidate patch of a descent step (group_descent_staged)
+  constexpr int JOBS = NT / 8;
+  __shared__ uint4 s_union[JOBS][kUnionRows];   // per 8-lane group: the candidate patch of a descent step (group_descent_staged)
   __shared__ uint4 s_tile[kTilePitch * kTilePitch];       // the `pre` records of the workgroup's tile + halo
   static_assert(kTilePitch == kSweepTile + 2, "tile + 1-cell halo");
   SweepCtl* const ctl = a.ctl;
@@ -886,8 +893,8 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   if (tid < kTilePitch) { hi_ = 0; hj_ = tid; } else if (tid < 2 * kTilePitch) { hi_ = kTilePitch - 1; hj_ = tid - kTilePitch; }
   else if (tid < 2 * kTilePitch + kSweepTile) { hi_ = 1 + tid - 2 * kTilePitch; hj_ = 0; } else { hi_ = 1 + tid - 2 * kTilePitch - kSweepTile; hj_ = kTilePitch - 1; }
   const int gi = ty * kSweepTile - 1 + hi_, gj = tx * kSweepTile - 1 + hj_;
-  const bool own_in = ci < NI && cj < NJ, halo_in = tid < 2 * kTilePitch + 2 * kSweepTile && gi >= 0 && gj >= 0 && gi < NI && gj < NJ;
-  uint4 own_rec = *(const uint4*)(a.pre + (size_t)min(ci, NI - 1) * NJ + min(cj, NJ - 1));
+  const bool own_in = tid < kSweepTile * kSweepTile && ci < NI && cj < NJ, halo_in = tid < 2 * kTilePitch + 2 * kSweepTile && gi >= 0 && gj >= 0 && gi < NI && gj < NJ;
+  uint4 own_rec = *(const uint4*)(a.pre + (size_t)min(ci, NI - 1) * NJ + min(cj, NJ - 1));   // (threads past the tile's 256 cells: a clamped address, dropped)
   uint4 halo_rec = *(const uint4*)(a.pre + (size_t)min(max(gi, 0), NI - 1) * NJ + min(max(gj, 0), NJ - 1));
   asm volatile("" ::: "memory");   // (the record loads stay above the skip test)
   __syncthreads();
@@ -897,7 +904,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   }
   if (!own_in) own_rec = make_uint4(0u, 0u, 0u, 0u);
   if (!halo_in) halo_rec = make_uint4(0u, 0u, 0u, 0u);
-  s_tile[(li + 1) * kTilePitch + lj + 1] = own_rec;
+  if (tid < kSweepTile * kSweepTile) s_tile[(li + 1) * kTilePitch + lj + 1] = own_rec;
   if (tid < 2 * kTilePitch + 2 * kSweepTile) s_tile[hi_ * kTilePitch + hj_] = halo_rec;
   __syncthreads();
   {  // ---- this workgroup's cells: which of them can loop_body change at all (sdof_classify_kernel's test, on the records)
@@ -910,7 +917,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
 #pragma unroll
         for (int dc = -1; dc <= 1; dc++) {
           if (!dr && !dc) continue;
-          const Cell nb = cell_of(s_tile[(li + 1 + dr) * kTilePitch + lj + 1 + dc]);
+          const Cell nb = cell_of(s_tile[min(li + 1 + dr, kTilePitch - 1) * kTilePitch + lj + 1 + dc]);
           const int a0 = cur.f0 - nb.f0, a1 = cur.f1 - nb.f1;
           if ((nb.mark & 0xFF) && a0 * a0 + a1 * a1 >= 9) cand = true;
         }
@@ -929,7 +936,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   if (tid == 0 && n0) (void)__hip_atomic_fetch_add(&ctl->ncand, n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (waited for with this workgroup's other accesses before it arrives)
   if (stats == 1 && tid == 0 && n0) sweep_log(253u, n0);
   // ---- round 0 on this workgroup's candidates: reads `pre` (and B[1], equal to it), writes B[0], round 1's queue and the list of changes
-  for (unsigned base = 0; base < n0; base += (unsigned)kJobsPerGroup) {
+  for (unsigned base = 0; base < n0; base += (unsigned)JOBS) {
     const unsigned job = base + (unsigned)(tid >> 3);
     int target = -1, chg = -1;
     if (job < n0) {
@@ -1009,7 +1016,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   for (int k = 1; n != 0; k++) {
     // A round that fits one batch is left to ticket 0 alone (workgroup-scoped synchronisation: no L2 write-back, no invalidation in front of the next
     // round's loads); the others wait for the end of the sweep.  Once alone, always alone: longer lists are walked in passes.
-    if (!solo && n <= min(stay_above, (unsigned)kJobsPerGroup)) {
+    if (!solo && n <= min(stay_above, (unsigned)JOBS)) {
       if (ticket != 0) { parked = true; break; }
       solo = true;
     }
@@ -1018,8 +1025,8 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
     Cell* __restrict__ Bcur = a.B[par];
     const uint32_t* __restrict__ Qcur = a.Q[par];
     const unsigned stride = solo ? 1u : N0;
-    for (unsigned batch = solo ? 0u : ticket; batch * (unsigned)kJobsPerGroup < n; batch += stride) {
-      const unsigned job = batch * (unsigned)kJobsPerGroup + (unsigned)(tid >> 3);
+    for (unsigned batch = solo ? 0u : ticket; batch * (unsigned)JOBS < n; batch += stride) {
+      const unsigned job = batch * (unsigned)JOBS + (unsigned)(tid >> 3);
       int target = -1, chg = -1;
       if (job < n) {
         const int cell = (int)load_u32_sc1(Qcur + job);
@@ -1093,7 +1100,7 @@ __global__ __launch_bounds__(256) void sdof_sweep_kernel(DImg i1, DImg i2, int w
   __syncthreads();
   if (s_giveup) return;
   const unsigned fn = s_flushn;
-  for (unsigned i = ticket * 256u + (unsigned)tid; i < fn; i += N0 * 256u) {
+  for (unsigned i = ticket * (unsigned)NT + (unsigned)tid; i < fn; i += N0 * (unsigned)NT) {
     const uint32_t cell = load_u32_sc1(a.chg + i);
     Cell c = load_cell_sc1(a.B[0] + cell);   // a changed cell is carried into the round after its change: both round buffers hold its final value
     c.mark &= 0xFF;
@@ -1128,10 +1135,12 @@ __global__ __launch_bounds__(256) void sdof_readback_kernel(const int32_t* __res
   const int k0 = kps[2 * i], k1 = kps[2 * i + 1];
   const int q0 = k0 / div, q1 = k1 / div;  // :207-208
   int o0 = k0, o1 = k1, d = 0; uint8_t v = 0;
-  if (m.mark.has(q0, q1) && m.mark.row<uint8_t>(q0)[q1]) {
-    const int32_t* f = m.flow.row<int32_t>(q0) + 2 * q1;
-    o0 = k0 + f[0] * ms; o1 = k1 + f[1] * ms; d = m.dist.row<int32_t>(q0)[q1]; v = 1;  // :210-211
-  }
+  // (mark, flow and distance in one round trip: unconditional loads at clamped coordinates)
+  const int c0 = min(max(q0, 0), m.mark.nr - 1), c1 = min(max(q1, 0), m.mark.nc - 1);
+  const uint8_t mk = m.mark.row<uint8_t>(c0)[c1];
+  const int32_t* f = m.flow.row<int32_t>(c0) + 2 * c1;
+  const int f0 = f[0], f1 = f[1], dd = m.dist.row<int32_t>(c0)[c1];
+  if (m.mark.has(q0, q1) && mk) { o0 = k0 + f0 * ms; o1 = k1 + f1 * ms; d = dd; v = 1; }  // :210-211
   out_pos[2 * i] = o0; out_pos[2 * i + 1] = o1; out_dist[i] = d; out_valid[i] = v;
   if constexpr (LINK) merge_link_one(link, i, o0, o1, k0, k1, v != 0);
 }
@@ -1467,9 +1476,13 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
             if (fused_sweeps) {   // one launch per sweep: every workgroup classifies its tile of cells and runs round 0 on them, the last one to finish runs the rest
               const int tiles = ((NI + kSweepTile - 1) / kSweepTile) * ((NJ + kSweepTile - 1) / kSweepTile);
               const int nsub = std::max(1, std::min(kSubCounters, tiles / 16));
-              sdof_sweep_kernel<WS><<<tiles, 256, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs, tuning("sdof.stats", 0), nsub,
-                                                                  (unsigned)tuning("sdof.sweep_stay", (int)kStayThreshold), sweep_base + (unsigned)Ki,
-                                                                  Ki > 0 && tuning("sdof.skip_empty", 1) ? 1 : 0);
+              const int want_nt = tuning("sdof.sweep_threads", 0), nt = want_nt ? want_nt : (tiles <= 512 ? 512 : 256);
+              auto sweep = [&](auto NTc) {
+                constexpr int NT = decltype(NTc)::value;
+                sdof_sweep_kernel<WS, NT><<<tiles, NT, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs, tuning("sdof.stats", 0), nsub,
+                                                                (unsigned)tuning("sdof.sweep_stay", NT / 8), sweep_base + (unsigned)Ki, Ki > 0 && tuning("sdof.skip_empty", 1) ? 1 : 0);
+              };
+              if (nt == 512) sweep(std::integral_constant<int, 512>()); else sweep(std::integral_constant<int, 256>());
               continue;
             }
             sdof_classify_kernel<<<(cells + 255) / 256, 256, 0, st>>>(maps(0, scale), NI, NJ, rs);
