@@ -641,21 +641,29 @@ __global__ __launch_bounds__(256) void fast9_write_rows_kernel(DImg F, const uin
   __shared__ uint32_t gsum[4];
   const int r = blockIdx.x, band = r / TH;
   uint32_t s = 0;
+  // (round 6) Everything the row needs first — its own corner words, two 16-byte pieces of the tile totals above, one of the row counts above — is requested in ONE memory
+  // round trip (clamped addresses, results masked: no branch in front of a load); frames up to 4K need no more than that.  The loops used to follow each other, each
+  // waiting for its own loads, and the corner words were only asked for behind the block sum: four dependent round trips in a launch that is little else.
+  const int n16 = band * ntc;   // u16 tile totals of the bands above
+  const int b0 = band * TH * ntc, n8 = r * ntc - b0;   // u8 counts of the rows above this one inside its band
+  const uint4* t4 = (const uint4*)tiletot;
+  const uint4* c4 = (const uint4*)(rowcnt + b0);
+  const int t = threadIdx.x;
+  const uint32_t m_first = segs[(size_t)r * nsc + min(t, nsc - 1)];
+  const int nt4 = n16 / 8, nc4 = n8 / 16;
+  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+  uint4 va = t4[min(t, max(nt4 - 1, 0))], vb = t4[min(t + 256, max(nt4 - 1, 0))], vc = c4[min(t, max(nc4 - 1, 0))];   // (tiletot / rowcnt: at least 16 bytes each)
+  if (t >= nt4) va = z4;
+  if (t + 256 >= nt4) vb = z4;
+  if (t >= nc4) vc = z4;
   {  // both ranges start 16-byte aligned (the arrays are 256-byte aligned, TH * ntc is a multiple of 16): 16-byte loads, SWAR sums
-    const int n16 = band * ntc;   // u16 tile totals of the bands above
-    const uint4* t4 = (const uint4*)tiletot;
-    for (int i = threadIdx.x; i < n16 / 8; i += 256) {
-      const uint4 v = t4[i];
-      s += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16) + (v.z & 0xFFFFu) + (v.z >> 16) + (v.w & 0xFFFFu) + (v.w >> 16);
-    }
-    for (int i = (n16 & ~7) + threadIdx.x; i < n16; i += 256) s += tiletot[i];
-    const int b0 = band * TH * ntc, n8 = r * ntc - b0;   // u8 counts of the rows above this one inside its band
-    const uint4* c4 = (const uint4*)(rowcnt + b0);
-    for (int i = threadIdx.x; i < n8 / 16; i += 256) {
-      const uint4 v = c4[i];
-      s = __builtin_amdgcn_sad_u8(v.x, 0u, s); s = __builtin_amdgcn_sad_u8(v.y, 0u, s); s = __builtin_amdgcn_sad_u8(v.z, 0u, s); s = __builtin_amdgcn_sad_u8(v.w, 0u, s);
-    }
-    for (int i = (n8 & ~15) + threadIdx.x; i < n8; i += 256) s += rowcnt[b0 + i];
+    auto sum16 = [&](const uint4& v) { s += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16) + (v.z & 0xFFFFu) + (v.z >> 16) + (v.w & 0xFFFFu) + (v.w >> 16); };
+    auto sum8 = [&](const uint4& v) { s = __builtin_amdgcn_sad_u8(v.x, 0u, s); s = __builtin_amdgcn_sad_u8(v.y, 0u, s); s = __builtin_amdgcn_sad_u8(v.z, 0u, s); s = __builtin_amdgcn_sad_u8(v.w, 0u, s); };
+    sum16(va); sum16(vb); sum8(vc);
+    for (int i = 512 + t; i < nt4; i += 256) sum16(t4[i]);
+    for (int i = (n16 & ~7) + t; i < n16; i += 256) s += tiletot[i];
+    for (int i = 256 + t; i < nc4; i += 256) sum8(c4[i]);
+    for (int i = (n8 & ~15) + t; i < n8; i += 256) s += rowcnt[b0 + i];
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
@@ -665,7 +673,7 @@ __global__ __launch_bounds__(256) void fast9_write_rows_kernel(DImg F, const uin
   const uint16_t* f0 = F.row<uint16_t>(r);
   for (int u0 = 0; u0 < nsc; u0 += 256) {   // 256 segments = 4096 px per step (one step up to 4K frames)
     const int u = u0 + threadIdx.x;
-    uint32_t m = u < nsc ? segs[(size_t)r * nsc + u] : 0;
+    uint32_t m = u < nsc ? (u0 == 0 ? m_first : segs[(size_t)r * nsc + u]) : 0;
     uint32_t tot;
     uint32_t k = base + block_exscan((uint32_t)__popc(m), &tot);
     base += tot;
