@@ -660,7 +660,11 @@ int vpp_pyrlk_match(const vpp_image_desc* prev, const vpp_image_desc* grad, cons
   hipStream_t st = as_stream(stream);
   // lanes per keypoint: enough waves to cover the 1024 SIMDs a few times over, no more (total work grows with LPK)
   int lpk = tuning("pyrlk.lpk", 0);
-  if (lpk == 0) lpk = n >= 80000 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));  // measured: tools/tune_pyrlk.py (round 2: 16 lanes win up to 40 k keypoints, 8 from 100 k; 8 also beats 1 lane per keypoint at 400 k)
+  // measured: tools/lk_lpk_ab.py (round 6, 1080p, 3 levels, 7 x 7, us per call by lanes per keypoint 8 / 16 / 32 / 64): 2 000: 135 / 102 / 83 / 74 · 4 000: 112 / 91 / 85 / 91 ·
+  // 8 000: 139 / 112 / 106 / 150 · 10 000: 134 / 109 / 118 / 169 · 16 000: 168 / 143 / 183 / 235 · 20 000: 171 / 201 / 213 / 287 · 40 000: 306 / 325 / 381 / 519.  16 lanes per keypoint are
+  // n / 4 waves: past 16 384 keypoints they no longer fit the chip at once (4 per SIMD) and the second generation costs more than 8 lanes' longer chains (round 2's table
+  // switched at 80 000).
+  if (lpk == 0) lpk = n > 16384 ? 8 : (n >= 8000 ? 16 : (n >= 3500 ? 32 : 64));
   if (winsize > 11) lpk = 1;                  // the group kernels hold up to 128 window offsets (11 x 11 = 121: the window of the reference's own benchmark,
   else if (winsize > 7 && lpk == 8) lpk = 16;  // benchmarks/pyrlk_opencv_comparison.cc:47); 8 lanes per keypoint would hold 11-16 taps per lane in registers: 16 at least
   // 9 x 9 / 11 x 11 hold 2.5 x the taps: 32 lanes per keypoint stay ahead of 16 at every count measured (11 x 11, 4 levels, us: 10 k 334 vs 345, 20 k 534 vs 648, 40 k 952 vs 1 011)
@@ -711,7 +715,7 @@ int vpp_pyrlk_match_batch(const vpp_image_desc* prev, const vpp_image_desc* grad
   }
   if (total == 0) return VPP_OK;
   int lpk = tuning("pyrlk.lpk", 0);
-  if (lpk == 0) lpk = total >= 80000 ? 8 : (total >= 8000 ? 16 : (total >= 3500 ? 32 : 64));   // the single call's table (vpp_pyrlk_match), on the launch's total
+  if (lpk == 0) lpk = total > 16384 ? 8 : (total >= 8000 ? 16 : (total >= 3500 ? 32 : 64));   // the single call's table (vpp_pyrlk_match), on the launch's total
   if (winsize > 7 && lpk == 8) lpk = 16;
   if (winsize > 7 && winsize <= 11 && tuning("pyrlk.lpk", 0) == 0 && lpk == 16) lpk = 32;
   const bool grouped = (winsize == 3 || winsize == 5 || winsize == 7 || winsize == 9 || winsize == 11) && (lpk == 8 || lpk == 16 || lpk == 32 || lpk == 64);
