@@ -16,6 +16,7 @@
 // the same type and order, from the same truncated intermediate values as the chain of per-level kernels, so the result is
 // bit-identical; the halo recomputation costs (2T+3)^2 / (2T)^2 per level, all of it on chip.
 #include "common.hpp"
+#include <type_traits>
 #include "sdof_tail.hpp"
 using namespace vpp_amd;
 
@@ -349,11 +350,14 @@ template <int CH> struct GrayFast {   // rgb_to_graylevel of four pixels (GraySr
     }
   }
 };
-struct Swar3 { Chain ch; int TX, TY, tx_lo, tx_hi, ty_lo, ty_hi, tiles_x8; };
+struct Swar3 { Chain ch; int TX, TY, tx_lo, tx_hi, ty_lo, ty_hi, tiles_x8, wide; };   // wide: source and level 0 are 16-byte aligned (the patch goes in as 16-byte pieces)
 
-template <class FAST, class SRC>
-__device__ __forceinline__ void pyramid_swar3_body(const Swar3& a, const int bid) {
-  constexpr int R0 = 41, W0 = 22, G1 = 10, R1 = 19, G2 = 4;   // level-0 patch rows / dwords per row, level-1 groups per row / patch rows, level-2 groups
+// WIDE (round 6, copy producer, 16-byte aligned source and level 0): the patch is 41 rows of 96 bytes from column 64 tx - 16 — six 16-byte pieces per row, 246 loads, ONE
+// pass of the workgroup — instead of 41 x 22 dwords from column 64 tx - 12 in 3.5 passes with a division, two tests and a 4-byte store per dword: the staging was a third of
+// the kernel's instructions.  The four bytes more on either side are read and never used.
+template <class FAST, class SRC, bool WIDE>
+__device__ __forceinline__ void pyramid_swar3_body_(const Swar3& a, const int bid) {
+  constexpr int R0 = 41, W0 = WIDE ? 24 : 22, XO = WIDE ? 1 : 0, G1 = 10, R1 = 19, G2 = 4;   // level-0 patch rows / dwords per row (XO: dword of the patch's column 64 tx - 12), level-1 groups per row / patch rows, level-2 groups
   int ty, tx;
   {
     // blocks [0, 2 n_edge): the edge tiles, one 8 x 8 tile of the tile kernel each (two per 8 x 16 tile, so that no workgroup runs two in a row —
@@ -376,6 +380,15 @@ __device__ __forceinline__ void pyramid_swar3_body(const Swar3& a, const int bid
   const DImg L0 = a.ch.lv[0], L1 = a.ch.lv[1], L2 = a.ch.lv[2], src = a.ch.src;
   const int r2 = 8 * ty, c2 = 16 * tx;
   const int pr0 = 4 * r2 - 6, pc0 = 4 * c2 - 12;   // origin of the level-0 patch; level-1 patch: rows from 2 r2 - 2, columns from 2 c2 - 4
+  if constexpr (WIDE) {
+    for (int idx = threadIdx.x; idx < R0 * 6; idx += 256) {
+      const int y = idx / 6, x = idx - y * 6;
+      const ptrdiff_t col = pc0 - 4 + 16 * x;
+      const uint4 v = *(const uint4*)(src.p0 + (ptrdiff_t)(pr0 + y) * src.pitch + col);
+      *(uint4*)&s0[y * W0 + 4 * x] = v;
+      if (y >= 6 && y < 38 && x >= 1 && x < 5) *(uint4*)(L0.p0 + (ptrdiff_t)(pr0 + y) * L0.pitch + col) = v;   // the owned 32 x 64 pixels
+    }
+  } else
   for (int idx = threadIdx.x; idx < R0 * W0; idx += 256) {
     const int y = idx / W0, x = idx - y * W0;
     const uint32_t v = FAST::load4(src, pr0 + y, pc0 + 4 * x);
@@ -385,8 +398,8 @@ __device__ __forceinline__ void pyramid_swar3_body(const Swar3& a, const int bid
   __syncthreads();
   for (int idx = threadIdx.x; idx < R0 * G1; idx += 256) {   // horizontal pass of level 0: level-1 columns 2 c2 - 4 + 4 g + k from patch bytes 8 g .. 8 g + 15
     const int y = idx / G1, g = idx - y * G1;
-    const uint2 lo = *(const uint2*)&s0[y * W0 + 2 * g], hi = *(const uint2*)&s0[y * W0 + 2 * g + 2];
-    sh0[idx] = hpass4(lo.x, lo.y, hi.x, hi.y);
+    const uint32_t* q = &s0[y * W0 + XO + 2 * g];
+    sh0[idx] = hpass4(q[0], q[1], q[2], q[3]);
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < R1 * G1; idx += 256) {   // vertical pass: level-1 row 2 r2 - 2 + i from patch rows 2 i .. 2 i + 4
@@ -408,6 +421,12 @@ __device__ __forceinline__ void pyramid_swar3_body(const Swar3& a, const int bid
     const uint32_t* p = &sh1[2 * i * G2 + g];
     *(uint32_t*)(L2.p0 + (ptrdiff_t)(r2 + i) * L2.pitch + (c2 + 4 * g)) = vpass4(p[0], p[G2], p[2 * G2], p[3 * G2], p[4 * G2]);
   }
+}
+
+template <class FAST, class SRC>
+__device__ __forceinline__ void pyramid_swar3_body(const Swar3& a, const int bid) {
+  if constexpr (std::is_same<FAST, CopyFast>::value) { if (a.wide) { pyramid_swar3_body_<FAST, SRC, true>(a, bid); return; } }
+  pyramid_swar3_body_<FAST, SRC, false>(a, bid);
 }
 
 // interior tile ranges of the packed path along one axis: tiles [lo, hi) of `step2` level-2 pixels whose level-0 patch (from 4 t0 - lead0, `span0`
@@ -444,7 +463,7 @@ __global__ __launch_bounds__(256) void pyramid_swar3_pair_tail_kernel(Swar3 a, S
 }
 
 // the packed kernel's arguments for one pyramid; false: unaligned levels or no interior tile (the tile kernel takes the pyramid); *blocks = its grid
-inline bool swar3_args(const vpp_image_desc* levels, const vpp_image_desc* src, Swar3* out, int* blocks) {
+inline bool swar3_args(const vpp_image_desc* levels, const vpp_image_desc* src, Swar3* out, int* blocks, bool copy_producer = true) {
   auto al4 = [](const vpp_image_desc& d) { return ((uintptr_t)d.first_pixel & 3) == 0 && (d.pitch & 3) == 0; };
   if (!(al4(levels[0]) && al4(levels[1]) && al4(levels[2]) && al4(*src))) return false;
   Swar3& a = *out;
@@ -452,7 +471,9 @@ inline bool swar3_args(const vpp_image_desc* levels, const vpp_image_desc* src, 
   a.ch.src = dimg(src); a.ch.nlevels = 3;
   a.TY = (levels[2].nrows + 7) / 8; a.TX = (levels[2].ncols + 15) / 16; a.tiles_x8 = (levels[2].ncols + 7) / 8;
   swar3_axis(levels[0].nrows, levels[1].nrows, levels[2].nrows, levels[0].border, levels[1].border, levels[2].border, 8, 6, 41, a.TY, &a.ty_lo, &a.ty_hi);
-  swar3_axis(levels[0].ncols, levels[1].ncols, levels[2].ncols, levels[0].border, levels[1].border, levels[2].border, 16, 12, 88, a.TX, &a.tx_lo, &a.tx_hi);
+  auto al16 = [](const vpp_image_desc& d) { return ((uintptr_t)d.first_pixel & 15) == 0 && (d.pitch & 15) == 0; };
+  a.wide = copy_producer && tuning("pyr.wide", 1) && al16(levels[0]) && al16(*src) ? 1 : 0;
+  swar3_axis(levels[0].ncols, levels[1].ncols, levels[2].ncols, levels[0].border, levels[1].border, levels[2].border, 16, a.wide ? 16 : 12, a.wide ? 96 : 88, a.TX, &a.tx_lo, &a.tx_hi);
   if (a.ty_hi <= a.ty_lo || a.tx_hi <= a.tx_lo) return false;   // no interior tile: the tile kernel
   const int n_int = (a.ty_hi - a.ty_lo) * (a.tx_hi - a.tx_lo), n_edge = a.TY * a.TX - n_int;
   *blocks = 2 * n_edge + n_int;
@@ -461,7 +482,7 @@ inline bool swar3_args(const vpp_image_desc* levels, const vpp_image_desc* src, 
 template <class FAST, class SRC>
 bool launch_swar3(const vpp_image_desc* levels, const vpp_image_desc* src, hipStream_t st) {
   Swar3 a; int blocks = 0;
-  if (!swar3_args(levels, src, &a, &blocks)) return false;
+  if (!swar3_args(levels, src, &a, &blocks, std::is_same<FAST, CopyFast>::value)) return false;
   pyramid_swar3_kernel<FAST, SRC><<<blocks, 256, 0, st>>>(a);
   return true;
 }
