@@ -7,6 +7,8 @@ from vpp_amd.synth import P, u8_image, DeviceImage, flow_scene
 from vpp_amd import capi
 V = ctypes.c_void_p
 lib = capi.lib(); capi.check(lib.vpp_init(0)); st = capi.stream_ptr()
+for kv in os.environ.get("VPP_TUNE", "").split(","):   # tuning knobs for this run: VPP_TUNE="name=value,..."
+    if "=" in kv: lib.vpp_set_tuning(kv.split("=")[0].encode(), int(kv.split("=")[1]))
 s1, s2, sk = flow_scene(2160, 3840, spacing=10)
 e1, e2 = DeviceImage.from_host(u8_image(s1, border=3)), DeviceImage.from_host(u8_image(s2, border=3))
 m = len(sk); dk = torch.from_numpy(sk).cuda()
