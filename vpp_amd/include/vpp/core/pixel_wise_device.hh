@@ -53,25 +53,47 @@ template <class V, int R, int C> struct boxnbh_px {  // box_nbh2d<V,R,C> at a po
 // The same two accessors over an LDS tile (pixel_wise_tile_kernel): the row pitch is a compile-time constant, so the taps of an unrolled window are
 // ds_read instructions with immediate offsets from ONE base register.  READ-ONLY by type (const V&): the tile is a copy, a write through it would never reach
 // the image — so this path is only taken under the caller's `_nbh_read_only` option (launch), and a callable that assigns through it anyway does not compile.
-template <class V, int LP> struct nbh_tile_px {
-  const char* p;
-  __device__ const V& operator()(int dr, int dc) const { return *(const V*)(p + dr * LP + dc * (int)sizeof(V)); }
-  __device__ const V& operator()(vint2 d) const { return (*this)(d[0], d[1]); }
+// A4 (round 6): the lane's chunk starts 4-byte aligned in the tile and V is a 3-byte pixel (vuchar3).  A tap is then returned BY VALUE, cut out of the ALIGNED dwords that
+// hold it (offset from the chunk's start: 3 i + dr LP + 3 dc — a constant once the callable's window loops are unrolled, so the compiler knows which dwords and which
+// shift, and reads every dword of the window's rows once for the lane's four pixels: 7 ds_read_b32 per row instead of 120 ds_read_u8).  Through a `const V&` the
+// callable's per-component reads are three byte reads per tap — 75 per pixel of a 5 x 5 window, which is what the tile kernel was bound by.  (One unaligned 4-byte
+// read per tap was measured first: 115 us against the byte reads' 50 — LDS dwords at odd addresses are slow.)
+template <class V, bool A4> struct tile_tap {
+  typedef const V& type;
+  static __device__ type get(const char* b, int off) { return *(const V*)(b + off); }
 };
-template <class V, int R, int C, int LP> struct boxnbh_tile_px {
-  const char* p;
-  __device__ const V& operator()(int dr, int dc) const { return *(const V*)(p + dr * LP + dc * (int)sizeof(V)); }
-  __device__ const V& north() const { return (*this)(-1, 0); }
-  __device__ const V& south() const { return (*this)(1, 0); }
-  __device__ const V& east() const { return (*this)(0, 1); }
-  __device__ const V& west() const { return (*this)(0, -1); }
+template <> struct tile_tap<vector<unsigned char, 3>, true> {
+  typedef vector<unsigned char, 3> type;
+  static __device__ type get(const char* b, int off) {
+    const unsigned* w = (const unsigned*)__builtin_assume_aligned(b, 4);
+    const int wi = off >> 2, sh = off & 3;
+    const unsigned lo = w[wi], hi = sh >= 2 ? w[wi + 1] : 0u;
+    type r;   // component j is byte sh + j of the dword pair: one bit-field extract (or a byte-select operand of the callable's own add) each
+#pragma unroll
+    for (int j = 0; j < 3; j++) r.v[j] = (unsigned char)(sh + j < 4 ? lo >> (8 * (sh + j)) : hi >> (8 * (sh + j - 4)));
+    return r;
+  }
+};
+template <class V, int LP, bool A4 = false> struct nbh_tile_px {
+  const char* b; int o;   // the tap (dr, dc) is at b + o + dr LP + dc sizeof(V); A4: b = the lane's chunk (4-byte aligned), o = the pixel's offset in it
+  __device__ typename tile_tap<V, A4>::type operator()(int dr, int dc) const { return tile_tap<V, A4>::get(b, o + dr * LP + dc * (int)sizeof(V)); }
+  __device__ typename tile_tap<V, A4>::type operator()(vint2 d) const { return (*this)(d[0], d[1]); }
+};
+template <class V, int R, int C, int LP, bool A4 = false> struct boxnbh_tile_px {
+  const char* b; int o;
+  __device__ typename tile_tap<V, A4>::type operator()(int dr, int dc) const { return tile_tap<V, A4>::get(b, o + dr * LP + dc * (int)sizeof(V)); }
+  __device__ typename tile_tap<V, A4>::type north() const { return (*this)(-1, 0); }
+  __device__ typename tile_tap<V, A4>::type south() const { return (*this)(1, 0); }
+  __device__ typename tile_tap<V, A4>::type east() const { return (*this)(0, 1); }
+  __device__ typename tile_tap<V, A4>::type west() const { return (*this)(0, -1); }
   template <class F> __device__ void for_all(F f) const {
     for (int dr = -(R / 2); dr <= R / 2; dr++)
       for (int dc = -(C / 2); dc <= C / 2; dc++) f((*this)(dr, dc));
   }
 };
-template <class V, int LP> struct nbh_tile_acc { char* p00; int r00, c00; };                      // p00: the tile byte of pixel (r00, c00)
-template <class V, int R, int C, int LP> struct boxnbh_tile_acc { char* p00; int r00, c00; };
+
+template <class V, int LP, bool A4 = false> struct nbh_tile_acc { char* p00; int r00, c00; };                      // p00: the tile byte of pixel (r00, c00)
+template <class V, int R, int C, int LP, bool A4 = false> struct boxnbh_tile_acc { char* p00; int r00, c00; };
 
 template <class A> struct is_image_acc : std::false_type {};
 template <class V> struct is_image_acc<image_acc<V>> : std::true_type {};
@@ -125,11 +147,11 @@ template <class V, int NPX> __device__ nbh_px<V> arg(stage<nbh_acc<V>, NPX>&, co
 template <class V, int R, int C, int NPX> __device__ boxnbh_px<V, R, C> arg(stage<boxnbh_acc<V, R, C>, NPX>&, const boxnbh_acc<V, R, C>& a, int r, int c, int i) {
   return boxnbh_px<V, R, C>{(V*)((char*)a.p0 + (ptrdiff_t)r * a.pitch) + c + i, a.pitch};
 }
-template <class V, int LP, int NPX> __device__ nbh_tile_px<V, LP> arg(stage<nbh_tile_acc<V, LP>, NPX>&, const nbh_tile_acc<V, LP>& a, int r, int c, int i) {
-  return nbh_tile_px<V, LP>{a.p00 + (r - a.r00) * LP + (c + i - a.c00) * (int)sizeof(V)};
+template <class V, int LP, bool A4, int NPX> __device__ nbh_tile_px<V, LP, A4> arg(stage<nbh_tile_acc<V, LP, A4>, NPX>&, const nbh_tile_acc<V, LP, A4>& a, int r, int c, int i) {
+  return nbh_tile_px<V, LP, A4>{a.p00 + (r - a.r00) * LP + (c - a.c00) * (int)sizeof(V), i * (int)sizeof(V)};
 }
-template <class V, int R, int C, int LP, int NPX> __device__ boxnbh_tile_px<V, R, C, LP> arg(stage<boxnbh_tile_acc<V, R, C, LP>, NPX>&, const boxnbh_tile_acc<V, R, C, LP>& a, int r, int c, int i) {
-  return boxnbh_tile_px<V, R, C, LP>{a.p00 + (r - a.r00) * LP + (c + i - a.c00) * (int)sizeof(V)};
+template <class V, int R, int C, int LP, bool A4, int NPX> __device__ boxnbh_tile_px<V, R, C, LP, A4> arg(stage<boxnbh_tile_acc<V, R, C, LP, A4>, NPX>&, const boxnbh_tile_acc<V, R, C, LP, A4>& a, int r, int c, int i) {
+  return boxnbh_tile_px<V, R, C, LP, A4>{a.p00 + (r - a.r00) * LP + (c - a.c00) * (int)sizeof(V), i * (int)sizeof(V)};
 }
 template <class F, class... X> __device__ __forceinline__ void call_lvalues(F& f, X&&... x) { f(x...); }  // kernels may take `auto&`
 
@@ -174,12 +196,12 @@ template <class A> struct nbh_traits { static constexpr bool value = false; stat
 template <class V> struct nbh_traits<nbh_acc<V>> {
   static constexpr bool value = true; typedef V pixel;
   static constexpr int reach = 0;   // unknown: vouched for by `_nbh_read_only`
-  template <int LP> using tile = nbh_tile_acc<V, LP>;
+  template <int LP, bool A4 = false> using tile = nbh_tile_acc<V, LP, A4>;
 };
 template <class V, int R, int C> struct nbh_traits<boxnbh_acc<V, R, C>> {
   static constexpr bool value = true; typedef V pixel;
   static constexpr int reach = (R / 2 > C / 2 ? R / 2 : C / 2);
-  template <int LP> using tile = boxnbh_tile_acc<V, R, C, LP>;
+  template <int LP, bool A4 = false> using tile = boxnbh_tile_acc<V, R, C, LP, A4>;
 };
 template <class... A> struct first_nbh;
 template <class A0, class... A> struct first_nbh<A0, A...> {
@@ -192,13 +214,14 @@ template <class A, class T> __device__ __forceinline__ const typename std::condi
   if constexpr (nbh_traits<A>::value) return t; else return a;
 }
 
-template <int NPXK, class F, class... A>
+// A4: every lane's chunk of 4 pixels starts 4-byte aligned in the tile and the rows have no ragged tail (the launcher checks): 3-byte pixels are tapped out of aligned dwords (tile_tap)
+template <int NPXK, bool A4, class F, class... A>
 __global__ __launch_bounds__(256) void pixel_wise_tile_kernel(F f, int r0, int c0, int nrows, int ncols, A... acc) {
   typedef typename first_nbh<A...>::type NA;
   typedef typename nbh_traits<NA>::pixel V;
   typedef tile_geom<V, NPXK> G;
   constexpr int ES = G::ES, TW = G::TW, LP = G::LP, H = kTileH, TH = kTileRows, ROWS = TH + 2 * H, CPR = LP / 16;
-  __shared__ __attribute__((aligned(16))) char lds[ROWS * LP];
+  __shared__ __attribute__((aligned(16))) char lds[ROWS * LP + 16];   // (+ 16: tile_tap<.., true> reads the whole dword that holds a pixel's last byte)
   const NA& nb = first_nbh<A...>::get(acc...);
   const int tr = r0 + blockIdx.y * TH, tc = c0 + blockIdx.x * TW;
   // ---- stage: tile row rr holds image row tr - H + rr from pixel column tc - H on, at the byte offset `shift` (its global address modulo 16)
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(256) void pixel_wise_tile_kernel(F f, int r0, int c
   }
   __syncthreads();
   // ---- compute: wave w takes rows [w TH/4, (w + 1) TH/4) of the tile, a lane NPXK consecutive pixels
-  const typename nbh_traits<NA>::template tile<LP> ta{lds + shift + H * LP + H * ES, tr, tc};
+  const typename nbh_traits<NA>::template tile<LP, A4> ta{lds + shift + H * LP + H * ES, tr, tc};
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = tc + lane * NPXK;
   if (c >= c0 + ncols) return;
@@ -387,8 +410,13 @@ template <bool NBH_RO, class F, class... A> void launch(F f, int r0, int c0, int
       constexpr int NPXK = NPX % 4 == 0 ? 4 : 1;
       const bool vec = al && NPXK > 1;
       dim3 grid((ncols + 64 * (vec ? NPXK : 1) - 1) / (64 * (vec ? NPXK : 1)), (nrows + kTileRows - 1) / kTileRows);
-      if (vec) hipLaunchKernelGGL((pixel_wise_tile_kernel<NPXK, F, A...>), grid, dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
-      else hipLaunchKernelGGL((pixel_wise_tile_kernel<1, F, A...>), grid, dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
+      // 3-byte pixels, 4 per lane: a chunk starts 4-byte aligned in the tile when its first byte does in memory (16-byte aligned rows, c0 a multiple of 4: 12-byte chunks)
+      constexpr bool kA4 = sizeof(PV) == 3 && NPXK == 4 && kTileH % 4 == 0;
+      static const bool a4off = [] { const char* e = getenv("VPP_PW_TILE_A4"); return e && e[0] == '0'; }();   // A/B switch for the tests and the benchmark
+      if (kA4 && vec && !a4off && ((size_t)nb.p0 % 16) == 0 && c0 % 4 == 0 && ncols % 4 == 0)
+        hipLaunchKernelGGL((pixel_wise_tile_kernel<NPXK, kA4, F, A...>), grid, dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
+      else if (vec) hipLaunchKernelGGL((pixel_wise_tile_kernel<NPXK, false, F, A...>), grid, dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
+      else hipLaunchKernelGGL((pixel_wise_tile_kernel<1, false, F, A...>), grid, dim3(256), 0, (hipStream_t)device::stream(), f, r0, c0, nrows, ncols, acc...);
       const hipError_t e = hipGetLastError();
       if (e != hipSuccess) throw std::runtime_error(std::string("pixel_wise (device, tiled): launch failed: ") + hipGetErrorString(e));
       device::call_done();   // queued, not drained: vpp/core/device.hh
