@@ -70,7 +70,7 @@ template <> struct tile_tap<vector<unsigned char, 3>, true> {
     const unsigned lo = w[wi], hi = sh >= 2 ? w[wi + 1] : 0u;
     type r;   // component j is byte sh + j of the dword pair: one bit-field extract (or a byte-select operand of the callable's own add) each
 #pragma unroll
-    for (int j = 0; j < 3; j++) r.v[j] = (unsigned char)(sh + j < 4 ? lo >> (8 * (sh + j)) : hi >> (8 * (sh + j - 4)));
+    for (int j = 0; j < 3; j++) r.v[j] = (unsigned char)(sh + j < 4 ? __builtin_amdgcn_ubfe(lo, 8u * (unsigned)(sh + j), 8u) : __builtin_amdgcn_ubfe(hi, 8u * (unsigned)(sh + j - 4), 8u));
     return r;
   }
 };
