@@ -355,8 +355,9 @@ struct Swar3 { Chain ch; int TX, TY, tx_lo, tx_hi, ty_lo, ty_hi, tiles_x8, wide;
 // WIDE (round 6, copy producer, 16-byte aligned source and level 0): the patch is 41 rows of 96 bytes from column 64 tx - 16 — six 16-byte pieces per row, 246 loads, ONE
 // pass of the workgroup — instead of 41 x 22 dwords from column 64 tx - 12 in 3.5 passes with a division, two tests and a 4-byte store per dword: the staging was a third of
 // the kernel's instructions.  The four bytes more on either side are read and never used.
+constexpr int kSwarLds = 41 * 24 + 41 * 10 + 19 * 10 + 19 * 4 + 12;   // dwords: the packed path's stage buffers (one allocation for both staging variants)
 template <class FAST, class SRC, bool WIDE>
-__device__ __forceinline__ void pyramid_swar3_body_(const Swar3& a, const int bid) {
+__device__ __forceinline__ void pyramid_swar3_body_(const Swar3& a, const int bid, uint32_t* __restrict__ lds) {
   constexpr int R0 = 41, W0 = WIDE ? 24 : 22, XO = WIDE ? 1 : 0, G1 = 10, R1 = 19, G2 = 4;   // level-0 patch rows / dwords per row (XO: dword of the patch's column 64 tx - 12), level-1 groups per row / patch rows, level-2 groups
   int ty, tx;
   {
@@ -376,7 +377,9 @@ __device__ __forceinline__ void pyramid_swar3_body_(const Swar3& a, const int bi
       return;
     }
   }
-  __shared__ __attribute__((aligned(16))) uint32_t s0[R0 * W0], sh0[R0 * G1], s1[R1 * G1], sh1[R1 * G2];
+  constexpr int O1 = (R0 * W0 + 3) & ~3, O2 = (O1 + R0 * G1 + 3) & ~3, O3 = (O2 + R1 * G1 + 3) & ~3;   // the four stage buffers, 16-byte aligned, in the caller's one allocation
+  static_assert(O3 + R1 * G2 <= kSwarLds, "the stages' LDS");
+  uint32_t* const s0 = lds; uint32_t* const sh0 = lds + O1; uint32_t* const s1 = lds + O2; uint32_t* const sh1 = lds + O3;
   const DImg L0 = a.ch.lv[0], L1 = a.ch.lv[1], L2 = a.ch.lv[2], src = a.ch.src;
   const int r2 = 8 * ty, c2 = 16 * tx;
   const int pr0 = 4 * r2 - 6, pc0 = 4 * c2 - 12;   // origin of the level-0 patch; level-1 patch: rows from 2 r2 - 2, columns from 2 c2 - 4
@@ -425,8 +428,9 @@ __device__ __forceinline__ void pyramid_swar3_body_(const Swar3& a, const int bi
 
 template <class FAST, class SRC>
 __device__ __forceinline__ void pyramid_swar3_body(const Swar3& a, const int bid) {
-  if constexpr (std::is_same<FAST, CopyFast>::value) { if (a.wide) { pyramid_swar3_body_<FAST, SRC, true>(a, bid); return; } }
-  pyramid_swar3_body_<FAST, SRC, false>(a, bid);
+  __shared__ __attribute__((aligned(16))) uint32_t s_swar[kSwarLds];
+  if constexpr (std::is_same<FAST, CopyFast>::value) { if (a.wide) { pyramid_swar3_body_<FAST, SRC, true>(a, bid, s_swar); return; } }
+  pyramid_swar3_body_<FAST, SRC, false>(a, bid, s_swar);
 }
 
 // interior tile ranges of the packed path along one axis: tiles [lo, hi) of `step2` level-2 pixels whose level-0 patch (from 4 t0 - lead0, `span0`
