@@ -640,6 +640,26 @@ __device__ __forceinline__ void append_unique(uint32_t* __restrict__ flags, unsi
     if (push) store_u32_sc1(list + base + __popcll(b & ((1ull << lane) - 1ull)), (uint32_t)target);
   }
 }
+// The two appends that end a pass — the next round's queue and the list of changes — as ONE exchange and ONE slot atomic per wave (round 6): a lane carries at most one of
+// the two (the caller puts a job's change on a lane that never carries a queue target), so both lists' exchanges are one instruction, and so are the two leaders' counter
+// atomics: two memory round trips at the end of a pass instead of four.  Called at a point every lane of the wave reaches.
+__device__ __forceinline__ void append_either(uint32_t* __restrict__ qflags, unsigned* qcounter, uint32_t* __restrict__ qlist, int target,
+                                              uint32_t* __restrict__ cflags, unsigned* ccounter, uint32_t* __restrict__ clist, int chg) {
+  const bool isq = target >= 0, isc = !isq && chg >= 0;
+  bool push = false;
+  if (isq || isc) push = __hip_atomic_exchange(isq ? &qflags[target] : &cflags[chg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+  const unsigned long long bq = __ballot(push && isq), bc = __ballot(push && isc);
+  if (!(bq | bc)) return;
+  const int lane = __lane_id();
+  const int lq = bq ? __ffsll((long long)bq) - 1 : -1, lc = bc ? __ffsll((long long)bc) - 1 : -2;
+  unsigned base = 0;
+  if (lane == lq || lane == lc) base = __hip_atomic_fetch_add(lane == lq ? qcounter : ccounter, (unsigned)__popcll(lane == lq ? bq : bc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned baseq = __shfl(base, max(lq, 0)), basec = __shfl(base, max(lc, 0));
+  if (push) {
+    if (isq) store_u32_sc1(qlist + baseq + __popcll(bq & ((1ull << lane) - 1ull)), (uint32_t)target);
+    else store_u32_sc1(clist + basec + __popcll(bc & ((1ull << lane) - 1ull)), (uint32_t)chg);
+  }
+}
 // the queue of round parity `q`
 __device__ __forceinline__ void enqueue_targets(const RoundArrays& a, SweepCtl* ctl, int q, int target) { append_unique(a.qflag[q], &ctl->count[q], a.Q[q], target); }
 
@@ -945,10 +965,9 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
       const int qi = cell / NJ, qj = cell - qi * NJ;
       target = round_job<WS, false, true>(i1, i2, ws, m, patch, forward, NI, NJ, a, 0, a.B[1], a.B[0], cell, j, s_union[tid >> 3], stats, false, &changed,
                                           s_tile + (qi - ty * kSweepTile + 1) * kTilePitch + (qj - tx * kSweepTile + 1));
-      if (changed && j == 0) chg = cell;
+      if (changed && j == (forward ? 1 : 6)) chg = cell;   // (a lane that never carries a queue target: round_job's are the cell's own lane 0 / 7 and the LATER neighbours' lanes)
     }
-    enqueue_targets(a, ctl, 1, target);
-    append_unique(a.cflag, &ctl->nchanged, a.chg, chg);
+    append_either(a.qflag[1], &ctl->count[1], a.Q[1], target, a.cflag, &ctl->nchanged, a.chg, chg);
   }
   // ---- arrive; everybody but the last arriver and the stayers leaves
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1032,10 +1051,9 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
         const int cell = (int)load_u32_sc1(Qcur + job);
         bool changed;
         target = round_job<WS, false>(i1, i2, ws, m, patch, forward, NI, NJ, a, k, Bprev, Bcur, cell, j, s_union[tid >> 3], stats, true, &changed);
-        if (changed && j == 0) chg = cell;
+        if (changed && j == (forward ? 1 : 6)) chg = cell;
       }
-      enqueue_targets(a, ctl, par ^ 1, target);
-      append_unique(a.cflag, &ctl->nchanged, a.chg, chg);
+      append_either(a.qflag[par ^ 1], &ctl->count[par ^ 1], a.Q[par ^ 1], target, a.cflag, &ctl->nchanged, a.chg, chg);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
