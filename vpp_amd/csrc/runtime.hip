@@ -17,6 +17,19 @@ static std::mutex g_tune_mu;
 static std::map<std::string, int> g_tune;
 int tuning(const char* name, int dflt) {
   std::lock_guard<std::mutex> l(g_tune_mu);
+  // VPP_TUNE="knob=value,knob=value" presets the knobs of vpp_set_tuning for programs that cannot call it (the C++ harnesses under tools/ A/B runs); read once
+  static const bool env_read = [] {
+    if (const char* e = getenv("VPP_TUNE")) {
+      std::string t(e);
+      for (size_t i = 0; i < t.size();) {
+        const size_t c = t.find(',', i), end = c == std::string::npos ? t.size() : c, eq = t.find('=', i);
+        if (eq != std::string::npos && eq < end) g_tune[t.substr(i, eq - i)] = atoi(t.substr(eq + 1, end - eq - 1).c_str());
+        i = end + 1;
+      }
+    }
+    return true;
+  }();
+  (void)env_read;
   auto it = g_tune.find(name);
   return it == g_tune.end() ? dflt : it->second;
 }
