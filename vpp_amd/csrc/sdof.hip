@@ -970,6 +970,10 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
     append_either(a.qflag[1], &ctl->count[1], a.Q[1], target, a.cflag, &ctl->nchanged, a.chg, chg);
   }
   // ---- arrive; everybody but the last arriver and the stayers leaves
+  // (the queue's length — only whether it is worth staying — is requested with the pass's last stores, not behind them: a round trip less on the path of the tile that
+  // finishes last; it may miss what this workgroup's other waves are still appending, which the decision can live with)
+  unsigned queued = 0;
+  if (tid == 0 && n0) queued = __hip_atomic_load(&ctl->count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (stats == 1 && tid == 0 && n0) sweep_log(252u, n0);
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
     unsigned flags = 0, ticket = 0;
     // (what this workgroup wrote for the others — records, queue, lists — went out as write-through stores and every wave has waited for its own: no release)
     // (only a workgroup that had candidates itself looks at the queue: the others — nearly all of them at the finest scale — arrive one memory round trip earlier)
-    if (n0 && __hip_atomic_load(&ctl->count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > stay_above) {
+    if (n0 && queued > stay_above) {
       const unsigned t = __hip_atomic_fetch_add(&ctl->reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // before the arrival: the last arriver reads the final count
       // The registration must be PERFORMED before this workgroup's arrival below is: the two atomics go to different cache lines (different channels), and nothing
       // else orders them — an arrival that overtook the registration would let the last arriver read a short `reg` and publish a wrong nreg.  A returning atomic
