@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "tracker_device.hpp"
 #include <mutex>
+#include <type_traits>
 using namespace vpp_amd;
 
 namespace {
@@ -816,6 +817,68 @@ __global__ __launch_bounds__(256) void blockwise_maxima_kernel(DImg A, int bs, i
   if (vmax > 0) A.row<V>(pr)[pc] = vmax;
 }
 
+// The same filter with the image's rows read and written as rows (round 6).  A workgroup owns one row of blocks x a span of BPW whole blocks (<= 256 dwords of a row):
+// a thread takes one dword — 4 / 2 / 1 pixels — of each of the block row's bs rows, coalesced; every positive pixel raises its block's key {value bits, ~position in
+// the block's scan order} with one LDS atomic max (largest value, earliest position: the reference's strict `>` in row-major order; positive floats order like their
+// bits); after a barrier the thread writes its dwords back — zero but for a winner that falls into them.  One lane per block read a 4K frame's 10 x 10 blocks as ten 10-byte
+// segments 3 840 bytes apart and wrote them the same way: 23 us for 16.6 MB.
+template <class V>
+__global__ __launch_bounds__(256) void blockwise_maxima_rows_kernel(DImg A, int bs, int nbc, int BPW) {
+  constexpr int NPX = 4 / (int)sizeof(V);
+  __shared__ unsigned long long keys[256];   // BPW <= 256 NPX / bs <= 256 (bs >= 4)
+  const int br = blockIdx.y, r0 = br * bs, r1 = min(r0 + bs, A.nr);
+  const int bc0 = blockIdx.x * BPW, nb = min(BPW, nbc - bc0);          // this workgroup's blocks
+  const int span0 = bc0 * bs, span1 = min(span0 + nb * bs, A.nc);      // and their columns
+  const int t = threadIdx.x, c = span0 + t * NPX;
+  if (t < nb) keys[t] = 0ull;
+  __syncthreads();
+  const int n = min(NPX, span1 - c);                                    // pixels of this thread's dword inside the span (<= 0: none)
+  int lb[NPX], lc[NPX];                                                 // per pixel: block within the span, column within the block
+#pragma unroll
+  for (int k = 0; k < NPX; k++) { lb[k] = (t * NPX + k) / bs; lc[k] = t * NPX + k - lb[k] * bs; }
+  auto bits = [](V v) -> uint32_t { if constexpr (std::is_same<V, float>::value) return __float_as_uint(v); else return (uint32_t)v; };
+  if (n > 0) {
+    // rows in batches of 8: the batch's loads are all requested before the first is looked at (a runtime-trip loop of load -> test -> atomic ran one memory round
+    // trip per row; keeping a thread's per-block maxima in registers instead of the LDS atomics measured slower: 10.4 -> 12.4 us on a 4K u8 frame)
+    for (int rb = r0; rb < r1; rb += 8) {
+      V v[8][NPX];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const V* row = A.row<V>(min(rb + q, r1 - 1)) + c;
+        if (n == NPX) __builtin_memcpy(v[q], row, 4);
+        else { for (int k = 0; k < NPX; k++) v[q][k] = k < n ? row[k] : V(0); }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+#pragma unroll
+        for (int k = 0; k < NPX; k++)
+          if (rb + q < r1 && k < n && v[q][k] > V(0))
+            atomicMax(&keys[lb[k]], ((unsigned long long)bits(v[q][k]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)((rb + q - r0) * bs + lc[k])));
+    }
+  }
+  __syncthreads();
+  if (n <= 0) return;
+  // the winners that fall into this thread's dword: at most one per pixel's block
+  int wr[NPX]; uint32_t wv[NPX];
+#pragma unroll
+  for (int k = 0; k < NPX; k++) {
+    wr[k] = -1; wv[k] = 0;
+    if (k < n) {
+      const unsigned long long key = keys[lb[k]];
+      if (key) { const uint32_t pos = 0xFFFFFFFFu - (uint32_t)key; const int pr = (int)(pos / (uint32_t)bs), pc = (int)pos - pr * bs; if (pc == lc[k]) { wr[k] = pr; wv[k] = (uint32_t)(key >> 32); } }
+    }
+  }
+  auto from_bits = [](uint32_t b) -> V { if constexpr (std::is_same<V, float>::value) return __uint_as_float(b); else return (V)b; };
+  for (int r = r0; r < r1; r++) {
+    V* row = A.row<V>(r) + c;
+    V v[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; k++) v[k] = wr[k] == r - r0 ? from_bits(wv[k]) : V(0);
+    if (n == NPX) __builtin_memcpy(row, v, 4);
+    else { for (int k = 0; k < n; k++) row[k] = v[k]; }
+  }
+}
+
 thread_local Scratch g_scratch;
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -854,6 +917,25 @@ int vpp_blockwise_maxima_filter(const vpp_image_desc* img, int block_size, void*
   const unsigned grid = (unsigned)(((long long)nbr * nbc + 255) / 256);
   DImg A = dimg(img);
   hipStream_t st = as_stream(stream);
+  {  // rows as rows: blocks of 4 ... 256 dwords' worth of pixels (a workgroup's span is whole blocks); narrower / wider blocks keep one lane per block
+    const int npx = 4 / dtype_size(img->dtype);
+    if (block_size >= 4 && block_size <= 256 * npx && nbr <= 65535 && tuning("blockwise_maxima.rows", 1)) {
+      const int BPW = (256 * npx) / block_size;
+      const dim3 g((unsigned)((nbc + BPW - 1) / BPW), (unsigned)nbr);
+      switch (img->dtype) {
+        case VPP_U8: blockwise_maxima_rows_kernel<uint8_t><<<g, 256, 0, st>>>(A, block_size, nbc, BPW); break;
+        case VPP_I8: blockwise_maxima_rows_kernel<int8_t><<<g, 256, 0, st>>>(A, block_size, nbc, BPW); break;
+        case VPP_U16: blockwise_maxima_rows_kernel<uint16_t><<<g, 256, 0, st>>>(A, block_size, nbc, BPW); break;
+        case VPP_I16: blockwise_maxima_rows_kernel<int16_t><<<g, 256, 0, st>>>(A, block_size, nbc, BPW); break;
+        case VPP_I32: blockwise_maxima_rows_kernel<int32_t><<<g, 256, 0, st>>>(A, block_size, nbc, BPW); break;
+        case VPP_U32: blockwise_maxima_rows_kernel<uint32_t><<<g, 256, 0, st>>>(A, block_size, nbc, BPW); break;
+        case VPP_F32: blockwise_maxima_rows_kernel<float><<<g, 256, 0, st>>>(A, block_size, nbc, BPW); break;
+        default: VPP_REQUIRE(false, VPP_ERR_UNSUPPORTED, "vpp_blockwise_maxima_filter: unsupported dtype %d", img->dtype);
+      }
+      VPP_LAUNCH_CHECK();
+      return VPP_OK;
+    }
+  }
   switch (img->dtype) {
     case VPP_U8: blockwise_maxima_kernel<uint8_t><<<grid, 256, 0, st>>>(A, block_size, nbr, nbc); break;
     case VPP_I8: blockwise_maxima_kernel<int8_t><<<grid, 256, 0, st>>>(A, block_size, nbr, nbc); break;
