@@ -219,7 +219,8 @@ def test_fast9_dense_4k_is_the_corrected_ring_detector(lib):
 
 
 @pytest.mark.parametrize("dtype", [vi.U8, vi.I8, vi.U16, vi.I16, vi.I32, vi.U32, vi.F32])
-@pytest.mark.parametrize("shape,bs", [((20, 30), 10), ((23, 31), 10), ((9, 9), 4), ((5, 40), 7), ((16, 16), 1), ((70, 300), 300)])
+# (the last two: several workgroup spans per row of blocks, blocks cut by the right / bottom edge — blockwise_maxima_rows_kernel; block sizes 1 and 300 on 4-byte pixels keep one lane per block)
+@pytest.mark.parametrize("shape,bs", [((20, 30), 10), ((23, 31), 10), ((9, 9), 4), ((5, 40), 7), ((16, 16), 1), ((70, 300), 300), ((37, 2100), 10), ((41, 1300), 33)])
 def test_blockwise_maxima_filter_matches_oracle(lib, orc, dtype, shape, bs):
     signed = dtype in (vi.I8, vi.I16, vi.I32, vi.F32)
     img = rand_image(*shape, dtype, 1, border=2, seed=bs + shape[1], lo=-3 if signed else 0, hi=6, fill_border=True)
