@@ -122,34 +122,20 @@ __global__ __launch_bounds__(256) void ve_count_kernel(int n, const int32_t* __r
   __syncthreads();
   if (threadIdx.x == 0) blocksum[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
-__global__ __launch_bounds__(1024) void ve_scan_kernel(int nblocks, int32_t* __restrict__ blocksum, int32_t* __restrict__ total) {
-  // exclusive scan of the block counts by one workgroup, 1024 entries per pass
-  __shared__ int s[1024];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nblocks; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < nblocks ? blocksum[i] : 0;
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      const int t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
-      __syncthreads();
-      s[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < nblocks) blocksum[i] = carry + s[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += s[1023];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *total = carry;
-}
-__global__ __launch_bounds__(256) void ve_index_kernel(int n, const int32_t* __restrict__ age, const int32_t* __restrict__ blocksum, int32_t* __restrict__ newidx) {
-  // new index of every alive entry: block offset + rank inside the block (waves in order, lanes in order)
+__global__ __launch_bounds__(256) void ve_index_kernel(int n, const int32_t* __restrict__ age, const int32_t* __restrict__ blocksum, int32_t* __restrict__ newidx, int32_t* __restrict__ total) {
+  // new index of every alive entry: block offset + rank inside the block (waves in order, lanes in order).  The block offset = the sum of the COUNTS of the blocks
+  // before this one, summed here (a few dozen words out of L2; round 6: the single-workgroup scan launch between the count and this pass is gone); the last block leaves the total.
   __shared__ int wsum[4];
-  int run = blocksum[blockIdx.x];
+  __shared__ int psum[4];
+  int run;
+  {
+    int s = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) s += blocksum[j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) psum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    run = psum[0] + psum[1] + psum[2] + psum[3];
+  }
   for (int k = 0; k < kScanBlock / 256; k++) {
     const int i = blockIdx.x * kScanBlock + k * 256 + threadIdx.x;
     const bool a = i < n && age[i] > 0;
@@ -163,6 +149,7 @@ __global__ __launch_bounds__(256) void ve_index_kernel(int n, const int32_t* __r
     run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     __syncthreads();
   }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = run;
 }
 
 __global__ __launch_bounds__(256) void ve_fill16_kernel(uint4* __restrict__ p, size_t units, uint32_t v) {
@@ -394,8 +381,7 @@ static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
     const int nblocks = (n + kScanBlock - 1) / kScanBlock;
     if (n > 0) {
       ve_count_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum);
-      ve_scan_kernel<<<1, 1024, 0, st>>>(nblocks, ve->blocksum, ve->dcount);
-      ve_index_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum, ve->newidx);
+      ve_index_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum, ve->newidx, ve->dcount);
     } else { rc = device_fill(ve->dcount, 0, 4, st); if (rc != VPP_OK) return rc; }
     if (det_cap > ve->det_cap) {
       ve_quiesce(ve);
