@@ -78,16 +78,19 @@ namespace {
 template <bool TRAJ>
 __global__ __launch_bounds__(256) void ve_finish_kernel(int n, int32_t* __restrict__ pos, int32_t* __restrict__ vel, int32_t* __restrict__ age, const int32_t* __restrict__ fpos,
                                                         const uint8_t* __restrict__ fvalid, MergeLists lists, DImg frame2, int th, float* __restrict__ ring,
-                                                        int32_t* __restrict__ head, int32_t* __restrict__ len, uint8_t* __restrict__ alive, int slots, int max_len) {
+                                                        int32_t* __restrict__ head, int32_t* __restrict__ len, uint8_t* __restrict__ alive, int slots, int max_len,
+                                                        int32_t* __restrict__ blocksum) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  int a = 0;
+  if (i < n) {
   const int nr = frame2.nr, nc = frame2.nc;
   const bool merged = merge_removes(lists, i);
   const int p0 = pos[2 * i], p1 = pos[2 * i + 1];
   const int r = fpos[2 * i], c = fpos[2 * i + 1];
   const bool inside = r >= 0 && c >= 0 && r < nr && c < nc;
   const int score = inside ? fast9_score_at(frame2, r, c, th) : fast9_score_at(frame2, p0, p1, th);   // an out-of-frame match removes the keypoint where it was (:50-53)
-  int a = age[i], q0 = p0, q1 = p1;
+  int q0 = p0, q1 = p1;
+  a = age[i];
   if (fvalid[i]) {  // the match callback (video_extruder.hpp:48-53)
     if (inside) {   // keypoint_container::move (keypoint_container.hpp:136-150)
       vel[2 * i] = r - p0; vel[2 * i + 1] = c - p1;
@@ -109,28 +112,28 @@ __global__ __launch_bounds__(256) void ve_finish_kernel(int n, int32_t* __restri
       len[i] = l;
     } else alive[i] = 0;  // die() (:132)
   }
+  }
+  // a re-detection frame's compaction starts from the number of entries this workgroup leaves alive (round 6: the count pass that re-read every age is gone)
+  if (!TRAJ && blocksum) {
+    __shared__ int wcount[4];
+    const unsigned long long b = __ballot(a > 0);
+    if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+  }
 }
 
 // ---- compaction: alive entries keep their order (keypoint_container.hpp:22-55) -----------------------------------------
 constexpr int kScanBlock = 1024;
-__global__ __launch_bounds__(256) void ve_count_kernel(int n, const int32_t* __restrict__ age, int32_t* __restrict__ blocksum) {
-  __shared__ int s[4];
-  int c = 0;
-  for (int k = 0; k < kScanBlock / 256; k++) { const int i = blockIdx.x * kScanBlock + k * 256 + threadIdx.x; c += (i < n && age[i] > 0); }
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) blocksum[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
-}
 __global__ __launch_bounds__(256) void ve_index_kernel(int n, const int32_t* __restrict__ age, const int32_t* __restrict__ blocksum, int32_t* __restrict__ newidx, int32_t* __restrict__ total) {
   // new index of every alive entry: block offset + rank inside the block (waves in order, lanes in order).  The block offset = the sum of the COUNTS of the blocks
-  // before this one, summed here (a few dozen words out of L2; round 6: the single-workgroup scan launch between the count and this pass is gone); the last block leaves the total.
+  // before this one, summed here (a few hundred words out of L2, left per 256 entries by ve_finish_kernel; round 6: the count pass and the single-workgroup scan launch in front of this pass are gone); the last block leaves the total.
   __shared__ int wsum[4];
   __shared__ int psum[4];
   int run;
   {
     int s = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) s += blocksum[j];
+    for (int j = threadIdx.x; j < (int)blockIdx.x * (kScanBlock / 256); j += 256) s += blocksum[j];   // (counts per 256 entries: ve_finish_kernel's workgroups)
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) psum[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -229,7 +232,7 @@ int ve_reserve(vpp_video_extruder* ve, int want, hipStream_t st) {
   if (rc == VPP_OK) rc = dalloc(&nw.fdist, ncap);
   if (rc == VPP_OK) rc = dalloc(&nw.scores, ncap);
   if (rc == VPP_OK) rc = dalloc(&nw.newidx, ncap);
-  if (rc == VPP_OK) rc = dalloc(&nw.blocksum, (size_t)ncap / kScanBlock + 2);
+  if (rc == VPP_OK) rc = dalloc(&nw.blocksum, (size_t)ncap / 256 + 2);   // alive counts per 256 entries (ve_finish_kernel's workgroups)
   if (rc == VPP_OK) rc = dalloc(&nw.fvalid, ncap);
   if (rc == VPP_OK) rc = dalloc(&nw.merged, ncap);
   if (rc != VPP_OK) { release(nw); return rc; }
@@ -356,9 +359,9 @@ static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
     if (rc != VPP_OK) return rc;
     const MergeLists lists{link.head, link.next, link.age_now, link.cell_of};
     if (detect) ve_finish_kernel<false><<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, lists, dimg(frame2), p->detector_th, ve->tring[c],
-                                                                           ve->thead[c], ve->tlen[c], ve->talive[c], ve->ring, p->max_trajectory_length);
+                                                                           ve->thead[c], ve->tlen[c], ve->talive[c], ve->ring, p->max_trajectory_length, ve->blocksum);
     else ve_finish_kernel<true><<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, lists, dimg(frame2), p->detector_th, ve->tring[c],
-                                                                  ve->thead[c], ve->tlen[c], ve->talive[c], ve->ring, p->max_trajectory_length);
+                                                                  ve->thead[c], ve->tlen[c], ve->talive[c], ve->ring, p->max_trajectory_length, nullptr);
   }
   if (detect) {  // re-detection away from every container entry (:94-119)
     const int s = p->keypoint_spacing;
@@ -380,7 +383,6 @@ static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
     // when it next needs the container's size (ve_resolve)
     const int nblocks = (n + kScanBlock - 1) / kScanBlock;
     if (n > 0) {
-      ve_count_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum);
       ve_index_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum, ve->newidx, ve->dcount);
     } else { rc = device_fill(ve->dcount, 0, 4, st); if (rc != VPP_OK) return rc; }
     if (det_cap > ve->det_cap) {
