@@ -882,12 +882,65 @@ constexpr int kSweepTile = 16;   // a workgroup's cells: a 16 x 16 tile of the s
                                  // cells 256 candidates, 8 passes of round 0 one after the other: measured 90 us for the middle scale of the 4K bench scene)
 constexpr unsigned kGenFinal = 0xFFFFFFFFu;   // round field of the message that ends the sweep for parked workgroups
 
+// The read-back of ONE keypoint (semi_dense_optical_flow.hpp:205-212; sdof_readback_kernel, and the fused sweep's read-back workgroups).  SC1: the maps are read
+// with L1-bypassing loads (what the same launch's flush wrote write-through).  LINK (the tracker's step): the keypoint's match is also threaded onto the merge step's
+// per-cell list (merge_link_one: the first pass of video_extruder.hpp:60-84 needs exactly what this thread holds — old and new position and whether it matched).
+template <bool LINK, bool SC1>
+__device__ __forceinline__ void readback_one(int i, const int32_t* __restrict__ kps, int div, int ms, const Maps& m, int32_t* __restrict__ out_pos, int32_t* __restrict__ out_dist,
+                                             uint8_t* __restrict__ out_valid, const MergeLinkArgs& link) {
+  const int k0 = kps[2 * i], k1 = kps[2 * i + 1];
+  const int q0 = k0 / div, q1 = k1 / div;  // :207-208
+  int o0 = k0, o1 = k1, d = 0; uint8_t v = 0;
+  // (mark, flow and distance in one round trip: unconditional loads at clamped coordinates)
+  const int c0 = min(max(q0, 0), m.mark.nr - 1), c1 = min(max(q1, 0), m.mark.nc - 1);
+  uint8_t mk; int f0, f1, dd;
+  if constexpr (SC1) {
+    mk = __hip_atomic_load(m.mark.row<uint8_t>(c0) + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long ff = __hip_atomic_load((unsigned long long*)(m.flow.row<int32_t>(c0) + 2 * c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f0 = (int)(unsigned)ff; f1 = (int)(unsigned)(ff >> 32);
+    dd = (int)__hip_atomic_load((uint32_t*)m.dist.row<int32_t>(c0) + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    mk = m.mark.row<uint8_t>(c0)[c1];
+    const int32_t* f = m.flow.row<int32_t>(c0) + 2 * c1;
+    f0 = f[0]; f1 = f[1]; dd = m.dist.row<int32_t>(c0)[c1];
+  }
+  if (m.mark.has(q0, q1) && mk) { o0 = k0 + f0 * ms; o1 = k1 + f1 * ms; d = dd; v = 1; }  // :210-211
+  out_pos[2 * i] = o0; out_pos[2 * i + 1] = o1; out_dist[i] = d; out_valid[i] = v;
+  if constexpr (LINK) merge_link_one(link, i, o0, o1, k0, k1, v != 0);
+}
+// The read-back riding in the flow's LAST sweep launch (round 6): `blocks` extra workgroups behind the sweep's tiles.  They leave at once to their keypoints when the
+// sweep is one that skips (the common case: the same word every tile tests), otherwise when the sweep's last workgroup has said so in `go` (the sweep's id; after
+// the flush's write-through stores and every stayer's acknowledgement).  One dependent launch less per pair; the maps they read were written by earlier launches
+// or by this launch's flush — write-through, and no workgroup of this launch reads a map before (no stale line in any XCD's L2).
+struct ReadbackTail { const int32_t* kps; int n, div, ms; int32_t* out_pos; int32_t* out_dist; uint8_t* out_valid; MergeLinkArgs link; int blocks; unsigned* go; };
+
 // NT threads per workgroup = NT / 8 jobs per pass (round 6).  512 where two such workgroups per CU hold every tile at once (at most 512 tiles; the kernel's ~106 VGPRs
 // leave a SIMD 4 waves): round 0 of a tile with 33 ... 64 candidates is ONE pass instead of two one after the other — the passes are latency chains, not work, and on the
 // 4K bench scene the middle scale's tiles that set round 0's length have 40-66 candidates (round 0 ends 15.7 instead of 21 us after the classification).  256 where the
 // tiles are more (the finest 4K scale: 1 296).  1 024 threads (one workgroup per CU, a second generation of tiles) measured 0.197 against 0.180 ms per pair.
-template <int WS, int NT = 256>
-__global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats, int nsub, unsigned stay_above, unsigned sweep_id, int may_skip) {
+// RB: 0 = the sweep alone; 1 / 2 = with the read-back's workgroups behind its tiles (2: the tracker's LINK form)
+template <int WS, int NT = 256, int RB = 0>
+__global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats, int nsub, unsigned stay_above, unsigned sweep_id, int may_skip,
+                                                        ReadbackTail rb) {
+  const unsigned ntiles = RB ? gridDim.x - (unsigned)rb.blocks : gridDim.x;   // the sweep's own workgroups
+  if constexpr (RB != 0) {
+    if (blockIdx.x >= ntiles) {
+      __shared__ unsigned s_go;
+      if (threadIdx.x == 0) {
+        const unsigned sw = may_skip ? load_u32_sc1(a.skip) : 0u;
+        unsigned ok = may_skip && (sw == sweep_id || sw == sweep_id + 1u) ? 1u : 0u;   // a sweep that skips has nothing to wait for
+        // (a few hundred workgroups poll one word while the sweep runs: a fifth of a microsecond apart, so that they do not crowd the sweep's own hand-offs out of that L2 channel)
+        for (unsigned spin = 0; !ok && spin < kSpinLimit; spin++) { ok = load_u32_sc1(rb.go) == sweep_id ? 1u : 0u; if (!ok) __builtin_amdgcn_s_sleep(8); }
+        if (!ok) raise_barrier_timeout(a);
+        s_go = ok;
+      }
+      __syncthreads();
+      if (!s_go) return;
+      const int i = (int)(blockIdx.x - ntiles) * NT + (int)threadIdx.x;
+      if (i < rb.n) readback_one<RB == 2, true>(i, rb.kps, rb.div, rb.ms, m, rb.out_pos, rb.out_dist, rb.out_valid, rb.link);
+      return;
+    }
+  }
   __shared__ unsigned s_val, s_nreg, s_flags, s_ncand, s_flushn, s_giveup;
   __shared__ unsigned long long s_gen;
   __shared__ uint32_t s_cand[256];
@@ -897,7 +950,7 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
   static_assert(kTilePitch == kSweepTile + 2, "tile + 1-cell halo");
   SweepCtl* const ctl = a.ctl;
   const int tid = threadIdx.x, j = tid & 7;
-  if (stats == 1 && blockIdx.x == 0 && tid == 0) sweep_log(255u, gridDim.x);
+  if (stats == 1 && blockIdx.x == 0 && tid == 0) sweep_log(255u, ntiles);
   if (tid == 0) { s_ncand = 0; s_giveup = 0; }
   // (round 5) A sweep that found no candidate at all changed nothing, so the next sweep of the same scale (same test, same maps) finds none either: the earlier
   // sweep says so in a.skip and this one returns after one load instead of classifying, arriving and handing the control block back (9 us -> the launch's own cost).
@@ -919,7 +972,7 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
   asm volatile("" ::: "memory");   // (the record loads stay above the skip test)
   __syncthreads();
   if (may_skip && (skip_word == sweep_id || skip_word == sweep_id + 1u)) {   // (+ 1: what workgroup 0 of this very launch writes below — every workgroup decides alike)
-    if (blockIdx.x == 0 && tid == 0) { store_u32_sc1(a.skip, sweep_id + 1u); if (stats == 1) sweep_log(250u, gridDim.x); }   // still nothing: the next one may skip as well
+    if (blockIdx.x == 0 && tid == 0) { store_u32_sc1(a.skip, sweep_id + 1u); if (stats == 1) sweep_log(250u, ntiles); }   // still nothing: the next one may skip as well
     return;
   }
   if (!own_in) own_rec = make_uint4(0u, 0u, 0u, 0u);
@@ -991,7 +1044,7 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
     }
     // Two-level arrival: returning atomics on ONE word retire at ~11 ns each (1 300 workgroups at the finest 4K scale: 14 us, measured 30 us per empty sweep); the
     // workgroups arrive on nsub counters, 128 bytes apart, and the last one of each (which also hands its counter back zeroed) on ctl->done.
-    const unsigned sc = blockIdx.x % (unsigned)nsub, expect = gridDim.x / (unsigned)nsub + (sc < gridDim.x % (unsigned)nsub ? 1u : 0u);
+    const unsigned sc = blockIdx.x % (unsigned)nsub, expect = ntiles / (unsigned)nsub + (sc < ntiles % (unsigned)nsub ? 1u : 0u);
     if (__hip_atomic_fetch_add(&a.sub[sc * kSubStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1) {
       __hip_atomic_store(&a.sub[sc * kSubStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nsub - 1) flags |= 2u;
@@ -1129,7 +1182,11 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
     store_cell16(a.pre + cell, c); store_cell16(a.B[0] + cell, c); store_cell16(a.B[1] + cell, c);   // (read by later launches only)
     const int ci = (int)cell / NJ, cj = (int)cell - ci * NJ;
     int32_t* f = m.flow.row<int32_t>(ci) + 2 * cj;   // the maps: written here only, one writer per cell
-    f[0] = c.f0; f[1] = c.f1; m.dist.row<int32_t>(ci)[cj] = c.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)c.mark;
+    if constexpr (RB != 0) {   // (write-through: this launch's read-back workgroups read them)
+      __hip_atomic_store((unsigned long long*)f, ((unsigned long long)(unsigned)c.f1 << 32) | (unsigned)c.f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((uint32_t*)m.dist.row<int32_t>(ci) + cj, (uint32_t)c.dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(m.mark.row<uint8_t>(ci) + cj, (uint8_t)c.mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { f[0] = c.f0; f[1] = c.f1; m.dist.row<int32_t>(ci)[cj] = c.dist; m.mark.row<uint8_t>(ci)[cj] = (uint8_t)c.mark; }
     a.cflag[cell] = 0;
   }
   if (ticket != 0) {   // registered and done: ticket 0 may hand the control block back
@@ -1143,28 +1200,17 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
     while (__hip_atomic_load(&ctl->ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != N0 - 1 && ++spin < kSpinLimit) __builtin_amdgcn_s_sleep(1);
     if (spin >= kSpinLimit) raise_barrier_timeout(a);
   }
+  if constexpr (RB != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's own share of the flush has been performed
   __syncthreads();
+  if (RB != 0 && tid == 0) store_u32_sc1(rb.go, sweep_id);   // the sweep is over, every changed cell is in the maps: the read-back workgroups may go
   if (tid < (int)(sizeof(SweepCtl) / 4)) ((unsigned*)ctl)[tid] = 0u;   // zero between sweeps
 }
 
-// LINK (the tracker's step): the keypoint's match is also threaded onto the merge step's per-cell list (merge_link_one: the first pass of
-// video_extruder.hpp:60-84 needs exactly what this thread holds — the keypoint's old and new position and whether it matched)
 template <bool LINK>
 __global__ __launch_bounds__(256) void sdof_readback_kernel(const int32_t* __restrict__ kps, int n, int div, int ms, Maps m,
                                                             int32_t* __restrict__ out_pos, int32_t* __restrict__ out_dist, uint8_t* __restrict__ out_valid, MergeLinkArgs link) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int k0 = kps[2 * i], k1 = kps[2 * i + 1];
-  const int q0 = k0 / div, q1 = k1 / div;  // :207-208
-  int o0 = k0, o1 = k1, d = 0; uint8_t v = 0;
-  // (mark, flow and distance in one round trip: unconditional loads at clamped coordinates)
-  const int c0 = min(max(q0, 0), m.mark.nr - 1), c1 = min(max(q1, 0), m.mark.nc - 1);
-  const uint8_t mk = m.mark.row<uint8_t>(c0)[c1];
-  const int32_t* f = m.flow.row<int32_t>(c0) + 2 * c1;
-  const int f0 = f[0], f1 = f[1], dd = m.dist.row<int32_t>(c0)[c1];
-  if (m.mark.has(q0, q1) && mk) { o0 = k0 + f0 * ms; o1 = k1 + f1 * ms; d = dd; v = 1; }  // :210-211
-  out_pos[2 * i] = o0; out_pos[2 * i + 1] = o1; out_dist[i] = d; out_valid[i] = v;
-  if constexpr (LINK) merge_link_one(link, i, o0, o1, k0, k1, v != 0);
+  if (i < n) readback_one<LINK, false>(i, kps, div, ms, m, out_pos, out_dist, out_valid, link);
 }
 
 thread_local Scratch g_scratch;
@@ -1290,7 +1336,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
       auto take = [&](size_t bytes) { uint8_t* q = cv.base ? cv.base + cv.off : nullptr; cv.off += (bytes + 255) / 256 * 256; return q; };
       ra.Q[0] = (uint32_t*)take(cells * 4); ra.Q[1] = (uint32_t*)take(cells * 4); ra.chg = (uint32_t*)take(cells * 4);
       ra_flags_off = cv.off;   // zero between sweeps: queue / change flags (self-cleaning) and the control block
-      ra.qflag[0] = (uint32_t*)take(cells * 4); ra.qflag[1] = (uint32_t*)take(cells * 4); ra.cflag = (uint32_t*)take(cells * 4); ra.sub = (unsigned*)take((size_t)kSubCounters * kSubStride * 4); ra.ctl = (SweepCtl*)take(sizeof(SweepCtl)); ra.skip = (unsigned*)take(4);
+      ra.qflag[0] = (uint32_t*)take(cells * 4); ra.qflag[1] = (uint32_t*)take(cells * 4); ra.cflag = (uint32_t*)take(cells * 4); ra.sub = (unsigned*)take((size_t)kSubCounters * kSubStride * 4); ra.ctl = (SweepCtl*)take(sizeof(SweepCtl)); ra.skip = (unsigned*)take(8);   // [0] the skip word, [1] the read-back tail's go word
       ra_flags_bytes = cv.off - ra_flags_off;
       ra.err = device_error_word();
     }
@@ -1301,7 +1347,8 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   if (peek_device_error()) invalidate_scratch_notes();
   if (nstrips > 1) { int rc = g_strips.ensure(nstrips - 1); if (rc != VPP_OK) return rc; }
   // single strip: the mark and owner maps of all scales are reset here in one launch (nothing writes a scale's maps before its own phase)
-  const bool reset_up_front = nstrips == 1 && 3 * (nscales - min_scale) + 1 <= kResetSegs && tuning("sdof.reset_up_front", 1);
+  const bool reset_up_front = nstrips == 1 && 3 * (nscales - min_scale) + 2 <= kResetSegs && tuning("sdof.reset_up_front", 1);
+  unsigned* const skip_go_words = ra.skip;   // [0] the sweeps' skip word, [1] the read-back tail's go word: zeroed with the maps at the start of every pair
   const bool claim_up_front = reset_up_front && world == 1 && tuning("sdof.claim_up_front", 1);
   // Self-cleaning owner maps (single strip, single rank): every descent hands its cell back empty, so the owner maps are not part of the reset and the
   // mark reset shares ONE launch with the claims.  The slot's note says whether the maps of this layout were left clean by a call that ran to its end;
@@ -1379,6 +1426,11 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
       ra.p[q] = (uint4*)link->head; ra.units[q] = (uint32_t)link_head_units; ra.value[q] = 0xFFFFFFFFu;
       ra.first_block[q] = blocks; blocks += (ra.units[q] + 255) / 256;
     }
+    if (fused_sweeps) {   // the skip / go words: a replayed launch graph carries the same sweep ids again — the words of its previous replay must not pass for this one's
+      const int q = ra.nseg++;
+      ra.p[q] = (uint4*)skip_go_words; ra.units[q] = 1u; ra.value[q] = 0u;
+      ra.first_block[q] = blocks; blocks += 1;
+    }
     ra.first_block[ra.nseg] = blocks;
     if (self_cleaning) {
       if (!owner_known_clean) {   // one launch for the owner maps of all scales (before the launch that claims into them)
@@ -1410,6 +1462,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
     sdof_claim_all_kernel<<<(n + 255) / 256, 256, 0, st>>>(kps, n, patchsize, ca);
     VPP_LAUNCH_CHECK();
   }
+  bool readback_done = false;   // the last fused sweep's launch carried the read-back (ReadbackTail)
   for (int scale = nscales - 1; scale >= min_scale; scale--) {  // :92
     const int scale_div = 1 << scale;
     const uint8_t zero = 0;
@@ -1499,12 +1552,27 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
               const int tiles = ((NI + kSweepTile - 1) / kSweepTile) * ((NJ + kSweepTile - 1) / kSweepTile);
               const int nsub = std::max(1, std::min(kSubCounters, tiles / 16));
               const int want_nt = tuning("sdof.sweep_threads", 0), nt = want_nt ? want_nt : (tiles <= 512 ? 512 : 256);
-              auto sweep = [&](auto NTc) {
-                constexpr int NT = decltype(NTc)::value;
-                sdof_sweep_kernel<WS, NT><<<tiles, NT, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs, tuning("sdof.stats", 0), nsub,
-                                                                (unsigned)tuning("sdof.sweep_stay", NT / 8), sweep_base + (unsigned)Ki, Ki > 0 && tuning("sdof.skip_empty", 1) ? 1 : 0);
+              // the pair's LAST sweep carries the read-back as extra workgroups (ReadbackTail): one dependent launch less
+              const bool tail = scale == min_scale && Ki == propagation - 1 && tuning("sdof.readback_tail", 1);
+              auto sweep = [&](auto NTc, auto RBc) {
+                constexpr int NT = decltype(NTc)::value, RB = decltype(RBc)::value;
+                ReadbackTail rb{};
+                if constexpr (RB != 0) {
+                  const int ms_ = 1 << min_scale;
+                  rb.kps = kps; rb.n = n; rb.div = patchsize * ms_; rb.ms = ms_; rb.out_pos = out_pos; rb.out_dist = out_dist; rb.out_valid = out_valid;
+                  if (link) rb.link = *link;
+                  rb.blocks = (n + NT - 1) / NT; rb.go = rs.skip + 1;
+                }
+                sdof_sweep_kernel<WS, NT, RB><<<tiles + (RB ? (n + NT - 1) / NT : 0), NT, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs,
+                                                                tuning("sdof.stats", 0), nsub, (unsigned)tuning("sdof.sweep_stay", NT / 8), sweep_base + (unsigned)Ki,
+                                                                Ki > 0 && tuning("sdof.skip_empty", 1) ? 1 : 0, rb);
               };
-              if (nt == 512) sweep(std::integral_constant<int, 512>()); else sweep(std::integral_constant<int, 256>());
+              using N512 = std::integral_constant<int, 512>; using N256 = std::integral_constant<int, 256>;
+              using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>; using R2 = std::integral_constant<int, 2>;
+              if (tail) {
+                readback_done = true;
+                if (nt == 512) { if (link) sweep(N512(), R2()); else sweep(N512(), R1()); } else { if (link) sweep(N256(), R2()); else sweep(N256(), R1()); }
+              } else if (nt == 512) sweep(N512(), R0()); else sweep(N256(), R0());
               continue;
             }
             sdof_classify_kernel<<<(cells + 255) / 256, 256, 0, st>>>(maps(0, scale), NI, NJ, rs);
@@ -1533,7 +1601,8 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
     VPP_LAUNCH_CHECK();
   }
   const int ms = 1 << min_scale;
-  if (link) {
+  if (readback_done) { /* queued with the last sweep */ }
+  else if (link) {
     if (!reset_up_front) {   // no up-front reset launch on this path: the heads get their own
       ResetArgs rh; rh.nseg = 1; rh.p[0] = (uint4*)link->head; rh.units[0] = (uint32_t)link_head_units; rh.value[0] = 0xFFFFFFFFu; rh.first_block[0] = 0;
       rh.first_block[1] = (rh.units[0] + 255) / 256;
