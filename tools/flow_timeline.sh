@@ -10,10 +10,12 @@ F=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python - "$F" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
+rows = [r for r in rows if '__amd_rocclr' not in r['Kernel_Name'] and 'at::native' not in r['Kernel_Name']]   # (the harness's own tensor copies between the calls)
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# rounds_ab runs winsize 9 (11 calls) then winsize 7; take the 10th call of winsize 9: find readback kernels
-rb = [i for i, r in enumerate(rows) if 'sdof_readback' in r['Kernel_Name']]
-end = rb[9]; start = rb[8] + 1
+# rounds_ab runs winsize 9 (11 calls) then winsize 7; take the 10th call of winsize 9: a call starts with the pyramid pair's launch (the read-back rides in the last sweep's
+# launch since round 6, so it no longer ends a call in the trace)
+py = [i for i, r in enumerate(rows) if 'pyramid_swar3_pair' in r['Kernel_Name']]
+start = py[9]; end = py[10] - 1
 t0 = int(rows[start]['Start_Timestamp']); prev = None
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
