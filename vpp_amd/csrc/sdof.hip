@@ -672,7 +672,7 @@ __device__ __forceinline__ void enqueue_targets(const RoundArrays& a, SweepCtl* 
 // in the workgroup's LDS copy of its tile + halo (tile_at: the cell's entry, row pitch kTilePitch, out-of-domain entries zero): no memory round trip before the windows.
 constexpr int kTilePitch = 18;   // kSweepTile + 2
 __device__ __forceinline__ Cell cell_of(const uint4& v) { return Cell{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
-template <int WS, bool MAPS, bool TILE = false>
+template <int WS, bool MAPS, bool TILE = false, int TPITCH = kTilePitch>
 __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws, const Maps& m, int patch, int forward, int NI, int NJ, const RoundArrays& a, int k,
                                          const Cell* __restrict__ Bprev, Cell* __restrict__ Bcur, int cell, int j, uint4* __restrict__ slot, int stats, bool clear_flag,
                                          bool* changed_out, const uint4* __restrict__ tile_at = nullptr) {
@@ -694,7 +694,7 @@ __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws,
   // Whether the neighbour is marked at all is read from its `pre` record (a sweep only ever turns a 2 into a 1, :179): the round buffers' records are written for
   // marked cells only (descents, the end of a sweep) and never reset — an unmarked cell's entry there holds anything and is not looked at.
   Cell nb{0, 0, 0, 0};
-  if constexpr (TILE) nb = cell_of(tile_at[dr * kTilePitch + dc]);
+  if constexpr (TILE) nb = cell_of(tile_at[dr * TPITCH + dc]);
   else if (in) {
     nb = load_cell16(a.pre + (size_t)q0 * NJ + q1);
     if (earlier) { const Cell bq = load_cell_sc1(Bprev + (size_t)q0 * NJ + q1); if ((nb.mark & 0xFF) != 0) nb = bq; }
@@ -919,7 +919,9 @@ struct ReadbackTail { const int32_t* kps; int n, div, ms; int32_t* out_pos; int3
 // 4K bench scene the middle scale's tiles that set round 0's length have 40-66 candidates (round 0 ends 15.7 instead of 21 us after the classification).  256 where the
 // tiles are more (the finest 4K scale: 1 296).  1 024 threads (one workgroup per CU, a second generation of tiles) measured 0.197 against 0.180 ms per pair.
 // RB: 0 = the sweep alone; 1 / 2 = with the read-back's workgroups behind its tiles (2: the tracker's LINK form)
-template <int WS, int NT = 256, int RB = 0>
+// TS: the tile's edge in cells, 16 or 32 (round 6: 32 where 16 x 16 tiles would be more than 512 workgroups — the finest 4K scale, whose cells are a quarter marked:
+// 336 workgroups of 512 threads instead of 1 296 of 256 to dispatch, classify and count in)
+template <int WS, int NT = 256, int RB = 0, int TS = kSweepTile>
 __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws, Maps m, int patch, int forward, int NI, int NJ, RoundArrays a, int stats, int nsub, unsigned stay_above, unsigned sweep_id, int may_skip,
                                                         ReadbackTail rb) {
   const unsigned ntiles = RB ? gridDim.x - (unsigned)rb.blocks : gridDim.x;   // the sweep's own workgroups
@@ -943,11 +945,12 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
   }
   __shared__ unsigned s_val, s_nreg, s_flags, s_ncand, s_flushn, s_giveup;
   __shared__ unsigned long long s_gen;
-  __shared__ uint32_t s_cand[256];
+  constexpr int TP = TS + 2, CPT = (TS * TS + NT - 1) / NT, NHALO = 4 * TS + 4;   // tile pitch with the halo, cells per thread, halo entries
+  static_assert(NHALO <= NT, "one halo entry per thread");
+  __shared__ uint32_t s_cand[TS * TS];
   constexpr int JOBS = NT / 8;
   __shared__ uint4 s_union[JOBS][kUnionRows];   // per 8-lane group: the candidate patch of a descent step (group_descent_staged)
-  __shared__ uint4 s_tile[kTilePitch * kTilePitch];       // the `pre` records of the workgroup's tile + halo
-  static_assert(kTilePitch == kSweepTile + 2, "tile + 1-cell halo");
+  __shared__ uint4 s_tile[TP * TP];       // the `pre` records of the workgroup's tile + halo
   SweepCtl* const ctl = a.ctl;
   const int tid = threadIdx.x, j = tid & 7;
   if (stats == 1 && blockIdx.x == 0 && tid == 0) sweep_log(255u, ntiles);
@@ -955,19 +958,22 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
   // (round 5) A sweep that found no candidate at all changed nothing, so the next sweep of the same scale (same test, same maps) finds none either: the earlier
   // sweep says so in a.skip and this one returns after one load instead of classifying, arriving and handing the control block back (9 us -> the launch's own cost).
   const unsigned skip_word = may_skip ? load_u32_sc1(a.skip) : 0u;   // (every lane: one address, one broadcast)
-  // This workgroup's 16 x 16 cells and their 1-cell halo, `pre` records, into LDS: a thread's own cell + (threads 0 .. 67) one halo cell.  Requested BEFORE the skip word
-  // is looked at (one round trip for both), read by the classification below and by round 0's jobs (round 6: the classification used to load a marked cell's 8
+  // This workgroup's TS x TS cells and their 1-cell halo, `pre` records, into LDS: a thread's own cell(s) + (threads 0 .. 4 TS + 3) one halo cell.  Requested BEFORE the skip
+  // word is looked at (one round trip for both), read by the classification below and by round 0's jobs (round 6: the classification used to load a marked cell's 8
   // neighbours behind the cell's own record, and every job of round 0 its records again: two and three dependent round trips).
-  const int tiles_x = (NJ + kSweepTile - 1) / kSweepTile;
+  const int tiles_x = (NJ + TS - 1) / TS;
   const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
-  const int li = tid / kSweepTile, lj = tid % kSweepTile;
-  const int ci = ty * kSweepTile + li, cj = tx * kSweepTile + lj;
   int hi_ = 0, hj_ = 0;   // the halo entry this thread fills
-  if (tid < kTilePitch) { hi_ = 0; hj_ = tid; } else if (tid < 2 * kTilePitch) { hi_ = kTilePitch - 1; hj_ = tid - kTilePitch; }
-  else if (tid < 2 * kTilePitch + kSweepTile) { hi_ = 1 + tid - 2 * kTilePitch; hj_ = 0; } else { hi_ = 1 + tid - 2 * kTilePitch - kSweepTile; hj_ = kTilePitch - 1; }
-  const int gi = ty * kSweepTile - 1 + hi_, gj = tx * kSweepTile - 1 + hj_;
-  const bool own_in = tid < kSweepTile * kSweepTile && ci < NI && cj < NJ, halo_in = tid < 2 * kTilePitch + 2 * kSweepTile && gi >= 0 && gj >= 0 && gi < NI && gj < NJ;
-  uint4 own_rec = *(const uint4*)(a.pre + (size_t)min(ci, NI - 1) * NJ + min(cj, NJ - 1));   // (threads past the tile's 256 cells: a clamped address, dropped)
+  if (tid < TP) { hi_ = 0; hj_ = tid; } else if (tid < 2 * TP) { hi_ = TP - 1; hj_ = tid - TP; }
+  else if (tid < 2 * TP + TS) { hi_ = 1 + tid - 2 * TP; hj_ = 0; } else { hi_ = 1 + tid - 2 * TP - TS; hj_ = TP - 1; }
+  const int gi = ty * TS - 1 + hi_, gj = tx * TS - 1 + hj_;
+  const bool halo_in = tid < NHALO && gi >= 0 && gj >= 0 && gi < NI && gj < NJ;
+  uint4 own_rec[CPT];   // (cells past the tile / the domain: a clamped address, dropped)
+#pragma unroll
+  for (int q = 0; q < CPT; q++) {
+    const int cell_l = tid + q * NT, li = cell_l / TS, lj = cell_l - li * TS;
+    own_rec[q] = *(const uint4*)(a.pre + (size_t)min(ty * TS + li, NI - 1) * NJ + min(tx * TS + lj, NJ - 1));
+  }
   uint4 halo_rec = *(const uint4*)(a.pre + (size_t)min(max(gi, 0), NI - 1) * NJ + min(max(gj, 0), NJ - 1));
   asm volatile("" ::: "memory");   // (the record loads stay above the skip test)
   __syncthreads();
@@ -975,22 +981,29 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
     if (blockIdx.x == 0 && tid == 0) { store_u32_sc1(a.skip, sweep_id + 1u); if (stats == 1) sweep_log(250u, ntiles); }   // still nothing: the next one may skip as well
     return;
   }
-  if (!own_in) own_rec = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int q = 0; q < CPT; q++) {
+    const int cell_l = tid + q * NT, li = cell_l / TS, lj = cell_l - li * TS;
+    if (!(cell_l < TS * TS && ty * TS + li < NI && tx * TS + lj < NJ)) own_rec[q] = make_uint4(0u, 0u, 0u, 0u);
+    if (cell_l < TS * TS) s_tile[(li + 1) * TP + lj + 1] = own_rec[q];
+  }
   if (!halo_in) halo_rec = make_uint4(0u, 0u, 0u, 0u);
-  if (tid < kSweepTile * kSweepTile) s_tile[(li + 1) * kTilePitch + lj + 1] = own_rec;
-  if (tid < 2 * kTilePitch + 2 * kSweepTile) s_tile[hi_ * kTilePitch + hj_] = halo_rec;
+  if (tid < NHALO) s_tile[hi_ * TP + hj_] = halo_rec;
   __syncthreads();
-  {  // ---- this workgroup's cells: which of them can loop_body change at all (sdof_classify_kernel's test, on the records)
-    const int idx = ci * NJ + cj;
+  // ---- this workgroup's cells: which of them can loop_body change at all (sdof_classify_kernel's test, on the records)
+#pragma unroll
+  for (int q = 0; q < CPT; q++) {
+    const int cell_l = tid + q * NT, li = min(cell_l / TS, TS - 1), lj = cell_l - (cell_l / TS) * TS;
+    const int idx = (ty * TS + li) * NJ + tx * TS + lj;
     bool cand = false;
-    const Cell cur = cell_of(own_rec);
-    if (cur.mark & 0xFF) {   // (an out-of-domain entry is unmarked)
+    const Cell cur = cell_of(own_rec[q]);
+    if (cur.mark & 0xFF) {   // (an out-of-domain / out-of-tile entry is unmarked)
 #pragma unroll
       for (int dr = -1; dr <= 1; dr++)
 #pragma unroll
         for (int dc = -1; dc <= 1; dc++) {
           if (!dr && !dc) continue;
-          const Cell nb = cell_of(s_tile[min(li + 1 + dr, kTilePitch - 1) * kTilePitch + lj + 1 + dc]);
+          const Cell nb = cell_of(s_tile[(li + 1 + dr) * TP + lj + 1 + dc]);
           const int a0 = cur.f0 - nb.f0, a1 = cur.f1 - nb.f1;
           if ((nb.mark & 0xFF) && a0 * a0 + a1 * a1 >= 9) cand = true;
         }
@@ -1016,8 +1029,8 @@ __global__ __launch_bounds__(NT) void sdof_sweep_kernel(DImg i1, DImg i2, int ws
       const int cell = (int)s_cand[job];
       bool changed;
       const int qi = cell / NJ, qj = cell - qi * NJ;
-      target = round_job<WS, false, true>(i1, i2, ws, m, patch, forward, NI, NJ, a, 0, a.B[1], a.B[0], cell, j, s_union[tid >> 3], stats, false, &changed,
-                                          s_tile + (qi - ty * kSweepTile + 1) * kTilePitch + (qj - tx * kSweepTile + 1));
+      target = round_job<WS, false, true, TP>(i1, i2, ws, m, patch, forward, NI, NJ, a, 0, a.B[1], a.B[0], cell, j, s_union[tid >> 3], stats, false, &changed,
+                                              s_tile + (qi - ty * TS + 1) * TP + (qj - tx * TS + 1));
       if (changed && j == (forward ? 1 : 6)) chg = cell;   // (a lane that never carries a queue target: round_job's are the cell's own lane 0 / 7 and the LATER neighbours' lanes)
     }
     append_either(a.qflag[1], &ctl->count[1], a.Q[1], target, a.cflag, &ctl->nchanged, a.chg, chg);
@@ -1549,13 +1562,15 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
             sweep_base = g_sweep_seq.fetch_add((unsigned)propagation + 1u, std::memory_order_relaxed);
           for (int Ki = 0; Ki < propagation; Ki++) {
             if (fused_sweeps) {   // one launch per sweep: every workgroup classifies its tile of cells and runs round 0 on them, the last one to finish runs the rest
-              const int tiles = ((NI + kSweepTile - 1) / kSweepTile) * ((NJ + kSweepTile - 1) / kSweepTile);
+              const int tiles16 = ((NI + kSweepTile - 1) / kSweepTile) * ((NJ + kSweepTile - 1) / kSweepTile);
+              const int want_ts = tuning("sdof.sweep_tile", 0), ts = want_ts ? want_ts : (tiles16 > 512 ? 32 : 16);   // 32 x 32 cells per workgroup where 16 x 16 would be more than 512 workgroups
+              const int tiles = ((NI + ts - 1) / ts) * ((NJ + ts - 1) / ts);
               const int nsub = std::max(1, std::min(kSubCounters, tiles / 16));
               const int want_nt = tuning("sdof.sweep_threads", 0), nt = want_nt ? want_nt : (tiles <= 512 ? 512 : 256);
               // the pair's LAST sweep carries the read-back as extra workgroups (ReadbackTail): one dependent launch less
               const bool tail = scale == min_scale && Ki == propagation - 1 && tuning("sdof.readback_tail", 1);
-              auto sweep = [&](auto NTc, auto RBc) {
-                constexpr int NT = decltype(NTc)::value, RB = decltype(RBc)::value;
+              auto sweep_ts = [&](auto NTc, auto RBc, auto TSc) {
+                constexpr int NT = decltype(NTc)::value, RB = decltype(RBc)::value, TS = decltype(TSc)::value;
                 ReadbackTail rb{};
                 if constexpr (RB != 0) {
                   const int ms_ = 1 << min_scale;
@@ -1563,10 +1578,11 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
                   if (link) rb.link = *link;
                   rb.blocks = (n + NT - 1) / NT; rb.go = rs.skip + 1;
                 }
-                sdof_sweep_kernel<WS, NT, RB><<<tiles + (RB ? (n + NT - 1) / NT : 0), NT, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs,
+                sdof_sweep_kernel<WS, NT, RB, TS><<<tiles + (RB ? (n + NT - 1) / NT : 0), NT, 0, st>>>(dimg(&P1[scale]), dimg(&P2[scale]), winsize, maps(0, scale), patchsize, Ki % 2, NI, NJ, rs,
                                                                 tuning("sdof.stats", 0), nsub, (unsigned)tuning("sdof.sweep_stay", NT / 8), sweep_base + (unsigned)Ki,
                                                                 Ki > 0 && tuning("sdof.skip_empty", 1) ? 1 : 0, rb);
               };
+              auto sweep = [&](auto NTc, auto RBc) { if (ts == 32) sweep_ts(NTc, RBc, std::integral_constant<int, 32>()); else sweep_ts(NTc, RBc, std::integral_constant<int, 16>()); };
               using N512 = std::integral_constant<int, 512>; using N256 = std::integral_constant<int, 256>;
               using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>; using R2 = std::integral_constant<int, 2>;
               if (tail) {
