@@ -296,7 +296,7 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-constexpr int kUnionRows = 13;   // (WS + 2) rows of 16 bytes for WS <= 11; 13 x 16 B = 52 dwords per group: the 8 groups of a wave start 20 banks apart
+constexpr int kUnionRows = 15;   // (WS + 2) rows of 16 bytes for WS <= 11, and the sweeps' 15-row regions (group_descent_region); 15 x 16 B = 60 dwords per group: the 8 groups of a wave start 28 banks apart
 
 // group_descent with the candidates' windows staged through LDS.  The 3 / 5 / 8 candidates of a search step are the 8-neighbours of the
 // step's centre: their WS x WS windows all lie inside one (WS + 2) x (WS + 2) patch of image 2.  With a window per lane (WS 12-byte row loads
@@ -397,6 +397,90 @@ __device__ __forceinline__ GdMatch group_descent_staged(const WindowRegs<WS>& wa
   return GdMatch{m0 - p0, m1 - p1, match_distance};
 }
 
+// group_descent_staged for the sweeps' jobs (8 lanes, the start distance known) with a REGION instead of a patch per step (round 6): the group stages the rows within
+// H + RH of the step's centre (RH = 3 for windows up to 9 x 9: 15 rows of 16 bytes, the two loads per lane a patch took) and keeps stepping out of it while the centre
+// stays within RH - 1 of the region's — three search steps per memory round trip instead of one: a walk of 5 steps is 2 round trips.  A candidate's rows are cut out
+// of the staged rows at a run-time byte offset (0 .. 2 RH: a dword select + v_alignbyte).  Same windows, same sums, same first-of-minima selection: bit-identical.
+constexpr int kRegionRows = 15;
+template <int WS, bool HAVE_START = true, class DIST>
+__device__ __forceinline__ GdMatch group_descent_region(const WindowRegs<WS>& wa, bool a_ok, const DImg& i2, int p0, int p1, int pr0, int pr1, int start, int j,
+                                                        uint4* __restrict__ slot, DIST dist) {
+  constexpr int H = WS / 2, RH = ((kRegionRows - WS) / 2 < 3 ? (kRegionRows - WS) / 2 : 3), UR = WS + 2 * RH, ND = (WS + 3) / 4;
+  static_assert(RH >= 1 && UR <= kRegionRows && 2 * RH + WS <= 16, "the region is UR rows of 16 bytes");
+  constexpr uint32_t tail_mask = (WS % 4) ? ((1u << (8 * (WS % 4))) - 1u) : 0xFFFFFFFFu;
+  constexpr unsigned kFirst = 0xd22406u, kEnd = 0x27fb5bu, kDr = 0x9224u, kDc = 0x16au;
+  int m0 = pr0, m1 = pr1;
+  int match_distance = start;
+  unsigned match_i = 8;
+  int cr = 0, cc = 0;        // the staged region's centre
+  bool have_region = false;
+#pragma nounroll
+  for (int search = 0; search < 5; search++) {
+    bool covered = have_region && abs(pr0 - cr) <= RH - 1 && abs(pr1 - cc) <= RH - 1;   // (the same on the group's 8 lanes)
+    if (!covered) {
+      const int ur0 = pr0 - H - RH, uc0 = pr1 - H - RH;   // rows [ur0, ur0 + UR), 16 bytes from column uc0
+      have_region = a_ok && ur0 >= -i2.border && ur0 + UR <= i2.nr + i2.border && uc0 >= -i2.border && uc0 + 16 <= i2.nc + i2.border;
+      if (have_region) {
+        wave_lds_fence();   // the previous steps' reads are done
+        const uint8_t* src = i2.row<uint8_t>(ur0 + j) + uc0;
+        uint4 v0, v1 = make_uint4(0u, 0u, 0u, 0u);
+        __builtin_memcpy(&v0, src, 16);
+        if (j + 8 < UR) __builtin_memcpy(&v1, src + (ptrdiff_t)8 * i2.pitch, 16);
+        slot[j] = v0;
+        if (j + 8 < UR) slot[j + 8] = v1;
+        wave_lds_fence();
+        cr = pr0; cc = pr1; covered = true;
+      }
+    }
+    auto sad_at = [&](int dr, int dc) -> int {   // the window centred (dr, dc) from the step's centre, cut out of the region (full sums: see group_descent_staged)
+      const int row0 = pr0 + dr - cr + RH;
+      const uint32_t o = (uint32_t)(pr1 + dc - cc + RH), sel = o >> 2, sh = o & 3u;
+      uint32_t err = 0;
+#pragma unroll
+      for (int r = 0; r < WS; r++) {
+        const uint4 q = slot[row0 + r];
+        const uint32_t w[5] = {q.x, q.y, q.z, q.w, 0u};
+        uint32_t x[ND + 1];
+#pragma unroll
+        for (int d = 0; d <= ND; d++) x[d] = sel ? w[d + 1 < 5 ? d + 1 : 4] : w[d < 5 ? d : 4];
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+          const uint32_t m = d == ND - 1 ? tail_mask : 0xFFFFFFFFu;
+          const uint32_t b = __builtin_amdgcn_alignbyte(x[d + 1], x[d], sh);
+          err = __builtin_amdgcn_sad_u8(wa.d[r][d] & m, b & m, err);
+        }
+      }
+      return (int)err;
+    };
+    if constexpr (!HAVE_START) {   // the distance at the prediction itself (the per-keypoint descents: the sweeps pass d2)
+      if (search == 0) match_distance = covered ? (i2.has(pr0, pr1) ? sad_at(0, 0) : INT_MAX) : dist(pr0, pr1, INT_MAX);
+    }
+    const unsigned first = (kFirst >> (3 * match_i)) & 7u, end = (kEnd >> (3 * match_i)) & 7u;
+    const unsigned count = ((end - first - 1u) & 7u) + 1u;
+    const unsigned ci = (first + (unsigned)j) & 7u;
+    const int cdr = (int)((kDr >> (2 * ci)) & 3u) - 1, cdc = (int)((kDc >> (2 * ci)) & 3u) - 1;
+    const int n0 = pr0 + cdr, n1 = pr1 + cdc;
+    int d = INT_MAX;
+    if ((unsigned)j < count) d = covered ? (i2.has(n0, n1) ? sad_at(cdr, cdc) : INT_MAX) : dist(n0, n1, match_distance);
+    unsigned long long key = ((unsigned long long)(unsigned)d << 3) | (unsigned)j;
+    {
+      auto take_min = [&](unsigned lo, unsigned hi) { const unsigned long long ok = ((unsigned long long)hi << 32) | lo; key = ok < key ? ok : key; };
+      take_min(dpp_mov<0xB1>((unsigned)key), dpp_mov<0xB1>((unsigned)(key >> 32)));
+      take_min(dpp_mov<0x4E>((unsigned)key), dpp_mov<0x4E>((unsigned)(key >> 32)));
+      take_min(dpp_mov<0x141>((unsigned)key), dpp_mov<0x141>((unsigned)(key >> 32)));
+    }
+    const int best = (int)(unsigned)(key >> 3);
+    if (best < match_distance) {
+      const unsigned wi = (first + (unsigned)(key & 7u)) & 7u;
+      m0 = pr0 + (int)((kDr >> (2 * wi)) & 3u) - 1; m1 = pr1 + (int)((kDc >> (2 * wi)) & 3u) - 1;
+      match_i = wi; match_distance = best;
+    }
+    if (pr0 == m0 && pr1 == m1) break;
+    pr0 = m0; pr1 = m1;
+  }
+  return GdMatch{m0 - p0, m1 - p1, match_distance};
+}
+
 // The same phase with 8 lanes per keypoint: the candidates of one search step (the 3, 5 or 8 neighbours the reference walks one after
 // the other) are evaluated by the lanes of the group side by side and the winner is the minimum of (distance << 3 | position in the
 // walk) — the sequential rule "replace on strictly smaller" keeps the FIRST of equal minima, and a candidate that the sequential walk
@@ -472,6 +556,7 @@ __global__ __launch_bounds__(64) void sdof_descent_group_kernel(const int32_t* _
     } else return distance_fn<WS>(i1, i2, p0, p1, b0, b1, ws, th);
   };
   GdMatch g;
+  // (the 8-lane kernels through group_descent_region<WS, false>: 4K pair 0.1633 -> 0.1625 ms, 1080p -0.7 us — within the noise, not taken)
   if constexpr (WS != 0) g = group_descent_staged<WS, G>(wa, a_ok, i2, p0, p1, pr0, pr1, false, INT_MAX, j, s_union[threadIdx.x / G], dist);
   else g = group_descent(dist, p0, p1, pr0, pr1, dist(pr0, pr1, INT_MAX), j);
   if (j != 0) return;
@@ -745,7 +830,7 @@ __device__ __forceinline__ int round_job(const DImg& i1, const DImg& i2, int ws,
     if (!__ballot(found)) break;   // no group of this wave has a descent left
     if (found) {
       GdMatch g;   // :173-175; its first distance is d2 itself
-      if constexpr (WS != 0) g = group_descent_staged<WS>(wa, a_ok, i2, r, c, r + n0, c + n1, true, d2k, j, slot, dist);
+      if constexpr (WS != 0) g = group_descent_region<WS>(wa, a_ok, i2, r, c, r + n0, c + n1, d2k, j, slot, dist);
       else g = group_descent(dist, r, c, r + n0, c + n1, d2k, j);
       if (g.distance < cur.dist) { cur.mark = 1; cur.f0 = g.f0; cur.f1 = g.f1; cur.dist = g.distance; }   // :179-184
     }
