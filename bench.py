@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--regions", type=int, default=5, help="timed regions of exactly --steps launches each; the median one (by wall clock) is reported, all are listed")
-    ap.add_argument("--preheat", type=float, default=0.3, help="seconds of untimed, reported replays before each headline timed region (clock ramp)")
+    ap.add_argument("--preheat", type=float, default=2.0, help="seconds of untimed, reported replays before each headline timed region (a fresh box needs seconds of load to reach its steady clocks: 0.3 s measured 0.686 of the HBM peak as the first run on a box, 0.711 as the second, 0.745 with 1.5 - 5 s)")
     ap.add_argument("--workload", default="box5x5", choices=["box5x5"])
     ap.add_argument("--sets", type=int, default=64, help="distinct 4K frame sets (64 per step): 64 sets = 1.6 GB of sources + 1.6 GB of results, all of them read and written by every step "
                     "(a larger rotation only adds address-translation misses: 128 sets measured 1-4 %% slower on four boxes)")
@@ -95,8 +95,9 @@ def main():
             behind the last recorded kernel, so the event time brackets the K kernels on the device clock and excludes the
             host's graph-submission latency (~9 us, i.e. 5 % of a K = 20 region); falls back to stream events around the replay.
           otherwise: torch.cuda.CUDAGraph (the launch also queues torch work), stream events around the replay.
-        preheat_s > 0: untimed, REPORTED replays for that long right before the timed regions (the GPU clocks ramp over the
-        first few hundred microseconds of work after an idle period such as the CPU-baseline leg).
+        preheat_s > 0: untimed, REPORTED replays for that long right before the timed regions (the GPU's clocks ramp after an idle
+        period such as the CPU-baseline leg, and a FRESH box takes seconds of load to reach its steady state — round 6: the first
+        run on a box read 0.686 of the HBM peak with 0.3 s, 0.745 with 1.5 s and more; default 2 s).
         args.regions regions are timed; the one reported is the median by wall clock, all are listed in the JSON line."""
         for i in range(warmup):
             launch(i, st)
