@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--regions", type=int, default=5, help="timed regions of exactly --steps launches each; the median one (by wall clock) is reported, all are listed")
+    ap.add_argument("--preheat-max", type=float, default=8.0, help="upper bound of the preheat: it goes on past --preheat while consecutive batches still get faster")
     ap.add_argument("--preheat", type=float, default=2.0, help="seconds of untimed, reported replays before each headline timed region (a fresh box needs seconds of load to reach its steady clocks: 0.3 s measured 0.686 of the HBM peak as the first run on a box, 0.711 as the second, 0.745 with 1.5 - 5 s)")
     ap.add_argument("--workload", default="box5x5", choices=["box5x5"])
     ap.add_argument("--sets", type=int, default=64, help="distinct 4K frame sets (64 per step): 64 sets = 1.6 GB of sources + 1.6 GB of results, all of them read and written by every step "
@@ -145,11 +146,19 @@ def main():
             t_pre = time.perf_counter()
             n_pre = 0
             batch = max(1, 4000 // max(steps, 1))  # replays queued back to back between host syncs: the GPU must stay busy to hold its clocks
-            while time.perf_counter() - t_pre < preheat_s:
+            # at least preheat_s; then on while the box is still speeding up (a batch more than 0.5 % faster than the one before it), at most args.preheat_max seconds
+            prev_dt, settled = None, False
+            while True:
+                t_b = time.perf_counter()
                 for _ in range(batch):
                     replay()
                 n_pre += steps * batch
                 torch.cuda.synchronize()
+                dt = time.perf_counter() - t_b
+                el = time.perf_counter() - t_pre
+                settled = prev_dt is not None and dt > prev_dt * 0.995   # (the latest pair of batches only)
+                prev_dt = dt
+                if el >= args.preheat_max or (el >= preheat_s and settled): break
             preheat["ms"] += (time.perf_counter() - t_pre) * 1e3
             preheat["launches"] += n_pre
         regions = []
