@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from vpp_amd.synth import P, u8_image, DeviceImage, texture
 from vpp_amd import capi, image as vi, pyr
+if os.environ.get("VPP_AMD_LIB"): capi.LIB_PATH = os.environ["VPP_AMD_LIB"]   # A/B of several builds on one box
 lib = capi.lib(); capi.check(lib.vpp_init(0))
 def time_graph(launch, steps=200):
     for i in range(5): launch(capi.stream_ptr())
