@@ -123,20 +123,20 @@ def test_fused_pyramid_equals_the_per_level_chain_and_the_oracle(lib, orc, shape
 @pytest.mark.parametrize("shape,border", [((271, 481), 3), ((600, 1000), 4), ((1080, 1920), 4), ((1081, 1923), 3), ((2160, 3840), 4), ((520, 4160), 18)])
 def test_packed_pyramid_tile_geometries_agree_with_the_oracle(lib, orc, shape, border):
     """The packed three-level kernel's interior by tile geometry (tuning pyr.row_tiles: 0 = 8 x 16 tiles of level 2, 2 / 4 = row tiles of 2 / 4 x 64, the default) and
-    workgroup order (pyr.xcd), and with the 16-byte staging off (pyr.wide = 0): every byte of every level equals the oracle's chain — interiors whose width is not a
+    workgroup order (pyr.xcd), tiles per workgroup (pyr.tiles_per_wg: the next tile's patch is requested before the current one's passes), and with the 16-byte staging off (pyr.wide = 0): every byte of every level equals the oracle's chain — interiors whose width is not a
     multiple of a row tile (the last tile of a row overlaps its neighbour), odd extents, a wide border."""
     img = rand_image(*shape, vi.U8, 1, border=0, seed=33)
     hp = pyr.host_pyramid(orc, img, 3, border)
     d = DeviceImage.from_host(img)
     try:
-        for wide, rt, xcd in ((1, 4, 1), (1, 4, 0), (1, 2, 1), (1, 2, 0), (1, 0, 0), (0, 4, 1)):
-            lib.vpp_set_tuning(b"pyr.wide", wide); lib.vpp_set_tuning(b"pyr.row_tiles", rt); lib.vpp_set_tuning(b"pyr.xcd", xcd)
+        for wide, rt, xcd, per in ((1, 4, 1, 2), (1, 4, 0, 3), (1, 8, 1, 2), (1, 8, 0, 1), (1, 8, 1, 5), (1, 2, 1, 1), (1, 2, 0, 4), (1, 0, 0, 1), (0, 4, 1, 2)):
+            lib.vpp_set_tuning(b"pyr.wide", wide); lib.vpp_set_tuning(b"pyr.row_tiles", rt); lib.vpp_set_tuning(b"pyr.xcd", xcd); lib.vpp_set_tuning(b"pyr.tiles_per_wg", per)
             dp = pyr.device_pyramid(lib, d, 3, border)
             _sync(lib)
             for l, (h, dv) in enumerate(zip(hp, dp)):
-                np.testing.assert_array_equal(dv.download().raw, h.raw, err_msg=f"level {l}, wide {wide}, row_tiles {rt}, xcd {xcd}")
+                np.testing.assert_array_equal(dv.download().raw, h.raw, err_msg=f"level {l}, wide {wide}, row_tiles {rt}, xcd {xcd}, tiles per workgroup {per}")
     finally:
-        for k in (b"pyr.wide", b"pyr.row_tiles", b"pyr.xcd"):
+        for k in (b"pyr.wide", b"pyr.row_tiles", b"pyr.xcd", b"pyr.tiles_per_wg"):
             lib.vpp_set_tuning(k, -1)
 
 

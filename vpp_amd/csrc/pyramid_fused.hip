@@ -351,12 +351,12 @@ template <int CH> struct GrayFast {   // rgb_to_graylevel of four pixels (GraySr
   }
 };
 struct Swar3 { Chain ch; int TX, TY, tx_lo, tx_hi, ty_lo, ty_hi, tiles_x8, wide;   // wide: source and level 0 are 16-byte aligned (the patch goes in as 16-byte pieces)
-               int row_tiles, tx8_lo, tx8_hi, wt, xcd; };   // row_tiles (2 / 4, else 0): the interior as ROW tiles (pyramid_swarw_body), columns [tx8_lo, tx8_hi) of 8 x 8 tiles, wt tiles per row
+               int row_tiles, tx8_lo, tx8_hi, wt, xcd, per_wg; };   // row_tiles (2 / 4 / 8, else 0): the interior as ROW tiles (pyramid_swarw_body), columns [tx8_lo, tx8_hi) of 8 x 8 tiles, wt tiles per row
 
 // WIDE (round 6, copy producer, 16-byte aligned source and level 0): the patch is 41 rows of 96 bytes from column 64 tx - 16 — six 16-byte pieces per row, 246 loads, ONE
 // pass of the workgroup — instead of 41 x 22 dwords from column 64 tx - 12 in 3.5 passes with a division, two tests and a 4-byte store per dword: the staging was a third of
 // the kernel's instructions.  The four bytes more on either side are read and never used.
-constexpr int kSwarLds = 25 * 72 + 25 * 34 + 11 * 34 + 11 * 16 + 12;   // dwords: the packed path's stage buffers (one allocation for all the variants; the largest: 4-row tiles)
+constexpr int kSwarLds = 41 * 72 + 41 * 34 + 19 * 34 + 19 * 16 + 12;   // dwords: the packed path's stage buffers (one allocation for all the variants; the largest: the row tiles of 8 x 64)
 template <class FAST, class SRC, bool WIDE>
 __device__ __forceinline__ void pyramid_swar3_body_(const Swar3& a, const int bid, uint32_t* __restrict__ lds) {
   constexpr int R0 = 41, W0 = WIDE ? 24 : 22, XO = WIDE ? 1 : 0, G1 = 10, R1 = 19, G2 = 4;   // level-0 patch rows / dwords per row (XO: dword of the patch's column 64 tx - 12), level-1 groups per row / patch rows, level-2 groups
@@ -427,12 +427,14 @@ __device__ __forceinline__ void pyramid_swar3_body_(const Swar3& a, const int bi
   }
 }
 
-// ROW tiles (round 6, copy producer, 16-byte aligned source and level 0): the same passes on a tile of TH2 x 64 pixels of level 2 (4 TH2 x 256 of level 0, TH2 = 2 or 4)
-// instead of 8 x 16.  Measured with the arithmetic taken out (stage + level-0 store only, interior tiles only, 4K): 32 x 64-pixel tiles 9.1 us, 16 x 128 8.2 us, 8 x 256 6.7 us
-// — about a copy's time — although the flat tile loads 2.4 x its pixels instead of 1.9 x: a 64-byte row of a tile is half a cache line, written by one workgroup and
-// completed by another one later, and its 96-byte patch rows straddle two lines each; 256-byte rows are whole lines.  The frame's edge ring stays with the tile kernel's
-// code on 8 x 8 tiles of level 2 (one workgroup each, numbered first); the interior is the rectangle of those tiles that the packed arithmetic may own, cut into row tiles
-// from its left edge, the last tile of a row moved left to end at the rectangle's right edge (the overlap is computed twice, to the same bytes).
+// ROW tiles (round 6, copy producer, 16-byte aligned source and level 0): the same passes on a tile of TH2 x 64 pixels of level 2 (4 TH2 x 256 of level 0; TH2 = 8 by
+// default, 2 / 4 by tuning) instead of 8 x 16.  Measured with the arithmetic taken out (stage + level-0 store only, interior tiles only, 4K): 32 x 64-pixel tiles 9.1 us,
+// 16 x 128 8.2 us, 8 x 256 6.7 us — about a copy's time — although the flat tile loads 2.4 x its pixels instead of 1.9 x: a 64-byte row of a tile is half a cache line,
+// written by one workgroup and completed by another one later, and its 96-byte patch rows straddle two lines each; 256-byte rows are whole lines.  With the arithmetic
+// (4K, border 3, per pyramid): 8 x 16 tiles 12.3 us, 2 x 64 11.3, 4 x 64 10.0, 8 x 64 9.2 (1.28 x halo; 1 012 workgroups); the flow's pair + tail launch 25.6 -> 20.8 us.
+// The frame's edge ring stays with the tile kernel's code on 8 x 8 tiles of level 2 (one workgroup each, numbered first); the interior is the rectangle of those tiles that
+// the packed arithmetic may own, cut into row tiles from its left edge, the last tile of a row moved left to end at the rectangle's right edge (the overlap is computed
+// twice, to the same bytes).  Counters (tools/pyr_pmc.sh): 2.7 M VALU wave-instructions per 4K pyramid against 3.4 M before, ~1 M of them in the 374 edge workgroups.
 template <class SRC, int TH2>
 __device__ __forceinline__ void pyramid_swarw_body(const Swar3& a, const int bid, uint32_t* __restrict__ lds) {
   constexpr int TW2 = 64, R0 = 4 * TH2 + 9, NP = (4 * TW2 + 32) / 16, W0 = 4 * NP, G1 = (2 * TW2 + 8) / 4, R1 = 2 * TH2 + 3, G2 = TW2 / 4;
@@ -446,52 +448,87 @@ __device__ __forceinline__ void pyramid_swarw_body(const Swar3& a, const int bid
     chain_tile<uint8_t, int, 1, 8, SRC, 3, true>(a.ch, ty, tx);
     return;
   }
-  int q = bid - n_edge;
-  const int nrt = (a.ty_hi - a.ty_lo) * (8 / TH2);   // tile rows of the interior
-  int trow, tcol;
+  // A workgroup takes `per_wg` consecutive tiles (down a column of tiles where the order is XCD-aware; 1 by default) and requests the next tile's patch — three 16-byte
+  // pieces per thread at most, in registers — before it starts on the passes of the current one.  Measured no faster with 2 or 3 tiles per workgroup (4K: 9.4 -> 9.8 us
+  // with 8-row tiles, 10.3 -> 10.3 / 11.3 with 4-row tiles): the kernel is bound by what it issues, not by the patch's round trip.
+  const int nrt = (a.ty_hi - a.ty_lo) * (8 / TH2), ntiles = nrt * a.wt;   // tile rows of the interior, tiles
+  int w = bid - n_edge;
   if (a.xcd) {   // consecutive workgroups go to the 8 XCDs in turn: an XCD takes a contiguous run of tiles, ordered DOWN the columns (a tile's patch shares 9 of its rows with the tile below)
-    const int n8 = (nrt * a.wt) & ~7;
-    if (q < n8) q = (q & 7) * (n8 >> 3) + (q >> 3);
-    tcol = q / nrt; trow = q - tcol * nrt;
-  } else { trow = q / a.wt; tcol = q - trow * a.wt; }
-  const int r2 = 8 * a.ty_lo + TH2 * trow, c2 = min(8 * a.tx8_lo + TW2 * tcol, 8 * a.tx8_hi - TW2);
+    const int nw = (ntiles + a.per_wg - 1) / a.per_wg, n8 = nw & ~7;
+    if (w < n8) w = (w & 7) * (n8 >> 3) + (w >> 3);
+  }
+  const int t0 = w * a.per_wg, t1 = min(t0 + a.per_wg, ntiles);
   constexpr int O1 = R0 * W0, O2 = (O1 + R0 * G1 + 3) & ~3, O3 = (O2 + R1 * G1 + 3) & ~3;
   static_assert(O1 % 4 == 0 && O3 + R1 * G2 <= kSwarLds && G1 % 2 == 0 && G1 >= 2 * G2 + 2, "the stages' LDS");
   uint32_t* const s0 = lds; uint32_t* const sh0 = lds + O1; uint32_t* const s1 = lds + O2; uint32_t* const sh1 = lds + O3;
   const DImg L0 = a.ch.lv[0], L1 = a.ch.lv[1], L2 = a.ch.lv[2], src = a.ch.src;
-  const int pr0 = 4 * r2 - 6, pc0 = 4 * c2 - 16;   // origin of the level-0 patch (R0 rows of W0 dwords); level-1 patch: rows from 2 r2 - 2, columns from 2 c2 - 4
-  for (int idx = threadIdx.x; idx < R0 * NP; idx += 256) {
-    const int y = idx / NP, x = idx - y * NP;
-    const ptrdiff_t col = pc0 + 16 * x;
-    const uint4 v = *(const uint4*)(src.p0 + (ptrdiff_t)(pr0 + y) * src.pitch + col);
-    *(uint4*)&s0[y * W0 + 4 * x] = v;
-    if (y >= 6 && y < 6 + 4 * TH2 && x >= 1 && x < NP - 1) *(uint4*)(L0.p0 + (ptrdiff_t)(pr0 + y) * L0.pitch + col) = v;   // the owned 4 TH2 x 256 pixels
+  constexpr int NLD = (R0 * NP + 255) / 256;   // pieces per thread
+  // this thread's pieces: patch row / piece of each, as byte offsets into the source / level 0 (same for every tile) and the LDS dword
+  int poff[NLD], loff[NLD], ldw[NLD]; bool own[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; k++) {
+    const int idx = min((int)threadIdx.x + 256 * k, R0 * NP - 1), y = idx / NP, x = idx - y * NP;
+    poff[k] = y * src.pitch + 16 * x; loff[k] = y * L0.pitch + 16 * x; ldw[k] = y * W0 + 4 * x;
+    own[k] = (int)threadIdx.x + 256 * k < R0 * NP && y >= 6 && y < 6 + 4 * TH2 && x >= 1 && x < NP - 1;
   }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < R0 * G1; idx += 256) {   // horizontal pass of level 0: level-1 columns 2 c2 - 4 + 4 g + k from patch bytes 4 + 8 g .. 4 + 8 g + 15
-    const int y = idx / G1, g = idx - y * G1;
-    const uint32_t* q4 = &s0[y * W0 + 1 + 2 * g];
-    sh0[idx] = hpass4(q4[0], q4[1], q4[2], q4[3]);
+  auto origin = [&](int t, int& r2, int& c2) {
+    int trow, tcol;
+    if (a.xcd) { tcol = t / nrt; trow = t - tcol * nrt; } else { trow = t / a.wt; tcol = t - trow * a.wt; }
+    r2 = 8 * a.ty_lo + TH2 * trow; c2 = min(8 * a.tx8_lo + TW2 * tcol, 8 * a.tx8_hi - TW2);
+  };
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (an array of HIP's uint4 stays in scratch memory)
+  u32x4 v[NLD];
+  int r2, c2;
+  origin(t0, r2, c2);
+  {
+    const uint8_t* p = src.p0 + (ptrdiff_t)(4 * r2 - 6) * src.pitch + (4 * c2 - 16);   // origin of the level-0 patch (R0 rows of W0 dwords); level-1 patch: rows from 2 r2 - 2, columns from 2 c2 - 4
+#pragma unroll
+    for (int k = 0; k < NLD; k++) v[k] = *(const u32x4*)(p + poff[k]);
   }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < R1 * G1; idx += 256) {   // vertical pass: level-1 row 2 r2 - 2 + i from patch rows 2 i .. 2 i + 4
-    const int i = idx / G1, g = idx - i * G1;
-    const uint32_t* p = &sh0[2 * i * G1 + g];
-    const uint32_t v = vpass4(p[0], p[G1], p[2 * G1], p[3 * G1], p[4 * G1]);
-    s1[idx] = v;
-    if (i >= 2 && i < 2 + 2 * TH2 && g >= 1 && g < G1 - 1) *(uint32_t*)(L1.p0 + (ptrdiff_t)(2 * r2 - 2 + i) * L1.pitch + (2 * c2 - 4 + 4 * g)) = v;   // the owned 2 TH2 x 128
-  }
-  __syncthreads();
-  if (threadIdx.x < R1 * G2) {   // horizontal pass of level 1: level-2 columns c2 + 4 g + k
-    const int i = threadIdx.x / G2, g = threadIdx.x - i * G2;
-    const uint2 lo = *(const uint2*)&s1[i * G1 + 2 * g], hi = *(const uint2*)&s1[i * G1 + 2 * g + 2];
-    sh1[threadIdx.x] = hpass4(lo.x, lo.y, hi.x, hi.y);
-  }
-  __syncthreads();
-  if (threadIdx.x < TH2 * G2) {    // vertical pass: the TH2 x 64 tile of level 2
-    const int i = threadIdx.x / G2, g = threadIdx.x - i * G2;
-    const uint32_t* p = &sh1[2 * i * G2 + g];
-    *(uint32_t*)(L2.p0 + (ptrdiff_t)(r2 + i) * L2.pitch + (c2 + 4 * g)) = vpass4(p[0], p[G2], p[2 * G2], p[3 * G2], p[4 * G2]);
+  for (int t = t0; t < t1; t++) {
+    {
+      uint8_t* o = L0.p0 + (ptrdiff_t)(4 * r2 - 6) * L0.pitch + (4 * c2 - 16);
+#pragma unroll
+      for (int k = 0; k < NLD; k++) {
+        if (k < NLD - 1 || (int)threadIdx.x + 256 * k < R0 * NP) *(u32x4*)&s0[ldw[k]] = v[k];
+        if (own[k]) *(u32x4*)(o + loff[k]) = v[k];   // the owned 4 TH2 x 256 pixels
+      }
+    }
+    __syncthreads();
+    const int cr2 = r2, cc2 = c2;
+    if (t + 1 < t1) {   // the next tile's patch: in flight during this tile's passes
+      origin(t + 1, r2, c2);
+      const uint8_t* p = src.p0 + (ptrdiff_t)(4 * r2 - 6) * src.pitch + (4 * c2 - 16);
+#pragma unroll
+      for (int k = 0; k < NLD; k++) v[k] = *(const u32x4*)(p + poff[k]);
+    }
+    for (int idx = threadIdx.x; idx < R0 * G1; idx += 256) {   // horizontal pass of level 0: level-1 columns 2 c2 - 4 + 4 g + k from patch bytes 4 + 8 g .. 4 + 8 g + 15
+      const int y = idx / G1, g = idx - y * G1;
+      const uint32_t* q4 = &s0[y * W0 + 1 + 2 * g];
+      sh0[idx] = hpass4(q4[0], q4[1], q4[2], q4[3]);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < R1 * G1; idx += 256) {   // vertical pass: level-1 row 2 r2 - 2 + i from patch rows 2 i .. 2 i + 4
+      const int i = idx / G1, g = idx - i * G1;
+      const uint32_t* p = &sh0[2 * i * G1 + g];
+      const uint32_t x = vpass4(p[0], p[G1], p[2 * G1], p[3 * G1], p[4 * G1]);
+      s1[idx] = x;
+      if (i >= 2 && i < 2 + 2 * TH2 && g >= 1 && g < G1 - 1) *(uint32_t*)(L1.p0 + (ptrdiff_t)(2 * cr2 - 2 + i) * L1.pitch + (2 * cc2 - 4 + 4 * g)) = x;   // the owned 2 TH2 x 128
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < R1 * G2; u += 256) {   // horizontal pass of level 1: level-2 columns c2 + 4 g + k
+      const int i = u / G2, g = u - i * G2;
+      const uint2 lo = *(const uint2*)&s1[i * G1 + 2 * g], hi = *(const uint2*)&s1[i * G1 + 2 * g + 2];
+      sh1[u] = hpass4(lo.x, lo.y, hi.x, hi.y);
+    }
+    __syncthreads();
+    static_assert(TH2 * G2 <= 256, "one pass");
+    if (threadIdx.x < TH2 * G2) {    // vertical pass: the TH2 x 64 tile of level 2
+      const int i = threadIdx.x / G2, g = threadIdx.x - i * G2;
+      const uint32_t* p = &sh1[2 * i * G2 + g];
+      *(uint32_t*)(L2.p0 + (ptrdiff_t)(cr2 + i) * L2.pitch + (cc2 + 4 * g)) = vpass4(p[0], p[G2], p[2 * G2], p[3 * G2], p[4 * G2]);
+    }
+    // (no barrier at the loop's end: the next tile's writes to a stage buffer come at least one barrier after this tile's last reads of it)
   }
 }
 
@@ -500,6 +537,7 @@ __device__ __forceinline__ void pyramid_swar3_body(const Swar3& a, const int bid
   __shared__ __attribute__((aligned(16))) uint32_t s_swar[kSwarLds];
   if constexpr (std::is_same<FAST, CopyFast>::value) {
     if (a.row_tiles == 4) { pyramid_swarw_body<SRC, 4>(a, bid, s_swar); return; }
+    if (a.row_tiles == 8) { pyramid_swarw_body<SRC, 8>(a, bid, s_swar); return; }
     if (a.row_tiles == 2) { pyramid_swarw_body<SRC, 2>(a, bid, s_swar); return; }
     if (a.wide) { pyramid_swar3_body_<FAST, SRC, true>(a, bid, s_swar); return; }
   }
@@ -554,13 +592,14 @@ inline bool swar3_args(const vpp_image_desc* levels, const vpp_image_desc* src, 
   if (a.ty_hi <= a.ty_lo || a.tx_hi <= a.tx_lo) return false;   // no interior tile: the tile kernel
   const int n_int = (a.ty_hi - a.ty_lo) * (a.tx_hi - a.tx_lo), n_edge = a.TY * a.TX - n_int;
   *blocks = 2 * n_edge + n_int;
-  a.row_tiles = 0; a.tx8_lo = a.tx8_hi = a.wt = 0; a.xcd = (int)tuning("pyr.xcd", 1);
-  const int rt = (int)tuning("pyr.row_tiles", 4);
-  if (a.wide && (rt == 2 || rt == 4)) {   // the interior as row tiles of rt x 64 pixels of level 2 (pyramid_swarw_body): its columns in units of the edge ring's 8 x 8 tiles
+  a.row_tiles = 0; a.tx8_lo = a.tx8_hi = a.wt = 0; a.per_wg = 1; a.xcd = (int)tuning("pyr.xcd", 1);
+  const int rt = (int)tuning("pyr.row_tiles", 8);
+  if (a.wide && (rt == 2 || rt == 4 || rt == 8)) {   // the interior as row tiles of rt x 64 pixels of level 2 (pyramid_swarw_body): its columns in units of the edge ring's 8 x 8 tiles
     swar3_axis(levels[0].ncols, levels[1].ncols, levels[2].ncols, levels[0].border, levels[1].border, levels[2].border, 8, 16, 64, a.tiles_x8, &a.tx8_lo, &a.tx8_hi);
     if (a.tx8_hi - a.tx8_lo >= 8) {
       a.row_tiles = rt; a.wt = (a.tx8_hi - a.tx8_lo + 7) / 8;
-      *blocks = a.TY * a.tiles_x8 - (a.ty_hi - a.ty_lo) * (a.tx8_hi - a.tx8_lo) + (a.ty_hi - a.ty_lo) * (8 / rt) * a.wt;
+      a.per_wg = std::max(1, std::min(8, (int)tuning("pyr.tiles_per_wg", 1)));
+      *blocks = a.TY * a.tiles_x8 - (a.ty_hi - a.ty_lo) * (a.tx8_hi - a.tx8_lo) + ((a.ty_hi - a.ty_lo) * (8 / rt) * a.wt + a.per_wg - 1) / a.per_wg;
     }
   }
   return true;
