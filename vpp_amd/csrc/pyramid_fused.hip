@@ -435,7 +435,7 @@ __device__ __forceinline__ void pyramid_swar3_body_(const Swar3& a, const int bi
 // The frame's edge ring stays with the tile kernel's code on 8 x 8 tiles of level 2 (one workgroup each, numbered first); the interior is the rectangle of those tiles that
 // the packed arithmetic may own, cut into row tiles from its left edge, the last tile of a row moved left to end at the rectangle's right edge (the overlap is computed
 // twice, to the same bytes).  Counters (tools/pyr_pmc.sh): 2.7 M VALU wave-instructions per 4K pyramid against 3.4 M before, ~1 M of them in the 374 edge workgroups.
-template <class SRC, int TH2>
+template <class FAST, class SRC, int TH2>
 __device__ __forceinline__ void pyramid_swarw_body(const Swar3& a, const int bid, uint32_t* __restrict__ lds) {
   constexpr int TW2 = 64, R0 = 4 * TH2 + 9, NP = (4 * TW2 + 32) / 16, W0 = 4 * NP, G1 = (2 * TW2 + 8) / 4, R1 = 2 * TH2 + 3, G2 = TW2 / 4;
   const int TX8 = a.tiles_x8, wi = a.tx8_hi - a.tx8_lo;
@@ -468,7 +468,8 @@ __device__ __forceinline__ void pyramid_swarw_body(const Swar3& a, const int bid
 #pragma unroll
   for (int k = 0; k < NLD; k++) {
     const int idx = min((int)threadIdx.x + 256 * k, R0 * NP - 1), y = idx / NP, x = idx - y * NP;
-    poff[k] = y * src.pitch + 16 * x; loff[k] = y * L0.pitch + 16 * x; ldw[k] = y * W0 + 4 * x;
+    poff[k] = std::is_same<FAST, CopyFast>::value ? y * src.pitch + 16 * x : (y << 16 | 16 * x);   // (a producer other than the copy gets the piece's patch row and column)
+    loff[k] = y * L0.pitch + 16 * x; ldw[k] = y * W0 + 4 * x;
     own[k] = (int)threadIdx.x + 256 * k < R0 * NP && y >= 6 && y < 6 + 4 * TH2 && x >= 1 && x < NP - 1;
   }
   auto origin = [&](int t, int& r2, int& c2) {
@@ -478,13 +479,23 @@ __device__ __forceinline__ void pyramid_swarw_body(const Swar3& a, const int bid
   };
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (an array of HIP's uint4 stays in scratch memory)
   u32x4 v[NLD];
+  // the patch of the tile at (r2, c2) of level 2: origin (4 r2 - 6, 4 c2 - 16) of level 0, R0 rows of W0 dwords; level-1 patch: rows from 2 r2 - 2, columns from 2 c2 - 4
+  auto request = [&](int r2, int c2) {
+    if constexpr (std::is_same<FAST, CopyFast>::value) {
+      const uint8_t* p = src.p0 + (ptrdiff_t)(4 * r2 - 6) * src.pitch + (4 * c2 - 16);
+#pragma unroll
+      for (int k = 0; k < NLD; k++) v[k] = *(const u32x4*)(p + poff[k]);
+    } else {   // (the ingest as producer: four pixels per dword from 12 / 16 source bytes)
+#pragma unroll
+      for (int k = 0; k < NLD; k++) {
+        const int r = 4 * r2 - 6 + (poff[k] >> 16), c = 4 * c2 - 16 + (poff[k] & 0xFFFF);
+        v[k] = u32x4{FAST::load4(src, r, c), FAST::load4(src, r, c + 4), FAST::load4(src, r, c + 8), FAST::load4(src, r, c + 12)};
+      }
+    }
+  };
   int r2, c2;
   origin(t0, r2, c2);
-  {
-    const uint8_t* p = src.p0 + (ptrdiff_t)(4 * r2 - 6) * src.pitch + (4 * c2 - 16);   // origin of the level-0 patch (R0 rows of W0 dwords); level-1 patch: rows from 2 r2 - 2, columns from 2 c2 - 4
-#pragma unroll
-    for (int k = 0; k < NLD; k++) v[k] = *(const u32x4*)(p + poff[k]);
-  }
+  request(r2, c2);
   for (int t = t0; t < t1; t++) {
     {
       uint8_t* o = L0.p0 + (ptrdiff_t)(4 * r2 - 6) * L0.pitch + (4 * c2 - 16);
@@ -498,9 +509,7 @@ __device__ __forceinline__ void pyramid_swarw_body(const Swar3& a, const int bid
     const int cr2 = r2, cc2 = c2;
     if (t + 1 < t1) {   // the next tile's patch: in flight during this tile's passes
       origin(t + 1, r2, c2);
-      const uint8_t* p = src.p0 + (ptrdiff_t)(4 * r2 - 6) * src.pitch + (4 * c2 - 16);
-#pragma unroll
-      for (int k = 0; k < NLD; k++) v[k] = *(const u32x4*)(p + poff[k]);
+      request(r2, c2);
     }
     for (int idx = threadIdx.x; idx < R0 * G1; idx += 256) {   // horizontal pass of level 0: level-1 columns 2 c2 - 4 + 4 g + k from patch bytes 4 + 8 g .. 4 + 8 g + 15
       const int y = idx / G1, g = idx - y * G1;
@@ -535,10 +544,10 @@ __device__ __forceinline__ void pyramid_swarw_body(const Swar3& a, const int bid
 template <class FAST, class SRC>
 __device__ __forceinline__ void pyramid_swar3_body(const Swar3& a, const int bid) {
   __shared__ __attribute__((aligned(16))) uint32_t s_swar[kSwarLds];
+  if (a.row_tiles == 8) { pyramid_swarw_body<FAST, SRC, 8>(a, bid, s_swar); return; }
   if constexpr (std::is_same<FAST, CopyFast>::value) {
-    if (a.row_tiles == 4) { pyramid_swarw_body<SRC, 4>(a, bid, s_swar); return; }
-    if (a.row_tiles == 8) { pyramid_swarw_body<SRC, 8>(a, bid, s_swar); return; }
-    if (a.row_tiles == 2) { pyramid_swarw_body<SRC, 2>(a, bid, s_swar); return; }
+    if (a.row_tiles == 4) { pyramid_swarw_body<FAST, SRC, 4>(a, bid, s_swar); return; }
+    if (a.row_tiles == 2) { pyramid_swarw_body<FAST, SRC, 2>(a, bid, s_swar); return; }
     if (a.wide) { pyramid_swar3_body_<FAST, SRC, true>(a, bid, s_swar); return; }
   }
   pyramid_swar3_body_<FAST, SRC, false>(a, bid, s_swar);
@@ -594,7 +603,9 @@ inline bool swar3_args(const vpp_image_desc* levels, const vpp_image_desc* src, 
   *blocks = 2 * n_edge + n_int;
   a.row_tiles = 0; a.tx8_lo = a.tx8_hi = a.wt = 0; a.per_wg = 1; a.xcd = (int)tuning("pyr.xcd", 1);
   const int rt = (int)tuning("pyr.row_tiles", 8);
-  if (a.wide && (rt == 2 || rt == 4 || rt == 8)) {   // the interior as row tiles of rt x 64 pixels of level 2 (pyramid_swarw_body): its columns in units of the edge ring's 8 x 8 tiles
+  // (the ingest as producer: level 0 16-byte aligned is all the row tiles need — its source is read through the producer's own dword loads; 8-row tiles only)
+  const bool gray_rows = !copy_producer && rt == 8 && tuning("pyr.gray_row_tiles", 1) && al16(levels[0]);
+  if ((a.wide && (rt == 2 || rt == 4 || rt == 8)) || gray_rows) {   // the interior as row tiles of rt x 64 pixels of level 2 (pyramid_swarw_body): its columns in units of the edge ring's 8 x 8 tiles
     swar3_axis(levels[0].ncols, levels[1].ncols, levels[2].ncols, levels[0].border, levels[1].border, levels[2].border, 8, 16, 64, a.tiles_x8, &a.tx8_lo, &a.tx8_hi);
     if (a.tx8_hi - a.tx8_lo >= 8) {
       a.row_tiles = rt; a.wt = (a.tx8_hi - a.tx8_lo + 7) / 8;
