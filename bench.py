@@ -674,6 +674,9 @@ def main():
             ve = px.get("video_extruder_4k") or {}
             if "ms_per_update_median_steady" in ve:
                 legs["semi_dense_flow_4k"]["tracker_ms_per_update_median_steady"] = rnd(ve["ms_per_update_median_steady"])
+            loop = (ve.get("ms_per_frame_frames_3_to_end_incl_detection_frames") or {}).get("frames_in_hbm") or {}
+            if "push_frame_gray" in loop:   # the reference example's loop (examples/video_extruder.cc:44-58), frames 3 .. end incl. the detection frames: the two-frame update / one call per frame
+                legs["semi_dense_flow_4k"]["video_loop_ms_per_frame"] = {k: rnd(loop[k]) for k in ("video_extruder_update_gray", "push_frame_gray", "push_frame_rgb") if k in loop}
             if "frames_per_s" in ve:   # ONE tracker rate: video_extruder_update on resident gray frames, frames 3 .. end incl. detection frames and the final wait
                 legs["semi_dense_flow_4k"]["tracker_frames_per_s"] = round(ve["frames_per_s"])
         if "flow_strips_4k" in px:
