@@ -576,12 +576,20 @@ __global__ __launch_bounds__(256) void pyramid_swar3_pair_kernel(Swar3 a, Swar3 
   else pyramid_swar3_body<FAST, SRC>(b, (int)blockIdx.x - blocks_a);
 }
 
-// the pair + `tail_blocks` blocks of the flow's map reset and claims (sdof_tail.hpp): independent work in one launch.  The tail's blocks come FIRST — short,
-// memory-only workgroups that are gone by the time the pyramid tiles (VALU-bound, ~25 us at 4K) have ramped up
+// the pair + `tail_blocks` blocks of the flow's map reset and claims (sdof_tail.hpp): independent work in one launch.  The tail's blocks — short, memory-only workgroups —
+// come LAST since the pyramid tiles are row tiles (they fill the launch's drain: 21.5 -> 20.4 us, the 4K pair -1.5 us; bit 31 of `tail_blocks`, tuning sdof.tail_last);
+// with the 8 x 16 tiles of before (VALU-bound, ~25 us at 4K) they came first and were gone by the time the tiles had ramped up
 template <class FAST, class SRC>
 __global__ __launch_bounds__(256) void pyramid_swar3_pair_tail_kernel(Swar3 a, Swar3 b, int blocks_a, unsigned tail_blocks, ResetClaimTail t) {
-  if (blockIdx.x < tail_blocks) { reset_claim_block(t.a, t.kps, t.n, t.patch, t.c, blockIdx.x); return; }
-  const int bid = (int)(blockIdx.x - tail_blocks);
+  int bid;
+  if (tail_blocks & 0x80000000u) {   // (tuning sdof.tail_last) the tail's blocks behind the pyramids' tiles
+    const unsigned npyr = gridDim.x - (tail_blocks & 0x7FFFFFFFu);
+    if (blockIdx.x >= npyr) { reset_claim_block(t.a, t.kps, t.n, t.patch, t.c, blockIdx.x - npyr); return; }
+    bid = (int)blockIdx.x;
+  } else {
+    if (blockIdx.x < tail_blocks) { reset_claim_block(t.a, t.kps, t.n, t.patch, t.c, blockIdx.x); return; }
+    bid = (int)(blockIdx.x - tail_blocks);
+  }
   if (bid < blocks_a) pyramid_swar3_body<FAST, SRC>(a, bid);
   else pyramid_swar3_body<FAST, SRC>(b, bid - blocks_a);
 }
@@ -705,7 +713,7 @@ int pyramid_pair_with_tail(const vpp_image_desc* levels_a, const vpp_image_desc*
        same_domain(&levels_a[0], src_a) && same_domain(&levels_b[0], src_b) && chain_shape_ok(levels_a, 3) && chain_shape_ok(levels_b, 3);
   Swar3 a, b; int na = 0, nb = 0;
   if (!(ok && swar3_args(levels_a, src_a, &a, &na) && swar3_args(levels_b, src_b, &b, &nb))) return VPP_OK;
-  pyramid_swar3_pair_tail_kernel<CopyFast, CopySrc<uint8_t, 1>><<<tail_blocks + (unsigned)(na + nb), 256, 0, st>>>(a, b, na, tail_blocks, tail);
+  pyramid_swar3_pair_tail_kernel<CopyFast, CopySrc<uint8_t, 1>><<<tail_blocks + (unsigned)(na + nb), 256, 0, st>>>(a, b, na, tail_blocks | (tuning("sdof.tail_last", 1) ? 0x80000000u : 0u), tail);
   VPP_LAUNCH_CHECK();
   *fused = true;
   return VPP_OK;
