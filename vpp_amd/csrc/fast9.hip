@@ -308,13 +308,20 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
       }
     }
   }
-  wave_fence_lds();
   // ---- phase 2: ring test + score on the compacted candidates ----
-  for (int base = 0; base < ncand; base += 64) {
-    const int k = base + lane;
-    if (k < ncand) {
-      const int id = cand[wv][k], j = id / TW, col = id - j * TW;
-      const int lr = wv * (TH / 4) + j;
+  // (round 6) The four waves' candidate lists are walked as ONE list, 256 candidates per step: a wave used to walk its own list, 64 per step — 70-80 candidates per wave
+  // on the bench frame are two steps with the second one a fifth full; pooled, the workgroup's ~300 are 1.2 steps per wave.
+  __shared__ int s_ncand[4];
+  if (lane == 0) s_ncand[wv] = ncand;
+  __syncthreads();
+  const int nc0 = s_ncand[0], nc1 = nc0 + s_ncand[1], nc2 = nc1 + s_ncand[2], nctot = nc2 + s_ncand[3];
+  for (int base = 0; base < nctot; base += 256) {
+    const int kk = base + (int)threadIdx.x;
+    if (kk < nctot) {
+      const int cw = (kk >= nc0) + (kk >= nc1) + (kk >= nc2);   // the wave whose list holds candidate kk, and its place there
+      const int k = kk - (cw == 0 ? 0 : (cw == 1 ? nc0 : (cw == 2 ? nc1 : nc2)));
+      const int id = cand[cw][k], j = id / TW, col = id - j * TW;
+      const int lr = cw * (TH / 4) + j;
       const uint8_t* p = tile + (lr + HALO) * LP + col + 4;
       const int v = p[0];
       const int vhi = min(v + thc, 255), vlo = max(v - thc, 0);
@@ -351,15 +358,15 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
             atomicMax(&blkkey[(size_t)br * nbc + bc], ((unsigned long long)s16 << 32) | (0xFFFFFFFFu - ((r << 16) | cc)));
           }
         } else {
-          if (FUSED) fsc[wv][id] = (uint16_t)f;
+          if (FUSED) fsc[cw][id] = (uint16_t)f;
           else F.row<uint16_t>(r0 + lr)[c0 + col] = (uint16_t)f;
-          atomicOr(&words[wv][j], 1ull << col);
+          atomicOr(&words[cw][j], 1ull << col);
         }
       }
     }
   }
   if (MODE == VPP_FAST9_BLOCKWISE || MODE == kDenseU8 || MODE == kDenseI32) return;
-  wave_fence_lds();
+  __syncthreads();   // (a wave's words / scores are written by all four)
   if constexpr (FUSED) {
     __shared__ uint32_t wtot[4], s_last, s_excl;
     const int band = blockIdx.y, bx = blockIdx.x;
