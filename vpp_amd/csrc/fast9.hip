@@ -283,6 +283,15 @@ __global__ __launch_bounds__(256) void fast9_detect2_kernel(DImg A, DImg M, int 
         pass4 = ((pe >> 15) & 1u) | ((po >> 14) & 2u) | ((pe >> 29) & 4u) | ((po >> 28) & 8u);
         const int ncol = A.nc - cg;   // pixels of this group inside the image
         if (ncol < 4) pass4 &= (1u << ncol) - 1u;
+        if (has_mask && pass4) {
+          // (round 6) a pixel whose mask byte is 0 cannot be a corner (planes & 0, below): it never becomes a candidate.  One dword of mask per group, where a group has
+          // a candidate at all, instead of a byte load per corner behind the ring test — the tracker's mask is 0 almost everywhere (a square around every keypoint).
+          const uint8_t* mp = M.row<uint8_t>(r) + cg;
+          uint32_t m4 = 0;
+          if (ncol >= 4) __builtin_memcpy(&m4, mp, 4);
+          else for (int k = 0; k < ncol; k++) m4 |= (uint32_t)mp[k] << (8 * k);
+          pass4 &= ((m4 & 0xFFu) ? 1u : 0u) | ((m4 & 0xFF00u) ? 2u : 0u) | ((m4 & 0xFF0000u) ? 4u : 0u) | ((m4 & 0xFF000000u) ? 8u : 0u);
+        }
         if (MODE == VPP_FAST9_LOCAL_MAXIMA) {
           uint16_t* fr = F.row<uint16_t>(r) + cg;
           if (ncol >= 4) *(uint2*)fr = make_uint2(0u, 0u);
