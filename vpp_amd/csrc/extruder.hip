@@ -65,7 +65,8 @@ static void ve_quiesce(vpp_video_extruder* ve) {
 namespace vpp_amd {
 int keypoint_mask_squares(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, hipStream_t st);
 int sdof_flow_linked(const vpp_image_desc* i1, const vpp_image_desc* i2, const vpp_image_desc* pyr1, const vpp_image_desc* pyr2, const int32_t* kps, int n, int winsize, int nscales,
-                     int propagation, int patchsize, int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, const MergeLinkArgs* link, size_t link_head_units, void* stream);   // sdof.hip
+                     int propagation, int patchsize, int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, const MergeLinkArgs* link, size_t link_head_units, void* stream,
+                     const vpp_image_desc* build2_levels = nullptr, const vpp_image_desc* build2_src = nullptr);   // sdof.hip
 }
 
 namespace {
@@ -316,12 +317,13 @@ static int ve_resolve(const vpp_video_extruder* cve) {
 }
 
 // pyr1 / pyr2 != nullptr: the frames' pyramids are the tracker's own (vpp_video_extruder_push_frame) and the flow takes them as they are
+// build2_src != nullptr (with them): pyr2 is not built yet — the flow builds it from that frame into build2_levels in its first launch (or this function does, when there is no flow)
 static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2, const vpp_video_extruder_params* p, void* stream,
-                     const vpp_image_desc* pyr1, const vpp_image_desc* pyr2);
+                     const vpp_image_desc* pyr1, const vpp_image_desc* pyr2, const vpp_image_desc* build2_levels, const vpp_image_desc* build2_src);
 static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2, const vpp_video_extruder_params* p, void* stream,
-                     const vpp_image_desc* pyr1, const vpp_image_desc* pyr2) {
+                     const vpp_image_desc* pyr1, const vpp_image_desc* pyr2, const vpp_image_desc* build2_levels = nullptr, const vpp_image_desc* build2_src = nullptr) {
   const int frame_id = ve ? ve->frame_id : 0;
-  const int rc = step_body(ve, frame1, frame2, p, stream, pyr1, pyr2);
+  const int rc = step_body(ve, frame1, frame2, p, stream, pyr1, pyr2, build2_levels, build2_src);
   // A failed update must not advance the tracker's clock: the caller's frame counter has not advanced either, and frame_id % detector_period decides which
   // frames re-detect for the rest of the sequence.  (What the failed call had already queued is the caller's to discard: re-upload the state.)
   if (rc != VPP_OK && ve) ve->frame_id = frame_id;
@@ -329,7 +331,7 @@ static int step_impl(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
   return rc;
 }
 static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const vpp_image_desc* frame2, const vpp_video_extruder_params* p, void* stream,
-                     const vpp_image_desc* pyr1, const vpp_image_desc* pyr2) {
+                     const vpp_image_desc* pyr1, const vpp_image_desc* pyr2, const vpp_image_desc* build2_levels, const vpp_image_desc* build2_src) {
   VPP_REQUIRE(ve && p && valid_desc(frame1) && valid_desc(frame2), VPP_ERR_INVALID_ARG, "vpp_video_extruder_step: invalid argument");
   // everything that can be refused is refused before anything is queued or counted (the reference throws here too: fast.hpp:937-938)
   VPP_REQUIRE(frame2->dtype == VPP_U8 && frame2->channels == 1 && frame1->dtype == VPP_U8 && frame1->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_video_extruder_step: u8 x1 frames only");
@@ -355,13 +357,18 @@ static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
     MergeLinkArgs link; size_t head_units = 0;
     rc = keypoint_merge_prepare(ve->age[c], n, ve->nrows, ve->ncols, p->keypoint_spacing, &link, &head_units, st);
     if (rc != VPP_OK) return rc;
-    rc = sdof_flow_linked(frame1, frame2, pyr1, pyr2, ve->pos[c], n, p->winsize, p->nscales, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, &link, head_units, stream);
+    rc = sdof_flow_linked(frame1, frame2, pyr1, pyr2, ve->pos[c], n, p->winsize, p->nscales, p->propagation, 5, ve->fpos, ve->fdist, ve->fvalid, &link, head_units, stream,
+                          build2_levels, build2_src);
     if (rc != VPP_OK) return rc;
     const MergeLists lists{link.head, link.next, link.age_now, link.cell_of};
     if (detect) ve_finish_kernel<false><<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, lists, dimg(frame2), p->detector_th, ve->tring[c],
                                                                            ve->thead[c], ve->tlen[c], ve->talive[c], ve->ring, p->max_trajectory_length, ve->blocksum);
     else ve_finish_kernel<true><<<(n + 255) / 256, 256, 0, st>>>(n, ve->pos[c], ve->vel[c], ve->age[c], ve->fpos, ve->fvalid, lists, dimg(frame2), p->detector_th, ve->tring[c],
                                                                   ve->thead[c], ve->tlen[c], ve->talive[c], ve->ring, p->max_trajectory_length, nullptr);
+  }
+  if (n <= 0 && build2_src) {   // no flow to carry the new frame's pyramid: built here (the detection below reads its level 0, the next update all of it)
+    rc = build2_src->channels == 1 ? vpp_pyramid_build(build2_levels, p->nscales, build2_src, stream) : vpp_rgb_pyramid_build(build2_levels, p->nscales, build2_src, stream);
+    if (rc != VPP_OK) return rc;
   }
   if (detect) {  // re-detection away from every container entry (:94-119)
     const int s = p->keypoint_spacing;
@@ -465,13 +472,19 @@ static int push_impl(vpp_video_extruder* ve, const vpp_image_desc* frame, const 
   const int in = ve->have_prev ? 1 - ve->pyr_prev : ve->pyr_prev;
   vpp_image_desc fill[8];
   for (int l = 0; l < p->nscales; l++) { fill[l] = ve->pyr[in][l]; fill[l].border = ve->pyr_fill; }
-  rc = frame->channels == 1 ? vpp_pyramid_build(fill, p->nscales, frame, stream) : vpp_rgb_pyramid_build(fill, p->nscales, frame, stream);
-  if (rc != VPP_OK) return rc;
-  if (ingested) { VPP_HIP_TRY(hipEventRecord(ingested, as_stream(stream))); *recorded = true; }
+  // (round 6) With a previous frame there is an update behind this pyramid, and the update's flow starts with a launch of independent work (map reset + claims): the pyramid's
+  // tiles ride in that launch (step_body hands frame and levels to the flow) instead of being one of their own — 9 + 6.6 us of launches become one of ~12 at 4K
+  // (not for frames coming through the host staging buffers: `ingested` would be recorded behind the whole update instead of behind the frame's last reader)
+  const bool in_flow = ve->have_prev && !ingested && frame->channels == 1 && tuning("ve.pyramid_in_flow", 1);   // (gray frames: the shared launch is the copy producer's)
+  if (!in_flow) {
+    rc = frame->channels == 1 ? vpp_pyramid_build(fill, p->nscales, frame, stream) : vpp_rgb_pyramid_build(fill, p->nscales, frame, stream);
+    if (rc != VPP_OK) return rc;
+    if (ingested) { VPP_HIP_TRY(hipEventRecord(ingested, as_stream(stream))); *recorded = true; }
+  }
   if (!ve->have_prev) { ve->have_prev = true; return VPP_OK; }
   vpp_image_desc f1 = ve->pyr[ve->pyr_prev][0], f2 = fill[0];
   f1.border = ve->pyr_fill;
-  rc = step_impl(ve, &f1, &f2, p, stream, ve->pyr[ve->pyr_prev], ve->pyr[in]);
+  rc = step_impl(ve, &f1, &f2, p, stream, ve->pyr[ve->pyr_prev], ve->pyr[in], in_flow ? fill : nullptr, in_flow ? frame : nullptr);
   if (rc != VPP_OK) { ve->have_prev = false; return rc; }   // the state of a failed update is the caller's to re-upload; the next frame starts over as `prev`
   ve->pyr_prev = in;
   return VPP_OK;

@@ -1383,8 +1383,10 @@ namespace {
 int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t* kps, int n, int winsize,
               int nscales, int min_scale, int propagation, int patchsize, int nstrips, vpp_comm* comm, int32_t* out_pos,
               int32_t* out_dist, uint8_t* out_valid, void* stream, const vpp_image_desc* pre1 = nullptr, const vpp_image_desc* pre2 = nullptr,
-              const MergeLinkArgs* link = nullptr, size_t link_head_units = 0) {
+              const MergeLinkArgs* link = nullptr, size_t link_head_units = 0, const vpp_image_desc* build2_levels = nullptr, const vpp_image_desc* build2_src = nullptr) {
   // link != nullptr (the tracker): the merge lists' heads are reset with the maps and the read-back threads every match onto its cell's list
+  // build2_src != nullptr (the tracker's one-call-per-frame form, with pre1 / pre2): pre2's levels are not built yet — this call builds them from the frame `build2_src`
+  // (u8 x1, or x3 / x4 through the ingest) into `build2_levels` (pre2's levels with the border to fill), in its first launch where that launch can carry them
   // pre1 / pre2 != nullptr (vpp_semi_dense_optical_flow_pyramids): the caller's pyramids of the two frames are used as they are, i1 / i2 are their levels 0
   VPP_REQUIRE(valid_desc(i1) && valid_desc(i2) && same_domain(i1, i2), VPP_ERR_INVALID_ARG, "vpp_semi_dense_optical_flow: invalid frames");
   VPP_REQUIRE(i1->dtype == VPP_U8 && i1->channels == 1 && i2->dtype == VPP_U8 && i2->channels == 1, VPP_ERR_UNSUPPORTED, "vpp_semi_dense_optical_flow: u8 x1 frames only");
@@ -1487,6 +1489,14 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
                     P1[s_].nrows, P1[s_].ncols, winsize / 2);
       P1[s_] = pre1[s_]; P2[s_] = pre2[s_];
     }
+    if (build2_src) {
+      VPP_REQUIRE(build2_levels && valid_desc(build2_src), VPP_ERR_INVALID_ARG, "semi-dense flow: the second pyramid's levels / frame are missing");
+      pyr_pending = self_cleaning && nscales == 3 && build2_src->channels == 1 && tuning("sdof.tail_in_pyramid", 1);
+      if (!pyr_pending) {
+        rc = build2_src->channels == 1 ? vpp_pyramid_build(build2_levels, nscales, build2_src, stream) : vpp_rgb_pyramid_build(build2_levels, nscales, build2_src, stream);
+        if (rc) return rc;
+      }
+    }
   } else {
     for (int s_ = 0; s_ < nscales; s_++) {
       B1[s_] = P1[s_]; B2[s_] = P2[s_];
@@ -1503,7 +1513,8 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   for (int s_ = min_scale; s_ < nscales; s_++) owner_sig = (owner_sig * 1099511628211ull) ^ ((unsigned long long)ow_off[s_] << 20) ^ (unsigned long long)ow_bytes[s_];
   const bool owner_known_clean = self_cleaning && slot.note(1, owner_sig);   // never while recording / on a buffer a graph was recorded on
   slot.set_note(1, 0);   // until this call has queued every descent
-  if (pyr_pending && !(reset_up_front && self_cleaning)) { pyr_pending = false; rc = vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream); if (rc) return rc; }   // (cannot happen: self_cleaning implies both)
+  auto build_plain = [&]() { return build2_src ? vpp_pyramid_build(build2_levels, nscales, build2_src, stream) : vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream); };
+  if (pyr_pending && !(reset_up_front && self_cleaning)) { pyr_pending = false; rc = build_plain(); if (rc) return rc; }   // (cannot happen: self_cleaning implies both)
   if (reset_up_front) {
     ResetArgs ra; ra.nseg = 0; uint32_t blocks = 0;
     for (int s_ = min_scale; s_ < nscales; s_++) {
@@ -1547,8 +1558,10 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
       if (pyr_pending) {
         pyr_pending = false;
         ResetClaimTail tail{ra, kps, n, patchsize, ca};
-        rc = pyramid_pair_with_tail(B1, i1, B2, i2, nscales, tail, blocks + (unsigned)((n + 255) / 256), st, &fused); if (rc) return rc;
-        if (!fused) { rc = vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream); if (rc) return rc; }
+        rc = build2_src ? pyramid_one_with_tail(build2_levels, build2_src, nscales, tail, blocks + (unsigned)((n + 255) / 256), st, &fused)
+                        : pyramid_pair_with_tail(B1, i1, B2, i2, nscales, tail, blocks + (unsigned)((n + 255) / 256), st, &fused);
+        if (rc) return rc;
+        if (!fused) { rc = build_plain(); if (rc) return rc; }
       }
       if (!fused) sdof_reset_claim_kernel<<<blocks + (unsigned)((n + 255) / 256), 256, 0, st>>>(ra, kps, n, patchsize, ca);
     } else sdof_reset_kernel<<<blocks, 256, 0, st>>>(ra);
@@ -1740,9 +1753,10 @@ extern "C" int vpp_semi_dense_optical_flow_pyramids(const vpp_image_desc* pyr1, 
 // The tracker's flow (extruder.hip): over the frames (pyr1 == nullptr) or over its own pyramids, with the merge step's first pass folded in.
 namespace vpp_amd {
 int sdof_flow_linked(const vpp_image_desc* i1, const vpp_image_desc* i2, const vpp_image_desc* pyr1, const vpp_image_desc* pyr2, const int32_t* kps, int n, int winsize, int nscales,
-                     int propagation, int patchsize, int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, const MergeLinkArgs* link, size_t link_head_units, void* stream) {
+                     int propagation, int patchsize, int32_t* out_pos, int32_t* out_dist, uint8_t* out_valid, const MergeLinkArgs* link, size_t link_head_units, void* stream,
+                     const vpp_image_desc* build2_levels, const vpp_image_desc* build2_src) {
   return flow_impl(pyr1 ? &pyr1[0] : i1, pyr1 ? &pyr2[0] : i2, kps, n, winsize, nscales, 0, propagation, patchsize, 1, nullptr, out_pos, out_dist, out_valid, stream, pyr1, pyr2, link,
-                   link_head_units);
+                   link_head_units, pyr1 ? build2_levels : nullptr, pyr1 ? build2_src : nullptr);
 }
 }  // namespace vpp_amd
 
