@@ -718,16 +718,20 @@ int pyramid_pair_with_tail(const vpp_image_desc* levels_a, const vpp_image_desc*
   *fused = true;
   return VPP_OK;
 }
-// ONE pyramid (the new frame of a tracker that keeps the previous frame's) with the tail's blocks in its launch: the pair kernel with an empty second pyramid
+// ONE pyramid (the new frame of a tracker that keeps the previous frame's; a gray frame, or an rgb / rgba frame through the ingest) with the tail's blocks in its launch:
+// the pair kernel with an empty second pyramid
 int pyramid_one_with_tail(const vpp_image_desc* levels, const vpp_image_desc* src, int nlevels, const ResetClaimTail& tail, unsigned tail_blocks, hipStream_t st, bool* fused) {
   *fused = false;
   if (!(nlevels == 3 && levels && src && tuning("pyr.fused", 1) && tuning("pyr.swar", 1) && tuning("pyr.pair", 1))) return VPP_OK;
-  bool ok = true;
-  for (int l = 0; l < 3 && ok; l++) ok = valid_desc(&levels[l]) && same_type(&levels[l], src);
-  ok = ok && valid_desc(src) && src->dtype == VPP_U8 && src->channels == 1 && same_domain(&levels[0], src) && chain_shape_ok(levels, 3);
+  bool ok = valid_desc(src) && src->dtype == VPP_U8 && (src->channels == 1 || src->channels == 3 || src->channels == 4);
+  for (int l = 0; l < 3 && ok; l++) ok = valid_desc(&levels[l]) && levels[l].dtype == VPP_U8 && levels[l].channels == 1;
+  ok = ok && same_domain(&levels[0], src) && chain_shape_ok(levels, 3);
   Swar3 a; int na = 0;
-  if (!(ok && swar3_args(levels, src, &a, &na))) return VPP_OK;
-  pyramid_swar3_pair_tail_kernel<CopyFast, CopySrc<uint8_t, 1>><<<tail_blocks + (unsigned)na, 256, 0, st>>>(a, a, na, tail_blocks | (tuning("sdof.tail_last", 1) ? 0x80000000u : 0u), tail);
+  if (!(ok && swar3_args(levels, src, &a, &na, src->channels == 1))) return VPP_OK;
+  const unsigned tb = tail_blocks | (tuning("sdof.tail_last", 1) ? 0x80000000u : 0u), grid = tail_blocks + (unsigned)na;
+  if (src->channels == 1) pyramid_swar3_pair_tail_kernel<CopyFast, CopySrc<uint8_t, 1>><<<grid, 256, 0, st>>>(a, a, na, tb, tail);
+  else if (src->channels == 3) pyramid_swar3_pair_tail_kernel<GrayFast<3>, GraySrc<3>><<<grid, 256, 0, st>>>(a, a, na, tb, tail);   // (the ingest as producer: vpp_rgb_pyramid_build's kernel)
+  else pyramid_swar3_pair_tail_kernel<GrayFast<4>, GraySrc<4>><<<grid, 256, 0, st>>>(a, a, na, tb, tail);
   VPP_LAUNCH_CHECK();
   *fused = true;
   return VPP_OK;

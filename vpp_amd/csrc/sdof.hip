@@ -1491,7 +1491,7 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
     }
     if (build2_src) {
       VPP_REQUIRE(build2_levels && valid_desc(build2_src), VPP_ERR_INVALID_ARG, "semi-dense flow: the second pyramid's levels / frame are missing");
-      pyr_pending = self_cleaning && nscales == 3 && build2_src->channels == 1 && tuning("sdof.tail_in_pyramid", 1);
+      pyr_pending = self_cleaning && nscales == 3 && tuning("sdof.tail_in_pyramid", 1);
       if (!pyr_pending) {
         rc = build2_src->channels == 1 ? vpp_pyramid_build(build2_levels, nscales, build2_src, stream) : vpp_rgb_pyramid_build(build2_levels, nscales, build2_src, stream);
         if (rc) return rc;
@@ -1513,7 +1513,10 @@ int flow_impl(const vpp_image_desc* i1, const vpp_image_desc* i2, const int32_t*
   for (int s_ = min_scale; s_ < nscales; s_++) owner_sig = (owner_sig * 1099511628211ull) ^ ((unsigned long long)ow_off[s_] << 20) ^ (unsigned long long)ow_bytes[s_];
   const bool owner_known_clean = self_cleaning && slot.note(1, owner_sig);   // never while recording / on a buffer a graph was recorded on
   slot.set_note(1, 0);   // until this call has queued every descent
-  auto build_plain = [&]() { return build2_src ? vpp_pyramid_build(build2_levels, nscales, build2_src, stream) : vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream); };
+  auto build_plain = [&]() {
+    if (!build2_src) return vpp_pyramid_build_pair(B1, i1, B2, i2, nscales, stream);
+    return build2_src->channels == 1 ? vpp_pyramid_build(build2_levels, nscales, build2_src, stream) : vpp_rgb_pyramid_build(build2_levels, nscales, build2_src, stream);
+  };
   if (pyr_pending && !(reset_up_front && self_cleaning)) { pyr_pending = false; rc = build_plain(); if (rc) return rc; }   // (cannot happen: self_cleaning implies both)
   if (reset_up_front) {
     ResetArgs ra; ra.nseg = 0; uint32_t blocks = 0;

@@ -39,7 +39,7 @@ __device__ __forceinline__ void reset_claim_block(const ResetArgs& a, const int3
 // launch.  *fused = false (nothing launched) when the pair does not take the packed kernel: the caller then launches the two things itself.
 int pyramid_pair_with_tail(const vpp_image_desc* levels_a, const vpp_image_desc* src_a, const vpp_image_desc* levels_b, const vpp_image_desc* src_b, int nlevels,
                            const ResetClaimTail& tail, unsigned tail_blocks, hipStream_t st, bool* fused);
-// the same for ONE pyramid (u8 x1 source)
+// the same for ONE pyramid (u8 x1 source, or x3 / x4 through the ingest)
 int pyramid_one_with_tail(const vpp_image_desc* levels, const vpp_image_desc* src, int nlevels, const ResetClaimTail& tail, unsigned tail_blocks, hipStream_t st, bool* fused);
 
 }  // namespace vpp_amd
