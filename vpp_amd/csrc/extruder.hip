@@ -475,7 +475,8 @@ static int push_impl(vpp_video_extruder* ve, const vpp_image_desc* frame, const 
   // (round 6) With a previous frame there is an update behind this pyramid, and the update's flow starts with a launch of independent work (map reset + claims): the pyramid's
   // tiles ride in that launch (step_body hands frame and levels to the flow) instead of being one of their own — 9 + 6.6 us of launches become one of ~12 at 4K
   // (not for frames coming through the host staging buffers: `ingested` would be recorded behind the whole update instead of behind the frame's last reader)
-  const bool in_flow = ve->have_prev && !ingested && tuning("ve.pyramid_in_flow", 1);
+  // (nor behind a re-detection: the update first waits for the host to learn the container's new size — a pyramid launch queued ahead of that wait runs during it)
+  const bool in_flow = ve->have_prev && !ingested && !ve->pending && tuning("ve.pyramid_in_flow", 1);
   if (!in_flow) {
     rc = frame->channels == 1 ? vpp_pyramid_build(fill, p->nscales, frame, stream) : vpp_rgb_pyramid_build(fill, p->nscales, frame, stream);
     if (rc != VPP_OK) return rc;
