@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void ve_finish_kernel(int n, int32_t* __restri
 
 // ---- compaction: alive entries keep their order (keypoint_container.hpp:22-55) -----------------------------------------
 constexpr int kScanBlock = 1024;
-__global__ __launch_bounds__(256) void ve_index_kernel(int n, const int32_t* __restrict__ age, const int32_t* __restrict__ blocksum, int32_t* __restrict__ newidx, int32_t* __restrict__ total) {
+__device__ __forceinline__ void ve_index_block(const unsigned bid, const unsigned nblocks, int n, const int32_t* __restrict__ age, const int32_t* __restrict__ blocksum, int32_t* __restrict__ newidx, int32_t* __restrict__ total) {
   // new index of every alive entry: block offset + rank inside the block (waves in order, lanes in order).  The block offset = the sum of the COUNTS of the blocks
   // before this one, summed here (a few hundred words out of L2, left per 256 entries by ve_finish_kernel; round 6: the count pass and the single-workgroup scan launch in front of this pass are gone); the last block leaves the total.
   __shared__ int wsum[4];
@@ -134,14 +134,14 @@ __global__ __launch_bounds__(256) void ve_index_kernel(int n, const int32_t* __r
   int run;
   {
     int s = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x * (kScanBlock / 256); j += 256) s += blocksum[j];   // (counts per 256 entries: ve_finish_kernel's workgroups)
+    for (int j = threadIdx.x; j < (int)bid * (kScanBlock / 256); j += 256) s += blocksum[j];   // (counts per 256 entries: ve_finish_kernel's workgroups)
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) psum[threadIdx.x >> 6] = s;
     __syncthreads();
     run = psum[0] + psum[1] + psum[2] + psum[3];
   }
   for (int k = 0; k < kScanBlock / 256; k++) {
-    const int i = blockIdx.x * kScanBlock + k * 256 + threadIdx.x;
+    const int i = (int)bid * kScanBlock + k * 256 + threadIdx.x;
     const bool a = i < n && age[i] > 0;
     const unsigned long long b = __ballot(a);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -153,9 +153,19 @@ __global__ __launch_bounds__(256) void ve_index_kernel(int n, const int32_t* __r
     run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     __syncthreads();
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = run;
+  if (bid == nblocks - 1 && threadIdx.x == 0) *total = run;
 }
 
+__global__ __launch_bounds__(256) void ve_index_kernel(int n, const int32_t* __restrict__ age, const int32_t* __restrict__ blocksum, int32_t* __restrict__ newidx, int32_t* __restrict__ total) {
+  ve_index_block(blockIdx.x, gridDim.x, n, age, blocksum, newidx, total);
+}
+// the mask's fill with the index pass as the launch's first blocks: two independent things behind ve_finish_kernel in one launch (round 6: a launch of a few blocks costs ~4.8 us by itself)
+__global__ __launch_bounds__(256) void ve_fill16_index_kernel(uint4* __restrict__ p, size_t units, uint32_t v, unsigned index_blocks, int n, const int32_t* __restrict__ age,
+                                                              const int32_t* __restrict__ blocksum, int32_t* __restrict__ newidx, int32_t* __restrict__ total) {
+  if (blockIdx.x < index_blocks) { ve_index_block(blockIdx.x, index_blocks, n, age, blocksum, newidx, total); return; }
+  const size_t u = (size_t)(blockIdx.x - index_blocks) * 256 + threadIdx.x;
+  if (u < units) p[u] = make_uint4(v, v, v, v);
+}
 __global__ __launch_bounds__(256) void ve_fill16_kernel(uint4* __restrict__ p, size_t units, uint32_t v) {
   const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (u < units) p[u] = make_uint4(v, v, v, v);
@@ -383,15 +393,19 @@ static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
     }
     vpp_image_desc md{ve->mask + (size_t)s * ve->mask_pitch + s, ve->nrows, ve->ncols, ve->mask_pitch, s, VPP_U8, 1};
     // fill_with_border(mask, 1) (:101): the mask block is the tracker's own, rows and padding: one memset instead of a pass over bordered rows
-    ve_fill16_kernel<<<(unsigned)((ve->mask_bytes / 16 + 255) / 256), 256, 0, st>>>((uint4*)ve->mask, ve->mask_bytes / 16, 0x01010101u);   // (the runtime's memset is two dispatches)
-    rc = keypoint_mask_squares(&md, ve->pos[c], n, s, st);
-    if (rc != VPP_OK) return rc;
     // the alive count and the number of keypoints found stay on the device: the kernels behind them read the two words, the host reads its copy
     // when it next needs the container's size (ve_resolve)
     const int nblocks = (n + kScanBlock - 1) / kScanBlock;
-    if (n > 0) {
-      ve_index_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum, ve->newidx, ve->dcount);
-    } else { rc = device_fill(ve->dcount, 0, 4, st); if (rc != VPP_OK) return rc; }
+    const unsigned fill_blocks = (unsigned)((ve->mask_bytes / 16 + 255) / 256);
+    if (n > 0 && tuning("ve.index_in_fill", 1))
+      ve_fill16_index_kernel<<<fill_blocks + (unsigned)nblocks, 256, 0, st>>>((uint4*)ve->mask, ve->mask_bytes / 16, 0x01010101u, (unsigned)nblocks, n, ve->age[c], ve->blocksum, ve->newidx, ve->dcount);
+    else {
+      ve_fill16_kernel<<<fill_blocks, 256, 0, st>>>((uint4*)ve->mask, ve->mask_bytes / 16, 0x01010101u);   // (the runtime's memset is two dispatches)
+      if (n > 0) ve_index_kernel<<<nblocks, 256, 0, st>>>(n, ve->age[c], ve->blocksum, ve->newidx, ve->dcount);
+      else { rc = device_fill(ve->dcount, 0, 4, st); if (rc != VPP_OK) return rc; }
+    }
+    rc = keypoint_mask_squares(&md, ve->pos[c], n, s, st);
+    if (rc != VPP_OK) return rc;
     if (det_cap > ve->det_cap) {
       ve_quiesce(ve);
       dfree(ve->det);
