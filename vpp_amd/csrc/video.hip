@@ -129,8 +129,9 @@ __global__ __launch_bounds__(256) void lbp_kernel(DImg out, DImg in, int wide) {
 __global__ __launch_bounds__(256) void keypoint_mask_kernel(DImg mask, const int32_t* __restrict__ rc, int n, int s) {
   // one thread per (keypoint, square row): the row's 2s zero bytes go out as (unaligned) 16- and 4-byte stores — 2 stores for s = 10 where byte stores
   // were 20 per thread, 30 M on a 4K frame with 75 k keypoints (27 -> 8 us)
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int k = (int)(t / (2 * s)), dr = (int)(t - (long long)k * 2 * s) - s;
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;   // (n * 2 s < 2^32: checked by the launcher — a 64-bit division here was half of the kernel's instructions)
+  const uint32_t rows = 2u * (uint32_t)s;
+  const int k = (int)(t / rows), dr = (int)(t - (uint32_t)k * rows) - s;
   if (k >= n) return;
   const int r = rc[2 * k] + dr, c = rc[2 * k + 1];
   if (r < -mask.border || r >= mask.nr + mask.border) return;
@@ -248,6 +249,7 @@ namespace vpp_amd {
 int keypoint_mask_squares(const vpp_image_desc* mask, const int32_t* rc, int n, int spacing, hipStream_t st) {
   if (n == 0) return VPP_OK;
   const long long threads = (long long)n * 2 * spacing;
+  VPP_REQUIRE(threads + 256 < (1ll << 32), VPP_ERR_INVALID_ARG, "vpp_keypoint_mask: %d keypoints x %d rows exceed one launch", n, 2 * spacing);
   keypoint_mask_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(dimg(mask), rc, n, spacing);
   VPP_LAUNCH_CHECK();
   return VPP_OK;
