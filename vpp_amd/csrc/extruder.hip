@@ -12,6 +12,7 @@
 // Trajectories are fixed-capacity rings in HBM, newest position first from `head`.  Nothing in an update waits for the device: a
 // re-detection leaves the container's new size in HBM for the kernels behind it and the host reads its copy when it next needs it
 // (ve_resolve).  vpp_video_extruder_push_frame / _push_host_frame are the video loop's shape: one frame per call, `prev` and its pyramid kept here.
+#include <chrono>
 #include "common.hpp"
 #include "tracker_device.hpp"
 #include <algorithm>
@@ -33,7 +34,10 @@ struct vpp_video_extruder {
   uint8_t *fvalid = nullptr, *merged = nullptr, *mask = nullptr;
   int mask_spacing = -1, mask_pitch = 0, det_cap = 0;
   size_t mask_bytes = 0;
-  int32_t* host_count = nullptr;  // pinned: [0] alive count of the compaction, [1] keypoints found by the re-detection (copies of dcount)
+  int32_t* host_count = nullptr;  // pinned: [0] alive count of the compaction, [1] keypoints found by the re-detection (copies of dcount);
+                                  // bytes 8 .. 15: the same two counts + the update's frame id in ONE 64-bit word (stamp << 42 | found << 21 | alive; stamp = 2^21 | frame id mod 2^21), stored by the
+                                  // rebuild launch's FIRST block — the host polls it instead of waiting for the launch's end (ve_resolve)
+  unsigned pending_stamp = 0;
   int32_t* dcount = nullptr;      // the same two words in HBM, read by the kernels queued behind the re-detection
   hipEvent_t count_ready = nullptr;
   bool pending = false;           // a re-detection left the container size on the device: n is an upper bound until ve_resolve
@@ -183,6 +187,10 @@ struct RebuildArgs {
   int n, dcap, slots, max_len, frame_id, compact_blocks;
 };
 __global__ __launch_bounds__(256) void ve_rebuild_kernel(RebuildArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // (both counts are final before this launch starts: the host need not wait for its end to learn them)
+    const unsigned long long w = ((unsigned long long)(0x200000u | ((unsigned)a.frame_id & 0x1FFFFFu)) << 42) | ((unsigned long long)(unsigned)min(a.dn[1], (1 << 21) - 1) << 21) | (unsigned long long)(unsigned)a.dn[0];
+    __hip_atomic_store((unsigned long long*)(a.host_counts + 2), w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if ((int)blockIdx.x < a.compact_blocks) {
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 4, j = threadIdx.x & 15;
     if (i >= a.n) return;
@@ -287,7 +295,7 @@ int vpp_video_extruder_create(vpp_video_extruder** out, int nrows, int ncols, in
   void* h = nullptr;
   if (vpp_malloc_host(64, &h) != VPP_OK) { delete ve; return VPP_ERR_HIP; }
   ve->host_count = (int32_t*)h;
-  ve->host_count[0] = ve->host_count[1] = 0;
+  ve->host_count[0] = ve->host_count[1] = 0; ve->host_count[2] = ve->host_count[3] = 0;
   if (dalloc(&ve->dcount, 2) != VPP_OK || hipEventCreateWithFlags(&ve->count_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ve->queued, hipEventDisableTiming) != hipSuccess) {
     if (ve->count_ready) (void)hipEventDestroy(ve->count_ready);
@@ -320,6 +328,22 @@ int vpp_video_extruder_destroy(vpp_video_extruder* ve) {
 static int ve_resolve(const vpp_video_extruder* cve) {
   vpp_video_extruder* ve = const_cast<vpp_video_extruder*>(cve);
   if (!ve->pending) return VPP_OK;
+  // (round 6) The counts are known when the rebuild launch STARTS, and its first block stores them — stamped with the update's frame id — into a pinned word: polling that
+  // word returns ~13 us (the rebuild) + the runtime's completion path earlier than the event behind the launch; everything queued next is ordered behind it by the stream.
+  // Bounded: after 2 ms (a fault, a stream that has not started) the event decides.
+  if (tuning("ve.poll_counts", 1) && ve->det_cap < (1 << 21) && ve->n < (1 << 21)) {
+    const volatile unsigned long long* w = (const volatile unsigned long long*)(ve->host_count + 2);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+      const unsigned long long v = __atomic_load_n((const unsigned long long*)w, __ATOMIC_ACQUIRE);
+      if ((unsigned)(v >> 42) == ve->pending_stamp) {
+        ve->n = (int)(v & 0x1FFFFFu) + std::min((int)((v >> 21) & 0x1FFFFFu), ve->pending_cap);
+        ve->pending = false;
+        return VPP_OK;
+      }
+      if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+  }
   VPP_HIP_TRY(hipEventSynchronize(ve->count_ready));
   ve->n = ve->host_count[0] + std::min(ve->host_count[1], ve->pending_cap);
   ve->pending = false;
@@ -424,11 +448,12 @@ static int step_body(vpp_video_extruder* ve, const vpp_image_desc* frame1, const
     ra.dn = ve->dcount; ra.det = ve->det; ra.host_counts = ve->host_count;
     ra.n = n; ra.dcap = det_cap; ra.slots = ve->ring; ra.max_len = p->max_trajectory_length; ra.frame_id = ve->frame_id;
     ra.compact_blocks = (int)(((size_t)n * 16 + 255) / 256);
+    __atomic_store_n((unsigned long long*)(ve->host_count + 2), 0ull, __ATOMIC_RELEASE);   // (a tracker whose state was re-uploaded sees the same frame ids again)
     ve_rebuild_kernel<<<(unsigned)(ra.compact_blocks + (det_cap + 255) / 256), 256, 0, st>>>(ra);
     VPP_HIP_TRY(hipEventRecord(ve->count_ready, st));
     ve->cur = d;
     ve->n = n + det_cap;   // upper bound until ve_resolve
-    ve->pending = true; ve->pending_cap = det_cap;
+    ve->pending = true; ve->pending_cap = det_cap; ve->pending_stamp = 0x200000u | ((unsigned)ve->frame_id & 0x1FFFFFu);   // (never 0: the word is zeroed before the launch)
   }
   VPP_LAUNCH_CHECK();
   return VPP_OK;
