@@ -231,6 +231,22 @@ __global__ __launch_bounds__(256) void pixel_wise_tile_kernel(F f, int r0, int c
   // Staged: every byte of the tile's rows that lies inside the buffer's mirror [nb.lo, nb.hi) — for a view (sub-image) that is more than the view's own
   // bordered area, as on the host, where a tap may reach whatever the parent image holds there; bytes outside the buffer are never touched (nor legally tapped).
   const int want_hi = shift + (TW + 2 * H) * ES;
+  // (round 6) A tile whose staged bytes all lie inside the buffer — one test per workgroup — requests its chunks back to back, without a test or a branch in front of any
+  // load, and stores them afterwards: in the guarded loop below every pass of the workgroup waits for its own load before the next one is requested.
+  constexpr int NIT = (ROWS * CPR + 255) / 256;
+  if (nb.pitch > 0 && ga >= nb.lo && ga + (ptrdiff_t)(ROWS - 1) * nb.pitch + ((want_hi + 15) & ~15) <= nb.hi) {
+    u32x4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int k = min((int)threadIdx.x + 256 * it, ROWS * CPR - 1), rr = k / CPR, off = (k - rr * CPR) * 16;
+      v[it] = *(const u32x4*)(ga + (ptrdiff_t)rr * nb.pitch + (off < want_hi ? off : 0));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int k = (int)threadIdx.x + 256 * it, rr = k / CPR, off = (k - rr * CPR) * 16;
+      if (k < ROWS * CPR && off < want_hi) *(u32x4*)(lds + rr * LP + off) = v[it];
+    }
+  } else
   for (int k = threadIdx.x; k < ROWS * CPR; k += 256) {
     const int rr = k / CPR, off = (k - rr * CPR) * 16;
     if (off >= want_hi) continue;
