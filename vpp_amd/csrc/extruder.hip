@@ -89,14 +89,32 @@ __global__ __launch_bounds__(256) void ve_finish_kernel(int n, int32_t* __restri
   int a = 0;
   if (i < n) {
   const int nr = frame2.nr, nc = frame2.nc;
-  const bool merged = merge_removes(lists, i);
+  // (round 6) Three memory round trips instead of seven: everything that depends on i alone is requested first, in one go (the loads used to follow each other behind
+  // the merge's list walk, the score's branch, the match's branch and the trajectory's branch — each waited for where its branch ended); then the cell's list head with
+  // the score's 17 taps (at the position the match selects: no branch around them); then the walk.
+  const int a_now = lists.age_now[i], cell = lists.cell_of[i];
   const int p0 = pos[2 * i], p1 = pos[2 * i + 1];
   const int r = fpos[2 * i], c = fpos[2 * i + 1];
-  const bool inside = r >= 0 && c >= 0 && r < nr && c < nc;
-  const int score = inside ? fast9_score_at(frame2, r, c, th) : fast9_score_at(frame2, p0, p1, th);   // an out-of-frame match removes the keypoint where it was (:50-53)
-  int q0 = p0, q1 = p1;
   a = age[i];
-  if (fvalid[i]) {  // the match callback (video_extruder.hpp:48-53)
+  const bool matched = fvalid[i] != 0;
+  int hd = 0, ln = 0;
+  if (TRAJ) { hd = head[i]; ln = len[i]; }
+  asm volatile("" :: "v"(a_now), "v"(cell), "v"(p0), "v"(p1), "v"(r), "v"(c), "v"(a), "v"(hd), "v"(ln));
+  const bool inside = r >= 0 && c >= 0 && r < nr && c < nc;
+  int j = lists.head[cell];
+  const int score = fast9_score_at(frame2, inside ? r : p0, inside ? c : p1, th);   // an out-of-frame match removes the keypoint where it was (:50-53)
+  bool merged;
+  {  // merge_removes(lists, i) with its first two loads already here
+    int E = -1, L = -1;
+    bool earlier = false;
+    for (; j >= 0; j = lists.next[j]) {
+      if (j < i) { earlier = true; E = max(E, lists.age_now[j]); }
+      else if (j > i) L = max(L, lists.age_now[j]);
+    }
+    merged = (earlier && a_now <= E) ? (a_now < E) : (L > a_now);
+  }
+  int q0 = p0, q1 = p1;
+  if (matched) {  // the match callback (video_extruder.hpp:48-53)
     if (inside) {   // keypoint_container::move (keypoint_container.hpp:136-150)
       vel[2 * i] = r - p0; vel[2 * i + 1] = c - p1;
       pos[2 * i] = r; pos[2 * i + 1] = c;
@@ -108,11 +126,11 @@ __global__ __launch_bounds__(256) void ve_finish_kernel(int n, int32_t* __restri
   age[i] = a;
   if (TRAJ) {
     if (a > 0) {  // move_to + pop_oldest_position (video_extruder.hpp:125-130)
-      const int h = (head[i] + slots - 1) % slots;
+      const int h = (hd + slots - 1) % slots;
       float* p = ring + ((size_t)i * slots + h) * 2;
       p[0] = (float)q0; p[1] = (float)q1;
       head[i] = h;
-      int l = len[i] + 1;
+      int l = ln + 1;
       if (l > max_len) l--;
       len[i] = l;
     } else alive[i] = 0;  // die() (:132)
